@@ -1,0 +1,5 @@
+"""CPU oracle for the EfficientVLM distillation hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package; the product (``efficientvlm_amd``) never does.
+"""

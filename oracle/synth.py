@@ -1,0 +1,48 @@
+"""Synthetic batches of the GD / ITR tensor contract.  TEST + BENCH INPUTS.
+
+Shapes follow dataset/pretrain_dataset.py:233-281 (image, text_ids, text_atts, text_ids_masked,
+masked_pos, masked_ids); values are seeded CPU draws so the reference run, the oracle and the HIP
+path see byte-identical inputs.
+"""
+import torch
+
+GEOMS = {
+    # hidden 64 / 4 heads (d_h = 16) / 5 image tokens / 8 text tokens; 6+6 student, 12+12 teacher
+    "tiny": dict(hidden=64, heads=4, ffn=128, vocab=128, max_pos=64, image_res=32, embed_dim=16,
+                 L=8, M=3, s_vit_layers=6, t_vit_layers=12, s_text_layers=6, t_text_layers=12,
+                 cls=1, sep=2, mask=3, lo=10, std=0.15),
+    # X-VLM-small student / X-VLM-base teacher, 224^2, 30 tokens, 8 masked positions
+    "full": dict(hidden=768, heads=12, ffn=3072, vocab=30522, max_pos=512, image_res=224, embed_dim=256,
+                 L=30, M=8, s_vit_layers=6, t_vit_layers=12, s_text_layers=6, t_text_layers=12,
+                 cls=101, sep=102, mask=103, lo=1000, std=0.02),
+}
+
+
+def make_batch(geom, B, seed, ragged=False, image_res=None):
+    g = torch.Generator().manual_seed(seed)
+    R = image_res or geom["image_res"]
+    L, M = geom["L"], geom["M"]
+    image = torch.randn(B, 3, R, R, generator=g)
+    ids = torch.randint(geom["lo"], geom["vocab"], (B, L), generator=g)
+    atts = torch.ones(B, L, dtype=torch.long)
+    lens = [L] * B
+    if ragged:
+        for b in range(1, B, 2):  # odd rows are shorter and 0-padded
+            lens[b] = max(M + 2, L - 2 - (b % 3))
+    for b in range(B):
+        ids[b, 0] = geom["cls"]
+        ids[b, lens[b] - 1] = geom["sep"]
+        ids[b, lens[b]:] = 0
+        atts[b, lens[b]:] = 0
+    ids_masked = ids.clone()
+    masked_pos = torch.zeros(B, M, dtype=torch.long)
+    masked_ids = torch.full((B, M), -100, dtype=torch.long)
+    for b in range(B):
+        n_mask = M if b % 2 == 0 else M - 1       # one padded slot (pos 0 / label -100) on odd rows
+        perm = torch.randperm(lens[b] - 2, generator=g)[:n_mask] + 1
+        perm, _ = torch.sort(perm)
+        masked_pos[b, :n_mask] = perm
+        masked_ids[b, :n_mask] = ids[b, perm]
+        ids_masked[b, perm] = geom["mask"]
+    return dict(image=image, text_ids=ids, text_atts=atts, text_ids_masked=ids_masked,
+                masked_pos=masked_pos, masked_ids=masked_ids)
