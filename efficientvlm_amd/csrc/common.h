@@ -1,0 +1,141 @@
+// Shared device/host helpers for the gfx950 kernels of libevlm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/evlm_hip.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+// ---- error plumbing ------------------------------------------------------------------------
+int evlm_set_error(const char* fmt, ...);
+#define EVLM_REQUIRE(cond, ...)                      \
+  do {                                               \
+    if (!(cond)) return evlm_set_error(__VA_ARGS__); \
+  } while (0)
+#define EVLM_LAUNCH_CHECK(name)                                                    \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) return evlm_set_error("%s: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---- scalar conversions --------------------------------------------------------------------
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float x) { return (bf16)x; }
+
+// ---- 4-wide vector access (4 consecutive elements) -------------------------------------------
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  __device__ __forceinline__ static void load(const float* p, float v[4]) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  __device__ __forceinline__ static void store(float* p, const float v[4]) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+template <> struct Vec4<bf16> {
+  __device__ __forceinline__ static void load(const bf16* p, float v[4]) {
+    bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+  }
+  __device__ __forceinline__ static void store(bf16* p, const float v[4]) {
+    bf16x4 t = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = t;
+  }
+};
+
+// 8 consecutive elements -> 8 floats (16-byte load for bf16, 2x16-byte for f32)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
+  Vec4<float>::load(p, v);
+  Vec4<float>::load(p + 4, v + 4);
+}
+template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float v[8]) {
+  bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float v[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float v[8]) {
+  Vec4<float>::store(p, v);
+  Vec4<float>::store(p + 4, v + 4);
+}
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float v[8]) {
+  bf16x8 t;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
+  *reinterpret_cast<bf16x8*>(p) = t;
+}
+
+// ---- activations (fp32 math) ---------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float quick_gelu(float x) { return x * sigmoidf_(1.702f * x); }
+__device__ __forceinline__ float quick_gelu_grad(float x) {
+  const float s = sigmoidf_(1.702f * x);
+  return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+__device__ __forceinline__ float act_apply(int act, float x) {
+  return act == EVLM_ACT_GELU ? gelu_erf(x) : (act == EVLM_ACT_QUICK_GELU ? quick_gelu(x) : x);
+}
+__device__ __forceinline__ float act_grad(int act, float x) {
+  return act == EVLM_ACT_GELU ? gelu_erf_grad(x) : (act == EVLM_ACT_QUICK_GELU ? quick_gelu_grad(x) : 1.0f);
+}
+
+// ---- wave / block reductions (64-lane waves) ------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` holds >= 16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = red[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int imin(int64_t a, int64_t b) { return (int)(a < b ? a : b); }
+
+// run `body<T>` for the runtime dtype
+#define EVLM_DISPATCH_DTYPE(dt, NAME, ...)                        \
+  if ((dt) == EVLM_F32) { typedef float T; __VA_ARGS__ }          \
+  else if ((dt) == EVLM_BF16) { typedef bf16 T; __VA_ARGS__ }     \
+  else return evlm_set_error("%s: bad dtype %d", NAME, (int)(dt));

@@ -1,0 +1,409 @@
+// GEMM with fused epilogue for gfx950 (MI355X).
+//
+//   C[i,j] = epi( alpha * sum_k P(i,k) * Q(j,k) )
+//
+// bf16 path : 128x128x64 workgroup tile, 4 waves (2x2) of 64x64, v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+//             Operands are staged global -> VGPR -> LDS (double buffered, one barrier per K tile).
+//             K-contiguous operands ([rows][K]) live in LDS as 128-byte rows with a 16-byte-chunk XOR swizzle
+//             and are read with ds_read_b128; reduction-major operands ([K][rows], the backward products) live
+//             as 256-byte rows (XOR swizzle) and are read TRANSPOSED with ds_read_b64_tr_b16, so dX = dY*W and
+//             dW = dY^T*X need no transposed copies in HBM.
+//             The MFMA takes Q as its A operand and P as its B operand, so each lane ends up holding FOUR
+//             CONSECUTIVE j of one output row i: bias/gate loads and the C store are 8/16-byte vectors.
+// f32 path  : exact fp32 (v_mfma_f32_16x16x4_f32), 64x64x16 tile; the parity path.
+//
+// Both paths share one epilogue (bias, pre/post-activation gate, GELU/quick-GELU, activation backward,
+// residual add, optional pre-activation store).
+#include "common.h"
+
+struct GemmP {
+  const void* P; const void* Q; void* C;
+  const float* bias; const float* gate;
+  void* preact; const void* aux; const void* residual;
+  int I, J, K, ldp, ldq, ldc, ldx;
+  int c_f32, act, gate_pos, dact;
+  float alpha;
+  int tiles_i, tiles_j;
+};
+
+// ---------------------------------------------------------------------------------------------
+// epilogue: 4 consecutive j (j0..j0+3) of row i, fp32 accumulators in v[4]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void epilogue4(const GemmP& g, int i, int j0, float v[4]) {
+  if (i >= g.I || j0 >= g.J) return;
+  const int nv = min(4, g.J - j0);
+  const bool full = (nv == 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] *= g.alpha;
+  if (g.bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (e < nv) v[e] += g.bias[j0 + e];
+  }
+  const size_t xo = (size_t)i * g.ldx + j0;
+  if (g.preact) {
+    T* pa = reinterpret_cast<T*>(g.preact) + xo;
+    if (full) Vec4<T>::store(pa, v);
+    else for (int e = 0; e < nv; ++e) pa[e] = from_f<T>(v[e]);
+  }
+  float gz[4] = {1.f, 1.f, 1.f, 1.f};
+  if (g.gate) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (e < nv) gz[e] = g.gate[j0 + e];
+  }
+  if (g.act != EVLM_ACT_NONE) {
+    if (g.gate_pos == EVLM_GATE_PRE_ACT) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_apply(g.act, v[e] * gz[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_apply(g.act, v[e]) * gz[e];
+    }
+  } else if (g.gate) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= gz[e];
+  }
+  if (g.dact != EVLM_ACT_NONE) {
+    float h[4] = {0.f, 0.f, 0.f, 0.f};
+    const T* ax = reinterpret_cast<const T*>(g.aux) + xo;
+    if (full) Vec4<T>::load(ax, h);
+    else for (int e = 0; e < nv; ++e) h[e] = to_f(ax[e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= act_grad(g.dact, h[e]);
+  }
+  if (g.residual) {
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    const T* rp = reinterpret_cast<const T*>(g.residual) + xo;
+    if (full) Vec4<T>::load(rp, r);
+    else for (int e = 0; e < nv; ++e) r[e] = to_f(rp[e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += r[e];
+  }
+  const size_t co = (size_t)i * g.ldc + j0;
+  if (g.c_f32) {
+    float* c = reinterpret_cast<float*>(g.C) + co;
+    if (full) Vec4<float>::store(c, v);
+    else for (int e = 0; e < nv; ++e) c[e] = v[e];
+  } else {
+    T* c = reinterpret_cast<T*>(g.C) + co;
+    if (full) Vec4<T>::store(c, v);
+    else for (int e = 0; e < nv; ++e) c[e] = from_f<T>(v[e]);
+  }
+}
+
+// XCD-aware, bijective block -> tile map: blocks b and b+8 share an XCD (and its L2), so give each
+// XCD a contiguous range of tile ids; inside the range j runs fastest (tiles sharing a P row panel).
+__device__ __forceinline__ void tile_coords(const GemmP& g, int& ti, int& tj) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  ti = t / g.tiles_j;
+  tj = t - ti * g.tiles_j;
+}
+
+// =============================================================================================
+// bf16 kernel
+// =============================================================================================
+#define BT 128   // tile rows (i) and cols (j)
+#define BK 64    // k per LDS tile
+#define TILE_BYTES (BT * BK * 2)   // 16 KiB per operand per stage
+
+// global -> registers: 4 x 16-byte chunks per thread per operand
+template <bool TR>
+__device__ __forceinline__ void stage_load(const bf16* base, int ld, int rows, int K, int row0, int k0, int tid,
+                                           uint4 r[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int id = tid + 256 * c;
+    const bf16* p;
+    bool ok;
+    if (!TR) {  // [rows][K]: tile = 128 rows x 8 chunks (64 k)
+      const int row = id >> 3, kc = id & 7;
+      ok = (row0 + row < rows) && (k0 + kc * 8 < K);
+      p = base + (size_t)(row0 + row) * ld + k0 + kc * 8;
+    } else {    // [K][rows]: tile = 64 k-rows x 16 chunks (128 rows)
+      const int kr = id >> 4, cc = id & 15;
+      ok = (k0 + kr < K) && (row0 + cc * 8 < rows);
+      p = base + (size_t)(k0 + kr) * ld + row0 + cc * 8;
+    }
+    r[c] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+  }
+}
+
+template <bool TR>
+__device__ __forceinline__ void stage_store(char* sm, int tid, const uint4 r[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int id = tid + 256 * c;
+    int off;
+    if (!TR) {
+      const int row = id >> 3, kc = id & 7;
+      off = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+    } else {
+      const int kr = id >> 4, cc = id & 15;
+      off = kr * 256 + ((cc ^ (((kr & 3) << 2) | ((kr >> 2) & 3))) << 4);
+    }
+    *reinterpret_cast<uint4*>(sm + off) = r[c];
+  }
+}
+
+// fragment of 16 rows (rt-th 16-row group of the 128-row tile) x 32 k (k-step ks) for lane `lane`:
+// 8 bf16 = row (lane&15), k = 8*(lane>>4) + 0..7    (MFMA 16x16x32 A/B operand map)
+template <bool TR>
+__device__ __forceinline__ bf16x8 frag_read(const char* sm, int rt, int ks, int lane) {
+  if (!TR) {
+    const int row = rt * 16 + (lane & 15);
+    const int c = ks * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(sm + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+  } else {
+    const int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3;
+    bf16x8 out;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kr = ks * 32 + g * 8 + h * 4 + q;
+      const int ch = rt * 2 + (p >> 1);
+      const int off = kr * 256 + ((ch ^ (((kr & 3) << 2) | ((kr >> 2) & 3))) << 4) + ((p & 1) << 3);
+      bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (bf16x4 __attribute__((address_space(3)))*)(sm + off));
+      out[4 * h + 0] = t[0]; out[4 * h + 1] = t[1]; out[4 * h + 2] = t[2]; out[4 * h + 3] = t[3];
+    }
+    return out;
+  }
+}
+
+template <bool PT, bool QT>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][P tile | Q tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave & 1, wj = wave >> 1;
+  int ti, tj;
+  tile_coords(g, ti, tj);
+  const int i0 = ti * BT, j0 = tj * BT;
+  const bf16* P = reinterpret_cast<const bf16*>(g.P);
+  const bf16* Q = reinterpret_cast<const bf16*>(g.Q);
+
+  f32x4 acc[4][4];   // [tj][ti] : D rows = j (Q side), D cols = i (P side)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 rp[4], rq[4];
+  const int nt = (g.K + BK - 1) / BK;
+  stage_load<PT>(P, g.ldp, g.I, g.K, i0, 0, tid, rp);
+  stage_load<QT>(Q, g.ldq, g.J, g.K, j0, 0, tid, rq);
+  stage_store<PT>(smem, tid, rp);
+  stage_store<QT>(smem + TILE_BYTES, tid, rq);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const char* sp = smem + (t & 1) * 2 * TILE_BYTES;
+    const char* sq = sp + TILE_BYTES;
+    if (t + 1 < nt) {   // issue next tile's global loads before the MFMA block (latency hides under it)
+      stage_load<PT>(P, g.ldp, g.I, g.K, i0, (t + 1) * BK, tid, rp);
+      stage_load<QT>(Q, g.ldq, g.J, g.K, j0, (t + 1) * BK, tid, rq);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fp[4], fq[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        fp[a] = frag_read<PT>(sp, wi * 4 + a, ks, lane);
+        fq[a] = frag_read<QT>(sq, wj * 4 + a, ks, lane);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[a], fp[b], acc[a][b], 0, 0, 0);
+    }
+    if (t + 1 < nt) {
+      char* np_ = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+      stage_store<PT>(np_, tid, rp);
+      stage_store<QT>(np_ + TILE_BYTES, tid, rq);
+    }
+    __syncthreads();
+  }
+
+  // D map: col (i) = lane & 15, row (j) = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = i0 + wi * 64 + b * 16 + (lane & 15);
+      const int j = j0 + wj * 64 + a * 16 + (lane >> 4) * 4;
+      float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+      epilogue4<bf16>(g, i, j, v);
+    }
+}
+
+// =============================================================================================
+// exact-fp32 kernel (parity path): 64x64x16 tile, 4 waves (2x2) of 32x32, v_mfma_f32_16x16x4_f32
+// =============================================================================================
+#define FT 64
+#define FK 16
+#define FLD (FT + 4)
+
+template <bool TR>
+__device__ __forceinline__ void f32_stage(const float* base, int ld, int rows, int K, int row0, int k0, int tid,
+                                          float (*s)[FLD]) {
+  if (!TR) {  // [rows][K]: thread loads 4 consecutive k of one row
+    const int row = tid >> 2, kc = (tid & 3) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row0 + row < rows) {
+      const float* p = base + (size_t)(row0 + row) * ld + k0 + kc;
+      if (k0 + kc + 3 < K) Vec4<float>::load(p, v);
+      else for (int e = 0; e < 4; ++e) if (k0 + kc + e < K) v[e] = p[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[kc + e][row] = v[e];
+  } else {    // [K][rows]: thread loads 4 consecutive rows of one k
+    const int kr = tid >> 4, c4 = (tid & 15) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (k0 + kr < K) {
+      const float* p = base + (size_t)(k0 + kr) * ld + row0 + c4;
+      if (row0 + c4 + 3 < rows) Vec4<float>::load(p, v);
+      else for (int e = 0; e < 4; ++e) if (row0 + c4 + e < rows) v[e] = p[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[kr][c4 + e] = v[e];
+  }
+}
+
+template <bool PT, bool QT>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP g) {
+  __shared__ __attribute__((aligned(16))) float sp[FK][FLD];
+  __shared__ __attribute__((aligned(16))) float sq[FK][FLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave & 1, wj = wave >> 1;
+  int ti, tj;
+  tile_coords(g, ti, tj);
+  const int i0 = ti * FT, j0 = tj * FT;
+  const float* P = reinterpret_cast<const float*>(g.P);
+  const float* Q = reinterpret_cast<const float*>(g.Q);
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < g.K; k0 += FK) {
+    f32_stage<PT>(P, g.ldp, g.I, g.K, i0, k0, tid, sp);
+    f32_stage<QT>(Q, g.ldq, g.J, g.K, j0, k0, tid, sq);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < FK / 4; ++ks) {
+      const int kk = ks * 4 + (lane >> 4);
+      float fp[2], fq[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        fp[a] = sp[kk][wi * 32 + a * 16 + (lane & 15)];
+        fq[a] = sq[kk][wj * 32 + a * 16 + (lane & 15)];
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fq[a], fp[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int i = i0 + wi * 32 + b * 16 + (lane & 15);
+      const int j = j0 + wj * 32 + a * 16 + (lane >> 4) * 4;
+      float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+      epilogue4<float>(g, i, j, v);
+    }
+}
+
+// =============================================================================================
+// column sums (bias gradients)
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int I, int J, int ld, float* out, int rows_per_block) {
+  __shared__ float red[8][32 * 9];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 column-octets x 8 row lanes
+  const int j0 = blockIdx.x * 256 + tx * 8;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(I, r0 + rows_per_block);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (j0 < J) {
+    for (int i = r0 + ty; i < r1; i += 8) {
+      float v[8];
+      if (j0 + 8 <= ld) load8<T>(X + (size_t)i * ld + j0, v);
+      else for (int e = 0; e < 8; ++e) v[e] = (j0 + e < J) ? to_f(X[(size_t)i * ld + j0 + e]) : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e + tx] = acc[e];   // +tx: skew against bank conflicts
+  __syncthreads();
+  if (ty == 0 && j0 < J) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = 0.f;
+      for (int y = 0; y < 8; ++y) s += red[y][tx * 8 + e + tx];
+      if (j0 + e < J) atomicAdd(out + j0 + e, s);
+    }
+  }
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(a && a->P && a->Q && a->C, "evlm_gemm: null operand");
+  EVLM_REQUIRE(a->I > 0 && a->J > 0 && a->K > 0, "evlm_gemm: bad shape I=%d J=%d K=%d", a->I, a->J, a->K);
+  EVLM_REQUIRE(!(a->dact && (a->gate || a->act)), "evlm_gemm: dact excludes act/gate");
+  EVLM_REQUIRE(!a->dact || a->aux, "evlm_gemm: dact needs aux");
+  const int vec = a->dtype == EVLM_BF16 ? 8 : 4;
+  EVLM_REQUIRE(a->ldp % vec == 0 && a->ldq % vec == 0, "evlm_gemm: ldp/ldq must be multiples of %d", vec);
+  EVLM_REQUIRE(a->ldc % 4 == 0, "evlm_gemm: ldc must be a multiple of 4");
+  EVLM_REQUIRE((!a->preact && !a->aux && !a->residual) || a->ldx % 4 == 0, "evlm_gemm: ldx must be a multiple of 4");
+  EVLM_REQUIRE(((uintptr_t)a->P | (uintptr_t)a->Q | (uintptr_t)a->C) % 16 == 0, "evlm_gemm: operands must be 16-byte aligned");
+  GemmP g;
+  g.P = a->P; g.Q = a->Q; g.C = a->C; g.bias = a->bias; g.gate = a->gate;
+  g.preact = a->preact; g.aux = a->aux; g.residual = a->residual;
+  g.I = a->I; g.J = a->J; g.K = a->K; g.ldp = a->ldp; g.ldq = a->ldq; g.ldc = a->ldc; g.ldx = a->ldx;
+  g.c_f32 = (a->dtype == EVLM_F32) ? 1 : a->c_f32;
+  g.act = a->act; g.gate_pos = a->gate_pos; g.dact = a->dact; g.alpha = a->alpha;
+  const int pt = a->p_trans ? 1 : 0, qt = a->q_trans ? 1 : 0;
+  if (a->dtype == EVLM_BF16) {
+    g.tiles_i = ceil_div(g.I, BT); g.tiles_j = ceil_div(g.J, BT);
+    dim3 grid(g.tiles_i * g.tiles_j), block(256);
+    const size_t lds = 4 * TILE_BYTES;
+#define LAUNCH_BF16(PT_, QT_) hipLaunchKernelGGL((gemm_bf16_kernel<PT_, QT_>), grid, block, lds, stream, g)
+    if (!pt && !qt) LAUNCH_BF16(false, false);
+    else if (!pt && qt) LAUNCH_BF16(false, true);
+    else if (pt && qt) LAUNCH_BF16(true, true);
+    else LAUNCH_BF16(true, false);
+#undef LAUNCH_BF16
+  } else if (a->dtype == EVLM_F32) {
+    g.tiles_i = ceil_div(g.I, FT); g.tiles_j = ceil_div(g.J, FT);
+    dim3 grid(g.tiles_i * g.tiles_j), block(256);
+#define LAUNCH_F32(PT_, QT_) hipLaunchKernelGGL((gemm_f32_kernel<PT_, QT_>), grid, block, 0, stream, g)
+    if (!pt && !qt) LAUNCH_F32(false, false);
+    else if (!pt && qt) LAUNCH_F32(false, true);
+    else if (pt && qt) LAUNCH_F32(true, true);
+    else LAUNCH_F32(true, false);
+#undef LAUNCH_F32
+  } else {
+    return evlm_set_error("evlm_gemm: bad dtype %d", a->dtype);
+  }
+  EVLM_LAUNCH_CHECK("evlm_gemm");
+  return 0;
+}
+
+extern "C" int evlm_colsum(int dtype, const void* X, int I, int J, int ldx, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(X && out && I > 0 && J > 0, "evlm_colsum: bad args");
+  const int rpb = 256;
+  dim3 grid(ceil_div(J, 256), ceil_div(I, rpb)), block(256);
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_colsum",
+    hipLaunchKernelGGL((colsum_kernel<T>), grid, block, 0, stream, (const T*)X, I, J, ldx, out, rpb);)
+  EVLM_LAUNCH_CHECK("evlm_colsum");
+  return 0;
+}

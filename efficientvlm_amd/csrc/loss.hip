@@ -1,0 +1,314 @@
+// Distillation / task loss reductions for gfx950 — all HBM-bound streaming kernels (16-byte loads,
+// wave shuffles + one LDS step per block, one atomic per block).  Scalars stay on the device: the forward
+// kernels accumulate weight*term into a device word, the backward kernels read dL/d(term) from a device word.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// MSE   (get_kd_loss, GeneralDistill.py:60-82)
+// ---------------------------------------------------------------------------------------------
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void mse_fwd_kernel(const TA* __restrict__ a, const TB* __restrict__ b, int64_t n,
+                                                      float coef, float* __restrict__ loss) {
+  __shared__ float red[16];
+  float s = 0.f;
+  const int64_t nv = n >> 3;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nv; c += (int64_t)gridDim.x * blockDim.x) {
+    float x[8], y[8];
+    load8<TA>(a + c * 8, x);
+    load8<TB>(b + c * 8, y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = x[e] - y[e]; s = fmaf(d, d, s); }
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (nv << 3) + threadIdx.x; i < n; i += blockDim.x) { const float d = to_f(a[i]) - to_f(b[i]); s = fmaf(d, d, s); }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(loss, s * coef);
+}
+
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const TA* __restrict__ a, const TB* __restrict__ b, int64_t n,
+                                                      float coef, const float* __restrict__ gout, TA* __restrict__ ga) {
+  const float c2 = coef * gout[0];
+  const int64_t nv = n >> 3;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nv; c += (int64_t)gridDim.x * blockDim.x) {
+    float x[8], y[8];
+    load8<TA>(a + c * 8, x);
+    load8<TB>(b + c * 8, y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = c2 * (x[e] - y[e]);
+    store8<TA>(ga + c * 8, x);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (nv << 3) + threadIdx.x; i < n; i += blockDim.x) ga[i] = from_f<TA>(c2 * (to_f(a[i]) - to_f(b[i])));
+}
+
+#define DISPATCH2(da, db, NAME, ...)                                                         \
+  if (da == EVLM_F32 && db == EVLM_F32) { typedef float TA; typedef float TB; __VA_ARGS__ }  \
+  else if (da == EVLM_BF16 && db == EVLM_BF16) { typedef bf16 TA; typedef bf16 TB; __VA_ARGS__ } \
+  else if (da == EVLM_BF16 && db == EVLM_F32) { typedef bf16 TA; typedef float TB; __VA_ARGS__ } \
+  else if (da == EVLM_F32 && db == EVLM_BF16) { typedef float TA; typedef bf16 TB; __VA_ARGS__ } \
+  else return evlm_set_error("%s: bad dtypes", NAME);
+
+extern "C" int evlm_mse_fwd(int dtype_a, const void* a, int dtype_b, const void* b, int64_t n, float weight,
+                            float* loss, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(a && b && loss && n > 0, "evlm_mse_fwd: bad args");
+  const int grid = imin(2048, (n / 8 + 255) / 256 + 1);
+  const float coef = weight / (float)n;
+  DISPATCH2(dtype_a, dtype_b, "evlm_mse_fwd",
+    hipLaunchKernelGGL((mse_fwd_kernel<TA, TB>), dim3(grid), dim3(256), 0, stream, (const TA*)a, (const TB*)b, n, coef, loss);)
+  EVLM_LAUNCH_CHECK("evlm_mse_fwd");
+  return 0;
+}
+extern "C" int evlm_mse_bwd(int dtype_a, const void* a, int dtype_b, const void* b, int64_t n, float weight,
+                            const float* gout, void* grad_a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(a && b && gout && grad_a && n > 0, "evlm_mse_bwd: bad args");
+  const int grid = imin(2048, (n / 8 + 255) / 256 + 1);
+  const float coef = 2.0f * weight / (float)n;
+  DISPATCH2(dtype_a, dtype_b, "evlm_mse_bwd",
+    hipLaunchKernelGGL((mse_bwd_kernel<TA, TB>), dim3(grid), dim3(256), 0, stream, (const TA*)a, (const TB*)b, n, coef, gout, (TA*)grad_a);)
+  EVLM_LAUNCH_CHECK("evlm_mse_bwd");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row-wise log-sum-exp helper: one 256-thread block per row
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float row_lse(const T* __restrict__ x, int C, float mul, float* red) {
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) m = fmaxf(m, to_f(x[c]) * mul);
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) s += __expf(to_f(x[c]) * mul - m);
+  s = block_sum(s, red);
+  return m + __logf(s);
+}
+
+// hard-label CE:  rowloss[r] = lse - logit[label]   (0 for ignored rows)
+template <typename T>
+__global__ __launch_bounds__(256) void ce_row_kernel(const T* __restrict__ logits, int C, int ld,
+                                                     const int64_t* __restrict__ labels, int ignore_index,
+                                                     float* __restrict__ lse_out) {
+  __shared__ float red[16];
+  const int r = blockIdx.x, R = gridDim.x;
+  const T* x = logits + (size_t)r * ld;
+  const float lse = row_lse<T>(x, C, 1.0f, red);
+  if (threadIdx.x == 0) {
+    const int64_t lb = labels[r];
+    lse_out[r] = lse;
+    lse_out[R + r] = (lb == ignore_index) ? 0.f : lse - to_f(x[lb]);
+  }
+}
+__global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict__ rowloss, const int64_t* __restrict__ labels,
+                                                        int R, int ignore_index, float weight, int32_t* __restrict__ valid,
+                                                        float* __restrict__ loss) {
+  __shared__ float red[16];
+  float s = 0.f, n = 0.f;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    s += rowloss[r];
+    n += (labels[r] != ignore_index) ? 1.f : 0.f;
+  }
+  s = block_sum(s, red);
+  n = block_sum(n, red);
+  if (threadIdx.x == 0) {
+    valid[0] = (int32_t)n;
+    atomicAdd(loss, weight * s / n);   // all rows ignored -> NaN, as F.cross_entropy
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logits, int C, int ld,
+                                                     const int64_t* __restrict__ labels, int ignore_index, float weight,
+                                                     const float* __restrict__ lse, const int32_t* __restrict__ valid,
+                                                     const float* __restrict__ gout, T* __restrict__ dl, int ldd) {
+  const int r = blockIdx.x;
+  const int64_t lb = labels[r];
+  const T* x = logits + (size_t)r * ld;
+  T* d = dl + (size_t)r * ldd;
+  if (lb == ignore_index) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) d[c] = from_f<T>(0.f);
+    return;
+  }
+  const float g = gout[0] * weight / (float)valid[0];
+  const float l = lse[r];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float p = __expf(to_f(x[c]) - l);
+    d[c] = from_f<T>(g * (p - (c == lb ? 1.f : 0.f)));
+  }
+}
+
+extern "C" int evlm_ce_fwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
+                           float weight, float* lse, int32_t* valid_count, float* loss, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(logits && labels && lse && valid_count && loss && R > 0 && C > 0, "evlm_ce_fwd: bad args");
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_ce_fwd",
+    hipLaunchKernelGGL((ce_row_kernel<T>), dim3(R), dim3(256), 0, stream, (const T*)logits, C, ld, labels, ignore_index, lse);)
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)(lse + R), labels, R, ignore_index, weight, valid_count, loss);
+  EVLM_LAUNCH_CHECK("evlm_ce_fwd");
+  return 0;
+}
+extern "C" int evlm_ce_bwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
+                           float weight, const float* lse, const int32_t* valid_count, const float* gout,
+                           void* dlogits, int ldd, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(logits && labels && lse && valid_count && gout && dlogits, "evlm_ce_bwd: bad args");
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_ce_bwd",
+    hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(R), dim3(256), 0, stream, (const T*)logits, C, ld, labels, ignore_index, weight, lse, valid_count, gout, (T*)dlogits, ldd);)
+  EVLM_LAUNCH_CHECK("evlm_ce_bwd");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// KL(log_softmax(s*it) || softmax(t*it)), batchmean   (soft_cross_entropy, GeneralDistill.py:84-89)
+// ---------------------------------------------------------------------------------------------
+template <typename TS, typename TT>
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const TS* __restrict__ s, int lds_, const TT* __restrict__ t, int ldt,
+                                                     int C, float it, float coef, float* __restrict__ lse_s,
+                                                     float* __restrict__ lse_t, float* __restrict__ loss) {
+  __shared__ float red[16];
+  const int r = blockIdx.x;
+  const TS* sr = s + (size_t)r * lds_;
+  const TT* tr = t + (size_t)r * ldt;
+  const float ls = row_lse<TS>(sr, C, it, red);
+  const float lt = row_lse<TT>(tr, C, it, red);
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float lpt = to_f(tr[c]) * it - lt, lps = to_f(sr[c]) * it - ls;
+    acc += __expf(lpt) * (lpt - lps);
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    lse_s[r] = ls; lse_t[r] = lt;
+    atomicAdd(loss, acc * coef);
+  }
+}
+template <typename TS, typename TT>
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const TS* __restrict__ s, int lds_, const TT* __restrict__ t, int ldt,
+                                                     int C, float it, float coef, const float* __restrict__ lse_s,
+                                                     const float* __restrict__ lse_t, const float* __restrict__ gout,
+                                                     TS* __restrict__ ds, int ldds) {
+  const int r = blockIdx.x;
+  const TS* sr = s + (size_t)r * lds_;
+  const TT* tr = t + (size_t)r * ldt;
+  TS* dr = ds + (size_t)r * ldds;
+  const float g = gout[0] * coef * it, ls = lse_s[r], lt = lse_t[r];
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+    dr[c] = from_f<TS>(g * (__expf(to_f(sr[c]) * it - ls) - __expf(to_f(tr[c]) * it - lt)));
+}
+extern "C" int evlm_kl_fwd(int dtype_s, const void* s, int lds_, int dtype_t, const void* t, int ldt, int R, int C,
+                           float inv_t, float weight, float* lse_s, float* lse_t, float* loss, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(s && t && lse_s && lse_t && loss && R > 0 && C > 0, "evlm_kl_fwd: bad args");
+  const float coef = weight / (float)R;
+  DISPATCH2(dtype_s, dtype_t, "evlm_kl_fwd",
+    hipLaunchKernelGGL((kl_fwd_kernel<TA, TB>), dim3(R), dim3(256), 0, stream, (const TA*)s, lds_, (const TB*)t, ldt, C, inv_t, coef, lse_s, lse_t, loss);)
+  EVLM_LAUNCH_CHECK("evlm_kl_fwd");
+  return 0;
+}
+extern "C" int evlm_kl_bwd(int dtype_s, const void* s, int lds_, int dtype_t, const void* t, int ldt, int R, int C,
+                           float inv_t, float weight, const float* lse_s, const float* lse_t, const float* gout,
+                           void* ds, int ldds, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(s && t && lse_s && lse_t && gout && ds, "evlm_kl_bwd: bad args");
+  const float coef = weight / (float)R;
+  DISPATCH2(dtype_s, dtype_t, "evlm_kl_bwd",
+    hipLaunchKernelGGL((kl_bwd_kernel<TA, TB>), dim3(R), dim3(256), 0, stream, (const TA*)s, lds_, (const TB*)t, ldt, C, inv_t, coef, lse_s, lse_t, gout, (TA*)ds, ldds);)
+  EVLM_LAUNCH_CHECK("evlm_kl_bwd");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// log_softmax rows
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void lsm_fwd_kernel(const T* __restrict__ x, int C, int ld, T* __restrict__ y, int ldy) {
+  __shared__ float red[16];
+  const T* xr = x + (size_t)blockIdx.x * ld;
+  T* yr = y + (size_t)blockIdx.x * ldy;
+  const float l = row_lse<T>(xr, C, 1.0f, red);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) yr[c] = from_f<T>(to_f(xr[c]) - l);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void lsm_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, int C, int ld,
+                                                      T* __restrict__ dx) {
+  __shared__ float red[16];
+  const T* yr = y + (size_t)blockIdx.x * ld;
+  const T* dr = dy + (size_t)blockIdx.x * ld;
+  T* xr = dx + (size_t)blockIdx.x * ld;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) s += to_f(dr[c]);
+  s = block_sum(s, red);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) xr[c] = from_f<T>(to_f(dr[c]) - __expf(to_f(yr[c])) * s);
+}
+extern "C" int evlm_log_softmax_fwd(int dtype, const void* x, int R, int C, int ld, void* y, int ldy, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(x && y && R > 0 && C > 0, "evlm_log_softmax_fwd: bad args");
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_log_softmax_fwd",
+    hipLaunchKernelGGL((lsm_fwd_kernel<T>), dim3(R), dim3(256), 0, stream, (const T*)x, C, ld, (T*)y, ldy);)
+  EVLM_LAUNCH_CHECK("evlm_log_softmax_fwd");
+  return 0;
+}
+extern "C" int evlm_log_softmax_bwd(int dtype, const void* y, const void* dy, int R, int C, int ld, void* dx, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(y && dy && dx && R > 0 && C > 0, "evlm_log_softmax_bwd: bad args");
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_log_softmax_bwd",
+    hipLaunchKernelGGL((lsm_bwd_kernel<T>), dim3(R), dim3(256), 0, stream, (const T*)y, (const T*)dy, C, ld, (T*)dx);)
+  EVLM_LAUNCH_CHECK("evlm_log_softmax_bwd");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimiser-side helpers
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  const int64_t nv = n >> 2;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nv; c += (int64_t)gridDim.x * blockDim.x) {
+    float v[4];
+    Vec4<float>::load(x + c * 4, v);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0) for (int64_t i = (nv << 2) + threadIdx.x; i < n; i += blockDim.x) s += x[i] * x[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(out, s);
+}
+extern "C" int evlm_sumsq(const float* x, int64_t n, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(x && out && n > 0, "evlm_sumsq: bad args");
+  EVLM_REQUIRE(((uintptr_t)x) % 16 == 0, "evlm_sumsq: x must be 16-byte aligned");
+  const int grid = imin(2048, (n / 4 + 255) / 256 + 1);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, stream, x, n, out);
+  EVLM_LAUNCH_CHECK("evlm_sumsq");
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2, const float* __restrict__ gnorm_sq,
+                                                    float max_norm, bf16* __restrict__ pb) {
+  float clip = 1.0f;
+  if (gnorm_sq && max_norm > 0.f) clip = fminf(1.0f, max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f));
+  const float step = lr * sqrtf(bc2) / bc1;   // transformers.AdamW: step_size = lr * sqrt(bc2) / bc1
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * clip;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    float pi = p[i] - step * mi / (sqrtf(vi) + eps);
+    pi -= lr * wd * pi;                                               // decoupled decay AFTER the Adam update
+    p[i] = pi;
+    if (pb) pb[i] = (bf16)pi;
+  }
+}
+extern "C" int evlm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, float bias_c1, float bias_c2, const float* gnorm_sq,
+                               float max_norm, void* p_bf16, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(p && g && m && v && n > 0, "evlm_adamw_step: bad args");
+  const int grid = imin(4096, (n + 255) / 256);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2, gnorm_sq, max_norm, (bf16*)p_bf16);
+  EVLM_LAUNCH_CHECK("evlm_adamw_step");
+  return 0;
+}

@@ -1,0 +1,445 @@
+// Embeddings, data movement, gate kernels and the error plumbing of libevlm_hip.so (gfx950).
+// Everything here is HBM-bound: 16-byte vector accesses, consecutive lanes on consecutive addresses.
+#include <stdarg.h>
+#include "common.h"
+
+// ---- error plumbing --------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+int evlm_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return 1;
+}
+extern "C" const char* evlm_last_error(void) { return g_err; }
+extern "C" int evlm_abi_version(void) { return 1; }
+
+// ---- BERT embeddings -------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const int64_t* __restrict__ ids, int L, int d,
+                                                             const float* __restrict__ word, const float* __restrict__ pos,
+                                                             const float* __restrict__ type0, T* __restrict__ out, int rows) {
+  const int per = d >> 3;
+  for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < (int64_t)rows * per; id += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(id / per), c = (int)(id - (int64_t)row * per);
+    const int l = row % L;
+    float w[8], p[8], t[8];
+    load8<float>(word + (size_t)ids[row] * d + c * 8, w);
+    load8<float>(pos + (size_t)l * d + c * 8, p);
+    load8<float>(type0 + c * 8, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[e] = (w[e] + t[e]) + p[e];   // same association order as eff_bert.py:207-211
+    store8<T>(out + (size_t)row * d + c * 8, w);
+  }
+}
+// one block per sequence position l: dpos[l] += sum_b de[b,l]; dtype0 += that; dword[ids[b,l]] += de[b,l] (atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void bert_embed_bwd_kernel(const int64_t* __restrict__ ids, int B, int L, int d,
+                                                             const T* __restrict__ de, int pad_id, float* __restrict__ dword,
+                                                             float* __restrict__ dpos, float* __restrict__ dtype0) {
+  const int l = blockIdx.x;
+  for (int j = threadIdx.x; j < d; j += blockDim.x) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float g = to_f(de[((size_t)b * L + l) * d + j]);
+      acc += g;
+      const int64_t w = ids[(size_t)b * L + l];
+      if (w != pad_id) atomicAdd(dword + (size_t)w * d + j, g);
+    }
+    dpos[(size_t)l * d + j] += acc;
+    atomicAdd(dtype0 + j, acc);
+  }
+}
+extern "C" int evlm_bert_embed_fwd(int dtype, const int64_t* ids, int B, int L, int d, const float* word,
+                                   const float* pos, const float* type0, void* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(ids && word && pos && type0 && out && B > 0 && L > 0 && d % 8 == 0, "evlm_bert_embed_fwd: bad args");
+  const int rows = B * L;
+  const int grid = imin(2048, ceil_div((int64_t)rows * (d / 8), 256));
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_bert_embed_fwd",
+    hipLaunchKernelGGL((bert_embed_fwd_kernel<T>), dim3(grid), dim3(256), 0, stream, ids, L, d, word, pos, type0, (T*)out, rows);)
+  EVLM_LAUNCH_CHECK("evlm_bert_embed_fwd");
+  return 0;
+}
+extern "C" int evlm_bert_embed_bwd(int dtype, const int64_t* ids, int B, int L, int d, const void* de, int pad_id,
+                                   float* dword, float* dpos, float* dtype0, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(ids && de && dword && dpos && dtype0, "evlm_bert_embed_bwd: bad args");
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_bert_embed_bwd",
+    hipLaunchKernelGGL((bert_embed_bwd_kernel<T>), dim3(L), dim3(256), 0, stream, ids, B, L, d, (const T*)de, pad_id, dword, dpos, dtype0);)
+  EVLM_LAUNCH_CHECK("evlm_bert_embed_bwd");
+  return 0;
+}
+
+// ---- ViT patch embedding as a GEMM: im2row + token assembly ------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void im2row_kernel(const float* __restrict__ img, int B, int C, int R, int p,
+                                                     T* __restrict__ out) {
+  const int G = R / p, K = C * p * p, per = K >> 3, pc = p >> 3;
+  const int64_t total = (int64_t)B * G * G * per;
+  for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = id / per;
+    const int c8 = (int)(id - row * per);
+    const int b = (int)(row / (G * G)), g = (int)(row - (int64_t)b * G * G), gy = g / G, gx = g - gy * G;
+    const int c = c8 / (p * pc), rem = c8 - c * p * pc, py = rem / pc, px0 = (rem - py * pc) * 8;
+    float v[8];
+    load8<float>(img + (((size_t)b * C + c) * R + gy * p + py) * R + gx * p + px0, v);
+    store8<T>(out + row * K + c8 * 8, v);
+  }
+}
+extern "C" int evlm_im2row(int dtype, const float* image, int B, int C, int R, int p, void* patches, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(image && patches && B > 0 && p % 8 == 0 && R % p == 0, "evlm_im2row: bad args (patch %d must be a multiple of 8)", p);
+  const int G = R / p;
+  const int64_t total = (int64_t)B * G * G * (C * p * p / 8);
+  const int grid = imin(4096, (total + 255) / 256);
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_im2row",
+    hipLaunchKernelGGL((im2row_kernel<T>), dim3(grid), dim3(256), 0, stream, image, B, C, R, p, (T*)patches);)
+  EVLM_LAUNCH_CHECK("evlm_im2row");
+  return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vit_embed_fwd_kernel(const T* __restrict__ tok, const float* __restrict__ cls,
+                                                            const float* __restrict__ pos, int B, int Tn, int d,
+                                                            T* __restrict__ x) {
+  const int per = d >> 3, N = Tn + 1;
+  const int64_t total = (int64_t)B * N * per;
+  for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = id / per;
+    const int c = (int)(id - row * per);
+    const int b = (int)(row / N), n = (int)(row - (int64_t)b * N);
+    float v[8], ps[8];
+    if (n == 0) load8<float>(cls + c * 8, v);
+    else load8<T>(tok + ((size_t)b * Tn + n - 1) * d + c * 8, v);
+    load8<float>(pos + (size_t)n * d + c * 8, ps);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += ps[e];
+    store8<T>(x + row * d + c * 8, v);
+  }
+}
+// one block per token position n: dpos[n] += sum_b dx[b,n]; n==0 -> dcls too; n>=1 -> dtok copy
+template <typename T>
+__global__ __launch_bounds__(256) void vit_embed_bwd_kernel(const T* __restrict__ dx, int B, int Tn, int d,
+                                                            T* __restrict__ dtok, float* __restrict__ dcls,
+                                                            float* __restrict__ dpos) {
+  const int n = blockIdx.x, N = Tn + 1;
+  for (int j = threadIdx.x; j < d; j += blockDim.x) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const T g = dx[((size_t)b * N + n) * d + j];
+      acc += to_f(g);
+      if (n > 0) dtok[((size_t)b * Tn + n - 1) * d + j] = g;
+    }
+    dpos[(size_t)n * d + j] += acc;
+    if (n == 0) dcls[j] += acc;
+  }
+}
+extern "C" int evlm_vit_embed_fwd(int dtype, const void* tok, const float* cls, const float* pos, int B, int T_, int d,
+                                  void* x, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(tok && cls && pos && x && d % 8 == 0, "evlm_vit_embed_fwd: bad args");
+  const int64_t total = (int64_t)B * (T_ + 1) * (d / 8);
+  const int grid = imin(4096, (total + 255) / 256);
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_vit_embed_fwd",
+    hipLaunchKernelGGL((vit_embed_fwd_kernel<T>), dim3(grid), dim3(256), 0, stream, (const T*)tok, cls, pos, B, T_, d, (T*)x);)
+  EVLM_LAUNCH_CHECK("evlm_vit_embed_fwd");
+  return 0;
+}
+extern "C" int evlm_vit_embed_bwd(int dtype, const void* dx, int B, int T_, int d, void* dtok, float* dcls, float* dpos,
+                                  void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(dx && dtok && dcls && dpos, "evlm_vit_embed_bwd: bad args");
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_vit_embed_bwd",
+    hipLaunchKernelGGL((vit_embed_bwd_kernel<T>), dim3(T_ + 1), dim3(256), 0, stream, (const T*)dx, B, T_, d, (T*)dtok, dcls, dpos);)
+  EVLM_LAUNCH_CHECK("evlm_vit_embed_bwd");
+  return 0;
+}
+
+// ---- masked-position gather (MLM head input) ----------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_fwd_kernel(const T* __restrict__ x, const int64_t* __restrict__ pos,
+                                                              int L, int M, int d, T* __restrict__ out, int rows) {
+  const int per = d >> 3;
+  for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < (int64_t)rows * per; id += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(id / per), c = (int)(id - (int64_t)row * per), b = row / M;
+    float v[8];
+    load8<T>(x + ((size_t)b * L + pos[row]) * d + c * 8, v);
+    store8<T>(out + (size_t)row * d + c * 8, v);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const T* __restrict__ dout, const int64_t* __restrict__ pos,
+                                                              int L, int M, int d, T* __restrict__ dx, int rows) {
+  const int per = d >> 3;
+  for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < (int64_t)rows * per; id += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(id / per), c = (int)(id - (int64_t)row * per), b = row / L, l = row - b * L;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m = 0; m < M; ++m)
+      if (pos[(size_t)b * M + m] == l) {
+        float v[8];
+        load8<T>(dout + ((size_t)b * M + m) * d + c * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      }
+    store8<T>(dx + (size_t)row * d + c * 8, acc);
+  }
+}
+extern "C" int evlm_gather_rows_fwd(int dtype, const void* x, const int64_t* pos, int B, int L, int M, int d, void* out,
+                                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(x && pos && out && d % 8 == 0, "evlm_gather_rows_fwd: bad args");
+  const int rows = B * M;
+  const int grid = imin(2048, ceil_div((int64_t)rows * (d / 8), 256));
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_gather_rows_fwd",
+    hipLaunchKernelGGL((gather_rows_fwd_kernel<T>), dim3(grid), dim3(256), 0, stream, (const T*)x, pos, L, M, d, (T*)out, rows);)
+  EVLM_LAUNCH_CHECK("evlm_gather_rows_fwd");
+  return 0;
+}
+extern "C" int evlm_gather_rows_bwd(int dtype, const void* dout, const int64_t* pos, int B, int L, int M, int d, void* dx,
+                                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(dout && pos && dx && d % 8 == 0, "evlm_gather_rows_bwd: bad args");
+  const int rows = B * L;
+  const int grid = imin(2048, ceil_div((int64_t)rows * (d / 8), 256));
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_gather_rows_bwd",
+    hipLaunchKernelGGL((gather_rows_bwd_kernel<T>), dim3(grid), dim3(256), 0, stream, (const T*)dout, pos, L, M, d, (T*)dx, rows);)
+  EVLM_LAUNCH_CHECK("evlm_gather_rows_bwd");
+  return 0;
+}
+
+// ---- dtype cast ---------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t n) {
+  const int64_t nv = n >> 3;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nv; c += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+    load8<TS>(s + c * 8, v);
+    store8<TD>(d + c * 8, v);
+  }
+  if (blockIdx.x == 0) for (int64_t i = (nv << 3) + threadIdx.x; i < n; i += blockDim.x) d[i] = from_f<TD>(to_f(s[i]));
+}
+extern "C" int evlm_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(src && dst && n > 0, "evlm_cast: bad args");
+  EVLM_REQUIRE((((uintptr_t)src) | ((uintptr_t)dst)) % 16 == 0, "evlm_cast: pointers must be 16-byte aligned");
+  const int grid = imin(4096, (n / 8 + 255) / 256 + 1);
+  if (src_dtype == EVLM_F32 && dst_dtype == EVLM_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(grid), dim3(256), 0, stream, (const float*)src, (bf16*)dst, n);
+  else if (src_dtype == EVLM_BF16 && dst_dtype == EVLM_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(grid), dim3(256), 0, stream, (const bf16*)src, (float*)dst, n);
+  else if (src_dtype == EVLM_F32 && dst_dtype == EVLM_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, stream, (const float*)src, (float*)dst, n);
+  else if (src_dtype == EVLM_BF16 && dst_dtype == EVLM_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, stream, (const bf16*)src, (bf16*)dst, n);
+  else return evlm_set_error("evlm_cast: bad dtypes");
+  EVLM_LAUNCH_CHECK("evlm_cast");
+  return 0;
+}
+
+// ---- backward of the gated activations (only when L0 gates are active) -----------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gated_act_bwd_kernel(const T* __restrict__ da, const T* __restrict__ h,
+                                                            const float* __restrict__ gate, int I, int J, int ld, int act,
+                                                            int gate_pos, T* __restrict__ dh, float* __restrict__ dgate,
+                                                            int rows_per_block) {
+  __shared__ float red[8][32 * 9];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int j0 = blockIdx.x * 256 + tx * 8;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(I, r0 + rows_per_block);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gz[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) gz[e] = (j0 + e < J) ? (gate ? gate[j0 + e] : 1.f) : 0.f;
+  if (j0 < J) {
+    for (int i = r0 + ty; i < r1; i += 8) {
+      float a[8], hv[8], o[8];
+      load8<T>(da + (size_t)i * ld + j0, a);
+      load8<T>(h + (size_t)i * ld + j0, hv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (gate_pos == EVLM_GATE_PRE_ACT) {
+          const float t = a[e] * act_grad(act, hv[e] * gz[e]);
+          o[e] = t * gz[e];
+          acc[e] += t * hv[e];
+        } else {
+          o[e] = a[e] * act_grad(act, hv[e]) * gz[e];
+          acc[e] += a[e] * act_apply(act, hv[e]);
+        }
+      }
+      store8<T>(dh + (size_t)i * ld + j0, o);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ty][tx * 9 + e] = acc[e];
+  __syncthreads();
+  if (ty == 0 && j0 < J && dgate) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = 0.f;
+      for (int y = 0; y < 8; ++y) s += red[y][tx * 9 + e];
+      if (j0 + e < J) atomicAdd(dgate + j0 + e, s);
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const T* __restrict__ x, int64_t n, int act, T* __restrict__ y) {
+  const int64_t nv = n >> 3;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nv; c += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+    load8<T>(x + c * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act_apply(act, v[e]);
+    store8<T>(y + c * 8, v);
+  }
+  if (blockIdx.x == 0) for (int64_t i = (nv << 3) + threadIdx.x; i < n; i += blockDim.x) y[i] = from_f<T>(act_apply(act, to_f(x[i])));
+}
+extern "C" int evlm_act_fwd(int dtype, const void* x, int64_t n, int act, void* y, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(x && y && n > 0, "evlm_act_fwd: bad args");
+  const int grid = imin(4096, (n / 8 + 255) / 256 + 1);
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_act_fwd",
+    hipLaunchKernelGGL((act_fwd_kernel<T>), dim3(grid), dim3(256), 0, stream, (const T*)x, n, act, (T*)y);)
+  EVLM_LAUNCH_CHECK("evlm_act_fwd");
+  return 0;
+}
+extern "C" int evlm_gated_act_bwd(int dtype, const void* da, const void* h, const float* gate, int I, int J, int ld,
+                                  int act, int gate_pos, void* dh, float* dgate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(da && h && dh && ld % 8 == 0 && J % 8 == 0, "evlm_gated_act_bwd: bad args");
+  EVLM_REQUIRE((gate == nullptr) == (dgate == nullptr), "evlm_gated_act_bwd: gate and dgate go together");
+  const int rpb = 256;
+  dim3 grid(ceil_div(J, 256), ceil_div(I, rpb)), block(256);
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_gated_act_bwd",
+    hipLaunchKernelGGL((gated_act_bwd_kernel<T>), grid, block, 0, stream, (const T*)da, (const T*)h, gate, I, J, ld, act, gate_pos, (T*)dh, dgate, rpb);)
+  EVLM_LAUNCH_CHECK("evlm_gated_act_bwd");
+  return 0;
+}
+
+// ---- hard-concrete L0 gates ----------------------------------------------------------------------
+#define L0_LIMIT_A (-0.1f)
+#define L0_LIMIT_B (1.1f)
+__global__ __launch_bounds__(256) void l0_sample_fwd_kernel(const float* __restrict__ loga, const float* __restrict__ eps,
+                                                            int64_t n, float inv_t, float* __restrict__ z) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float u = eps[i];
+    const float y = 1.0f / (1.0f + expf(-((logf(u) - logf(1.0f - u) + loga[i]) * inv_t)));
+    const float s = y * (L0_LIMIT_B - L0_LIMIT_A) + L0_LIMIT_A;
+    z[i] = fminf(fmaxf(s, 0.f), 1.f);
+  }
+}
+__global__ __launch_bounds__(256) void l0_sample_bwd_kernel(const float* __restrict__ loga, const float* __restrict__ eps,
+                                                            const float* __restrict__ dz, int64_t n, float inv_t,
+                                                            float* __restrict__ dloga) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float u = eps[i];
+    const float y = 1.0f / (1.0f + expf(-((logf(u) - logf(1.0f - u) + loga[i]) * inv_t)));
+    const float s = y * (L0_LIMIT_B - L0_LIMIT_A) + L0_LIMIT_A;
+    const float pass = (s > 0.f && s < 1.f) ? 1.f : 0.f;     // hardtanh backward: open interval
+    dloga[i] = dz[i] * pass * (L0_LIMIT_B - L0_LIMIT_A) * y * (1.f - y) * inv_t;
+  }
+}
+extern "C" int evlm_l0_sample_fwd(const float* loga, const float* eps, int64_t n, float temperature, float* z, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(loga && eps && z && n > 0, "evlm_l0_sample_fwd: bad args");
+  hipLaunchKernelGGL(l0_sample_fwd_kernel, dim3(imin(1024, (n + 255) / 256)), dim3(256), 0, stream, loga, eps, n, 1.0f / temperature, z);
+  EVLM_LAUNCH_CHECK("evlm_l0_sample_fwd");
+  return 0;
+}
+extern "C" int evlm_l0_sample_bwd(const float* loga, const float* eps, const float* dz, int64_t n, float temperature,
+                                  float* dloga, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(loga && eps && dz && dloga && n > 0, "evlm_l0_sample_bwd: bad args");
+  hipLaunchKernelGGL(l0_sample_bwd_kernel, dim3(imin(1024, (n + 255) / 256)), dim3(256), 0, stream, loga, eps, dz, n, 1.0f / temperature, dloga);
+  EVLM_LAUNCH_CHECK("evlm_l0_sample_bwd");
+  return 0;
+}
+
+// eval masks: one block per layer row.  k = round_half_even(size - sum(1 - cdf_qz(0)));  the k smallest
+// sigmoid(loga/T*magic) by ascending (value, index) become 0, everything else 1.
+__global__ __launch_bounds__(256) void l0_det_kernel(const float* __restrict__ loga, int size, float temperature,
+                                                     float magic, float* __restrict__ z) {
+  extern __shared__ float soft[];
+  __shared__ double dred[4];
+  __shared__ int kzero;
+  const float* la = loga + (size_t)blockIdx.x * size;
+  float* zr = z + (size_t)blockIdx.x * size;
+  const float xn = (0.f - L0_LIMIT_A) / (L0_LIMIT_B - L0_LIMIT_A);
+  const float lg = (float)(log((double)xn) - log(1.0 - (double)xn));
+  double nz = 0.0;
+  for (int i = threadIdx.x; i < size; i += blockDim.x) {
+    float c = 1.0f / (1.0f + expf(-(lg * temperature - la[i])));
+    c = fminf(fmaxf(c, 1e-6f), 1.0f - 1e-6f);
+    nz += (double)(1.0f - c);
+    soft[i] = 1.0f / (1.0f + expf(-(la[i] / temperature * magic)));
+  }
+  for (int o = 32; o > 0; o >>= 1) nz += __shfl_xor(nz, o, 64);
+  if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = nz;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tot = dred[0] + dred[1] + dred[2] + dred[3];
+    const float expected_nonzeros = (float)tot;                    // the reference sums in fp32
+    const double ez = (double)size - (double)expected_nonzeros;    // python float arithmetic
+    kzero = (int)rint(ez);                                         // python round(): half to even
+  }
+  __syncthreads();
+  const int k = kzero;
+  for (int i = threadIdx.x; i < size; i += blockDim.x) {
+    if (k <= 0) { zr[i] = 1.0f; continue; }
+    const float v = soft[i];
+    int rank = 0;
+    for (int j = 0; j < size; ++j) {
+      const float w = soft[j];
+      rank += (w < v || (w == v && j < i)) ? 1 : 0;
+    }
+    zr[i] = rank < k ? 0.0f : 1.0f;
+  }
+}
+extern "C" int evlm_l0_deterministic(const float* loga, int rows, int size, float temperature, float magical_number,
+                                     float* z, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(loga && z && rows > 0 && size > 0 && size <= 16384, "evlm_l0_deterministic: bad args");
+  hipLaunchKernelGGL(l0_det_kernel, dim3(rows), dim3(256), size * sizeof(float), stream, loga, size, temperature, magical_number, z);
+  EVLM_LAUNCH_CHECK("evlm_l0_deterministic");
+  return 0;
+}
+
+// ---- row-wise L2 normalisation (F.normalize(dim=-1), get_features xvlm.py:375-382) -------------------
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x, int d, int ldx, float eps, T* __restrict__ y,
+                                                         float* __restrict__ inv_norm, int rows) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (size_t)row * ldx;
+  float s = 0.f;
+  for (int i = lane; i < d; i += 64) { const float v = to_f(xr[i]); s += v * v; }
+  const float inv = 1.0f / fmaxf(sqrtf(wave_sum(s)), eps);
+  for (int i = lane; i < d; i += 64) y[(size_t)row * d + i] = from_f<T>(to_f(xr[i]) * inv);
+  if (lane == 0 && inv_norm) inv_norm[row] = inv;
+}
+// dx = inv * (dy - y * sum(dy*y))
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy,
+                                                         const float* __restrict__ inv_norm, int d, T* __restrict__ dx, int rows) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* yr = y + (size_t)row * d;
+  const T* dr = dy + (size_t)row * d;
+  float s = 0.f;
+  for (int i = lane; i < d; i += 64) s += to_f(yr[i]) * to_f(dr[i]);
+  s = wave_sum(s);
+  const float inv = inv_norm[row];
+  for (int i = lane; i < d; i += 64) dx[(size_t)row * d + i] = from_f<T>(inv * (to_f(dr[i]) - to_f(yr[i]) * s));
+}
+extern "C" int evlm_l2norm_fwd(int dtype, const void* x, int rows, int d, int ldx, float eps, void* y, float* inv_norm, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(x && y && rows > 0 && d > 0, "evlm_l2norm_fwd: bad args");
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_l2norm_fwd",
+    hipLaunchKernelGGL((l2norm_fwd_kernel<T>), dim3(ceil_div(rows, 4)), dim3(256), 0, stream, (const T*)x, d, ldx, eps, (T*)y, inv_norm, rows);)
+  EVLM_LAUNCH_CHECK("evlm_l2norm_fwd");
+  return 0;
+}
+extern "C" int evlm_l2norm_bwd(int dtype, const void* y, const void* dy, const float* inv_norm, int rows, int d, void* dx, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(y && dy && inv_norm && dx && rows > 0, "evlm_l2norm_bwd: bad args");
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_l2norm_bwd",
+    hipLaunchKernelGGL((l2norm_bwd_kernel<T>), dim3(ceil_div(rows, 4)), dim3(256), 0, stream, (const T*)y, (const T*)dy, inv_norm, d, (T*)dx, rows);)
+  EVLM_LAUNCH_CHECK("evlm_l2norm_bwd");
+  return 0;
+}

@@ -1,0 +1,156 @@
+// LayerNorm forward / backward for gfx950.  HBM-bound: one 64-lane wave per row, 16-byte vector loads,
+// two-pass mean / variance in fp32 (matches ATen's numerics; BERT uses eps = 1e-12 so the variance must be exact).
+#include "common.h"
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, int rows, int d,
+                                                     T* __restrict__ y, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (size_t)row * d;
+  const int nchunk = d >> 3;
+  float s = 0.f;
+  for (int c = lane; c < nchunk; c += 64) {
+    float v[8];
+    load8<T>(xr + c * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e];
+  }
+  for (int i = (nchunk << 3) + lane; i < d; i += 64) s += to_f(xr[i]);
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+  for (int c = lane; c < nchunk; c += 64) {
+    float v[8];
+    load8<T>(xr + c * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float t = v[e] - mean; q += t * t; }
+  }
+  for (int i = (nchunk << 3) + lane; i < d; i += 64) { const float t = to_f(xr[i]) - mean; q += t * t; }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+  T* yr = y + (size_t)row * d;
+  for (int c = lane; c < nchunk; c += 64) {
+    float v[8], gm[8], bt[8];
+    load8<T>(xr + c * 8, v);
+    load8<float>(gamma + c * 8, gm);
+    load8<float>(beta + c * 8, bt);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
+    store8<T>(yr + c * 8, v);
+  }
+  for (int i = (nchunk << 3) + lane; i < d; i += 64) yr[i] = from_f<T>((to_f(xr[i]) - mean) * rstd * gamma[i] + beta[i]);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+}
+
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma += sum_rows dy*xhat;  dbeta += sum_rows dy.
+// Each block walks rows blockIdx.x*4 + w, += gridDim.x*4 and keeps per-thread partial dgamma/dbeta for the
+// columns it owns (d <= 64*8*DCH), reduced over the 4 waves through LDS, then ONE atomicAdd per column per block.
+#define LN_DCH 6   // up to 64*8*6 = 3072 columns
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, int rows, int d, T* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  extern __shared__ float sred[];   // [2][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = d >> 3;
+  float pg[LN_DCH][8], pb[LN_DCH][8];
+#pragma unroll
+  for (int u = 0; u < LN_DCH; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pg[u][e] = 0.f; pb[u][e] = 0.f; }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const T* xr = x + (size_t)row * d;
+    const T* dr = dy + (size_t)row * d;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < LN_DCH; ++u) {
+      const int c = lane + 64 * u;
+      if (c < nchunk) {
+        float xv[8], dv[8], gm[8];
+        load8<T>(xr + c * 8, xv);
+        load8<T>(dr + c * 8, dv);
+        load8<float>(gamma + c * 8, gm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[e] - mu) * rs, gd = gm[e] * dv[e];
+          s1 += gd; s2 += gd * xh;
+          pg[u][e] += dv[e] * xh; pb[u][e] += dv[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+    T* dxr = dx + (size_t)row * d;
+#pragma unroll
+    for (int u = 0; u < LN_DCH; ++u) {
+      const int c = lane + 64 * u;
+      if (c < nchunk) {
+        float xv[8], dv[8], gm[8], o[8];
+        load8<T>(xr + c * 8, xv);
+        load8<T>(dr + c * 8, dv);
+        load8<float>(gamma + c * 8, gm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[e] - mu) * rs;
+          o[e] = rs * (gm[e] * dv[e] - s1 - xh * s2);
+        }
+        store8<T>(dxr + c * 8, o);
+      }
+    }
+  }
+  // reduce the 4 waves' partials
+  float* sg = sred;
+  float* sb = sred + d;
+  for (int i = threadIdx.x; i < 2 * d; i += 256) sred[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < LN_DCH; ++u) {
+    const int c = lane + 64 * u;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(&sg[c * 8 + e], pg[u][e]);
+        atomicAdd(&sb[c * 8 + e], pb[u][e]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < d; i += 256) {
+    atomicAdd(dgamma + i, sg[i]);
+    atomicAdd(dbeta + i, sb[i]);
+  }
+}
+
+extern "C" int evlm_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, float eps,
+                                  int rows, int d, void* y, float* mean, float* rstd, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(x && y && gamma && beta && rows > 0 && d > 0, "evlm_layernorm_fwd: bad args");
+  EVLM_REQUIRE(d % 8 == 0, "evlm_layernorm_fwd: d=%d must be a multiple of 8", d);
+  dim3 grid(ceil_div(rows, 4)), block(256);
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_fwd",
+    hipLaunchKernelGGL((ln_fwd_kernel<T>), grid, block, 0, stream, (const T*)x, gamma, beta, eps, rows, d, (T*)y, mean, rstd);)
+  EVLM_LAUNCH_CHECK("evlm_layernorm_fwd");
+  return 0;
+}
+
+extern "C" int evlm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                                  const float* rstd, int rows, int d, void* dx, float* dgamma, float* dbeta,
+                                  void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "evlm_layernorm_bwd: bad args");
+  EVLM_REQUIRE(d % 8 == 0 && d <= 64 * 8 * LN_DCH, "evlm_layernorm_bwd: d=%d unsupported (multiple of 8, <= %d)", d, 64 * 8 * LN_DCH);
+  const int nblk = imin(ceil_div(rows, 4), 1024);
+  dim3 grid(nblk), block(256);
+  const size_t lds = 2 * (size_t)d * sizeof(float);
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_bwd",
+    hipLaunchKernelGGL((ln_bwd_kernel<T>), grid, block, lds, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, rows, d, (T*)dx, dgamma, dbeta);)
+  EVLM_LAUNCH_CHECK("evlm_layernorm_bwd");
+  return 0;
+}

@@ -1,0 +1,750 @@
+"""Autograd-aware host wrappers over the C ABI of libevlm_hip.so.
+
+Every function here launches hand-written gfx950 kernels on the current HIP stream through ctypes
+(`_lib`); PyTorch only supplies device memory, streams and the autograd tape.  Nothing falls back to
+ATen math: a CPU tensor or a missing library raises.
+
+Compute dtype: activations are either torch.float32 (exact-fp32 parity path, fp32-input MFMA) or
+torch.bfloat16 (fast path: bf16 storage, fp32 accumulate).  Parameters stay fp32 (checkpoint ABI); the
+bf16 path reads packed bf16 compute copies from `WeightCache`.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+_EMPTY = {}
+
+
+def _lib():
+    return L.load()
+
+
+# ---------------------------------------------------------------------------------------------------
+# weight cache: packed compute copies of fp32 master parameters
+# ---------------------------------------------------------------------------------------------------
+class WeightCache:
+    """compute-dtype copies of (tuples of) fp32 parameters, re-cast when a parameter's version changes.
+
+    A tuple of [n_i, k] weights is packed row-wise into one [sum n_i, k] matrix (fused QKV / KV
+    projections); biases likewise into one fp32 vector."""
+
+    def __init__(self):
+        self._store = {}
+        self.epoch = 0          # bump to force a re-cast of trainable weights (e.g. before graph capture)
+
+    def invalidate(self):
+        self.epoch += 1
+
+    def get(self, params, dtype):
+        key = (tuple(id(p) for p in params), dtype)
+        vers = tuple(p._version for p in params)
+        grad = any(p.requires_grad for p in params)
+        ent = self._store.get(key)
+        if ent is not None and ent[1] == vers and (not grad or ent[2] == self.epoch) and ent[3] == params[0].data_ptr():
+            return ent[0]
+        if len(params) == 1 and params[0].dtype == dtype and params[0].is_contiguous():
+            buf = params[0].detach()
+        else:
+            rows = sum(p.shape[0] for p in params)
+            shape = (rows,) + tuple(params[0].shape[1:])
+            buf = ent[0] if (ent is not None and ent[0].shape == shape and ent[3] == params[0].data_ptr()) \
+                else torch.empty(shape, dtype=dtype, device=params[0].device)
+            lib, r0 = _lib(), 0
+            for p in params:
+                pd = p.detach()
+                if not pd.is_contiguous():
+                    pd = pd.contiguous()
+                dst = buf[r0:r0 + p.shape[0]]
+                L.check(lib.evlm_cast(L.dt(pd), L.ptr(pd), L.dt(dst), L.ptr(dst), pd.numel(), L.stream()), "cast")
+                r0 += p.shape[0]
+        self._store[key] = (buf, vers, self.epoch, params[0].data_ptr())
+        return buf
+
+
+CACHE = WeightCache()
+
+
+def _as2d(x):
+    """view x [..., K] as rows x K with a uniform row stride; returns (tensor, rows, K, ld)."""
+    K = x.shape[-1]
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    if x.dim() == 2:
+        if x.stride(0) % 8 != 0 and x.shape[0] > 1:
+            x = x.contiguous()
+        return x, x.shape[0], K, (x.stride(0) if x.shape[0] > 1 else K)
+    if not x.is_contiguous():
+        # collapsible leading dims?  (e.g. x[:, 0, :] of a contiguous [B, L, d])
+        x2 = x.reshape(-1, K) if _collapsible(x) else x.contiguous().view(-1, K)
+        return _as2d(x2)
+    return x, x.numel() // K, K, K
+
+
+def _collapsible(x):
+    try:
+        v = x.view(-1, x.shape[-1])
+        return v.data_ptr() == x.data_ptr()
+    except RuntimeError:
+        return False
+
+
+def _gemm(dtype, P, Q, Cm, I, J, K, ldp, ldq, ldc, p_trans=0, q_trans=0, bias=None, gate=None, preact=None,
+          aux=None, residual=None, ldx=0, alpha=1.0, act=L.ACT_NONE, gate_pos=L.GATE_PRE, dact=L.ACT_NONE, c_f32=0):
+    a = L.GemmArgs(dtype=dtype, c_f32=c_f32, p_trans=p_trans, q_trans=q_trans, I=I, J=J, K=K, ldp=ldp, ldq=ldq,
+                   ldc=ldc, ldx=ldx, P=L.ptr(P), Q=L.ptr(Q), C=L.ptr(Cm), bias=L.ptr(bias), gate=L.ptr(gate),
+                   preact=L.ptr(preact), aux=L.ptr(aux), residual=L.ptr(residual), alpha=alpha, act=act,
+                   gate_pos=gate_pos, dact=dact)
+    L.check(_lib().evlm_gemm(C.byref(a), L.stream()), "gemm")
+
+
+def _colsum(x2d, I, J, ld):
+    out = torch.zeros(J, dtype=torch.float32, device=x2d.device)
+    L.check(_lib().evlm_colsum(L.dt(x2d), L.ptr(x2d), I, J, ld, L.ptr(out), L.stream()), "colsum")
+    return out
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+# ---------------------------------------------------------------------------------------------------
+# Linear (optionally several weights packed along the output dim) with fused epilogue
+# ---------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b) (+ residual);  W = rows of `weights` packed (fused QKV / KV projections)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, act, out_f32, nw, *wb):
+        weights, biases = wb[:nw], wb[nw:]
+        L.require_cuda(x, *weights)
+        x2, M, K, ldp = _as2d(x)
+        dtype = L.dt(x2)
+        W = CACHE.get(weights, x2.dtype)
+        b = CACHE.get(biases, torch.float32) if biases and biases[0] is not None else None
+        N = W.shape[0]
+        ydt = torch.float32 if out_f32 else x2.dtype
+        ldc = _pad8(N)
+        ybuf = torch.empty((M, ldc), dtype=ydt, device=x.device) if ldc == N else \
+            torch.zeros((M, ldc), dtype=ydt, device=x.device)
+        need_grad = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        preact = None
+        if act != L.ACT_NONE and need_grad:
+            preact = torch.empty((M, ldc), dtype=x2.dtype, device=x.device)
+        r2 = None
+        if residual is not None:
+            r2, rm, rn, ldr = _as2d(residual)
+            if ldr != ldc or r2.dtype != x2.dtype:
+                raise RuntimeError("residual must be contiguous [M, N] of the activation dtype")
+        _gemm(dtype, x2, W, ybuf, M, N, K, ldp, K, ldc, bias=b, preact=preact, residual=r2, ldx=ldc, act=act,
+              c_f32=1 if out_f32 else 0)
+        ctx.save_for_backward(x2, W, preact)
+        ctx.meta = (M, N, K, ldp, ldc, act, nw, tuple(w.shape[0] for w in weights), biases and biases[0] is not None,
+                    residual is not None, x.shape, out_f32)
+        y = ybuf[:, :N] if ldc != N else ybuf
+        return y.unflatten(0, x.shape[:-1]) if x.dim() > 2 else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, preact = ctx.saved_tensors
+        M, N, K, ldp, ldc, act, nw, rows, has_bias, has_res, xshape, out_f32 = ctx.meta
+        dtype = L.dt(x2)
+        lib = _lib()
+        d2 = dy.reshape(M, N)
+        if d2.dtype != x2.dtype:          # f32-output heads only: bring the gradient to the compute dtype
+            d2 = cast(d2.contiguous(), x2.dtype)
+        if d2.stride(1) != 1 or d2.stride(0) % 8 != 0 or d2.stride(0) < _pad8(N):
+            buf = torch.zeros((M, _pad8(N)), dtype=x2.dtype, device=x2.device)
+            buf[:, :N].copy_(d2)
+            d2 = buf
+        ldd = d2.stride(0)
+        dres = dy if has_res else None
+        if act != L.ACT_NONE:
+            dh = torch.empty_like(preact) if ldd == ldc else torch.zeros_like(preact)
+            if ldd != ldc:
+                raise RuntimeError("internal: activation backward needs matching leading dimensions")
+            L.check(lib.evlm_gated_act_bwd(dtype, L.ptr(d2), L.ptr(preact), None, M, _pad8(N), ldc, act, L.GATE_POST,
+                                           L.ptr(dh), None, L.stream()), "act_bwd")
+            d2, ldd = dh, ldc
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxb = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
+            _gemm(dtype, d2, W, dxb, M, K, N, ldd, K, K, p_trans=0, q_trans=1)     # dX = dY W
+            dx = dxb.view(xshape)
+        dW = torch.empty((N, K), dtype=torch.float32, device=x2.device)
+        _gemm(dtype, d2, x2, dW, N, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1)   # dW = dY^T X
+        gw, r0 = [], 0
+        for r in rows:
+            gw.append(dW[r0:r0 + r])
+            r0 += r
+        gb = [None] * nw
+        if has_bias:
+            db = _colsum(d2, M, N, ldd)
+            gb, r0 = [], 0
+            for r in rows:
+                gb.append(db[r0:r0 + r])
+                r0 += r
+        return (dx, dres, None, None, None, *gw, *gb)
+
+
+def linear(x, weight, bias=None, act=L.ACT_NONE, residual=None, out_f32=False):
+    return _Linear.apply(x, residual, act, out_f32, 1, weight, bias)
+
+
+def linear_packed(x, weights, biases):
+    """one GEMM for several Linear layers sharing the input: returns [.., sum N_i]"""
+    return _Linear.apply(x, None, L.ACT_NONE, False, len(weights), *weights, *biases)
+
+
+# ---------------------------------------------------------------------------------------------------
+# MLP block: y = act_gate(x W1^T + b1) W2^T + b2 + residual     (CLIPMLP / BertIntermediate+BertOutput.dense)
+# ---------------------------------------------------------------------------------------------------
+class _MLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gate, residual, act, gate_pos):
+        L.require_cuda(x, w1, w2)
+        x2, M, K, ldp = _as2d(x)
+        dtype = L.dt(x2)
+        W1, W2 = CACHE.get((w1,), x2.dtype), CACHE.get((w2,), x2.dtype)
+        Fh, N = W1.shape[0], W2.shape[0]
+        need_grad = torch.is_grad_enabled()
+        h = torch.empty((M, Fh), dtype=x2.dtype, device=x.device) if need_grad else None
+        a = torch.empty((M, Fh), dtype=x2.dtype, device=x.device)
+        g32 = None
+        if gate is not None:
+            g32 = gate.detach().reshape(-1).to(torch.float32).contiguous()
+        _gemm(dtype, x2, W1, a, M, Fh, K, ldp, K, Fh, bias=b1.detach(), gate=g32, preact=h, ldx=Fh, act=act, gate_pos=gate_pos)
+        y = torch.empty((M, N), dtype=x2.dtype, device=x.device)
+        r2 = None
+        if residual is not None:
+            r2 = residual.reshape(M, N)
+            if not r2.is_contiguous():
+                r2 = r2.contiguous()
+        _gemm(dtype, a, W2, y, M, N, Fh, Fh, Fh, N, bias=b2.detach(), residual=r2, ldx=N)
+        ctx.save_for_backward(x2, W1, W2, h, a, g32)
+        ctx.meta = (M, K, Fh, N, ldp, act, gate_pos, x.shape, gate.shape if gate is not None else None,
+                    residual is not None)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W1, W2, h, a, g32 = ctx.saved_tensors
+        M, K, Fh, N, ldp, act, gate_pos, xshape, gshape, has_res = ctx.meta
+        dtype = L.dt(x2)
+        lib = _lib()
+        d2 = dy.reshape(M, N)
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        dev = x2.device
+        dh = torch.empty((M, Fh), dtype=x2.dtype, device=dev)
+        dgate = None
+        if g32 is None:
+            # dH = (dY W2) .* act'(h), fused into the GEMM epilogue
+            _gemm(dtype, d2, W2, dh, M, Fh, N, N, Fh, Fh, p_trans=0, q_trans=1, aux=h, ldx=Fh, dact=act)
+        else:
+            da = torch.empty((M, Fh), dtype=x2.dtype, device=dev)
+            _gemm(dtype, d2, W2, da, M, Fh, N, N, Fh, Fh, p_trans=0, q_trans=1)
+            dg = torch.zeros(Fh, dtype=torch.float32, device=dev)
+            L.check(lib.evlm_gated_act_bwd(dtype, L.ptr(da), L.ptr(h), L.ptr(g32), M, Fh, Fh, act, gate_pos, L.ptr(dh),
+                                           L.ptr(dg), L.stream()), "gated_act_bwd")
+            dgate = dg.view(gshape)
+        dW2 = torch.empty((N, Fh), dtype=torch.float32, device=dev)
+        _gemm(dtype, d2, a, dW2, N, Fh, M, N, Fh, Fh, p_trans=1, q_trans=1, c_f32=1)
+        db2 = _colsum(d2, M, N, N)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxb = torch.empty((M, K), dtype=x2.dtype, device=dev)
+            _gemm(dtype, dh, W1, dxb, M, K, Fh, Fh, K, K, p_trans=0, q_trans=1)
+            dx = dxb.view(xshape)
+        dW1 = torch.empty((Fh, K), dtype=torch.float32, device=dev)
+        _gemm(dtype, dh, x2, dW1, Fh, K, M, Fh, ldp, K, p_trans=1, q_trans=1, c_f32=1)
+        db1 = _colsum(dh, M, Fh, Fh)
+        return dx, dW1, db1, dW2, db2, dgate, (dy if has_res else None), None, None
+
+
+def mlp(x, w1, b1, w2, b2, act, gate=None, gate_pos=L.GATE_PRE, residual=None):
+    return _MLP.apply(x, w1, b1, w2, b2, gate, residual, act, gate_pos)
+
+
+# ---------------------------------------------------------------------------------------------------
+# LayerNorm
+# ---------------------------------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        L.require_cuda(x, gamma)
+        d = x.shape[-1]
+        xc = x if x.is_contiguous() else x.contiguous()
+        rows = xc.numel() // d
+        y = torch.empty_like(xc)
+        need = torch.is_grad_enabled()
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
+        L.check(_lib().evlm_layernorm_fwd(L.dt(xc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(beta.detach()), eps, rows, d,
+                                          L.ptr(y), L.ptr(mean), L.ptr(rstd), L.stream()), "layernorm_fwd")
+        ctx.save_for_backward(xc, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, gamma, mean, rstd = ctx.saved_tensors
+        d = xc.shape[-1]
+        rows = xc.numel() // d
+        dyc = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty_like(xc)
+        dg = torch.zeros(d, dtype=torch.float32, device=xc.device)
+        db = torch.zeros(d, dtype=torch.float32, device=xc.device)
+        L.check(_lib().evlm_layernorm_bwd(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd),
+                                          rows, d, L.ptr(dx), L.ptr(dg), L.ptr(db), L.stream()), "layernorm_bwd")
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps):
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention core (probabilities are an output)
+# ---------------------------------------------------------------------------------------------------
+class _Attention(torch.autograd.Function):
+    """qbuf: [B, Lq, *] packed buffer holding Q at column q_off; kvbuf: [Bkv, Lk, *] holding K at k_off and V at
+    v_off (qbuf is kvbuf for self-attention).  Returns (O [B,Lq,H*dh], P [B,H,Lq,Lk])."""
+
+    @staticmethod
+    def forward(ctx, qbuf, kvbuf, mask, gate, H, dh, q_off, k_off, v_off, scale, want_probs):
+        L.require_cuda(qbuf, kvbuf)
+        assert qbuf.is_contiguous() and kvbuf.is_contiguous()
+        B, Lq, ldq = qbuf.shape
+        Bkv, Lk, ldk = kvbuf.shape
+        dev, tdt = qbuf.device, qbuf.dtype
+        O = torch.empty((B, Lq, H * dh), dtype=tdt, device=dev)
+        need = any(ctx.needs_input_grad)
+        P = torch.empty((B, H, Lq, Lk), dtype=tdt, device=dev) if (want_probs or need) else None
+        m32 = mask.detach().to(torch.float32).contiguous() if mask is not None else None
+        g32 = gate.detach().reshape(-1).to(torch.float32).contiguous() if gate is not None else None
+        es = qbuf.element_size()
+        a = L.AttnFwdArgs(dtype=L.dt(tdt), p_dtype=L.dt(tdt), B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, ldq=ldq, ldk=ldk, ldv=ldk,
+                          ldo=H * dh, Q=C.c_void_p(qbuf.data_ptr() + q_off * es), K=C.c_void_p(kvbuf.data_ptr() + k_off * es),
+                          V=C.c_void_p(kvbuf.data_ptr() + v_off * es), kv_index=None, mask=L.ptr(m32), head_gate=L.ptr(g32),
+                          scale=scale, O=L.ptr(O), P=L.ptr(P))
+        L.check(_lib().evlm_attention_fwd(C.byref(a), L.stream()), "attention_fwd")
+        ctx.save_for_backward(qbuf, kvbuf, P, g32)
+        ctx.meta = (H, dh, q_off, k_off, v_off, scale, qbuf is kvbuf or qbuf.data_ptr() == kvbuf.data_ptr(),
+                    gate.shape if gate is not None else None)
+        return O, P
+
+    @staticmethod
+    def backward(ctx, dO, dP):
+        qbuf, kvbuf, P, g32 = ctx.saved_tensors
+        H, dh, q_off, k_off, v_off, scale, self_attn, gshape = ctx.meta
+        B, Lq, ldq = qbuf.shape
+        Bkv, Lk, ldk = kvbuf.shape
+        dev, tdt = qbuf.device, qbuf.dtype
+        es = qbuf.element_size()
+        dOc = dO if dO.is_contiguous() else dO.contiguous()
+        dPc = None
+        if dP is not None:
+            dPc = dP if dP.is_contiguous() else dP.contiguous()
+            if dPc.dtype != tdt:
+                dPc = dPc.to(tdt)
+        d = H * dh
+        assert ldq == (3 * d if self_attn else d) and ldk == (3 * d if self_attn else 2 * d), "packed buffers must be exact"
+        dqbuf = torch.empty_like(qbuf)                       # the kernels write every element of the packed grads
+        dkvbuf = dqbuf if self_attn else torch.empty_like(kvbuf)
+        dS = torch.empty((B, H, Lq, Lk), dtype=tdt, device=dev)
+        dgate = torch.zeros(H, dtype=torch.float32, device=dev) if g32 is not None else None
+        a = L.AttnBwdArgs(dtype=L.dt(tdt), p_dtype=L.dt(tdt), B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, ldq=ldq, ldk=ldk, ldv=ldk,
+                          ldo=H * dh, lddq=ldq, lddk=ldk, lddv=ldk,
+                          Q=C.c_void_p(qbuf.data_ptr() + q_off * es), K=C.c_void_p(kvbuf.data_ptr() + k_off * es),
+                          V=C.c_void_p(kvbuf.data_ptr() + v_off * es), P=L.ptr(P), dO=L.ptr(dOc), dP_ext=L.ptr(dPc),
+                          kv_index=None, head_gate=L.ptr(g32), scale=scale, dS=L.ptr(dS),
+                          dQ=C.c_void_p(dqbuf.data_ptr() + q_off * es), dK=C.c_void_p(dkvbuf.data_ptr() + k_off * es),
+                          dV=C.c_void_p(dkvbuf.data_ptr() + v_off * es), dgate=L.ptr(dgate))
+        L.check(_lib().evlm_attention_bwd(C.byref(a), L.stream()), "attention_bwd")
+        dg = dgate.view(gshape) if dgate is not None else None
+        if self_attn:
+            return dqbuf, None, None, dg, None, None, None, None, None, None, None
+        return dqbuf, dkvbuf, None, dg, None, None, None, None, None, None, None
+
+
+def self_attention(qkv, H, dh, scale, mask=None, gate=None, want_probs=True):
+    """qkv: [B, L, 3*H*dh] packed (q | k | v)"""
+    d = H * dh
+    return _Attention.apply(qkv, qkv, mask, gate, H, dh, 0, d, 2 * d, scale, want_probs)
+
+
+def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True):
+    """q: [B, Lq, H*dh]; kv: [B, Lk, 2*H*dh] packed (k | v)"""
+    d = H * dh
+    return _Attention.apply(q, kv, mask, gate, H, dh, 0, 0, d, scale, want_probs)
+
+
+# ---------------------------------------------------------------------------------------------------
+# losses (device scalars)
+# ---------------------------------------------------------------------------------------------------
+class _MSE(torch.autograd.Function):
+    """weight * mean((a-b)^2); gradient flows to `a` only (b is the detached teacher)"""
+
+    @staticmethod
+    def forward(ctx, a, b, weight):
+        L.require_cuda(a, b)
+        ac = a if a.is_contiguous() else a.contiguous()
+        bc = b if b.is_contiguous() else b.contiguous()
+        out = torch.zeros((), dtype=torch.float32, device=a.device)
+        L.check(_lib().evlm_mse_fwd(L.dt(ac), L.ptr(ac), L.dt(bc), L.ptr(bc), ac.numel(), weight, L.ptr(out), L.stream()), "mse_fwd")
+        ctx.save_for_backward(ac, bc)
+        ctx.weight = weight
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ac, bc = ctx.saved_tensors
+        gc = g.to(torch.float32).contiguous()
+        ga = torch.empty_like(ac)
+        L.check(_lib().evlm_mse_bwd(L.dt(ac), L.ptr(ac), L.dt(bc), L.ptr(bc), ac.numel(), ctx.weight, L.ptr(gc), L.ptr(ga),
+                                    L.stream()), "mse_bwd")
+        return ga, None, None
+
+
+def mse(a, b, weight=1.0):
+    return _MSE.apply(a, b.detach(), float(weight))
+
+
+def _rows2d(x):
+    Cn = x.shape[-1]
+    x2 = x.reshape(-1, Cn) if x.dim() != 2 else x
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    return x2, x2.shape[0], Cn, x2.stride(0) if x2.shape[0] > 1 else Cn
+
+
+class _CE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        L.require_cuda(logits, labels)
+        x2, R, Cn, ld = _rows2d(logits)
+        lab = labels.reshape(-1).to(torch.int64).contiguous()
+        out = torch.zeros((), dtype=torch.float32, device=logits.device)
+        lse = torch.empty(2 * R, dtype=torch.float32, device=logits.device)
+        valid = torch.zeros(1, dtype=torch.int32, device=logits.device)
+        L.check(_lib().evlm_ce_fwd(L.dt(x2), L.ptr(x2), R, Cn, ld, L.ptr(lab), ignore_index, 1.0, L.ptr(lse), L.ptr(valid),
+                                   L.ptr(out), L.stream()), "ce_fwd")
+        ctx.save_for_backward(x2, lab, lse, valid)
+        ctx.meta = (R, Cn, ld, ignore_index, logits.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, lab, lse, valid = ctx.saved_tensors
+        R, Cn, ld, ignore_index, shape = ctx.meta
+        gc = g.to(torch.float32).contiguous()
+        ldd = _pad8(Cn)
+        dl = torch.empty((R, ldd), dtype=x2.dtype, device=x2.device) if ldd == Cn else \
+            torch.zeros((R, ldd), dtype=x2.dtype, device=x2.device)
+        L.check(_lib().evlm_ce_bwd(L.dt(x2), L.ptr(x2), R, Cn, ld, L.ptr(lab), ignore_index, 1.0, L.ptr(lse), L.ptr(valid),
+                                   L.ptr(gc), L.ptr(dl), ldd, L.stream()), "ce_bwd")
+        d = dl[:, :Cn] if ldd != Cn else dl
+        if len(shape) > 2:
+            d = d.unflatten(0, shape[:-1])
+        return d, None, None
+
+
+def cross_entropy(logits, labels, ignore_index=-100):
+    return _CE.apply(logits, labels, ignore_index)
+
+
+class _KL(torch.autograd.Function):
+    """soft_cross_entropy(predicts, targets): KLDiv(log_softmax(s*inv_t), softmax(t*inv_t), batchmean)"""
+
+    @staticmethod
+    def forward(ctx, s, t, inv_t):
+        L.require_cuda(s, t)
+        s2, R, Cn, lds = _rows2d(s)
+        t2, Rt, Ct, ldt = _rows2d(t)
+        assert (R, Cn) == (Rt, Ct)
+        out = torch.zeros((), dtype=torch.float32, device=s.device)
+        ls = torch.empty(R, dtype=torch.float32, device=s.device)
+        lt = torch.empty(R, dtype=torch.float32, device=s.device)
+        L.check(_lib().evlm_kl_fwd(L.dt(s2), L.ptr(s2), lds, L.dt(t2), L.ptr(t2), ldt, R, Cn, inv_t, 1.0, L.ptr(ls), L.ptr(lt),
+                                   L.ptr(out), L.stream()), "kl_fwd")
+        ctx.save_for_backward(s2, t2, ls, lt)
+        ctx.meta = (R, Cn, lds, ldt, inv_t, s.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        s2, t2, ls, lt = ctx.saved_tensors
+        R, Cn, lds, ldt, inv_t, shape = ctx.meta
+        gc = g.to(torch.float32).contiguous()
+        ldd = _pad8(Cn)
+        ds = torch.empty((R, ldd), dtype=s2.dtype, device=s2.device) if ldd == Cn else \
+            torch.zeros((R, ldd), dtype=s2.dtype, device=s2.device)
+        L.check(_lib().evlm_kl_bwd(L.dt(s2), L.ptr(s2), lds, L.dt(t2), L.ptr(t2), ldt, R, Cn, inv_t, 1.0, L.ptr(ls), L.ptr(lt),
+                                   L.ptr(gc), L.ptr(ds), ldd, L.stream()), "kl_bwd")
+        d = ds[:, :Cn] if ldd != Cn else ds
+        if len(shape) > 2:
+            d = d.unflatten(0, shape[:-1])
+        return d, None, None
+
+
+def soft_cross_entropy(predicts, targets, temperature=1.0):
+    return _KL.apply(predicts, targets.detach(), 1.0 / float(temperature))
+
+
+class _LogSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        L.require_cuda(x)
+        xc = x if x.is_contiguous() else x.contiguous()
+        Cn = xc.shape[-1]
+        R = xc.numel() // Cn
+        y = torch.empty_like(xc)
+        L.check(_lib().evlm_log_softmax_fwd(L.dt(xc), L.ptr(xc), R, Cn, Cn, L.ptr(y), Cn, L.stream()), "log_softmax_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        Cn = y.shape[-1]
+        R = y.numel() // Cn
+        dyc = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty_like(y)
+        L.check(_lib().evlm_log_softmax_bwd(L.dt(y), L.ptr(y), L.ptr(dyc), R, Cn, Cn, L.ptr(dx), L.stream()), "log_softmax_bwd")
+        return dx
+
+
+def log_softmax(x):
+    return _LogSoftmax.apply(x)
+
+
+# ---------------------------------------------------------------------------------------------------
+# embeddings / gathers / activations
+# ---------------------------------------------------------------------------------------------------
+class _BertEmbed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, word, pos, typ, pad_id, dtype):
+        L.require_cuda(ids, word)
+        B, Ln = ids.shape
+        d = word.shape[1]
+        idc = ids.to(torch.int64).contiguous()
+        out = torch.empty((B, Ln, d), dtype=dtype, device=word.device)
+        L.check(_lib().evlm_bert_embed_fwd(L.dt(dtype), L.ptr(idc), B, Ln, d, L.ptr(word.detach()), L.ptr(pos.detach()),
+                                           L.ptr(typ.detach()), L.ptr(out), L.stream()), "bert_embed_fwd")
+        ctx.save_for_backward(idc)
+        ctx.meta = (word.shape, pos.shape, typ.shape, pad_id)
+        return out
+
+    @staticmethod
+    def backward(ctx, de):
+        (idc,) = ctx.saved_tensors
+        wshape, pshape, tshape, pad_id = ctx.meta
+        B, Ln = idc.shape
+        d = wshape[1]
+        dec = de if de.is_contiguous() else de.contiguous()
+        dword = torch.zeros(wshape, dtype=torch.float32, device=de.device)
+        dpos = torch.zeros(pshape, dtype=torch.float32, device=de.device)
+        dtyp = torch.zeros(tshape, dtype=torch.float32, device=de.device)
+        L.check(_lib().evlm_bert_embed_bwd(L.dt(dec), L.ptr(idc), B, Ln, d, L.ptr(dec), pad_id, L.ptr(dword), L.ptr(dpos),
+                                           L.ptr(dtyp), L.stream()), "bert_embed_bwd")
+        return None, dword, dpos, dtyp, None, None
+
+
+def bert_embed(ids, word, pos, typ, pad_id, dtype):
+    return _BertEmbed.apply(ids, word, pos, typ, pad_id, dtype)
+
+
+class _VitEmbed(torch.autograd.Function):
+    """conv patch-embed (as im2row + GEMM) + class token + position embeddings"""
+
+    @staticmethod
+    def forward(ctx, image, patch_w, cls, pos, patch, dtype):
+        L.require_cuda(image, patch_w)
+        B, Cn, R, _ = image.shape
+        d = patch_w.shape[0]
+        G = R // patch
+        Tn, K = G * G, Cn * patch * patch
+        lib = _lib()
+        img = image.to(torch.float32).contiguous()
+        patches = torch.empty((B * Tn, K), dtype=dtype, device=image.device)
+        L.check(lib.evlm_im2row(L.dt(dtype), L.ptr(img), B, Cn, R, patch, L.ptr(patches), L.stream()), "im2row")
+        W = CACHE.get((patch_w,), dtype).view(d, K)
+        tok = torch.empty((B * Tn, d), dtype=dtype, device=image.device)
+        _gemm(L.dt(dtype), patches, W, tok, B * Tn, d, K, K, K, d)
+        x = torch.empty((B, Tn + 1, d), dtype=dtype, device=image.device)
+        L.check(lib.evlm_vit_embed_fwd(L.dt(dtype), L.ptr(tok), L.ptr(cls.detach()), L.ptr(pos.detach()), B, Tn, d, L.ptr(x),
+                                       L.stream()), "vit_embed_fwd")
+        ctx.save_for_backward(patches)
+        ctx.meta = (B, Tn, d, K, patch_w.shape, pos.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (patches,) = ctx.saved_tensors
+        B, Tn, d, K, wshape, pshape = ctx.meta
+        lib = _lib()
+        dxc = dx if dx.is_contiguous() else dx.contiguous()
+        dtok = torch.empty((B * Tn, d), dtype=dxc.dtype, device=dx.device)
+        dcls = torch.zeros(d, dtype=torch.float32, device=dx.device)
+        dpos = torch.zeros(pshape, dtype=torch.float32, device=dx.device)
+        L.check(lib.evlm_vit_embed_bwd(L.dt(dxc), L.ptr(dxc), B, Tn, d, L.ptr(dtok), L.ptr(dcls), L.ptr(dpos), L.stream()),
+                "vit_embed_bwd")
+        dW = torch.empty((d, K), dtype=torch.float32, device=dx.device)
+        _gemm(L.dt(dxc), dtok, patches, dW, d, K, B * Tn, d, K, K, p_trans=1, q_trans=1, c_f32=1)
+        return None, dW.view(wshape), dcls, dpos, None, None
+
+
+def vit_embed(image, patch_w, cls, pos, patch, dtype):
+    return _VitEmbed.apply(image, patch_w, cls, pos, patch, dtype)
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pos):
+        L.require_cuda(x, pos)
+        B, Ln, d = x.shape
+        M = pos.shape[1]
+        xc = x if x.is_contiguous() else x.contiguous()
+        pc = pos.to(torch.int64).contiguous()
+        out = torch.empty((B, M, d), dtype=x.dtype, device=x.device)
+        L.check(_lib().evlm_gather_rows_fwd(L.dt(xc), L.ptr(xc), L.ptr(pc), B, Ln, M, d, L.ptr(out), L.stream()), "gather_fwd")
+        ctx.save_for_backward(pc)
+        ctx.meta = (B, Ln, M, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (pc,) = ctx.saved_tensors
+        B, Ln, M, d = ctx.meta
+        dc = dout if dout.is_contiguous() else dout.contiguous()
+        dx = torch.empty((B, Ln, d), dtype=dout.dtype, device=dout.device)
+        L.check(_lib().evlm_gather_rows_bwd(L.dt(dc), L.ptr(dc), L.ptr(pc), B, Ln, M, d, L.ptr(dx), L.stream()), "gather_bwd")
+        return dx, None
+
+
+def gather_rows(x, pos):
+    return _GatherRows.apply(x, pos)
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        L.require_cuda(x)
+        xc = x if x.is_contiguous() else x.contiguous()
+        y = torch.empty_like(xc)
+        L.check(_lib().evlm_act_fwd(L.dt(xc), L.ptr(xc), xc.numel(), act, L.ptr(y), L.stream()), "act_fwd")
+        ctx.save_for_backward(xc)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        d = xc.shape[-1]
+        rows = xc.numel() // d
+        dyc = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty_like(xc)
+        L.check(_lib().evlm_gated_act_bwd(L.dt(xc), L.ptr(dyc), L.ptr(xc), None, rows, d, d, ctx.act, L.GATE_POST, L.ptr(dx),
+                                          None, L.stream()), "act_bwd")
+        return dx, None
+
+
+def gelu(x):
+    return _Act.apply(x, L.ACT_GELU)
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        L.require_cuda(x)
+        x2, rows, d, ld = _as2d(x)
+        y = torch.empty((rows, d), dtype=x2.dtype, device=x.device)
+        inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+        L.check(_lib().evlm_l2norm_fwd(L.dt(x2), L.ptr(x2), rows, d, ld, eps, L.ptr(y), L.ptr(inv), L.stream()), "l2norm_fwd")
+        ctx.save_for_backward(y, inv)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        rows, d = y.shape
+        dyc = dy.reshape(rows, d)
+        if not dyc.is_contiguous():
+            dyc = dyc.contiguous()
+        dx = torch.empty_like(y)
+        L.check(_lib().evlm_l2norm_bwd(L.dt(y), L.ptr(y), L.ptr(dyc), L.ptr(inv), rows, d, L.ptr(dx), L.stream()), "l2norm_bwd")
+        return dx.view(ctx.shape), None
+
+
+def l2_normalize(x, eps=1e-12):
+    return _L2Norm.apply(x, eps)
+
+
+def cast(x, dtype):
+    """differentiable dtype cast through the HIP cast kernel"""
+    if x.dtype == dtype:
+        return x
+    return _Cast.apply(x, dtype)
+
+
+class _Cast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        L.require_cuda(x)
+        xc = x if x.is_contiguous() else x.contiguous()
+        y = torch.empty(xc.shape, dtype=dtype, device=x.device)
+        L.check(_lib().evlm_cast(L.dt(xc), L.ptr(xc), L.dt(dtype), L.ptr(y), xc.numel(), L.stream()), "cast")
+        ctx.src = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dyc = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty(dyc.shape, dtype=ctx.src, device=dy.device)
+        L.check(_lib().evlm_cast(L.dt(dyc), L.ptr(dyc), L.dt(ctx.src), L.ptr(dx), dyc.numel(), L.stream()), "cast")
+        return dx, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# L0 gates
+# ---------------------------------------------------------------------------------------------------
+class _L0Sample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loga, eps, temperature):
+        L.require_cuda(loga, eps)
+        la = loga.detach().contiguous()
+        ep = eps.to(torch.float32).contiguous()
+        z = torch.empty_like(la)
+        L.check(_lib().evlm_l0_sample_fwd(L.ptr(la), L.ptr(ep), la.numel(), temperature, L.ptr(z), L.stream()), "l0_sample_fwd")
+        ctx.save_for_backward(la, ep)
+        ctx.t = temperature
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        la, ep = ctx.saved_tensors
+        dzc = dz.to(torch.float32).contiguous()
+        dl = torch.empty_like(la)
+        L.check(_lib().evlm_l0_sample_bwd(L.ptr(la), L.ptr(ep), L.ptr(dzc), la.numel(), ctx.t, L.ptr(dl), L.stream()), "l0_sample_bwd")
+        return dl, None, None
+
+
+def l0_sample(loga, eps, temperature):
+    return _L0Sample.apply(loga, eps, float(temperature))
+
+
+def l0_deterministic(loga, temperature, magical_number):
+    L.require_cuda(loga)
+    la = loga.detach().to(torch.float32).contiguous()
+    rows, size = la.shape
+    z = torch.empty_like(la)
+    L.check(_lib().evlm_l0_deterministic(L.ptr(la), rows, size, float(temperature), float(magical_number), L.ptr(z), L.stream()),
+            "l0_deterministic")
+    return z
+
+
+def default_scale(dh):
+    return 1.0 / math.sqrt(dh)

@@ -1,0 +1,231 @@
+/*
+ * evlm_hip.h — C ABI of libevlm_hip.so: the MI355X (gfx950) kernels behind the EfficientVLM
+ * distillation hot path.
+ *
+ * The reference (swaggy-TN/EfficientVLM) has no native boundary: its hot path issues stock ATen ops
+ * from Python nn.Modules.  This header is the boundary a maintainer would bind to
+ * replace those op sequences; every entry point cites the reference lines whose arithmetic it replaces.
+ * Paths are relative to the reference checkout.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never synchronises,
+ *     never allocates; workspaces are caller-provided;
+ *   - dtype: EVLM_F32 (exact fp32, fp32-input MFMA) or EVLM_BF16 (bf16 storage, fp32 accumulate);
+ *   - returns 0 on success, non-zero on error; evlm_last_error() gives the message (thread-local).
+ *   - row-major tensors; `ld*` = leading dimension in ELEMENTS.  For 16-byte vector access every
+ *     ld must be a multiple of 8 (bf16) / 4 (f32) and padding columns inside ld must hold finite
+ *     values (callers keep them zero).
+ */
+#ifndef EVLM_HIP_H
+#define EVLM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { EVLM_F32 = 0, EVLM_BF16 = 1 };
+enum { EVLM_ACT_NONE = 0, EVLM_ACT_GELU = 1, EVLM_ACT_QUICK_GELU = 2 };
+enum { EVLM_GATE_PRE_ACT = 0, EVLM_GATE_POST_ACT = 1 };
+
+const char* evlm_last_error(void);
+int evlm_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:   C[i,j] = epi( alpha * sum_k P(i,k) * Q(j,k) )      i<I, j<J
+ *   P is stored [I][K] (p_trans=0, K contiguous) or [K][I] (p_trans=1); Q likewise with J.
+ *   epi(v):  v += bias[j];  preact[i,j] = v (optional store);
+ *            gate_pos==PRE : v *= gate[j];  v = act(v);   gate_pos==POST: v = act(v) * gate[j]
+ *            dact != 0     : v *= act'(aux[i,j])           (backward of the activation, gate==NULL)
+ *            v += residual[i,j]
+ *   C is dtype or f32 (c_f32=1); preact/aux/residual have dtype `dtype` and leading dimension ldx.
+ * Replaces: every nn.Linear on the path — CLIPAttention q/k/v/out_proj (efficient_models/eff_vit.py:134-199),
+ *   CLIPMLP fc1 (*mlp_z) quick_gelu fc2 (eff_vit.py:214-220), BertSelfAttention query/key/value
+ *   (eff_bert.py:277-296), BertSelfOutput.dense (:375), BertIntermediate gelu (:445-447) * mlp_z (:553-557),
+ *   BertOutput.dense (:459), the tied MLM decoder (:744), patch-embed conv as im2row GEMM (eff_vit.py:444),
+ *   build_mlp / vision_proj / text_proj (efficient_models/xvlm.py:77-83,230-231) — and their autograd
+ *   backward products dX = dY*W (p_trans=0,q_trans=1) and dW = dY^T*X (p_trans=1,q_trans=1).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int dtype;            /* element type of P, Q, preact, aux, residual */
+  int c_f32;            /* 1: C is f32 regardless of dtype */
+  int p_trans, q_trans;
+  int I, J, K;
+  int ldp, ldq, ldc, ldx;
+  const void* P;
+  const void* Q;
+  void* C;
+  const float* bias;    /* [J] f32 or NULL */
+  const float* gate;    /* [J] f32 or NULL */
+  void* preact;         /* [I,J] or NULL */
+  const void* aux;      /* [I,J] or NULL (with dact) */
+  const void* residual; /* [I,J] or NULL */
+  float alpha;
+  int act;              /* EVLM_ACT_* */
+  int gate_pos;         /* EVLM_GATE_* */
+  int dact;             /* EVLM_ACT_* : multiply by act'(aux) */
+} evlm_gemm_args;
+
+int evlm_gemm(const evlm_gemm_args* args, void* stream);
+
+/* out[j] (+)= sum_i X[i,j]   (f32 out; bias gradients = column sums of dY).  out must be zeroed by the caller
+ * unless it should accumulate.  Replaces the bias branch of Linear backward. */
+int evlm_colsum(int dtype, const void* X, int I, int J, int ldx, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension (two-pass mean/variance in f32, like ATen).
+ * Replaces nn.LayerNorm: eff_vit.py layer_norm1/2, pre_layrnorm, post_layernorm (eps 1e-5);
+ *   eff_bert.py BertEmbeddings.LayerNorm (:212), BertSelfOutput (:380), BertOutput (:461),
+ *   BertPredictionHeadTransform (:725) (eps 1e-12); build_mlp LayerNorm (xvlm.py:80).
+ * mean/rstd: [rows] f32, saved for backward (may be NULL in no-grad mode).
+ * ---------------------------------------------------------------------------------------------- */
+int evlm_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, float eps,
+                       int rows, int d, void* y, float* mean, float* rstd, void* stream);
+/* dx = LN backward; dgamma/dbeta [d] f32 are ACCUMULATED (caller zeroes). */
+int evlm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                       const float* rstd, int rows, int d, void* dx, float* dgamma, float* dbeta, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-head attention core with the probability map as an OUTPUT (the KD losses consume it).
+ *   S = scale * Q K^T + mask[b, k] ;  P = softmax(S) ;  O = (P V) * head_gate[h]
+ *   Q: [B, Lq, H, dh] with row stride ldq (so packed QKV buffers work), K/V: [Bkv, Lk, H, dh] (ldk, ldv);
+ *   kv_index (int32 [B] or NULL) maps query batch b to its K/V batch row (hard-negative reuse);
+ *   mask: additive f32 [B, Lk] or NULL (the reference's (1-m)*-10000, eff_bert.py:1012, eff_vit.py:339);
+ *   P: [B, H, Lq, Lk] of p_dtype (EVLM_F32 or EVLM_BF16);  O: [B, Lq, H*dh] (ldo).
+ * Replaces CLIPAttention bmm-softmax-bmm (eff_vit.py:144-195) and BertSelfAttention matmul /sqrt(d)
+ *   +mask softmax matmul *= head_z (eff_bert.py:317-355), self- and cross-attention alike.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int dtype, p_dtype;
+  int B, H, Lq, Lk, dh;
+  int ldq, ldk, ldv, ldo;       /* row strides in elements */
+  const void* Q; const void* K; const void* V;
+  const int32_t* kv_index;
+  const float* mask;
+  const float* head_gate;       /* [H] f32 or NULL */
+  float scale;
+  void* O; void* P;
+} evlm_attn_fwd_args;
+int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream);
+
+/* backward: given dO and (optionally) an external gradient dP_ext on the probability map (from the
+ * attention-map KD loss), produce dQ, dK, dV (+ dgate[H] accumulated, f32).  dS ([B,H,Lq,Lk], dtype) is a
+ * caller-provided workspace.  With kv_index, dK/dV rows are ACCUMULATED in f32 buffers dK32/dV32
+ * ([Bkv,Lk,H,dh], caller-zeroed) instead of dK/dV. */
+typedef struct {
+  int dtype, p_dtype;
+  int B, H, Lq, Lk, dh;
+  int ldq, ldk, ldv, ldo;
+  int lddq, lddk, lddv;
+  const void* Q; const void* K; const void* V; const void* P;
+  const void* dO; const void* dP_ext;
+  const int32_t* kv_index;
+  const float* head_gate;
+  float scale;
+  void* dS;
+  void* dQ; void* dK; void* dV;
+  float* dgate;
+} evlm_attn_bwd_args;
+int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Distillation / task losses.  Scalars are f32 DEVICE words; forward ACCUMULATES weight*term into
+ * *loss so one word can collect a whole loss mix without host syncs.  `gout` is a device f32 word
+ * holding dL/d(term-sum) for the backward kernels.
+ * ---------------------------------------------------------------------------------------------- */
+/* *loss += weight * sum((a-b)^2) / n      — MSELoss() of get_kd_loss (GeneralDistill.py:60-82); the
+ * attention-map variant passes weight = last-dim size (":69 * student_att.shape[-1]"). */
+int evlm_mse_fwd(int dtype_a, const void* a, int dtype_b, const void* b, int64_t n, float weight,
+                 float* loss, void* stream);
+/* grad_a = (*gout) * weight * 2 (a-b) / n */
+int evlm_mse_bwd(int dtype_a, const void* a, int dtype_b, const void* b, int64_t n, float weight,
+                 const float* gout, void* grad_a, void* stream);
+
+/* hard-label cross entropy, mean over rows with label != ignore_index (F.cross_entropy: MLM loss
+ * eff_bert.py:1697-1699, ITM xvlm.py:484, ITC :399-400).  logits [R,C] (ld), labels int64.
+ * lse [2R] f32 workspace (lse, then per-row losses) saved for backward; *loss += weight * mean;
+ * valid_count: device int32 word (written). */
+int evlm_ce_fwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
+                float weight, float* lse, int32_t* valid_count, float* loss, void* stream);
+int evlm_ce_bwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
+                float weight, const float* lse, const int32_t* valid_count, const float* gout,
+                void* dlogits, int ldd, void* stream);
+
+/* soft_cross_entropy (GeneralDistill.py:84-89): KLDiv(log_softmax(s*inv_t), softmax(t*inv_t), batchmean)
+ * over R rows of C classes.  lse_s/lse_t [R] f32 saved for backward.  d s = (p_s - p_t) * inv_t / R. */
+int evlm_kl_fwd(int dtype_s, const void* s, int lds, int dtype_t, const void* t, int ldt, int R, int C,
+                float inv_t, float weight, float* lse_s, float* lse_t, float* loss, void* stream);
+int evlm_kl_bwd(int dtype_s, const void* s, int lds, int dtype_t, const void* t, int ldt, int R, int C,
+                float inv_t, float weight, const float* lse_s, const float* lse_t, const float* gout,
+                void* ds, int ldds, void* stream);
+
+/* row-wise log_softmax (for the soft-label ITC branch, xvlm.py:411-414) and its backward */
+int evlm_log_softmax_fwd(int dtype, const void* x, int R, int C, int ld, void* y, int ldy, void* stream);
+int evlm_log_softmax_bwd(int dtype, const void* y, const void* dy, int R, int C, int ld, void* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embeddings and data movement
+ * ---------------------------------------------------------------------------------------------- */
+/* e[b,l,:] = word[ids[b,l]] + type0 + pos[l]   (BertEmbeddings before LayerNorm, eff_bert.py:203-211) */
+int evlm_bert_embed_fwd(int dtype, const int64_t* ids, int B, int L, int d, const float* word,
+                        const float* pos, const float* type0, void* out, void* stream);
+/* scatter-add of de into dword (skipping pad id, nn.Embedding padding_idx eff_bert.py:171), dpos, dtype0 (f32, accumulated) */
+int evlm_bert_embed_bwd(int dtype, const int64_t* ids, int B, int L, int d, const void* de, int pad_id,
+                        float* dword, float* dpos, float* dtype0, void* stream);
+/* patches[b*G*G + gy*G + gx, c*p*p + py*p + px] = image[b,c,gy*p+py,gx*p+px]  (Conv2d k=s=p as a GEMM, eff_vit.py:444) */
+int evlm_im2row(int dtype, const float* image, int B, int C, int R, int p, void* patches, void* stream);
+/* x[b,0,:] = cls + pos[0];  x[b,1+t,:] = tok[b,t,:] + pos[1+t]   (eff_vit.py:447-449) */
+int evlm_vit_embed_fwd(int dtype, const void* tok, const float* cls, const float* pos, int B, int T, int d,
+                       void* x, void* stream);
+/* dtok = dx[:,1:,:]; dcls += sum_b dx[b,0]; dpos += sum_b dx[b]  (f32 accumulated) */
+int evlm_vit_embed_bwd(int dtype, const void* dx, int B, int T, int d, void* dtok, float* dcls, float* dpos,
+                       void* stream);
+/* out[b,m,:] = x[b,pos[b,m],:]   (gather_seq_out_by_pos, eff_bert.py:1631-1632) and its scatter-add backward */
+int evlm_gather_rows_fwd(int dtype, const void* x, const int64_t* pos, int B, int L, int M, int d, void* out,
+                         void* stream);
+int evlm_gather_rows_bwd(int dtype, const void* dout, const int64_t* pos, int B, int L, int M, int d, void* dx,
+                         void* stream);
+/* y = x / max(||x||_2, eps) per row (F.normalize(dim=-1) of get_features, efficient_models/xvlm.py:375-382);
+ * x rows have stride ldx (the CLS-token slice), y is dense [rows,d]; inv_norm [rows] f32 saved for backward. */
+int evlm_l2norm_fwd(int dtype, const void* x, int rows, int d, int ldx, float eps, void* y, float* inv_norm, void* stream);
+int evlm_l2norm_bwd(int dtype, const void* y, const void* dy, const float* inv_norm, int rows, int d, void* dx, void* stream);
+/* dst = cast(src) between f32 and bf16; n elements.  (master f32 weights -> bf16 compute copies, grads back) */
+int evlm_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
+/* y[i,j] = a[i,j] * dact(h[i,j]) * gate-aware backward of the gated activations (used when gates are present):
+ *   PRE  (ViT,  eff_vit.py:216-218):  a = act(h*z):  dh = da*act'(h z)*z ;  dz[j] += sum_i da*act'(h z)*h
+ *   POST (BERT, eff_bert.py:553-557): a = act(h)*z:  dh = da*act'(h)*z   ;  dz[j] += sum_i da*act(h)      */
+/* y = act(x), n elements (the GELU of build_mlp, xvlm.py:81, which follows a LayerNorm and so cannot ride a GEMM epilogue) */
+int evlm_act_fwd(int dtype, const void* x, int64_t n, int act, void* y, void* stream);
+/* gate == NULL (then dgate == NULL): plain activation backward dh = da * act'(h). */
+int evlm_gated_act_bwd(int dtype, const void* da, const void* h, const float* gate, int I, int J, int ld,
+                       int act, int gate_pos, void* dh, float* dgate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Hard-concrete L0 gates (efficient_models/xvlm_l0_module.py)
+ * ---------------------------------------------------------------------------------------------- */
+/* z = hardtanh(sigmoid((log u - log(1-u) + loga)/T)*1.2 - 0.1, 0, 1)   (:180-182,246-250); all f32 */
+int evlm_l0_sample_fwd(const float* loga, const float* eps, int64_t n, float temperature, float* z, void* stream);
+int evlm_l0_sample_bwd(const float* loga, const float* eps, const float* dz, int64_t n, float temperature,
+                       float* dloga, void* stream);
+/* eval masks (:253-271): per row of `size` gates, k = round(size - sum(1-cdf_qz(0))) smallest
+ * sigmoid(loga/T*magic) are set to 0, the rest 1.  Selection order = ascending (value, index). */
+int evlm_l0_deterministic(const float* loga, int rows, int size, float temperature, float magical_number,
+                          float* z, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser-side helpers (next-tier row §8f-1; kept minimal here)
+ * ---------------------------------------------------------------------------------------------- */
+/* *out += sum(x^2) over n f32 values (global grad norm, apex_ddp_accelerator.py:99-102) */
+int evlm_sumsq(const float* x, int64_t n, float* out, void* stream);
+/* HF-AdamW step (optim.py:67, transformers AdamW: Adam update then p -= lr*wd*p), with the gradient
+ * pre-scaled by min(1, max_norm/ (sqrt(*gnorm_sq)+1e-6)); also refreshes the bf16 compute copy. */
+int evlm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, float bias_c1, float bias_c2, const float* gnorm_sq,
+                    float max_norm, void* p_bf16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVLM_HIP_H */

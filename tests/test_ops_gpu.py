@@ -1,0 +1,369 @@
+"""Kernel-level parity: every HIP op (through the C ABI via efficientvlm_amd.ops) against a plain PyTorch fp32
+reference of the same arithmetic.  fp32 path: <= 1e-4 relative (north_star tolerance); bf16 path: inputs are rounded
+to bf16 first and the result must be within 2^-7 relative of the fp32 reference of those rounded inputs.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    from efficientvlm_amd import ops as o
+    return o
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def tol(dtype):
+    return 1e-4 if dtype == torch.float32 else 1.2e-2
+
+
+def rnd(shape, dtype, g, scale=1.0):
+    x = torch.randn(shape, generator=g) * scale
+    return x.to(dtype).to(DEV)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("pt,qt", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("I,J,K", [(200, 136, 96), (128, 256, 128), (77, 1002, 64), (300, 24, 200)])
+def test_gemm_layouts(dtype, pt, qt, I, J, K):
+    o = ops()
+    from efficientvlm_amd import _lib as L
+    g = torch.Generator().manual_seed(I * 7 + J * 3 + K + pt * 2 + qt)
+    p8 = lambda n: (n + 7) // 8 * 8
+    # operands with padded leading dimensions (pads are zero)
+    Pm = torch.zeros((K, p8(I)) if pt else (I, p8(K)), dtype=dtype, device=DEV)
+    Qm = torch.zeros((K, p8(J)) if qt else (J, p8(K)), dtype=dtype, device=DEV)
+    Pv = Pm[:, :I] if pt else Pm[:, :K]
+    Qv = Qm[:, :J] if qt else Qm[:, :K]
+    Pv.copy_(rnd(Pv.shape, dtype, g))
+    Qv.copy_(rnd(Qv.shape, dtype, g))
+    Cm = torch.zeros((I, p8(J)), dtype=dtype, device=DEV)
+    o._gemm(L.dt(dtype), Pm, Qm, Cm, I, J, K, Pm.stride(0), Qm.stride(0), Cm.stride(0), p_trans=pt, q_trans=qt)
+    A = Pv.float().t() if pt else Pv.float()
+    Bm = Qv.float().t() if qt else Qv.float()
+    ref = A @ Bm.t()
+    assert rel_err(Cm[:, :J].float(), ref) < tol(dtype)
+    assert float(Cm[:, J:].abs().sum()) == 0.0     # pad columns untouched
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(dtype):
+    o = ops()
+    from efficientvlm_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    I, J, K = 150, 264, 128
+    X, W = rnd((I, K), dtype, g), rnd((J, K), dtype, g, 0.2)
+    bias, gate = rnd((J,), torch.float32, g), torch.rand(J, generator=g).to(DEV)
+    R = rnd((I, J), dtype, g)
+    lin = X.float() @ W.float().t() + bias
+    for act, fn in ((L.ACT_GELU, F.gelu), (L.ACT_QUICK_GELU, lambda t: t * torch.sigmoid(1.702 * t))):
+        for gp in (L.GATE_PRE, L.GATE_POST):
+            Cm = torch.empty((I, J), dtype=dtype, device=DEV)
+            H = torch.empty((I, J), dtype=dtype, device=DEV)
+            o._gemm(L.dt(dtype), X, W, Cm, I, J, K, K, K, J, bias=bias, gate=gate, preact=H, residual=R, ldx=J, act=act, gate_pos=gp)
+            ref = (fn(lin * gate) if gp == L.GATE_PRE else fn(lin) * gate) + R.float()
+            assert rel_err(Cm.float(), ref) < tol(dtype), (act, gp)
+            assert rel_err(H.float(), lin) < tol(dtype)
+    # activation backward fused in the epilogue:  C = (X W^T) .* act'(aux)
+    aux = rnd((I, J), dtype, g)
+    for act in (L.ACT_GELU, L.ACT_QUICK_GELU):
+        Cm = torch.empty((I, J), dtype=dtype, device=DEV)
+        o._gemm(L.dt(dtype), X, W, Cm, I, J, K, K, K, J, aux=aux, ldx=J, dact=act)
+        a32 = aux.float().requires_grad_(True)
+        y = F.gelu(a32) if act == L.ACT_GELU else a32 * torch.sigmoid(1.702 * a32)
+        (dact,) = torch.autograd.grad(y.sum(), a32)
+        assert rel_err(Cm.float(), (X.float() @ W.float().t()) * dact) < tol(dtype)
+    # f32 output from bf16 operands
+    if dtype == torch.bfloat16:
+        Cf = torch.empty((I, J), dtype=torch.float32, device=DEV)
+        o._gemm(L.dt(dtype), X, W, Cf, I, J, K, K, K, J, c_f32=1)
+        assert rel_err(Cf, X.float() @ W.float().t()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_and_packed_autograd(dtype):
+    o = ops()
+    g = torch.Generator().manual_seed(11)
+    B, Ls, K, N = 3, 37, 64, 72
+    x = rnd((B, Ls, K), dtype, g).requires_grad_(True)
+    ws = [torch.nn.Parameter(rnd((N, K), torch.float32, g, 0.2)) for _ in range(3)]
+    bs = [torch.nn.Parameter(rnd((N,), torch.float32, g, 0.2)) for _ in range(3)]
+    y = o.linear_packed(x, ws, bs)
+    assert y.shape == (B, Ls, 3 * N)
+    go = rnd(y.shape, dtype, g)
+    y.backward(go)
+    xr = x.detach().float().requires_grad_(True)
+    wr = [w.detach().to(dtype).float().requires_grad_(True) for w in ws]
+    br = [b.detach().clone().requires_grad_(True) for b in bs]
+    yr = torch.cat([F.linear(xr, w, b) for w, b in zip(wr, br)], dim=-1)
+    yr.backward(go.float())
+    assert rel_err(y.float(), yr) < tol(dtype)
+    assert rel_err(x.grad.float(), xr.grad) < tol(dtype)
+    for w, w2, b, b2 in zip(ws, wr, bs, br):
+        assert rel_err(w.grad, w2.grad) < tol(dtype)
+        assert rel_err(b.grad, b2.grad) < tol(dtype)
+    # CLS-slice input (strided rows), odd output width (padded ld), residual
+    w = torch.nn.Parameter(rnd((10, K), torch.float32, g, 0.3))
+    b = torch.nn.Parameter(rnd((10,), torch.float32, g))
+    xs = x.detach()[:, 0, :]
+    y2 = o.linear(xs, w, b)
+    assert rel_err(y2.float(), F.linear(xs.float(), w.detach().to(dtype).float(), b.detach())) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act_name,gate_pos", [("quick_gelu", 0), ("gelu", 1)])
+@pytest.mark.parametrize("with_gate", [False, True])
+def test_mlp_block(dtype, act_name, gate_pos, with_gate):
+    o = ops()
+    from efficientvlm_amd import _lib as L
+    g = torch.Generator().manual_seed(13)
+    M, K, Fh = 210, 64, 136
+    x = rnd((2, M // 2, K), dtype, g).requires_grad_(True)
+    w1 = torch.nn.Parameter(rnd((Fh, K), torch.float32, g, 0.3)); b1 = torch.nn.Parameter(rnd((Fh,), torch.float32, g, 0.3))
+    w2 = torch.nn.Parameter(rnd((K, Fh), torch.float32, g, 0.3)); b2 = torch.nn.Parameter(rnd((K,), torch.float32, g, 0.3))
+    gate = (torch.rand(1, 1, Fh, generator=g).to(DEV) * 1.2).clamp(0, 1).requires_grad_(True) if with_gate else None
+    act = L.ACT_QUICK_GELU if act_name == "quick_gelu" else L.ACT_GELU
+    y = o.mlp(x, w1, b1, w2, b2, act, gate=gate, gate_pos=gate_pos, residual=x)
+    go = rnd(y.shape, dtype, g)
+    y.backward(go)
+    fn = (lambda t: t * torch.sigmoid(1.702 * t)) if act_name == "quick_gelu" else F.gelu
+    xr = x.detach().float().requires_grad_(True)
+    ps = [p.detach().to(dtype).float().requires_grad_(True) if p.dim() == 2 else p.detach().clone().requires_grad_(True)
+          for p in (w1, b1, w2, b2)]
+    gr = gate.detach().clone().requires_grad_(True) if with_gate else None
+    h = F.linear(xr, ps[0], ps[1])
+    if dtype == torch.bfloat16:   # the kernel rounds the hidden activation to bf16 between the two GEMMs
+        pass
+    if gate_pos == 0:
+        a = fn(h * gr) if with_gate else fn(h)
+    else:
+        a = fn(h) * gr if with_gate else fn(h)
+    yr = F.linear(a, ps[2], ps[3]) + xr
+    yr.backward(go.float())
+    t = tol(dtype) * (3 if dtype == torch.bfloat16 else 1)
+    assert rel_err(y.float(), yr) < t
+    assert rel_err(x.grad.float(), xr.grad) < t
+    for p, pr in zip((w1, b1, w2, b2), ps):
+        assert rel_err(p.grad, pr.grad) < t
+    if with_gate:
+        assert rel_err(gate.grad, gr.grad) < t
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("d,eps", [(64, 1e-12), (768, 1e-5), (1536, 1e-5)])
+def test_layernorm(dtype, d, eps):
+    o = ops()
+    g = torch.Generator().manual_seed(17)
+    x = (rnd((5, 41, d), dtype, g) * 2 + 0.5).requires_grad_(True)
+    gm = torch.nn.Parameter(1 + 0.1 * rnd((d,), torch.float32, g)); bt = torch.nn.Parameter(rnd((d,), torch.float32, g))
+    y = o.layer_norm(x, gm, bt, eps)
+    go = rnd(y.shape, dtype, g)
+    y.backward(go)
+    xr = x.detach().float().requires_grad_(True)
+    g2, b2 = gm.detach().clone().requires_grad_(True), bt.detach().clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (d,), g2, b2, eps)
+    yr.backward(go.float())
+    assert rel_err(y.float(), yr) < tol(dtype)
+    assert rel_err(x.grad.float(), xr.grad) < tol(dtype) * 2
+    assert rel_err(gm.grad, g2.grad) < tol(dtype) * 2
+    assert rel_err(bt.grad, b2.grad) < tol(dtype) * 2
+
+
+def _ref_attention(q, k, v, mask, gate, scale):
+    s = q @ k.transpose(-1, -2) * scale
+    if mask is not None:
+        s = s + mask[:, None, None, :]
+    p = torch.softmax(s, -1)
+    o_ = p @ v
+    if gate is not None:
+        o_ = o_ * gate.view(1, -1, 1, 1)
+    return o_, p
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,L,dh", [(2, 4, 5, 16), (2, 12, 197, 64), (3, 12, 30, 64), (1, 2, 70, 32)])
+def test_self_attention(dtype, B, H, L, dh):
+    o = ops()
+    g = torch.Generator().manual_seed(19 + L)
+    d = H * dh
+    qkv = rnd((B, L, 3 * d), dtype, g).requires_grad_(True)
+    mask = torch.zeros(B, L)
+    mask[0, L - 2:] = -10000.0
+    mask = mask.to(DEV)
+    gate = torch.rand(1, H, 1, 1, generator=g).to(DEV).requires_grad_(True)
+    scale = dh ** -0.5
+    O, P = o.self_attention(qkv, H, dh, scale, mask=mask, gate=gate)
+    gO, gP = rnd(O.shape, dtype, g), rnd(P.shape, dtype, g, 0.1)
+    (O.float() * gO.float()).sum().add((P.float() * gP.float()).sum()).backward()
+    xr = qkv.detach().float().requires_grad_(True)
+    gr = gate.detach().clone().requires_grad_(True)
+    sp = lambda t: t.view(B, L, H, dh).transpose(1, 2)
+    q, k, v = xr[..., :d], xr[..., d:2 * d], xr[..., 2 * d:]
+    Or, Pr = _ref_attention(sp(q), sp(k), sp(v), mask, gr, scale)
+    Or = Or.transpose(1, 2).reshape(B, L, d)
+    ((Or * gO.float()).sum() + (Pr * gP.float()).sum()).backward()
+    t = tol(dtype)
+    assert rel_err(P.float(), Pr) < t
+    assert rel_err(O.float(), Or) < t * 2
+    assert rel_err(qkv.grad.float(), xr.grad) < t * 4
+    assert rel_err(gate.grad, gr.grad) < t * 4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Lq,Lk,dh", [(2, 4, 8, 5, 16), (3, 12, 30, 197, 64)])
+def test_cross_attention(dtype, B, H, Lq, Lk, dh):
+    o = ops()
+    g = torch.Generator().manual_seed(23)
+    d = H * dh
+    q = rnd((B, Lq, d), dtype, g).requires_grad_(True)
+    kv = rnd((B, Lk, 2 * d), dtype, g).requires_grad_(True)
+    scale = 1.0 / math.sqrt(dh)
+    O, P = o.cross_attention(q, kv, H, dh, scale)
+    gO = rnd(O.shape, dtype, g)
+    (O.float() * gO.float()).sum().backward()
+    qr, kvr = q.detach().float().requires_grad_(True), kv.detach().float().requires_grad_(True)
+    sp = lambda t, Ln: t.reshape(B, Ln, H, dh).transpose(1, 2)
+    Or, Pr = _ref_attention(sp(qr, Lq), sp(kvr[..., :d], Lk), sp(kvr[..., d:], Lk), None, None, scale)
+    Or = Or.transpose(1, 2).reshape(B, Lq, d)
+    (Or * gO.float()).sum().backward()
+    t = tol(dtype)
+    assert rel_err(P.float(), Pr) < t
+    assert rel_err(O.float(), Or) < t * 2
+    assert rel_err(q.grad.float(), qr.grad) < t * 4
+    assert rel_err(kv.grad.float(), kvr.grad) < t * 4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_losses(dtype):
+    o = ops()
+    g = torch.Generator().manual_seed(29)
+    a = rnd((3, 7, 5, 11), dtype, g).requires_grad_(True)
+    b = rnd((3, 7, 5, 11), dtype, g)
+    l = o.mse(a, b, weight=11.0)
+    l.backward()
+    ar = a.detach().float().requires_grad_(True)
+    lr = F.mse_loss(ar, b.float()) * 11.0
+    lr.backward()
+    assert rel_err(l, lr) < 1e-5 and rel_err(a.grad.float(), ar.grad) < tol(dtype)
+    # hard-label CE with ignored rows, odd class count (padded gradient buffer)
+    R, Cn = 24, 1003
+    logits = rnd((4, 6, Cn), dtype, g, 2.0).requires_grad_(True)
+    labels = torch.randint(0, Cn, (4, 6), generator=g)
+    labels[0, 1] = -100; labels[3, 5] = -100
+    labels = labels.to(DEV)
+    l = o.cross_entropy(logits.view(-1, Cn), labels.view(-1))
+    (l * 1.7).backward()
+    lg = logits.detach().float().requires_grad_(True)
+    lr = F.cross_entropy(lg.view(-1, Cn), labels.view(-1), ignore_index=-100)
+    (lr * 1.7).backward()
+    assert rel_err(l, lr) < 1e-5 and rel_err(logits.grad.float(), lg.grad) < tol(dtype)
+    # KL (soft_cross_entropy) with temperature
+    s = rnd((4, 6, Cn), dtype, g, 2.0).requires_grad_(True)
+    t_ = rnd((4, 6, Cn), dtype, g, 2.0)
+    l = o.soft_cross_entropy(s, t_, temperature=2.0)
+    l.backward()
+    sr = s.detach().float().requires_grad_(True)
+    lr = F.kl_div(F.log_softmax(sr / 2.0, -1).view(-1, Cn), F.softmax(t_.float() / 2.0, -1).view(-1, Cn), reduction="batchmean")
+    lr.backward()
+    assert rel_err(l, lr) < 2e-5 and rel_err(s.grad.float(), sr.grad) < tol(dtype)
+    # log_softmax
+    x = rnd((9, 33), dtype, g, 3.0).requires_grad_(True)
+    y = o.log_softmax(x)
+    gy = rnd(y.shape, dtype, g)
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    yr = F.log_softmax(xr, -1)
+    yr.backward(gy.float())
+    assert rel_err(y.float(), yr) < tol(dtype) and rel_err(x.grad.float(), xr.grad) < tol(dtype) * 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embeddings_and_movement(dtype):
+    o = ops()
+    g = torch.Generator().manual_seed(31)
+    V, Pm, d, B, Ls = 50, 20, 64, 3, 9
+    word = torch.nn.Parameter(rnd((V, d), torch.float32, g)); pos = torch.nn.Parameter(rnd((Pm, d), torch.float32, g))
+    typ = torch.nn.Parameter(rnd((2, d), torch.float32, g))
+    ids = torch.randint(1, V, (B, Ls), generator=g); ids[1, 6:] = 0
+    ids = ids.to(DEV)
+    e = o.bert_embed(ids, word, pos, typ, 0, dtype)
+    ge = rnd(e.shape, dtype, g)
+    e.backward(ge)
+    wr, pr, tr = (p.detach().clone().requires_grad_(True) for p in (word, pos, typ))
+    er = F.embedding(ids, wr, padding_idx=0) + tr[0] + pr[:Ls][None]
+    er.backward(ge.float())
+    assert rel_err(e.float(), er) < tol(dtype)
+    for p, p2 in ((word, wr), (pos, pr), (typ, tr)):
+        assert rel_err(p.grad, p2.grad) < 1e-5
+    # ViT patch embedding
+    img = torch.randn(2, 3, 32, 32, generator=g).to(DEV)
+    pw = torch.nn.Parameter(rnd((d, 3, 16, 16), torch.float32, g, 0.1)); cls = torch.nn.Parameter(rnd((d,), torch.float32, g))
+    pe = torch.nn.Parameter(rnd((5, d), torch.float32, g))
+    x = o.vit_embed(img, pw, cls, pe, 16, dtype)
+    gx = rnd(x.shape, dtype, g)
+    x.backward(gx)
+    pw2, c2, p2 = (p.detach().clone().requires_grad_(True) for p in (pw, cls, pe))
+    im = img.to(dtype).float()
+    t = F.conv2d(im, pw2.to(dtype).float() if dtype == torch.bfloat16 else pw2, stride=16).flatten(2).transpose(1, 2)
+    xr = torch.cat([c2.expand(2, 1, -1), t], 1) + p2[None]
+    xr.backward(gx.float())
+    assert rel_err(x.float(), xr) < tol(dtype)
+    assert rel_err(pw.grad, pw2.grad) < tol(dtype) and rel_err(cls.grad, c2.grad) < 1e-5 and rel_err(pe.grad, p2.grad) < 1e-5
+    # masked-position gather with duplicate positions
+    h = rnd((B, Ls, d), dtype, g).requires_grad_(True)
+    mp = torch.tensor([[1, 3, 0, 0], [2, 2, 5, 0], [8, 1, 4, 6]]).to(DEV)
+    y = o.gather_rows(h, mp)
+    gy = rnd(y.shape, dtype, g)
+    y.backward(gy)
+    hr = h.detach().float().requires_grad_(True)
+    yr = torch.gather(hr, 1, mp.unsqueeze(2).expand(-1, -1, d))
+    yr.backward(gy.float())
+    assert torch.equal(y.float(), yr) and rel_err(h.grad.float(), hr.grad) < tol(dtype)
+    # L2 normalise on a strided CLS slice, GELU
+    z = rnd((B, Ls, d), dtype, g).requires_grad_(True)
+    n = o.l2_normalize(z[:, 0, :])
+    gn = rnd(n.shape, dtype, g)
+    n.backward(gn)
+    zr = z.detach().float().requires_grad_(True)
+    nr = F.normalize(zr[:, 0, :], dim=-1)
+    nr.backward(gn.float())
+    assert rel_err(n.float(), nr) < tol(dtype) and rel_err(z.grad.float(), zr.grad) < tol(dtype) * 2
+    u = rnd((7, 128), dtype, g, 2.0).requires_grad_(True)
+    v = o.gelu(u)
+    v.backward(torch.ones_like(v))
+    ur = u.detach().float().requires_grad_(True)
+    F.gelu(ur).sum().backward()
+    assert rel_err(v.float(), F.gelu(ur)) < tol(dtype) and rel_err(u.grad.float(), ur.grad) < tol(dtype)
+    # casts
+    c = torch.randn(1001, generator=g).to(DEV)
+    assert torch.equal(o.cast(c, torch.bfloat16), c.to(torch.bfloat16))
+
+
+def test_l0_gates_match_reference_fixture(golden_dir):
+    """train-mode z within fp32 rounding; eval-mode 0/1 masks BIT-EXACT against the reference's own output."""
+    import os
+    o = ops()
+    fx = dict(np.load(os.path.join(golden_dir, "l0_full.npz")))
+    names = {"vision_head": "vision_head_loga", "text_head": "text_head_loga", "cross_head": "cross_head_loga",
+             "vision_intermediate": "vision_int_loga", "text_intermediate": "text_int_loga",
+             "cross_intermediate": "cross_int_loga"}
+    for t, pn in names.items():
+        loga = torch.from_numpy(fx["in." + pn]).to(DEV).requires_grad_(True)
+        eps = torch.from_numpy(fx["in.eps." + t]).to(DEV)
+        z = o.l0_sample(loga, eps, 2.0 / 3.0)
+        ref = torch.from_numpy(fx[f"train.z.{t}_z"]).reshape(z.shape)
+        assert float((z.cpu() - ref).abs().max()) < 2e-6, t
+        ze = o.l0_deterministic(loga, 2.0 / 3.0, 0.8)
+        refe = fx[f"eval.z.{t}_z"].reshape(ze.shape)
+        assert np.array_equal(ze.cpu().numpy(), refe), f"eval mask of {t} differs from the reference"
