@@ -129,7 +129,7 @@ class _Linear(torch.autograd.Function):
         ldc = _pad8(N)
         ybuf = torch.empty((M, ldc), dtype=ydt, device=x.device) if ldc == N else \
             torch.zeros((M, ldc), dtype=ydt, device=x.device)
-        need_grad = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        need_grad = any(ctx.needs_input_grad)
         preact = None
         if act != L.ACT_NONE and need_grad:
             preact = torch.empty((M, ldc), dtype=x2.dtype, device=x.device)
@@ -209,7 +209,7 @@ class _MLP(torch.autograd.Function):
         dtype = L.dt(x2)
         W1, W2 = CACHE.get((w1,), x2.dtype), CACHE.get((w2,), x2.dtype)
         Fh, N = W1.shape[0], W2.shape[0]
-        need_grad = torch.is_grad_enabled()
+        need_grad = any(ctx.needs_input_grad)
         h = torch.empty((M, Fh), dtype=x2.dtype, device=x.device) if need_grad else None
         a = torch.empty((M, Fh), dtype=x2.dtype, device=x.device)
         g32 = None
@@ -279,7 +279,7 @@ class _LayerNorm(torch.autograd.Function):
         xc = x if x.is_contiguous() else x.contiguous()
         rows = xc.numel() // d
         y = torch.empty_like(xc)
-        need = torch.is_grad_enabled()
+        need = any(ctx.needs_input_grad)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
         L.check(_lib().evlm_layernorm_fwd(L.dt(xc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(beta.detach()), eps, rows, d,
