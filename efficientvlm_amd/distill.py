@@ -1,0 +1,102 @@
+"""Distillation losses and the general-distillation (GD) step — the loss helpers every reference driver
+duplicates (GeneralDistill.py:60-104) plus the loss mixes of GeneralDistill.py:369-376 and Eff_Retrieval.py:165-178,
+with the same names and argument meaning.  MSE and the dual-softmax KL run as HIP reductions (evlm_mse_*, evlm_kl_*);
+each term is a device scalar, so a whole step issues no host synchronisation.
+"""
+import torch
+
+from . import ops
+
+
+def get_cor_teacher(teacher_reps, student_reps, is_attn=False):
+    """GeneralDistill.py:91-104: teacher layer -> student layer map (every k-th state / last map of each block)"""
+    teacher_reps = [t.detach() for t in teacher_reps]
+    nt, ns = len(teacher_reps), len(student_reps)
+    if is_attn:
+        assert nt % ns == 0
+        k = nt // ns
+        return [teacher_reps[i * k + k - 1] for i in range(ns)]
+    assert (nt - 1) % (ns - 1) == 0
+    k = (nt - 1) // (ns - 1)
+    return [teacher_reps[i * k] for i in range(ns)]
+
+
+def get_kd_loss(student_reps=None, teacher_reps=None, is_attn=False, loss=None, device="cuda", is_img=False):
+    """GeneralDistill.py:60-82.  `loss`/`device` are accepted for signature compatibility; the MSE is the HIP kernel.
+    The reference's torch.where(att <= -1e2, 0, att) is a no-op on probabilities and is not issued."""
+    kd_loss = 0
+    for layer, (s, t) in enumerate(zip(student_reps, teacher_reps)):
+        if is_attn:
+            kd_loss = kd_loss + ops.mse(s, t, weight=float(s.shape[-1]))
+        elif is_img and layer == 6:
+            continue
+        else:
+            kd_loss = kd_loss + ops.mse(s, t)
+    return kd_loss
+
+
+def soft_cross_entropy(predicts, targets, temperature=1.0):
+    """GeneralDistill.py:84-89; callers that pre-divide by T (as the reference does) pass temperature=1."""
+    return ops.soft_cross_entropy(predicts, targets, temperature)
+
+
+def kd_terms(S, T, temperature=1.0, with_cross_attn=False):
+    """the per-pair KD scalars of GeneralDistill.py:300-366 (+ cross-attention maps, Eff_Retrieval.py:141-159)"""
+    sh, th, sa, ta = S["hidden_dict"], T["hidden_dict"], S["attention_dict"], T["attention_dict"]
+    out = {}
+
+    def pair(name, hkey, akey, is_img=False):
+        out[name + "_hidden"] = get_kd_loss(sh[hkey], get_cor_teacher(th[hkey], sh[hkey]), is_img=is_img)
+        out[name + "_attn"] = get_kd_loss(sa[akey], get_cor_teacher(ta[akey], sa[akey], True), is_attn=True)
+
+    pair("text", "text_hidden_states", "text_attentions")
+    pair("image", "image_hidden_states", "image_attentions", is_img=True)
+    pair("itm_pos", "itm_pos_hidden_states", "itm_pos_attentions")
+    pair("itm_neg", "itm_neg_hidden_states", "itm_neg_attentions")
+    if "mlm_hidden_states" in sh:
+        pair("mlm", "mlm_hidden_states", "mlm_attentions")
+        out["mlm_logits"] = soft_cross_entropy(S["logits_dict"]["mlm_logits"], T["logits_dict"]["mlm_logits"], temperature)
+    out["itm_logits"] = soft_cross_entropy(S["logits_dict"]["itm_head_logits"], T["logits_dict"]["itm_head_logits"], temperature)
+    if with_cross_attn:
+        sc, tc = S["cross_attention_dict"], T["cross_attention_dict"]
+        for nm in ("itm_pos", "itm_neg"):
+            k = nm + "_cross_attentions"
+            out[nm + "_cross"] = get_kd_loss(sc[k], get_cor_teacher(tc[k], sc[k], True), is_attn=True)
+    return out
+
+
+def gd_loss_mix(loss, kd):
+    """GeneralDistill.py:369-376"""
+    loss_small = loss["loss_itc"] + loss["loss_itm"] + loss["loss_mlm"]
+    loss_text_kd = kd["text_attn"] + kd["text_hidden"]
+    loss_img_kd = kd["image_attn"] + 0.1 * kd["image_hidden"]
+    loss_cross_kd = (kd["itm_neg_attn"] + kd["itm_neg_hidden"] + kd["itm_pos_attn"] + kd["itm_pos_hidden"]
+                     + kd["mlm_attn"] + kd["mlm_hidden"])
+    loss_kd = kd["itm_logits"] + kd["mlm_logits"] + loss_text_kd + loss_img_kd + loss_cross_kd
+    return loss_small * 0.6 + loss_kd * 0.4, dict(loss_small=loss_small, loss_text_kd=loss_text_kd,
+                                                  loss_img_kd=loss_img_kd, loss_cross_kd=loss_cross_kd, loss_kd=loss_kd)
+
+
+def itr_loss_mix(loss, kd, lagrangian):
+    """Eff_Retrieval.py:165-178"""
+    loss_text_kd = kd["text_hidden"] + kd["text_attn"]
+    loss_img_kd = 0.2 * kd["image_hidden"] + kd["image_attn"]
+    loss_cross_kd = (kd["itm_neg_hidden"] + kd["itm_pos_hidden"] + kd["itm_pos_attn"] + kd["itm_pos_cross"]
+                     + kd["itm_neg_attn"] + kd["itm_neg_cross"]) * 0.5
+    loss_kd = kd["itm_logits"] + (loss_text_kd + loss_img_kd + loss_cross_kd) * 0.33
+    loss_small = loss["loss_itc"] + loss["loss_itm"]
+    return (loss_kd + loss_small) * 0.5 + lagrangian, dict(loss_text_kd=loss_text_kd, loss_img_kd=loss_img_kd,
+                                                           loss_cross_kd=loss_cross_kd, loss_kd=loss_kd)
+
+
+def gd_forward(student, teacher, batch, temperature=1.0):
+    """student forward (autograd on), teacher forward (no_grad), every KD term and the GD loss mix
+    (GeneralDistill.py:289-376).  batch: dict(image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids)."""
+    kw = dict(text_ids_masked=batch["text_ids_masked"], masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"],
+              output_attentions=True, output_hidden_states=True)
+    S = student(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+    with torch.no_grad():
+        T = teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+    kd = kd_terms(S, T, temperature)
+    total, mix = gd_loss_mix(S["loss"], kd)
+    return total, S, T, kd, mix

@@ -1,0 +1,531 @@
+"""BERT text / cross-modal encoder with L0 gate hooks — drop-in for the reference's efficient_models/eff_bert.py
+(and, with z=None, models/xbert.py): same class names, constructor arguments, forward keywords, output objects and
+state-dict keys.  Only the classes on the distillation path are provided (SURVEY.md §2 row 3:
+BertFor{PreTraining,NSP,SequenceClassification,...} and load_tf_weights_in_bert are unused HF boilerplate).
+
+Arithmetic (all in libevlm_hip.so):
+    embeddings gather-add            -> evlm_bert_embed + evlm_layernorm (eps 1e-12)      (eff_bert.py:188-215)
+    query/key/value                  -> ONE packed GEMM ([3d,d] self, [2d,d] key/value over image tokens for cross)
+    matmul /sqrt(d) +mask softmax matmul *= head_z -> evlm_attention (probabilities returned BEFORE dropout, :338-361)
+    BertSelfOutput dense + input     -> GEMM with residual epilogue, then LayerNorm        (:374-381)
+    BertIntermediate gelu * mlp_z, BertOutput dense + input -> two GEMMs with fused epilogues, then LayerNorm (:445-462,:553-557)
+    MLM head                         -> gather rows, dense+GELU epilogue, LayerNorm, tied-decoder GEMM, fused CE (:1691-1702)
+
+Dropout: the distillation recipe's parity configuration (and the bench) use p = 0; p > 0 raises rather than silently
+differing (RNG parity with the reference's CUDA dropout stream is not reproducible anyway).
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import ops
+from .._lib import ACT_GELU, GATE_POST
+from ..runtime import BertConfig, ModelOutput, compute_dtype
+from .eff_vit import find_pruneable_heads_and_indices, prune_linear_layer
+
+__all__ = ["BertConfig", "BertModel", "BertForMaskedLM", "BertEmbeddings", "BertSelfAttention", "BertSelfOutput",
+           "BertAttention", "BertIntermediate", "BertOutput", "BertLayer", "BertEncoder", "BertLMPredictionHead",
+           "BertOnlyMLMHead", "BertPredictionHeadTransform", "BertPreTrainedModel", "MaskedLMOutput"]
+
+
+def _check_dropout(p, what):
+    if p and p > 0:
+        raise NotImplementedError(f"{what} = {p}: the HIP path implements the p = 0 configuration used for parity and "
+                                  "benchmarking; set hidden_dropout_prob = attention_probs_dropout_prob = 0")
+
+
+class BertEmbeddings(nn.Module):
+    """eff_bert.py:168-215"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=config.pad_token_id)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)
+        self.token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        _check_dropout(config.hidden_dropout_prob, "hidden_dropout_prob")
+        self.register_buffer("position_ids", torch.arange(config.max_position_embeddings).expand((1, -1)))
+        self.position_embedding_type = getattr(config, "position_embedding_type", "absolute")
+        if self.position_embedding_type != "absolute":
+            raise NotImplementedError("only absolute position embeddings are used by the reference configs")
+        self.config = config
+
+    def forward(self, input_ids=None, token_type_ids=None, position_ids=None, inputs_embeds=None, past_key_values_length=0):
+        if inputs_embeds is not None or position_ids is not None or past_key_values_length:
+            raise NotImplementedError("inputs_embeds / custom position_ids / cached decoding are off the distillation path")
+        if token_type_ids is not None and bool((token_type_ids != 0).any()):
+            raise NotImplementedError("token_type_ids != 0 never occur on the distillation path (eff_bert.py:201-202)")
+        L = input_ids.shape[1]
+        e = ops.bert_embed(input_ids, self.word_embeddings.weight, self.position_embeddings.weight[:L],
+                           self.token_type_embeddings.weight, self.config.pad_token_id, compute_dtype())
+        return ops.layer_norm(e, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+
+
+class BertSelfAttention(nn.Module):
+    """eff_bert.py:218-364 (parameters + head bookkeeping; the math is issued by BertAttention.forward)"""
+
+    def __init__(self, config, is_cross_attention):
+        super().__init__()
+        self.config = config
+        if config.hidden_size % config.num_attention_heads != 0 and not hasattr(config, "embedding_size"):
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                             % (config.hidden_size, config.num_attention_heads))
+        self.fp16 = getattr(config, "fp16", False)   # pre- vs post-scaling of Q: same maths
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = int(config.hidden_size / config.num_attention_heads)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.query = nn.Linear(config.hidden_size, self.all_head_size)
+        kv_in = config.encoder_width if is_cross_attention else config.hidden_size
+        self.key = nn.Linear(kv_in, self.all_head_size)
+        self.value = nn.Linear(kv_in, self.all_head_size)
+        _check_dropout(config.attention_probs_dropout_prob, "attention_probs_dropout_prob")
+        self.is_cross_attention = is_cross_attention
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
+                encoder_attention_mask=None, past_key_value=None, output_attentions=False, head_z=None):
+        """returns (context [B,L,all_head], probs | None).  masks are additive [B,1,1,Lk] (key masks)."""
+        if head_mask is not None or past_key_value is not None:
+            raise NotImplementedError("head_mask / past_key_value are off the distillation path")
+        H, dh = self.num_attention_heads, self.attention_head_size
+        scale = 1.0 / math.sqrt(dh)
+        if encoder_hidden_states is not None:
+            q = ops.linear(hidden_states, self.query.weight, self.query.bias)
+            kv = ops.linear_packed(encoder_hidden_states, (self.key.weight, self.value.weight), (self.key.bias, self.value.bias))
+            ctx, probs = ops.cross_attention(q, kv, H, dh, scale, mask=_key_mask(encoder_attention_mask), gate=head_z,
+                                             want_probs=bool(output_attentions))
+        else:
+            qkv = ops.linear_packed(hidden_states, (self.query.weight, self.key.weight, self.value.weight),
+                                    (self.query.bias, self.key.bias, self.value.bias))
+            ctx, probs = ops.self_attention(qkv, H, dh, scale, mask=_key_mask(attention_mask), gate=head_z,
+                                            want_probs=bool(output_attentions))
+        outputs = (ctx, probs) if output_attentions else (ctx,)
+        return outputs + (None,)
+
+
+def _key_mask(m):
+    """additive [B,1,1,Lk] (or [B,Lk]) -> [B,Lk] fp32 for the attention kernel"""
+    if m is None:
+        return None
+    if m.dim() == 4:
+        if m.shape[1] != 1 or m.shape[2] != 1:
+            raise NotImplementedError("per-query (causal) masks belong to the VQA decoder (BASELINE config 4), not built yet")
+        m = m[:, 0, 0, :]
+    return m
+
+
+class BertSelfOutput(nn.Module):
+    """eff_bert.py:367-381"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        _check_dropout(config.hidden_dropout_prob, "hidden_dropout_prob")
+
+    def forward(self, hidden_states, input_tensor, head_layer_z=None):
+        if head_layer_z is not None:
+            raise NotImplementedError("head_layer_z is dead plumbing in the reference (BertEncoder never forwards it)")
+        h = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor)
+        return ops.layer_norm(h, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+
+
+class BertAttention(nn.Module):
+    """eff_bert.py:384-433"""
+
+    def __init__(self, config, is_cross_attention=False):
+        super().__init__()
+        self.self = BertSelfAttention(config, is_cross_attention)
+        self.output = BertSelfOutput(config)
+        self.pruned_heads = set()
+
+    def prune_heads(self, heads):
+        if len(heads) == 0:
+            return
+        heads, index = find_pruneable_heads_and_indices(heads, self.self.num_attention_heads,
+                                                        self.self.attention_head_size, self.pruned_heads)
+        self.self.query = prune_linear_layer(self.self.query, index)
+        self.self.key = prune_linear_layer(self.self.key, index)
+        self.self.value = prune_linear_layer(self.self.value, index)
+        self.output.dense = prune_linear_layer(self.output.dense, index, dim=1)
+        self.self.num_attention_heads = self.self.num_attention_heads - len(heads)
+        self.self.all_head_size = self.self.attention_head_size * self.self.num_attention_heads
+        self.pruned_heads = self.pruned_heads.union(heads)
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
+                encoder_attention_mask=None, past_key_value=None, output_attentions=False, head_z=None, head_layer_z=None):
+        self_outputs = self.self(hidden_states, attention_mask, head_mask, encoder_hidden_states, encoder_attention_mask,
+                                 past_key_value, output_attentions, head_z=head_z)
+        attention_output = self.output(self_outputs[0], hidden_states, head_layer_z=head_layer_z)
+        return (attention_output,) + self_outputs[1:]
+
+
+class BertIntermediate(nn.Module):
+    """eff_bert.py:436-448 (parameter container; fused into BertLayer.feed_forward_chunk)"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+        if config.hidden_act != "gelu":
+            raise NotImplementedError("BERT hidden_act other than erf-GELU is not used by the reference configs")
+
+    def forward(self, hidden_states):
+        return ops.linear(hidden_states, self.dense.weight, self.dense.bias, act=ACT_GELU)
+
+
+class BertOutput(nn.Module):
+    """eff_bert.py:451-462"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        _check_dropout(config.hidden_dropout_prob, "hidden_dropout_prob")
+
+    def forward(self, hidden_states, input_tensor):
+        h = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor)
+        return ops.layer_norm(h, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+
+
+class BertLayer(nn.Module):
+    """eff_bert.py:465-560"""
+
+    def __init__(self, config, layer_num):
+        super().__init__()
+        self.config = config
+        self.attention = BertAttention(config)
+        self.has_cross_attention = (layer_num >= config.fusion_layer)
+        if self.has_cross_attention:
+            self.layer_num = layer_num
+            self.crossattention = BertAttention(config, is_cross_attention=True)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
+                encoder_attention_mask=None, past_key_value=None, output_attentions=False, head_z=None,
+                head_layer_z=None, mlp_z=None):
+        if self.has_cross_attention and head_z is not None:
+            assert isinstance(head_z, tuple)
+            head_z, cross_head_z = head_z
+        else:
+            cross_head_z = None
+        self_attention_outputs = self.attention(hidden_states, attention_mask, head_mask,
+                                                output_attentions=output_attentions, head_z=head_z, head_layer_z=head_layer_z)
+        attention_output = self_attention_outputs[0]
+        outputs = self_attention_outputs[1:-1]
+        if self.has_cross_attention:
+            assert encoder_hidden_states is not None, "encoder_hidden_states must be given for cross-attention layers"
+            if type(encoder_hidden_states) == list:                               # eff_bert.py:517-527
+                k = (self.layer_num - self.config.fusion_layer) % len(encoder_hidden_states)
+                enc, enc_mask = encoder_hidden_states[k], encoder_attention_mask[k]
+            else:
+                enc, enc_mask = encoder_hidden_states, encoder_attention_mask
+            cross_attention_outputs = self.crossattention(attention_output, attention_mask, head_mask, enc, enc_mask,
+                                                          output_attentions=output_attentions, head_z=cross_head_z)
+            attention_output = cross_attention_outputs[0]
+            outputs = outputs + cross_attention_outputs[1:-1]
+        self.mlp_z = mlp_z
+        layer_output = self.feed_forward_chunk(attention_output)
+        return (layer_output,) + outputs + (None,)
+
+    def feed_forward_chunk(self, attention_output):
+        """eff_bert.py:552-560: gelu(dense(x)) * mlp_z -> dense -> +x -> LayerNorm (the gate comes AFTER the activation)"""
+        o = self.output
+        h = ops.mlp(attention_output, self.intermediate.dense.weight, self.intermediate.dense.bias, o.dense.weight,
+                    o.dense.bias, ACT_GELU, gate=self.mlp_z, gate_pos=GATE_POST, residual=attention_output)
+        return ops.layer_norm(h, o.LayerNorm.weight, o.LayerNorm.bias, o.LayerNorm.eps)
+
+
+class BertEncoder(nn.Module):
+    """eff_bert.py:563-694"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.layer = nn.ModuleList([BertLayer(config, i) for i in range(config.num_hidden_layers)])
+        self.fusion_layer = self.config.fusion_layer
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
+                encoder_attention_mask=None, past_key_values=None, use_cache=None, output_attentions=False,
+                output_hidden_states=False, return_dict=True, mode="multi_modal", head_z=None, head_layer_z=None, mlp_z=None):
+        all_hidden_states = () if output_hidden_states else None
+        all_self_attentions = () if output_attentions else None
+        all_cross_attentions = () if output_attentions else None
+        if mode == "text":
+            start_layer, output_layer = 0, self.fusion_layer
+        elif mode == "fusion":
+            start_layer, output_layer = self.fusion_layer, self.config.num_hidden_layers
+        elif mode == "multi_modal":
+            start_layer, output_layer = 0, self.config.num_hidden_layers
+        else:
+            raise ValueError(f"mode {mode} is not supported")
+        for i in range(start_layer, output_layer):
+            layer_module = self.layer[i]
+            if output_hidden_states:
+                all_hidden_states = all_hidden_states + (hidden_states,)
+            # gate indexing reproduced verbatim, including the offset-free multi_modal quirk (eff_bert.py:612-620)
+            if i >= self.fusion_layer and head_z is not None:
+                first = (i - self.fusion_layer) * 2
+                cur_head_z = (head_z[first], head_z[first + 1])
+                cur_mlp_z = mlp_z[i - self.fusion_layer]
+            elif head_z is not None:
+                cur_head_z = head_z[i]
+                cur_mlp_z = mlp_z[i]
+            else:
+                cur_mlp_z, cur_head_z = None, None
+            layer_outputs = layer_module(hidden_states, attention_mask, None, encoder_hidden_states, encoder_attention_mask,
+                                         None, output_attentions, head_z=cur_head_z if head_z is not None else None,
+                                         mlp_z=cur_mlp_z if mlp_z is not None else None)
+            hidden_states = layer_outputs[0]
+            if output_attentions:
+                all_self_attentions = all_self_attentions + (layer_outputs[1],)
+                if len(layer_outputs) > 3:
+                    all_cross_attentions = all_cross_attentions + (layer_outputs[2],)
+        if output_hidden_states:
+            all_hidden_states = all_hidden_states + (hidden_states,)
+        if not return_dict:
+            return tuple(v for v in [hidden_states, None, all_hidden_states, all_self_attentions, all_cross_attentions]
+                         if v is not None)
+        return ModelOutput(last_hidden_state=hidden_states, past_key_values=None, hidden_states=all_hidden_states,
+                           attentions=all_self_attentions, cross_attentions=all_cross_attentions)
+
+
+class BertPredictionHeadTransform(nn.Module):
+    """eff_bert.py:712-726"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+    def forward(self, hidden_states):
+        h = ops.linear(hidden_states, self.dense.weight, self.dense.bias, act=ACT_GELU)
+        return ops.layer_norm(h, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+
+
+class BertLMPredictionHead(nn.Module):
+    """eff_bert.py:729-746: decoder.weight is tied to the word embeddings, decoder.bias to `bias`"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.transform = BertPredictionHeadTransform(config)
+        self.decoder = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(config.vocab_size))
+        self.decoder.bias = self.bias
+
+    def forward(self, hidden_states):
+        h = self.transform(hidden_states)
+        return ops.linear(h, self.decoder.weight, self.decoder.bias)
+
+
+class BertOnlyMLMHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.predictions = BertLMPredictionHead(config)
+
+    def forward(self, sequence_output):
+        return self.predictions(sequence_output)
+
+
+class BertPreTrainedModel(nn.Module):
+    """the slice of transformers.PreTrainedModel (4.12.5) the path uses: config, _init_weights, init_weights + tying"""
+    base_model_prefix = "bert"
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = BertConfig.from_any(config)
+
+    def _init_weights(self, module):
+        """eff_bert.py:792-802"""
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+
+    def get_input_embeddings(self):
+        return None
+
+    def get_output_embeddings(self):
+        return None
+
+    def init_weights(self):
+        self.apply(self._init_weights)
+        self.tie_weights()
+
+    def tie_weights(self):
+        out, inp = self.get_output_embeddings(), self.get_input_embeddings()
+        if out is not None and inp is not None:
+            out.weight = inp.weight
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+
+class BertModel(BertPreTrainedModel):
+    """eff_bert.py:896-1162"""
+
+    def __init__(self, config, add_pooling_layer=True):
+        super().__init__(config)
+        config = self.config
+        self.embeddings = BertEmbeddings(config)
+        self.encoder = BertEncoder(config)
+        self.pooler = None
+        if add_pooling_layer:
+            raise NotImplementedError("the pooler is never built on the path (xvlm.py:180 add_pooling_layer=False)")
+        self.init_weights()
+
+    def get_input_embeddings(self):
+        return self.embeddings.word_embeddings
+
+    def set_input_embeddings(self, value):
+        self.embeddings.word_embeddings = value
+
+    def prune_heads(self, heads_to_prune, is_cross=None):
+        """eff_bert.py:925-949"""
+        if is_cross == "cross":
+            for layer, heads in heads_to_prune.items():
+                remainder, quotient = layer % 2, layer // 2
+                if remainder == 0:
+                    self.encoder.layer[3 + quotient].attention.prune_heads(heads)
+                else:
+                    self.encoder.layer[3 + quotient].crossattention.prune_heads(heads)
+        elif is_cross == "decoder":
+            for layer, heads in heads_to_prune.items():
+                remainder, quotient = layer % 2, layer // 2
+                if remainder == 0:
+                    self.encoder.layer[quotient].attention.prune_heads(heads)
+                else:
+                    self.encoder.layer[quotient].crossattention.prune_heads(heads)
+        else:
+            for layer, heads in heads_to_prune.items():
+                self.encoder.layer[layer].attention.prune_heads(heads)
+
+    def get_extended_attention_mask(self, attention_mask, input_shape, device, is_decoder):
+        """eff_bert.py:953-1013: (1 - m) * -10000 broadcast to [B,1,1,L]"""
+        if attention_mask.dim() == 3:
+            ext = attention_mask[:, None, :, :]
+        elif attention_mask.dim() == 2:
+            if is_decoder:
+                raise NotImplementedError("causal decoder masks belong to the VQA decoder (BASELINE config 4), not built yet")
+            ext = attention_mask[:, None, None, :]
+        else:
+            raise ValueError("Wrong shape for input_ids (shape {}) or attention_mask (shape {})".format(
+                input_shape, attention_mask.shape))
+        return (1.0 - ext.to(dtype=torch.float32)) * -10000.0
+
+    def invert_attention_mask(self, encoder_attention_mask):
+        """transformers 4.12.5 ModuleUtilsMixin.invert_attention_mask: (1 - m) * -10000 (fp32)"""
+        if encoder_attention_mask.dim() == 3:
+            ext = encoder_attention_mask[:, None, :, :]
+        else:
+            ext = encoder_attention_mask[:, None, None, :]
+        return (1.0 - ext.to(dtype=torch.float32)) * -10000.0
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
+                inputs_embeds=None, encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None,
+                return_dict=None, is_decoder=False, mode="multi_modal", head_z=None, head_layer_z=None, mlp_z=None):
+        output_attentions = output_attentions if output_attentions is not None else self.config.output_attentions
+        output_hidden_states = output_hidden_states if output_hidden_states is not None else self.config.output_hidden_states
+        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        if input_ids is not None and inputs_embeds is not None:
+            raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+        elif input_ids is not None:
+            input_shape, device = input_ids.size(), input_ids.device
+        elif inputs_embeds is not None:
+            input_shape, device = inputs_embeds.size()[:-1], inputs_embeds.device
+        elif encoder_embeds is not None:
+            input_shape, device = encoder_embeds.size()[:-1], encoder_embeds.device
+        else:
+            raise ValueError("You have to specify either input_ids or inputs_embeds or encoder_embeds")
+        batch_size, seq_length = input_shape
+        if past_key_values is not None or head_mask is not None:
+            raise NotImplementedError("past_key_values / head_mask are off the distillation path")
+        if attention_mask is None:
+            attention_mask = torch.ones((batch_size, seq_length), device=device)
+        extended_attention_mask = self.get_extended_attention_mask(attention_mask, input_shape, device, is_decoder)
+        if encoder_hidden_states is not None:
+            if type(encoder_hidden_states) == list:
+                enc_shape = encoder_hidden_states[0].size()[:2]
+            else:
+                enc_shape = encoder_hidden_states.size()[:2]
+            if type(encoder_attention_mask) == list:
+                encoder_extended_attention_mask = [self.invert_attention_mask(m) for m in encoder_attention_mask]
+            elif encoder_attention_mask is None:
+                encoder_extended_attention_mask = self.invert_attention_mask(torch.ones(enc_shape, device=device))
+            else:
+                encoder_extended_attention_mask = self.invert_attention_mask(encoder_attention_mask)
+        else:
+            encoder_extended_attention_mask = None
+        if encoder_embeds is None:
+            embedding_output = self.embeddings(input_ids=input_ids, position_ids=position_ids,
+                                               token_type_ids=token_type_ids, inputs_embeds=inputs_embeds)
+        else:
+            embedding_output = encoder_embeds
+        encoder_outputs = self.encoder(embedding_output, attention_mask=extended_attention_mask, head_mask=None,
+                                       encoder_hidden_states=encoder_hidden_states,
+                                       encoder_attention_mask=encoder_extended_attention_mask,
+                                       output_attentions=output_attentions, output_hidden_states=output_hidden_states,
+                                       return_dict=return_dict, mode=mode, head_z=head_z, head_layer_z=head_layer_z, mlp_z=mlp_z)
+        sequence_output = encoder_outputs[0]
+        if not return_dict:
+            return (sequence_output, None) + tuple(encoder_outputs[1:])
+        return ModelOutput(last_hidden_state=sequence_output, pooler_output=None,
+                           past_key_values=encoder_outputs.past_key_values, hidden_states=encoder_outputs.hidden_states,
+                           attentions=encoder_outputs.attentions, cross_attentions=encoder_outputs.cross_attentions)
+
+
+class MaskedLMOutput(ModelOutput):
+    """eff_bert.py:1601-1608"""
+
+
+class BertForMaskedLM(BertPreTrainedModel):
+    """eff_bert.py:1610-1728"""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.bert = BertModel(self.config, add_pooling_layer=False)
+        self.cls = BertOnlyMLMHead(self.config)
+        self.init_weights()
+
+    def get_input_embeddings(self):
+        return self.bert.embeddings.word_embeddings
+
+    def get_output_embeddings(self):
+        return self.cls.predictions.decoder
+
+    def set_output_embeddings(self, new_embeddings):
+        self.cls.predictions.decoder = new_embeddings
+
+    def gather_seq_out_by_pos(self, seq, pos):
+        return ops.gather_rows(seq, pos)
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
+                inputs_embeds=None, encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                labels=None, output_attentions=None, output_hidden_states=None, return_dict=None, is_decoder=False,
+                mode="multi_modal", return_logits=False, masked_pos=None, head_z=None, head_layer_z=None, mlp_z=None):
+        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        outputs = self.bert(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids,
+                            position_ids=position_ids, head_mask=head_mask, inputs_embeds=inputs_embeds,
+                            encoder_embeds=encoder_embeds, encoder_hidden_states=encoder_hidden_states,
+                            encoder_attention_mask=encoder_attention_mask, output_attentions=output_attentions,
+                            output_hidden_states=output_hidden_states, return_dict=return_dict, is_decoder=is_decoder,
+                            mode=mode, head_z=head_z, head_layer_z=head_layer_z, mlp_z=mlp_z)
+        sequence_output = outputs[0]
+        if masked_pos is not None:
+            sequence_output = self.gather_seq_out_by_pos(sequence_output, masked_pos)
+        prediction_scores = self.cls(sequence_output)
+        if return_logits:
+            return prediction_scores
+        masked_lm_loss = None
+        if labels is not None:
+            masked_lm_loss = ops.cross_entropy(prediction_scores.reshape(-1, self.config.vocab_size), labels.reshape(-1))
+        if not return_dict:
+            output = (prediction_scores,) + tuple(outputs[2:])
+            return ((masked_lm_loss,) + output) if masked_lm_loss is not None else output
+        return MaskedLMOutput(loss=masked_lm_loss, logits=prediction_scores, hidden_states=outputs.hidden_states,
+                              attentions=outputs.attentions, cross_attentions=outputs.cross_attentions)
