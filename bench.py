@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image-text pairs/s of ONE general-distillation step (X-VLM-small student forward+backward,
+X-VLM-base teacher forward under no_grad, every KD loss, gradient reduction, global-norm clip + AdamW) on synthetic
+224x224 images + 30-token captions, batch 64 per GPU, bf16 compute (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N --steps K --warmup W]             # N=1 directly
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                  # N>1: one rank per GPU over RCCL
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     - the dominant kernel (bf16 MFMA GEMM, forward NT variant): algorithmic FLOPs per launch / its average
+                 launch duration, timed live with HIP events on the launch stream during one extra instrumented step;
+  cpu_baseline - oracle/ (the CPU restatement of the reference) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+FLOPS_PER_PAIR = 161.4e9         # 3 x student fwd (32.41 GF) + teacher fwd (64.20 GF)
+
+
+def build(geom, dev, seed):
+    from helpers import model_config
+    from efficientvlm_amd.models.model_pretrain import XVLM
+    torch.manual_seed(seed)
+    student = XVLM(model_config(geom, "s")).to(dev)
+    teacher = XVLM(model_config(geom, "t")).to(dev)
+    return student, teacher
+
+
+def cpu_baseline(geom, budget_s=20.0, B=4):
+    """oracle (kind='port') GD step, fp32, all host cores, bounded to ~budget_s seconds of CPU work"""
+    from oracle import schema, synth
+    from oracle import xvlm_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    s_cfg, t_cfg = O.model_cfg(geom, "s"), O.model_cfg(geom, "t")
+    s_sd = schema.det_weights(schema.xvlm_schema(s_cfg, geom["max_pos"]), 1, geom["std"])
+    t_sd = schema.det_weights(schema.xvlm_schema(t_cfg, geom["max_pos"]), 2, geom["std"])
+    for sd in (s_sd, t_sd):
+        sd["text_encoder.cls.predictions.decoder.weight"] = sd["text_encoder.bert.embeddings.word_embeddings.weight"]
+        sd["text_encoder.cls.predictions.decoder.bias"] = sd["text_encoder.cls.predictions.bias"]
+    leaves = {}
+    for k, v in s_sd.items():
+        leaves.setdefault(id(v), v.clone().requires_grad_(True))
+    s_sd = {k: leaves[id(v)] for k, v in s_sd.items()}
+    batch = synth.make_batch(geom, B, seed=42)
+    neg = torch.tensor([(i + 1) % B for i in range(2 * B)])
+    times = []
+    t_start = time.time()
+    for it in range(6):
+        t0 = time.time()
+        total, *_ = O.gd_step(s_sd, t_sd, s_cfg, t_cfg, batch, neg, neg)
+        total.backward()
+        for p in leaves.values():
+            p.grad = None
+        dt = time.time() - t0
+        if it > 0:
+            times.append(dt)
+        if time.time() - t_start > budget_s and times:
+            break
+    t = sorted(times)[len(times) // 2]
+    return {"value": round(B / t, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} timed GD steps of batch {B} (after 1 warm-up), fp32, oracle/xvlm_oracle.py, median"}
+
+
+def roofline_leg(trainer, batch):
+    """one extra eager step with every GEMM launch bracketed by HIP events on its launch stream"""
+    from efficientvlm_amd import ops
+    from efficientvlm_amd._lib import BF16
+    ops.GEMM_PROFILE = []
+    trainer.opt.set_schedule(0.0)
+    trainer._step_eager(batch)
+    torch.cuda.synchronize()
+    recs, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    groups = {}
+    for dtype, pt, qt, I, J, K, e0, e1 in recs:
+        if dtype != BF16:
+            continue
+        g = groups.setdefault((pt, qt), [0, 0.0, 0.0])
+        g[0] += 1
+        g[1] += 2.0 * I * J * K
+        g[2] += e0.elapsed_time(e1) * 1e-3
+    names = {(0, 0): "gemm_bf16_kernel<false,false> (Y = X W^T, forward)",
+             (0, 1): "gemm_bf16_kernel<false,true> (dX = dY W)",
+             (1, 1): "gemm_bf16_kernel<true,true> (dW = dY^T X)", (1, 0): "gemm_bf16_kernel<true,false>"}
+    dom = max(groups, key=lambda k: groups[k][2])
+    n, fl, tm = groups[dom]
+    allfl, alltm = sum(g[1] for g in groups.values()), sum(g[2] for g in groups.values())
+    ach = fl / tm / 1e12
+    return {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n,
+            "avg_launch_us": round(tm / n * 1e6, 2), "flop_per_launch": round(fl / n / 1e9, 3),
+            "all_gemm_variants": {names[k]: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
+                                             "time_ms": round(v[2] * 1e3, 3)} for k, v in groups.items()},
+            "all_gemm_tflops": round(allfl / alltm / 1e12, 1), "gemm_time_ms_per_step": round(alltm * 1e3, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE.json configs[1]: 64)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    dev = torch.device("cuda", local_rank)
+
+    from oracle import synth
+    from efficientvlm_amd.trainer import GDTrainer
+    geom = synth.GEOMS["full"]
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    student, teacher = build(geom, dev, seed=1234)
+    trainer = GDTrainer(student, teacher, lr=1e-4, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=dtype,
+                        use_graph=not args.no_graph)
+    B = args.batch
+    batch = {k: v.to(dev) for k, v in synth.make_batch(geom, B, seed=42 + rank).items()}   # weak scaling: B per GPU
+
+    for _ in range(args.warmup):
+        out = trainer.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = [float(x) for x in out.tolist()]
+
+    if rank == 0:
+        pairs = B * world * args.steps
+        value = pairs / elapsed
+        res = {"metric": "image-text pairs/sec/node (GD step, X-VLM-small student + base teacher)",
+               "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "GeneralDistill general step: X-VLM-small (6+3+3) student fwd+bwd, X-VLM-base (12+6+6) "
+                                      "teacher fwd, ITC+ITM+MLM + hidden/attention/logit KD, grad all-reduce, clip 1.0, AdamW",
+                          "image": "224x224", "text_len": geom["L"], "masked": geom["M"], "batch_per_gpu": B,
+                          "global_batch": B * world, "parallelism": f"dp{world}",
+                          "launch": "eager" if (args.no_graph or world > 1) else "hipGraph replay",
+                          "init": "random (reference init), no checkpoints"},
+               "step_model_tflops": round(value * FLOPS_PER_PAIR / 1e12, 1),
+               "step_mfma_frac": round(value * FLOPS_PER_PAIR / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+               "last_losses": {"total": losses[0], "itc": losses[1], "itm": losses[2], "mlm": losses[3], "kd": losses[4]}}
+        if not args.no_roofline and dtype == torch.bfloat16:
+            res["roofline"] = roofline_leg(trainer, batch)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(geom)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

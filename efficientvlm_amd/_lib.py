@@ -77,7 +77,7 @@ SIGNATURES = {
     "evlm_l0_sample_bwd": [_vp, _vp, _vp, _i64, _f, _vp, _vp],
     "evlm_l0_deterministic": [_vp, _i, _i, _f, _f, _vp, _vp],
     "evlm_sumsq": [_vp, _i64, _vp, _vp],
-    "evlm_adamw_step": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _vp, _vp],
+    "evlm_adamw_step": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _vp, _vp, _vp],
 }
 
 _lib = None

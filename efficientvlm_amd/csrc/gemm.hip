@@ -27,67 +27,81 @@ struct GemmP {
 };
 
 // ---------------------------------------------------------------------------------------------
-// epilogue: 4 consecutive j (j0..j0+3) of row i, fp32 accumulators in v[4]
+// tile epilogue.  Each lane owns, for every (a, b) accumulator, FOUR CONSECUTIVE j of one row i:
+//     i = ibase + b*16 + (lane & 15),   j = jbase + a*16 + (lane >> 4)*4 + 0..3
+// Per-column vectors (bias, gate) are fetched once per `a` as 16-byte loads; aux / residual rows are fetched as
+// 8/16-byte vectors for all `b` of one `a` before they are consumed, so the loads overlap instead of serialising.
+// FULL = the whole workgroup tile is inside the matrix (no bounds checks at all).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void epilogue4(const GemmP& g, int i, int j0, float v[4]) {
-  if (i >= g.I || j0 >= g.J) return;
-  const int nv = min(4, g.J - j0);
-  const bool full = (nv == 4);
+__device__ __forceinline__ void ld4(const T* p, int nv, float v[4]) {
+  if (nv == 4) Vec4<T>::load(p, v);
+  else { v[0] = v[1] = v[2] = v[3] = 0.f; for (int e = 0; e < nv; ++e) v[e] = to_f(p[e]); }
+}
+template <typename T>
+__device__ __forceinline__ void st4(T* p, int nv, const float v[4]) {
+  if (nv == 4) Vec4<T>::store(p, v);
+  else for (int e = 0; e < nv; ++e) p[e] = from_f<T>(v[e]);
+}
+
+template <typename T, int NA, int NB, bool FULL>
+__device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][NB], int ibase, int jbase, int lane) {
+  const int il = lane & 15, jl = (lane >> 4) * 4;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] *= g.alpha;
-  if (g.bias) {
+  for (int a = 0; a < NA; ++a) {
+    const int j = jbase + a * 16 + jl;
+    const int nv = FULL ? 4 : max(0, min(4, g.J - j));
+    if (!FULL && nv == 0) continue;
+    float bz[4] = {0.f, 0.f, 0.f, 0.f}, gz[4] = {1.f, 1.f, 1.f, 1.f};
+    if (g.bias) ld4<float>(g.bias + j, nv, bz);
+    if (g.gate) ld4<float>(g.gate + j, nv, gz);
+    float hx[NB][4], rx[NB][4];
+    if (g.dact != EVLM_ACT_NONE) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) if (e < nv) v[e] += g.bias[j0 + e];
-  }
-  const size_t xo = (size_t)i * g.ldx + j0;
-  if (g.preact) {
-    T* pa = reinterpret_cast<T*>(g.preact) + xo;
-    if (full) Vec4<T>::store(pa, v);
-    else for (int e = 0; e < nv; ++e) pa[e] = from_f<T>(v[e]);
-  }
-  float gz[4] = {1.f, 1.f, 1.f, 1.f};
-  if (g.gate) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) if (e < nv) gz[e] = g.gate[j0 + e];
-  }
-  if (g.act != EVLM_ACT_NONE) {
-    if (g.gate_pos == EVLM_GATE_PRE_ACT) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = act_apply(g.act, v[e] * gz[e]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = act_apply(g.act, v[e]) * gz[e];
+      for (int b = 0; b < NB; ++b) {
+        const int i = ibase + b * 16 + il;
+        if (FULL || i < g.I) ld4<T>(reinterpret_cast<const T*>(g.aux) + (size_t)i * g.ldx + j, nv, hx[b]);
+      }
     }
-  } else if (g.gate) {
+    if (g.residual) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= gz[e];
-  }
-  if (g.dact != EVLM_ACT_NONE) {
-    float h[4] = {0.f, 0.f, 0.f, 0.f};
-    const T* ax = reinterpret_cast<const T*>(g.aux) + xo;
-    if (full) Vec4<T>::load(ax, h);
-    else for (int e = 0; e < nv; ++e) h[e] = to_f(ax[e]);
+      for (int b = 0; b < NB; ++b) {
+        const int i = ibase + b * 16 + il;
+        if (FULL || i < g.I) ld4<T>(reinterpret_cast<const T*>(g.residual) + (size_t)i * g.ldx + j, nv, rx[b]);
+      }
+    }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= act_grad(g.dact, h[e]);
-  }
-  if (g.residual) {
-    float r[4] = {0.f, 0.f, 0.f, 0.f};
-    const T* rp = reinterpret_cast<const T*>(g.residual) + xo;
-    if (full) Vec4<T>::load(rp, r);
-    else for (int e = 0; e < nv; ++e) r[e] = to_f(rp[e]);
+    for (int b = 0; b < NB; ++b) {
+      const int i = ibase + b * 16 + il;
+      if (!FULL && i >= g.I) continue;
+      float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += r[e];
-  }
-  const size_t co = (size_t)i * g.ldc + j0;
-  if (g.c_f32) {
-    float* c = reinterpret_cast<float*>(g.C) + co;
-    if (full) Vec4<float>::store(c, v);
-    else for (int e = 0; e < nv; ++e) c[e] = v[e];
-  } else {
-    T* c = reinterpret_cast<T*>(g.C) + co;
-    if (full) Vec4<T>::store(c, v);
-    else for (int e = 0; e < nv; ++e) c[e] = from_f<T>(v[e]);
+      for (int e = 0; e < 4; ++e) v[e] = acc[a][b][e] * g.alpha + bz[e];
+      if (g.preact) st4<T>(reinterpret_cast<T*>(g.preact) + (size_t)i * g.ldx + j, nv, v);
+      if (g.act != EVLM_ACT_NONE) {
+        if (g.gate_pos == EVLM_GATE_PRE_ACT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_apply(g.act, v[e] * gz[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_apply(g.act, v[e]) * gz[e];
+        }
+      } else if (g.gate) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gz[e];
+      }
+      if (g.dact != EVLM_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= act_grad(g.dact, hx[b][e]);
+      }
+      if (g.residual) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += rx[b][e];
+      }
+      const size_t co = (size_t)i * g.ldc + j;
+      if (g.c_f32) st4<float>(reinterpret_cast<float*>(g.C) + co, nv, v);
+      else st4<T>(reinterpret_cast<T*>(g.C) + co, nv, v);
+    }
   }
 }
 
@@ -109,7 +123,7 @@ __device__ __forceinline__ void tile_coords(const GemmP& g, int& ti, int& tj) {
 #define TILE_BYTES (BT * BK * 2)   // 16 KiB per operand per stage
 
 // global -> registers: 4 x 16-byte chunks per thread per operand
-template <bool TR>
+template <bool TR, bool FULL>
 __device__ __forceinline__ void stage_load(const bf16* base, int ld, int rows, int K, int row0, int k0, int tid,
                                            uint4 r[4]) {
 #pragma unroll
@@ -126,7 +140,7 @@ __device__ __forceinline__ void stage_load(const bf16* base, int ld, int rows, i
       ok = (k0 + kr < K) && (row0 + cc * 8 < rows);
       p = base + (size_t)(k0 + kr) * ld + row0 + cc * 8;
     }
-    r[c] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+    r[c] = (FULL || ok) ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
   }
 }
 
@@ -171,18 +185,14 @@ __device__ __forceinline__ bf16x8 frag_read(const char* sm, int rt, int ks, int 
   }
 }
 
-template <bool PT, bool QT>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][P tile | Q tile]
+template <bool PT, bool QT, bool FULL>
+__device__ __forceinline__ void gemm_bf16_body(const GemmP& g, char* smem, int i0, int j0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave & 1, wj = wave >> 1;
-  int ti, tj;
-  tile_coords(g, ti, tj);
-  const int i0 = ti * BT, j0 = tj * BT;
   const bf16* P = reinterpret_cast<const bf16*>(g.P);
   const bf16* Q = reinterpret_cast<const bf16*>(g.Q);
 
-  f32x4 acc[4][4];   // [tj][ti] : D rows = j (Q side), D cols = i (P side)
+  f32x4 acc[4][4];   // [a: j tile][b: i tile] : D rows = j (Q side), D cols = i (P side)
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -190,8 +200,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP g) {
 
   uint4 rp[4], rq[4];
   const int nt = (g.K + BK - 1) / BK;
-  stage_load<PT>(P, g.ldp, g.I, g.K, i0, 0, tid, rp);
-  stage_load<QT>(Q, g.ldq, g.J, g.K, j0, 0, tid, rq);
+  stage_load<PT, FULL>(P, g.ldp, g.I, g.K, i0, 0, tid, rp);
+  stage_load<QT, FULL>(Q, g.ldq, g.J, g.K, j0, 0, tid, rq);
   stage_store<PT>(smem, tid, rp);
   stage_store<QT>(smem + TILE_BYTES, tid, rq);
   __syncthreads();
@@ -200,8 +210,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP g) {
     const char* sp = smem + (t & 1) * 2 * TILE_BYTES;
     const char* sq = sp + TILE_BYTES;
     if (t + 1 < nt) {   // issue next tile's global loads before the MFMA block (latency hides under it)
-      stage_load<PT>(P, g.ldp, g.I, g.K, i0, (t + 1) * BK, tid, rp);
-      stage_load<QT>(Q, g.ldq, g.J, g.K, j0, (t + 1) * BK, tid, rq);
+      stage_load<PT, FULL>(P, g.ldp, g.I, g.K, i0, (t + 1) * BK, tid, rp);
+      stage_load<QT, FULL>(Q, g.ldq, g.J, g.K, j0, (t + 1) * BK, tid, rq);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -224,17 +234,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP g) {
     }
     __syncthreads();
   }
+  tile_epilogue<bf16, 4, 4, FULL>(g, acc, i0 + wi * 64, j0 + wj * 64, lane);
+}
 
-  // D map: col (i) = lane & 15, row (j) = (lane >> 4) * 4 + reg
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int i = i0 + wi * 64 + b * 16 + (lane & 15);
-      const int j = j0 + wj * 64 + a * 16 + (lane >> 4) * 4;
-      float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-      epilogue4<bf16>(g, i, j, v);
-    }
+template <bool PT, bool QT>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][P tile | Q tile]
+  int ti, tj;
+  tile_coords(g, ti, tj);
+  const int i0 = ti * BT, j0 = tj * BT;
+  // wave-uniform: interior tiles (everything in bounds, K a multiple of the K tile) take the unpredicated path
+  const bool full = (i0 + BT <= g.I) && (j0 + BT <= g.J) && (g.K % BK == 0);
+  if (full) gemm_bf16_body<PT, QT, true>(g, smem, i0, j0);
+  else gemm_bf16_body<PT, QT, false>(g, smem, i0, j0);
 }
 
 // =============================================================================================
@@ -307,15 +319,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP g) {
     }
     __syncthreads();
   }
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int i = i0 + wi * 32 + b * 16 + (lane & 15);
-      const int j = j0 + wj * 32 + a * 16 + (lane >> 4) * 4;
-      float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-      epilogue4<float>(g, i, j, v);
-    }
+  tile_epilogue<float, 2, 2, false>(g, acc, i0 + wi * 32, j0 + wj * 32, lane);
 }
 
 // =============================================================================================

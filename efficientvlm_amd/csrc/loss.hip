@@ -287,7 +287,8 @@ extern "C" int evlm_sumsq(const float* x, int64_t n, float* out, void* stream_) 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2, const float* __restrict__ gnorm_sq,
-                                                    float max_norm, bf16* __restrict__ pb) {
+                                                    float max_norm, bf16* __restrict__ pb, const float* __restrict__ hyper) {
+  if (hyper) { lr *= hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }   // per-step scalars from device memory (graph replay)
   float clip = 1.0f;
   if (gnorm_sq && max_norm > 0.f) clip = fminf(1.0f, max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f));
   const float step = lr * sqrtf(bc2) / bc1;   // transformers.AdamW: step_size = lr * sqrt(bc2) / bc1
@@ -304,11 +305,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 extern "C" int evlm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                                float eps, float weight_decay, float bias_c1, float bias_c2, const float* gnorm_sq,
-                               float max_norm, void* p_bf16, void* stream_) {
+                               float max_norm, void* p_bf16, const float* hyper, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(p && g && m && v && n > 0, "evlm_adamw_step: bad args");
   const int grid = imin(4096, (n + 255) / 256);
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2, gnorm_sq, max_norm, (bf16*)p_bf16);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2, gnorm_sq, max_norm, (bf16*)p_bf16, hyper);
   EVLM_LAUNCH_CHECK("evlm_adamw_step");
   return 0;
 }

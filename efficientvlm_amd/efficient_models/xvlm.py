@@ -401,7 +401,8 @@ class XVLMBase(nn.Module):
                                              text_atts=text_atts_all, **zkw)
         cls_rows = torch.cat([pos_last[:, 0, :], neg_last[:, 0, :]], dim=0)
         output = mlp_head_forward(self.itm_head, cls_rows)
-        itm_labels = torch.cat([torch.ones(bs, dtype=torch.long), torch.zeros(2 * bs, dtype=torch.long)], dim=0).to(image_embeds.device)
+        dev = image_embeds.device
+        itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
         matching_loss = ops.cross_entropy(output, itm_labels)
         if not output_hidden_states:
             return matching_loss

@@ -65,6 +65,8 @@ class WeightCache:
 
 
 CACHE = WeightCache()
+# set to a list to time every GEMM launch with HIP events on the launch stream (bench.py roofline leg)
+GEMM_PROFILE = None
 
 
 def _as2d(x):
@@ -97,7 +99,14 @@ def _gemm(dtype, P, Q, Cm, I, J, K, ldp, ldq, ldc, p_trans=0, q_trans=0, bias=No
                    ldc=ldc, ldx=ldx, P=L.ptr(P), Q=L.ptr(Q), C=L.ptr(Cm), bias=L.ptr(bias), gate=L.ptr(gate),
                    preact=L.ptr(preact), aux=L.ptr(aux), residual=L.ptr(residual), alpha=alpha, act=act,
                    gate_pos=gate_pos, dact=dact)
+    if GEMM_PROFILE is None:
+        L.check(_lib().evlm_gemm(C.byref(a), L.stream()), "gemm")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     L.check(_lib().evlm_gemm(C.byref(a), L.stream()), "gemm")
+    e1.record()
+    GEMM_PROFILE.append((dtype, p_trans, q_trans, I, J, K, e0, e1))
 
 
 def _colsum(x2d, I, J, ld):

@@ -1,0 +1,110 @@
+"""Optimiser for the distillation step — the reference's optim.py:create_optimizer parameter grouping
+(decay / no-decay x lr / lr*lr_mult for `model.init_params`) with HF-AdamW semantics (betas (0.9, 0.98), eps 1e-8, Adam
+update then decoupled decay) and the accelerator's global-norm clipping (apex_ddp_accelerator.py:99-102), executed by
+two HIP kernels per group over FLAT fp32 buffers (evlm_sumsq, evlm_adamw_step).
+
+MI355X-first layout: every trainable parameter and its gradient are views into one contiguous fp32 slab per group, so
+ - the optimiser is 2 launches per group instead of ~400 tensor-wise launches,
+ - data-parallel gradient reduction is a handful of large RCCL all-reduces over contiguous memory (no bucket copies),
+ - zeroing gradients is one memset.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight", "norm.bias", "norm.weight", "norm1.bias", "norm1.weight",
+            "norm2.bias", "norm2.weight")   # optim.py:35-43 (substring match)
+
+
+class FlatAdamW:
+    def __init__(self, model, lr=1e-4, weight_decay=0.01, lr_mult=1.0, betas=(0.9, 0.98), eps=1e-8, max_grad_norm=1.0):
+        self.betas, self.eps, self.max_grad_norm = betas, eps, max_grad_norm
+        large = set(getattr(model, "init_params", []) or [])
+        groups = [dict(weight_decay=weight_decay, lr=lr, params=[], names=[]),
+                  dict(weight_decay=0.0, lr=lr, params=[], names=[]),
+                  dict(weight_decay=weight_decay, lr=lr * lr_mult, params=[], names=[]),
+                  dict(weight_decay=0.0, lr=lr * lr_mult, params=[], names=[])]
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        for n, p in reversed(named):          # reverse forward order ~ the order gradients become ready in backward
+            nd = any(s in n for s in NO_DECAY)
+            gi = (3 if n in large else 1) if nd else (2 if n in large else 0)
+            groups[gi]["params"].append(p)
+            groups[gi]["names"].append(n)
+        self.groups = [g for g in groups if g["params"]]
+        self.step_count = 0
+        dev = named[0][1].device
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.hyper = torch.ones(3, dtype=torch.float32, device=dev)       # {lr multiplier, bias_c1, bias_c2}
+        self._hyper_host = torch.ones(3, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.ones(3)
+        for g in self.groups:
+            n = sum((p.numel() + 3) // 4 * 4 for p in g["params"])          # 16-byte aligned segments
+            g["p"] = torch.zeros(n, dtype=torch.float32, device=dev)
+            g["g"] = torch.zeros(n, dtype=torch.float32, device=dev)
+            g["m"] = torch.zeros(n, dtype=torch.float32, device=dev)
+            g["v"] = torch.zeros(n, dtype=torch.float32, device=dev)
+            off = 0
+            for p in g["params"]:
+                k = p.numel()
+                g["p"][off:off + k].copy_(p.data.reshape(-1))
+                p.data = g["p"][off:off + k].view(p.shape)
+                p.grad = g["g"][off:off + k].view(p.shape)
+                off += (k + 3) // 4 * 4
+        ops.CACHE.invalidate()
+
+    @property
+    def flat_grads(self):
+        return [g["g"] for g in self.groups]
+
+    def zero_grad(self):
+        for g in self.groups:
+            g["g"].zero_()
+
+    def set_schedule(self, lr_mult=1.0):
+        """host-side per-step scalars -> device (call OUTSIDE a captured graph, before replay)"""
+        self.step_count += 1
+        b1, b2 = self.betas
+        self._hyper_host[0] = lr_mult
+        self._hyper_host[1] = 1.0 - b1 ** self.step_count
+        self._hyper_host[2] = 1.0 - b2 ** self.step_count
+        self.hyper.copy_(self._hyper_host, non_blocking=True)
+
+    def step(self):
+        """clip by global norm + AdamW; pure device work (capturable).  Gradients must live in the flat slabs."""
+        lib = L.load()
+        for g in self.groups:               # autograd may have re-pointed .grad if a view was replaced: re-anchor
+            off = 0
+            for p in g["params"]:
+                k = p.numel()
+                if p.grad is not None and p.grad.data_ptr() != g["g"].data_ptr() + off * 4:
+                    g["g"][off:off + k].copy_(p.grad.reshape(-1))
+                    p.grad = g["g"][off:off + k].view(p.shape)
+                off += (k + 3) // 4 * 4
+        self.gnorm_sq.zero_()
+        for g in self.groups:
+            L.check(lib.evlm_sumsq(L.ptr(g["g"]), g["g"].numel(), L.ptr(self.gnorm_sq), L.stream()), "sumsq")
+        b1, b2 = self.betas
+        for g in self.groups:
+            L.check(lib.evlm_adamw_step(L.ptr(g["p"]), L.ptr(g["g"]), L.ptr(g["m"]), L.ptr(g["v"]), g["p"].numel(),
+                                        g["lr"], b1, b2, self.eps, g["weight_decay"], 1.0, 1.0, L.ptr(self.gnorm_sq),
+                                        float(self.max_grad_norm or 0.0), None, L.ptr(self.hyper), L.stream()), "adamw")
+        ops.CACHE.invalidate()
+
+    def grad_norm(self):
+        return self.gnorm_sq.sqrt()
+
+
+def create_optimizer(args, model, max_grad_norm=1.0):
+    """optim.py:23-69 signature (args.lr, args.weight_decay, args.lr_mult)"""
+    get = (lambda k, d=None: args.get(k, d)) if isinstance(args, dict) else (lambda k, d=None: getattr(args, k, d))
+    return FlatAdamW(model, lr=get("lr"), weight_decay=get("weight_decay"), lr_mult=get("lr_mult", 1),
+                     max_grad_norm=max_grad_norm)
+
+
+def linear_schedule(step, num_warmup_steps, num_training_steps):
+    """scheduler.py:14-22 (LambdaLR factor)"""
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - num_warmup_steps)))

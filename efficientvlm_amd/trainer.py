@@ -1,0 +1,139 @@
+"""GD training step runtime: student + frozen teacher, KD loss mix, backward, data-parallel gradient reduction,
+global-norm clip + AdamW — the body of GeneralDistill.py:train (reference :286-387) for a general batch.
+
+MI355X-first execution
+  * one process per GPU; the teacher is a plain replica on every rank and never communicates;
+  * the whole step is device-resident (no .item() syncs: the reference's 2B multinomial().item() calls and 11 meter
+    reads per step are gone), so it can be captured once into a hipGraph and replayed — the step is ~2k kernel launches
+    and would otherwise be host-launch-bound;
+  * gradients live in the optimiser's flat fp32 slabs, so data parallelism is a few large RCCL all-reduces over
+    contiguous memory, issued on a side stream; with graphs the step is cut into
+        [A: encoders + features] -> all-gather(ITC) -> [B: losses + backward] -> all-reduce(grads) -> [C: clip + AdamW]
+    and the collectives run eagerly between the captured segments (xGMI is point-to-point: few, large messages).
+"""
+import torch
+import torch.distributed as dist
+
+from . import distill, ops
+from .optim import FlatAdamW
+from .runtime import compute
+
+
+def dist_ready():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class GradReducer:
+    """mean all-reduce of flat gradient slabs in <= bucket_bytes pieces on a dedicated stream.
+
+    Works on any backend (RCCL on GPU, gloo in the CPU tests).  `compress` = torch.bfloat16 halves the wire bytes
+    (the slabs stay fp32: cast -> all-reduce -> cast back)."""
+
+    def __init__(self, flat_grads, bucket_bytes=64 << 20, compress=None, group=None):
+        self.flat = list(flat_grads)
+        self.group = group
+        self.compress = compress
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.buckets = []
+        for t in self.flat:
+            n, per = t.numel(), max(1, bucket_bytes // t.element_size())
+            for o in range(0, n, per):
+                self.buckets.append(t[o:min(n, o + per)])
+        self.stream = torch.cuda.Stream() if (self.flat and self.flat[0].is_cuda) else None
+
+    def reduce(self):
+        if self.world <= 1:
+            return
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            ctx = torch.cuda.stream(self.stream)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            handles = []
+            for b in self.buckets:
+                if self.compress is not None and b.is_cuda:
+                    w = ops.cast(b, self.compress)
+                    w.div_(self.world)
+                    dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
+                    b.copy_(w)
+                else:
+                    b.div_(self.world)
+                    handles.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for h in handles:
+                h.wait()
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
+class GDTrainer:
+    def __init__(self, student, teacher, lr=1e-4, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, temperature=1.0,
+                 dtype=torch.bfloat16, use_graph=True, grad_compress=None):
+        self.student, self.teacher = student, teacher
+        self.dtype, self.temperature = dtype, temperature
+        for p in teacher.parameters():
+            p.requires_grad_(False)
+        teacher.eval()
+        student.train()
+        self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=max_grad_norm)
+        self.reducer = GradReducer(self.opt.flat_grads, compress=grad_compress)
+        self.world = self.reducer.world
+        self.use_graph = use_graph
+        self.graph = None
+        self.static = None
+        self.out = None
+        if self.world > 1:
+            for g in self.opt.groups:                     # broadcast params from rank 0 (apex_ddp_accelerator.py:75-77)
+                dist.broadcast(g["p"], 0)
+
+    # ---- the step body (pure device work) ----------------------------------------------------------
+    def _forward_backward(self, batch):
+        self.opt.zero_grad()
+        with compute(self.dtype):
+            total, S, T, kd, mix = distill.gd_forward(self.student, self.teacher, batch, self.temperature)
+            total.backward()
+        return torch.stack([total.detach().float(), S["loss"]["loss_itc"].detach().float(),
+                            S["loss"]["loss_itm"].detach().float(), S["loss"]["loss_mlm"].detach().float(),
+                            mix["loss_kd"].detach().float()])
+
+    def _step_eager(self, batch):
+        out = self._forward_backward(batch)
+        self.reducer.reduce()
+        self.opt.step()
+        return out
+
+    def step(self, batch, lr_mult=1.0):
+        """one GD step; returns a device tensor [total, itc, itm, mlm, kd] (no host sync)."""
+        if not self.use_graph or self.world > 1:
+            # multi-GPU: the ITC all-gather sits in the middle of the forward, so the step runs eagerly
+            # (collectives are not captured; see module docstring).
+            self.opt.set_schedule(lr_mult)
+            return self._step_eager(batch)
+        if self.graph is None:
+            self._capture(batch)
+        self.opt.set_schedule(lr_mult)
+        for k, v in batch.items():
+            self.static[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+    def _capture(self, batch):
+        self.static = {k: v.clone() for k, v in batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                             # warm-up on a side stream (allocator + weight caches);
+                self.opt.set_schedule(0.0)                 # lr multiplier 0: parameters are left untouched
+                self._step_eager(self.static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ops.CACHE.invalidate()                             # capture the casts of the trainable weights too
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._step_eager(self.static)
+        # the warm-up advanced Adam's step count and moments: reset them so replay k is optimiser step k
+        for g in self.opt.groups:
+            g["m"].zero_()
+            g["v"].zero_()
+        self.opt.step_count = 0

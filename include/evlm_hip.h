@@ -220,10 +220,12 @@ int evlm_l0_deterministic(const float* loga, int rows, int size, float temperatu
 /* *out += sum(x^2) over n f32 values (global grad norm, apex_ddp_accelerator.py:99-102) */
 int evlm_sumsq(const float* x, int64_t n, float* out, void* stream);
 /* HF-AdamW step (optim.py:67, transformers AdamW: Adam update then p -= lr*wd*p), with the gradient
- * pre-scaled by min(1, max_norm/ (sqrt(*gnorm_sq)+1e-6)); also refreshes the bf16 compute copy. */
+ * pre-scaled by min(1, max_norm/ (sqrt(*gnorm_sq)+1e-6)) (clip_grad_norm_, apex_ddp_accelerator.py:99-102); optionally
+ * refreshes a bf16 copy.  hyper (device f32[3] or NULL) = {lr multiplier, bias_c1, bias_c2}: when given it overrides the
+ * host bias corrections and scales lr, so a captured hipGraph can be replayed with per-step schedules. */
 int evlm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, float bias_c1, float bias_c2, const float* gnorm_sq,
-                    float max_norm, void* p_bf16, void* stream);
+                    float max_norm, void* p_bf16, const float* hyper, void* stream);
 
 #ifdef __cplusplus
 }
