@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
 class AttnFwdArgs(C.Structure):
     _fields_ = [("dtype", _i), ("p_dtype", _i),
                 ("B", _i), ("H", _i), ("Lq", _i), ("Lk", _i), ("dh", _i),
-                ("ldq", _i), ("ldk", _i), ("ldv", _i), ("ldo", _i),
+                ("ldq", _i), ("ldk", _i), ("ldv", _i), ("ldo", _i), ("ldpr", _i),
                 ("Q", _vp), ("K", _vp), ("V", _vp), ("kv_index", _vp), ("mask", _vp), ("head_gate", _vp),
                 ("scale", _f), ("O", _vp), ("P", _vp)]
 
@@ -39,7 +39,7 @@ class AttnBwdArgs(C.Structure):
     _fields_ = [("dtype", _i), ("p_dtype", _i),
                 ("B", _i), ("H", _i), ("Lq", _i), ("Lk", _i), ("dh", _i),
                 ("ldq", _i), ("ldk", _i), ("ldv", _i), ("ldo", _i),
-                ("lddq", _i), ("lddk", _i), ("lddv", _i),
+                ("lddq", _i), ("lddk", _i), ("lddv", _i), ("ldpr", _i),
                 ("Q", _vp), ("K", _vp), ("V", _vp), ("P", _vp), ("dO", _vp), ("dP_ext", _vp),
                 ("kv_index", _vp), ("head_gate", _vp), ("scale", _f),
                 ("dS", _vp), ("dQ", _vp), ("dK", _vp), ("dV", _vp), ("dgate", _vp)]

@@ -16,7 +16,7 @@
 struct AttnF {
   const void* Q; const void* K; const void* V; const int32_t* kv_index; const float* mask; const float* gate;
   void* O; void* P;
-  int B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo;
+  int B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, ldpr;
   float scale;
 };
 
@@ -82,12 +82,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnF a) {
     for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float inv = 1.0f / sum;
     const bool rowok = (q0 + r < a.Lq);
-    TP* Pr = reinterpret_cast<TP*>(a.P) + (((size_t)b * a.H + h) * a.Lq + (q0 + r)) * Lk;
+    TP* Pr = reinterpret_cast<TP*>(a.P) + (((size_t)b * a.H + h) * a.Lq + (q0 + r)) * a.ldpr;
     for (int k = kl; k < Lk; k += 16) {
       const float p = Ss[r * Lkp + k] * inv;
       Ss[r * Lkp + k] = p;
       if (rowok && a.P) Pr[k] = from_f<TP>(p);
     }
+    if (rowok && a.P) for (int k = Lk + kl; k < a.ldpr; k += 16) Pr[k] = from_f<TP>(0.f);
   }
   // O = P V
   float acc[AMAXU];
@@ -123,7 +124,7 @@ struct AttnB {
   const void* Q; const void* K; const void* V; const void* P; const void* dO; const void* dPext;
   const int32_t* kv_index; const float* gate;
   void* dS; void* dQ; void* dK; void* dV; float* dK32; float* dV32; float* dgate;
-  int B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+  int B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, ldpr;
   float scale;
 };
 
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnB a) {
   const T* Kb = reinterpret_cast<const T*>(a.K) + (size_t)bkv * Lk * a.ldk + h * dh;
   const T* Vb = reinterpret_cast<const T*>(a.V) + (size_t)bkv * Lk * a.ldv + h * dh;
   const bool rowok = (q0 + r < a.Lq);
-  const size_t prow = (((size_t)b * a.H + h) * a.Lq + (q0 + r)) * Lk;
+  const size_t prow = (((size_t)b * a.H + h) * a.Lq + (q0 + r)) * a.ldpr;
   const TP* Pr = reinterpret_cast<const TP*>(a.P) + prow;
   const TP* Er = a.dPext ? reinterpret_cast<const TP*>(a.dPext) + prow : nullptr;
 
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnB a) {
       }
       Ss[r * Lkp + k] = ds;
     }
+    if (rowok) for (int k = Lk + kl; k < a.ldpr; k += 16) dSr[k] = from_f<T>(0.f);
   }
   float acc[AMAXU];
 #pragma unroll
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnB a) {
   const int per = dh >> 2;               // d values per thread (contiguous block)
   const T* Qb = reinterpret_cast<const T*>(a.Q) + (size_t)b * a.Lq * a.ldq + h * dh;
   const T* dOb = reinterpret_cast<const T*>(a.dO) + (size_t)b * a.Lq * a.ldo + h * dh;
-  const size_t pbase = ((size_t)b * a.H + h) * a.Lq * Lk;
+  const size_t pbase = ((size_t)b * a.H + h) * a.Lq * a.ldpr;
   const TP* Pb = reinterpret_cast<const TP*>(a.P) + pbase;
   const T* dSb = reinterpret_cast<const T*>(a.dS) + pbase;
   float ak[32], av[32];
@@ -245,8 +247,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnB a) {
       const int rr = id >> 6, kk = id & 63;
       float ds = 0.f, p = 0.f;
       if (q0 + rr < a.Lq && k0 + kk < Lk) {
-        ds = to_f(dSb[(size_t)(q0 + rr) * Lk + k0 + kk]);
-        p = to_f(Pb[(size_t)(q0 + rr) * Lk + k0 + kk]);
+        ds = to_f(dSb[(size_t)(q0 + rr) * a.ldpr + k0 + kk]);
+        p = to_f(Pb[(size_t)(q0 + rr) * a.ldpr + k0 + kk]);
       }
       dSs[rr * (AKC + 1) + kk] = ds;
       Ps[rr * (AKC + 1) + kk] = p;
@@ -296,6 +298,7 @@ static int attn_check(int dtype, int p_dtype, int dh, const char* name) {
   else hipLaunchKernelGGL((KERNEL<float, bf16>), grid, block, lds, stream, arg);
 
 int evlm_attention_fwd_mfma(const evlm_attn_fwd_args* a, hipStream_t stream, int* handled);   // attention_mfma.hip
+int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int* handled);
 
 extern "C" int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -303,13 +306,14 @@ extern "C" int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream_) {
   if (int e = attn_check(a->dtype, a->p_dtype, a->dh, "evlm_attention_fwd")) return e;
   EVLM_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0, "evlm_attention_fwd: bad shape");
   EVLM_REQUIRE((a->ldq | a->ldk | a->ldv) % 8 == 0, "evlm_attention_fwd: row strides must be multiples of 8");
+  EVLM_REQUIRE(!a->P || (a->ldpr >= a->Lk && a->ldpr % 8 == 0), "evlm_attention_fwd: ldpr must be a multiple of 8 and >= Lk");
   int handled = 0;
   if (int e = evlm_attention_fwd_mfma(a, stream, &handled)) return e;
   if (handled) return 0;
   AttnF f;
   f.Q = a->Q; f.K = a->K; f.V = a->V; f.kv_index = a->kv_index; f.mask = a->mask; f.gate = a->head_gate;
   f.O = a->O; f.P = a->P; f.B = a->B; f.H = a->H; f.Lq = a->Lq; f.Lk = a->Lk; f.dh = a->dh;
-  f.ldq = a->ldq; f.ldk = a->ldk; f.ldv = a->ldv; f.ldo = a->ldo; f.scale = a->scale;
+  f.ldq = a->ldq; f.ldk = a->ldk; f.ldv = a->ldv; f.ldo = a->ldo; f.ldpr = a->ldpr; f.scale = a->scale;
   const int Lkp = (a->Lk + 3) & ~3;
   const size_t lds = sizeof(float) * ((size_t)(AQ + AKC) * (a->dh + 1) + (size_t)AQ * Lkp);
   EVLM_REQUIRE(lds <= 160 * 1024, "evlm_attention_fwd: Lk=%d too long for the LDS score block", a->Lk);
@@ -330,6 +334,12 @@ extern "C" int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream_) {
   EVLM_REQUIRE(a && a->Q && a->K && a->V && a->P && a->dO && a->dS && a->dQ, "evlm_attention_bwd: null operand");
   EVLM_REQUIRE(a->dK && a->dV, "evlm_attention_bwd: dK/dV required (f32 accumulators when kv_index is set)");
   if (int e = attn_check(a->dtype, a->p_dtype, a->dh, "evlm_attention_bwd")) return e;
+  EVLM_REQUIRE(a->ldpr >= a->Lk && a->ldpr % 8 == 0, "evlm_attention_bwd: ldpr must be a multiple of 8 and >= Lk");
+  {
+    int handled = 0;
+    if (int e = evlm_attention_bwd_mfma(a, stream, &handled)) return e;
+    if (handled) return 0;
+  }
   AttnB g;
   g.Q = a->Q; g.K = a->K; g.V = a->V; g.P = a->P; g.dO = a->dO; g.dPext = a->dP_ext; g.kv_index = a->kv_index;
   g.gate = a->head_gate; g.dS = a->dS; g.dQ = a->dQ; g.dgate = a->dgate;
@@ -337,7 +347,7 @@ extern "C" int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream_) {
   else { g.dK32 = nullptr; g.dV32 = nullptr; g.dK = a->dK; g.dV = a->dV; }
   g.B = a->B; g.H = a->H; g.Lq = a->Lq; g.Lk = a->Lk; g.dh = a->dh;
   g.ldq = a->ldq; g.ldk = a->ldk; g.ldv = a->ldv; g.ldo = a->ldo; g.lddq = a->lddq; g.lddk = a->lddk; g.lddv = a->lddv;
-  g.scale = a->scale;
+  g.scale = a->scale; g.ldpr = a->ldpr;
   const int Lkp = (a->Lk + 3) & ~3;
   const size_t ldsA = sizeof(float) * ((size_t)(AQ + AKC) * (a->dh + 1) + (size_t)AQ * Lkp);
   EVLM_REQUIRE(ldsA <= 160 * 1024, "evlm_attention_bwd: Lk=%d too long", a->Lk);

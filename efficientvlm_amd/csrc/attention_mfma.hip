@@ -1,9 +1,383 @@
-// MFMA (bf16) attention kernels for gfx950 — specialised shapes; everything else falls back to attention.hip.
+// bf16 MFMA attention kernels for gfx950 (head dim 64): the fast path behind evlm_attention_fwd / _bwd.
+//
+// Everything is computed TRANSPOSED (keys on the MFMA row index, queries on the lane's column index):
+//   S^T = K Q^T   -> each lane owns ONE query (lane & 15) and 4 keys per 16x16 tile, so a softmax row lives in one
+//                    lane's registers plus a 2-step shuffle over the 4 lane groups (no LDS round trip);
+//   O^T = V^T P^T -> the P^T accumulators are reused AS the MFMA B operand (same key<->k-slot assignment on both
+//                    operands), V^T comes from a row-major [key][d] LDS tile through ds_read_b64_tr_b16.
+// The probability map is an OUTPUT (the KD losses read it): rows are written once, with stride ldpr (padding zeroed).
 #include "common.h"
+
+struct MAttnF {
+  const bf16* Q; const bf16* K; const bf16* V; const int32_t* kv_index; const float* mask; const float* gate;
+  bf16* O; bf16* P;
+  int B, H, Lq, Lk, ldq, ldk, ldv, ldo, ldpr;
+  float scale;
+};
+
+#define DH 64
+
+// 16-byte chunk swizzles of the two row-major [key][64] bf16 tiles (128-byte rows)
+__device__ __forceinline__ int k_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }          // ds_read_b128 rows
+__device__ __forceinline__ int v_swz(int row, int chunk) { return chunk ^ (((row >> 1) & 3) << 1); }   // tr16 column reads
+
+// stage rows [0, nrows) of a [L][.. ld ..] tensor (64 columns at `base`) into a swizzled LDS tile; rows >= L are zero
+template <bool VSWZ>
+__device__ __forceinline__ void stage_rows(const bf16* base, int ld, int L, int nrows, char* sm) {
+  for (int id = threadIdx.x; id < nrows * 8; id += blockDim.x) {
+    const int row = id >> 3, c = id & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < L) v = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + c * 8);
+    const int cs = VSWZ ? v_swz(row, c) : k_swz(row, c);
+    *reinterpret_cast<uint4*>(sm + row * 128 + cs * 16) = v;
+  }
+}
+
+// A/B operand fragment (rows = keys, k = head dim) from a k_swz tile: row = 16*t + (lane&15), k = 32*ks + 8*(lane>>4)..+7
+__device__ __forceinline__ bf16x8 krow_frag(const char* sm, int t, int ks, int lane) {
+  const int row = t * 16 + (lane & 15), c = ks * 4 + (lane >> 4);
+  return *reinterpret_cast<const bf16x8*>(sm + row * 128 + k_swz(row, c) * 16);
+}
+// A operand = (tile)^T for a sum over KEYS: row index d = 16*dt + (lane&15); k-slots j=0..3 <-> keys 16*t0+4g+j,
+// j=4..7 <-> keys 16*t1+4g+(j-4)   (g = lane>>4).  `sm` is a v_swz tile.
+__device__ __forceinline__ bf16x8 vcol_frag(const char* sm, int t0, int t1, int dt, int lane) {
+  const int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3;
+  bf16x8 out;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = (h ? t1 : t0) * 16 + g * 4 + q;
+    const int off = row * 128 + v_swz(row, dt * 2 + (p >> 1)) * 16 + ((p & 1) << 3);
+    bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(sm + off));
+    out[4 * h + 0] = t[0]; out[4 * h + 1] = t[1]; out[4 * h + 2] = t[2]; out[4 * h + 3] = t[3];
+  }
+  return out;
+}
+
+// NT = number of 16-key tiles (even); one workgroup = 4 waves = 64 queries of one (batch, head)
+template <int NT>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(MAttnF a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;                          // [NT*16][64] bf16, k_swz
+  char* Vs = smem + NT * 16 * 128;          // [NT*16][64] bf16, v_swz
+  float* Ms = reinterpret_cast<float*>(smem + 2 * NT * 16 * 128);   // [NT*16] additive mask (+ -1e30 beyond Lk)
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
+  const int bkv = a.kv_index ? a.kv_index[b] : b;
+  const bf16* Kb = a.K + (size_t)bkv * a.Lk * a.ldk + h * DH;
+  const bf16* Vb = a.V + (size_t)bkv * a.Lk * a.ldv + h * DH;
+  stage_rows<false>(Kb, a.ldk, a.Lk, NT * 16, Ks);
+  stage_rows<true>(Vb, a.ldv, a.Lk, NT * 16, Vs);
+  for (int k = threadIdx.x; k < NT * 16; k += blockDim.x)
+    Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
+  __syncthreads();
+
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  if (q0 >= a.Lq) return;
+  const int q = q0 + ql;
+  const bool qok = q < a.Lq;
+  // B operand = Q^T: 8 consecutive head-dim values of this lane's query
+  bf16x8 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (qok) v = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + ks * 32 + g * 8);
+    qf[ks] = *reinterpret_cast<bf16x8*>(&v);
+  }
+  // S^T tiles: acc[t][r] = S[q][key = 16t + 4g + r]
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Ks, t, ks, lane), qf[ks], acc[t], 0, 0, 0);
+  }
+  // softmax over the keys of this lane's query: registers + the 4 lane groups
+  const float sc = a.scale * 1.44269504088896341f;   // exp(x) = exp2(x * log2 e)
+  float m = -3.0e38f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + t * 16 + g * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[t][r] = acc[t][r] * sc + mk[r] * 1.44269504088896341f;
+      m = fmaxf(m, acc[t][r]);
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[t][r] = exp2f(acc[t][r] - m);
+      sum += acc[t][r];
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  // P (bf16): 4 consecutive keys per lane per tile -> 8-byte stores; also the PV B operand
+  bf16x4 pk[NT];
+  bf16* Pr = a.P ? a.P + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr : nullptr;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pk[t][r] = (bf16)(acc[t][r] * inv);
+    const int kcol = t * 16 + g * 4;
+    if (Pr && qok && kcol < a.ldpr) *reinterpret_cast<bf16x4*>(Pr + kcol) = pk[t];
+  }
+  // O^T[d][q] = sum_key V[key][d] * P[q][key]
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NT / 2; ++s) {
+    bf16x8 pb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pb[r] = pk[2 * s][r]; pb[4 + r] = pk[2 * s + 1][r]; }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Vs, 2 * s, 2 * s + 1, dt, lane), pb, o[dt], 0, 0, 0);
+  }
+  if (qok) {
+    const float gz = a.gate ? a.gate[h] : 1.0f;
+    bf16* Or = a.O + ((size_t)b * a.Lq + q) * a.ldo + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 ov = {(bf16)(o[dt][0] * gz), (bf16)(o[dt][1] * gz), (bf16)(o[dt][2] * gz), (bf16)(o[dt][3] * gz)};
+      *reinterpret_cast<bf16x4*>(Or + dt * 16 + g * 4) = ov;
+    }
+  }
+}
+
+template <int NT>
+static int launch_fwd(const MAttnF& f, hipStream_t stream) {
+  const size_t lds = (size_t)2 * NT * 16 * 128 + (size_t)NT * 16 * sizeof(float);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dim3 grid((f.Lq + 63) / 64, f.H, f.B), block(256);
+  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT>), grid, block, lds, stream, f);
+  return 0;
+}
+
+// =============================================================================================
+// backward
+// =============================================================================================
+struct MAttnB {
+  const bf16* Q; const bf16* K; const bf16* V; const bf16* P; const bf16* dO; const bf16* E; const float* gate;
+  bf16* dS; bf16* dQ; bf16* dK; bf16* dV; float* dgate;
+  int B, H, Lq, Lk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, ldpr;
+  float scale;
+};
+
+// kernel A: same shape as the forward (a wave owns 16 queries and ALL keys):
+//   dPo^T = V dO^T ;  dP = gate*dPo + E ;  delta = rowsum(P .* dP) ;  dS = P .* (dP - delta) -> HBM (for kernel B)
+//   dQ^T  = scale * K^T dS^T           (dS^T accumulators reused as the MFMA B operand, K^T through tr16 reads)
+template <int NT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(MAttnB a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;                          // v_swz (column reads)
+  char* Vs = smem + NT * 16 * 128;          // k_swz (row reads)
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
+  stage_rows<true>(a.K + (size_t)b * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
+  stage_rows<false>(a.V + (size_t)b * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
+  __syncthreads();
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  if (q0 >= a.Lq) return;
+  const int q = q0 + ql;
+  const bool qok = q < a.Lq;
+  bf16x8 dof[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (qok) v = *reinterpret_cast<const uint4*>(a.dO + ((size_t)b * a.Lq + q) * a.ldo + h * DH + ks * 32 + g * 8);
+    dof[ks] = *reinterpret_cast<bf16x8*>(&v);
+  }
+  const size_t prow = (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr;
+  const float gz = a.gate ? a.gate[h] : 1.0f;
+  f32x4 acc[NT];
+  bf16x4 pv[NT];
+  float dsum = 0.f, gsum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, t, ks, lane), dof[ks], acc[t], 0, 0, 0);
+    const int kcol = t * 16 + g * 4;
+    const bool ok = qok && kcol < a.ldpr;
+    bf16x4 ev = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    pv[t] = ev;
+    if (ok) {
+      pv[t] = *reinterpret_cast<const bf16x4*>(a.P + prow + kcol);
+      if (a.E) ev = *reinterpret_cast<const bf16x4*>(a.E + prow + kcol);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = (float)pv[t][r], dpo = acc[t][r];
+      gsum += p * dpo;
+      const float dp = gz * dpo + (float)ev[r];
+      acc[t][r] = dp;
+      dsum += p * dp;
+    }
+  }
+  dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
+  if (a.dgate) {
+    float gs = (g == 0) ? 0.f : 0.f;
+    gs = gsum;                                   // every lane holds a partial over its keys; the wave sum is the total
+    gs = wave_sum(gs);
+    if (lane == 0) atomicAdd(a.dgate + h, gs);
+  }
+  bf16x4 dsk[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dsk[t][r] = (bf16)((float)pv[t][r] * (acc[t][r] - dsum));
+    const int kcol = t * 16 + g * 4;
+    if (qok && kcol < a.ldpr) *reinterpret_cast<bf16x4*>(a.dS + prow + kcol) = dsk[t];
+  }
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NT / 2; ++s) {
+    bf16x8 pb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pb[r] = dsk[2 * s][r]; pb[4 + r] = dsk[2 * s + 1][r]; }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Ks, 2 * s, 2 * s + 1, dt, lane), pb, o[dt], 0, 0, 0);
+  }
+  if (qok) {
+    bf16* dQr = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 ov = {(bf16)(o[dt][0] * a.scale), (bf16)(o[dt][1] * a.scale), (bf16)(o[dt][2] * a.scale), (bf16)(o[dt][3] * a.scale)};
+      *reinterpret_cast<bf16x4*>(dQr + dt * 16 + g * 4) = ov;
+    }
+  }
+}
+
+// kernel B: one workgroup = 64 keys of one (batch, head); wave w owns key tile w.  Sums over the queries in chunks of 32:
+//   dK^T[d][key] = scale * sum_q Q[q][d] dS[q][key] ;  dV^T[d][key] = gate * sum_q dO[q][d] P[q][key]
+// All four operands are [32 q][64] bf16 LDS tiles read by COLUMNS (ds_read_b64_tr_b16): the reduction index (q) is
+// the row index of every tile.
+__device__ __forceinline__ int p_swz(int row, int chunk) { return chunk ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1); }
+
+// stage a [32 rows][64 cols] tile: row r = source row (r0 + r) (zero if >= nrows), 8 chunks of 8 columns, col chunk c valid
+// iff c0 + 8c < ncols
+__device__ __forceinline__ void stage_qtile(const bf16* base, size_t ld, int r0, int nrows, int c0, int ncols, char* sm) {
+  const int id = threadIdx.x;            // 256 threads = 32 rows x 8 chunks
+  const int row = id >> 3, c = id & 7;
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (r0 + row < nrows && c0 + c * 8 < ncols) v = *reinterpret_cast<const uint4*>(base + (size_t)(r0 + row) * ld + c0 + c * 8);
+  *reinterpret_cast<uint4*>(sm + row * 128 + p_swz(row, c) * 16) = v;
+}
+// operand with k-slot j <-> tile row 8g + j and row/col index = tile column 16*ct + (lane&15)
+__device__ __forceinline__ bf16x8 qcol_frag(const char* sm, int ct, int lane) {
+  const int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3;
+  bf16x8 out;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = g * 8 + h * 4 + q;
+    const int off = row * 128 + p_swz(row, ct * 2 + (p >> 1)) * 16 + ((p & 1) << 3);
+    bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(sm + off));
+    out[4 * h + 0] = t[0]; out[4 * h + 1] = t[1]; out[4 * h + 2] = t[2]; out[4 * h + 3] = t[3];
+  }
+  return out;
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
+  __shared__ __attribute__((aligned(16))) char sm[4 * 32 * 128];
+  char* Qs = sm; char* dOs = sm + 4096; char* Ps = sm + 8192; char* Ss = sm + 12288;
+  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const bf16* Qb = a.Q + (size_t)b * a.Lq * a.ldq + h * DH;
+  const bf16* dOb = a.dO + (size_t)b * a.Lq * a.ldo + h * DH;
+  const size_t pbase = ((size_t)b * a.H + h) * a.Lq * a.ldpr;
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  for (int q0 = 0; q0 < a.Lq; q0 += 32) {
+    __syncthreads();
+    stage_qtile(Qb, a.ldq, q0, a.Lq, 0, DH, Qs);
+    stage_qtile(dOb, a.ldo, q0, a.Lq, 0, DH, dOs);
+    stage_qtile(a.P + pbase, a.ldpr, q0, a.Lq, k0, a.ldpr, Ps);
+    stage_qtile(a.dS + pbase, a.ldpr, q0, a.Lq, k0, a.ldpr, Ss);
+    __syncthreads();
+    const bf16x8 bS = qcol_frag(Ss, wave, lane), bP = qcol_frag(Ps, wave, lane);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qcol_frag(Qs, dt, lane), bS, dk[dt], 0, 0, 0);
+      dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qcol_frag(dOs, dt, lane), bP, dv[dt], 0, 0, 0);
+    }
+  }
+  const int key = k0 + wave * 16 + (lane & 15);
+  if (key < a.Lk) {
+    const float gz = a.gate ? a.gate[h] : 1.0f;
+    bf16* dKr = a.dK + ((size_t)b * a.Lk + key) * a.lddk + h * DH;
+    bf16* dVr = a.dV + ((size_t)b * a.Lk + key) * a.lddv + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 kv = {(bf16)(dk[dt][0] * a.scale), (bf16)(dk[dt][1] * a.scale), (bf16)(dk[dt][2] * a.scale), (bf16)(dk[dt][3] * a.scale)};
+      bf16x4 vv = {(bf16)(dv[dt][0] * gz), (bf16)(dv[dt][1] * gz), (bf16)(dv[dt][2] * gz), (bf16)(dv[dt][3] * gz)};
+      *reinterpret_cast<bf16x4*>(dKr + dt * 16 + g * 4) = kv;
+      *reinterpret_cast<bf16x4*>(dVr + dt * 16 + g * 4) = vv;
+    }
+  }
+}
+
+template <int NT>
+static void launch_bwd_dq(const MAttnB& f, hipStream_t stream) {
+  const size_t lds = (size_t)2 * NT * 16 * 128;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dim3 grid((f.Lq + 63) / 64, f.H, f.B), block(256);
+  hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NT>), grid, block, lds, stream, f);
+}
+
+int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int* handled) {
+  *handled = 0;
+  if (a->dtype != EVLM_BF16 || a->p_dtype != EVLM_BF16 || a->dh != DH || a->Lk > 608 || a->kv_index) return 0;
+  if ((a->ldq | a->ldk | a->ldv | a->ldo | a->lddq | a->lddk | a->lddv | a->ldpr) % 8 != 0) return 0;
+  MAttnB f;
+  f.Q = (const bf16*)a->Q; f.K = (const bf16*)a->K; f.V = (const bf16*)a->V; f.P = (const bf16*)a->P;
+  f.dO = (const bf16*)a->dO; f.E = (const bf16*)a->dP_ext; f.gate = a->head_gate;
+  f.dS = (bf16*)a->dS; f.dQ = (bf16*)a->dQ; f.dK = (bf16*)a->dK; f.dV = (bf16*)a->dV; f.dgate = a->dgate;
+  f.B = a->B; f.H = a->H; f.Lq = a->Lq; f.Lk = a->Lk; f.ldq = a->ldq; f.ldk = a->ldk; f.ldv = a->ldv; f.ldo = a->ldo;
+  f.lddq = a->lddq; f.lddk = a->lddk; f.lddv = a->lddv; f.ldpr = a->ldpr; f.scale = a->scale;
+  if (a->Lk <= 32) launch_bwd_dq<2>(f, stream);
+  else if (a->Lk <= 64) launch_bwd_dq<4>(f, stream);
+  else if (a->Lk <= 224) launch_bwd_dq<14>(f, stream);
+  else if (a->Lk <= 416) launch_bwd_dq<26>(f, stream);
+  else launch_bwd_dq<38>(f, stream);
+  dim3 gridB((a->Lk + 63) / 64, a->H, a->B), block(256);
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, gridB, block, 0, stream, f);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return evlm_set_error("evlm_attention_bwd(mfma): %s", hipGetErrorString(e));
+  *handled = 1;
+  return 0;
+}
 
 // returns 0 and sets *handled = 1 when a specialised kernel took the call
 int evlm_attention_fwd_mfma(const evlm_attn_fwd_args* a, hipStream_t stream, int* handled) {
-  (void)a; (void)stream;
   *handled = 0;
+  if (a->dtype != EVLM_BF16 || a->p_dtype != EVLM_BF16 || a->dh != DH || a->Lk > 608) return 0;
+  if ((a->ldq | a->ldk | a->ldv | a->ldo) % 8 != 0 || (a->P && a->ldpr % 8 != 0)) return 0;
+  MAttnF f;
+  f.Q = (const bf16*)a->Q; f.K = (const bf16*)a->K; f.V = (const bf16*)a->V; f.kv_index = a->kv_index;
+  f.mask = a->mask; f.gate = a->head_gate; f.O = (bf16*)a->O; f.P = (bf16*)a->P;
+  f.B = a->B; f.H = a->H; f.Lq = a->Lq; f.Lk = a->Lk; f.ldq = a->ldq; f.ldk = a->ldk; f.ldv = a->ldv; f.ldo = a->ldo;
+  f.ldpr = a->ldpr; f.scale = a->scale;
+  if (a->Lk <= 32) launch_fwd<2>(f, stream);
+  else if (a->Lk <= 64) launch_fwd<4>(f, stream);
+  else if (a->Lk <= 224) launch_fwd<14>(f, stream);
+  else if (a->Lk <= 416) launch_fwd<26>(f, stream);
+  else launch_fwd<38>(f, stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return evlm_set_error("evlm_attention_fwd(mfma): %s", hipGetErrorString(e));
+  *handled = 1;
   return 0;
 }

@@ -330,16 +330,18 @@ class _Attention(torch.autograd.Function):
         dev, tdt = qbuf.device, qbuf.dtype
         O = torch.empty((B, Lq, H * dh), dtype=tdt, device=dev)
         need = any(ctx.needs_input_grad)
-        P = torch.empty((B, H, Lq, Lk), dtype=tdt, device=dev) if (want_probs or need) else None
+        Lkp = _pad8(Lk)          # probability rows are padded to 16 bytes; the kernels zero the padding
+        Pbuf = torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev) if (want_probs or need) else None
+        P = (Pbuf[..., :Lk] if Lkp != Lk else Pbuf) if Pbuf is not None else None
         m32 = mask.detach().to(torch.float32).contiguous() if mask is not None else None
         g32 = gate.detach().reshape(-1).to(torch.float32).contiguous() if gate is not None else None
         es = qbuf.element_size()
         a = L.AttnFwdArgs(dtype=L.dt(tdt), p_dtype=L.dt(tdt), B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, ldq=ldq, ldk=ldk, ldv=ldk,
-                          ldo=H * dh, Q=C.c_void_p(qbuf.data_ptr() + q_off * es), K=C.c_void_p(kvbuf.data_ptr() + k_off * es),
-                          V=C.c_void_p(kvbuf.data_ptr() + v_off * es), kv_index=None, mask=L.ptr(m32), head_gate=L.ptr(g32),
-                          scale=scale, O=L.ptr(O), P=L.ptr(P))
+                          ldo=H * dh, ldpr=Lkp, Q=C.c_void_p(qbuf.data_ptr() + q_off * es),
+                          K=C.c_void_p(kvbuf.data_ptr() + k_off * es), V=C.c_void_p(kvbuf.data_ptr() + v_off * es),
+                          kv_index=None, mask=L.ptr(m32), head_gate=L.ptr(g32), scale=scale, O=L.ptr(O), P=L.ptr(Pbuf))
         L.check(_lib().evlm_attention_fwd(C.byref(a), L.stream()), "attention_fwd")
-        ctx.save_for_backward(qbuf, kvbuf, P, g32)
+        ctx.save_for_backward(qbuf, kvbuf, Pbuf, g32)
         ctx.meta = (H, dh, q_off, k_off, v_off, scale, qbuf is kvbuf or qbuf.data_ptr() == kvbuf.data_ptr(),
                     gate.shape if gate is not None else None)
         return O, P
@@ -353,19 +355,21 @@ class _Attention(torch.autograd.Function):
         dev, tdt = qbuf.device, qbuf.dtype
         es = qbuf.element_size()
         dOc = dO if dO.is_contiguous() else dO.contiguous()
+        Lkp = P.shape[-1]
         dPc = None
         if dP is not None:
-            dPc = dP if dP.is_contiguous() else dP.contiguous()
-            if dPc.dtype != tdt:
-                dPc = dPc.to(tdt)
+            dPc = _padded_base(dP, Lkp)          # the KD loss hands back a view of a padded buffer: no copy
+            if dPc is None:
+                dPc = torch.zeros((B, H, Lq, Lkp), dtype=tdt, device=dev)
+                dPc[..., :Lk].copy_(dP)
         d = H * dh
         assert ldq == (3 * d if self_attn else d) and ldk == (3 * d if self_attn else 2 * d), "packed buffers must be exact"
         dqbuf = torch.empty_like(qbuf)                       # the kernels write every element of the packed grads
         dkvbuf = dqbuf if self_attn else torch.empty_like(kvbuf)
-        dS = torch.empty((B, H, Lq, Lk), dtype=tdt, device=dev)
+        dS = torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev)
         dgate = torch.zeros(H, dtype=torch.float32, device=dev) if g32 is not None else None
         a = L.AttnBwdArgs(dtype=L.dt(tdt), p_dtype=L.dt(tdt), B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, ldq=ldq, ldk=ldk, ldv=ldk,
-                          ldo=H * dh, lddq=ldq, lddk=ldk, lddv=ldk,
+                          ldo=H * dh, lddq=ldq, lddk=ldk, lddv=ldk, ldpr=Lkp,
                           Q=C.c_void_p(qbuf.data_ptr() + q_off * es), K=C.c_void_p(kvbuf.data_ptr() + k_off * es),
                           V=C.c_void_p(kvbuf.data_ptr() + v_off * es), P=L.ptr(P), dO=L.ptr(dOc), dP_ext=L.ptr(dPc),
                           kv_index=None, head_gate=L.ptr(g32), scale=scale, dS=L.ptr(dS),
@@ -393,28 +397,57 @@ def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True):
 # ---------------------------------------------------------------------------------------------------
 # losses (device scalars)
 # ---------------------------------------------------------------------------------------------------
+def _padded_base(x, ldp=None):
+    """if x is a [..., :n] view of a contiguous [..., ld] buffer (attention maps with 16-byte padded rows), return that
+    buffer (a view, no copy); otherwise None."""
+    if x.dim() < 2 or x.stride(-1) != 1 or x.is_contiguous():
+        return None
+    ld = x.stride(-2)
+    if ld < x.shape[-1] or (ldp is not None and ld != ldp):
+        return None
+    shape = tuple(x.shape[:-1]) + (ld,)
+    strides, acc = [], 1
+    for s_ in reversed(shape):
+        strides.append(acc)
+        acc *= s_
+    strides = tuple(reversed(strides))
+    if tuple(x.stride()[:-1]) != strides[:-1]:
+        return None
+    return x.as_strided(shape, strides, x.storage_offset())
+
+
 class _MSE(torch.autograd.Function):
-    """weight * mean((a-b)^2); gradient flows to `a` only (b is the detached teacher)"""
+    """weight * mean((a-b)^2); gradient flows to `a` only (b is the detached teacher).  Attention maps arrive as views
+    of row-padded buffers whose padding is zero in both operands: the reduction then runs over the padded buffers
+    (same sum) and is normalised by the true element count."""
 
     @staticmethod
     def forward(ctx, a, b, weight):
         L.require_cuda(a, b)
-        ac = a if a.is_contiguous() else a.contiguous()
-        bc = b if b.is_contiguous() else b.contiguous()
+        n_true = a.numel()
+        pa, pb = _padded_base(a), _padded_base(b)
+        if pa is not None and pb is not None and pa.shape == pb.shape:
+            ac, bc, padded = pa, pb, True
+        else:
+            ac = a if a.is_contiguous() else a.contiguous()
+            bc = b if b.is_contiguous() else b.contiguous()
+            padded = False
+        w = weight * (ac.numel() / n_true)        # kernels divide by the element count they sweep
         out = torch.zeros((), dtype=torch.float32, device=a.device)
-        L.check(_lib().evlm_mse_fwd(L.dt(ac), L.ptr(ac), L.dt(bc), L.ptr(bc), ac.numel(), weight, L.ptr(out), L.stream()), "mse_fwd")
+        L.check(_lib().evlm_mse_fwd(L.dt(ac), L.ptr(ac), L.dt(bc), L.ptr(bc), ac.numel(), w, L.ptr(out), L.stream()), "mse_fwd")
         ctx.save_for_backward(ac, bc)
-        ctx.weight = weight
+        ctx.meta = (w, padded, a.shape)
         return out
 
     @staticmethod
     def backward(ctx, g):
         ac, bc = ctx.saved_tensors
+        w, padded, shape = ctx.meta
         gc = g.to(torch.float32).contiguous()
         ga = torch.empty_like(ac)
-        L.check(_lib().evlm_mse_bwd(L.dt(ac), L.ptr(ac), L.dt(bc), L.ptr(bc), ac.numel(), ctx.weight, L.ptr(gc), L.ptr(ga),
+        L.check(_lib().evlm_mse_bwd(L.dt(ac), L.ptr(ac), L.dt(bc), L.ptr(bc), ac.numel(), w, L.ptr(gc), L.ptr(ga),
                                     L.stream()), "mse_bwd")
-        return ga, None, None
+        return (ga[..., :shape[-1]] if padded else ga.view(shape)), None, None
 
 
 def mse(a, b, weight=1.0):

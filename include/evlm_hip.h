@@ -93,7 +93,8 @@ int evlm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* ga
  *   Q: [B, Lq, H, dh] with row stride ldq (so packed QKV buffers work), K/V: [Bkv, Lk, H, dh] (ldk, ldv);
  *   kv_index (int32 [B] or NULL) maps query batch b to its K/V batch row (hard-negative reuse);
  *   mask: additive f32 [B, Lk] or NULL (the reference's (1-m)*-10000, eff_bert.py:1012, eff_vit.py:339);
- *   P: [B, H, Lq, Lk] of p_dtype (EVLM_F32 or EVLM_BF16);  O: [B, Lq, H*dh] (ldo).
+ *   P: [B, H, Lq, Lk] of p_dtype (EVLM_F32 or EVLM_BF16) with ROW STRIDE ldpr >= Lk (a multiple of 8; the kernels
+ *   write zeros into the padding columns, so KD reductions may run over the padded buffer);  O: [B, Lq, H*dh] (ldo).
  * Replaces CLIPAttention bmm-softmax-bmm (eff_vit.py:144-195) and BertSelfAttention matmul /sqrt(d)
  *   +mask softmax matmul *= head_z (eff_bert.py:317-355), self- and cross-attention alike.
  * ---------------------------------------------------------------------------------------------- */
@@ -101,6 +102,7 @@ typedef struct {
   int dtype, p_dtype;
   int B, H, Lq, Lk, dh;
   int ldq, ldk, ldv, ldo;       /* row strides in elements */
+  int ldpr;                     /* row stride of P */
   const void* Q; const void* K; const void* V;
   const int32_t* kv_index;
   const float* mask;
@@ -119,6 +121,7 @@ typedef struct {
   int B, H, Lq, Lk, dh;
   int ldq, ldk, ldv, ldo;
   int lddq, lddk, lddv;
+  int ldpr;                     /* row stride of P, dP_ext and dS */
   const void* Q; const void* K; const void* V; const void* P;
   const void* dO; const void* dP_ext;
   const int32_t* kv_index;
