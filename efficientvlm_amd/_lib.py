@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libevlm_hip.so")
+LIB_PATH = os.environ.get("EVLM_LIB", os.path.join(_HERE, "libevlm_hip.so"))
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2

@@ -33,19 +33,32 @@ struct GemmP {
 // 8/16-byte vectors for all `b` of one `a` before they are consumed, so the loads overlap instead of serialising.
 // FULL = the whole workgroup tile is inside the matrix (no bounds checks at all).
 // ---------------------------------------------------------------------------------------------
+// (static register indices only: a runtime-indexed v[e] would push the arrays to scratch)
 template <typename T>
 __device__ __forceinline__ void ld4(const T* p, int nv, float v[4]) {
   if (nv == 4) Vec4<T>::load(p, v);
-  else { v[0] = v[1] = v[2] = v[3] = 0.f; for (int e = 0; e < nv; ++e) v[e] = to_f(p[e]); }
+  else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (e < nv) ? to_f(p[e]) : 0.f;
+  }
 }
 template <typename T>
 __device__ __forceinline__ void st4(T* p, int nv, const float v[4]) {
   if (nv == 4) Vec4<T>::store(p, v);
-  else for (int e = 0; e < nv; ++e) p[e] = from_f<T>(v[e]);
+  else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (e < nv) p[e] = from_f<T>(v[e]);
+  }
 }
 
-template <typename T, int NA, int NB, bool FULL>
-__device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][NB], int ibase, int jbase, int lane) {
+// LDS_OUT (bf16 interior tiles): C (and the pre-activation) are first written into swizzled [128][128] bf16 LDS tiles
+// (sC, sH; local row/col = global - (i0, j0)) and then streamed out by the whole workgroup as 256-byte rows
+// (copy_tile_out), instead of 8-byte stores scattered over 16 rows per wave instruction.
+__device__ __forceinline__ int ctile_off(int r, int c) { return r * 256 + ((((c >> 3) ^ (r & 15)) & 15) << 4) + ((c & 4) << 1); }
+
+template <typename T, int NA, int NB, bool FULL, bool LDS_OUT = false>
+__device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][NB], int ibase, int jbase, int lane,
+                                              char* sC = nullptr, char* sH = nullptr, int i0 = 0, int j0 = 0) {
   const int il = lane & 15, jl = (lane >> 4) * 4;
 #pragma unroll
   for (int a = 0; a < NA; ++a) {
@@ -56,28 +69,31 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][N
     if (g.bias) ld4<float>(g.bias + j, nv, bz);
     if (g.gate) ld4<float>(g.gate + j, nv, gz);
     float hx[NB][4], rx[NB][4];
-    if (g.dact != EVLM_ACT_NONE) {
+    if (FULL && g.dact != EVLM_ACT_NONE) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int i = ibase + b * 16 + il;
-        if (FULL || i < g.I) ld4<T>(reinterpret_cast<const T*>(g.aux) + (size_t)i * g.ldx + j, nv, hx[b]);
-      }
+      for (int b = 0; b < NB; ++b)
+        ld4<T>(reinterpret_cast<const T*>(g.aux) + (size_t)(ibase + b * 16 + il) * g.ldx + j, 4, hx[b]);
     }
-    if (g.residual) {
+    if (FULL && g.residual) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int i = ibase + b * 16 + il;
-        if (FULL || i < g.I) ld4<T>(reinterpret_cast<const T*>(g.residual) + (size_t)i * g.ldx + j, nv, rx[b]);
-      }
+      for (int b = 0; b < NB; ++b)
+        ld4<T>(reinterpret_cast<const T*>(g.residual) + (size_t)(ibase + b * 16 + il) * g.ldx + j, 4, rx[b]);
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int i = ibase + b * 16 + il;
       if (!FULL && i >= g.I) continue;
+      if (!FULL) {   // edge tiles: fetch per element block (rare; keeps the register budget of the interior path)
+        if (g.dact != EVLM_ACT_NONE) ld4<T>(reinterpret_cast<const T*>(g.aux) + (size_t)i * g.ldx + j, nv, hx[b]);
+        if (g.residual) ld4<T>(reinterpret_cast<const T*>(g.residual) + (size_t)i * g.ldx + j, nv, rx[b]);
+      }
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = acc[a][b][e] * g.alpha + bz[e];
-      if (g.preact) st4<T>(reinterpret_cast<T*>(g.preact) + (size_t)i * g.ldx + j, nv, v);
+      if (g.preact) {
+        if (LDS_OUT) Vec4<bf16>::store(reinterpret_cast<bf16*>(sH + ctile_off(i - i0, j - j0)), v);
+        else st4<T>(reinterpret_cast<T*>(g.preact) + (size_t)i * g.ldx + j, nv, v);
+      }
       if (g.act != EVLM_ACT_NONE) {
         if (g.gate_pos == EVLM_GATE_PRE_ACT) {
 #pragma unroll
@@ -99,7 +115,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][N
         for (int e = 0; e < 4; ++e) v[e] += rx[b][e];
       }
       const size_t co = (size_t)i * g.ldc + j;
-      if (g.c_f32) st4<float>(reinterpret_cast<float*>(g.C) + co, nv, v);
+      if (LDS_OUT) Vec4<bf16>::store(reinterpret_cast<bf16*>(sC + ctile_off(i - i0, j - j0)), v);
+      else if (g.c_f32) st4<float>(reinterpret_cast<float*>(g.C) + co, nv, v);
       else st4<T>(reinterpret_cast<T*>(g.C) + co, nv, v);
     }
   }
@@ -185,12 +202,89 @@ __device__ __forceinline__ bf16x8 frag_read(const char* sm, int rt, int ks, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fast path (K a multiple of 64): every tile, interior or edge, runs the same unpredicated main loop.  Rows / columns
+// beyond the matrix are CLAMPED to the last valid row / 16-byte chunk (they load valid memory and compute garbage
+// that is never stored), so there is no zero-fill branch and the LDS-DMA can be used everywhere.
+// ---------------------------------------------------------------------------------------------
+// per-lane source pointers of the 4 x 16-byte pieces this thread stages for one operand (tile-invariant part)
+// (element offsets from the operand base, 32-bit: the host routes operands of >= 2^31 elements to the generic kernel)
+template <bool TR>
+__device__ __forceinline__ void src_offs(int ld, int rows, int row0, int tid, int (&src)[4]) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int id = (c * 4 + wave) * 64 + lane;      // LDS slot id (16 bytes each), linear per wave instruction
+    if (!TR) {
+      const int row = id >> 3, cp = id & 7;
+      src[c] = min(row0 + row, rows - 1) * ld + ((cp ^ ((row >> 1) & 7)) << 3);
+    } else {
+      const int kr = id >> 4, cp = id & 15;
+      const int col = row0 + ((cp ^ (((kr & 3) << 2) | ((kr >> 2) & 3))) << 3);
+      src[c] = kr * ld + min(col, ((rows + 7) & ~7) - 8);
+    }
+  }
+}
+// LDS-DMA: global -> LDS directly (global_load_lds_dwordx4).  One wave instruction writes 1 KiB of LDS linearly
+// (wave-uniform base + lane*16); the XOR swizzle therefore lives in the per-lane SOURCE chunk (src_ptrs), the same
+// involution the fragment reads apply.
+__device__ __forceinline__ void stage_glds(const bf16* base, const int (&src)[4], int koff, char* sm, int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (src[c] + koff)),
+                                     (__attribute__((address_space(3))) void*)(sm + (c * 4 + wave) * 1024), 16, 0, 0);
+}
+struct Stage4 { uint4 a, b, c, d; };   // by-value register bundle (an array here ends up in scratch)
+__device__ __forceinline__ Stage4 stage_regs_load(const bf16* base, const int (&src)[4], int koff) {
+  Stage4 r;
+  r.a = *reinterpret_cast<const uint4*>(base + (src[0] + koff));
+  r.b = *reinterpret_cast<const uint4*>(base + (src[1] + koff));
+  r.c = *reinterpret_cast<const uint4*>(base + (src[2] + koff));
+  r.d = *reinterpret_cast<const uint4*>(base + (src[3] + koff));
+  return r;
+}
+__device__ __forceinline__ void stage_regs_store(char* sm, int tid, const Stage4& r) {
+  char* p = sm + tid * 16;           // slot id = (c*4 + wave)*64 + lane = c*256 + tid
+  *reinterpret_cast<uint4*>(p) = r.a;
+  *reinterpret_cast<uint4*>(p + 4096) = r.b;
+  *reinterpret_cast<uint4*>(p + 8192) = r.c;
+  *reinterpret_cast<uint4*>(p + 12288) = r.d;
+}
+
+// stream a swizzled [128][128] bf16 LDS tile to global memory as 256-byte rows (16 lanes x 16 bytes per row)
+template <bool FULL>
+__device__ __forceinline__ void copy_tile_out(const char* sT, bf16* dst, int ld, int i0, int j0, int I, int J, int tid) {
+  const int ch = tid & 15;
+  const int jc = j0 + ch * 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int r = (tid >> 4) + 16 * k;
+    if (!FULL && (i0 + r >= I || jc >= J)) continue;
+    const uint4 v = *reinterpret_cast<const uint4*>(sT + r * 256 + ((ch ^ (r & 15)) << 4));
+    bf16* d = dst + (size_t)(i0 + r) * ld + jc;
+    if (FULL || jc + 8 <= J) *reinterpret_cast<uint4*>(d) = v;
+    else {
+      const bf16x8 e = *reinterpret_cast<const bf16x8*>(&v);
+#pragma unroll
+      for (int x = 0; x < 8; ++x) if (x < J - jc) d[x] = e[x];
+    }
+  }
+}
+
 template <bool PT, bool QT, bool FULL>
-__device__ __forceinline__ void gemm_bf16_body(const GemmP& g, char* smem, int i0, int j0) {
+__device__ __forceinline__ void gemm_bf16_fast(const GemmP& g, char* smem, int i0, int j0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave & 1, wj = wave >> 1;
-  const bf16* P = reinterpret_cast<const bf16*>(g.P);
-  const bf16* Q = reinterpret_cast<const bf16*>(g.Q);
+  // LDS-DMA staging pays for NT and NN; the dW product (both operands reduction-major, 197 K tiles) measured 20 % faster
+  // through VGPRs (tools/gemm_bench.py)
+  constexpr bool DMA = !(PT && QT);
+  const bf16* Pb = reinterpret_cast<const bf16*>(g.P);
+  const bf16* Qb = reinterpret_cast<const bf16*>(g.Q);
+  int sp_[4], sq_[4];
+  src_offs<PT>(g.ldp, g.I, i0, tid, sp_);
+  src_offs<QT>(g.ldq, g.J, j0, tid, sq_);
+  const int kp = PT ? BK * g.ldp : BK, kq = QT ? BK * g.ldq : BK;   // element advance per K tile
 
   f32x4 acc[4][4];   // [a: j tile][b: i tile] : D rows = j (Q side), D cols = i (P side)
 #pragma unroll
@@ -198,20 +292,99 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& g, char* smem, int i
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  uint4 rp[4], rq[4];
-  const int nt = (g.K + BK - 1) / BK;
-  stage_load<PT, FULL>(P, g.ldp, g.I, g.K, i0, 0, tid, rp);
-  stage_load<QT, FULL>(Q, g.ldq, g.J, g.K, j0, 0, tid, rq);
-  stage_store<PT>(smem, tid, rp);
-  stage_store<QT>(smem + TILE_BYTES, tid, rq);
+  Stage4 rp, rq;
+  const int nt = g.K / BK;
+  if (DMA) {
+    stage_glds(Pb, sp_, 0, smem, tid);
+    stage_glds(Qb, sq_, 0, smem + TILE_BYTES, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    rp = stage_regs_load(Pb, sp_, 0);
+    rq = stage_regs_load(Qb, sq_, 0);
+    stage_regs_store(smem, tid, rp);
+    stage_regs_store(smem + TILE_BYTES, tid, rq);
+  }
   __syncthreads();
 
   for (int t = 0; t < nt; ++t) {
     const char* sp = smem + (t & 1) * 2 * TILE_BYTES;
     const char* sq = sp + TILE_BYTES;
-    if (t + 1 < nt) {   // issue next tile's global loads before the MFMA block (latency hides under it)
-      stage_load<PT, FULL>(P, g.ldp, g.I, g.K, i0, (t + 1) * BK, tid, rp);
-      stage_load<QT, FULL>(Q, g.ldq, g.J, g.K, j0, (t + 1) * BK, tid, rq);
+    char* nb = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+    if (t + 1 < nt) {   // next tile's loads are issued before the MFMA block: their latency hides under it
+      if (DMA) { stage_glds(Pb, sp_, (t + 1) * kp, nb, tid); stage_glds(Qb, sq_, (t + 1) * kq, nb + TILE_BYTES, tid); }
+      else { rp = stage_regs_load(Pb, sp_, (t + 1) * kp); rq = stage_regs_load(Qb, sq_, (t + 1) * kq); }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fp[4], fq[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        fp[a] = frag_read<PT>(sp, wi * 4 + a, ks, lane);
+        fq[a] = frag_read<QT>(sq, wj * 4 + a, ks, lane);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[a], fp[b], acc[a][b], 0, 0, 0);
+    }
+    if (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA of tile t+1 has landed
+    } else if (t + 1 < nt) {
+      stage_regs_store(nb, tid, rp);
+      stage_regs_store(nb + TILE_BYTES, tid, rq);
+    }
+    __syncthreads();
+  }
+#ifdef EVLM_DEBUG_NO_EPILOGUE
+  {
+    float keep = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) keep += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (keep == 123.456f) reinterpret_cast<float*>(g.C)[0] = keep;
+    return;
+  }
+#endif
+  if (!g.c_f32) {
+    // all staging buffers are dead after the last barrier: reuse them as the output tiles
+    char* sC = smem;
+    char* sH = smem + 2 * TILE_BYTES;
+    tile_epilogue<bf16, 4, 4, FULL, true>(g, acc, i0 + wi * 64, j0 + wj * 64, lane, sC, sH, i0, j0);
+    __syncthreads();
+    copy_tile_out<FULL>(sC, reinterpret_cast<bf16*>(g.C), g.ldc, i0, j0, g.I, g.J, tid);
+    if (g.preact) copy_tile_out<FULL>(sH, reinterpret_cast<bf16*>(g.preact), g.ldx, i0, j0, g.I, g.J, tid);
+  } else {
+    tile_epilogue<bf16, 4, 4, FULL>(g, acc, i0 + wi * 64, j0 + wj * 64, lane);
+  }
+}
+
+// generic path (K not a multiple of 64: only the vocabulary-sized reduction of the MLM decoder backward)
+template <bool PT, bool QT>
+__device__ __forceinline__ void gemm_bf16_generic(const GemmP& g, char* smem, int i0, int j0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave & 1, wj = wave >> 1;
+  const bf16* P = reinterpret_cast<const bf16*>(g.P);
+  const bf16* Q = reinterpret_cast<const bf16*>(g.Q);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint4 rp[4], rq[4];
+  const int nt = (g.K + BK - 1) / BK;
+  stage_load<PT, false>(P, g.ldp, g.I, g.K, i0, 0, tid, rp);
+  stage_load<QT, false>(Q, g.ldq, g.J, g.K, j0, 0, tid, rq);
+  stage_store<PT>(smem, tid, rp);
+  stage_store<QT>(smem + TILE_BYTES, tid, rq);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const char* sp = smem + (t & 1) * 2 * TILE_BYTES;
+    const char* sq = sp + TILE_BYTES;
+    if (t + 1 < nt) {
+      stage_load<PT, false>(P, g.ldp, g.I, g.K, i0, (t + 1) * BK, tid, rp);
+      stage_load<QT, false>(Q, g.ldq, g.J, g.K, j0, (t + 1) * BK, tid, rq);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -234,7 +407,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmP& g, char* smem, int i
     }
     __syncthreads();
   }
-  tile_epilogue<bf16, 4, 4, FULL>(g, acc, i0 + wi * 64, j0 + wj * 64, lane);
+  tile_epilogue<bf16, 4, 4, false>(g, acc, i0 + wi * 64, j0 + wj * 64, lane);
 }
 
 template <bool PT, bool QT>
@@ -243,10 +416,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP g) {
   int ti, tj;
   tile_coords(g, ti, tj);
   const int i0 = ti * BT, j0 = tj * BT;
-  // wave-uniform: interior tiles (everything in bounds, K a multiple of the K tile) take the unpredicated path
-  const bool full = (i0 + BT <= g.I) && (j0 + BT <= g.J) && (g.K % BK == 0);
-  if (full) gemm_bf16_body<PT, QT, true>(g, smem, i0, j0);
-  else gemm_bf16_body<PT, QT, false>(g, smem, i0, j0);
+  // wave-uniform: interior tiles skip every bounds check in the epilogue
+  const bool full = (i0 + BT <= g.I) && (j0 + BT <= g.J);
+  if (full) gemm_bf16_fast<PT, QT, true>(g, smem, i0, j0);
+  else gemm_bf16_fast<PT, QT, false>(g, smem, i0, j0);
+}
+template <bool PT, bool QT>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_generic_kernel(GemmP g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int ti, tj;
+  tile_coords(g, ti, tj);
+  gemm_bf16_generic<PT, QT>(g, smem, ti * BT, tj * BT);
 }
 
 // =============================================================================================
@@ -379,7 +559,13 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
     g.tiles_i = ceil_div(g.I, BT); g.tiles_j = ceil_div(g.J, BT);
     dim3 grid(g.tiles_i * g.tiles_j), block(256);
     const size_t lds = 4 * TILE_BYTES;
-#define LAUNCH_BF16(PT_, QT_) hipLaunchKernelGGL((gemm_bf16_kernel<PT_, QT_>), grid, block, lds, stream, g)
+    const bool fast = (g.K % BK == 0) && ((int64_t)(pt ? g.K : g.I) * g.ldp < (1ll << 31)) &&
+                      ((int64_t)(qt ? g.K : g.J) * g.ldq < (1ll << 31));
+#define LAUNCH_BF16(PT_, QT_)                                                                          \
+  do {                                                                                                 \
+    if (fast) hipLaunchKernelGGL((gemm_bf16_kernel<PT_, QT_>), grid, block, lds, stream, g);           \
+    else hipLaunchKernelGGL((gemm_bf16_generic_kernel<PT_, QT_>), grid, block, lds, stream, g);        \
+  } while (0)
     if (!pt && !qt) LAUNCH_BF16(false, false);
     else if (!pt && qt) LAUNCH_BF16(false, true);
     else if (pt && qt) LAUNCH_BF16(true, true);

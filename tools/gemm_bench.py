@@ -40,6 +40,6 @@ bench("vit fc2 dW (f32 out)", 768, 3072, M, 1, 1, c_f32=True)
 bench("vit qkv dW (f32 out)", 2304, 768, M, 1, 1, c_f32=True)
 bench("text qkv fwd", 1920, 2304, 768, 0, 0, bias=True)
 bench("text ffn1 fwd", 3840, 3072, 768, 0, 0, bias=True, act=L.ACT_GELU)
-bench("mlm decoder fwd", 512, 30522, 768, 0, 0, bias=True)
+bench("mlm decoder fwd", 512, 30528, 768, 0, 0, bias=True)
 bench("square 4096", 4096, 4096, 4096, 0, 0)
 bench("square 8192", 8192, 8192, 8192, 0, 0, reps=5)
