@@ -24,6 +24,7 @@ struct GemmP {
   int c_f32, act, gate_pos, dact;
   float alpha;
   int tiles_i, tiles_j;
+  int kt_per_split;   // K tiles (of 64) handled by one grid.y slice
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -54,9 +55,13 @@ __device__ __forceinline__ void st4(T* p, int nv, const float v[4]) {
 // LDS_OUT (bf16 interior tiles): C (and the pre-activation) are first written into swizzled [128][128] bf16 LDS tiles
 // (sC, sH; local row/col = global - (i0, j0)) and then streamed out by the whole workgroup as 256-byte rows
 // (copy_tile_out), instead of 8-byte stores scattered over 16 rows per wave instruction.
-__device__ __forceinline__ int ctile_off(int r, int c) { return r * 256 + ((((c >> 3) ^ (r & 15)) & 15) << 4) + ((c & 4) << 1); }
+template <int MT>
+__device__ __forceinline__ int ctile_off(int r, int c) {
+  constexpr int NC = 4 * MT;   // 16-byte chunks per LDS tile row
+  return r * (NC * 16) + ((((c >> 3) ^ r) & (NC - 1)) << 4) + ((c & 4) << 1);
+}
 
-template <typename T, int NA, int NB, bool FULL, bool LDS_OUT = false>
+template <typename T, int NA, int NB, bool FULL, bool LDS_OUT = false, int MT = 4>
 __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][NB], int ibase, int jbase, int lane,
                                               char* sC = nullptr, char* sH = nullptr, int i0 = 0, int j0 = 0) {
   const int il = lane & 15, jl = (lane >> 4) * 4;
@@ -91,7 +96,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][N
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = acc[a][b][e] * g.alpha + bz[e];
       if (g.preact) {
-        if (LDS_OUT) Vec4<bf16>::store(reinterpret_cast<bf16*>(sH + ctile_off(i - i0, j - j0)), v);
+        if (LDS_OUT) Vec4<bf16>::store(reinterpret_cast<bf16*>(sH + ctile_off<MT>(i - i0, j - j0)), v);
         else st4<T>(reinterpret_cast<T*>(g.preact) + (size_t)i * g.ldx + j, nv, v);
       }
       if (g.act != EVLM_ACT_NONE) {
@@ -115,7 +120,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][N
         for (int e = 0; e < 4; ++e) v[e] += rx[b][e];
       }
       const size_t co = (size_t)i * g.ldc + j;
-      if (LDS_OUT) Vec4<bf16>::store(reinterpret_cast<bf16*>(sC + ctile_off(i - i0, j - j0)), v);
+      if (LDS_OUT) Vec4<bf16>::store(reinterpret_cast<bf16*>(sC + ctile_off<MT>(i - i0, j - j0)), v);
       else if (g.c_f32) st4<float>(reinterpret_cast<float*>(g.C) + co, nv, v);
       else st4<T>(reinterpret_cast<T*>(g.C) + co, nv, v);
     }
@@ -206,62 +211,102 @@ __device__ __forceinline__ bf16x8 frag_read(const char* sm, int rt, int ks, int 
 // fast path (K a multiple of 64): every tile, interior or edge, runs the same unpredicated main loop.  Rows / columns
 // beyond the matrix are CLAMPED to the last valid row / 16-byte chunk (they load valid memory and compute garbage
 // that is never stored), so there is no zero-fill branch and the LDS-DMA can be used everywhere.
+//
+// MT = 16x16 accumulator tiles per wave per dimension: MT=4 -> 128x128 workgroup tile (large GEMMs),
+//                                                      MT=2 ->  64x64  workgroup tile (text-side GEMMs with < ~400
+//                                                               big tiles, which would leave most of the 256 CUs idle).
+// Split-K (f32 outputs only: weight gradients, whose output is small and whose K is the token count): grid.y slices K and
+// the partial tiles are combined with f32 atomics into the zero-initialised output.
 // ---------------------------------------------------------------------------------------------
-// per-lane source pointers of the 4 x 16-byte pieces this thread stages for one operand (tile-invariant part)
-// (element offsets from the operand base, 32-bit: the host routes operands of >= 2^31 elements to the generic kernel)
-template <bool TR>
-__device__ __forceinline__ void src_offs(int ld, int rows, int row0, int tid, int (&src)[4]) {
+template <int MT> struct TileCfg {
+  static constexpr int BTm = 32 * MT;                 // tile rows / cols
+  static constexpr int TB = BTm * BK * 2;             // bytes per operand tile per stage
+  static constexpr int NPW = MT;                      // 1-KiB pieces staged per wave per operand
+  static constexpr int TRCH = 4 * MT;                 // 16-byte chunks per row of a reduction-major tile ([64][BTm])
+};
+// swizzle of the 16-byte chunks of a reduction-major tile row (conflict-free ds_read_b64_tr_b16, see frag_read)
+template <int MT> __device__ __forceinline__ int tr_swz(int kr) {
+  return MT == 4 ? (((kr & 3) << 2) | ((kr >> 2) & 3)) : ((((kr >> 1) & 1) | (((kr >> 3) & 1) << 1)) << 1);
+}
+// per-lane source offsets (elements from the operand base; 32-bit: the host routes operands of >= 2^31 elements to the
+// generic kernel) of the MT x 16-byte pieces this thread stages for one operand
+template <bool TR, int MT>
+__device__ __forceinline__ void src_offs(int ld, int rows, int row0, int tid, int (&src)[MT]) {
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < MT; ++c) {
     const int id = (c * 4 + wave) * 64 + lane;      // LDS slot id (16 bytes each), linear per wave instruction
     if (!TR) {
       const int row = id >> 3, cp = id & 7;
       src[c] = min(row0 + row, rows - 1) * ld + ((cp ^ ((row >> 1) & 7)) << 3);
     } else {
-      const int kr = id >> 4, cp = id & 15;
-      const int col = row0 + ((cp ^ (((kr & 3) << 2) | ((kr >> 2) & 3))) << 3);
+      constexpr int NC = TileCfg<MT>::TRCH;
+      const int kr = id / NC, cp = id % NC;
+      const int col = row0 + ((cp ^ tr_swz<MT>(kr)) << 3);
       src[c] = kr * ld + min(col, ((rows + 7) & ~7) - 8);
     }
   }
 }
 // LDS-DMA: global -> LDS directly (global_load_lds_dwordx4).  One wave instruction writes 1 KiB of LDS linearly
-// (wave-uniform base + lane*16); the XOR swizzle therefore lives in the per-lane SOURCE chunk (src_ptrs), the same
+// (wave-uniform base + lane*16); the XOR swizzle therefore lives in the per-lane SOURCE chunk (src_offs), the same
 // involution the fragment reads apply.
-__device__ __forceinline__ void stage_glds(const bf16* base, const int (&src)[4], int koff, char* sm, int tid) {
+template <int MT>
+__device__ __forceinline__ void stage_glds(const bf16* base, const int (&src)[MT], int koff, char* sm, int tid) {
   const int wave = tid >> 6;
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < MT; ++c)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (src[c] + koff)),
                                      (__attribute__((address_space(3))) void*)(sm + (c * 4 + wave) * 1024), 16, 0, 0);
 }
-struct Stage4 { uint4 a, b, c, d; };   // by-value register bundle (an array here ends up in scratch)
-__device__ __forceinline__ Stage4 stage_regs_load(const bf16* base, const int (&src)[4], int koff) {
-  Stage4 r;
-  r.a = *reinterpret_cast<const uint4*>(base + (src[0] + koff));
-  r.b = *reinterpret_cast<const uint4*>(base + (src[1] + koff));
-  r.c = *reinterpret_cast<const uint4*>(base + (src[2] + koff));
-  r.d = *reinterpret_cast<const uint4*>(base + (src[3] + koff));
+template <int MT> struct StageR { uint4 r[MT]; };   // by-value register bundle
+template <int MT>
+__device__ __forceinline__ StageR<MT> stage_regs_load(const bf16* base, const int (&src)[MT], int koff) {
+  StageR<MT> r;
+#pragma unroll
+  for (int c = 0; c < MT; ++c) r.r[c] = *reinterpret_cast<const uint4*>(base + (src[c] + koff));
   return r;
 }
-__device__ __forceinline__ void stage_regs_store(char* sm, int tid, const Stage4& r) {
-  char* p = sm + tid * 16;           // slot id = (c*4 + wave)*64 + lane = c*256 + tid
-  *reinterpret_cast<uint4*>(p) = r.a;
-  *reinterpret_cast<uint4*>(p + 4096) = r.b;
-  *reinterpret_cast<uint4*>(p + 8192) = r.c;
-  *reinterpret_cast<uint4*>(p + 12288) = r.d;
+template <int MT>
+__device__ __forceinline__ void stage_regs_store(char* sm, int tid, const StageR<MT>& r) {
+#pragma unroll
+  for (int c = 0; c < MT; ++c) *reinterpret_cast<uint4*>(sm + c * 4096 + tid * 16) = r.r[c];   // slot id = c*256 + tid
 }
 
-// stream a swizzled [128][128] bf16 LDS tile to global memory as 256-byte rows (16 lanes x 16 bytes per row)
-template <bool FULL>
+// fragment reads for the MT-parametrised tiles
+template <bool TR, int MT>
+__device__ __forceinline__ bf16x8 frag_read_t(const char* sm, int rt, int ks, int lane) {
+  if (!TR) {
+    const int row = rt * 16 + (lane & 15);
+    const int c = ks * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(sm + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+  } else {
+    constexpr int RB = TileCfg<MT>::TRCH * 16;       // bytes per reduction row
+    const int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3;
+    bf16x8 out;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kr = ks * 32 + g * 8 + h * 4 + q;
+      const int ch = rt * 2 + (p >> 1);
+      const int off = kr * RB + ((ch ^ tr_swz<MT>(kr)) << 4) + ((p & 1) << 3);
+      bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(sm + off));
+      out[4 * h + 0] = t[0]; out[4 * h + 1] = t[1]; out[4 * h + 2] = t[2]; out[4 * h + 3] = t[3];
+    }
+    return out;
+  }
+}
+
+// stream a swizzled [BTm][BTm] bf16 LDS tile to global memory as full rows (16 bytes per lane, consecutive lanes on
+// consecutive addresses)
+template <bool FULL, int MT>
 __device__ __forceinline__ void copy_tile_out(const char* sT, bf16* dst, int ld, int i0, int j0, int I, int J, int tid) {
-  const int ch = tid & 15;
+  constexpr int NC = 4 * MT, RPP = 256 / NC, NPASS = 32 * MT / RPP;   // chunks per row, rows per pass, passes
+  const int ch = tid % NC;
   const int jc = j0 + ch * 8;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int r = (tid >> 4) + 16 * k;
+  for (int k = 0; k < NPASS; ++k) {
+    const int r = tid / NC + RPP * k;
     if (!FULL && (i0 + r >= I || jc >= J)) continue;
-    const uint4 v = *reinterpret_cast<const uint4*>(sT + r * 256 + ((ch ^ (r & 15)) << 4));
+    const uint4 v = *reinterpret_cast<const uint4*>(sT + r * (NC * 16) + ((ch ^ (r & (NC - 1))) << 4));
     bf16* d = dst + (size_t)(i0 + r) * ld + jc;
     if (FULL || jc + 8 <= J) *reinterpret_cast<uint4*>(d) = v;
     else {
@@ -272,67 +317,70 @@ __device__ __forceinline__ void copy_tile_out(const char* sT, bf16* dst, int ld,
   }
 }
 
-template <bool PT, bool QT, bool FULL>
+template <bool PT, bool QT, bool FULL, int MT>
 __device__ __forceinline__ void gemm_bf16_fast(const GemmP& g, char* smem, int i0, int j0) {
+  using TC = TileCfg<MT>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave & 1, wj = wave >> 1;
-  // LDS-DMA staging pays for NT and NN; the dW product (both operands reduction-major, 197 K tiles) measured 20 % faster
+  // LDS-DMA staging pays for NT and NN; the dW product (both operands reduction-major, long K) measured 20 % faster
   // through VGPRs (tools/gemm_bench.py)
   constexpr bool DMA = !(PT && QT);
   const bf16* Pb = reinterpret_cast<const bf16*>(g.P);
   const bf16* Qb = reinterpret_cast<const bf16*>(g.Q);
-  int sp_[4], sq_[4];
-  src_offs<PT>(g.ldp, g.I, i0, tid, sp_);
-  src_offs<QT>(g.ldq, g.J, j0, tid, sq_);
+  int sp_[MT], sq_[MT];
+  src_offs<PT, MT>(g.ldp, g.I, i0, tid, sp_);
+  src_offs<QT, MT>(g.ldq, g.J, j0, tid, sq_);
   const int kp = PT ? BK * g.ldp : BK, kq = QT ? BK * g.ldq : BK;   // element advance per K tile
 
-  f32x4 acc[4][4];   // [a: j tile][b: i tile] : D rows = j (Q side), D cols = i (P side)
+  f32x4 acc[MT][MT];   // [a: j tile][b: i tile] : D rows = j (Q side), D cols = i (P side)
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < MT; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  Stage4 rp, rq;
-  const int nt = g.K / BK;
+  StageR<MT> rp, rq;
+  const int nt_all = g.K / BK;
+  const int t0 = blockIdx.y * g.kt_per_split, t1 = min(nt_all, t0 + g.kt_per_split);   // this split's K tiles
   if (DMA) {
-    stage_glds(Pb, sp_, 0, smem, tid);
-    stage_glds(Qb, sq_, 0, smem + TILE_BYTES, tid);
+    stage_glds<MT>(Pb, sp_, t0 * kp, smem, tid);
+    stage_glds<MT>(Qb, sq_, t0 * kq, smem + TC::TB, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
-    rp = stage_regs_load(Pb, sp_, 0);
-    rq = stage_regs_load(Qb, sq_, 0);
-    stage_regs_store(smem, tid, rp);
-    stage_regs_store(smem + TILE_BYTES, tid, rq);
+    rp = stage_regs_load<MT>(Pb, sp_, t0 * kp);
+    rq = stage_regs_load<MT>(Qb, sq_, t0 * kq);
+    stage_regs_store<MT>(smem, tid, rp);
+    stage_regs_store<MT>(smem + TC::TB, tid, rq);
   }
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
-    const char* sp = smem + (t & 1) * 2 * TILE_BYTES;
-    const char* sq = sp + TILE_BYTES;
-    char* nb = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-    if (t + 1 < nt) {   // next tile's loads are issued before the MFMA block: their latency hides under it
-      if (DMA) { stage_glds(Pb, sp_, (t + 1) * kp, nb, tid); stage_glds(Qb, sq_, (t + 1) * kq, nb + TILE_BYTES, tid); }
-      else { rp = stage_regs_load(Pb, sp_, (t + 1) * kp); rq = stage_regs_load(Qb, sq_, (t + 1) * kq); }
+  for (int t = t0; t < t1; ++t) {
+    const int cur = (t - t0) & 1;
+    const char* sp = smem + cur * 2 * TC::TB;
+    const char* sq = sp + TC::TB;
+    char* nb = smem + (cur ^ 1) * 2 * TC::TB;
+    if (t + 1 < t1) {   // next tile's loads are issued before the MFMA block: their latency hides under it
+      if (DMA) { stage_glds<MT>(Pb, sp_, (t + 1) * kp, nb, tid); stage_glds<MT>(Qb, sq_, (t + 1) * kq, nb + TC::TB, tid); }
+      else { rp = stage_regs_load<MT>(Pb, sp_, (t + 1) * kp); rq = stage_regs_load<MT>(Qb, sq_, (t + 1) * kq); }
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fp[4], fq[4];
+      bf16x8 fp[MT], fq[MT];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        fp[a] = frag_read<PT>(sp, wi * 4 + a, ks, lane);
-        fq[a] = frag_read<QT>(sq, wj * 4 + a, ks, lane);
+      for (int a = 0; a < MT; ++a) {
+        fp[a] = frag_read_t<PT, MT>(sp, wi * MT + a, ks, lane);
+        fq[a] = frag_read_t<QT, MT>(sq, wj * MT + a, ks, lane);
       }
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < MT; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[a], fp[b], acc[a][b], 0, 0, 0);
     }
     if (DMA) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA of tile t+1 has landed
-    } else if (t + 1 < nt) {
-      stage_regs_store(nb, tid, rp);
-      stage_regs_store(nb + TILE_BYTES, tid, rq);
+    } else if (t + 1 < t1) {
+      stage_regs_store<MT>(nb, tid, rp);
+      stage_regs_store<MT>(nb + TC::TB, tid, rq);
     }
     __syncthreads();
   }
@@ -340,23 +388,39 @@ __device__ __forceinline__ void gemm_bf16_fast(const GemmP& g, char* smem, int i
   {
     float keep = 0.f;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) keep += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+      for (int b = 0; b < MT; ++b) keep += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
     if (keep == 123.456f) reinterpret_cast<float*>(g.C)[0] = keep;
     return;
   }
 #endif
-  if (!g.c_f32) {
+  const int ib = i0 + wi * 16 * MT, jb = j0 + wj * 16 * MT;
+  if (gridDim.y > 1) {
+    // split-K partial: f32 atomics into the zeroed output (host guarantees c_f32 and a bare epilogue)
+    const int il = lane & 15, jl = (lane >> 4) * 4;
+    float* Cf = reinterpret_cast<float*>(g.C);
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b) {
+        const int i = ib + b * 16 + il, j = jb + a * 16 + jl;
+        if (FULL || i < g.I) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (FULL || j + e < g.J) atomicAdd(Cf + (size_t)i * g.ldc + j + e, acc[a][b][e] * g.alpha);
+        }
+      }
+  } else if (!g.c_f32) {
     // all staging buffers are dead after the last barrier: reuse them as the output tiles
     char* sC = smem;
-    char* sH = smem + 2 * TILE_BYTES;
-    tile_epilogue<bf16, 4, 4, FULL, true>(g, acc, i0 + wi * 64, j0 + wj * 64, lane, sC, sH, i0, j0);
+    char* sH = smem + 2 * TC::TB;
+    tile_epilogue<bf16, MT, MT, FULL, true, MT>(g, acc, ib, jb, lane, sC, sH, i0, j0);
     __syncthreads();
-    copy_tile_out<FULL>(sC, reinterpret_cast<bf16*>(g.C), g.ldc, i0, j0, g.I, g.J, tid);
-    if (g.preact) copy_tile_out<FULL>(sH, reinterpret_cast<bf16*>(g.preact), g.ldx, i0, j0, g.I, g.J, tid);
+    copy_tile_out<FULL, MT>(sC, reinterpret_cast<bf16*>(g.C), g.ldc, i0, j0, g.I, g.J, tid);
+    if (g.preact) copy_tile_out<FULL, MT>(sH, reinterpret_cast<bf16*>(g.preact), g.ldx, i0, j0, g.I, g.J, tid);
   } else {
-    tile_epilogue<bf16, 4, 4, FULL>(g, acc, i0 + wi * 64, j0 + wj * 64, lane);
+    tile_epilogue<bf16, MT, MT, FULL>(g, acc, ib, jb, lane);
   }
 }
 
@@ -410,16 +474,17 @@ __device__ __forceinline__ void gemm_bf16_generic(const GemmP& g, char* smem, in
   tile_epilogue<bf16, 4, 4, false>(g, acc, i0 + wi * 64, j0 + wj * 64, lane);
 }
 
-template <bool PT, bool QT>
+template <bool PT, bool QT, int MT>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][P tile | Q tile]
+  constexpr int BTm = 32 * MT;
   int ti, tj;
   tile_coords(g, ti, tj);
-  const int i0 = ti * BT, j0 = tj * BT;
+  const int i0 = ti * BTm, j0 = tj * BTm;
   // wave-uniform: interior tiles skip every bounds check in the epilogue
-  const bool full = (i0 + BT <= g.I) && (j0 + BT <= g.J);
-  if (full) gemm_bf16_fast<PT, QT, true>(g, smem, i0, j0);
-  else gemm_bf16_fast<PT, QT, false>(g, smem, i0, j0);
+  const bool full = (i0 + BTm <= g.I) && (j0 + BTm <= g.J);
+  if (full) gemm_bf16_fast<PT, QT, true, MT>(g, smem, i0, j0);
+  else gemm_bf16_fast<PT, QT, false, MT>(g, smem, i0, j0);
 }
 template <bool PT, bool QT>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_generic_kernel(GemmP g) {
@@ -556,23 +621,54 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
   g.act = a->act; g.gate_pos = a->gate_pos; g.dact = a->dact; g.alpha = a->alpha;
   const int pt = a->p_trans ? 1 : 0, qt = a->q_trans ? 1 : 0;
   if (a->dtype == EVLM_BF16) {
-    g.tiles_i = ceil_div(g.I, BT); g.tiles_j = ceil_div(g.J, BT);
-    dim3 grid(g.tiles_i * g.tiles_j), block(256);
-    const size_t lds = 4 * TILE_BYTES;
     const bool fast = (g.K % BK == 0) && ((int64_t)(pt ? g.K : g.I) * g.ldp < (1ll << 31)) &&
                       ((int64_t)(qt ? g.K : g.J) * g.ldq < (1ll << 31));
-#define LAUNCH_BF16(PT_, QT_)                                                                          \
-  do {                                                                                                 \
-    if (fast) hipLaunchKernelGGL((gemm_bf16_kernel<PT_, QT_>), grid, block, lds, stream, g);           \
-    else hipLaunchKernelGGL((gemm_bf16_generic_kernel<PT_, QT_>), grid, block, lds, stream, g);        \
+    dim3 block(256);
+    if (!fast) {
+      g.tiles_i = ceil_div(g.I, BT); g.tiles_j = ceil_div(g.J, BT); g.kt_per_split = 0;
+      dim3 grid(g.tiles_i * g.tiles_j);
+      const size_t lds = 4 * TILE_BYTES;
+#define LAUNCH_GEN(PT_, QT_) hipLaunchKernelGGL((gemm_bf16_generic_kernel<PT_, QT_>), grid, block, lds, stream, g)
+      if (!pt && !qt) LAUNCH_GEN(false, false);
+      else if (!pt && qt) LAUNCH_GEN(false, true);
+      else if (pt && qt) LAUNCH_GEN(true, true);
+      else LAUNCH_GEN(true, false);
+#undef LAUNCH_GEN
+    } else {
+      // tile choice: 128x128 unless that leaves most of the 256 CUs (x2 resident workgroups) without work
+      const int t128 = ceil_div(g.I, 128) * ceil_div(g.J, 128);
+      const int mt = (t128 >= 384) ? 4 : 2;
+      const int bt = 32 * mt;
+      g.tiles_i = ceil_div(g.I, bt); g.tiles_j = ceil_div(g.J, bt);
+      const int tiles = g.tiles_i * g.tiles_j, nt = g.K / BK;
+      // split-K only for bare f32 outputs (weight gradients): combine by f32 atomics into the zeroed output
+      int splits = 1;
+      const bool bare = g.c_f32 && !g.bias && !g.gate && !g.preact && !g.aux && !g.residual && g.act == EVLM_ACT_NONE;
+      if (bare && tiles < 512 && nt >= 8) {
+        splits = imin(imin(ceil_div(768, tiles), nt / 4), 32);
+        if (splits < 1) splits = 1;
+      }
+      g.kt_per_split = ceil_div(nt, splits);
+      splits = ceil_div(nt, g.kt_per_split);
+      if (splits > 1) {
+        hipError_t me = hipMemsetAsync(g.C, 0, (size_t)g.I * g.ldc * sizeof(float), stream);
+        if (me != hipSuccess) return evlm_set_error("evlm_gemm: memset failed: %s", hipGetErrorString(me));
+      }
+      dim3 grid(tiles, splits);
+      const size_t lds = (size_t)4 * bt * BK * 2;
+#define LAUNCH_FAST(PT_, QT_)                                                                       \
+  do {                                                                                              \
+    if (mt == 4) hipLaunchKernelGGL((gemm_bf16_kernel<PT_, QT_, 4>), grid, block, lds, stream, g); \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<PT_, QT_, 2>), grid, block, lds, stream, g);         \
   } while (0)
-    if (!pt && !qt) LAUNCH_BF16(false, false);
-    else if (!pt && qt) LAUNCH_BF16(false, true);
-    else if (pt && qt) LAUNCH_BF16(true, true);
-    else LAUNCH_BF16(true, false);
-#undef LAUNCH_BF16
+      if (!pt && !qt) LAUNCH_FAST(false, false);
+      else if (!pt && qt) LAUNCH_FAST(false, true);
+      else if (pt && qt) LAUNCH_FAST(true, true);
+      else LAUNCH_FAST(true, false);
+#undef LAUNCH_FAST
+    }
   } else if (a->dtype == EVLM_F32) {
-    g.tiles_i = ceil_div(g.I, FT); g.tiles_j = ceil_div(g.J, FT);
+    g.tiles_i = ceil_div(g.I, FT); g.tiles_j = ceil_div(g.J, FT); g.kt_per_split = 0;
     dim3 grid(g.tiles_i * g.tiles_j), block(256);
 #define LAUNCH_F32(PT_, QT_) hipLaunchKernelGGL((gemm_f32_kernel<PT_, QT_>), grid, block, 0, stream, g)
     if (!pt && !qt) LAUNCH_F32(false, false);

@@ -367,3 +367,24 @@ def test_l0_gates_match_reference_fixture(golden_dir):
         ze = o.l0_deterministic(loga, 2.0 / 3.0, 0.8)
         refe = fx[f"eval.z.{t}_z"].reshape(ze.shape)
         assert np.array_equal(ze.cpu().numpy(), refe), f"eval mask of {t} differs from the reference"
+
+
+@pytest.mark.parametrize("pt,qt", [(0, 0), (0, 1), (1, 1)])
+def test_gemm_large_tiles_and_split_k(pt, qt):
+    """shapes that select the 128x128 tile (>= 384 tiles), edge tiles in both dimensions, and the split-K weight-gradient
+    path (f32 output, atomics)"""
+    o = ops()
+    from efficientvlm_amd import _lib as L
+    g = torch.Generator().manual_seed(41 + pt + 2 * qt)
+    dtype = torch.bfloat16
+    for (I, J, K, c_f32) in [(2500, 2600, 128, 0), (2560, 2560, 192, 0), (320, 264, 1920, 1), (768, 768, 1216, 1), (2500, 2600, 128, 1)]:
+        Pm = rnd((K, I) if pt else (I, K), dtype, g, 0.5)
+        Qm = rnd((K, J) if qt else (J, K), dtype, g, 0.5)
+        if pt and I % 8:
+            continue
+        Cm = torch.full((I, J), 7.0, dtype=torch.float32 if c_f32 else dtype, device=DEV)
+        o._gemm(L.dt(dtype), Pm, Qm, Cm, I, J, K, Pm.stride(0), Qm.stride(0), J, p_trans=pt, q_trans=qt, c_f32=c_f32)
+        A = Pm.float().t() if pt else Pm.float()
+        Bm = Qm.float().t() if qt else Qm.float()
+        ref = A @ Bm.t()
+        assert rel_err(Cm.float(), ref) < (2e-5 if c_f32 else tol(dtype)), (I, J, K, c_f32)
