@@ -25,6 +25,7 @@ struct GemmP {
   float alpha;
   int tiles_i, tiles_j;
   int kt_per_split;   // K tiles (of 64) handled by one grid.y slice
+  int bare_f32;       // f32 output with no epilogue terms (weight gradients): LDS-staged coalesced store / atomics
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -396,21 +397,44 @@ __device__ __forceinline__ void gemm_bf16_fast(const GemmP& g, char* smem, int i
   }
 #endif
   const int ib = i0 + wi * 16 * MT, jb = j0 + wj * 16 * MT;
-  if (gridDim.y > 1) {
-    // split-K partial: f32 atomics into the zeroed output (host guarantees c_f32 and a bare epilogue)
+  if (g.bare_f32) {
+    // weight gradients: the f32 tile goes through LDS so that each wave instruction covers 256 contiguous bytes
+    // (plain 16-byte stores, or f32 atomics for split-K partials: scattered dword atomics run ~17x slower)
+    constexpr int BTm = TC::BTm, NCF = BTm / 4;          // 16-byte chunks per f32 tile row
     const int il = lane & 15, jl = (lane >> 4) * 4;
-    float* Cf = reinterpret_cast<float*>(g.C);
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < MT; ++b) {
-        const int i = ib + b * 16 + il, j = jb + a * 16 + jl;
-        if (FULL || i < g.I) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (FULL || j + e < g.J) atomicAdd(Cf + (size_t)i * g.ldc + j + e, acc[a][b][e] * g.alpha);
+        const int r = (ib - i0) + b * 16 + il, c = (jb - j0) + a * 16 + jl;
+        f32x4 v = acc[a][b] * g.alpha;
+        *reinterpret_cast<f32x4*>(smem + r * (BTm * 4) + ((((c >> 2) ^ r) & (NCF - 1)) << 4)) = v;
+      }
+    __syncthreads();
+    float* Cf = reinterpret_cast<float*>(g.C);
+    if (gridDim.y > 1) {
+#pragma unroll 4
+      for (int k = 0; k < BTm * BTm / 256; ++k) {
+        const int id = k * 256 + tid, r = id / BTm, c = id % BTm;
+        if (FULL || (i0 + r < g.I && j0 + c < g.J)) {
+          const float v = *reinterpret_cast<const float*>(smem + r * (BTm * 4) + ((((c >> 2) ^ r) & (NCF - 1)) << 4) + ((c & 3) << 2));
+          atomicAdd(Cf + (size_t)(i0 + r) * g.ldc + j0 + c, v);
         }
       }
+    } else {
+#pragma unroll 4
+      for (int k = 0; k < BTm * NCF / 256; ++k) {
+        const int id = k * 256 + tid, r = id / NCF, ch = id % NCF, jc = j0 + ch * 4;
+        if (!FULL && (i0 + r >= g.I || jc >= g.J)) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * (BTm * 4) + (((ch ^ r) & (NCF - 1)) << 4));
+        float* d = Cf + (size_t)(i0 + r) * g.ldc + jc;
+        if (FULL || jc + 4 <= g.J) *reinterpret_cast<f32x4*>(d) = v;
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (jc + e < g.J) d[e] = v[e];
+        }
+      }
+    }
   } else if (!g.c_f32) {
     // all staging buffers are dead after the last barrier: reuse them as the output tiles
     char* sC = smem;
@@ -625,7 +649,7 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
                       ((int64_t)(qt ? g.K : g.J) * g.ldq < (1ll << 31));
     dim3 block(256);
     if (!fast) {
-      g.tiles_i = ceil_div(g.I, BT); g.tiles_j = ceil_div(g.J, BT); g.kt_per_split = 0;
+      g.tiles_i = ceil_div(g.I, BT); g.tiles_j = ceil_div(g.J, BT); g.kt_per_split = 0; g.bare_f32 = 0;
       dim3 grid(g.tiles_i * g.tiles_j);
       const size_t lds = 4 * TILE_BYTES;
 #define LAUNCH_GEN(PT_, QT_) hipLaunchKernelGGL((gemm_bf16_generic_kernel<PT_, QT_>), grid, block, lds, stream, g)
@@ -644,8 +668,9 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
       // split-K only for bare f32 outputs (weight gradients): combine by f32 atomics into the zeroed output
       int splits = 1;
       const bool bare = g.c_f32 && !g.bias && !g.gate && !g.preact && !g.aux && !g.residual && g.act == EVLM_ACT_NONE;
-      if (bare && tiles < 512 && nt >= 8) {
-        splits = imin(imin(ceil_div(768, tiles), nt / 4), 32);
+      g.bare_f32 = bare ? 1 : 0;
+      if (bare && tiles < 512 && nt >= 32) {
+        splits = imin(imin(ceil_div(768, tiles), nt / 8), 32);
         if (splits < 1) splits = 1;
       }
       g.kt_per_split = ceil_div(nt, splits);
@@ -668,7 +693,7 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
 #undef LAUNCH_FAST
     }
   } else if (a->dtype == EVLM_F32) {
-    g.tiles_i = ceil_div(g.I, FT); g.tiles_j = ceil_div(g.J, FT); g.kt_per_split = 0;
+    g.tiles_i = ceil_div(g.I, FT); g.tiles_j = ceil_div(g.J, FT); g.kt_per_split = 0; g.bare_f32 = 0;
     dim3 grid(g.tiles_i * g.tiles_j), block(256);
 #define LAUNCH_F32(PT_, QT_) hipLaunchKernelGGL((gemm_f32_kernel<PT_, QT_>), grid, block, 0, stream, g)
     if (!pt && !qt) LAUNCH_F32(false, false);
