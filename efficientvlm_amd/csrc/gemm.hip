@@ -26,6 +26,7 @@ struct GemmP {
   int tiles_i, tiles_j;
   int kt_per_split;   // K tiles (of 64) handled by one grid.y slice
   int bare_f32;       // f32 output with no epilogue terms (weight gradients): LDS-staged coalesced store / atomics
+  int accumulate;     // C += result (f32 atomics), no zero-fill
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -412,7 +413,7 @@ __device__ __forceinline__ void gemm_bf16_fast(const GemmP& g, char* smem, int i
       }
     __syncthreads();
     float* Cf = reinterpret_cast<float*>(g.C);
-    if (gridDim.y > 1) {
+    if (gridDim.y > 1 || g.accumulate) {
 #pragma unroll 4
       for (int k = 0; k < BTm * BTm / 256; ++k) {
         const int id = k * 256 + tid, r = id / BTm, c = id % BTm;
@@ -642,6 +643,10 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
   g.preact = a->preact; g.aux = a->aux; g.residual = a->residual;
   g.I = a->I; g.J = a->J; g.K = a->K; g.ldp = a->ldp; g.ldq = a->ldq; g.ldc = a->ldc; g.ldx = a->ldx;
   g.c_f32 = (a->dtype == EVLM_F32) ? 1 : a->c_f32;
+  g.accumulate = a->accumulate;
+  EVLM_REQUIRE(!a->accumulate || (a->dtype == EVLM_BF16 && a->c_f32 && !a->bias && !a->gate && !a->preact && !a->aux &&
+                                   !a->residual && a->act == EVLM_ACT_NONE && a->K % 64 == 0),
+               "evlm_gemm: accumulate needs a bare f32-output bf16 GEMM with K a multiple of 64");
   g.act = a->act; g.gate_pos = a->gate_pos; g.dact = a->dact; g.alpha = a->alpha;
   const int pt = a->p_trans ? 1 : 0, qt = a->q_trans ? 1 : 0;
   if (a->dtype == EVLM_BF16) {
@@ -661,13 +666,14 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
     } else {
       // tile choice: 128x128 unless that leaves most of the 256 CUs (x2 resident workgroups) without work
       const int t128 = ceil_div(g.I, 128) * ceil_div(g.J, 128);
-      const int mt = (t128 >= 384) ? 4 : 2;
+      const bool bare = g.c_f32 && !g.bias && !g.gate && !g.preact && !g.aux && !g.residual && g.act == EVLM_ACT_NONE;
+      // weight gradients with a long reduction keep the big tile and get their parallelism from split-K instead
+      const int mt = (t128 >= 384 || (bare && g.K >= 64 * BK && t128 >= 100)) ? 4 : 2;
       const int bt = 32 * mt;
       g.tiles_i = ceil_div(g.I, bt); g.tiles_j = ceil_div(g.J, bt);
       const int tiles = g.tiles_i * g.tiles_j, nt = g.K / BK;
       // split-K only for bare f32 outputs (weight gradients): combine by f32 atomics into the zeroed output
       int splits = 1;
-      const bool bare = g.c_f32 && !g.bias && !g.gate && !g.preact && !g.aux && !g.residual && g.act == EVLM_ACT_NONE;
       g.bare_f32 = bare ? 1 : 0;
       if (bare && tiles < 512 && nt >= 32) {
         splits = imin(imin(ceil_div(768, tiles), nt / 8), 32);
@@ -675,7 +681,7 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
       }
       g.kt_per_split = ceil_div(nt, splits);
       splits = ceil_div(nt, g.kt_per_split);
-      if (splits > 1) {
+      if (splits > 1 && !g.accumulate) {
         hipError_t me = hipMemsetAsync(g.C, 0, (size_t)g.I * g.ldc * sizeof(float), stream);
         if (me != hipSuccess) return evlm_set_error("evlm_gemm: memset failed: %s", hipGetErrorString(me));
       }

@@ -94,11 +94,13 @@ def _collapsible(x):
 
 
 def _gemm(dtype, P, Q, Cm, I, J, K, ldp, ldq, ldc, p_trans=0, q_trans=0, bias=None, gate=None, preact=None,
-          aux=None, residual=None, ldx=0, alpha=1.0, act=L.ACT_NONE, gate_pos=L.GATE_PRE, dact=L.ACT_NONE, c_f32=0):
+          aux=None, residual=None, ldx=0, alpha=1.0, act=L.ACT_NONE, gate_pos=L.GATE_PRE, dact=L.ACT_NONE, c_f32=0,
+          accumulate=0, p_off=0):
+    Pp = L.ptr(P) if not p_off else C.c_void_p(P.data_ptr() + p_off * P.element_size())
     a = L.GemmArgs(dtype=dtype, c_f32=c_f32, p_trans=p_trans, q_trans=q_trans, I=I, J=J, K=K, ldp=ldp, ldq=ldq,
-                   ldc=ldc, ldx=ldx, P=L.ptr(P), Q=L.ptr(Q), C=L.ptr(Cm), bias=L.ptr(bias), gate=L.ptr(gate),
+                   ldc=ldc, ldx=ldx, P=Pp, Q=L.ptr(Q), C=L.ptr(Cm), bias=L.ptr(bias), gate=L.ptr(gate),
                    preact=L.ptr(preact), aux=L.ptr(aux), residual=L.ptr(residual), alpha=alpha, act=act,
-                   gate_pos=gate_pos, dact=dact)
+                   gate_pos=gate_pos, dact=dact, accumulate=accumulate)
     if GEMM_PROFILE is None:
         L.check(_lib().evlm_gemm(C.byref(a), L.stream()), "gemm")
         return
@@ -109,9 +111,54 @@ def _gemm(dtype, P, Q, Cm, I, J, K, ldp, ldq, ldc, p_trans=0, q_trans=0, bias=No
     GEMM_PROFILE.append((dtype, p_trans, q_trans, I, J, K, e0, e1))
 
 
-def _colsum(x2d, I, J, ld):
-    out = torch.zeros(J, dtype=torch.float32, device=x2d.device)
-    L.check(_lib().evlm_colsum(L.dt(x2d), L.ptr(x2d), I, J, ld, L.ptr(out), L.stream()), "colsum")
+def _colsum(x2d, I, J, ld, out=None, x_off=0):
+    """out[j] += sum_i x[i, x_off + j]; a fresh zero vector when `out` is None"""
+    if out is None:
+        out = torch.zeros(J, dtype=torch.float32, device=x2d.device)
+    xp = L.ptr(x2d) if not x_off else C.c_void_p(x2d.data_ptr() + x_off * x2d.element_size())
+    L.check(_lib().evlm_colsum(L.dt(x2d), xp, I, J, ld, L.ptr(out), L.stream()), "colsum")
+    return out
+
+
+# When True (set by the trainer around backward), parameter gradients are ACCUMULATED straight into `param.grad`
+# (the optimiser's flat fp32 slabs) by the kernels themselves - f32 atomics from the dW GEMM, the bias column sums, the
+# LayerNorm and embedding backward kernels - and the autograd Functions return None for those inputs.  This removes the
+# ~500 per-step `grad += dW` element-wise launches and the dW temporaries.  Off by default (plain autograd semantics).
+WGRAD_INPLACE = False
+
+
+def _inplace(p):
+    g = getattr(p, "grad", None)
+    return WGRAD_INPLACE and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape
+
+
+def _wgrad(dtype, d2, ldd, x2, ldp, M, K, params, rows):
+    """dW_i = dY[:, rows_i]^T X for every packed weight; returns the list of gradients (None where accumulated in place)"""
+    out, r0 = [], 0
+    if not all(_inplace(w) for w in params) or dtype != L.BF16 or M % 64 != 0:
+        N = sum(rows)
+        dW = torch.empty((N, K), dtype=torch.float32, device=x2.device)
+        _gemm(dtype, d2, x2, dW, N, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1)
+        for r in rows:
+            out.append(dW[r0:r0 + r])
+            r0 += r
+        return out
+    for w, r in zip(params, rows):
+        _gemm(dtype, d2, x2, w.grad, r, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1, accumulate=1, p_off=r0)
+        out.append(None)
+        r0 += r
+    return out
+
+
+def _bgrad(d2, M, ldd, params, rows):
+    out, r0 = [], 0
+    for b, r in zip(params, rows):
+        if _inplace(b):
+            _colsum(d2, M, r, ldd, out=b.grad, x_off=r0)
+            out.append(None)
+        else:
+            out.append(_colsum(d2, M, r, ldd, x_off=r0))
+        r0 += r
     return out
 
 
@@ -150,6 +197,7 @@ class _Linear(torch.autograd.Function):
         _gemm(dtype, x2, W, ybuf, M, N, K, ldp, K, ldc, bias=b, preact=preact, residual=r2, ldx=ldc, act=act,
               c_f32=1 if out_f32 else 0)
         ctx.save_for_backward(x2, W, preact)
+        ctx.params = (weights, biases)
         ctx.meta = (M, N, K, ldp, ldc, act, nw, tuple(w.shape[0] for w in weights), biases and biases[0] is not None,
                     residual is not None, x.shape, out_f32)
         y = ybuf[:, :N] if ldc != N else ybuf
@@ -182,19 +230,9 @@ class _Linear(torch.autograd.Function):
             dxb = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
             _gemm(dtype, d2, W, dxb, M, K, N, ldd, K, K, p_trans=0, q_trans=1)     # dX = dY W
             dx = dxb.view(xshape)
-        dW = torch.empty((N, K), dtype=torch.float32, device=x2.device)
-        _gemm(dtype, d2, x2, dW, N, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1)   # dW = dY^T X
-        gw, r0 = [], 0
-        for r in rows:
-            gw.append(dW[r0:r0 + r])
-            r0 += r
-        gb = [None] * nw
-        if has_bias:
-            db = _colsum(d2, M, N, ldd)
-            gb, r0 = [], 0
-            for r in rows:
-                gb.append(db[r0:r0 + r])
-                r0 += r
+        weights, biases = ctx.params
+        gw = _wgrad(dtype, d2, ldd, x2, ldp, M, K, weights, rows)                        # dW = dY^T X
+        gb = _bgrad(d2, M, ldd, biases, rows) if has_bias else [None] * nw
         return (dx, dres, None, None, None, *gw, *gb)
 
 
@@ -233,6 +271,7 @@ class _MLP(torch.autograd.Function):
                 r2 = r2.contiguous()
         _gemm(dtype, a, W2, y, M, N, Fh, Fh, Fh, N, bias=b2.detach(), residual=r2, ldx=N)
         ctx.save_for_backward(x2, W1, W2, h, a, g32)
+        ctx.params = (w1, b1, w2, b2)
         ctx.meta = (M, K, Fh, N, ldp, act, gate_pos, x.shape, gate.shape if gate is not None else None,
                     residual is not None)
         return y.view(*x.shape[:-1], N)
@@ -259,17 +298,16 @@ class _MLP(torch.autograd.Function):
             L.check(lib.evlm_gated_act_bwd(dtype, L.ptr(da), L.ptr(h), L.ptr(g32), M, Fh, Fh, act, gate_pos, L.ptr(dh),
                                            L.ptr(dg), L.stream()), "gated_act_bwd")
             dgate = dg.view(gshape)
-        dW2 = torch.empty((N, Fh), dtype=torch.float32, device=dev)
-        _gemm(dtype, d2, a, dW2, N, Fh, M, N, Fh, Fh, p_trans=1, q_trans=1, c_f32=1)
-        db2 = _colsum(d2, M, N, N)
+        w1, b1, w2, b2 = ctx.params
+        (dW2,) = _wgrad(dtype, d2, N, a, Fh, M, Fh, (w2,), (N,))
+        (db2,) = _bgrad(d2, M, N, (b2,), (N,))
         dx = None
         if ctx.needs_input_grad[0]:
             dxb = torch.empty((M, K), dtype=x2.dtype, device=dev)
             _gemm(dtype, dh, W1, dxb, M, K, Fh, Fh, K, K, p_trans=0, q_trans=1)
             dx = dxb.view(xshape)
-        dW1 = torch.empty((Fh, K), dtype=torch.float32, device=dev)
-        _gemm(dtype, dh, x2, dW1, Fh, K, M, Fh, ldp, K, p_trans=1, q_trans=1, c_f32=1)
-        db1 = _colsum(dh, M, Fh, Fh)
+        (dW1,) = _wgrad(dtype, dh, Fh, x2, ldp, M, K, (w1,), (Fh,))
+        (db1,) = _bgrad(dh, M, Fh, (b1,), (Fh,))
         return dx, dW1, db1, dW2, db2, dgate, (dy if has_res else None), None, None
 
 
@@ -294,6 +332,7 @@ class _LayerNorm(torch.autograd.Function):
         L.check(_lib().evlm_layernorm_fwd(L.dt(xc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(beta.detach()), eps, rows, d,
                                           L.ptr(y), L.ptr(mean), L.ptr(rstd), L.stream()), "layernorm_fwd")
         ctx.save_for_backward(xc, gamma, mean, rstd)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -303,11 +342,13 @@ class _LayerNorm(torch.autograd.Function):
         rows = xc.numel() // d
         dyc = dy if dy.is_contiguous() else dy.contiguous()
         dx = torch.empty_like(xc)
-        dg = torch.zeros(d, dtype=torch.float32, device=xc.device)
-        db = torch.zeros(d, dtype=torch.float32, device=xc.device)
+        pg, pb = ctx.params
+        inplace = _inplace(pg) and _inplace(pb)
+        dg = pg.grad if inplace else torch.zeros(d, dtype=torch.float32, device=xc.device)
+        db = pb.grad if inplace else torch.zeros(d, dtype=torch.float32, device=xc.device)
         L.check(_lib().evlm_layernorm_bwd(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd),
                                           rows, d, L.ptr(dx), L.ptr(dg), L.ptr(db), L.stream()), "layernorm_bwd")
-        return dx, dg, db, None
+        return (dx, None, None, None) if inplace else (dx, dg, db, None)
 
 
 def layer_norm(x, gamma, beta, eps):
@@ -576,6 +617,7 @@ class _BertEmbed(torch.autograd.Function):
         L.check(_lib().evlm_bert_embed_fwd(L.dt(dtype), L.ptr(idc), B, Ln, d, L.ptr(word.detach()), L.ptr(pos.detach()),
                                            L.ptr(typ.detach()), L.ptr(out), L.stream()), "bert_embed_fwd")
         ctx.save_for_backward(idc)
+        ctx.params = (word, typ)
         ctx.meta = (word.shape, pos.shape, typ.shape, pad_id)
         return out
 
@@ -586,12 +628,14 @@ class _BertEmbed(torch.autograd.Function):
         B, Ln = idc.shape
         d = wshape[1]
         dec = de if de.is_contiguous() else de.contiguous()
-        dword = torch.zeros(wshape, dtype=torch.float32, device=de.device)
+        word, typ = ctx.params
+        wi, ti = _inplace(word), _inplace(typ)
+        dword = word.grad if wi else torch.zeros(wshape, dtype=torch.float32, device=de.device)   # 94 MB at full size
         dpos = torch.zeros(pshape, dtype=torch.float32, device=de.device)
-        dtyp = torch.zeros(tshape, dtype=torch.float32, device=de.device)
+        dtyp = typ.grad if ti else torch.zeros(tshape, dtype=torch.float32, device=de.device)
         L.check(_lib().evlm_bert_embed_bwd(L.dt(dec), L.ptr(idc), B, Ln, d, L.ptr(dec), pad_id, L.ptr(dword), L.ptr(dpos),
                                            L.ptr(dtyp), L.stream()), "bert_embed_bwd")
-        return None, dword, dpos, dtyp, None, None
+        return None, (None if wi else dword), dpos, (None if ti else dtyp), None, None
 
 
 def bert_embed(ids, word, pos, typ, pad_id, dtype):
@@ -619,6 +663,7 @@ class _VitEmbed(torch.autograd.Function):
         L.check(lib.evlm_vit_embed_fwd(L.dt(dtype), L.ptr(tok), L.ptr(cls.detach()), L.ptr(pos.detach()), B, Tn, d, L.ptr(x),
                                        L.stream()), "vit_embed_fwd")
         ctx.save_for_backward(patches)
+        ctx.params = (patch_w, cls, pos)
         ctx.meta = (B, Tn, d, K, patch_w.shape, pos.shape)
         return x
 
@@ -628,14 +673,21 @@ class _VitEmbed(torch.autograd.Function):
         B, Tn, d, K, wshape, pshape = ctx.meta
         lib = _lib()
         dxc = dx if dx.is_contiguous() else dx.contiguous()
+        patch_w, cls, pos = ctx.params
         dtok = torch.empty((B * Tn, d), dtype=dxc.dtype, device=dx.device)
-        dcls = torch.zeros(d, dtype=torch.float32, device=dx.device)
-        dpos = torch.zeros(pshape, dtype=torch.float32, device=dx.device)
+        ci, pi = _inplace(cls), _inplace(pos)
+        dcls = cls.grad if ci else torch.zeros(d, dtype=torch.float32, device=dx.device)
+        dpos = pos.grad if pi else torch.zeros(pshape, dtype=torch.float32, device=dx.device)
         L.check(lib.evlm_vit_embed_bwd(L.dt(dxc), L.ptr(dxc), B, Tn, d, L.ptr(dtok), L.ptr(dcls), L.ptr(dpos), L.stream()),
                 "vit_embed_bwd")
-        dW = torch.empty((d, K), dtype=torch.float32, device=dx.device)
-        _gemm(L.dt(dxc), dtok, patches, dW, d, K, B * Tn, d, K, K, p_trans=1, q_trans=1, c_f32=1)
-        return None, dW.view(wshape), dcls, dpos, None, None
+        if _inplace(patch_w) and L.dt(dxc) == L.BF16 and (B * Tn) % 64 == 0:
+            _gemm(L.BF16, dtok, patches, patch_w.grad, d, K, B * Tn, d, K, K, p_trans=1, q_trans=1, c_f32=1, accumulate=1)
+            dW = None
+        else:
+            dWb = torch.empty((d, K), dtype=torch.float32, device=dx.device)
+            _gemm(L.dt(dxc), dtok, patches, dWb, d, K, B * Tn, d, K, K, p_trans=1, q_trans=1, c_f32=1)
+            dW = dWb.view(wshape)
+        return None, dW, (None if ci else dcls), (None if pi else dpos), None, None
 
 
 def vit_embed(image, patch_w, cls, pos, patch, dtype):

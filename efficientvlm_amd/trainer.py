@@ -80,6 +80,7 @@ class GDTrainer:
         self.reducer = GradReducer(self.opt.flat_grads, compress=grad_compress)
         self.world = self.reducer.world
         self.use_graph = use_graph
+        self.wgrad_inplace = True
         self.graph = None
         self.static = None
         self.out = None
@@ -92,7 +93,11 @@ class GDTrainer:
         self.opt.zero_grad()
         with compute(self.dtype):
             total, S, T, kd, mix = distill.gd_forward(self.student, self.teacher, batch, self.temperature)
-            total.backward()
+            ops.WGRAD_INPLACE = self.wgrad_inplace      # kernels sum parameter gradients straight into the flat slabs
+            try:
+                total.backward()
+            finally:
+                ops.WGRAD_INPLACE = False
         return torch.stack([total.detach().float(), S["loss"]["loss_itc"].detach().float(),
                             S["loss"]["loss_itm"].detach().float(), S["loss"]["loss_mlm"].detach().float(),
                             mix["loss_kd"].detach().float()])

@@ -66,6 +66,8 @@ typedef struct {
   int act;              /* EVLM_ACT_* */
   int gate_pos;         /* EVLM_GATE_* */
   int dact;             /* EVLM_ACT_* : multiply by act'(aux) */
+  int accumulate;       /* 1: C += result (f32 atomics; bare f32-output bf16 GEMMs only) — weight gradients summed
+                           straight into the optimiser's gradient slab */
 } evlm_gemm_args;
 
 int evlm_gemm(const evlm_gemm_args* args, void* stream);

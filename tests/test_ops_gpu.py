@@ -388,3 +388,41 @@ def test_gemm_large_tiles_and_split_k(pt, qt):
         Bm = Qm.float().t() if qt else Qm.float()
         ref = A @ Bm.t()
         assert rel_err(Cm.float(), ref) < (2e-5 if c_f32 else tol(dtype)), (I, J, K, c_f32)
+
+
+def test_inplace_parameter_gradients_match_autograd():
+    """WGRAD_INPLACE (the trainer's mode): kernels accumulate dW / db / dgamma / dbeta straight into param.grad"""
+    o = ops()
+    from efficientvlm_amd import _lib as L
+    g = torch.Generator().manual_seed(43)
+    dtype = torch.bfloat16
+    M, K, N, Fh = 256, 64, 72, 136
+    x = rnd((2, M // 2, K), dtype, g)
+
+    def make():
+        gg = torch.Generator().manual_seed(7)
+        mk = lambda *s: torch.nn.Parameter(rnd(s, torch.float32, gg, 0.3))
+        return dict(ws=[mk(N, K) for _ in range(3)], bs=[mk(N) for _ in range(3)], w1=mk(Fh, 3 * N), b1=mk(Fh),
+                    w2=mk(K, Fh), b2=mk(K), gm=mk(K), bt=mk(K))
+
+    def run(P, inplace):
+        params = P["ws"] + P["bs"] + [P["w1"], P["b1"], P["w2"], P["b2"], P["gm"], P["bt"]]
+        for p in params:
+            p.grad = torch.full_like(p, 0.5) if inplace else None    # pre-existing content must be ADDED to
+        xi = x.clone().requires_grad_(True)
+        h = o.linear_packed(xi, P["ws"], P["bs"])
+        y = o.mlp(h, P["w1"], P["b1"], P["w2"], P["b2"], L.ACT_GELU, gate_pos=L.GATE_POST)
+        y = o.layer_norm(y, P["gm"], P["bt"], 1e-5)
+        y2 = o.linear_packed(xi, P["ws"], P["bs"])                    # the same weights used twice
+        o.WGRAD_INPLACE = inplace
+        try:
+            (y.float().square().mean() + y2.float().mean()).backward()
+        finally:
+            o.WGRAD_INPLACE = False
+        return [p.grad.clone() - (0.5 if inplace else 0.0) for p in params], xi.grad
+
+    ga, xa = run(make(), False)
+    gb, xb = run(make(), True)
+    assert rel_err(xb.float(), xa.float()) < 1e-6
+    for a, b in zip(ga, gb):
+        assert rel_err(b, a) < 3e-4      # the 0.5 pre-fill costs ~6e-8 absolute on gradients of ~1e-4
