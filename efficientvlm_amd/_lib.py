@@ -37,7 +37,7 @@ class AttnFwdArgs(C.Structure):
 
 class AttnBwdArgs(C.Structure):
     _fields_ = [("dtype", _i), ("p_dtype", _i),
-                ("B", _i), ("H", _i), ("Lq", _i), ("Lk", _i), ("dh", _i),
+                ("B", _i), ("H", _i), ("Lq", _i), ("Lk", _i), ("dh", _i), ("Bkv", _i),
                 ("ldq", _i), ("ldk", _i), ("ldv", _i), ("ldo", _i),
                 ("lddq", _i), ("lddk", _i), ("lddv", _i), ("ldpr", _i),
                 ("Q", _vp), ("K", _vp), ("V", _vp), ("P", _vp), ("dO", _vp), ("dP_ext", _vp),

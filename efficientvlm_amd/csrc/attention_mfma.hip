@@ -166,8 +166,9 @@ static int launch_fwd(const MAttnF& f, hipStream_t stream) {
 // =============================================================================================
 struct MAttnB {
   const bf16* Q; const bf16* K; const bf16* V; const bf16* P; const bf16* dO; const bf16* E; const float* gate;
+  const int32_t* kv_index;
   bf16* dS; bf16* dQ; bf16* dK; bf16* dV; float* dgate;
-  int B, H, Lq, Lk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, ldpr;
+  int B, Bkv, H, Lq, Lk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, ldpr;
   float scale;
 };
 
@@ -181,8 +182,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   char* Vs = smem + NT * 16 * 128;          // k_swz (row reads)
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
-  stage_rows<true>(a.K + (size_t)b * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
-  stage_rows<false>(a.V + (size_t)b * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
+  const int bkv = a.kv_index ? a.kv_index[b] : b;
+  stage_rows<true>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
+  stage_rows<false>(a.V + (size_t)bkv * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
   __syncthreads();
   const int q0 = blockIdx.x * 64 + wave * 16;
   if (q0 >= a.Lq) return;
@@ -225,9 +227,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   }
   dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
   if (a.dgate) {
-    float gs = (g == 0) ? 0.f : 0.f;
-    gs = gsum;                                   // every lane holds a partial over its keys; the wave sum is the total
-    gs = wave_sum(gs);
+    const float gs = wave_sum(gsum);             // every lane holds a partial over its own keys: the wave sum is the total
     if (lane == 0) atomicAdd(a.dgate + h, gs);
   }
   bf16x4 dsk[NT];
@@ -292,33 +292,39 @@ __device__ __forceinline__ bf16x8 qcol_frag(const char* sm, int ct, int lane) {
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
   __shared__ __attribute__((aligned(16))) char sm[4 * 32 * 128];
   char* Qs = sm; char* dOs = sm + 4096; char* Ps = sm + 8192; char* Ss = sm + 12288;
-  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
+  const int bkv = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const bf16* Qb = a.Q + (size_t)b * a.Lq * a.ldq + h * DH;
-  const bf16* dOb = a.dO + (size_t)b * a.Lq * a.ldo + h * DH;
-  const size_t pbase = ((size_t)b * a.H + h) * a.Lq * a.ldpr;
   f32x4 dk[4], dv[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  for (int q0 = 0; q0 < a.Lq; q0 += 32) {
-    __syncthreads();
-    stage_qtile(Qb, a.ldq, q0, a.Lq, 0, DH, Qs);
-    stage_qtile(dOb, a.ldo, q0, a.Lq, 0, DH, dOs);
-    stage_qtile(a.P + pbase, a.ldpr, q0, a.Lq, k0, a.ldpr, Ps);
-    stage_qtile(a.dS + pbase, a.ldpr, q0, a.Lq, k0, a.ldpr, Ss);
-    __syncthreads();
-    const bf16x8 bS = qcol_frag(Ss, wave, lane), bP = qcol_frag(Ps, wave, lane);
+  // every query batch that attends to this K/V row (one without kv_index; the positive / hard-negative / MLM passes
+  // that share an image with it): their contributions are summed here, in registers, in batch order (deterministic)
+  const int b_lo = a.kv_index ? 0 : bkv, b_hi = a.kv_index ? a.B : bkv + 1;
+  for (int b = b_lo; b < b_hi; ++b) {
+    if (a.kv_index && a.kv_index[b] != bkv) continue;       // block-uniform
+    const bf16* Qb = a.Q + (size_t)b * a.Lq * a.ldq + h * DH;
+    const bf16* dOb = a.dO + (size_t)b * a.Lq * a.ldo + h * DH;
+    const size_t pbase = ((size_t)b * a.H + h) * a.Lq * a.ldpr;
+    for (int q0 = 0; q0 < a.Lq; q0 += 32) {
+      __syncthreads();
+      stage_qtile(Qb, a.ldq, q0, a.Lq, 0, DH, Qs);
+      stage_qtile(dOb, a.ldo, q0, a.Lq, 0, DH, dOs);
+      stage_qtile(a.P + pbase, a.ldpr, q0, a.Lq, k0, a.ldpr, Ps);
+      stage_qtile(a.dS + pbase, a.ldpr, q0, a.Lq, k0, a.ldpr, Ss);
+      __syncthreads();
+      const bf16x8 bS = qcol_frag(Ss, wave, lane), bP = qcol_frag(Ps, wave, lane);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qcol_frag(Qs, dt, lane), bS, dk[dt], 0, 0, 0);
-      dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qcol_frag(dOs, dt, lane), bP, dv[dt], 0, 0, 0);
+      for (int dt = 0; dt < 4; ++dt) {
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qcol_frag(Qs, dt, lane), bS, dk[dt], 0, 0, 0);
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qcol_frag(dOs, dt, lane), bP, dv[dt], 0, 0, 0);
+      }
     }
   }
   const int key = k0 + wave * 16 + (lane & 15);
   if (key < a.Lk) {
     const float gz = a.gate ? a.gate[h] : 1.0f;
-    bf16* dKr = a.dK + ((size_t)b * a.Lk + key) * a.lddk + h * DH;
-    bf16* dVr = a.dV + ((size_t)b * a.Lk + key) * a.lddv + h * DH;
+    bf16* dKr = a.dK + ((size_t)bkv * a.Lk + key) * a.lddk + h * DH;
+    bf16* dVr = a.dV + ((size_t)bkv * a.Lk + key) * a.lddv + h * DH;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       bf16x4 kv = {(bf16)(dk[dt][0] * a.scale), (bf16)(dk[dt][1] * a.scale), (bf16)(dk[dt][2] * a.scale), (bf16)(dk[dt][3] * a.scale)};
@@ -340,11 +346,12 @@ static void launch_bwd_dq(const MAttnB& f, hipStream_t stream) {
 
 int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int* handled) {
   *handled = 0;
-  if (a->dtype != EVLM_BF16 || a->p_dtype != EVLM_BF16 || a->dh != DH || a->Lk > 608 || a->kv_index) return 0;
+  if (a->dtype != EVLM_BF16 || a->p_dtype != EVLM_BF16 || a->dh != DH || a->Lk > 608) return 0;
   if ((a->ldq | a->ldk | a->ldv | a->ldo | a->lddq | a->lddk | a->lddv | a->ldpr) % 8 != 0) return 0;
   MAttnB f;
   f.Q = (const bf16*)a->Q; f.K = (const bf16*)a->K; f.V = (const bf16*)a->V; f.P = (const bf16*)a->P;
-  f.dO = (const bf16*)a->dO; f.E = (const bf16*)a->dP_ext; f.gate = a->head_gate;
+  f.dO = (const bf16*)a->dO; f.E = (const bf16*)a->dP_ext; f.gate = a->head_gate; f.kv_index = a->kv_index;
+  f.Bkv = a->kv_index ? a->Bkv : a->B;
   f.dS = (bf16*)a->dS; f.dQ = (bf16*)a->dQ; f.dK = (bf16*)a->dK; f.dV = (bf16*)a->dV; f.dgate = a->dgate;
   f.B = a->B; f.H = a->H; f.Lq = a->Lq; f.Lk = a->Lk; f.ldq = a->ldq; f.ldk = a->ldk; f.ldv = a->ldv; f.ldo = a->ldo;
   f.lddq = a->lddq; f.lddk = a->lddk; f.lddv = a->lddv; f.ldpr = a->ldpr; f.scale = a->scale;
@@ -353,7 +360,7 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
   else if (a->Lk <= 224) launch_bwd_dq<14>(f, stream);
   else if (a->Lk <= 416) launch_bwd_dq<26>(f, stream);
   else launch_bwd_dq<38>(f, stream);
-  dim3 gridB((a->Lk + 63) / 64, a->H, a->B), block(256);
+  dim3 gridB((a->Lk + 63) / 64, a->H, f.Bkv), block(256);
   hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, gridB, block, 0, stream, f);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return evlm_set_error("evlm_attention_bwd(mfma): %s", hipGetErrorString(e));

@@ -48,40 +48,44 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 }
 
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma += sum_rows dy*xhat;  dbeta += sum_rows dy.
-// Each block walks rows blockIdx.x*4 + w, += gridDim.x*4 and keeps per-thread partial dgamma/dbeta for the
-// columns it owns (d <= 64*8*DCH), reduced over the 4 waves through LDS, then ONE atomicAdd per column per block.
-#define LN_DCH 6   // up to 64*8*6 = 3072 columns
-template <typename T>
+// One wave per row, the row (x, dy) is read ONCE and kept in registers (DCH 16-byte chunks per lane: d <= 512*DCH).
+// Each block walks rows blockIdx.x*4 + w, += gridDim.x*4 and keeps per-lane partial dgamma/dbeta for the columns it
+// owns; the 4 waves are reduced through LDS, then ONE f32 atomic per column per block.
+template <typename T, int DCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, int rows, int d, T* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  extern __shared__ float sred[];   // [2][d]
+  extern __shared__ float sred[];   // [4 waves][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
-  float pg[LN_DCH][8], pb[LN_DCH][8];
+  float pg[DCH][8], pb[DCH][8], gm[DCH][8];
 #pragma unroll
-  for (int u = 0; u < LN_DCH; ++u)
+  for (int u = 0; u < DCH; ++u) {
+    const int c = lane + 64 * u;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { pg[u][e] = 0.f; pb[u][e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { pg[u][e] = 0.f; pb[u][e] = 0.f; gm[u][e] = 0.f; }
+    if (c < nchunk) load8<float>(gamma + c * 8, gm[u]);
+  }
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     const T* xr = x + (size_t)row * d;
     const T* dr = dy + (size_t)row * d;
     const float mu = mean[row], rs = rstd[row];
+    float xh[DCH][8], gd[DCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < LN_DCH; ++u) {
+    for (int u = 0; u < DCH; ++u) {
       const int c = lane + 64 * u;
       if (c < nchunk) {
-        float xv[8], dv[8], gm[8];
+        float xv[8], dv[8];
         load8<T>(xr + c * 8, xv);
         load8<T>(dr + c * 8, dv);
-        load8<float>(gamma + c * 8, gm);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float xh = (xv[e] - mu) * rs, gd = gm[e] * dv[e];
-          s1 += gd; s2 += gd * xh;
-          pg[u][e] += dv[e] * xh; pb[u][e] += dv[e];
+          xh[u][e] = (xv[e] - mu) * rs;
+          gd[u][e] = gm[u][e] * dv[e];
+          s1 += gd[u][e]; s2 += gd[u][e] * xh[u][e];
+          pg[u][e] += dv[e] * xh[u][e]; pb[u][e] += dv[e];
         }
       }
     }
@@ -89,42 +93,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     s2 = wave_sum(s2) / (float)d;
     T* dxr = dx + (size_t)row * d;
 #pragma unroll
-    for (int u = 0; u < LN_DCH; ++u) {
+    for (int u = 0; u < DCH; ++u) {
       const int c = lane + 64 * u;
       if (c < nchunk) {
-        float xv[8], dv[8], gm[8], o[8];
-        load8<T>(xr + c * 8, xv);
-        load8<T>(dr + c * 8, dv);
-        load8<float>(gamma + c * 8, gm);
+        float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xh = (xv[e] - mu) * rs;
-          o[e] = rs * (gm[e] * dv[e] - s1 - xh * s2);
-        }
+        for (int e = 0; e < 8; ++e) o[e] = rs * (gd[u][e] - s1 - xh[u][e] * s2);
         store8<T>(dxr + c * 8, o);
       }
     }
   }
-  // reduce the 4 waves' partials
-  float* sg = sred;
-  float* sb = sred + d;
-  for (int i = threadIdx.x; i < 2 * d; i += 256) sred[i] = 0.f;
-  __syncthreads();
+  float* mine = sred + wave * 2 * d;
 #pragma unroll
-  for (int u = 0; u < LN_DCH; ++u) {
+  for (int u = 0; u < DCH; ++u) {
     const int c = lane + 64 * u;
     if (c < nchunk) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        atomicAdd(&sg[c * 8 + e], pg[u][e]);
-        atomicAdd(&sb[c * 8 + e], pb[u][e]);
-      }
+      store8<float>(mine + c * 8, pg[u]);
+      store8<float>(mine + d + c * 8, pb[u]);
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < d; i += 256) {
-    atomicAdd(dgamma + i, sg[i]);
-    atomicAdd(dbeta + i, sb[i]);
+  for (int i = threadIdx.x; i < 2 * d; i += 256) {
+    const float v = sred[i] + sred[2 * d + i] + sred[4 * d + i] + sred[6 * d + i];
+    atomicAdd((i < d ? dgamma + i : dbeta + (i - d)), v);
   }
 }
 
@@ -145,12 +136,14 @@ extern "C" int evlm_layernorm_bwd(int dtype, const void* dy, const void* x, cons
                                   void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "evlm_layernorm_bwd: bad args");
-  EVLM_REQUIRE(d % 8 == 0 && d <= 64 * 8 * LN_DCH, "evlm_layernorm_bwd: d=%d unsupported (multiple of 8, <= %d)", d, 64 * 8 * LN_DCH);
-  const int nblk = imin(ceil_div(rows, 4), 1024);
+  EVLM_REQUIRE(d % 8 == 0 && d <= 2048, "evlm_layernorm_bwd: d=%d unsupported (multiple of 8, <= 2048)", d);
+  const int nblk = imin(ceil_div(rows, 8), 1024);      // >= 2 rows per wave: amortises the per-block column atomics
   dim3 grid(nblk), block(256);
-  const size_t lds = 2 * (size_t)d * sizeof(float);
+  const size_t lds = 8 * (size_t)d * sizeof(float);
+#define LN_BWD(DCH_) hipLaunchKernelGGL((ln_bwd_kernel<T, DCH_>), grid, block, lds, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, rows, d, (T*)dx, dgamma, dbeta)
   EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_bwd",
-    hipLaunchKernelGGL((ln_bwd_kernel<T>), grid, block, lds, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, rows, d, (T*)dx, dgamma, dbeta);)
+    if (d <= 512) LN_BWD(1); else if (d <= 1024) LN_BWD(2); else if (d <= 1536) LN_BWD(3); else LN_BWD(4);)
+#undef LN_BWD
   EVLM_LAUNCH_CHECK("evlm_layernorm_bwd");
   return 0;
 }

@@ -83,8 +83,12 @@ class BertSelfAttention(nn.Module):
         self.is_cross_attention = is_cross_attention
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
-                encoder_attention_mask=None, past_key_value=None, output_attentions=False, head_z=None):
-        """returns (context [B,L,all_head], probs | None).  masks are additive [B,1,1,Lk] (key masks)."""
+                encoder_attention_mask=None, past_key_value=None, output_attentions=False, head_z=None,
+                encoder_batch_index=None):
+        """returns (context [B,L,all_head], probs | None).  masks are additive [B,1,1,Lk] (key masks).
+
+        encoder_batch_index (extension): LongTensor [B] mapping each text batch row to its row of encoder_hidden_states,
+        so the K/V projection of an image shared by several text rows is computed (and differentiated) once."""
         if head_mask is not None or past_key_value is not None:
             raise NotImplementedError("head_mask / past_key_value are off the distillation path")
         H, dh = self.num_attention_heads, self.attention_head_size
@@ -93,7 +97,7 @@ class BertSelfAttention(nn.Module):
             q = ops.linear(hidden_states, self.query.weight, self.query.bias)
             kv = ops.linear_packed(encoder_hidden_states, (self.key.weight, self.value.weight), (self.key.bias, self.value.bias))
             ctx, probs = ops.cross_attention(q, kv, H, dh, scale, mask=_key_mask(encoder_attention_mask), gate=head_z,
-                                             want_probs=bool(output_attentions))
+                                             want_probs=bool(output_attentions), kv_index=encoder_batch_index)
         else:
             qkv = ops.linear_packed(hidden_states, (self.query.weight, self.key.weight, self.value.weight),
                                     (self.query.bias, self.key.bias, self.value.bias))
@@ -153,9 +157,10 @@ class BertAttention(nn.Module):
         self.pruned_heads = self.pruned_heads.union(heads)
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
-                encoder_attention_mask=None, past_key_value=None, output_attentions=False, head_z=None, head_layer_z=None):
+                encoder_attention_mask=None, past_key_value=None, output_attentions=False, head_z=None, head_layer_z=None,
+                encoder_batch_index=None):
         self_outputs = self.self(hidden_states, attention_mask, head_mask, encoder_hidden_states, encoder_attention_mask,
-                                 past_key_value, output_attentions, head_z=head_z)
+                                 past_key_value, output_attentions, head_z=head_z, encoder_batch_index=encoder_batch_index)
         attention_output = self.output(self_outputs[0], hidden_states, head_layer_z=head_layer_z)
         return (attention_output,) + self_outputs[1:]
 
@@ -203,7 +208,7 @@ class BertLayer(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_value=None, output_attentions=False, head_z=None,
-                head_layer_z=None, mlp_z=None):
+                head_layer_z=None, mlp_z=None, encoder_batch_index=None):
         if self.has_cross_attention and head_z is not None:
             assert isinstance(head_z, tuple)
             head_z, cross_head_z = head_z
@@ -221,7 +226,8 @@ class BertLayer(nn.Module):
             else:
                 enc, enc_mask = encoder_hidden_states, encoder_attention_mask
             cross_attention_outputs = self.crossattention(attention_output, attention_mask, head_mask, enc, enc_mask,
-                                                          output_attentions=output_attentions, head_z=cross_head_z)
+                                                          output_attentions=output_attentions, head_z=cross_head_z,
+                                                          encoder_batch_index=encoder_batch_index)
             attention_output = cross_attention_outputs[0]
             outputs = outputs + cross_attention_outputs[1:-1]
         self.mlp_z = mlp_z
@@ -247,7 +253,8 @@ class BertEncoder(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_values=None, use_cache=None, output_attentions=False,
-                output_hidden_states=False, return_dict=True, mode="multi_modal", head_z=None, head_layer_z=None, mlp_z=None):
+                output_hidden_states=False, return_dict=True, mode="multi_modal", head_z=None, head_layer_z=None, mlp_z=None,
+                encoder_batch_index=None):
         all_hidden_states = () if output_hidden_states else None
         all_self_attentions = () if output_attentions else None
         all_cross_attentions = () if output_attentions else None
@@ -275,7 +282,8 @@ class BertEncoder(nn.Module):
                 cur_mlp_z, cur_head_z = None, None
             layer_outputs = layer_module(hidden_states, attention_mask, None, encoder_hidden_states, encoder_attention_mask,
                                          None, output_attentions, head_z=cur_head_z if head_z is not None else None,
-                                         mlp_z=cur_mlp_z if mlp_z is not None else None)
+                                         mlp_z=cur_mlp_z if mlp_z is not None else None,
+                                         encoder_batch_index=encoder_batch_index)
             hidden_states = layer_outputs[0]
             if output_attentions:
                 all_self_attentions = all_self_attentions + (layer_outputs[1],)
@@ -428,7 +436,8 @@ class BertModel(BertPreTrainedModel):
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
                 inputs_embeds=None, encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None,
-                return_dict=None, is_decoder=False, mode="multi_modal", head_z=None, head_layer_z=None, mlp_z=None):
+                return_dict=None, is_decoder=False, mode="multi_modal", head_z=None, head_layer_z=None, mlp_z=None,
+                encoder_batch_index=None):
         output_attentions = output_attentions if output_attentions is not None else self.config.output_attentions
         output_hidden_states = output_hidden_states if output_hidden_states is not None else self.config.output_hidden_states
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
@@ -470,7 +479,8 @@ class BertModel(BertPreTrainedModel):
                                        encoder_hidden_states=encoder_hidden_states,
                                        encoder_attention_mask=encoder_extended_attention_mask,
                                        output_attentions=output_attentions, output_hidden_states=output_hidden_states,
-                                       return_dict=return_dict, mode=mode, head_z=head_z, head_layer_z=head_layer_z, mlp_z=mlp_z)
+                                       return_dict=return_dict, mode=mode, head_z=head_z, head_layer_z=head_layer_z, mlp_z=mlp_z,
+                                       encoder_batch_index=encoder_batch_index)
         sequence_output = encoder_outputs[0]
         if not return_dict:
             return (sequence_output, None) + tuple(encoder_outputs[1:])

@@ -5,6 +5,10 @@ import torch
 from .xvlm import XVLMBase
 
 
+from .. import ops
+from ..efficient_models.xvlm import mlp_head_forward
+
+
 class XVLM(XVLMBase):
     def __init__(self, config):
         # the reference hard-codes load_vision_params=load_text_params=True (model_pretrain.py:7-8); a config may set
@@ -13,12 +17,20 @@ class XVLM(XVLMBase):
         super().__init__(config, load_vision_params=load, load_text_params=load, use_contrastive_loss=True,
                          use_matching_loss=True, use_mlm_loss=True, use_bbox_loss=True, config_text=None)
 
+    # One batched pass instead of the reference's four: the text layers run once on [text ; masked text]
+    # (2B rows) and the fusion layers once on [ITM-pos ; ITM-neg (2B) ; MLM] (4B rows); the cross-attention K/V projection
+    # of each image is computed once per fusion layer and shared through a batch index instead of being recomputed for
+    # the gathered hard-negative copies.  Row-wise identical arithmetic, 3-4x larger GEMMs, ~1/3 of the launches.
+    batched_passes = True
+
     def forward(self, image, text_ids, text_atts, text_ids_masked=None, masked_pos=None, masked_ids=None, image_atts=None,
                 idx_to_group_img=None, target_bbox=None, is_image=None, ret_bbox_loss=False, output_attentions=None,
                 output_hidden_states=None):
         assert output_attentions == output_hidden_states
         if ret_bbox_loss:
             raise NotImplementedError("region (bbox) batches are outside the benchmarked general-distillation path")
+        if self.batched_passes and output_attentions:
+            return self._forward_batched(image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids)
         out = self.get_vision_embeds(image, output_attentions=output_attentions, output_hidden_states=output_hidden_states)
         image_embeds, image_atts, image_hidden_states, image_attentions = out
         t = self.get_text_embeds(text_ids, text_atts, output_attentions=output_attentions, output_hidden_states=output_hidden_states)
@@ -48,5 +60,59 @@ class XVLM(XVLMBase):
         logits_dict["mlm_logits"] = mlm[1]
         cross_attention_dict["mlm_cross_attentions"] = mlm[4]
         loss = {"loss_itc": loss_itc, "loss_itm": itm["loss"], "loss_mlm": mlm[0]}
+        return {"loss": loss, "hidden_dict": hidden_dict, "attention_dict": attention_dict,
+                "cross_attention_dict": cross_attention_dict, "logits_dict": logits_dict}
+
+    def _forward_batched(self, image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids):
+        """same outputs as the pass-by-pass forward above (reference model_pretrain.py:11-82), batched as described at
+        `batched_passes`."""
+        B = image.shape[0]
+        dev = image.device
+        image_embeds, image_atts, image_hidden_states, image_attentions = self.get_vision_embeds(
+            image, output_attentions=True, output_hidden_states=True)
+        core = self._text_core()
+        # text layers 0..F-1 on [text_ids ; text_ids_masked]
+        t = core(torch.cat([text_ids, text_ids_masked], 0), attention_mask=torch.cat([text_atts, text_atts], 0),
+                 return_dict=True, mode="text", output_attentions=True, output_hidden_states=True)
+        text_embeds, mlm_text = t.last_hidden_state[:B], t.last_hidden_state[B:]
+        text_hidden_states = tuple(h[:B] for h in t.hidden_states)
+        text_attentions = tuple(a[:B] for a in t.attentions)
+        with torch.no_grad():
+            self.temp.clamp_(0.001, 0.5)
+        image_feat, text_feat = self.get_features(image_embeds, text_embeds)
+        loss_itc = self.get_contrastive_loss(image_feat, text_feat)
+        img_neg, txt_neg = self._sample_negatives(image_feat, text_feat, None)
+        self.last_neg_idx = torch.cat([img_neg, txt_neg])
+        # fusion layers on [pos (B) ; neg (2B: text|text_neg x img_neg|img) ; mlm (B)]
+        ar = torch.arange(B, device=dev)
+        txt_all = torch.cat([text_embeds, text_embeds, torch.index_select(text_embeds, 0, txt_neg), mlm_text], 0)
+        atts_all = torch.cat([text_atts, text_atts, torch.index_select(text_atts, 0, txt_neg), text_atts], 0)
+        img_index = torch.cat([ar, img_neg, ar, ar], 0)
+        f = core(encoder_embeds=txt_all, attention_mask=atts_all, encoder_hidden_states=image_embeds,
+                 encoder_attention_mask=torch.index_select(image_atts, 0, img_index), encoder_batch_index=img_index,
+                 return_dict=True, mode="fusion", output_attentions=True, output_hidden_states=True)
+        cut = lambda tup, lo, hi: tuple(x[lo:hi] for x in tup)
+        last = f.last_hidden_state
+        itm_logits = mlp_head_forward(self.itm_head, last[:3 * B, 0, :])
+        itm_labels = torch.cat([torch.ones(B, dtype=torch.long, device=dev), torch.zeros(2 * B, dtype=torch.long, device=dev)])
+        loss_itm = ops.cross_entropy(itm_logits, itm_labels)
+        # MLM head on the masked positions of the last quarter
+        enc = self.text_encoder
+        mlm_seq = enc.gather_seq_out_by_pos(last[3 * B:], masked_pos)
+        mlm_logits = enc.cls(mlm_seq)
+        loss_mlm = ops.cross_entropy(mlm_logits.reshape(-1, enc.config.vocab_size), masked_ids.reshape(-1))
+        nF = len(t.attentions)
+        hidden_dict = {"image_hidden_states": image_hidden_states, "text_hidden_states": text_hidden_states,
+                       "itm_pos_hidden_states": cut(f.hidden_states, 0, B),
+                       "itm_neg_hidden_states": cut(f.hidden_states, B, 3 * B),
+                       "mlm_hidden_states": tuple(h[B:] for h in t.hidden_states[:nF]) + cut(f.hidden_states, 3 * B, 4 * B)}
+        attention_dict = {"image_attentions": image_attentions, "text_attentions": text_attentions,
+                          "itm_pos_attentions": cut(f.attentions, 0, B), "itm_neg_attentions": cut(f.attentions, B, 3 * B),
+                          "mlm_attentions": tuple(a[B:] for a in t.attentions) + cut(f.attentions, 3 * B, 4 * B)}
+        cross_attention_dict = {"itm_pos_cross_attentions": cut(f.cross_attentions, 0, B),
+                                "itm_neg_cross_attentions": cut(f.cross_attentions, B, 3 * B),
+                                "mlm_cross_attentions": cut(f.cross_attentions, 3 * B, 4 * B)}
+        logits_dict = {"itm_head_logits": itm_logits, "mlm_logits": mlm_logits}
+        loss = {"loss_itc": loss_itc, "loss_itm": loss_itm, "loss_mlm": loss_mlm}
         return {"loss": loss, "hidden_dict": hidden_dict, "attention_dict": attention_dict,
                 "cross_attention_dict": cross_attention_dict, "logits_dict": logits_dict}

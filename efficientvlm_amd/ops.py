@@ -363,7 +363,7 @@ class _Attention(torch.autograd.Function):
     v_off (qbuf is kvbuf for self-attention).  Returns (O [B,Lq,H*dh], P [B,H,Lq,Lk])."""
 
     @staticmethod
-    def forward(ctx, qbuf, kvbuf, mask, gate, H, dh, q_off, k_off, v_off, scale, want_probs):
+    def forward(ctx, qbuf, kvbuf, mask, gate, H, dh, q_off, k_off, v_off, scale, want_probs, kv_index=None):
         L.require_cuda(qbuf, kvbuf)
         assert qbuf.is_contiguous() and kvbuf.is_contiguous()
         B, Lq, ldq = qbuf.shape
@@ -380,16 +380,17 @@ class _Attention(torch.autograd.Function):
         a = L.AttnFwdArgs(dtype=L.dt(tdt), p_dtype=L.dt(tdt), B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, ldq=ldq, ldk=ldk, ldv=ldk,
                           ldo=H * dh, ldpr=Lkp, Q=C.c_void_p(qbuf.data_ptr() + q_off * es),
                           K=C.c_void_p(kvbuf.data_ptr() + k_off * es), V=C.c_void_p(kvbuf.data_ptr() + v_off * es),
-                          kv_index=None, mask=L.ptr(m32), head_gate=L.ptr(g32), scale=scale, O=L.ptr(O), P=L.ptr(Pbuf))
+                          kv_index=L.ptr(kv_index), mask=L.ptr(m32), head_gate=L.ptr(g32), scale=scale, O=L.ptr(O),
+                          P=L.ptr(Pbuf))
         L.check(_lib().evlm_attention_fwd(C.byref(a), L.stream()), "attention_fwd")
-        ctx.save_for_backward(qbuf, kvbuf, Pbuf, g32)
+        ctx.save_for_backward(qbuf, kvbuf, Pbuf, g32, kv_index)
         ctx.meta = (H, dh, q_off, k_off, v_off, scale, qbuf is kvbuf or qbuf.data_ptr() == kvbuf.data_ptr(),
                     gate.shape if gate is not None else None)
         return O, P
 
     @staticmethod
     def backward(ctx, dO, dP):
-        qbuf, kvbuf, P, g32 = ctx.saved_tensors
+        qbuf, kvbuf, P, g32, kv_index = ctx.saved_tensors
         H, dh, q_off, k_off, v_off, scale, self_attn, gshape = ctx.meta
         B, Lq, ldq = qbuf.shape
         Bkv, Lk, ldk = kvbuf.shape
@@ -409,18 +410,18 @@ class _Attention(torch.autograd.Function):
         dkvbuf = dqbuf if self_attn else torch.empty_like(kvbuf)
         dS = torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev)
         dgate = torch.zeros(H, dtype=torch.float32, device=dev) if g32 is not None else None
-        a = L.AttnBwdArgs(dtype=L.dt(tdt), p_dtype=L.dt(tdt), B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, ldq=ldq, ldk=ldk, ldv=ldk,
+        a = L.AttnBwdArgs(dtype=L.dt(tdt), p_dtype=L.dt(tdt), B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, Bkv=Bkv, ldq=ldq, ldk=ldk, ldv=ldk,
                           ldo=H * dh, lddq=ldq, lddk=ldk, lddv=ldk, ldpr=Lkp,
                           Q=C.c_void_p(qbuf.data_ptr() + q_off * es), K=C.c_void_p(kvbuf.data_ptr() + k_off * es),
                           V=C.c_void_p(kvbuf.data_ptr() + v_off * es), P=L.ptr(P), dO=L.ptr(dOc), dP_ext=L.ptr(dPc),
-                          kv_index=None, head_gate=L.ptr(g32), scale=scale, dS=L.ptr(dS),
+                          kv_index=L.ptr(kv_index), head_gate=L.ptr(g32), scale=scale, dS=L.ptr(dS),
                           dQ=C.c_void_p(dqbuf.data_ptr() + q_off * es), dK=C.c_void_p(dkvbuf.data_ptr() + k_off * es),
                           dV=C.c_void_p(dkvbuf.data_ptr() + v_off * es), dgate=L.ptr(dgate))
         L.check(_lib().evlm_attention_bwd(C.byref(a), L.stream()), "attention_bwd")
         dg = dgate.view(gshape) if dgate is not None else None
         if self_attn:
-            return dqbuf, None, None, dg, None, None, None, None, None, None, None
-        return dqbuf, dkvbuf, None, dg, None, None, None, None, None, None, None
+            return dqbuf, None, None, dg, None, None, None, None, None, None, None, None
+        return dqbuf, dkvbuf, None, dg, None, None, None, None, None, None, None, None
 
 
 def self_attention(qkv, H, dh, scale, mask=None, gate=None, want_probs=True):
@@ -429,10 +430,17 @@ def self_attention(qkv, H, dh, scale, mask=None, gate=None, want_probs=True):
     return _Attention.apply(qkv, qkv, mask, gate, H, dh, 0, d, 2 * d, scale, want_probs)
 
 
-def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True):
-    """q: [B, Lq, H*dh]; kv: [B, Lk, 2*H*dh] packed (k | v)"""
+def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True, kv_index=None):
+    """q: [B, Lq, H*dh]; kv: [Bkv, Lk, 2*H*dh] packed (k | v).  kv_index (int32 [B]) maps each query batch to its K/V
+    row, so image tokens shared by several text batches are projected (and their gradient reduced) once."""
     d = H * dh
-    return _Attention.apply(q, kv, mask, gate, H, dh, 0, 0, d, scale, want_probs)
+    if kv_index is not None:
+        if q.dtype == torch.bfloat16 and dh == 64 and kv.shape[1] <= 608:
+            kv_index = kv_index.to(torch.int32).contiguous()
+        else:                                   # exact-fp32 / generic path: materialise the gather (autograd scatters back)
+            kv = torch.index_select(kv, 0, kv_index.long())
+            kv_index = None
+    return _Attention.apply(q, kv, mask, gate, H, dh, 0, 0, d, scale, want_probs, kv_index)
 
 
 # ---------------------------------------------------------------------------------------------------

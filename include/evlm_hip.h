@@ -116,11 +116,14 @@ int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream);
 
 /* backward: given dO and (optionally) an external gradient dP_ext on the probability map (from the
  * attention-map KD loss), produce dQ, dK, dV (+ dgate[H] accumulated, f32).  dS ([B,H,Lq,Lk], dtype) is a
- * caller-provided workspace.  With kv_index, dK/dV rows are ACCUMULATED in f32 buffers dK32/dV32
- * ([Bkv,Lk,H,dh], caller-zeroed) instead of dK/dV. */
+ * caller-provided workspace.  With kv_index (several query batches sharing one K/V row: the image tokens of the
+ * positive, hard-negative and MLM fusion passes) dK/dV are [Bkv,Lk,H,dh]: the bf16 MFMA path sums the sharing query
+ * batches inside one workgroup per K/V row (deterministic); the generic path ACCUMULATES with f32 atomics and then
+ * expects dK/dV to be caller-zeroed f32 buffers. */
 typedef struct {
   int dtype, p_dtype;
   int B, H, Lq, Lk, dh;
+  int Bkv;                      /* K/V batch rows (== B without kv_index) */
   int ldq, ldk, ldv, ldo;
   int lddq, lddk, lddv;
   int ldpr;                     /* row stride of P, dP_ext and dS */

@@ -426,3 +426,30 @@ def test_inplace_parameter_gradients_match_autograd():
     assert rel_err(xb.float(), xa.float()) < 1e-6
     for a, b in zip(ga, gb):
         assert rel_err(b, a) < 3e-4      # the 0.5 pre-fill costs ~6e-8 absolute on gradients of ~1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cross_attention_shared_kv_index(dtype):
+    """several query batches attend to the same K/V row (positive / hard-negative / MLM passes sharing an image):
+    forward equals the materialised gather; dKV is the sum over the sharing batches"""
+    o = ops()
+    g = torch.Generator().manual_seed(47)
+    B, Bkv, H, Lq, Lk, dh = 7, 3, 12, 30, 197, 64
+    d = H * dh
+    q = rnd((B, Lq, d), dtype, g).requires_grad_(True)
+    kv = rnd((Bkv, Lk, 2 * d), dtype, g).requires_grad_(True)
+    idx = torch.tensor([0, 2, 1, 1, 0, 2, 1]).to(DEV)
+    scale = 1.0 / math.sqrt(dh)
+    O, P = o.cross_attention(q, kv, H, dh, scale, kv_index=idx)
+    gO, gP = rnd(O.shape, dtype, g), rnd(P.shape, dtype, g, 0.1)
+    ((O.float() * gO.float()).sum() + (P.float() * gP.float()).sum()).backward()
+    qr, kvr = q.detach().float().requires_grad_(True), kv.detach().float().requires_grad_(True)
+    kvg = kvr[idx]
+    sp = lambda t, Ln: t.reshape(B, Ln, H, dh).transpose(1, 2)
+    Or, Pr = _ref_attention(sp(qr, Lq), sp(kvg[..., :d], Lk), sp(kvg[..., d:], Lk), None, None, scale)
+    Or = Or.transpose(1, 2).reshape(B, Lq, d)
+    ((Or * gO.float()).sum() + (Pr * gP.float()).sum()).backward()
+    t = tol(dtype)
+    assert rel_err(P.float(), Pr) < t and rel_err(O.float(), Or) < t * 2
+    assert rel_err(q.grad.float(), qr.grad) < t * 4
+    assert rel_err(kv.grad.float(), kvr.grad) < t * 4
