@@ -14,6 +14,7 @@
 //
 // Both paths share one epilogue (bias, pre/post-activation gate, GELU/quick-GELU, activation backward,
 // residual add, optional pre-activation store).
+#include <stdlib.h>
 #include "common.h"
 
 struct GemmP {
@@ -668,7 +669,11 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
       const int t128 = ceil_div(g.I, 128) * ceil_div(g.J, 128);
       const bool bare = g.c_f32 && !g.bias && !g.gate && !g.preact && !g.aux && !g.residual && g.act == EVLM_ACT_NONE;
       // weight gradients with a long reduction keep the big tile and get their parallelism from split-K instead
-      const int mt = (t128 >= 384 || (bare && g.K >= 64 * BK && t128 >= 100)) ? 4 : 2;
+      // 128x128 tiles unless their wave quantisation on the 512 resident slots (2 per CU) wastes more than the ~12 % the
+      // 64x64 tile loses in arithmetic intensity (tools/gemm_mt.py)
+      const float eff4 = (float)t128 / (float)(ceil_div(t128, 512) * 512);
+      int mt = (eff4 >= 0.65f || (bare && g.K >= 64 * BK && t128 >= 100)) ? 4 : 2;
+      { static const char* force = getenv("EVLM_FORCE_MT"); if (force) mt = atoi(force); }   // tuning aid
       const int bt = 32 * mt;
       g.tiles_i = ceil_div(g.I, bt); g.tiles_j = ceil_div(g.J, bt);
       const int tiles = g.tiles_i * g.tiles_j, nt = g.K / BK;
