@@ -28,6 +28,7 @@ struct GemmP {
   int kt_per_split;   // K tiles (of 64) handled by one grid.y slice
   int bare_f32;       // f32 output with no epilogue terms (weight gradients): LDS-staged coalesced store / atomics
   int accumulate;     // C += result (f32 atomics), no zero-fill
+  float* psum;        // [I] += sum_k P(i,k) (bias gradient), or nullptr
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -341,6 +342,16 @@ __device__ __forceinline__ void gemm_bf16_fast(const GemmP& g, char* smem, int i
 #pragma unroll
     for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // bias gradient riding on the dW GEMM: sum_k P(i,k) = (ones x P^T) -> one extra MFMA per i tile for the waves that own
+  // the first j tile of the first tile column (every row of the result tile is the same column sum)
+  const bool do_psum = (g.psum != nullptr) && (j0 == 0) && (wj == 0);
+  f32x4 ps[MT];
+#pragma unroll
+  for (int b = 0; b < MT; ++b) ps[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
   StageR<MT> rp, rq;
   const int nt_all = g.K / BK;
   const int t0 = blockIdx.y * g.kt_per_split, t1 = min(nt_all, t0 + g.kt_per_split);   // this split's K tiles
@@ -378,6 +389,10 @@ __device__ __forceinline__ void gemm_bf16_fast(const GemmP& g, char* smem, int i
 #pragma unroll
         for (int b = 0; b < MT; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[a], fp[b], acc[a][b], 0, 0, 0);
+      if (do_psum) {
+#pragma unroll
+        for (int b = 0; b < MT; ++b) ps[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fp[b], ps[b], 0, 0, 0);
+      }
     }
     if (DMA) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA of tile t+1 has landed
@@ -399,6 +414,13 @@ __device__ __forceinline__ void gemm_bf16_fast(const GemmP& g, char* smem, int i
   }
 #endif
   const int ib = i0 + wi * 16 * MT, jb = j0 + wj * 16 * MT;
+  if (do_psum && lane < 16) {       // D rows are identical: lanes 0..15 (row group 0) hold the 16 columns of each i tile
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+      const int i = ib + b * 16 + lane;
+      if (FULL || i < g.I) atomicAdd(g.psum + i, ps[b][0]);
+    }
+  }
   if (g.bare_f32) {
     // weight gradients: the f32 tile goes through LDS so that each wave instruction covers 256 contiguous bytes
     // (plain 16-byte stores, or f32 atomics for split-K partials: scattered dword atomics run ~17x slower)
@@ -645,6 +667,8 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
   g.I = a->I; g.J = a->J; g.K = a->K; g.ldp = a->ldp; g.ldq = a->ldq; g.ldc = a->ldc; g.ldx = a->ldx;
   g.c_f32 = (a->dtype == EVLM_F32) ? 1 : a->c_f32;
   g.accumulate = a->accumulate;
+  g.psum = a->psum;
+  EVLM_REQUIRE(!a->psum || (a->dtype == EVLM_BF16 && a->K % 64 == 0), "evlm_gemm: psum needs bf16 operands and K a multiple of 64");
   EVLM_REQUIRE(!a->accumulate || (a->dtype == EVLM_BF16 && a->c_f32 && !a->bias && !a->gate && !a->preact && !a->aux &&
                                    !a->residual && a->act == EVLM_ACT_NONE && a->K % 64 == 0),
                "evlm_gemm: accumulate needs a bare f32-output bf16 GEMM with K a multiple of 64");

@@ -95,12 +95,12 @@ def _collapsible(x):
 
 def _gemm(dtype, P, Q, Cm, I, J, K, ldp, ldq, ldc, p_trans=0, q_trans=0, bias=None, gate=None, preact=None,
           aux=None, residual=None, ldx=0, alpha=1.0, act=L.ACT_NONE, gate_pos=L.GATE_PRE, dact=L.ACT_NONE, c_f32=0,
-          accumulate=0, p_off=0):
+          accumulate=0, p_off=0, psum=None):
     Pp = L.ptr(P) if not p_off else C.c_void_p(P.data_ptr() + p_off * P.element_size())
     a = L.GemmArgs(dtype=dtype, c_f32=c_f32, p_trans=p_trans, q_trans=q_trans, I=I, J=J, K=K, ldp=ldp, ldq=ldq,
                    ldc=ldc, ldx=ldx, P=Pp, Q=L.ptr(Q), C=L.ptr(Cm), bias=L.ptr(bias), gate=L.ptr(gate),
                    preact=L.ptr(preact), aux=L.ptr(aux), residual=L.ptr(residual), alpha=alpha, act=act,
-                   gate_pos=gate_pos, dact=dact, accumulate=accumulate)
+                   gate_pos=gate_pos, dact=dact, accumulate=accumulate, psum=L.ptr(psum))
     if GEMM_PROFILE is None:
         L.check(_lib().evlm_gemm(C.byref(a), L.stream()), "gemm")
         return
@@ -132,22 +132,39 @@ def _inplace(p):
     return WGRAD_INPLACE and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape
 
 
-def _wgrad(dtype, d2, ldd, x2, ldp, M, K, params, rows):
-    """dW_i = dY[:, rows_i]^T X for every packed weight; returns the list of gradients (None where accumulated in place)"""
-    out, r0 = [], 0
-    if not all(_inplace(w) for w in params) or dtype != L.BF16 or M % 64 != 0:
+def _wgrad(dtype, d2, ldd, x2, ldp, M, K, params, rows, biases=None):
+    """dW_i = dY[:, rows_i]^T X for every packed weight (and, when `biases` is given, db_i = column sums of dY riding
+    on the same GEMM).  Returns (weight grads, bias grads); entries are None where accumulated in place."""
+    gw, gb, r0 = [], [], 0
+    fast = dtype == L.BF16 and M % 64 == 0
+    has_b = biases is not None and len(biases) and biases[0] is not None
+    if not (fast and all(_inplace(w) for w in params)):
         N = sum(rows)
         dW = torch.empty((N, K), dtype=torch.float32, device=x2.device)
-        _gemm(dtype, d2, x2, dW, N, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1)
-        for r in rows:
-            out.append(dW[r0:r0 + r])
+        db = torch.zeros(N, dtype=torch.float32, device=x2.device) if (has_b and fast) else None
+        _gemm(dtype, d2, x2, dW, N, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1, psum=db)
+        for i, r in enumerate(rows):
+            gw.append(dW[r0:r0 + r])
+            if has_b:
+                if db is not None:
+                    gb.append(db[r0:r0 + r])
+                else:
+                    gb.append(_colsum(d2, M, r, ldd, x_off=r0))
             r0 += r
-        return out
-    for w, r in zip(params, rows):
-        _gemm(dtype, d2, x2, w.grad, r, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1, accumulate=1, p_off=r0)
-        out.append(None)
+        return gw, (gb if has_b else [None] * len(rows))
+    for i, (w, r) in enumerate(zip(params, rows)):
+        b = biases[i] if has_b else None
+        if b is not None and _inplace(b):
+            ps, res = b.grad, None
+        elif b is not None:
+            ps = res = torch.zeros(r, dtype=torch.float32, device=x2.device)
+        else:
+            ps = res = None
+        _gemm(dtype, d2, x2, w.grad, r, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1, accumulate=1, p_off=r0, psum=ps)
+        gw.append(None)
+        gb.append(res)
         r0 += r
-    return out
+    return gw, gb
 
 
 def _bgrad(d2, M, ldd, params, rows):
@@ -231,8 +248,7 @@ class _Linear(torch.autograd.Function):
             _gemm(dtype, d2, W, dxb, M, K, N, ldd, K, K, p_trans=0, q_trans=1)     # dX = dY W
             dx = dxb.view(xshape)
         weights, biases = ctx.params
-        gw = _wgrad(dtype, d2, ldd, x2, ldp, M, K, weights, rows)                        # dW = dY^T X
-        gb = _bgrad(d2, M, ldd, biases, rows) if has_bias else [None] * nw
+        gw, gb = _wgrad(dtype, d2, ldd, x2, ldp, M, K, weights, rows, biases if has_bias else None)   # dW = dY^T X, db
         return (dx, dres, None, None, None, *gw, *gb)
 
 
@@ -299,15 +315,13 @@ class _MLP(torch.autograd.Function):
                                            L.ptr(dg), L.stream()), "gated_act_bwd")
             dgate = dg.view(gshape)
         w1, b1, w2, b2 = ctx.params
-        (dW2,) = _wgrad(dtype, d2, N, a, Fh, M, Fh, (w2,), (N,))
-        (db2,) = _bgrad(d2, M, N, (b2,), (N,))
+        (dW2,), (db2,) = _wgrad(dtype, d2, N, a, Fh, M, Fh, (w2,), (N,), (b2,))
         dx = None
         if ctx.needs_input_grad[0]:
             dxb = torch.empty((M, K), dtype=x2.dtype, device=dev)
             _gemm(dtype, dh, W1, dxb, M, K, Fh, Fh, K, K, p_trans=0, q_trans=1)
             dx = dxb.view(xshape)
-        (dW1,) = _wgrad(dtype, dh, Fh, x2, ldp, M, K, (w1,), (Fh,))
-        (db1,) = _bgrad(dh, M, Fh, (b1,), (Fh,))
+        (dW1,), (db1,) = _wgrad(dtype, dh, Fh, x2, ldp, M, K, (w1,), (Fh,), (b1,))
         return dx, dW1, db1, dW2, db2, dgate, (dy if has_res else None), None, None
 
 

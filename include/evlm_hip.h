@@ -68,6 +68,9 @@ typedef struct {
   int dact;             /* EVLM_ACT_* : multiply by act'(aux) */
   int accumulate;       /* 1: C += result (f32 atomics; bare f32-output bf16 GEMMs only) — weight gradients summed
                            straight into the optimiser's gradient slab */
+  float* psum;          /* optional [I] f32: psum[i] += sum_k P(i,k)  (bias gradient = column sums of dY, produced by the
+                           dW GEMM itself from the dY tile it already holds: one extra MFMA against a ones fragment).
+                           bf16, K % 64 == 0 only; ACCUMULATED with f32 atomics */
 } evlm_gemm_args;
 
 int evlm_gemm(const evlm_gemm_args* args, void* stream);
