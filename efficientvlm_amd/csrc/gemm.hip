@@ -534,6 +534,121 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmP g) {
   if (full) gemm_bf16_fast<PT, QT, true, MT>(g, smem, i0, j0);
   else gemm_bf16_fast<PT, QT, false, MT>(g, smem, i0, j0);
 }
+// ---------------------------------------------------------------------------------------------
+// persistent, cross-tile pipelined variant for bf16-output NT / NN GEMMs (the forward and dX products, K = 768..3072:
+// only 12..48 K tiles per output tile, so the per-tile fixed cost - first-stage DMA latency, epilogue, workgroup
+// relaunch - is what separates them from the steady-state MFMA rate).  One workgroup per resident slot walks the tile
+// list; the first K tile of the NEXT output tile is DMA'd into the free half of LDS while the current tile's
+// epilogue runs out of the other half.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_ij(const GemmP& g, int t_lin, int ntiles, int& ti, int& tj) {
+  const int q = ntiles >> 3, r = ntiles & 7, xcd = t_lin & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t_lin >> 3);
+  ti = t / g.tiles_j;
+  tj = t - ti * g.tiles_j;
+}
+
+template <bool PT, bool QT, int MT>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_persist_kernel(GemmP g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // region 0 | region 1, each [P tile | Q tile]
+  using TC = TileCfg<MT>;
+  constexpr int BTm = TC::BTm, RB = 2 * TC::TB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave & 1, wj = wave >> 1;
+  const bf16* Pb = reinterpret_cast<const bf16*>(g.P);
+  const bf16* Qb = reinterpret_cast<const bf16*>(g.Q);
+  const int kp = PT ? BK * g.ldp : BK, kq = QT ? BK * g.ldq : BK;
+  const int nt = g.K / BK, ntiles = g.tiles_i * g.tiles_j;
+  // the epilogue needs one [BTm][BTm] bf16 tile per output (C, optionally the pre-activation): with MT = 4 a tile is a
+  // whole region, so a pre-activation output leaves no room for the prefetch
+  const bool overlap = (MT == 2) || (g.preact == nullptr);
+
+  int tile = blockIdx.x, ti, tj;
+  tile_ij(g, tile, ntiles, ti, tj);
+  int i0 = ti * BTm, j0 = tj * BTm;
+  int sp_[MT], sq_[MT];
+  src_offs<PT, MT>(g.ldp, g.I, i0, tid, sp_);
+  src_offs<QT, MT>(g.ldq, g.J, j0, tid, sq_);
+  stage_glds<MT>(Pb, sp_, 0, smem, tid);
+  stage_glds<MT>(Qb, sq_, 0, smem + TC::TB, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int first = 0;                     // region that holds K tile 0 of the current output tile
+
+  while (true) {
+    f32x4 acc[MT][MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nt; ++t) {
+      const int cur = first ^ (t & 1);
+      const char* sp = smem + cur * RB;
+      const char* sq = sp + TC::TB;
+      char* nb = smem + (cur ^ 1) * RB;
+      if (t + 1 < nt) { stage_glds<MT>(Pb, sp_, (t + 1) * kp, nb, tid); stage_glds<MT>(Qb, sq_, (t + 1) * kq, nb + TC::TB, tid); }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 fp[MT], fq[MT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+          fp[a] = frag_read_t<PT, MT>(sp, wi * MT + a, ks, lane);
+          fq[a] = frag_read_t<QT, MT>(sq, wj * MT + a, ks, lane);
+        }
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int b = 0; b < MT; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[a], fp[b], acc[a][b], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    // every LDS region is free here.  Prefetch the next output tile's first K tile into region 1 ...
+    const int next = tile + gridDim.x;
+    const bool has_next = next < ntiles;
+    int ni0 = 0, nj0 = 0;
+    if (has_next) {
+      tile_ij(g, next, ntiles, ti, tj);
+      ni0 = ti * BTm; nj0 = tj * BTm;
+      src_offs<PT, MT>(g.ldp, g.I, ni0, tid, sp_);
+      src_offs<QT, MT>(g.ldq, g.J, nj0, tid, sq_);
+      if (overlap) { stage_glds<MT>(Pb, sp_, 0, smem + RB, tid); stage_glds<MT>(Qb, sq_, 0, smem + RB + TC::TB, tid); }
+    }
+    // ... while this tile's epilogue runs out of region 0 (and region 1 too when there is no overlap)
+    const int ib = i0 + wi * 16 * MT, jb = j0 + wj * 16 * MT;
+    char* sC = smem;
+    char* sH = (MT == 2) ? smem + TC::TB : smem + RB;
+    const bool full = (i0 + BTm <= g.I) && (j0 + BTm <= g.J);
+    if (full) tile_epilogue<bf16, MT, MT, true, true, MT>(g, acc, ib, jb, lane, sC, sH, i0, j0);
+    else tile_epilogue<bf16, MT, MT, false, true, MT>(g, acc, ib, jb, lane, sC, sH, i0, j0);
+    __syncthreads();
+    if (full) {
+      copy_tile_out<true, MT>(sC, reinterpret_cast<bf16*>(g.C), g.ldc, i0, j0, g.I, g.J, tid);
+      if (g.preact) copy_tile_out<true, MT>(sH, reinterpret_cast<bf16*>(g.preact), g.ldx, i0, j0, g.I, g.J, tid);
+    } else {
+      copy_tile_out<false, MT>(sC, reinterpret_cast<bf16*>(g.C), g.ldc, i0, j0, g.I, g.J, tid);
+      if (g.preact) copy_tile_out<false, MT>(sH, reinterpret_cast<bf16*>(g.preact), g.ldx, i0, j0, g.I, g.J, tid);
+    }
+    if (!has_next) break;
+    if (!overlap) {
+      __syncthreads();                 // the output tiles have been read out of LDS
+      stage_glds<MT>(Pb, sp_, 0, smem + RB, tid);
+      stage_glds<MT>(Qb, sq_, 0, smem + RB + TC::TB, tid);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (full) {
+      // wait for the prefetch DMA only: vmcnt retires in issue order and the only younger operations still in flight
+      // are this tile's output stores (MT*MT/2 per thread and output), which may drain under the next main loop
+      if (MT == 4) { if (g.preact) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+      else { if (g.preact) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    tile = next; i0 = ni0; j0 = nj0; first = 1;
+  }
+}
+
 template <bool PT, bool QT>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_generic_kernel(GemmP g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -716,10 +831,18 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
       }
       dim3 grid(tiles, splits);
       const size_t lds = (size_t)4 * bt * BK * 2;
-#define LAUNCH_FAST(PT_, QT_)                                                                       \
-  do {                                                                                              \
-    if (mt == 4) hipLaunchKernelGGL((gemm_bf16_kernel<PT_, QT_, 4>), grid, block, lds, stream, g); \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<PT_, QT_, 2>), grid, block, lds, stream, g);         \
+      // bf16-output NT / NN products: persistent cross-tile pipelined kernel, one workgroup per resident slot
+      static const bool no_persist = getenv("EVLM_NO_PERSIST") != nullptr;      // tuning aid
+      // (measured, tools/gemm_mt.py: +4 % on the 64x64-tile shapes, -10 % on the 128x128 ones, where the hardware
+      //  dispatcher's relaunch already overlaps a neighbour's MFMA phase with the epilogue)
+      const bool persist = !g.c_f32 && !(pt && qt) && !no_persist && mt == 2;
+      if (persist) grid = dim3(imin(tiles, 256 * (mt == 4 ? 2 : 4)), 1);
+#define LAUNCH_FAST(PT_, QT_)                                                                                \
+  do {                                                                                                       \
+    if (persist && mt == 4) hipLaunchKernelGGL((gemm_bf16_persist_kernel<PT_, QT_, 4>), grid, block, lds, stream, g); \
+    else if (persist) hipLaunchKernelGGL((gemm_bf16_persist_kernel<PT_, QT_, 2>), grid, block, lds, stream, g);       \
+    else if (mt == 4) hipLaunchKernelGGL((gemm_bf16_kernel<PT_, QT_, 4>), grid, block, lds, stream, g);       \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<PT_, QT_, 2>), grid, block, lds, stream, g);                   \
   } while (0)
       if (!pt && !qt) LAUNCH_FAST(false, false);
       else if (!pt && qt) LAUNCH_FAST(false, true);
