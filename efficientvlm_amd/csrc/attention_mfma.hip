@@ -53,9 +53,11 @@ __device__ __forceinline__ bf16x8 vcol_frag(const char* sm, int t0, int t1, int 
   return out;
 }
 
-// NT = number of 16-key tiles (even); one workgroup = 4 waves = 64 queries of one (batch, head)
-template <int NT>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(MAttnF a) {
+// NT = number of 16-key tiles (even).  One workgroup = up to 16 waves x 16 queries of one (batch, head): with Lq <= 256
+// (the ViT's 197 tokens) a single workgroup covers every query, so K and V are staged into LDS exactly once per
+// (batch, head) instead of once per 64-query block on four different XCDs.
+template <int NT, int MAXW>
+__global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;                          // [NT*16][64] bf16, k_swz
   char* Vs = smem + NT * 16 * 128;          // [NT*16][64] bf16, v_swz
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(MAttnF a) {
     Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
   __syncthreads();
 
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 16;
   if (q0 >= a.Lq) return;
   const int q = q0 + ql;
   const bool qok = q < a.Lq;
@@ -153,11 +155,13 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(MAttnF a) {
 
 template <int NT>
 static int launch_fwd(const MAttnF& f, hipStream_t stream) {
+  constexpr int MAXW = NT <= 14 ? 16 : 4;              // register budget: 16 waves/workgroup need <= 128 VGPRs
   const size_t lds = (size_t)2 * NT * 16 * 128 + (size_t)NT * 16 * sizeof(float);
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  dim3 grid((f.Lq + 63) / 64, f.H, f.B), block(256);
-  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT>), grid, block, lds, stream, f);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int nw = imin(MAXW, (f.Lq + 15) / 16);         // waves per workgroup (16 queries each)
+  dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
+  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT, MAXW>), grid, block, lds, stream, f);
   return 0;
 }
 
@@ -175,8 +179,8 @@ struct MAttnB {
 // kernel A: same shape as the forward (a wave owns 16 queries and ALL keys):
 //   dPo^T = V dO^T ;  dP = gate*dPo + E ;  delta = rowsum(P .* dP) ;  dS = P .* (dP - delta) -> HBM (for kernel B)
 //   dQ^T  = scale * K^T dS^T           (dS^T accumulators reused as the MFMA B operand, K^T through tr16 reads)
-template <int NT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(MAttnB a) {
+template <int NT, int MAXW>
+__global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;                          // v_swz (column reads)
   char* Vs = smem + NT * 16 * 128;          // k_swz (row reads)
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   stage_rows<true>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
   stage_rows<false>(a.V + (size_t)bkv * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
   __syncthreads();
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 16;
   if (q0 >= a.Lq) return;
   const int q = q0 + ql;
   const bool qok = q < a.Lq;
@@ -337,11 +341,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
 
 template <int NT>
 static void launch_bwd_dq(const MAttnB& f, hipStream_t stream) {
+  constexpr int MAXW = NT <= 14 ? 8 : 4;
   const size_t lds = (size_t)2 * NT * 16 * 128;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  dim3 grid((f.Lq + 63) / 64, f.H, f.B), block(256);
-  hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NT>), grid, block, lds, stream, f);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<NT, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int nw = imin(MAXW, (f.Lq + 15) / 16);
+  dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
+  hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NT, MAXW>), grid, block, lds, stream, f);
 }
 
 int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int* handled) {
