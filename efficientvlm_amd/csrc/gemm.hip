@@ -344,7 +344,11 @@ __device__ __forceinline__ void gemm_bf16_fast(const GemmP& g, char* smem, int i
 
   // bias gradient riding on the dW GEMM: sum_k P(i,k) = (ones x P^T) -> one extra MFMA per i tile for the waves that own
   // the first j tile of the first tile column (every row of the result tile is the same column sum)
+#ifdef EVLM_GEMM_STAMP
+  const bool do_psum = false;
+#else
   const bool do_psum = (g.psum != nullptr) && (j0 == 0) && (wj == 0);
+#endif
   f32x4 ps[MT];
 #pragma unroll
   for (int b = 0; b < MT; ++b) ps[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -352,6 +356,9 @@ __device__ __forceinline__ void gemm_bf16_fast(const GemmP& g, char* smem, int i
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
+#ifdef EVLM_GEMM_STAMP
+  unsigned long long st0 = __builtin_amdgcn_s_memtime(), st1 = 0, st2 = 0, st3 = 0;
+#endif
   StageR<MT> rp, rq;
   const int nt_all = g.K / BK;
   const int t0 = blockIdx.y * g.kt_per_split, t1 = min(nt_all, t0 + g.kt_per_split);   // this split's K tiles
@@ -366,6 +373,9 @@ __device__ __forceinline__ void gemm_bf16_fast(const GemmP& g, char* smem, int i
     stage_regs_store<MT>(smem + TC::TB, tid, rq);
   }
   __syncthreads();
+#ifdef EVLM_GEMM_STAMP
+  st1 = __builtin_amdgcn_s_memtime();
+#endif
 
   for (int t = t0; t < t1; ++t) {
     const int cur = (t - t0) & 1;
@@ -413,7 +423,11 @@ __device__ __forceinline__ void gemm_bf16_fast(const GemmP& g, char* smem, int i
     return;
   }
 #endif
+#ifdef EVLM_GEMM_STAMP
+  st2 = __builtin_amdgcn_s_memtime();
+#endif
   const int ib = i0 + wi * 16 * MT, jb = j0 + wj * 16 * MT;
+#ifndef EVLM_GEMM_STAMP
   if (do_psum && lane < 16) {       // D rows are identical: lanes 0..15 (row group 0) hold the 16 columns of each i tile
 #pragma unroll
     for (int b = 0; b < MT; ++b) {
@@ -421,6 +435,7 @@ __device__ __forceinline__ void gemm_bf16_fast(const GemmP& g, char* smem, int i
       if (FULL || i < g.I) atomicAdd(g.psum + i, ps[b][0]);
     }
   }
+#endif
   if (g.bare_f32) {
     // weight gradients: the f32 tile goes through LDS so that each wave instruction covers 256 contiguous bytes
     // (plain 16-byte stores, or f32 atomics for split-K partials: scattered dword atomics run ~17x slower)
@@ -470,6 +485,14 @@ __device__ __forceinline__ void gemm_bf16_fast(const GemmP& g, char* smem, int i
   } else {
     tile_epilogue<bf16, MT, MT, FULL>(g, acc, ib, jb, lane);
   }
+#ifdef EVLM_GEMM_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  st3 = __builtin_amdgcn_s_memtime();
+  if (tid == 0 && g.psum) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(g.psum) + (size_t)blockIdx.x * 4;
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+  }
+#endif
 }
 
 // generic path (K not a multiple of 64: only the vocabulary-sized reduction of the MLM decoder backward)
@@ -647,6 +670,129 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_persist_kernel(GemmP g) {
     __syncthreads();
     tile = next; i0 = ni0; j0 = nj0; first = 1;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 128x128 tile, K step 32, THREE-stage LDS ring (48 KiB -> three workgroups per CU) with the LDS-DMA of K step t+2 left
+// in flight across the barrier (counted vmcnt).  In-kernel stamps of the two-stage kernel above showed ~1700 cycles per
+// 64-deep step against 1024 of MFMA issue: one step is shorter than the HBM/L2 round trip, so `vmcnt(0)` at every
+// barrier exposed load latency.  Two steps of prefetch distance + 12 waves per CU cover it.
+// ---------------------------------------------------------------------------------------------
+#define BK3 32
+#define TB3 (128 * BK3 * 2)          // 8 KiB per operand per stage
+
+// per-lane source offsets of the 2 x 16-byte pieces per operand this thread stages per K step
+template <bool TR>
+__device__ __forceinline__ void src_offs3(int ld, int rows, int row0, int tid, int (&src)[2]) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int id = (c * 4 + wave) * 64 + lane;
+    if (!TR) {     // [128 rows][32 k]: 64-byte rows, 4 chunks, swizzle (row>>2)&3
+      const int row = id >> 2, cp = id & 3;
+      src[c] = min(row0 + row, rows - 1) * ld + ((cp ^ ((row >> 2) & 3)) << 3);
+    } else {       // [32 k][128 cols]: 256-byte rows, 16 chunks
+      const int kr = id >> 4, cp = id & 15;
+      const int col = row0 + ((cp ^ (((kr & 3) << 2) | ((kr >> 2) & 3))) << 3);
+      src[c] = kr * ld + min(col, ((rows + 7) & ~7) - 8);
+    }
+  }
+}
+__device__ __forceinline__ void stage_glds3(const bf16* base, const int (&src)[2], int koff, char* sm, int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (src[c] + koff)),
+                                     (__attribute__((address_space(3))) void*)(sm + (c * 4 + wave) * 1024), 16, 0, 0);
+}
+template <bool TR>
+__device__ __forceinline__ bf16x8 frag_read3(const char* sm, int rt, int lane) {
+  if (!TR) {
+    const int row = rt * 16 + (lane & 15), c = lane >> 4;
+    return *reinterpret_cast<const bf16x8*>(sm + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+  } else {
+    const int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3;
+    bf16x8 out;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kr = g * 8 + h * 4 + q;
+      const int ch = rt * 2 + (p >> 1);
+      const int off = kr * 256 + ((ch ^ (((kr & 3) << 2) | ((kr >> 2) & 3))) << 4) + ((p & 1) << 3);
+      bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(sm + off));
+      out[4 * h + 0] = t[0]; out[4 * h + 1] = t[1]; out[4 * h + 2] = t[2]; out[4 * h + 3] = t[3];
+    }
+    return out;
+  }
+}
+
+template <bool PT, bool QT>
+__global__ __launch_bounds__(256, 3) void gemm_bf16_s3_kernel(GemmP g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 stages x [P tile | Q tile] = 48 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave & 1, wj = wave >> 1;
+  int ti, tj;
+  tile_coords(g, ti, tj);
+  const int i0 = ti * 128, j0 = tj * 128;
+  const bf16* Pb = reinterpret_cast<const bf16*>(g.P);
+  const bf16* Qb = reinterpret_cast<const bf16*>(g.Q);
+  int sp_[2], sq_[2];
+  src_offs3<PT>(g.ldp, g.I, i0, tid, sp_);
+  src_offs3<QT>(g.ldq, g.J, j0, tid, sq_);
+  const int kp = PT ? BK3 * g.ldp : BK3, kq = QT ? BK3 * g.ldq : BK3;
+  const int nt = g.K / BK3;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // prologue: K steps 0 and 1 in flight, wait for step 0 only
+  stage_glds3(Pb, sp_, 0, smem, tid);
+  stage_glds3(Qb, sq_, 0, smem + TB3, tid);
+  if (nt > 1) {
+    stage_glds3(Pb, sp_, kp, smem + 2 * TB3, tid);
+    stage_glds3(Qb, sq_, kq, smem + 3 * TB3, tid);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const char* sp = smem + cur * 2 * TB3;
+    const char* sq = sp + TB3;
+    int nxt2 = cur + 2; if (nxt2 >= 3) nxt2 -= 3;
+    if (t + 2 < nt) {      // stage (t+2)%3 was last read in step t-1: every wave passed that step's closing barrier
+      stage_glds3(Pb, sp_, (t + 2) * kp, smem + nxt2 * 2 * TB3, tid);
+      stage_glds3(Qb, sq_, (t + 2) * kq, smem + nxt2 * 2 * TB3 + TB3, tid);
+    }
+    bf16x8 fp[4], fq[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      fp[a] = frag_read3<PT>(sp, wi * 4 + a, lane);
+      fq[a] = frag_read3<QT>(sq, wj * 4 + a, lane);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[a], fp[b], acc[a][b], 0, 0, 0);
+    // step t+1 must have landed before anyone reads it; step t+2 (the 4 youngest DMAs) stays in flight
+    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    cur = cur + 1; if (cur >= 3) cur = 0;
+  }
+  // epilogue through LDS (32 KiB of the 48): same as the two-stage kernel
+  const int ib = i0 + wi * 64, jb = j0 + wj * 64;
+  const bool full = (i0 + 128 <= g.I) && (j0 + 128 <= g.J);
+  char* sC = smem;
+  char* sH = nullptr;     // a pre-activation output does not fit beside C: the host does not route such GEMMs here
+  if (full) tile_epilogue<bf16, 4, 4, true, true, 4>(g, acc, ib, jb, lane, sC, sH, i0, j0);
+  else tile_epilogue<bf16, 4, 4, false, true, 4>(g, acc, ib, jb, lane, sC, sH, i0, j0);
+  __syncthreads();
+  if (full) copy_tile_out<true, 4>(sC, reinterpret_cast<bf16*>(g.C), g.ldc, i0, j0, g.I, g.J, tid);
+  else copy_tile_out<false, 4>(sC, reinterpret_cast<bf16*>(g.C), g.ldc, i0, j0, g.I, g.J, tid);
 }
 
 template <bool PT, bool QT>
@@ -837,9 +983,14 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
       //  dispatcher's relaunch already overlaps a neighbour's MFMA phase with the epilogue)
       const bool persist = !g.c_f32 && !(pt && qt) && !no_persist && mt == 2;
       if (persist) grid = dim3(imin(tiles, 256 * (mt == 4 ? 2 : 4)), 1);
+      static const bool no_s3 = getenv("EVLM_NO_S3") != nullptr;                 // tuning aid
+      // short reductions only: measured +5..15 % at K = 768, -20 % at K >= 3072 (tools/gemm_mt.py, gemm_bench.py)
+      const bool s3 = mt == 4 && !g.c_f32 && !g.preact && !no_s3 && splits == 1 && g.K <= 1024;
+      const size_t lds3 = 6 * TB3;
 #define LAUNCH_FAST(PT_, QT_)                                                                                \
   do {                                                                                                       \
-    if (persist && mt == 4) hipLaunchKernelGGL((gemm_bf16_persist_kernel<PT_, QT_, 4>), grid, block, lds, stream, g); \
+    if (s3) hipLaunchKernelGGL((gemm_bf16_s3_kernel<PT_, QT_>), grid, block, lds3, stream, g);               \
+    else if (persist && mt == 4) hipLaunchKernelGGL((gemm_bf16_persist_kernel<PT_, QT_, 4>), grid, block, lds, stream, g); \
     else if (persist) hipLaunchKernelGGL((gemm_bf16_persist_kernel<PT_, QT_, 2>), grid, block, lds, stream, g);       \
     else if (mt == 4) hipLaunchKernelGGL((gemm_bf16_kernel<PT_, QT_, 4>), grid, block, lds, stream, g);       \
     else hipLaunchKernelGGL((gemm_bf16_kernel<PT_, QT_, 2>), grid, block, lds, stream, g);                   \
