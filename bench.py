@@ -155,8 +155,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dp = bool(os.environ.get("EVLM_FORCE_REDUCE"))      # exercise the N>1 code path (collectives) on one GPU
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
@@ -203,7 +205,7 @@ def main():
                                       "teacher fwd, ITC+ITM+MLM + hidden/attention/logit KD, grad all-reduce, clip 1.0, AdamW",
                           "image": "224x224", "text_len": geom["L"], "masked": geom["M"], "batch_per_gpu": B,
                           "global_batch": B * world, "parallelism": f"dp{world}",
-                          "launch": "eager" if (args.no_graph or world > 1) else "hipGraph replay",
+                          "launch": "eager" if (args.no_graph or world > 1 or force_dp) else "hipGraph replay",
                           "init": "random (reference init), no checkpoints"},
                "step_model_tflops": round(value * FLOPS_PER_PAIR / 1e12, 1),
                "step_mfma_frac": round(value * FLOPS_PER_PAIR / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
@@ -213,7 +215,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()
 

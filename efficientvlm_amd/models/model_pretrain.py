@@ -22,6 +22,7 @@ class XVLM(XVLMBase):
     # of each image is computed once per fusion layer and shared through a batch index instead of being recomputed for
     # the gathered hard-negative copies.  Row-wise identical arithmetic, 3-4x larger GEMMs, ~1/3 of the launches.
     batched_passes = True
+    on_vision_grad = None      # optional callback: fired (tensor hook) when backward has produced d(loss)/d(image_embeds)
 
     def forward(self, image, text_ids, text_atts, text_ids_masked=None, masked_pos=None, masked_ids=None, image_atts=None,
                 idx_to_group_img=None, target_bbox=None, is_image=None, ret_bbox_loss=False, output_attentions=None,
@@ -70,6 +71,9 @@ class XVLM(XVLMBase):
         dev = image.device
         image_embeds, image_atts, image_hidden_states, image_attentions = self.get_vision_embeds(
             image, output_attentions=True, output_hidden_states=True)
+        if self.on_vision_grad is not None and image_embeds.requires_grad:
+            cb = self.on_vision_grad
+            image_embeds.register_hook(lambda grad: (cb(), grad)[1])
         core = self._text_core()
         # text layers 0..F-1 on [text_ids ; text_ids_masked]
         t = core(torch.cat([text_ids, text_ids_masked], 0), attention_mask=torch.cat([text_atts, text_atts], 0),

@@ -20,7 +20,8 @@ NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight", "norm.bias", "norm.wei
 
 
 class FlatAdamW:
-    def __init__(self, model, lr=1e-4, weight_decay=0.01, lr_mult=1.0, betas=(0.9, 0.98), eps=1e-8, max_grad_norm=1.0):
+    def __init__(self, model, lr=1e-4, weight_decay=0.01, lr_mult=1.0, betas=(0.9, 0.98), eps=1e-8, max_grad_norm=1.0,
+                 late_prefix="vision_encoder."):
         self.betas, self.eps, self.max_grad_norm = betas, eps, max_grad_norm
         large = set(getattr(model, "init_params", []) or [])
         groups = [dict(weight_decay=weight_decay, lr=lr, params=[], names=[]),
@@ -46,17 +47,30 @@ class FlatAdamW:
             g["m"] = torch.zeros(n, dtype=torch.float32, device=dev)
             g["v"] = torch.zeros(n, dtype=torch.float32, device=dev)
             off = 0
-            for p in g["params"]:
+            g["late_from"] = None      # slab offset where the parameters whose gradients arrive LAST in backward start
+            for p, nme in zip(g["params"], g["names"]):
                 k = p.numel()
+                if g["late_from"] is None and nme.startswith(late_prefix):
+                    g["late_from"] = off
                 g["p"][off:off + k].copy_(p.data.reshape(-1))
                 p.data = g["p"][off:off + k].view(p.shape)
                 p.grad = g["g"][off:off + k].view(p.shape)
                 off += (k + 3) // 4 * 4
+            if g["late_from"] is None:
+                g["late_from"] = n
         ops.CACHE.invalidate()
 
     @property
     def flat_grads(self):
         return [g["g"] for g in self.groups]
+
+    def grad_segments(self):
+        """(early, late) lists of slab views: `early` = heads + text/fusion encoder (their gradients are complete once
+        backward reaches the image encoder), `late` = the image encoder.  The slabs are laid out in reverse forward
+        order, so each is one contiguous range per group."""
+        early = [g["g"][:g["late_from"]] for g in self.groups if g["late_from"] > 0]
+        late = [g["g"][g["late_from"]:] for g in self.groups if g["late_from"] < g["g"].numel()]
+        return early, late
 
     def zero_grad(self):
         for g in self.groups:

@@ -7,9 +7,9 @@ MI355X-first execution
     reads per step are gone), so it can be captured once into a hipGraph and replayed — the step is ~2k kernel launches
     and would otherwise be host-launch-bound;
   * gradients live in the optimiser's flat fp32 slabs, so data parallelism is a few large RCCL all-reduces over
-    contiguous memory, issued on a side stream; with graphs the step is cut into
-        [A: encoders + features] -> all-gather(ITC) -> [B: losses + backward] -> all-reduce(grads) -> [C: clip + AdamW]
-    and the collectives run eagerly between the captured segments (xGMI is point-to-point: few, large messages).
+    contiguous memory on a side stream (xGMI is point-to-point: few, large messages); the text / fusion / head part
+    of the slabs is reduced from a tensor hook while the ViT backward is still running, the ViT part after it.
+    With N > 1 the step runs eagerly (it is GPU-bound either way; RCCL collectives are not capturable here).
 """
 import torch
 import torch.distributed as dist
@@ -27,22 +27,35 @@ class GradReducer:
     """mean all-reduce of flat gradient slabs in <= bucket_bytes pieces on a dedicated stream.
 
     Works on any backend (RCCL on GPU, gloo in the CPU tests).  `compress` = torch.bfloat16 halves the wire bytes
-    (the slabs stay fp32: cast -> all-reduce -> cast back)."""
+    (the slabs stay fp32: cast -> all-reduce -> cast back).
 
-    def __init__(self, flat_grads, bucket_bytes=64 << 20, compress=None, group=None):
+    Overlap with backward: the slabs are laid out in reverse forward order, so `reduce_async(early)` can be launched
+    from a tensor hook the moment backward crosses into the image encoder (every text / fusion / head gradient is then
+    enqueued) and runs on the side stream under the ViT backward; `reduce_async(late)` + `finish()` follow after
+    backward.  Few, large messages: xGMI is point-to-point, rings are per-link bound."""
+
+    def __init__(self, flat_grads, bucket_bytes=64 << 20, compress=None, group=None, force=False):
         self.flat = list(flat_grads)
         self.group = group
         self.compress = compress
+        self.bucket_bytes = bucket_bytes
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.buckets = []
-        for t in self.flat:
-            n, per = t.numel(), max(1, bucket_bytes // t.element_size())
-            for o in range(0, n, per):
-                self.buckets.append(t[o:min(n, o + per)])
+        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
+        self.buckets = self._buckets(self.flat)
         self.stream = torch.cuda.Stream() if (self.flat and self.flat[0].is_cuda) else None
+        self._pending = []
 
-    def reduce(self):
-        if self.world <= 1:
+    def _buckets(self, tensors):
+        out = []
+        for t in tensors:
+            n, per = t.numel(), max(1, self.bucket_bytes // t.element_size())
+            for o in range(0, n, per):
+                out.append(t[o:min(n, o + per)])
+        return out
+
+    def reduce_async(self, tensors):
+        """enqueue the mean all-reduce of `tensors` behind everything already enqueued on the current stream"""
+        if not self.active:
             return
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -51,8 +64,7 @@ class GradReducer:
             import contextlib
             ctx = contextlib.nullcontext()
         with ctx:
-            handles = []
-            for b in self.buckets:
+            for b in self._buckets(tensors):
                 if self.compress is not None and b.is_cuda:
                     w = ops.cast(b, self.compress)
                     w.div_(self.world)
@@ -60,11 +72,24 @@ class GradReducer:
                     b.copy_(w)
                 else:
                     b.div_(self.world)
-                    handles.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            for h in handles:
-                h.wait()
+                    self._pending.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        if not self.active:
+            return
         if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                for h in self._pending:
+                    h.wait()
             torch.cuda.current_stream().wait_stream(self.stream)
+        else:
+            for h in self._pending:
+                h.wait()
+        self._pending = []
+
+    def reduce(self):
+        self.reduce_async(self.flat)
+        self.finish()
 
 
 class GDTrainer:
@@ -77,8 +102,14 @@ class GDTrainer:
         teacher.eval()
         student.train()
         self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=max_grad_norm)
-        self.reducer = GradReducer(self.opt.flat_grads, compress=grad_compress)
+        import os
+        self.reducer = GradReducer(self.opt.flat_grads, compress=grad_compress,
+                                   force=bool(os.environ.get("EVLM_FORCE_REDUCE")))
         self.world = self.reducer.world
+        self._early, self._late = self.opt.grad_segments()
+        self._early_sent = False
+        if self.reducer.active and hasattr(student, "on_vision_grad"):
+            student.on_vision_grad = self._on_vision_grad      # fires when backward enters the image encoder
         self.use_graph = use_graph
         self.wgrad_inplace = True
         self.graph = None
@@ -102,17 +133,27 @@ class GDTrainer:
                             S["loss"]["loss_itm"].detach().float(), S["loss"]["loss_mlm"].detach().float(),
                             mix["loss_kd"].detach().float()])
 
+    def _on_vision_grad(self):
+        """tensor hook on the ViT output: text / fusion / head gradients are all enqueued -> reduce them under the ViT
+        backward"""
+        if not self._early_sent:
+            self._early_sent = True
+            self.reducer.reduce_async(self._early)
+
     def _step_eager(self, batch):
+        self._early_sent = False
         out = self._forward_backward(batch)
-        self.reducer.reduce()
+        if self.reducer.active:
+            self.reducer.reduce_async(self._late if self._early_sent else self.opt.flat_grads)
+            self.reducer.finish()
         self.opt.step()
         return out
 
     def step(self, batch, lr_mult=1.0):
         """one GD step; returns a device tensor [total, itc, itm, mlm, kd] (no host sync)."""
-        if not self.use_graph or self.world > 1:
-            # multi-GPU: the ITC all-gather sits in the middle of the forward, so the step runs eagerly
-            # (collectives are not captured; see module docstring).
+        if not self.use_graph or self.reducer.active:
+            # multi-GPU: the step runs eagerly - RCCL collectives cannot be captured into a hipGraph on this stack
+            # (tools/rccl_graph_probe.py crashes), and the eager step is GPU-bound anyway (same ms/step as the replay).
             self.opt.set_schedule(lr_mult)
             return self._step_eager(batch)
         if self.graph is None:

@@ -105,3 +105,20 @@ def test_single_process_allgather_is_identity():
     from efficientvlm_amd.efficient_models.xvlm import allgather
     x = torch.randn(4, 3)
     assert allgather(x) is x
+
+
+def _segment_case(rank, world):
+    """early / late segment reduction (overlap path) gives the same result as one full reduce"""
+    from efficientvlm_amd.trainer import GradReducer
+    torch.manual_seed(1)
+    base = torch.randn(5000)
+    flat = [base.clone() * (rank + 1)]
+    red = GradReducer(flat, bucket_bytes=4096)
+    red.reduce_async([flat[0][:1234]])       # "early" part, launched from the backward hook
+    red.reduce_async([flat[0][1234:]])       # "late" part, after backward
+    red.finish()
+    return bool(torch.allclose(flat[0], base * (sum(range(1, world + 1)) / world), rtol=1e-6, atol=1e-6))
+
+
+def test_segmented_overlap_reduction_equals_full_reduce():
+    assert run2(_segment_case) == [True, True]

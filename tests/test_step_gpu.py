@@ -200,3 +200,49 @@ def test_gd_step_matches_oracle_on_fresh_inputs():
     for k in S["loss"]:
         close(S["loss"][k], oS["loss"][k], 1e-4, 0, k)
     close(S["logits_dict"]["mlm_logits"].float(), oS["logits_dict"]["mlm_logits"], 1e-4, 1e-5, "mlm_logits")
+
+
+_DP_SCRIPT = r"""
+import os, sys, json, torch
+sys.path.insert(0, os.environ["EVLM_REPO"]); sys.path.insert(0, os.path.join(os.environ["EVLM_REPO"], "tests"))
+import torch.distributed as dist
+from oracle import synth
+from test_step_gpu import build_gd
+from efficientvlm_amd.trainer import GDTrainer
+dp = bool(os.environ.get("EVLM_FORCE_REDUCE"))
+if dp:
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+geom = synth.GEOMS["tiny"]
+student, teacher = build_gd(geom, 7)
+tr = GDTrainer(student, teacher, lr=1e-3, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=torch.float32,
+               use_graph=False)
+batch = {k: v.cuda() for k, v in synth.make_batch(geom, 4, seed=3).items()}
+torch.manual_seed(0)       # hard-negative multinomial draws
+out = [tr.step(batch).tolist() for _ in range(3)]
+assert tr.reducer.active == dp and (tr._early_sent or not dp)
+torch.cuda.synchronize()
+if dp:
+    dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_data_parallel_code_path_on_one_gpu_matches_plain_step():
+    """The N>1 path (RCCL group, early-segment all-reduce launched from the backward hook on a side stream, eager
+    launch) with world_size 1 must reproduce the plain trainer: a mean all-reduce over one rank is the identity."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(dp):
+        env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+        env.pop("EVLM_FORCE_REDUCE", None)
+        if dp:
+            env["EVLM_FORCE_REDUCE"] = "1"
+        r = subprocess.run([sys.executable, "-c", _DP_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+        return np.array(json.loads(line[7:]))
+
+    a, b = run(False), run(True)
+    assert np.allclose(a, b, rtol=2e-4, atol=1e-5), (a, b)
