@@ -1,0 +1,349 @@
+// 256x256x64 "ping-pong" bf16 GEMM for gfx950 (MI355X):  C[i,j] = epi( alpha * sum_k P[i,k] * Q[j,k] ), both operands
+// K-contiguous (forward products x W^T; the data-gradient products run here too, on the W^T copies the weight cache keeps).
+//
+// Why a second kernel: with a 128x128 tile one K step needs as many cycles of the CU's vector-memory pipe (32 KiB of
+// LDS-DMA at 64 B/clk) as of MFMA issue, so that kernel tops out near 60 % MFMA utilisation inside its K loop.  A
+// 256x256 tile halves the bytes per flop; what is left is to keep the matrix cores fed from ONE resident workgroup:
+//
+//   * 8 waves = 2 groups (wr) x 4 (wc); a wave owns 128 (i) x 64 (j) of C = 8 x 4 accumulators of 16x16 (128 VGPRs).
+//     SIMD s hosts wave s of group 0 and wave s of group 1.
+//   * The groups run ONE BARRIER APART (group 1 takes an extra s_barrier on entry, group 0 one on exit): every phase is
+//     [LDS reads + LDS-DMA issue] barrier [16 MFMAs] barrier, so while one group's wave owns the SIMD's matrix core the
+//     other group's wave on that SIMD issues its memory work - the MFMA pipe alternates between the two waves.
+//   * One K tile (64 deep) = 4 phases = the four 64x32 quadrants of the wave's C block (i-lo x j-lo, i-lo x j-hi,
+//     i-hi x j-hi, i-hi x j-lo): phase 0 reads the i-lo P fragments and the j-lo Q fragments, phase 1 the j-hi Q
+//     fragments, phase 2 the i-hi P fragments (over the i-lo registers), phase 3 nothing.
+//   * LDS: 2 buffers x 4 units of 16 KiB.  A unit is what ONE phase consumes - PL / PH: the i-lo / i-hi 64 rows of both
+//     wave groups, QL / QH: the j-lo / j-hi 32 columns of all four wave columns - as [128 rows][64 k] with the 16-byte
+//     chunks XOR-swizzled by (row >> 1) & 7 (conflict-free ds_read_b128).  It is filled by 2 global_load_lds_dwordx4 per
+//     wave (the swizzle is applied to the per-lane SOURCE address; the LDS image of a wave instruction is linear).
+//   * Staging order in time is PL(t) QL(t) QH(t) PH(t) PL(t+1) ... one unit per phase: phase 0 of K tile t issues QH(t+1),
+//     phase 1 PH(t+1), phase 2 PL(t+2), phase 3 QL(t+2) - each into the region whose last reader finished at least one
+//     full phase earlier (WAR: a unit read in phase r is free after both groups' reads retired, i.e. from phase r+2) and
+//     five phases before its consumer.  RAW: every wave waits `vmcnt(8)` (the four younger units stay in flight) in the
+//     phase BEFORE the consuming one, ahead of that phase's first barrier, so both groups have passed a barrier that
+//     follows every wave's wait before either reads the unit.
+//
+// Persistent: one workgroup per CU walks tiles b, b + grid, ...; the next tile's first six units are issued before the
+// current tile's epilogue (see below), so neither the launch nor the first HBM round trip is paid per tile.
+#include <stdlib.h>
+#include "gemm_common.h"
+
+#define PPU 16384                     // bytes per staging unit: 128 rows x 64 k x 2 B
+#define PPB 65536                     // bytes per buffer: PL | PH | QL | QH
+#define OFF_PL 0
+#define OFF_PH PPU
+#define OFF_QL (2 * PPU)
+#define OFF_QH (3 * PPU)
+
+struct PPSrc { int pl[2], ph[2], ql[2], qh[2]; };   // per-lane source element offsets of the 2 x 16 bytes staged per unit
+
+// tile row (P units) / tile column (Q units) of unit row u
+__device__ __forceinline__ int pp_prow(int u, int hi) { return (u >> 6) * 128 + (u & 63) + hi * 64; }
+__device__ __forceinline__ int pp_qcol(int u, int hi) { return (u >> 5) * 64 + (u & 31) + hi * 32; }
+
+__device__ __forceinline__ void pp_src(const GemmP& g, int i0, int j0, int tid, PPSrc& s) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int id = (c * 8 + wave) * 64 + lane;          // 16-byte LDS slot, linear per wave instruction
+    const int u = id >> 3, cp = id & 7;
+    const int koff = (cp ^ ((u >> 1) & 7)) << 3;
+    s.pl[c] = min(i0 + pp_prow(u, 0), g.I - 1) * g.ldp + koff;
+    s.ph[c] = min(i0 + pp_prow(u, 1), g.I - 1) * g.ldp + koff;
+    s.ql[c] = min(j0 + pp_qcol(u, 0), g.J - 1) * g.ldq + koff;
+    s.qh[c] = min(j0 + pp_qcol(u, 1), g.J - 1) * g.ldq + koff;
+  }
+}
+
+#define PP_GLDS(base, so, kel, ldsoff)                                                                              \
+  do {                                                                                                              \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((base) + ((so)[0] + (kel))),   \
+                                     (__attribute__((address_space(3))) void*)(smem + (ldsoff) + wave * 1024), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((base) + ((so)[1] + (kel))),   \
+                                     (__attribute__((address_space(3))) void*)(smem + (ldsoff) + (8 + wave) * 1024), 16, 0, 0); \
+  } while (0)
+
+#define PP_LD(ptr, off) (*reinterpret_cast<const bf16x8*>((ptr) + (off)))
+
+// [memory work] | barrier | MFMAs | barrier : the sched_barriers keep hipcc from moving MFMAs (pure register ops) across
+#define PP_MFMA_BEGIN()                 \
+  __builtin_amdgcn_sched_barrier(0);    \
+  __builtin_amdgcn_s_barrier();         \
+  __builtin_amdgcn_sched_barrier(0);    \
+  __builtin_amdgcn_s_setprio(1)
+#define PP_MFMA_END()                   \
+  __builtin_amdgcn_s_setprio(0);        \
+  __builtin_amdgcn_sched_barrier(0);    \
+  __builtin_amdgcn_s_barrier();         \
+  __builtin_amdgcn_sched_barrier(0)
+
+#define PP_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// 16 MFMAs: acc[AO + a][b] += Qf[a][ks] x Pf[b][ks]
+#define PP_QUAD(ACC, AO, QF)                                                                              \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                        \
+  _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                           \
+  _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                           \
+      ACC[AO + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(QF[a][ks], pf[b][ks], ACC[AO + a][b], 0, 0, 0)
+
+// one K tile out of buffer BUF (compile-time LDS offsets)
+#define PP_KTILE(BUF, t)                                                                                   \
+  do {                                                                                                     \
+    constexpr int B0 = (BUF) * PPB, B1 = ((BUF) ^ 1) * PPB;                                                \
+    const bool n1 = (t) + 1 < nt, n2 = (t) + 2 < nt;                                                       \
+    /* ---- phase 0: i-lo x j-lo ---- */                                                                   \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
+      ql[a][0] = PP_LD(qr0, B0 + OFF_QL + a * 2048); ql[a][1] = PP_LD(qr1, B0 + OFF_QL + a * 2048); }      \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                        \
+      pf[b][0] = PP_LD(pr0, B0 + OFF_PL + b * 2048); pf[b][1] = PP_LD(pr1, B0 + OFF_PL + b * 2048); }      \
+    if (n1) PP_GLDS(Qb, src.qh, ((t) + 1) * 64, B1 + OFF_QH);                                              \
+    if (n1) PP_WAIT(8); else PP_WAIT(2);                                                                   \
+    PP_MFMA_BEGIN(); PP_QUAD(accL, 0, ql); PP_MFMA_END();                                                  \
+    /* ---- phase 1: i-lo x j-hi ---- */                                                                   \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
+      qh[a][0] = PP_LD(qr0, B0 + OFF_QH + a * 2048); qh[a][1] = PP_LD(qr1, B0 + OFF_QH + a * 2048); }      \
+    if (n1) PP_GLDS(Pb, src.ph, ((t) + 1) * 64, B1 + OFF_PH);                                              \
+    if (n1) PP_WAIT(8); else PP_WAIT(0);                                                                   \
+    PP_MFMA_BEGIN(); PP_QUAD(accL, 2, qh); PP_MFMA_END();                                                  \
+    /* ---- phase 2: i-hi x j-hi ---- */                                                                   \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                        \
+      pf[b][0] = PP_LD(pr0, B0 + OFF_PH + b * 2048); pf[b][1] = PP_LD(pr1, B0 + OFF_PH + b * 2048); }      \
+    if (n2) PP_GLDS(Pb, src.pl, ((t) + 2) * 64, B0 + OFF_PL);                                              \
+    PP_MFMA_BEGIN(); PP_QUAD(accH, 2, qh); PP_MFMA_END();                                                  \
+    /* ---- phase 3: i-hi x j-lo ---- */                                                                   \
+    if (n2) PP_GLDS(Qb, src.ql, ((t) + 2) * 64, B0 + OFF_QL);                                              \
+    if (n2) PP_WAIT(8); else if (n1) PP_WAIT(4);                                                           \
+    PP_MFMA_BEGIN(); PP_QUAD(accH, 0, ql); PP_MFMA_END();                                                  \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// epilogue.  Each wave converts its own 128 x 64 block through a wave-PRIVATE 4 KiB LDS window (32 rows x 64 columns at
+// a time): no workgroup barrier, the staging buffers stay free for the next tile's prologue DMAs, and the global stores
+// are full 128-byte row segments.  Per-column vectors and the aux / residual fragments are fetched in ONE batch per
+// 64-row half before they are consumed - with a single resident workgroup nothing else would hide a chain of dependent
+// global loads.
+// ---------------------------------------------------------------------------------------------
+#define PP_EPI_OFF (2 * PPB)          // 8 x 4 KiB windows behind the staging buffers (160 KiB of LDS in total)
+
+template <bool FULL>
+__device__ __forceinline__ void pp_epi_cols(const GemmP& g, int jb, int lane, f32x4 (&bz)[4]) {
+  const int jl = (lane >> 4) * 4;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int j = jb + a * 16 + jl;
+    const int jc = FULL ? j : min(j, g.J - 4);
+    bz[a] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + jc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// MODE 1: the pre-activation output (alpha * acc + bias); MODE 2: C
+template <bool FULL, int MODE>
+__device__ __forceinline__ void pp_epi_half(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4],
+                                            int ib, int jb, int lane, char* sw, bf16* dst, int ldd) {
+  const int il = lane & 15, jl = (lane >> 4) * 4;
+  const bool need_h = MODE == 2 && g.dact != EVLM_ACT_NONE, need_r = MODE == 2 && g.residual != nullptr;
+  bf16x4 xx[4][4];                   // aux (activation backward) OR residual fragments: the host never routes both here
+  if (need_h || need_r) {
+    const bf16* xb = reinterpret_cast<const bf16*>(need_h ? g.aux : g.residual);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = ib + b * 16 + il, j = jb + a * 16 + jl;
+        const size_t o = (size_t)(FULL ? i : min(i, g.I - 1)) * g.ldx + (FULL ? j : min(j, g.J - 4));
+        xx[a][b] = *reinterpret_cast<const bf16x4*>(xb + o);
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      const int b = c * 2 + bb;
+      const int r = bb * 16 + il;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][e] * g.alpha + bz[a][e];
+        if (MODE == 2) {
+          if (g.act != EVLM_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_apply(g.act, v[e]);
+          }
+          if (need_h) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= act_grad(g.dact, (float)xx[a][b][e]);
+          }
+          if (need_r) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)xx[a][b][e];
+          }
+        }
+        const int ch = a * 2 + (jl >> 3);
+        Vec4<bf16>::store(reinterpret_cast<bf16*>(sw + r * 128 + ((ch ^ (r & 7)) << 4) + ((jl & 4) << 1)), v);
+      }
+    }
+    asm volatile("" ::: "memory");           // same-wave LDS traffic is in order; keep the compiler from reordering it
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = k * 8 + (lane >> 3), ch = lane & 7;
+      const uint4 v16 = *reinterpret_cast<const uint4*>(sw + r * 128 + ((ch ^ (r & 7)) << 4));
+      const int i = ib + c * 32 + r, j = jb + ch * 8;
+      if (FULL || (i < g.I && j < g.J)) *reinterpret_cast<uint4*>(dst + (size_t)i * ldd + j) = v16;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <bool FULL>
+__device__ __forceinline__ void pp_epilogue(const GemmP& g, f32x4 (&accL)[4][4], f32x4 (&accH)[4][4], int ib, int jb, int lane,
+                                            char* sw) {
+  f32x4 bz[4];
+  pp_epi_cols<FULL>(g, jb, lane, bz);
+  if (g.preact) {
+    pp_epi_half<FULL, 1>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx);
+    pp_epi_half<FULL, 1>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx);
+  }
+  pp_epi_half<FULL, 2>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
+  pp_epi_half<FULL, 2>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
+}
+
+// XCD-aware bijective map of a virtual block id onto the tile grid (see tile_coords): blocks that share an XCD (id mod 8)
+// get a contiguous range of tile ids, j fastest
+__device__ __forceinline__ void pp_tile_ij(const GemmP& g, int vb, int ntiles, int& ti, int& tj) {
+  const int q = ntiles >> 3, r = ntiles & 7, xcd = vb & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+  ti = t / g.tiles_j;
+  tj = t - ti * g.tiles_j;
+}
+
+// persistent: gridDim.x = min(tiles, CUs) (a multiple of 8 when tiles exceed the CU count); workgroup b runs tiles
+// b, b + grid, ...  The next tile's first six staging units are issued BEFORE the epilogue of the current one.
+__global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 64 KiB staging + 8 x 4 KiB epilogue windows; ALL LDS
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ntiles = g.tiles_i * g.tiles_j;
+  int vb = blockIdx.x;
+  int ti, tj;
+  pp_tile_ij(g, vb, ntiles, ti, tj);
+  int i0 = ti * 256, j0 = tj * 256;
+  const bf16* Pb = reinterpret_cast<const bf16*>(g.P);
+  const bf16* Qb = reinterpret_cast<const bf16*>(g.Q);
+  PPSrc src;
+  pp_src(g, i0, j0, tid, src);
+  const int nt = g.K >> 6;
+
+  // per-lane fragment read pointers: row (lane & 15) of a 16-row fragment, 16-byte chunk (ks*4 + (lane >> 4)) ^ swizzle
+  const int l15 = lane & 15, lg = lane >> 4, sw = (l15 >> 1) & 7;
+  const int o0 = l15 * 128 + ((lg ^ sw) << 4), o1 = o0 ^ 64;
+  const char* pr0 = smem + wr * (64 * 128) + o0;
+  const char* pr1 = smem + wr * (64 * 128) + o1;
+  const char* qr0 = smem + wc * (32 * 128) + o0;
+  const char* qr1 = smem + wc * (32 * 128) + o1;
+  char* swin = smem + PP_EPI_OFF + wave * 4096;
+
+  f32x4 accL[4][4], accH[4][4];     // [j fragment][i fragment]; L: i rows 0..63 of the wave's block, H: 64..127
+  bf16x8 pf[4][2], ql[2][2], qh[2][2];
+
+  // prologue (host guarantees nt >= 2): PL0 QL0 QH0 PH0 PL1 QL1 in flight
+  PP_GLDS(Pb, src.pl, 0, OFF_PL);
+  PP_GLDS(Qb, src.ql, 0, OFF_QL);
+  PP_GLDS(Qb, src.qh, 0, OFF_QH);
+  PP_GLDS(Pb, src.ph, 0, OFF_PH);
+  PP_GLDS(Pb, src.pl, 64, PPB + OFF_PL);
+  PP_GLDS(Qb, src.ql, 64, PPB + OFF_QL);
+  PP_WAIT(8);                                     // PL0, QL0 have landed (this wave's share)
+
+#ifdef PP_STAMP
+  unsigned long long stp[5]; int stn = 0;
+  stp[4] = __builtin_amdgcn_s_memtime();
+#endif
+  while (true) {
+#ifdef PP_STAMP
+    stp[0] = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { accL[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; accH[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one barrier behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {
+      PP_KTILE(0, t);
+      PP_KTILE(1, t + 1);
+    }
+    if (t < nt) PP_KTILE(0, t);
+    if (wr == 0) __builtin_amdgcn_s_barrier();    // re-align the groups: every LDS read of the K loop has retired
+    __builtin_amdgcn_sched_barrier(0);
+
+#ifdef PP_STAMP
+    stp[1] = __builtin_amdgcn_s_memtime();
+#endif
+    const int ib = i0 + wr * 128, jb = j0 + wc * 64;
+    const bool full = (i0 + 256 <= g.I) && (j0 + 256 <= g.J);
+    vb += gridDim.x;
+    const bool more = vb < ntiles;
+    if (more) {                                   // next tile: its first six units fly under this tile's epilogue
+      pp_tile_ij(g, vb, ntiles, ti, tj);
+      i0 = ti * 256; j0 = tj * 256;
+      pp_src(g, i0, j0, tid, src);
+      PP_GLDS(Pb, src.pl, 0, OFF_PL);
+      PP_GLDS(Qb, src.ql, 0, OFF_QL);
+      PP_GLDS(Qb, src.qh, 0, OFF_QH);
+      PP_GLDS(Pb, src.ph, 0, OFF_PH);
+      PP_GLDS(Pb, src.pl, 64, PPB + OFF_PL);
+      PP_GLDS(Qb, src.ql, 64, PPB + OFF_QL);
+    }
+#ifdef PP_STAMP
+    stp[2] = __builtin_amdgcn_s_memtime();
+#endif
+    if (full) pp_epilogue<true>(g, accL, accH, ib, jb, lane, swin);
+    else pp_epilogue<false>(g, accL, accH, ib, jb, lane, swin);
+#ifdef PP_STAMP
+    stp[3] = __builtin_amdgcn_s_memtime();
+    PP_WAIT(0);
+    if (tid == 0 && g.psum) {     // [start, k-loop end, next prologue issued, epilogue issued, all retired, kernel entry]
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(g.psum) + ((size_t)blockIdx.x * 4 + stn) * 6;
+      o[0] = stp[0]; o[1] = stp[1]; o[2] = stp[2]; o[3] = stp[3]; o[4] = __builtin_amdgcn_s_memtime(); o[5] = stp[4];
+    }
+    ++stn;
+#endif
+    if (!more) break;
+    PP_WAIT(0);                                   // the six units (and this tile's stores: one counter) have retired
+  }
+}
+
+// bf16 in / bf16 out, both operands K-contiguous, K a multiple of 64 and >= 128, 32-bit operand offsets, J % 8 == 0
+bool evlm_gemm_pp256_eligible(const GemmP& g, int pt, int qt) {
+#ifndef PP_STAMP
+  if (g.psum) return false;
+#endif
+  if (pt || qt || g.c_f32 || g.accumulate || g.gate) return false;
+  if (g.dact != EVLM_ACT_NONE && g.residual) return false;
+  if (g.K % 64 != 0 || g.K < 128 || g.J % 8 != 0 || g.ldc % 8 != 0) return false;
+  if ((g.preact || g.aux || g.residual) && g.ldx % 8 != 0) return false;
+  if ((int64_t)g.I * g.ldp >= (1ll << 31) || (int64_t)g.J * g.ldq >= (1ll << 31)) return false;
+  return true;
+}
+
+int evlm_gemm_pp256_launch(GemmP& g, hipStream_t stream) {
+  static bool attr_set = false;
+  const int lds = 2 * PPB + 8 * 4096;
+  if (!attr_set) {     // 160 KiB of dynamic LDS needs the opt-in
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp256_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return evlm_set_error("evlm_gemm: cannot reserve 160 KiB LDS: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  g.tiles_i = ceil_div(g.I, 256); g.tiles_j = ceil_div(g.J, 256); g.kt_per_split = 0; g.bare_f32 = 0;
+  const int tiles = g.tiles_i * g.tiles_j;
+  hipLaunchKernelGGL(gemm_bf16_pp256_kernel, dim3(imin(tiles, 256)), dim3(512), lds, stream, g);
+  return 0;
+}
