@@ -20,7 +20,8 @@
 #include "gemm_common.h"
 
 // 256x256 ping-pong kernel (gemm_pp256.hip)
-int evlm_gemm_pp256_launch(GemmP& g, hipStream_t stream);
+int evlm_gemm_pp256_launch(GemmP& g, int pt, int qt, hipStream_t stream);
+int evlm_gemm_pp256_splits(const GemmP& g);
 bool evlm_gemm_pp256_eligible(const GemmP& g, int pt, int qt);
 
 
@@ -826,9 +827,13 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
     // its tiles fill the 256 CUs well enough (measured crossover, tools/gemm_pp256.py)
     static const int pp_pct = getenv("EVLM_PP256_PCT") ? atoi(getenv("EVLM_PP256_PCT")) : 55;   // tuning aid; > 100 disables
     if (evlm_gemm_pp256_eligible(g, pt, qt)) {
-      const int t256 = ceil_div(g.I, 256) * ceil_div(g.J, 256);
-      if (t256 * 100 >= pp_pct * ceil_div(t256, 256) * 256) {
-        if (evlm_gemm_pp256_launch(g, stream)) return -1;
+      const int items = ceil_div(g.I, 256) * ceil_div(g.J, 256) * evlm_gemm_pp256_splits(g);
+      if (items * 100 >= pp_pct * ceil_div(items, 256) * 256) {
+        if (g.c_f32 && evlm_gemm_pp256_splits(g) > 1 && !g.accumulate) {
+          hipError_t me = hipMemsetAsync(g.C, 0, (size_t)g.I * g.ldc * sizeof(float), stream);
+          if (me != hipSuccess) return evlm_set_error("evlm_gemm: memset failed: %s", hipGetErrorString(me));
+        }
+        if (evlm_gemm_pp256_launch(g, pt, qt, stream)) return -1;
         EVLM_LAUNCH_CHECK("evlm_gemm");
         return 0;
       }

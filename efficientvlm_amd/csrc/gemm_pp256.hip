@@ -1,5 +1,9 @@
-// 256x256x64 "ping-pong" bf16 GEMM for gfx950 (MI355X):  C[i,j] = epi( alpha * sum_k P[i,k] * Q[j,k] ), both operands
-// K-contiguous (forward products x W^T; the data-gradient products run here too, on the W^T copies the weight cache keeps).
+// 256x256x64 "ping-pong" bf16 GEMM for gfx950 (MI355X):  C[i,j] = epi( alpha * sum_k P(i,k) * Q(j,k) ).
+// Operands are K-contiguous ([rows][K]: forward products x W^T) or reduction-major ([K][rows]: W in dX = dY W, both
+// operands in dW = dY^T X); the latter are read from LDS with the transposing ds_read_b64_tr_b16, so no transposed copy
+// ever exists in HBM.  bf16 output goes through the fused epilogue; weight gradients leave as f32 (plain stores, or f32
+// atomics into the flat gradient slab when the reduction is split over workgroups / accumulated in place), with the
+// bias gradient (row sums of dY^T) computed on the VALU from the fragments that are in registers anyway.
 //
 // Why a second kernel: with a 128x128 tile one K step needs as many cycles of the CU's vector-memory pipe (32 KiB of
 // LDS-DMA at 64 B/clk) as of MFMA issue, so that kernel tops out near 60 % MFMA utilisation inside its K loop.  A
@@ -29,30 +33,56 @@
 #include <stdlib.h>
 #include "gemm_common.h"
 
-#define PPU 16384                     // bytes per staging unit: 128 rows x 64 k x 2 B
+#define PPU 16384                     // bytes per staging unit: 128 operand rows x 64 k x 2 B
 #define PPB 65536                     // bytes per buffer: PL | PH | QL | QH
 #define OFF_PL 0
 #define OFF_PH PPU
 #define OFF_QL (2 * PPU)
 #define OFF_QH (3 * PPU)
+#define PP_EPI_OFF (2 * PPB)          // 8 x 4 KiB epilogue windows behind the staging buffers (160 KiB of LDS in total)
 
 struct PPSrc { int pl[2], ph[2], ql[2], qh[2]; };   // per-lane source element offsets of the 2 x 16 bytes staged per unit
 
 // tile row (P units) / tile column (Q units) of unit row u
 __device__ __forceinline__ int pp_prow(int u, int hi) { return (u >> 6) * 128 + (u & 63) + hi * 64; }
 __device__ __forceinline__ int pp_qcol(int u, int hi) { return (u >> 5) * 64 + (u & 31) + hi * 32; }
+// 16-byte-chunk swizzle of a reduction-major unit row ([64 k][128 rows], 256-byte rows): conflict-free tr reads
+__device__ __forceinline__ int pp_trswz(int kr) { return ((kr & 3) << 2) | ((kr >> 2) & 3); }
 
+// K-contiguous unit: [128 rows][64 k], 128-byte rows, chunk ^= (row >> 1) & 7.  Reduction-major unit: [64 k][128 rows].
+// One wave instruction fills 1 KiB of LDS linearly, so the swizzle is applied to the per-lane SOURCE chunk.
+template <bool PT, bool QT>
 __device__ __forceinline__ void pp_src(const GemmP& g, int i0, int j0, int tid, PPSrc& s) {
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int id = (c * 8 + wave) * 64 + lane;          // 16-byte LDS slot, linear per wave instruction
-    const int u = id >> 3, cp = id & 7;
-    const int koff = (cp ^ ((u >> 1) & 7)) << 3;
-    s.pl[c] = min(i0 + pp_prow(u, 0), g.I - 1) * g.ldp + koff;
-    s.ph[c] = min(i0 + pp_prow(u, 1), g.I - 1) * g.ldp + koff;
-    s.ql[c] = min(j0 + pp_qcol(u, 0), g.J - 1) * g.ldq + koff;
-    s.qh[c] = min(j0 + pp_qcol(u, 1), g.J - 1) * g.ldq + koff;
+    {
+      const int u = id >> 3, cp = id & 7;
+      const int koff = (cp ^ ((u >> 1) & 7)) << 3;
+      if (!PT) {
+        s.pl[c] = min(i0 + pp_prow(u, 0), g.I - 1) * g.ldp + koff;
+        s.ph[c] = min(i0 + pp_prow(u, 1), g.I - 1) * g.ldp + koff;
+      }
+      if (!QT) {
+        s.ql[c] = min(j0 + pp_qcol(u, 0), g.J - 1) * g.ldq + koff;
+        s.qh[c] = min(j0 + pp_qcol(u, 1), g.J - 1) * g.ldq + koff;
+      }
+    }
+    {
+      const int kr = id >> 4, cp = id & 15;
+      const int u0 = (cp ^ pp_trswz(kr)) << 3;
+      if (PT) {
+        const int lim = ((g.I + 7) & ~7) - 8;
+        s.pl[c] = kr * g.ldp + min(i0 + pp_prow(u0, 0), lim);
+        s.ph[c] = kr * g.ldp + min(i0 + pp_prow(u0, 1), lim);
+      }
+      if (QT) {
+        const int lim = ((g.J + 7) & ~7) - 8;
+        s.ql[c] = kr * g.ldq + min(j0 + pp_qcol(u0, 0), lim);
+        s.qh[c] = kr * g.ldq + min(j0 + pp_qcol(u0, 1), lim);
+      }
+    }
   }
 }
 
@@ -64,7 +94,39 @@ __device__ __forceinline__ void pp_src(const GemmP& g, int i0, int j0, int tid, 
                                      (__attribute__((address_space(3))) void*)(smem + (ldsoff) + (8 + wave) * 1024), 16, 0, 0); \
   } while (0)
 
-#define PP_LD(ptr, off) (*reinterpret_cast<const bf16x8*>((ptr) + (off)))
+// Fragment f (16 operand rows) x k sub-step ks (32 deep) of the unit at byte offset `uo`.  `lb` is ONE per-lane base
+// (pp_lane_base): every other address term is a compile-time XOR / immediate, so the K loop carries no address registers.
+//   K-contiguous unit : row (lane & 15) of fragment f, chunk (ks*4 + (lane >> 4)) ^ swizzle   -> (lb ^ ks*64) + f*2048
+//   reduction-major   : two transposing reads (h = 0, 1) of k rows ks*32 + (lane >> 4)*8 + h*4 + q; the swizzled chunk
+//                       differs from the lane's base chunk only in the bits (f >> 1, f & 1, h)  -> lb ^ (those bits << 4)
+template <bool TR>
+__device__ __forceinline__ bf16x8 pp_frag(const char* smem, int uo, int lb, int f, int ks) {
+  if (!TR) {
+    return *reinterpret_cast<const bf16x8*>(smem + (lb ^ (ks << 6)) + (uo + f * 2048));
+  } else {
+    bf16x8 out;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int cz = ((f >> 1) << 6) | ((f & 1) << 5) | (h << 4);
+      bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (bf16x4 __attribute__((address_space(3)))*)(smem + (lb ^ cz) + (uo + ks * 8192 + h * 1024)));
+      out[4 * h + 0] = t[0]; out[4 * h + 1] = t[1]; out[4 * h + 2] = t[2]; out[4 * h + 3] = t[3];
+    }
+    return out;
+  }
+}
+// per-lane base for pp_frag; `wsel` = wave row (P units: 2 x 64 unit rows) or wave column (Q units: 4 x 32)
+template <bool TR, bool IS_P>
+__device__ __forceinline__ int pp_lane_base(int lane, int wsel) {
+  if (!TR) {
+    const int l15 = lane & 15;
+    return (wsel * (IS_P ? 64 : 32) + l15) * 128 + (((lane >> 4) ^ ((l15 >> 1) & 7)) << 4);
+  } else {
+    const int g4 = lane >> 4, w = lane & 15, q = w >> 2, pp = w & 3;
+    const int hi = IS_P ? (((wsel ^ (q >> 1)) << 1) | (q & 1)) : (wsel ^ q);     // chunk bits 3:2 at f = 0
+    return g4 * 2048 + q * 256 + ((pp & 1) << 3) + (hi << 6) + ((g4 & 1) << 5) + ((pp >> 1) << 4);
+  }
+}
 
 // [memory work] | barrier | MFMAs | barrier : the sched_barriers keep hipcc from moving MFMAs (pure register ops) across
 #define PP_MFMA_BEGIN()                 \
@@ -87,33 +149,45 @@ __device__ __forceinline__ void pp_src(const GemmP& g, int i0, int j0, int tid, 
   _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                           \
       ACC[AO + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(QF[a][ks], pf[b][ks], ACC[AO + a][b], 0, 0, 0)
 
-// one K tile out of buffer BUF (compile-time LDS offsets)
+// bias gradient: per-lane partial row sums of the P fragments in registers (lane holds k = 8*(lane>>4)..+7 of row lane&15)
+#define PP_PSUM(PS, BO)                                                                                    \
+  if (OUT == 1 && do_psum) {                                                                               \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) PS[(BO) + b] += (float)pf[b][ks][e];                     \
+  }
+
+// one K tile out of buffer BUF (compile-time LDS offsets); K tile index t of nt, operands at Pk / Qk
 #define PP_KTILE(BUF, t)                                                                                   \
   do {                                                                                                     \
     constexpr int B0 = (BUF) * PPB, B1 = ((BUF) ^ 1) * PPB;                                                \
     const bool n1 = (t) + 1 < nt, n2 = (t) + 2 < nt;                                                       \
     /* ---- phase 0: i-lo x j-lo ---- */                                                                   \
     _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
-      ql[a][0] = PP_LD(qr0, B0 + OFF_QL + a * 2048); ql[a][1] = PP_LD(qr1, B0 + OFF_QL + a * 2048); }      \
+      ql[a][0] = pp_frag<QT>(smem, B0 + OFF_QL, qlb, a, 0);                                     \
+      ql[a][1] = pp_frag<QT>(smem, B0 + OFF_QL, qlb, a, 1); }                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                        \
-      pf[b][0] = PP_LD(pr0, B0 + OFF_PL + b * 2048); pf[b][1] = PP_LD(pr1, B0 + OFF_PL + b * 2048); }      \
-    if (n1) PP_GLDS(Qb, src.qh, ((t) + 1) * 64, B1 + OFF_QH);                                              \
+      pf[b][0] = pp_frag<PT>(smem, B0 + OFF_PL, plb, b, 0);                                     \
+      pf[b][1] = pp_frag<PT>(smem, B0 + OFF_PL, plb, b, 1); }                                   \
+    if (n1) PP_GLDS(Qk, src.qh, ((t) + 1) * kq, B1 + OFF_QH);                                              \
     if (n1) PP_WAIT(8); else PP_WAIT(2);                                                                   \
-    PP_MFMA_BEGIN(); PP_QUAD(accL, 0, ql); PP_MFMA_END();                                                  \
+    PP_MFMA_BEGIN(); PP_QUAD(accL, 0, ql); PP_PSUM(ps, 0); PP_MFMA_END();                                  \
     /* ---- phase 1: i-lo x j-hi ---- */                                                                   \
     _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
-      qh[a][0] = PP_LD(qr0, B0 + OFF_QH + a * 2048); qh[a][1] = PP_LD(qr1, B0 + OFF_QH + a * 2048); }      \
-    if (n1) PP_GLDS(Pb, src.ph, ((t) + 1) * 64, B1 + OFF_PH);                                              \
+      qh[a][0] = pp_frag<QT>(smem, B0 + OFF_QH, qlb, a, 0);                                     \
+      qh[a][1] = pp_frag<QT>(smem, B0 + OFF_QH, qlb, a, 1); }                                   \
+    if (n1) PP_GLDS(Pk, src.ph, ((t) + 1) * kp, B1 + OFF_PH);                                              \
     if (n1) PP_WAIT(8); else PP_WAIT(0);                                                                   \
     PP_MFMA_BEGIN(); PP_QUAD(accL, 2, qh); PP_MFMA_END();                                                  \
     /* ---- phase 2: i-hi x j-hi ---- */                                                                   \
     _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                        \
-      pf[b][0] = PP_LD(pr0, B0 + OFF_PH + b * 2048); pf[b][1] = PP_LD(pr1, B0 + OFF_PH + b * 2048); }      \
-    if (n2) PP_GLDS(Pb, src.pl, ((t) + 2) * 64, B0 + OFF_PL);                                              \
-    PP_MFMA_BEGIN(); PP_QUAD(accH, 2, qh); PP_MFMA_END();                                                  \
+      pf[b][0] = pp_frag<PT>(smem, B0 + OFF_PH, plb, b, 0);                                     \
+      pf[b][1] = pp_frag<PT>(smem, B0 + OFF_PH, plb, b, 1); }                                   \
+    if (n2) PP_GLDS(Pk, src.pl, ((t) + 2) * kp, B0 + OFF_PL);                                              \
+    PP_MFMA_BEGIN(); PP_QUAD(accH, 2, qh); PP_PSUM(ps, 4); PP_MFMA_END();                                  \
     /* ---- phase 3: i-hi x j-lo ---- */                                                                   \
-    if (n2) PP_GLDS(Qb, src.ql, ((t) + 2) * 64, B0 + OFF_QL);                                              \
+    if (n2) PP_GLDS(Qk, src.ql, ((t) + 2) * kq, B0 + OFF_QL);                                              \
     if (n2) PP_WAIT(8); else if (n1) PP_WAIT(4);                                                           \
     PP_MFMA_BEGIN(); PP_QUAD(accH, 0, ql); PP_MFMA_END();                                                  \
   } while (0)
@@ -125,7 +199,6 @@ __device__ __forceinline__ void pp_src(const GemmP& g, int i0, int j0, int tid, 
 // 64-row half before they are consumed - with a single resident workgroup nothing else would hide a chain of dependent
 // global loads.
 // ---------------------------------------------------------------------------------------------
-#define PP_EPI_OFF (2 * PPB)          // 8 x 4 KiB windows behind the staging buffers (160 KiB of LDS in total)
 
 template <bool FULL>
 __device__ __forceinline__ void pp_epi_cols(const GemmP& g, int jb, int lane, f32x4 (&bz)[4]) {
@@ -212,6 +285,46 @@ __device__ __forceinline__ void pp_epilogue(const GemmP& g, f32x4 (&accL)[4][4],
   pp_epi_half<FULL, 2>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
 }
 
+// weight gradients: f32 tile out of the same 4 KiB window, 16 rows x 64 columns at a time.  Plain 16-byte stores when the
+// workgroup owns the whole reduction and the output is not accumulated; otherwise f32 atomics issued so that one wave
+// instruction covers 256 contiguous bytes (scattered dword atomics run an order of magnitude slower).
+template <bool FULL>
+__device__ __forceinline__ void pp_epi_f32_half(const GemmP& g, f32x4 (&acc)[4][4], int ib, int jb, int lane, char* sw,
+                                                bool atomic) {
+  const int il = lane & 15, jq = lane >> 4;
+  float* Cf = reinterpret_cast<float*>(g.C);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      f32x4 v = acc[a][b];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= g.alpha;
+      *reinterpret_cast<f32x4*>(sw + il * 256 + (((a * 4 + jq) ^ il) << 4)) = v;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (atomic) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = *reinterpret_cast<const float*>(sw + r * 256 + (((lane >> 2) ^ r) << 4) + ((lane & 3) << 2));
+        const int i = ib + b * 16 + r, j = jb + lane;
+        if (FULL || (i < g.I && j < g.J)) atomicAdd(Cf + (size_t)i * g.ldc + j, v);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = k * 4 + (lane >> 4), ch = lane & 15;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sw + r * 256 + ((ch ^ r) << 4));
+        const int i = ib + b * 16 + r, j = jb + ch * 4;
+        if (FULL || (i < g.I && j < g.J)) *reinterpret_cast<f32x4*>(Cf + (size_t)i * g.ldc + j) = v;   // J % 4 == 0
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // XCD-aware bijective map of a virtual block id onto the tile grid (see tile_coords): blocks that share an XCD (id mod 8)
 // get a contiguous range of tile ids, j fastest
 __device__ __forceinline__ void pp_tile_ij(const GemmP& g, int vb, int ntiles, int& ti, int& tj) {
@@ -221,44 +334,44 @@ __device__ __forceinline__ void pp_tile_ij(const GemmP& g, int vb, int ntiles, i
   tj = t - ti * g.tiles_j;
 }
 
-// persistent: gridDim.x = min(tiles, CUs) (a multiple of 8 when tiles exceed the CU count); workgroup b runs tiles
-// b, b + grid, ...  The next tile's first six staging units are issued BEFORE the epilogue of the current one.
+// persistent: gridDim.x = min(work items, CUs); workgroup b runs items b, b + grid, ...  An item is (K split, tile);
+// split s covers K tiles [s * kt_per_split, ...).  The next item's first six staging units are issued BEFORE the epilogue
+// of the current one.   OUT 0: bf16 through the fused epilogue;  OUT 1: bare f32 (weight gradients).
+template <bool PT, bool QT, int OUT>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 64 KiB staging + 8 x 4 KiB epilogue windows; ALL LDS
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int ntiles = g.tiles_i * g.tiles_j;
+  const int nt_all = g.K >> 6;
+  const int splits = (nt_all + g.kt_per_split - 1) / g.kt_per_split;
+  const int nitems = ntiles * splits;
+  const int kp = PT ? 64 * g.ldp : 64, kq = QT ? 64 * g.ldq : 64;     // elements per K tile step
   int vb = blockIdx.x;
   int ti, tj;
-  pp_tile_ij(g, vb, ntiles, ti, tj);
+  int sp = vb / ntiles;
+  pp_tile_ij(g, vb - sp * ntiles, ntiles, ti, tj);
   int i0 = ti * 256, j0 = tj * 256;
-  const bf16* Pb = reinterpret_cast<const bf16*>(g.P);
-  const bf16* Qb = reinterpret_cast<const bf16*>(g.Q);
+  int nt = min(nt_all - sp * g.kt_per_split, g.kt_per_split);
+  const bf16* Pk = reinterpret_cast<const bf16*>(g.P) + (size_t)sp * g.kt_per_split * kp;
+  const bf16* Qk = reinterpret_cast<const bf16*>(g.Q) + (size_t)sp * g.kt_per_split * kq;
   PPSrc src;
-  pp_src(g, i0, j0, tid, src);
-  const int nt = g.K >> 6;
-
-  // per-lane fragment read pointers: row (lane & 15) of a 16-row fragment, 16-byte chunk (ks*4 + (lane >> 4)) ^ swizzle
-  const int l15 = lane & 15, lg = lane >> 4, sw = (l15 >> 1) & 7;
-  const int o0 = l15 * 128 + ((lg ^ sw) << 4), o1 = o0 ^ 64;
-  const char* pr0 = smem + wr * (64 * 128) + o0;
-  const char* pr1 = smem + wr * (64 * 128) + o1;
-  const char* qr0 = smem + wc * (32 * 128) + o0;
-  const char* qr1 = smem + wc * (32 * 128) + o1;
+  pp_src<PT, QT>(g, i0, j0, tid, src);
   char* swin = smem + PP_EPI_OFF + wave * 4096;
+  const int plb = pp_lane_base<PT, true>(lane, wr), qlb = pp_lane_base<QT, false>(lane, wc);
 
   f32x4 accL[4][4], accH[4][4];     // [j fragment][i fragment]; L: i rows 0..63 of the wave's block, H: 64..127
   bf16x8 pf[4][2], ql[2][2], qh[2][2];
+  float ps[8];                      // OUT 1: per-lane partial row sums of P (bias gradient), i fragments 0..7
 
-  // prologue (host guarantees nt >= 2): PL0 QL0 QH0 PH0 PL1 QL1 in flight
-  PP_GLDS(Pb, src.pl, 0, OFF_PL);
-  PP_GLDS(Qb, src.ql, 0, OFF_QL);
-  PP_GLDS(Qb, src.qh, 0, OFF_QH);
-  PP_GLDS(Pb, src.ph, 0, OFF_PH);
-  PP_GLDS(Pb, src.pl, 64, PPB + OFF_PL);
-  PP_GLDS(Qb, src.ql, 64, PPB + OFF_QL);
+  // prologue (host guarantees >= 2 K tiles per item): PL0 QL0 QH0 PH0 PL1 QL1 in flight
+  PP_GLDS(Pk, src.pl, 0, OFF_PL);
+  PP_GLDS(Qk, src.ql, 0, OFF_QL);
+  PP_GLDS(Qk, src.qh, 0, OFF_QH);
+  PP_GLDS(Pk, src.ph, 0, OFF_PH);
+  PP_GLDS(Pk, src.pl, kp, PPB + OFF_PL);
+  PP_GLDS(Qk, src.ql, kq, PPB + OFF_QL);
   PP_WAIT(8);                                     // PL0, QL0 have landed (this wave's share)
-
 #ifdef PP_STAMP
   unsigned long long stp[5]; int stn = 0;
   stp[4] = __builtin_amdgcn_s_memtime();
@@ -267,10 +380,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
 #ifdef PP_STAMP
     stp[0] = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef PP_STAMP
+    const bool do_psum = false;
+#else
+    const bool do_psum = OUT == 1 && g.psum != nullptr && tj == 0 && wc == 0;
+#endif
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) { accL[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; accH[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) ps[b] = 0.f;
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one barrier behind group 0
     __builtin_amdgcn_sched_barrier(0);
@@ -282,30 +402,49 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
     if (t < nt) PP_KTILE(0, t);
     if (wr == 0) __builtin_amdgcn_s_barrier();    // re-align the groups: every LDS read of the K loop has retired
     __builtin_amdgcn_sched_barrier(0);
-
 #ifdef PP_STAMP
     stp[1] = __builtin_amdgcn_s_memtime();
 #endif
     const int ib = i0 + wr * 128, jb = j0 + wc * 64;
     const bool full = (i0 + 256 <= g.I) && (j0 + 256 <= g.J);
     vb += gridDim.x;
-    const bool more = vb < ntiles;
-    if (more) {                                   // next tile: its first six units fly under this tile's epilogue
-      pp_tile_ij(g, vb, ntiles, ti, tj);
+    const bool more = vb < nitems;
+    if (more) {                                   // next item: its first six units fly under this item's epilogue
+      sp = vb / ntiles;
+      pp_tile_ij(g, vb - sp * ntiles, ntiles, ti, tj);
       i0 = ti * 256; j0 = tj * 256;
-      pp_src(g, i0, j0, tid, src);
-      PP_GLDS(Pb, src.pl, 0, OFF_PL);
-      PP_GLDS(Qb, src.ql, 0, OFF_QL);
-      PP_GLDS(Qb, src.qh, 0, OFF_QH);
-      PP_GLDS(Pb, src.ph, 0, OFF_PH);
-      PP_GLDS(Pb, src.pl, 64, PPB + OFF_PL);
-      PP_GLDS(Qb, src.ql, 64, PPB + OFF_QL);
+      nt = min(nt_all - sp * g.kt_per_split, g.kt_per_split);
+      Pk = reinterpret_cast<const bf16*>(g.P) + (size_t)sp * g.kt_per_split * kp;
+      Qk = reinterpret_cast<const bf16*>(g.Q) + (size_t)sp * g.kt_per_split * kq;
+      pp_src<PT, QT>(g, i0, j0, tid, src);
+      PP_GLDS(Pk, src.pl, 0, OFF_PL);
+      PP_GLDS(Qk, src.ql, 0, OFF_QL);
+      PP_GLDS(Qk, src.qh, 0, OFF_QH);
+      PP_GLDS(Pk, src.ph, 0, OFF_PH);
+      PP_GLDS(Pk, src.pl, kp, PPB + OFF_PL);
+      PP_GLDS(Qk, src.ql, kq, PPB + OFF_QL);
     }
 #ifdef PP_STAMP
     stp[2] = __builtin_amdgcn_s_memtime();
 #endif
-    if (full) pp_epilogue<true>(g, accL, accH, ib, jb, lane, swin);
-    else pp_epilogue<false>(g, accL, accH, ib, jb, lane, swin);
+    if (OUT == 0) {
+      if (full) pp_epilogue<true>(g, accL, accH, ib, jb, lane, swin);
+      else pp_epilogue<false>(g, accL, accH, ib, jb, lane, swin);
+    } else {
+      const bool atomic = g.accumulate || splits > 1;
+      if (full) { pp_epi_f32_half<true>(g, accL, ib, jb, lane, swin, atomic); pp_epi_f32_half<true>(g, accH, ib + 64, jb, lane, swin, atomic); }
+      else { pp_epi_f32_half<false>(g, accL, ib, jb, lane, swin, atomic); pp_epi_f32_half<false>(g, accH, ib + 64, jb, lane, swin, atomic); }
+      if (do_psum) {                              // lanes l, l+16, l+32, l+48 hold the four k quarters of row l
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          float v = ps[b];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          const int i = ib + b * 16 + lane;
+          if (lane < 16 && i < g.I) atomicAdd(g.psum + i, v);
+        }
+      }
+    }
 #ifdef PP_STAMP
     stp[3] = __builtin_amdgcn_s_memtime();
     PP_WAIT(0);
@@ -316,34 +455,69 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
     ++stn;
 #endif
     if (!more) break;
-    PP_WAIT(0);                                   // the six units (and this tile's stores: one counter) have retired
+    PP_WAIT(0);                                   // the six units (and this item's stores: one counter) have retired
   }
 }
 
-// bf16 in / bf16 out, both operands K-contiguous, K a multiple of 64 and >= 128, 32-bit operand offsets, J % 8 == 0
+// bf16 operands, K a multiple of 64 with >= 2 K tiles per workgroup item, 32-bit operand offsets, 16-byte rows.
+// bf16 output with the fused epilogue (no L0 gates, not aux AND residual), or the bare f32 weight-gradient form.
 bool evlm_gemm_pp256_eligible(const GemmP& g, int pt, int qt) {
-#ifndef PP_STAMP
+  if (g.K % 64 != 0 || g.K < 128) return false;
+  if ((int64_t)(pt ? g.K : g.I) * g.ldp >= (1ll << 31) || (int64_t)(qt ? g.K : g.J) * g.ldq >= (1ll << 31)) return false;
+  if (g.c_f32) {
+    // measured (tools/gemm_pp256.py): with one workgroup per CU the f32 atomics of a split reduction (1.3 TB/s chip-wide)
+    // are fully exposed, so weight gradients stay on the 128x128 kernels unless asked for
+    static const bool wgrad = getenv("EVLM_PP256_WGRAD") != nullptr;
+    if (!wgrad) return false;
+    const bool bare = !g.bias && !g.gate && !g.preact && !g.aux && !g.residual && g.act == EVLM_ACT_NONE && g.dact == EVLM_ACT_NONE;
+    return bare && pt && qt && g.J % 4 == 0 && g.ldc % 4 == 0;
+#ifdef PP_STAMP
+  }
+#else
+  }
   if (g.psum) return false;
 #endif
-  if (pt || qt || g.c_f32 || g.accumulate || g.gate) return false;
-  if (g.dact != EVLM_ACT_NONE && g.residual) return false;
-  if (g.K % 64 != 0 || g.K < 128 || g.J % 8 != 0 || g.ldc % 8 != 0) return false;
+  if (pt || g.accumulate || g.gate) return false;
+  if (g.dact != EVLM_ACT_NONE && (g.residual || qt)) return false;   // (the activation-backward dX runs faster on 128x128)
+  if (g.J % 8 != 0 || g.ldc % 8 != 0) return false;
   if ((g.preact || g.aux || g.residual) && g.ldx % 8 != 0) return false;
-  if ((int64_t)g.I * g.ldp >= (1ll << 31) || (int64_t)g.J * g.ldq >= (1ll << 31)) return false;
   return true;
 }
 
-int evlm_gemm_pp256_launch(GemmP& g, hipStream_t stream) {
-  static bool attr_set = false;
+// number of K splits the launch below will use (the caller zero-fills C when it is > 1 and C is not accumulated into)
+int evlm_gemm_pp256_splits(const GemmP& g) {
+  if (!g.c_f32) return 1;
+  const int tiles = ceil_div(g.I, 256) * ceil_div(g.J, 256), nt = g.K / 64;
+  if (tiles >= 200 || nt < 8) return 1;
+  int splits = imin(ceil_div(256, tiles), nt / 4);           // >= 4 K tiles per item
+  if (splits < 1) splits = 1;
+  int kps = ceil_div(nt, splits);
+  splits = ceil_div(nt, kps);
+  while (splits > 1 && nt - (splits - 1) * kps < 2) { ++kps; splits = ceil_div(nt, kps); }   // last item keeps >= 2 K tiles
+  return splits;
+}
+
+int evlm_gemm_pp256_launch(GemmP& g, int pt, int qt, hipStream_t stream) {
   const int lds = 2 * PPB + 8 * 4096;
-  if (!attr_set) {     // 160 KiB of dynamic LDS needs the opt-in
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp256_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return evlm_set_error("evlm_gemm: cannot reserve 160 KiB LDS: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-  g.tiles_i = ceil_div(g.I, 256); g.tiles_j = ceil_div(g.J, 256); g.kt_per_split = 0; g.bare_f32 = 0;
-  const int tiles = g.tiles_i * g.tiles_j;
-  hipLaunchKernelGGL(gemm_bf16_pp256_kernel, dim3(imin(tiles, 256)), dim3(512), lds, stream, g);
+  g.tiles_i = ceil_div(g.I, 256); g.tiles_j = ceil_div(g.J, 256); g.bare_f32 = g.c_f32;
+  const int tiles = g.tiles_i * g.tiles_j, nt = g.K / 64;
+  const int splits = evlm_gemm_pp256_splits(g);
+  g.kt_per_split = ceil_div(nt, splits);
+  const dim3 grid(imin((int64_t)tiles * ceil_div(nt, g.kt_per_split), 256)), block(512);
+#define PP_LAUNCH(PT_, QT_, OUT_)                                                                             \
+  do {                                                                                                        \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set) {     /* 160 KiB of dynamic LDS needs the opt-in */                                        \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp256_kernel<PT_, QT_, OUT_>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);                    \
+      if (e != hipSuccess) return evlm_set_error("evlm_gemm: cannot reserve 160 KiB LDS: %s", hipGetErrorString(e)); \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL((gemm_bf16_pp256_kernel<PT_, QT_, OUT_>), grid, block, lds, stream, g);                \
+  } while (0)
+  if (g.c_f32) PP_LAUNCH(true, true, 1);
+  else if (qt) PP_LAUNCH(false, true, 0);
+  else PP_LAUNCH(false, false, 0);
+#undef PP_LAUNCH
   return 0;
 }

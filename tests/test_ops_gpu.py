@@ -453,3 +453,78 @@ def test_cross_attention_shared_kv_index(dtype):
     assert rel_err(P.float(), Pr) < t and rel_err(O.float(), Or) < t * 2
     assert rel_err(q.grad.float(), qr.grad) < t * 4
     assert rel_err(kv.grad.float(), kvr.grad) < t * 4
+
+
+def _pp256_case(o, L, g, I, J, K, qt=0, bias=False, res=False, act=0, dact=0):
+    dtype = torch.bfloat16
+    Pm = rnd((I, K), dtype, g, 0.5)
+    Qm = rnd((K, J) if qt else (J, K), dtype, g, 0.1)
+    Cm = torch.full((I, J), 7.0, dtype=dtype, device=DEV)
+    kw = {}
+    b = r = h = aux = None
+    if bias:
+        b = rnd((J,), torch.float32, g); kw["bias"] = b
+    if res:
+        r = rnd((I, J), dtype, g); kw.update(residual=r, ldx=J)
+    if act:
+        h = torch.full((I, J), 3.0, dtype=dtype, device=DEV); kw.update(act=act, preact=h, ldx=J)
+    if dact:
+        aux = rnd((I, J), dtype, g); kw.update(dact=dact, aux=aux, ldx=J)
+    o._gemm(L.dt(dtype), Pm, Qm, Cm, I, J, K, Pm.stride(0), Qm.stride(0), J, q_trans=qt, **kw)
+    ref = Pm.float() @ (Qm.float() if qt else Qm.float().t())
+    if bias:
+        ref = ref + b
+    pre = ref
+    if act == L.ACT_GELU:
+        ref = torch.nn.functional.gelu(ref)
+    if act == L.ACT_QUICK_GELU:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    if dact == L.ACT_QUICK_GELU:
+        x = aux.float(); s = torch.sigmoid(1.702 * x); ref = ref * (s + 1.702 * x * s * (1 - s))
+    if res:
+        ref = ref + r.float()
+    assert rel_err(Cm.float(), ref) < tol(dtype), (I, J, K, qt, bias, res, act, dact)
+    if act:
+        assert rel_err(h.float(), pre) < tol(dtype), ("preact", I, J, K)
+
+
+def test_gemm_pp256_persistent_tiles_and_epilogues():
+    """shapes routed to the 256x256 ping-pong kernel: several tiles per workgroup (persistent loop + next-tile prefetch),
+    ragged last tiles in both dimensions, odd and minimal K-tile counts, every fused epilogue it supports, and the
+    reduction-major Q operand (data gradients, transposing LDS reads)"""
+    o = ops()
+    from efficientvlm_amd import _lib as L
+    g = torch.Generator().manual_seed(47)
+    _pp256_case(o, L, g, 4096 + 40, 4096 + 8, 192, bias=True)                    # 289 tiles: 2 per workgroup, ragged edges
+    _pp256_case(o, L, g, 5120, 3072, 128, bias=True, res=True)                   # 240 tiles, minimal K (2 K tiles)
+    _pp256_case(o, L, g, 6144, 2560, 320, bias=True, act=L.ACT_QUICK_GELU)       # pre-activation second output, odd K tiles
+    _pp256_case(o, L, g, 4100, 4096, 256, bias=True, act=L.ACT_GELU)
+    _pp256_case(o, L, g, 4096, 4096, 256, dact=L.ACT_QUICK_GELU)
+    _pp256_case(o, L, g, 12608, 768, 768, bias=True, res=True)                   # the ViT out-projection shape (150 tiles)
+    _pp256_case(o, L, g, 4096 + 24, 4096, 192, qt=1)                             # dX = dY W, W reduction-major
+    _pp256_case(o, L, g, 12608, 768, 2304, qt=1)
+
+
+def test_gemm_pp256_weight_gradient_variant_subprocess():
+    """the f32 / split-K / bias-gradient form of the 256x256 kernel is off by default (EVLM_PP256_WGRAD): exercise it in a
+    child process against torch"""
+    import os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from efficientvlm_amd import ops, _lib as L
+torch.manual_seed(0)
+for (I, J, K, acc) in [(768, 768, 2048, True), (520, 264, 1024, False), (3072, 768, 1600, True), (256, 256, 128, False)]:
+    P = (torch.randn((K, I), device="cuda") * 0.5).bfloat16(); Q = (torch.randn((K, J), device="cuda") * 0.5).bfloat16()
+    C = torch.full((I, J), 0.25 if acc else 9.0, dtype=torch.float32, device="cuda")
+    ps = torch.zeros(I, dtype=torch.float32, device="cuda")
+    ops._gemm(L.BF16, P, Q, C, I, J, K, I, J, J, p_trans=1, q_trans=1, c_f32=1, psum=ps, accumulate=int(acc))
+    ref = P.float().t() @ Q.float() + (0.25 if acc else 0.0)
+    e = float((C - ref).norm() / ref.norm()); ep = float((ps - P.float().sum(0)).norm() / P.float().sum(0).norm())
+    assert e < 2e-5 and ep < 2e-5, (I, J, K, acc, e, ep)
+print("PP256_WGRAD_OK")
+''' % repo
+    env = dict(os.environ, EVLM_PP256_WGRAD="1", EVLM_PP256_PCT="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PP256_WGRAD_OK" in r.stdout, r.stderr[-2000:]

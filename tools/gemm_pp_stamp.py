@@ -28,4 +28,25 @@ def run(I, J, K, res=False):
         v = v[m]
         print(f"   tile#{n} ({m.sum():3d} wgs): start@{np.median(v[:,0]-t00):7.0f} kloop {np.median(v[:,1]-v[:,0]):6.0f}  next-issue {np.median(v[:,2]-v[:,1]):5.0f}"
               f"  epilogue-issue {np.median(v[:,3]-v[:,2]):6.0f}  drain {np.median(v[:,4]-v[:,3]):6.0f}   end@ med {np.median(v[:,4]-t00):7.0f} max {np.max(v[:,4]-t00):7.0f}")
-run(12608, 2304, 768); run(12608, 3072, 768); run(12608, 768, 768, res=True); run(12608, 768, 3072, res=True); run(4096, 4096, 4096)
+def run_tt(I, J, K, acc=True):
+    dt = torch.bfloat16
+    P = (torch.randn((K, I), device=dev) * 0.5).to(dt); Q = (torch.randn((K, J), device=dev) * 0.5).to(dt)
+    C = torch.zeros((I, J), dtype=torch.float32, device=dev)
+    st = torch.zeros(256 * 4 * 6, dtype=torch.int64, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        st.zero_()
+        e0.record()
+        ops._gemm(L.BF16, P, Q, C, I, J, K, I, J, J, p_trans=1, q_trans=1, c_f32=1, psum=st, accumulate=int(acc))
+        e1.record()
+    torch.cuda.synchronize()
+    s = st.cpu().numpy().reshape(256, 4, 6).astype(np.float64)
+    print(f"TT I={I} J={J} K={K}: wall {e0.elapsed_time(e1)*1e3:.1f} us")
+    for n in range(4):
+        v = s[:, n, :]; m = v[:, 0] > 0
+        if not m.any(): break
+        v = v[m]
+        print(f"   item#{n} ({m.sum():3d} wgs): kloop {np.median(v[:,1]-v[:,0]):6.0f}  next-issue {np.median(v[:,2]-v[:,1]):5.0f}"
+              f"  epilogue-issue {np.median(v[:,3]-v[:,2]):6.0f}  drain {np.median(v[:,4]-v[:,3]):6.0f}")
+run_tt(3072, 768, 12608); run_tt(768, 768, 12608); run_tt(768, 768, 12608, acc=False)
+run(12608, 2304, 768); run(12608, 768, 768, res=True)
