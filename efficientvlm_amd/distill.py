@@ -24,15 +24,15 @@ def get_cor_teacher(teacher_reps, student_reps, is_attn=False):
 def get_kd_loss(student_reps=None, teacher_reps=None, is_attn=False, loss=None, device="cuda", is_img=False):
     """GeneralDistill.py:60-82.  `loss`/`device` are accepted for signature compatibility; the MSE is the HIP kernel.
     The reference's torch.where(att <= -1e2, 0, att) is a no-op on probabilities and is not issued."""
-    kd_loss = 0
+    pairs, weights = [], []
     for layer, (s, t) in enumerate(zip(student_reps, teacher_reps)):
         if is_attn:
-            kd_loss = kd_loss + ops.mse(s, t, weight=float(s.shape[-1]))
+            pairs.append((s, t)); weights.append(float(s.shape[-1]))
         elif is_img and layer == 6:
             continue
         else:
-            kd_loss = kd_loss + ops.mse(s, t)
-    return kd_loss
+            pairs.append((s, t)); weights.append(1.0)
+    return ops.mse_sum(pairs, weights) if pairs else 0
 
 
 def soft_cross_entropy(predicts, targets, temperature=1.0):

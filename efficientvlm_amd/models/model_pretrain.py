@@ -78,9 +78,14 @@ class XVLM(XVLMBase):
         # text layers 0..F-1 on [text_ids ; text_ids_masked]
         t = core(torch.cat([text_ids, text_ids_masked], 0), attention_mask=torch.cat([text_atts, text_atts], 0),
                  return_dict=True, mode="text", output_attentions=True, output_hidden_states=True)
-        text_embeds, mlm_text = t.last_hidden_state[:B], t.last_hidden_state[B:]
-        text_hidden_states = tuple(h[:B] for h in t.hidden_states)
-        text_attentions = tuple(a[:B] for a in t.attentions)
+        # torch.split, not slices: its backward is ONE concatenation per tensor (a slice's is zero-fill + copy + add)
+        halves = lambda tup: tuple(zip(*[torch.split(x, [B, B], 0) for x in tup]))
+        text_hidden_states, mlm_text_hidden = halves(t.hidden_states)
+        if t.hidden_states[-1] is t.last_hidden_state:
+            text_embeds, mlm_text = text_hidden_states[-1], mlm_text_hidden[-1]
+        else:
+            text_embeds, mlm_text = torch.split(t.last_hidden_state, [B, B], 0)
+        text_attentions, mlm_text_attentions = halves(t.attentions)
         with torch.no_grad():
             self.temp.clamp_(0.001, 0.5)
         image_feat, text_feat = self.get_features(image_embeds, text_embeds)
@@ -95,27 +100,27 @@ class XVLM(XVLMBase):
         f = core(encoder_embeds=txt_all, attention_mask=atts_all, encoder_hidden_states=image_embeds,
                  encoder_attention_mask=torch.index_select(image_atts, 0, img_index), encoder_batch_index=img_index,
                  return_dict=True, mode="fusion", output_attentions=True, output_hidden_states=True)
-        cut = lambda tup, lo, hi: tuple(x[lo:hi] for x in tup)
+        thirds = lambda tup: tuple(zip(*[torch.split(x, [B, 2 * B, B], 0) for x in tup]))   # pos | neg | mlm
+        f_hid, f_att, f_cross = thirds(f.hidden_states), thirds(f.attentions), thirds(f.cross_attentions)
         last = f.last_hidden_state
         itm_logits = mlp_head_forward(self.itm_head, last[:3 * B, 0, :])
         itm_labels = torch.cat([torch.ones(B, dtype=torch.long, device=dev), torch.zeros(2 * B, dtype=torch.long, device=dev)])
         loss_itm = ops.cross_entropy(itm_logits, itm_labels)
         # MLM head on the masked positions of the last quarter
         enc = self.text_encoder
-        mlm_seq = enc.gather_seq_out_by_pos(last[3 * B:], masked_pos)
+        mlm_last = f_hid[2][-1] if f.hidden_states[-1] is last else last[3 * B:]
+        mlm_seq = enc.gather_seq_out_by_pos(mlm_last, masked_pos)
         mlm_logits = enc.cls(mlm_seq)
         loss_mlm = ops.cross_entropy(mlm_logits.reshape(-1, enc.config.vocab_size), masked_ids.reshape(-1))
         nF = len(t.attentions)
         hidden_dict = {"image_hidden_states": image_hidden_states, "text_hidden_states": text_hidden_states,
-                       "itm_pos_hidden_states": cut(f.hidden_states, 0, B),
-                       "itm_neg_hidden_states": cut(f.hidden_states, B, 3 * B),
-                       "mlm_hidden_states": tuple(h[B:] for h in t.hidden_states[:nF]) + cut(f.hidden_states, 3 * B, 4 * B)}
+                       "itm_pos_hidden_states": f_hid[0], "itm_neg_hidden_states": f_hid[1],
+                       "mlm_hidden_states": tuple(mlm_text_hidden[:nF]) + f_hid[2]}
         attention_dict = {"image_attentions": image_attentions, "text_attentions": text_attentions,
-                          "itm_pos_attentions": cut(f.attentions, 0, B), "itm_neg_attentions": cut(f.attentions, B, 3 * B),
-                          "mlm_attentions": tuple(a[B:] for a in t.attentions) + cut(f.attentions, 3 * B, 4 * B)}
-        cross_attention_dict = {"itm_pos_cross_attentions": cut(f.cross_attentions, 0, B),
-                                "itm_neg_cross_attentions": cut(f.cross_attentions, B, 3 * B),
-                                "mlm_cross_attentions": cut(f.cross_attentions, 3 * B, 4 * B)}
+                          "itm_pos_attentions": f_att[0], "itm_neg_attentions": f_att[1],
+                          "mlm_attentions": tuple(mlm_text_attentions) + f_att[2]}
+        cross_attention_dict = {"itm_pos_cross_attentions": f_cross[0], "itm_neg_cross_attentions": f_cross[1],
+                                "mlm_cross_attentions": f_cross[2]}
         logits_dict = {"itm_head_logits": itm_logits, "mlm_logits": mlm_logits}
         loss = {"loss_itc": loss_itc, "loss_itm": loss_itm, "loss_mlm": loss_mlm}
         return {"loss": loss, "hidden_dict": hidden_dict, "attention_dict": attention_dict,

@@ -33,12 +33,54 @@ class WeightCache:
 
     def __init__(self):
         self._store = {}
+        self._slab = {}         # id(param) -> [fp32 slab, bf16 slab, offset, numel, version, weakref]
         self.epoch = 0          # bump to force a re-cast of trainable weights (e.g. before graph capture)
 
     def invalidate(self):
         self.epoch += 1
 
+    # ---- optimiser-owned parameter slabs (optim.FlatAdamW): the bf16 mirror is kept current by the AdamW kernel ----
+    def register_slab(self, p, slab32, slab16, off):
+        import weakref
+        self._slab[id(p)] = [slab32, slab16, off, p.numel(), p._version, weakref.ref(p)]
+
+    def refresh_slab(self, slab32, slab16):
+        """re-cast a whole slab (construction; or a parameter was modified outside the optimiser)"""
+        L.check(_lib().evlm_cast(L.F32, L.ptr(slab32), L.BF16, L.ptr(slab16), slab32.numel(), L.stream()), "cast")
+        for ent in self._slab.values():
+            if ent[0] is slab32:
+                pr = ent[5]()
+                if pr is not None:
+                    ent[4] = pr._version
+
+    def _from_slab(self, params, dtype):
+        ents = []
+        for p in params:
+            e = self._slab.get(id(p))
+            if e is None or e[5]() is not p or p.data_ptr() != e[0].data_ptr() + e[2] * 4:
+                return None
+            ents.append(e)
+        if dtype not in (torch.float32, torch.bfloat16) or any(e[0] is not ents[0][0] for e in ents):
+            return None
+        if dtype == torch.bfloat16:
+            for p, e in zip(params, ents):
+                if p._version != e[4]:
+                    self.refresh_slab(e[0], e[1])
+        for a, b in zip(ents[:-1], ents[1:]):            # packed operand: the members must be back to back
+            if a[2] + a[3] != b[2]:
+                return None
+        if any(p.shape[1:] != params[0].shape[1:] for p in params):
+            return None
+        slab = ents[0][1] if dtype == torch.bfloat16 else ents[0][0]
+        n = sum(e[3] for e in ents)
+        rows = sum(p.shape[0] for p in params)
+        return slab[ents[0][2]:ents[0][2] + n].view((rows,) + tuple(params[0].shape[1:]))
+
     def get(self, params, dtype):
+        if self._slab and params[0].is_cuda:
+            v = self._from_slab(params, dtype)
+            if v is not None:
+                return v
         key = (tuple(id(p) for p in params), dtype)
         vers = tuple(p._version for p in params)
         grad = any(p.requires_grad for p in params)
@@ -515,6 +557,58 @@ class _MSE(torch.autograd.Function):
 
 def mse(a, b, weight=1.0):
     return _MSE.apply(a, b.detach(), float(weight))
+
+
+class _MSESum(torch.autograd.Function):
+    """sum_i weight_i * mean((a_i - b_i)^2) in ONE scalar: the kernels accumulate into the same fp32 cell, so a KD term
+    over L layers costs L reductions and nothing else (no per-layer zero-fill, no chain of scalar adds)."""
+
+    @staticmethod
+    def forward(ctx, weights, n, *tensors):
+        out = torch.zeros((), dtype=torch.float32, device=tensors[0].device)
+        saved, meta = [], []
+        for i in range(n):
+            a, b = tensors[i], tensors[n + i]
+            L.require_cuda(a, b)
+            n_true = a.numel()
+            pa, pb = _padded_base(a), _padded_base(b)
+            if pa is not None and pb is not None and pa.shape == pb.shape:
+                ac, bc, padded = pa, pb, True
+            else:
+                ac = a if a.is_contiguous() else a.contiguous()
+                bc = b if b.is_contiguous() else b.contiguous()
+                padded = False
+            w = weights[i] * (ac.numel() / n_true)
+            L.check(_lib().evlm_mse_fwd(L.dt(ac), L.ptr(ac), L.dt(bc), L.ptr(bc), ac.numel(), w, L.ptr(out), L.stream()),
+                    "mse_fwd")
+            saved += [ac, bc]
+            meta.append((w, padded, a.shape))
+        ctx.save_for_backward(*saved)
+        ctx.meta = meta
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gc = g.to(torch.float32).contiguous()
+        grads = []
+        for i, (w, padded, shape) in enumerate(ctx.meta):
+            ac, bc = ctx.saved_tensors[2 * i], ctx.saved_tensors[2 * i + 1]
+            if not ctx.needs_input_grad[2 + i]:
+                grads.append(None)
+                continue
+            ga = torch.empty_like(ac)
+            L.check(_lib().evlm_mse_bwd(L.dt(ac), L.ptr(ac), L.dt(bc), L.ptr(bc), ac.numel(), w, L.ptr(gc), L.ptr(ga),
+                                        L.stream()), "mse_bwd")
+            grads.append(ga[..., :shape[-1]] if padded else ga.view(shape))
+        return (None, None) + tuple(grads) + (None,) * ctx.n
+
+
+def mse_sum(pairs, weights=None):
+    """sum over (a, b) pairs of weight * mse(a, b); gradient to the a's only"""
+    n = len(pairs)
+    ws = [1.0] * n if weights is None else [float(w) for w in weights]
+    return _MSESum.apply(ws, n, *[a for a, _ in pairs], *[b.detach() for _, b in pairs])
 
 
 def _rows2d(x):

@@ -19,6 +19,27 @@ NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight", "norm.bias", "norm.wei
             "norm2.bias", "norm2.weight")   # optim.py:35-43 (substring match)
 
 
+_QKV_RANK = {"q_proj": 0, "k_proj": 1, "v_proj": 2, "query": 0, "key": 1, "value": 2}
+
+
+def _pack_order(named):
+    """forward (registration) order, except that the q / k / v projections of one attention module are placed in the
+    order the fused QKV / KV GEMMs pack them (CLIP registers k, v, q), so that the packed operand is ONE contiguous
+    slab range and needs no gather copy."""
+    first = {}
+    for idx, (n, _) in enumerate(named):
+        parts = n.split(".")
+        if len(parts) >= 2 and parts[-2] in _QKV_RANK:
+            first.setdefault((".".join(parts[:-2]), parts[-1]), idx)
+    def key(item):
+        idx, (n, _) = item
+        parts = n.split(".")
+        if len(parts) >= 2 and parts[-2] in _QKV_RANK:
+            return (first[(".".join(parts[:-2]), parts[-1])], _QKV_RANK[parts[-2]])
+        return (idx, 0)
+    return [it for _, it in sorted(enumerate(named), key=key)]
+
+
 class FlatAdamW:
     def __init__(self, model, lr=1e-4, weight_decay=0.01, lr_mult=1.0, betas=(0.9, 0.98), eps=1e-8, max_grad_norm=1.0,
                  late_prefix="vision_encoder."):
@@ -29,7 +50,7 @@ class FlatAdamW:
                   dict(weight_decay=weight_decay, lr=lr * lr_mult, params=[], names=[]),
                   dict(weight_decay=0.0, lr=lr * lr_mult, params=[], names=[])]
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
-        for n, p in reversed(named):          # reverse forward order ~ the order gradients become ready in backward
+        for n, p in _pack_order(named):       # forward order; q/k/v of one attention block adjacent in packing order
             nd = any(s in n for s in NO_DECAY)
             gi = (3 if n in large else 1) if nd else (2 if n in large else 0)
             groups[gi]["params"].append(p)
@@ -40,24 +61,35 @@ class FlatAdamW:
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.hyper = torch.ones(3, dtype=torch.float32, device=dev)       # {lr multiplier, bias_c1, bias_c2}
         self._hyper_host = torch.ones(3, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.ones(3)
+        lowp = dev.type == "cuda"
         for g in self.groups:
-            n = sum((p.numel() + 3) // 4 * 4 for p in g["params"])          # 16-byte aligned segments
+            n = sum((p.numel() + 7) // 8 * 8 for p in g["params"])          # 32-byte (fp32) / 16-byte (bf16) aligned segments
             g["p"] = torch.zeros(n, dtype=torch.float32, device=dev)
             g["g"] = torch.zeros(n, dtype=torch.float32, device=dev)
             g["m"] = torch.zeros(n, dtype=torch.float32, device=dev)
             g["v"] = torch.zeros(n, dtype=torch.float32, device=dev)
+            # bf16 mirror of the parameter slab, refreshed by the AdamW kernel itself: the compute-dtype weight copies the
+            # GEMMs read are views into it (ops.CACHE), so no per-tensor cast launches remain in the step
+            g["pb"] = torch.zeros(n, dtype=torch.bfloat16, device=dev) if lowp else None
             off = 0
-            g["late_from"] = None      # slab offset where the parameters whose gradients arrive LAST in backward start
+            late = []                  # [lo, hi) slab ranges of the parameters whose gradients arrive LAST in backward
             for p, nme in zip(g["params"], g["names"]):
                 k = p.numel()
-                if g["late_from"] is None and nme.startswith(late_prefix):
-                    g["late_from"] = off
+                seg = (k + 7) // 8 * 8
+                if nme.startswith(late_prefix):
+                    if late and late[-1][1] == off:
+                        late[-1][1] = off + seg
+                    else:
+                        late.append([off, off + seg])
                 g["p"][off:off + k].copy_(p.data.reshape(-1))
                 p.data = g["p"][off:off + k].view(p.shape)
                 p.grad = g["g"][off:off + k].view(p.shape)
-                off += (k + 3) // 4 * 4
-            if g["late_from"] is None:
-                g["late_from"] = n
+                if lowp:
+                    ops.CACHE.register_slab(p, g["p"], g["pb"], off)
+                off += seg
+            g["late"] = late
+            if lowp:
+                ops.CACHE.refresh_slab(g["p"], g["pb"])
         ops.CACHE.invalidate()
 
     @property
@@ -65,11 +97,18 @@ class FlatAdamW:
         return [g["g"] for g in self.groups]
 
     def grad_segments(self):
-        """(early, late) lists of slab views: `early` = heads + text/fusion encoder (their gradients are complete once
-        backward reaches the image encoder), `late` = the image encoder.  The slabs are laid out in reverse forward
-        order, so each is one contiguous range per group."""
-        early = [g["g"][:g["late_from"]] for g in self.groups if g["late_from"] > 0]
-        late = [g["g"][g["late_from"]:] for g in self.groups if g["late_from"] < g["g"].numel()]
+        """(early, late) lists of slab views: `late` = the image encoder (its gradients are produced last in backward),
+        `early` = everything else (text / fusion encoder, heads): complete once backward reaches the image encoder."""
+        early, late = [], []
+        for g in self.groups:
+            pos, n = 0, g["g"].numel()
+            for lo, hi in g["late"]:
+                if lo > pos:
+                    early.append(g["g"][pos:lo])
+                late.append(g["g"][lo:hi])
+                pos = hi
+            if pos < n:
+                early.append(g["g"][pos:n])
         return early, late
 
     def zero_grad(self):
@@ -95,7 +134,7 @@ class FlatAdamW:
                 if p.grad is not None and p.grad.data_ptr() != g["g"].data_ptr() + off * 4:
                     g["g"][off:off + k].copy_(p.grad.reshape(-1))
                     p.grad = g["g"][off:off + k].view(p.shape)
-                off += (k + 3) // 4 * 4
+                off += (k + 7) // 8 * 8
         self.gnorm_sq.zero_()
         for g in self.groups:
             L.check(lib.evlm_sumsq(L.ptr(g["g"]), g["g"].numel(), L.ptr(self.gnorm_sq), L.stream()), "sumsq")
@@ -103,7 +142,7 @@ class FlatAdamW:
         for g in self.groups:
             L.check(lib.evlm_adamw_step(L.ptr(g["p"]), L.ptr(g["g"]), L.ptr(g["m"]), L.ptr(g["v"]), g["p"].numel(),
                                         g["lr"], b1, b2, self.eps, g["weight_decay"], 1.0, 1.0, L.ptr(self.gnorm_sq),
-                                        float(self.max_grad_norm or 0.0), None, L.ptr(self.hyper), L.stream()), "adamw")
+                                        float(self.max_grad_norm or 0.0), L.ptr(g["pb"]), L.ptr(self.hyper), L.stream()), "adamw")
         ops.CACHE.invalidate()
 
     def grad_norm(self):
