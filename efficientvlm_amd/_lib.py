@@ -50,7 +50,8 @@ SIGNATURES = {
     "evlm_gemm": [C.POINTER(GemmArgs), _vp],
     "evlm_colsum": [_i, _vp, _i, _i, _i, _vp, _vp],
     "evlm_layernorm_fwd": [_i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp],
-    "evlm_layernorm_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "evlm_layernorm_bwd_blocks": [_i],
+    "evlm_layernorm_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "evlm_attention_fwd": [C.POINTER(AttnFwdArgs), _vp],
     "evlm_attention_bwd": [C.POINTER(AttnBwdArgs), _vp],
     "evlm_mse_fwd": [_i, _vp, _i, _vp, _i64, _f, _vp, _vp],

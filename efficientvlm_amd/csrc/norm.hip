@@ -55,7 +55,8 @@ template <typename T, int DCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, int rows, int d, T* __restrict__ dx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ partials) {
   extern __shared__ float sred[];   // [4 waves][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
@@ -67,39 +68,55 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int e = 0; e < 8; ++e) { pg[u][e] = 0.f; pb[u][e] = 0.f; gm[u][e] = 0.f; }
     if (c < nchunk) load8<float>(gamma + c * 8, gm[u]);
   }
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-    const T* xr = x + (size_t)row * d;
-    const T* dr = dy + (size_t)row * d;
-    const float mu = mean[row], rs = rstd[row];
-    float xh[DCH][8], gd[DCH][8];
-    float s1 = 0.f, s2 = 0.f;
+  // TWO rows per wave per trip: both rows' loads are in flight before either is reduced (one wave owns only a few rows,
+  // so without this every trip is a bare HBM round trip)
+  for (int row0 = (blockIdx.x * 4 + wave) * 2; row0 < rows; row0 += gridDim.x * 8) {
+    const int nr = min(2, rows - row0);
+    float xh[2][DCH][8], gd[2][DCH][8];
+    float mu[2], rs[2];
 #pragma unroll
-    for (int u = 0; u < DCH; ++u) {
-      const int c = lane + 64 * u;
-      if (c < nchunk) {
-        float xv[8], dv[8];
-        load8<T>(xr + c * 8, xv);
-        load8<T>(dr + c * 8, dv);
+    for (int r = 0; r < 2; ++r) {
+      const int row = min(row0 + r, rows - 1);
+      mu[r] = mean[row]; rs[r] = rstd[row];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          xh[u][e] = (xv[e] - mu) * rs;
-          gd[u][e] = gm[u][e] * dv[e];
-          s1 += gd[u][e]; s2 += gd[u][e] * xh[u][e];
-          pg[u][e] += dv[e] * xh[u][e]; pb[u][e] += dv[e];
+      for (int u = 0; u < DCH; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nchunk) {
+          load8<T>(x + (size_t)row * d + c * 8, xh[r][u]);
+          load8<T>(dy + (size_t)row * d + c * 8, gd[r][u]);
         }
       }
     }
-    s1 = wave_sum(s1) / (float)d;
-    s2 = wave_sum(s2) / (float)d;
-    T* dxr = dx + (size_t)row * d;
 #pragma unroll
-    for (int u = 0; u < DCH; ++u) {
-      const int c = lane + 64 * u;
-      if (c < nchunk) {
-        float o[8];
+    for (int r = 0; r < 2; ++r) {
+      if (r >= nr) break;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rs * (gd[u][e] - s1 - xh[u][e] * s2);
-        store8<T>(dxr + c * 8, o);
+      for (int u = 0; u < DCH; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nchunk) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xv = (xh[r][u][e] - mu[r]) * rs[r], dv = gd[r][u][e];
+            xh[r][u][e] = xv;
+            gd[r][u][e] = gm[u][e] * dv;
+            s1 += gd[r][u][e]; s2 += gd[r][u][e] * xv;
+            pg[u][e] += dv * xv; pb[u][e] += dv;
+          }
+        }
+      }
+      s1 = wave_sum(s1) / (float)d;
+      s2 = wave_sum(s2) / (float)d;
+      T* dxr = dx + (size_t)(row0 + r) * d;
+#pragma unroll
+      for (int u = 0; u < DCH; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nchunk) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = rs[r] * (gd[r][u][e] - s1 - xh[r][u][e] * s2);
+          store8<T>(dxr + c * 8, o);
+        }
       }
     }
   }
@@ -113,10 +130,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
   }
   __syncthreads();
+  // every block adding into the same 2*d floats is the contended-atomic regime (an order of magnitude below the plain
+  // store rate): with a workspace the block's column sums leave as plain stores and ln_bwd_reduce_kernel finishes them
   for (int i = threadIdx.x; i < 2 * d; i += 256) {
     const float v = sred[i] + sred[2 * d + i] + sred[4 * d + i] + sred[6 * d + i];
-    atomicAdd((i < d ? dgamma + i : dbeta + (i - d)), v);
+    if (partials) partials[(size_t)blockIdx.x * 2 * d + i] = v;
+    else atomicAdd((i < d ? dgamma + i : dbeta + (i - d)), v);
   }
+}
+
+// column sums of partials [nblk][2*d] -> dgamma / dbeta (accumulated).  grid (ceil(2d/256), LN_RED_SLICES): each thread sums
+// its slice of the block rows for one column, then one atomic per column per slice.
+#define LN_RED_SLICES 16
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partials, int nblk, int d,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * d) return;
+  const int per = (nblk + LN_RED_SLICES - 1) / LN_RED_SLICES;
+  const int r0 = blockIdx.y * per, r1 = min(nblk, r0 + per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    a0 += partials[(size_t)r * 2 * d + i]; a1 += partials[(size_t)(r + 1) * 2 * d + i];
+    a2 += partials[(size_t)(r + 2) * 2 * d + i]; a3 += partials[(size_t)(r + 3) * 2 * d + i];
+  }
+  for (; r < r1; ++r) a0 += partials[(size_t)r * 2 * d + i];
+  if (r1 > r0) atomicAdd((i < d ? dgamma + i : dbeta + (i - d)), (a0 + a1) + (a2 + a3));
 }
 
 extern "C" int evlm_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, float eps,
@@ -131,19 +170,26 @@ extern "C" int evlm_layernorm_fwd(int dtype, const void* x, const float* gamma, 
   return 0;
 }
 
+static int ln_bwd_blocks(int rows) { return imin(ceil_div(rows, 8), 768); }   // 12 resident waves per CU (150 VGPRs)
+
+extern "C" int evlm_layernorm_bwd_blocks(int rows) { return ln_bwd_blocks(rows); }
+
 extern "C" int evlm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
                                   const float* rstd, int rows, int d, void* dx, float* dgamma, float* dbeta,
-                                  void* stream_) {
+                                  float* partials, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "evlm_layernorm_bwd: bad args");
   EVLM_REQUIRE(d % 8 == 0 && d <= 2048, "evlm_layernorm_bwd: d=%d unsupported (multiple of 8, <= 2048)", d);
-  const int nblk = imin(ceil_div(rows, 8), 1024);      // >= 2 rows per wave: amortises the per-block column atomics
+  const int nblk = ln_bwd_blocks(rows);                // row pairs per wave
   dim3 grid(nblk), block(256);
   const size_t lds = 8 * (size_t)d * sizeof(float);
-#define LN_BWD(DCH_) hipLaunchKernelGGL((ln_bwd_kernel<T, DCH_>), grid, block, lds, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, rows, d, (T*)dx, dgamma, dbeta)
+#define LN_BWD(DCH_) hipLaunchKernelGGL((ln_bwd_kernel<T, DCH_>), grid, block, lds, stream, (const T*)dy, (const T*)x, gamma, mean, rstd, rows, d, (T*)dx, dgamma, dbeta, partials)
   EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_bwd",
     if (d <= 512) LN_BWD(1); else if (d <= 1024) LN_BWD(2); else if (d <= 1536) LN_BWD(3); else LN_BWD(4);)
 #undef LN_BWD
+  if (partials)
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(2 * d, 256), LN_RED_SLICES), dim3(256), 0, stream, partials, nblk, d,
+                       dgamma, dbeta);
   EVLM_LAUNCH_CHECK("evlm_layernorm_bwd");
   return 0;
 }

@@ -402,8 +402,9 @@ class _LayerNorm(torch.autograd.Function):
         inplace = _inplace(pg) and _inplace(pb)
         dg = pg.grad if inplace else torch.zeros(d, dtype=torch.float32, device=xc.device)
         db = pb.grad if inplace else torch.zeros(d, dtype=torch.float32, device=xc.device)
+        ws = torch.empty(_lib().evlm_layernorm_bwd_blocks(rows) * 2 * d, dtype=torch.float32, device=xc.device)
         L.check(_lib().evlm_layernorm_bwd(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd),
-                                          rows, d, L.ptr(dx), L.ptr(dg), L.ptr(db), L.stream()), "layernorm_bwd")
+                                          rows, d, L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(ws), L.stream()), "layernorm_bwd")
         return (dx, None, None, None) if inplace else (dx, dg, db, None)
 
 
@@ -439,6 +440,7 @@ class _Attention(torch.autograd.Function):
                           kv_index=L.ptr(kv_index), mask=L.ptr(m32), head_gate=L.ptr(g32), scale=scale, O=L.ptr(O),
                           P=L.ptr(Pbuf))
         L.check(_lib().evlm_attention_fwd(C.byref(a), L.stream()), "attention_fwd")
+        ctx.set_materialize_grads(False)        # an unused probability map must not cost a zero tensor in backward
         ctx.save_for_backward(qbuf, kvbuf, Pbuf, g32, kv_index)
         ctx.meta = (H, dh, q_off, k_off, v_off, scale, qbuf is kvbuf or qbuf.data_ptr() == kvbuf.data_ptr(),
                     gate.shape if gate is not None else None)
@@ -452,6 +454,8 @@ class _Attention(torch.autograd.Function):
         Bkv, Lk, ldk = kvbuf.shape
         dev, tdt = qbuf.device, qbuf.dtype
         es = qbuf.element_size()
+        if dO is None:
+            dO = torch.zeros((B, Lq, H * dh), dtype=tdt, device=dev)
         dOc = dO if dO.is_contiguous() else dO.contiguous()
         Lkp = P.shape[-1]
         dPc = None

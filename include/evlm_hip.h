@@ -88,9 +88,13 @@ int evlm_colsum(int dtype, const void* X, int I, int J, int ldx, float* out, voi
  * ---------------------------------------------------------------------------------------------- */
 int evlm_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, float eps,
                        int rows, int d, void* y, float* mean, float* rstd, void* stream);
-/* dx = LN backward; dgamma/dbeta [d] f32 are ACCUMULATED (caller zeroes). */
+/* dx = LN backward; dgamma/dbeta [d] f32 are ACCUMULATED (caller zeroes).  partials: optional f32 workspace of
+ * evlm_layernorm_bwd_blocks(rows) * 2 * d floats (uninitialised is fine): the per-workgroup column sums go through it
+ * with plain stores + a small second kernel instead of every workgroup's atomics landing on the same 2*d floats. */
+int evlm_layernorm_bwd_blocks(int rows);
 int evlm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
-                       const float* rstd, int rows, int d, void* dx, float* dgamma, float* dbeta, void* stream);
+                       const float* rstd, int rows, int d, void* dx, float* dgamma, float* dbeta, float* partials,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-head attention core with the probability map as an OUTPUT (the KD losses consume it).
