@@ -8,8 +8,9 @@ X-VLM-base teacher forward under no_grad, every KD loss, gradient reduction, glo
         bench.py --gpus N --steps K --warmup W                  # N>1: one rank per GPU over RCCL
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     - the dominant kernel (bf16 MFMA GEMM, forward NT variant): algorithmic FLOPs per launch / its average
-                 launch duration, timed live with HIP events on the launch stream during one extra instrumented step;
+  roofline     - the dominant kernel (the bf16 MFMA GEMM kernel with the largest share of the step): algorithmic FLOPs per
+                 launch / its average launch duration, timed live with HIP events on the launch stream during one extra
+                 instrumented step;
   cpu_baseline - oracle/ (the CPU restatement of the reference) timed on this box's host cores on a bounded sample.
 """
 import argparse
@@ -105,7 +106,10 @@ def cpu_baseline(timeout_s=150):
 
 
 def roofline_leg(trainer, batch):
-    """one extra eager step with every GEMM launch bracketed by HIP events on its launch stream"""
+    """one extra eager step with every GEMM launch bracketed by HIP events on its launch stream; launches are attributed to
+    the kernel that served them (evlm_gemm_last_kernel).  `traffic` = HBM bytes per launch of the dominant kernel from the
+    rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+    KiB -> bytes), null when that summary is absent."""
     from efficientvlm_amd import ops
     from efficientvlm_amd._lib import BF16
     ops.GEMM_PROFILE = []
@@ -114,25 +118,32 @@ def roofline_leg(trainer, batch):
     torch.cuda.synchronize()
     recs, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     groups = {}
-    for dtype, pt, qt, I, J, K, e0, e1 in recs:
+    for dtype, pt, qt, I, J, K, e0, e1, kern in recs:
         if dtype != BF16:
             continue
-        g = groups.setdefault((pt, qt), [0, 0.0, 0.0])
+        g = groups.setdefault(kern, [0, 0.0, 0.0])
         g[0] += 1
         g[1] += 2.0 * I * J * K
         g[2] += e0.elapsed_time(e1) * 1e-3
-    names = {(0, 0): "gemm_bf16_kernel<false,false> (Y = X W^T, forward)",
-             (0, 1): "gemm_bf16_kernel<false,true> (dX = dY W)",
-             (1, 1): "gemm_bf16_kernel<true,true> (dW = dY^T X)", (1, 0): "gemm_bf16_kernel<true,false>"}
     dom = max(groups, key=lambda k: groups[k][2])
     n, fl, tm = groups[dom]
     allfl, alltm = sum(g[1] for g in groups.values()), sum(g[2] for g in groups.values())
     ach = fl / tm / 1e12
-    return {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": n,
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        ent = next((v for k, v in pmc.get("kernels", {}).items() if dom.split("<")[0] in k and
+                    dom.split("<")[1].replace(" ", "") in k.replace(" ", "")), None)
+        if ent:
+            traffic = ent["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError, IndexError):
+        pass
+    return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches": n,
             "avg_launch_us": round(tm / n * 1e6, 2), "flop_per_launch": round(fl / n / 1e9, 3),
-            "all_gemm_variants": {names[k]: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
-                                             "time_ms": round(v[2] * 1e3, 3)} for k, v in groups.items()},
+            "all_gemm_kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
+                                     "time_ms": round(v[2] * 1e3, 3)} for k, v in groups.items()},
             "all_gemm_tflops": round(allfl / alltm / 1e12, 1), "gemm_time_ms_per_step": round(alltm * 1e3, 2)}
 
 

@@ -97,6 +97,7 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.evlm_last_error.restype = C.c_char_p
     lib.evlm_abi_version.restype = _i
+    lib.evlm_gemm_last_kernel.restype = C.c_char_p
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library drift
         fn.argtypes = argtypes

@@ -795,6 +795,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int I, int J, i
 // =============================================================================================
 // C ABI
 // =============================================================================================
+// which kernel served the calling thread's last evlm_gemm (profiling aid: bench.py attributes launch times to kernels)
+static thread_local const char* g_last_kernel = "";
+extern "C" const char* evlm_gemm_last_kernel(void) { return g_last_kernel; }
+
 extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(a && a->P && a->Q && a->C, "evlm_gemm: null operand");
@@ -834,6 +838,8 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
           if (me != hipSuccess) return evlm_set_error("evlm_gemm: memset failed: %s", hipGetErrorString(me));
         }
         if (evlm_gemm_pp256_launch(g, pt, qt, stream)) return -1;
+        g_last_kernel = g.c_f32 ? "gemm_bf16_pp256_kernel<true,true,1>" : (qt ? "gemm_bf16_pp256_kernel<false,true,0>"
+                                                                           : "gemm_bf16_pp256_kernel<false,false,0>");
         EVLM_LAUNCH_CHECK("evlm_gemm");
         return 0;
       }
@@ -848,6 +854,7 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
       else if (pt && qt) LAUNCH_GEN(true, true);
       else LAUNCH_GEN(true, false);
 #undef LAUNCH_GEN
+      g_last_kernel = "gemm_bf16_generic_kernel";
     } else {
       // tile choice: 128x128 unless that leaves most of the 256 CUs (x2 resident workgroups) without work
       const int t128 = ceil_div(g.I, 128) * ceil_div(g.J, 128);
@@ -899,6 +906,8 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
       else if (pt && qt) LAUNCH_FAST(true, true);
       else LAUNCH_FAST(true, false);
 #undef LAUNCH_FAST
+      g_last_kernel = s3 ? "gemm_bf16_s3_kernel" : (persist ? "gemm_bf16_persist_kernel<2>"
+                                                    : (mt == 4 ? "gemm_bf16_kernel<4>" : "gemm_bf16_kernel<2>"));
     }
   } else if (a->dtype == EVLM_F32) {
     g.tiles_i = ceil_div(g.I, FT); g.tiles_j = ceil_div(g.J, FT); g.kt_per_split = 0; g.bare_f32 = 0;
@@ -909,6 +918,7 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
     else if (pt && qt) LAUNCH_F32(true, true);
     else LAUNCH_F32(true, false);
 #undef LAUNCH_F32
+    g_last_kernel = "gemm_f32_kernel";
   } else {
     return evlm_set_error("evlm_gemm: bad dtype %d", a->dtype);
   }

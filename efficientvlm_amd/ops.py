@@ -150,7 +150,7 @@ def _gemm(dtype, P, Q, Cm, I, J, K, ldp, ldq, ldc, p_trans=0, q_trans=0, bias=No
     e0.record()
     L.check(_lib().evlm_gemm(C.byref(a), L.stream()), "gemm")
     e1.record()
-    GEMM_PROFILE.append((dtype, p_trans, q_trans, I, J, K, e0, e1))
+    GEMM_PROFILE.append((dtype, p_trans, q_trans, I, J, K, e0, e1, _lib().evlm_gemm_last_kernel().decode()))
 
 
 def _colsum(x2d, I, J, ld, out=None, x_off=0):

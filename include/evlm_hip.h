@@ -32,6 +32,8 @@ enum { EVLM_GATE_PRE_ACT = 0, EVLM_GATE_POST_ACT = 1 };
 
 const char* evlm_last_error(void);
 int evlm_abi_version(void);
+/* name of the kernel that served the calling thread's last evlm_gemm (profiling aid; static string) */
+const char* evlm_gemm_last_kernel(void);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM with fused epilogue:   C[i,j] = epi( alpha * sum_k P(i,k) * Q(j,k) )      i<I, j<J

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round profile bundle (run on the GPU box from the repo root): default bench line, rocprofv3 kernel stats of the bench
+# command, and the two PMC passes (FETCH_SIZE / WRITE_SIZE) summarised per kernel.  Only small summaries are kept.
+set -u
+OUT=gpurun_out/r01
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python3 bench.py > $OUT/bench_default.log 2>&1
+tail -1 $OUT/bench_default.log > $OUT/bench_1gpu.json
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/kt.log 2>&1
+python3 tools/rocpd_stats.py $OUT/kt/kt_results.db 12 $OUT/kernel_stats.csv 60 > $OUT/kernel_stats.txt 2>&1
+grep -o "{\"metric.*" $OUT/kt.log > $OUT/bench_under_rocprof.json
+rm -rf $OUT/kt
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf -o pf -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $OUT/pf.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pw -o pw -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $OUT/pw.log 2>&1
+python3 tools/pmc_traffic.py $OUT/pf/pf_results.db $OUT/pw/pw_results.db $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1
+rm -rf $OUT/pf $OUT/pw
+ls -la $OUT

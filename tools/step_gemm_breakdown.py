@@ -16,11 +16,11 @@ ops.GEMM_PROFILE=[]
 tr.opt.set_schedule(0.0); tr._step_eager(batch); torch.cuda.synchronize()
 recs,ops.GEMM_PROFILE=ops.GEMM_PROFILE,None
 agg={}
-for dt,pt,qt,I,J,K,e0,e1 in recs:
-    k=(dt,pt,qt,I,J,K); a=agg.setdefault(k,[0,0.0]); a[0]+=1; a[1]+=e0.elapsed_time(e1)*1e-3
+for dt,pt,qt,I,J,K,e0,e1,kn in recs:
+    k=(dt,pt,qt,I,J,K,kn); a=agg.setdefault(k,[0,0.0]); a[0]+=1; a[1]+=e0.elapsed_time(e1)*1e-3
 tot=sum(v[1] for v in agg.values())
 print(f"total gemm time {tot*1e3:.2f} ms, {len(recs)} launches")
 for k,v in sorted(agg.items(), key=lambda kv:-kv[1][1])[:40]:
-    dt,pt,qt,I,J,K=k
+    dt,pt,qt,I,J,K,kn=k
     fl=2.0*I*J*K*v[0]
-    print(f"dt={dt} pt={pt} qt={qt} I={I:6d} J={J:6d} K={K:6d} n={v[0]:3d} time={v[1]*1e3:7.3f} ms ({v[1]/tot*100:4.1f}%) {fl/v[1]/1e12:7.1f} TF/s")
+    print(f"dt={dt} pt={pt} qt={qt} I={I:6d} J={J:6d} K={K:6d} n={v[0]:3d} time={v[1]*1e3:7.3f} ms ({v[1]/tot*100:4.1f}%) {fl/v[1]/1e12:7.1f} TF/s {kn}")
