@@ -4,8 +4,7 @@ global-norm clip + AdamW — the body of GeneralDistill.py:train (reference :286
 MI355X-first execution
   * one process per GPU; the teacher is a plain replica on every rank and never communicates;
   * the whole step is device-resident (no .item() syncs: the reference's 2B multinomial().item() calls and 11 meter
-    reads per step are gone), so it can be captured once into a hipGraph and replayed — the step is ~2k kernel launches
-    and would otherwise be host-launch-bound;
+    reads per step are gone), so it can be captured once into a hipGraph and replayed (~1.2k kernel launches);
   * gradients live in the optimiser's flat fp32 slabs, so data parallelism is a few large RCCL all-reduces over
     contiguous memory on a side stream (xGMI is point-to-point: few, large messages); the text / fusion / head part
     of the slabs is reduced from a tensor hook while the ViT backward is still running, the ViT part after it.
@@ -29,7 +28,8 @@ class GradReducer:
     Works on any backend (RCCL on GPU, gloo in the CPU tests).  `compress` = torch.bfloat16 halves the wire bytes
     (the slabs stay fp32: cast -> all-reduce -> cast back).
 
-    Overlap with backward: the slabs are laid out in reverse forward order, so `reduce_async(early)` can be launched
+    Overlap with backward: the image encoder's parameters form one range of each slab, so `reduce_async(early)` (the
+    rest: text / fusion encoder and heads, optim.FlatAdamW.grad_segments) can be launched
     from a tensor hook the moment backward crosses into the image encoder (every text / fusion / head gradient is then
     enqueued) and runs on the side stream under the ViT backward; `reduce_async(late)` + `finish()` follow after
     backward.  Few, large messages: xGMI is point-to-point, rings are per-link bound."""
