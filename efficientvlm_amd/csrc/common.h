@@ -91,6 +91,34 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
   const float s = sigmoidf_(1.702f * x);
   return s * (1.0f + 1.702f * x * (1.0f - s));
 }
+// bf16-path variants: hardware reciprocal (1 ulp) and the Abramowitz-Stegun 7.1.26 erf (|error| <= 1.5e-7, far below a
+// bf16 ulp) instead of the IEEE division and erff() - the activation runs in GEMM epilogues, where a 256x256 tile applies
+// it to 128 values per lane with nothing else to hide behind
+__device__ __forceinline__ float quick_gelu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu_grad_fast(float x) {
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+  return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+// returns erf(x / sqrt 2) and exp(-x^2 / 2) (shared by GELU and its derivative)
+__device__ __forceinline__ float erf_half_fast(float x, float& e) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  e = __expf(-ax * ax);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  return copysignf(1.0f - poly * e, x);
+}
+__device__ __forceinline__ float gelu_erf_fast(float x) { float e; return 0.5f * x * (1.0f + erf_half_fast(x, e)); }
+__device__ __forceinline__ float gelu_erf_grad_fast(float x) {
+  float e;
+  const float cdf = 0.5f * (1.0f + erf_half_fast(x, e));
+  return cdf + x * 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float act_apply_fast(int act, float x) {
+  return act == EVLM_ACT_GELU ? gelu_erf_fast(x) : (act == EVLM_ACT_QUICK_GELU ? quick_gelu_fast(x) : x);
+}
+__device__ __forceinline__ float act_grad_fast(int act, float x) {
+  return act == EVLM_ACT_GELU ? gelu_erf_grad_fast(x) : (act == EVLM_ACT_QUICK_GELU ? quick_gelu_grad_fast(x) : 1.0f);
+}
 __device__ __forceinline__ float act_apply(int act, float x) {
   return act == EVLM_ACT_GELU ? gelu_erf(x) : (act == EVLM_ACT_QUICK_GELU ? quick_gelu(x) : x);
 }

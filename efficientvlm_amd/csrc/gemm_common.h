@@ -56,6 +56,7 @@ template <typename T, int NA, int NB, bool FULL, bool LDS_OUT = false, int MT = 
 __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][NB], int ibase, int jbase, int lane,
                                               char* sC = nullptr, char* sH = nullptr, int i0 = 0, int j0 = 0) {
   const int il = lane & 15, jl = (lane >> 4) * 4;
+  constexpr bool LOWP = sizeof(T) == 2;      // bf16 path: fast activation math (common.h); the f32 parity path stays exact
 #pragma unroll
   for (int a = 0; a < NA; ++a) {
     const int j = jbase + a * 16 + jl;
@@ -94,10 +95,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][N
       if (g.act != EVLM_ACT_NONE) {
         if (g.gate_pos == EVLM_GATE_PRE_ACT) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = act_apply(g.act, v[e] * gz[e]);
+          for (int e = 0; e < 4; ++e) v[e] = LOWP ? act_apply_fast(g.act, v[e] * gz[e]) : act_apply(g.act, v[e] * gz[e]);
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = act_apply(g.act, v[e]) * gz[e];
+          for (int e = 0; e < 4; ++e) v[e] = (LOWP ? act_apply_fast(g.act, v[e]) : act_apply(g.act, v[e])) * gz[e];
         }
       } else if (g.gate) {
 #pragma unroll
@@ -105,7 +106,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][N
       }
       if (g.dact != EVLM_ACT_NONE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= act_grad(g.dact, hx[b][e]);
+        for (int e = 0; e < 4; ++e) v[e] *= LOWP ? act_grad_fast(g.dact, hx[b][e]) : act_grad(g.dact, hx[b][e]);
       }
       if (g.residual) {
 #pragma unroll

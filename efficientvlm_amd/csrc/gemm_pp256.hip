@@ -243,11 +243,11 @@ __device__ __forceinline__ void pp_epi_half(const GemmP& g, f32x4 (&acc)[4][4], 
         if (MODE == 2) {
           if (g.act != EVLM_ACT_NONE) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_apply(g.act, v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = act_apply_fast(g.act, v[e]);
           }
           if (need_h) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= act_grad(g.dact, (float)xx[a][b][e]);
+            for (int e = 0; e < 4; ++e) v[e] *= act_grad_fast(g.dact, (float)xx[a][b][e]);
           }
           if (need_r) {
 #pragma unroll

@@ -194,7 +194,18 @@ def _wgrad(dtype, d2, ldd, x2, ldp, M, K, params, rows, biases=None):
                     gb.append(_colsum(d2, M, r, ldd, x_off=r0))
             r0 += r
         return gw, (gb if has_b else [None] * len(rows))
-    for i, (w, r) in enumerate(zip(params, rows)):
+    # packed members whose gradient views are back to back in the optimiser slab (q | k | v) take ONE product: a third
+    # of the launches and of the split-K atomics
+    def adjacent(t0, t1):
+        return t0.data_ptr() + t0.numel() * t0.element_size() == t1.data_ptr()
+    i = 0
+    while i < len(params):
+        j = i + 1
+        bi_in = has_b and biases[i] is not None and _inplace(biases[i])
+        while j < len(params) and adjacent(params[j - 1].grad, params[j].grad) and (
+                not has_b or (bi_in and biases[j] is not None and _inplace(biases[j]) and adjacent(biases[j - 1].grad, biases[j].grad))):
+            j += 1
+        r = sum(rows[i:j])
         b = biases[i] if has_b else None
         if b is not None and _inplace(b):
             ps, res = b.grad, None
@@ -202,10 +213,14 @@ def _wgrad(dtype, d2, ldd, x2, ldp, M, K, params, rows, biases=None):
             ps = res = torch.zeros(r, dtype=torch.float32, device=x2.device)
         else:
             ps = res = None
-        _gemm(dtype, d2, x2, w.grad, r, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1, accumulate=1, p_off=r0, psum=ps)
-        gw.append(None)
-        gb.append(res)
+        _gemm(dtype, d2, x2, params[i].grad, r, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1, accumulate=1, p_off=r0, psum=ps)
+        for k in range(i, j):
+            gw.append(None)
+            gb.append(res if k == i else None)
+        if res is not None and j - i > 1:       # (only reachable when has_b is False for the merged members)
+            raise AssertionError("merged members must have in-place bias gradients")
         r0 += r
+        i = j
     return gw, gb
 
 

@@ -405,10 +405,15 @@ def test_inplace_parameter_gradients_match_autograd():
         return dict(ws=[mk(N, K) for _ in range(3)], bs=[mk(N) for _ in range(3)], w1=mk(Fh, 3 * N), b1=mk(Fh),
                     w2=mk(K, Fh), b2=mk(K), gm=mk(K), bt=mk(K))
 
-    def run(P, inplace):
+    def run(P, inplace, slab=False):
         params = P["ws"] + P["bs"] + [P["w1"], P["b1"], P["w2"], P["b2"], P["gm"], P["bt"]]
         for p in params:
             p.grad = torch.full_like(p, 0.5) if inplace else None    # pre-existing content must be ADDED to
+        if slab:      # q | k | v gradients back to back, as in the optimiser slabs: the packed dW is ONE product
+            gw = torch.full((3 * N * K,), 0.5, device=DEV); gbv = torch.full((3 * N,), 0.5, device=DEV)
+            for i in range(3):
+                P["ws"][i].grad = gw[i * N * K:(i + 1) * N * K].view(N, K)
+                P["bs"][i].grad = gbv[i * N:(i + 1) * N]
         xi = x.clone().requires_grad_(True)
         h = o.linear_packed(xi, P["ws"], P["bs"])
         y = o.mlp(h, P["w1"], P["b1"], P["w2"], P["b2"], L.ACT_GELU, gate_pos=L.GATE_POST)
@@ -423,9 +428,11 @@ def test_inplace_parameter_gradients_match_autograd():
 
     ga, xa = run(make(), False)
     gb, xb = run(make(), True)
-    assert rel_err(xb.float(), xa.float()) < 1e-6
-    for a, b in zip(ga, gb):
+    gc, xc = run(make(), True, slab=True)
+    assert rel_err(xb.float(), xa.float()) < 1e-6 and rel_err(xc.float(), xa.float()) < 1e-6
+    for a, b, c in zip(ga, gb, gc):
         assert rel_err(b, a) < 3e-4      # the 0.5 pre-fill costs ~6e-8 absolute on gradients of ~1e-4
+        assert rel_err(c, a) < 3e-4
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
