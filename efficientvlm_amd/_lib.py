@@ -27,6 +27,11 @@ class GemmArgs(C.Structure):
                 ("alpha", _f), ("act", _i), ("gate_pos", _i), ("dact", _i), ("accumulate", _i), ("psum", _vp)]
 
 
+class WgradProblem(C.Structure):
+    _fields_ = [("P", _vp), ("Q", _vp), ("C", _vp), ("psum", _vp),
+                ("I", _i), ("J", _i), ("ldp", _i), ("ldq", _i), ("ldc", _i)]
+
+
 class AttnFwdArgs(C.Structure):
     _fields_ = [("dtype", _i), ("p_dtype", _i),
                 ("B", _i), ("H", _i), ("Lq", _i), ("Lk", _i), ("dh", _i),
@@ -50,6 +55,7 @@ SIGNATURES = {
     "evlm_gemm": [C.POINTER(GemmArgs), _vp],
     "evlm_colsum": [_i, _vp, _i, _i, _i, _vp, _vp],
     "evlm_layernorm_fwd": [_i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp],
+    "evlm_wgrad_grouped": [C.POINTER(WgradProblem), _i, _i, _vp],
     "evlm_layernorm_bwd_blocks": [_i],
     "evlm_layernorm_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "evlm_attention_fwd": [C.POINTER(AttnFwdArgs), _vp],

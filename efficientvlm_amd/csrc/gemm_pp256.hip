@@ -31,6 +31,7 @@
 // Persistent: one workgroup per CU walks tiles b, b + grid, ...; the next tile's first six units are issued before the
 // current tile's epilogue (see below), so neither the launch nor the first HBM round trip is paid per tile.
 #include <stdlib.h>
+#include <string.h>
 #include "gemm_common.h"
 
 #define PPU 16384                     // bytes per staging unit: 128 operand rows x 64 k x 2 B
@@ -288,13 +289,26 @@ __device__ __forceinline__ void pp_epilogue(const GemmP& g, f32x4 (&accL)[4][4],
 // weight gradients: f32 tile out of the same 4 KiB window, 16 rows x 64 columns at a time.  Plain 16-byte stores when the
 // workgroup owns the whole reduction and the output is not accumulated; otherwise f32 atomics issued so that one wave
 // instruction covers 256 contiguous bytes (scattered dword atomics run an order of magnitude slower).
+// mode 0: plain stores, 1: f32 atomics, 2: C += tile by load / add / store (the tile has ONE owner in the launch: grouped
+// weight gradients accumulating into the gradient slab)
 template <bool FULL>
 __device__ __forceinline__ void pp_epi_f32_half(const GemmP& g, f32x4 (&acc)[4][4], int ib, int jb, int lane, char* sw,
-                                                bool atomic) {
+                                                int mode) {
   const int il = lane & 15, jq = lane >> 4;
   float* Cf = reinterpret_cast<float*>(g.C);
+  const bool atomic = mode == 1;
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
+    f32x4 cold[4];
+    if (mode == 2) {                         // issue the C loads first: they fly under the LDS transpose below
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = k * 4 + (lane >> 4), ch = lane & 15;
+        const int i = ib + b * 16 + r, j = jb + ch * 4;
+        cold[k] = (FULL || (i < g.I && j < g.J)) ? *reinterpret_cast<const f32x4*>(Cf + (size_t)i * g.ldc + j)
+                                                 : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       f32x4 v = acc[a][b];
@@ -315,7 +329,8 @@ __device__ __forceinline__ void pp_epi_f32_half(const GemmP& g, f32x4 (&acc)[4][
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int r = k * 4 + (lane >> 4), ch = lane & 15;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(sw + r * 256 + ((ch ^ r) << 4));
+        f32x4 v = *reinterpret_cast<const f32x4*>(sw + r * 256 + ((ch ^ r) << 4));
+        if (mode == 2) v += cold[k];
         const int i = ib + b * 16 + r, j = jb + ch * 4;
         if (FULL || (i < g.I && j < g.J)) *reinterpret_cast<f32x4*>(Cf + (size_t)i * g.ldc + j) = v;   // J % 4 == 0
       }
@@ -334,23 +349,51 @@ __device__ __forceinline__ void pp_tile_ij(const GemmP& g, int vb, int ntiles, i
   tj = t - ti * g.tiles_j;
 }
 
+// Grouped launch (weight gradients of many layers in ONE launch, no split-K): up to PP_MAXG problems that share the
+// reduction length K; item ids run over the concatenated tile lists (tile0 = prefix sums).
+#define PP_MAXG 40
+struct PPGroup {
+  int n;
+  int rmw;                         // 1: C += tile by load/add/store (single owner); 0: atomics (a C appears twice)
+  int tile0[PP_MAXG + 1];
+  const void* P[PP_MAXG]; const void* Q[PP_MAXG]; void* C[PP_MAXG]; float* psum[PP_MAXG];
+  int I[PP_MAXG], J[PP_MAXG], ldp[PP_MAXG], ldq[PP_MAXG], ldc[PP_MAXG];
+};
+
+// select problem `vb` belongs to; returns the tile id inside it
+__device__ __forceinline__ int pp_group_select(const PPGroup& grp, int vb, GemmP& g) {
+  int p = 0;
+  while (p + 1 < grp.n && vb >= grp.tile0[p + 1]) ++p;
+  g.P = grp.P[p]; g.Q = grp.Q[p]; g.C = grp.C[p]; g.psum = grp.psum[p];
+  g.I = grp.I[p]; g.J = grp.J[p]; g.ldp = grp.ldp[p]; g.ldq = grp.ldq[p]; g.ldc = grp.ldc[p];
+  g.tiles_i = (g.I + 255) >> 8; g.tiles_j = (g.J + 255) >> 8;
+  return vb - grp.tile0[p];
+}
+
 // persistent: gridDim.x = min(work items, CUs); workgroup b runs items b, b + grid, ...  An item is (K split, tile);
 // split s covers K tiles [s * kt_per_split, ...).  The next item's first six staging units are issued BEFORE the epilogue
 // of the current one.   OUT 0: bf16 through the fused epilogue;  OUT 1: bare f32 (weight gradients).
-template <bool PT, bool QT, int OUT>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
+template <bool PT, bool QT, int OUT, bool GROUPED>
+__device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 64 KiB staging + 8 x 4 KiB epilogue windows; ALL LDS
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
-  const int ntiles = g.tiles_i * g.tiles_j;
   const int nt_all = g.K >> 6;
-  const int splits = (nt_all + g.kt_per_split - 1) / g.kt_per_split;
-  const int nitems = ntiles * splits;
-  const int kp = PT ? 64 * g.ldp : 64, kq = QT ? 64 * g.ldq : 64;     // elements per K tile step
+  const int splits = GROUPED ? 1 : (nt_all + g.kt_per_split - 1) / g.kt_per_split;
   int vb = blockIdx.x;
-  int ti, tj;
-  int sp = vb / ntiles;
-  pp_tile_ij(g, vb - sp * ntiles, ntiles, ti, tj);
+  int ntiles, nitems, ti, tj, sp = 0;
+  if (GROUPED) {
+    nitems = grp->tile0[grp->n];
+    const int t = pp_group_select(*grp, vb, g);
+    ntiles = g.tiles_i * g.tiles_j;
+    ti = t / g.tiles_j; tj = t - ti * g.tiles_j;      // (each XCD's consecutive ids share a P row panel)
+  } else {
+    ntiles = g.tiles_i * g.tiles_j;
+    nitems = ntiles * splits;
+    sp = vb / ntiles;
+    pp_tile_ij(g, vb - sp * ntiles, ntiles, ti, tj);
+  }
+  int kp = PT ? 64 * g.ldp : 64, kq = QT ? 64 * g.ldq : 64;           // elements per K tile step
   int i0 = ti * 256, j0 = tj * 256;
   int nt = min(nt_all - sp * g.kt_per_split, g.kt_per_split);
   const bf16* Pk = reinterpret_cast<const bf16*>(g.P) + (size_t)sp * g.kt_per_split * kp;
@@ -407,11 +450,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
 #endif
     const int ib = i0 + wr * 128, jb = j0 + wc * 64;
     const bool full = (i0 + 256 <= g.I) && (j0 + 256 <= g.J);
+    GemmP gc = g;                                 // the finished item's problem (the grouped form switches g below)
     vb += gridDim.x;
     const bool more = vb < nitems;
     if (more) {                                   // next item: its first six units fly under this item's epilogue
-      sp = vb / ntiles;
-      pp_tile_ij(g, vb - sp * ntiles, ntiles, ti, tj);
+      if (GROUPED) {
+        const int t = pp_group_select(*grp, vb, g);
+        ti = t / g.tiles_j; tj = t - ti * g.tiles_j;
+        kp = PT ? 64 * g.ldp : 64; kq = QT ? 64 * g.ldq : 64;
+      } else {
+        sp = vb / ntiles;
+        pp_tile_ij(g, vb - sp * ntiles, ntiles, ti, tj);
+      }
       i0 = ti * 256; j0 = tj * 256;
       nt = min(nt_all - sp * g.kt_per_split, g.kt_per_split);
       Pk = reinterpret_cast<const bf16*>(g.P) + (size_t)sp * g.kt_per_split * kp;
@@ -428,12 +478,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
     stp[2] = __builtin_amdgcn_s_memtime();
 #endif
     if (OUT == 0) {
-      if (full) pp_epilogue<true>(g, accL, accH, ib, jb, lane, swin);
-      else pp_epilogue<false>(g, accL, accH, ib, jb, lane, swin);
+      if (full) pp_epilogue<true>(gc, accL, accH, ib, jb, lane, swin);
+      else pp_epilogue<false>(gc, accL, accH, ib, jb, lane, swin);
     } else {
-      const bool atomic = g.accumulate || splits > 1;
-      if (full) { pp_epi_f32_half<true>(g, accL, ib, jb, lane, swin, atomic); pp_epi_f32_half<true>(g, accH, ib + 64, jb, lane, swin, atomic); }
-      else { pp_epi_f32_half<false>(g, accL, ib, jb, lane, swin, atomic); pp_epi_f32_half<false>(g, accH, ib + 64, jb, lane, swin, atomic); }
+      const int mode = GROUPED ? (grp->rmw ? 2 : 1) : ((gc.accumulate || splits > 1) ? 1 : 0);
+      if (full) { pp_epi_f32_half<true>(gc, accL, ib, jb, lane, swin, mode); pp_epi_f32_half<true>(gc, accH, ib + 64, jb, lane, swin, mode); }
+      else { pp_epi_f32_half<false>(gc, accL, ib, jb, lane, swin, mode); pp_epi_f32_half<false>(gc, accH, ib + 64, jb, lane, swin, mode); }
       if (do_psum) {                              // lanes l, l+16, l+32, l+48 hold the four k quarters of row l
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -441,7 +491,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
           v += __shfl_xor(v, 16, 64);
           v += __shfl_xor(v, 32, 64);
           const int i = ib + b * 16 + lane;
-          if (lane < 16 && i < g.I) atomicAdd(g.psum + i, v);
+          if (lane < 16 && i < gc.I) atomicAdd(gc.psum + i, v);
         }
       }
     }
@@ -457,6 +507,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
     if (!more) break;
     PP_WAIT(0);                                   // the six units (and this item's stores: one counter) have retired
   }
+}
+
+template <bool PT, bool QT, int OUT>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
+  pp256_body<PT, QT, OUT, false>(g, nullptr);
+}
+__global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_grouped_kernel(GemmP g, PPGroup grp) {
+  pp256_body<true, true, 1, true>(g, &grp);
 }
 
 // bf16 operands, K a multiple of 64 with >= 2 K tiles per workgroup item, 32-bit operand offsets, 16-byte rows.
@@ -519,5 +577,49 @@ int evlm_gemm_pp256_launch(GemmP& g, int pt, int qt, hipStream_t stream) {
   else if (qt) PP_LAUNCH(false, true, 0);
   else PP_LAUNCH(false, false, 0);
 #undef PP_LAUNCH
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// grouped weight gradients: C_n (+)= P_n^T Q_n for problems sharing the reduction length K, one persistent launch per
+// <= PP_MAXG problems, every output tile owned by exactly one workgroup item (no split-K, no atomics unless two problems
+// of a launch accumulate into the same C).
+// ---------------------------------------------------------------------------------------------
+extern "C" int evlm_wgrad_grouped(const evlm_wgrad_problem* pr, int n, int K, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(pr && n > 0, "evlm_wgrad_grouped: no problems");
+  EVLM_REQUIRE(K % 64 == 0 && K >= 128, "evlm_wgrad_grouped: K=%d must be a multiple of 64, >= 128", K);
+  const int lds = 2 * PPB + 8 * 4096;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp256_grouped_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return evlm_set_error("evlm_wgrad_grouped: cannot reserve 160 KiB LDS: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  for (int base = 0; base < n; base += PP_MAXG) {
+    const int m = imin(PP_MAXG, n - base);
+    PPGroup grp;
+    grp.n = m; grp.rmw = 1; grp.tile0[0] = 0;
+    for (int k = 0; k < m; ++k) {
+      const evlm_wgrad_problem& q = pr[base + k];
+      EVLM_REQUIRE(q.P && q.Q && q.C && q.I > 0 && q.J > 0, "evlm_wgrad_grouped: bad problem %d", base + k);
+      EVLM_REQUIRE(q.ldp % 8 == 0 && q.ldq % 8 == 0 && q.ldc % 4 == 0 && q.J % 4 == 0,
+                   "evlm_wgrad_grouped: problem %d: ldp/ldq must be multiples of 8, ldc and J of 4", base + k);
+      EVLM_REQUIRE(((uintptr_t)q.P | (uintptr_t)q.Q | (uintptr_t)q.C) % 16 == 0, "evlm_wgrad_grouped: 16-byte alignment");
+      EVLM_REQUIRE((int64_t)K * q.ldp < (1ll << 31) && (int64_t)K * q.ldq < (1ll << 31), "evlm_wgrad_grouped: operand too large");
+      grp.P[k] = q.P; grp.Q[k] = q.Q; grp.C[k] = q.C; grp.psum[k] = q.psum;
+      grp.I[k] = q.I; grp.J[k] = q.J; grp.ldp[k] = q.ldp; grp.ldq[k] = q.ldq; grp.ldc[k] = q.ldc;
+      grp.tile0[k + 1] = grp.tile0[k] + ceil_div(q.I, 256) * ceil_div(q.J, 256);
+      for (int o = 0; o < k; ++o)
+        if (grp.C[o] == q.C) grp.rmw = 0;           // two contributions to one C in this launch: fall back to atomics
+    }
+    GemmP g;
+    memset(&g, 0, sizeof(g));
+    g.K = K; g.alpha = 1.0f; g.c_f32 = 1; g.bare_f32 = 1; g.accumulate = 1; g.kt_per_split = K / 64;
+    g.act = EVLM_ACT_NONE; g.dact = EVLM_ACT_NONE;
+    hipLaunchKernelGGL(gemm_bf16_pp256_grouped_kernel, dim3(imin(grp.tile0[m], 256)), dim3(512), lds, stream, g, grp);
+  }
+  EVLM_LAUNCH_CHECK("evlm_wgrad_grouped");
   return 0;
 }

@@ -169,6 +169,38 @@ def _colsum(x2d, I, J, ld, out=None, x_off=0):
 WGRAD_INPLACE = False
 
 
+# Deferred weight gradients (trainer mode, with WGRAD_INPLACE): set to a list and the in-place dW products of Linear /
+# MLP backward are queued instead of launched; flush_wgrad() then runs every queued product of one reduction length as
+# ONE grouped launch of the 256x256 kernel, each output tile owned by one workgroup - no split-K and none of its f32
+# atomics.  The queue keeps dY and X alive until the flush (MI355X: 288 GB of HBM make that free).
+WGRAD_DEFER = None
+WGRAD_DEFER_MIN_K = 1024
+
+
+def flush_wgrad():
+    """launch the queued weight-gradient products (no-op when nothing is queued)"""
+    global WGRAD_DEFER
+    q = WGRAD_DEFER
+    if not q:
+        return
+    WGRAD_DEFER = [] if q is not None else None
+    by_k = {}
+    for rec in q:
+        by_k.setdefault(rec[0], []).append(rec)
+    lib = _lib()
+    for K, recs in by_k.items():
+        # large problems first: the persistent workgroups take items in order
+        recs.sort(key=lambda r: -(r[5] * r[6]))
+        arr = (L.WgradProblem * len(recs))()
+        for k, (_, d2, p_off, x2, cgrad, I, J, ldd, ldp, ps) in enumerate(recs):
+            arr[k].P = d2.data_ptr() + p_off * d2.element_size()
+            arr[k].Q = x2.data_ptr()
+            arr[k].C = cgrad.data_ptr()
+            arr[k].psum = ps.data_ptr() if ps is not None else None
+            arr[k].I, arr[k].J, arr[k].ldp, arr[k].ldq, arr[k].ldc = I, J, ldd, ldp, J
+        L.check(lib.evlm_wgrad_grouped(arr, len(recs), K, L.stream()), "wgrad_grouped")
+
+
 def _inplace(p):
     g = getattr(p, "grad", None)
     return WGRAD_INPLACE and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape
@@ -213,7 +245,11 @@ def _wgrad(dtype, d2, ldd, x2, ldp, M, K, params, rows, biases=None):
             ps = res = torch.zeros(r, dtype=torch.float32, device=x2.device)
         else:
             ps = res = None
-        _gemm(dtype, d2, x2, params[i].grad, r, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1, accumulate=1, p_off=r0, psum=ps)
+        if (WGRAD_DEFER is not None and res is None and M >= WGRAD_DEFER_MIN_K and r % 8 == 0 and K % 8 == 0
+                and (r0 * d2.element_size()) % 16 == 0 and M * max(ldd, ldp) < (1 << 31)):
+            WGRAD_DEFER.append((M, d2, r0, x2, params[i].grad, r, K, ldd, ldp, ps))
+        else:
+            _gemm(dtype, d2, x2, params[i].grad, r, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1, accumulate=1, p_off=r0, psum=ps)
         for k in range(i, j):
             gw.append(None)
             gb.append(res if k == i else None)

@@ -112,6 +112,8 @@ class GDTrainer:
             student.on_vision_grad = self._on_vision_grad      # fires when backward enters the image encoder
         self.use_graph = use_graph
         self.wgrad_inplace = True
+        import os
+        self.defer_wgrad = self.dtype == torch.bfloat16 and not os.environ.get("EVLM_NO_DEFER_WGRAD")
         self.graph = None
         self.static = None
         self.out = None
@@ -125,10 +127,13 @@ class GDTrainer:
         with compute(self.dtype):
             total, S, T, kd, mix = distill.gd_forward(self.student, self.teacher, batch, self.temperature)
             ops.WGRAD_INPLACE = self.wgrad_inplace      # kernels sum parameter gradients straight into the flat slabs
+            ops.WGRAD_DEFER = [] if (self.wgrad_inplace and self.defer_wgrad) else None   # ... dW products grouped per K
             try:
                 total.backward()
+                ops.flush_wgrad()
             finally:
                 ops.WGRAD_INPLACE = False
+                ops.WGRAD_DEFER = None
         return torch.stack([total.detach().float(), S["loss"]["loss_itc"].detach().float(),
                             S["loss"]["loss_itm"].detach().float(), S["loss"]["loss_mlm"].detach().float(),
                             mix["loss_kd"].detach().float()])
@@ -138,6 +143,7 @@ class GDTrainer:
         backward"""
         if not self._early_sent:
             self._early_sent = True
+            ops.flush_wgrad()                 # the queued text / fusion weight gradients must be in the slabs first
             self.reducer.reduce_async(self._early)
 
     def _step_eager(self, batch):

@@ -77,6 +77,18 @@ typedef struct {
 
 int evlm_gemm(const evlm_gemm_args* args, void* stream);
 
+/* Grouped weight gradients: C_n += P_n^T Q_n for n problems that share the reduction length K (bf16 operands, f32 C),
+ * ONE persistent launch per <= 40 problems with every 256x256 output tile owned by one workgroup (no split-K atomics).
+ * P_n = dY stored [K][I] (row stride ldp), Q_n = X stored [K][J] (ldq), C_n [I][J] (ldc) is ACCUMULATED into;
+ * psum_n (optional [I] f32) += column sums of dY (the bias gradient).  Replaces the weight branch of every nn.Linear
+ * backward of a layer group (autograd's per-layer grad_weight = grad_output^T @ input): the caller defers them and
+ * flushes once per reduction length (ops.flush_wgrad), which MI355X's HBM capacity makes free. */
+typedef struct {
+  const void* P; const void* Q; void* C; float* psum;
+  int I, J, ldp, ldq, ldc;
+} evlm_wgrad_problem;
+int evlm_wgrad_grouped(const evlm_wgrad_problem* problems, int n, int K, void* stream);
+
 /* out[j] (+)= sum_i X[i,j]   (f32 out; bias gradients = column sums of dY).  out must be zeroed by the caller
  * unless it should accumulate.  Replaces the bias branch of Linear backward. */
 int evlm_colsum(int dtype, const void* X, int I, int J, int ldx, float* out, void* stream);

@@ -535,3 +535,40 @@ print("PP256_WGRAD_OK")
     env = dict(os.environ, EVLM_PP256_WGRAD="1", EVLM_PP256_PCT="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PP256_WGRAD_OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_grouped_weight_gradients_match_per_layer_products():
+    """evlm_wgrad_grouped (one persistent launch, every output tile owned by one workgroup) against torch, including ragged
+    tiles, the bias-gradient row sums, accumulation into pre-filled C and two problems adding into the SAME C"""
+    o = ops()
+    from efficientvlm_amd import _lib as L
+    g = torch.Generator().manual_seed(53)
+    K = 1600
+    shapes = [(768, 768), (2304, 768), (520, 264), (768, 3072), (256, 256)]
+    probs, keep = [], []
+    for (I, J) in shapes:
+        dY = rnd((K, I), torch.bfloat16, g, 0.5); X = rnd((K, J), torch.bfloat16, g, 0.5)
+        Cm = torch.full((I, J), 0.25, dtype=torch.float32, device=DEV); ps = torch.full((I,), 0.5, dtype=torch.float32, device=DEV)
+        probs.append((dY, X, Cm, ps)); keep.append((dY, X))
+    dY2 = rnd((K, 768), torch.bfloat16, g, 0.5); X2 = rnd((K, 768), torch.bfloat16, g, 0.5)
+
+    def launch(plist):
+        arr = (L.WgradProblem * len(plist))()
+        for k, (dY, X, Cm, ps) in enumerate(plist):
+            arr[k].P, arr[k].Q, arr[k].C = dY.data_ptr(), X.data_ptr(), Cm.data_ptr()
+            arr[k].psum = ps.data_ptr() if ps is not None else None
+            arr[k].I, arr[k].J, arr[k].ldp, arr[k].ldq, arr[k].ldc = dY.shape[1], X.shape[1], dY.shape[1], X.shape[1], X.shape[1]
+        L.check(L.load().evlm_wgrad_grouped(arr, len(plist), K, L.stream()), "wgrad_grouped")
+
+    launch(probs + [(dY2, X2, probs[0][2], None)])       # last problem adds into the first problem's C (atomic mode)
+    for n, (dY, X, Cm, ps) in enumerate(probs):
+        ref = dY.float().t() @ X.float() + 0.25
+        if n == 0:
+            ref = ref + dY2.float().t() @ X2.float()
+        assert rel_err(Cm, ref) < 2e-5, ("C", n)
+        assert rel_err(ps, dY.float().sum(0) + 0.5) < 2e-5, ("psum", n)
+    for (_, _, Cm, ps) in probs:
+        Cm.fill_(0.25); ps.fill_(0.5)
+    launch(probs)                                          # single owner per C: load / add / store mode
+    for n, (dY, X, Cm, ps) in enumerate(probs):
+        assert rel_err(Cm, dY.float().t() @ X.float() + 0.25) < 2e-5, ("C rmw", n)
