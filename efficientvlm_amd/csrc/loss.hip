@@ -75,15 +75,31 @@ extern "C" int evlm_mse_bwd(int dtype_a, const void* a, int dtype_b, const void*
 // ---------------------------------------------------------------------------------------------
 // row-wise log-sum-exp helper: one 256-thread block per row
 // ---------------------------------------------------------------------------------------------
+// one sweep over the row: 16-byte loads where the row is 16-byte aligned, running (max, sum exp) per thread merged at the
+// end (online softmax), so a vocabulary-sized row is read once instead of twice
 template <typename T>
 __device__ __forceinline__ float row_lse(const T* __restrict__ x, int C, float mul, float* red) {
-  float m = -INFINITY;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) m = fmaxf(m, to_f(x[c]) * mul);
-  m = block_max(m, red);
-  float s = 0.f;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) s += __expf(to_f(x[c]) * mul - m);
-  s = block_sum(s, red);
-  return m + __logf(s);
+  float m = -INFINITY, s = 0.f;
+  const bool vec = ((uintptr_t)x & 15) == 0;
+  const int nv = vec ? (C >> 3) : 0;
+  for (int c = threadIdx.x; c < nv; c += blockDim.x) {
+    float v[8];
+    load8<T>(x + c * 8, v);
+    float mx = v[0] * mul;
+#pragma unroll
+    for (int e = 1; e < 8; ++e) mx = fmaxf(mx, v[e] * mul);
+    if (mx > m) { s *= __expf(m - mx); m = mx; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += __expf(v[e] * mul - m);
+  }
+  for (int c = nv * 8 + threadIdx.x; c < C; c += blockDim.x) {
+    const float v = to_f(x[c]) * mul;
+    if (v > m) { s *= __expf(m - v); m = v; }
+    s += __expf(v - m);
+  }
+  const float M = block_max(m, red);
+  s = block_sum(m == -INFINITY ? 0.f : s * __expf(m - M), red);
+  return M + __logf(s);
 }
 
 // hard-label CE:  rowloss[r] = lse - logit[label]   (0 for ignored rows)
@@ -173,7 +189,19 @@ __global__ __launch_bounds__(256) void kl_fwd_kernel(const TS* __restrict__ s, i
   const float ls = row_lse<TS>(sr, C, it, red);
   const float lt = row_lse<TT>(tr, C, it, red);
   float acc = 0.f;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  const bool vec = (((uintptr_t)sr | (uintptr_t)tr) & 15) == 0;
+  const int nv = vec ? (C >> 3) : 0;
+  for (int c = threadIdx.x; c < nv; c += blockDim.x) {
+    float sv[8], tv[8];
+    load8<TS>(sr + c * 8, sv);
+    load8<TT>(tr + c * 8, tv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float lpt = tv[e] * it - lt, lps = sv[e] * it - ls;
+      acc += __expf(lpt) * (lpt - lps);
+    }
+  }
+  for (int c = nv * 8 + threadIdx.x; c < C; c += blockDim.x) {
     const float lpt = to_f(tr[c]) * it - lt, lps = to_f(sr[c]) * it - ls;
     acc += __expf(lpt) * (lpt - lps);
   }

@@ -276,6 +276,19 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
+_SCRATCH = {}
+
+
+def _scratch(key, shape, dtype, device, zero=False):
+    """persistent work buffer (static address: safe under hipGraph capture); zero-filled once when `zero`"""
+    k = (key, dtype, str(device))
+    t = _SCRATCH.get(k)
+    if t is None:
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+        _SCRATCH[k] = t
+    return t
+
+
 # ---------------------------------------------------------------------------------------------------
 # Linear (optionally several weights packed along the output dim) with fused epilogue
 # ---------------------------------------------------------------------------------------------------
@@ -337,8 +350,18 @@ class _Linear(torch.autograd.Function):
             d2, ldd = dh, ldc
         dx = None
         if ctx.needs_input_grad[0]:
-            dxb = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
-            _gemm(dtype, d2, W, dxb, M, K, N, ldd, K, K, p_trans=0, q_trans=1)     # dX = dY W
+            n64 = (N + 63) // 64 * 64
+            if dtype == L.BF16 and N % 64 != 0 and N >= 4096 and M <= 2048 and ldd >= n64 and act == L.ACT_NONE:
+                # skinny product with a vocabulary-sized ragged reduction (MLM decoder): zero-pad W's rows to a multiple
+                # of 64 (dY's padding columns are zero already) so the split-K f32 path applies, then cast once
+                Wp = _scratch(("wpad", n64, K), (n64, K), x2.dtype, x2.device, zero=True)
+                Wp[:N].copy_(W)
+                d32 = torch.zeros((M, K), dtype=torch.float32, device=x2.device)
+                _gemm(dtype, d2, Wp, d32, M, K, n64, ldd, K, K, p_trans=0, q_trans=1, c_f32=1)
+                dxb = cast(d32, x2.dtype)
+            else:
+                dxb = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
+                _gemm(dtype, d2, W, dxb, M, K, N, ldd, K, K, p_trans=0, q_trans=1)     # dX = dY W
             dx = dxb.view(xshape)
         weights, biases = ctx.params
         gw, gb = _wgrad(dtype, d2, ldd, x2, ldp, M, K, weights, rows, biases if has_bias else None)   # dW = dY^T X, db
