@@ -213,64 +213,91 @@ __device__ __forceinline__ void pp_epi_cols(const GemmP& g, int jb, int lane, f3
 }
 
 // MODE 1: the pre-activation output (alpha * acc + bias); MODE 2: C
-template <bool FULL, int MODE>
-__device__ __forceinline__ void pp_epi_half(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4],
-                                            int ib, int jb, int lane, char* sw, bf16* dst, int ldd) {
-  const int il = lane & 15, jl = (lane >> 4) * 4;
-  const bool need_h = MODE == 2 && g.dact != EVLM_ACT_NONE, need_r = MODE == 2 && g.residual != nullptr;
-  bf16x4 xx[4][4];                   // aux (activation backward) OR residual fragments: the host never routes both here
-  if (need_h || need_r) {
-    const bf16* xb = reinterpret_cast<const bf16*>(need_h ? g.aux : g.residual);
+struct PPRows { uint4 r[4]; };     // 32 rows x 128 bytes of aux / residual for one wave: 16 bytes per lane, 8 rows per entry
+
+template <bool FULL>
+__device__ __forceinline__ PPRows pp_epi_rows(const GemmP& g, const bf16* xb, int i0, int jb, int lane) {
+  PPRows x;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int i = ib + b * 16 + il, j = jb + a * 16 + jl;
-        const size_t o = (size_t)(FULL ? i : min(i, g.I - 1)) * g.ldx + (FULL ? j : min(j, g.J - 4));
-        xx[a][b] = *reinterpret_cast<const bf16x4*>(xb + o);
-      }
+  for (int k = 0; k < 4; ++k) {
+    const int i = i0 + k * 8 + (lane >> 3), j = jb + (lane & 7) * 8;
+    const size_t o = (size_t)(FULL ? i : min(i, g.I - 1)) * g.ldx + (FULL ? j : min(j, g.J - 8));
+    x.r[k] = *reinterpret_cast<const uint4*>(xb + o);
   }
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-#pragma unroll
-    for (int bb = 0; bb < 2; ++bb) {
-      const int b = c * 2 + bb;
-      const int r = bb * 16 + il;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][e] * g.alpha + bz[a][e];
-        if (MODE == 2) {
-          if (g.act != EVLM_ACT_NONE) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_apply_fast(g.act, v[e]);
-          }
-          if (need_h) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= act_grad_fast(g.dact, (float)xx[a][b][e]);
-          }
-          if (need_r) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)xx[a][b][e];
-          }
-        }
-        const int ch = a * 2 + (jl >> 3);
-        Vec4<bf16>::store(reinterpret_cast<bf16*>(sw + r * 128 + ((ch ^ (r & 7)) << 4) + ((jl & 4) << 1)), v);
-      }
-    }
-    asm volatile("" ::: "memory");           // same-wave LDS traffic is in order; keep the compiler from reordering it
-    __builtin_amdgcn_wave_barrier();
+  return x;
+}
+
+// one 32-row chunk (i fragments b0, b0 + 1) of the wave's block through its LDS window
+template <bool FULL, int MODE>
+__device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4], int b0, const PPRows& xr,
+                                             bool need_h, bool need_r, int ic, int jb, int lane, char* sw, bf16* dst, int ldd) {
+  const int il = lane & 15, jl = (lane >> 4) * 4;
+  if (need_h || need_r) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int r = k * 8 + (lane >> 3), ch = lane & 7;
-      const uint4 v16 = *reinterpret_cast<const uint4*>(sw + r * 128 + ((ch ^ (r & 7)) << 4));
-      const int i = ib + c * 32 + r, j = jb + ch * 8;
-      if (FULL || (i < g.I && j < g.J)) *reinterpret_cast<uint4*>(dst + (size_t)i * ldd + j) = v16;
+      *reinterpret_cast<uint4*>(sw + r * 128 + ((ch ^ (r & 7)) << 4)) = xr.r[k];
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
+#pragma unroll
+  for (int bb = 0; bb < 2; ++bb) {
+    const int r = bb * 16 + il;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int ch = a * 2 + (jl >> 3);
+      bf16* cell = reinterpret_cast<bf16*>(sw + r * 128 + ((ch ^ (r & 7)) << 4) + ((jl & 4) << 1));
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[a][b0 + bb][e] * g.alpha + bz[a][e];
+      if (MODE == 2) {
+        if (g.act != EVLM_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_apply_fast(g.act, v[e]);
+        }
+        if (need_h || need_r) {
+          const bf16x4 xx = *reinterpret_cast<const bf16x4*>(cell);
+          if (need_h) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= act_grad_fast(g.dact, (float)xx[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)xx[e];
+          }
+        }
+      }
+      Vec4<bf16>::store(cell, v);
+    }
+  }
+  asm volatile("" ::: "memory");           // same-wave LDS traffic is in order; keep the compiler from reordering it
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = k * 8 + (lane >> 3), ch = lane & 7;
+    const uint4 v16 = *reinterpret_cast<const uint4*>(sw + r * 128 + ((ch ^ (r & 7)) << 4));
+    const int i = ic + r, j = jb + ch * 8;
+    if (FULL || (i < g.I && j < g.J)) *reinterpret_cast<uint4*>(dst + (size_t)i * ldd + j) = v16;
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// MODE 1: the pre-activation output (alpha * acc + bias); MODE 2: C.  aux (activation backward) OR residual rows (the host
+// never routes both here) are fetched as FULL 128-byte row segments, both chunks of the half in one batch; they reach the
+// fragment layout through the wave's LDS window, where the result then overwrites them in place.
+template <bool FULL, int MODE>
+__device__ __forceinline__ void pp_epi_half(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4],
+                                            int ib, int jb, int lane, char* sw, bf16* dst, int ldd) {
+  const bool need_h = MODE == 2 && g.dact != EVLM_ACT_NONE, need_r = MODE == 2 && g.residual != nullptr;
+  PPRows x0, x1;
+  if (need_h || need_r) {
+    const bf16* xb = reinterpret_cast<const bf16*>(need_h ? g.aux : g.residual);
+    x0 = pp_epi_rows<FULL>(g, xb, ib, jb, lane);
+    x1 = pp_epi_rows<FULL>(g, xb, ib + 32, jb, lane);
+  }
+  pp_epi_chunk<FULL, MODE>(g, acc, bz, 0, x0, need_h, need_r, ib, jb, lane, sw, dst, ldd);
+  pp_epi_chunk<FULL, MODE>(g, acc, bz, 2, x1, need_h, need_r, ib + 32, jb, lane, sw, dst, ldd);
 }
 
 template <bool FULL>
@@ -536,7 +563,7 @@ bool evlm_gemm_pp256_eligible(const GemmP& g, int pt, int qt) {
   if (g.psum) return false;
 #endif
   if (pt || g.accumulate || g.gate) return false;
-  if (g.dact != EVLM_ACT_NONE && (g.residual || qt)) return false;   // (the activation-backward dX runs faster on 128x128)
+  if (g.dact != EVLM_ACT_NONE && g.residual) return false;
   if (g.J % 8 != 0 || g.ldc % 8 != 0) return false;
   if ((g.preact || g.aux || g.residual) && g.ldx % 8 != 0) return false;
   return true;

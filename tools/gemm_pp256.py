@@ -61,8 +61,10 @@ def run_dgrad(name, I, J, K, reps=20, dact=0):
     f = lambda: ops._gemm(L.BF16, P, Q, C, I, J, K, K, J, J, q_trans=1, **extra)
     f(); torch.cuda.synchronize()
     ref = P.float() @ Q.float()
-    if dact:
+    if dact == L.ACT_QUICK_GELU:
         x = aux.float(); sg = torch.sigmoid(1.702 * x); ref = ref * (sg + 1.702 * x * sg * (1 - sg))
+    if dact == L.ACT_GELU:
+        x = aux.float(); ref = ref * (0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * 3.141592653589793) ** 0.5)
     d = (C.float() - ref).abs().max().item(); sc = ref.abs().max().item()
     for _ in range(3): f()
     torch.cuda.synchronize()
@@ -113,7 +115,6 @@ run_wgrad("vit out dW + db", 768, 768, M, psum=True, accumulate=True)
 run_wgrad("text out dW", 768, 768, 7680, psum=True)
 run_wgrad("text out dW 2B", 768, 768, 3840, psum=True)
 run_wgrad("wgrad edge", 520, 264, 1024, psum=True)
-run_wgrad("mlm decoder dW", 30522, 768, 512)
 run("vit qkv fwd (bias)", M, 2304, 768, bias=True)
 run("vit out_proj (bias+res)", M, 768, 768, bias=True, res=True)
 run("vit fc1 teacher (bias+qgelu)", M, 3072, 768, bias=True)
