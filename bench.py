@@ -114,7 +114,9 @@ def roofline_leg(trainer, batch):
     from efficientvlm_amd._lib import BF16
     ops.GEMM_PROFILE = []
     trainer.opt.set_schedule(0.0)
+    overlap, trainer.overlap_teacher = trainer.overlap_teacher, False     # one stream: a launch is timed with the chip to itself
     trainer._step_eager(batch)
+    trainer.overlap_teacher = overlap
     torch.cuda.synchronize()
     recs, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     groups = {}

@@ -89,14 +89,47 @@ def itr_loss_mix(loss, kd, lagrangian):
                                                            loss_cross_kd=loss_cross_kd, loss_kd=loss_kd)
 
 
-def gd_forward(student, teacher, batch, temperature=1.0):
+_SIDE = {}
+
+
+def _tensors(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors(v)
+    elif isinstance(obj, (tuple, list)):
+        for v in obj:
+            yield from _tensors(v)
+
+
+def gd_forward(student, teacher, batch, temperature=1.0, overlap_teacher=False):
     """student forward (autograd on), teacher forward (no_grad), every KD term and the GD loss mix
-    (GeneralDistill.py:289-376).  batch: dict(image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids)."""
+    (GeneralDistill.py:289-376).  batch: dict(image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids).
+
+    overlap_teacher: the two forwards are independent (each draws its own hard negatives, as in the reference), so the
+    teacher runs on a second HIP stream: its HBM-bound kernels (LayerNorm, attention maps) and partly-filled GEMM launches
+    share the chip with the student's instead of queueing behind them."""
     kw = dict(text_ids_masked=batch["text_ids_masked"], masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"],
               output_attentions=True, output_hidden_states=True)
-    S = student(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
-    with torch.no_grad():
-        T = teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+    if overlap_teacher and batch["image"].is_cuda:
+        cur = torch.cuda.current_stream()
+        dev = batch["image"].device
+        side = _SIDE.get(dev)
+        if side is None:
+            side = _SIDE[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            T = teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+        S = student(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+        cur.wait_stream(side)
+        if not torch.cuda.is_current_stream_capturing():
+            for t in _tensors(T):          # allocated on the side stream, consumed on this one
+                t.record_stream(cur)
+    else:
+        S = student(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+        with torch.no_grad():
+            T = teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
     kd = kd_terms(S, T, temperature)
     total, mix = gd_loss_mix(S["loss"], kd)
     return total, S, T, kd, mix

@@ -114,6 +114,7 @@ class GDTrainer:
         self.wgrad_inplace = True
         import os
         self.defer_wgrad = self.dtype == torch.bfloat16 and not os.environ.get("EVLM_NO_DEFER_WGRAD")
+        self.overlap_teacher = not os.environ.get("EVLM_NO_OVERLAP_TEACHER")     # teacher forward on a second stream
         self.graph = None
         self.static = None
         self.out = None
@@ -125,7 +126,8 @@ class GDTrainer:
     def _forward_backward(self, batch):
         self.opt.zero_grad()
         with compute(self.dtype):
-            total, S, T, kd, mix = distill.gd_forward(self.student, self.teacher, batch, self.temperature)
+            total, S, T, kd, mix = distill.gd_forward(self.student, self.teacher, batch, self.temperature,
+                                                      overlap_teacher=self.overlap_teacher)
             ops.WGRAD_INPLACE = self.wgrad_inplace      # kernels sum parameter gradients straight into the flat slabs
             ops.WGRAD_DEFER = [] if (self.wgrad_inplace and self.defer_wgrad) else None   # ... dW products grouped per K
             try:
