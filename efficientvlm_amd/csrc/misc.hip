@@ -33,21 +33,24 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const int64_t* __re
     store8<T>(out + (size_t)row * d + c * 8, w);
   }
 }
-// one block per sequence position l: dpos[l] += sum_b de[b,l]; dtype0 += that; dword[ids[b,l]] += de[b,l] (atomics)
+// block (l, c): position l, sequences [c*EMB_BC, ...): dpos[l] += sum_b de[b,l]; dtype0 += that; dword[ids[b,l]] += de[b,l]
+// (f32 atomics; the batch is cut into chunks so that L x B/EMB_BC workgroups share the sweep instead of L)
+#define EMB_BC 8
 template <typename T>
 __global__ __launch_bounds__(256) void bert_embed_bwd_kernel(const int64_t* __restrict__ ids, int B, int L, int d,
                                                              const T* __restrict__ de, int pad_id, float* __restrict__ dword,
                                                              float* __restrict__ dpos, float* __restrict__ dtype0) {
   const int l = blockIdx.x;
+  const int b0 = blockIdx.y * EMB_BC, b1 = min(B, b0 + EMB_BC);
   for (int j = threadIdx.x; j < d; j += blockDim.x) {
     float acc = 0.f;
-    for (int b = 0; b < B; ++b) {
+    for (int b = b0; b < b1; ++b) {
       const float g = to_f(de[((size_t)b * L + l) * d + j]);
       acc += g;
       const int64_t w = ids[(size_t)b * L + l];
       if (w != pad_id) atomicAdd(dword + (size_t)w * d + j, g);
     }
-    dpos[(size_t)l * d + j] += acc;
+    atomicAdd(dpos + (size_t)l * d + j, acc);
     atomicAdd(dtype0 + j, acc);
   }
 }
@@ -67,7 +70,7 @@ extern "C" int evlm_bert_embed_bwd(int dtype, const int64_t* ids, int B, int L, 
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(ids && de && dword && dpos && dtype0, "evlm_bert_embed_bwd: bad args");
   EVLM_DISPATCH_DTYPE(dtype, "evlm_bert_embed_bwd",
-    hipLaunchKernelGGL((bert_embed_bwd_kernel<T>), dim3(L), dim3(256), 0, stream, ids, B, L, d, (const T*)de, pad_id, dword, dpos, dtype0);)
+    hipLaunchKernelGGL((bert_embed_bwd_kernel<T>), dim3(L, ceil_div(B, EMB_BC)), dim3(256), 0, stream, ids, B, L, d, (const T*)de, pad_id, dword, dpos, dtype0);)
   EVLM_LAUNCH_CHECK("evlm_bert_embed_bwd");
   return 0;
 }
