@@ -21,13 +21,25 @@ struct MAttnF {
 __device__ __forceinline__ int k_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }          // ds_read_b128 rows
 __device__ __forceinline__ int v_swz(int row, int chunk) { return chunk ^ (((row >> 1) & 3) << 1); }   // tr16 column reads
 
-// stage rows [0, nrows) of a [L][.. ld ..] tensor (64 columns at `base`) into a swizzled LDS tile; rows >= L are zero
+// Key order inside the LDS tiles.  Keys are PERMUTED within every block of 32: key 32s + 8g + 4h + r sits in LDS row
+// (2s + h)*16 + 4g + r, i.e. MFMA tile 2s + h, row 4g + r.  An accumulator lane (g = lane >> 4) of the tile pair (2s, 2s+1)
+// then holds keys 32s + 8g + 0..3 (tile 2s) and + 4..7 (tile 2s+1): EIGHT CONSECUTIVE keys, so the probability map, the
+// external dP and dS move as 16-byte pieces (64 contiguous bytes per row per wave instruction) instead of 8-byte ones,
+// and the k-slot <-> key map of the second MFMA's B operand becomes the natural one.  Fragment reads are unchanged.
+__device__ __forceinline__ int key_row(int key) {
+  return (((key >> 5) << 1) | ((key >> 2) & 1)) * 16 + ((key >> 3) & 3) * 4 + (key & 3);
+}
+// first key of accumulator tile t for lane group g (keys key0 .. key0 + 3)
+__device__ __forceinline__ int tile_key0(int t, int g) { return (t >> 1) * 32 + g * 8 + (t & 1) * 4; }
+
+// stage keys [0, nrows) of a [L][.. ld ..] tensor (64 columns at `base`) into a swizzled LDS tile; keys >= L are zero
 template <bool VSWZ>
 __device__ __forceinline__ void stage_rows(const bf16* base, int ld, int L, int nrows, char* sm) {
   for (int id = threadIdx.x; id < nrows * 8; id += blockDim.x) {
-    const int row = id >> 3, c = id & 7;
+    const int key = id >> 3, c = id & 7;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < L) v = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + c * 8);
+    if (key < L) v = *reinterpret_cast<const uint4*>(base + (size_t)key * ld + c * 8);
+    const int row = key_row(key);
     const int cs = VSWZ ? v_swz(row, c) : k_swz(row, c);
     *reinterpret_cast<uint4*>(sm + row * 128 + cs * 16) = v;
   }
@@ -85,7 +97,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
     if (qok) v = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + ks * 32 + g * 8);
     qf[ks] = *reinterpret_cast<bf16x8*>(&v);
   }
-  // S^T tiles: acc[t][r] = S[q][key = 16t + 4g + r]
+  // S^T tiles: acc[t][r] = S[q][key = tile_key0(t, g) + r]
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   float m = -3.0e38f;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + t * 16 + g * 4);
+    const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + tile_key0(t, g));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       acc[t][r] = acc[t][r] * sc + mk[r] * 1.44269504088896341f;
@@ -126,8 +138,16 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) pk[t][r] = (bf16)(acc[t][r] * inv);
-    const int kcol = t * 16 + g * 4;
-    if (Pr && qok && kcol < a.ldpr) *reinterpret_cast<bf16x4*>(Pr + kcol) = pk[t];
+  }
+#pragma unroll
+  for (int s = 0; s < NT / 2; ++s) {            // 8 consecutive keys per lane: one 16-byte store per tile pair
+    const int kcol = s * 32 + g * 8;
+    if (Pr && qok && kcol < a.ldpr) {
+      bf16x8 pp;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pp[r] = pk[2 * s][r]; pp[4 + r] = pk[2 * s + 1][r]; }
+      *reinterpret_cast<bf16x8*>(Pr + kcol) = pp;
+    }
   }
   // O^T[d][q] = sum_key V[key][d] * P[q][key]
   f32x4 o[4];
@@ -207,26 +227,32 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   bf16x4 pv[NT];
   float dsum = 0.f, gsum = 0.f;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, t, ks, lane), dof[ks], acc[t], 0, 0, 0);
-    const int kcol = t * 16 + g * 4;
+  for (int s = 0; s < NT / 2; ++s) {            // tile pair: this lane's 8 consecutive keys 32s + 8g .. + 7
+    const int kcol = s * 32 + g * 8;
     const bool ok = qok && kcol < a.ldpr;
-    bf16x4 ev = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-    pv[t] = ev;
+    bf16x8 p8, e8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { p8[r] = (bf16)0.f; e8[r] = (bf16)0.f; }
     if (ok) {
-      pv[t] = *reinterpret_cast<const bf16x4*>(a.P + prow + kcol);
-      if (a.E) ev = *reinterpret_cast<const bf16x4*>(a.E + prow + kcol);
+      p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
+      if (a.E) e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float p = (float)pv[t][r], dpo = acc[t][r];
-      gsum += p * dpo;
-      const float dp = gz * dpo + (float)ev[r];
-      acc[t][r] = dp;
-      dsum += p * dp;
+    for (int hh = 0; hh < 2; ++hh) {
+      const int t = 2 * s + hh;
+      acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, t, ks, lane), dof[ks], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pv[t][r] = p8[hh * 4 + r];
+        const float p = (float)pv[t][r], dpo = acc[t][r];
+        gsum += p * dpo;
+        const float dp = gz * dpo + (float)e8[hh * 4 + r];
+        acc[t][r] = dp;
+        dsum += p * dp;
+      }
     }
   }
   dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
@@ -239,8 +265,16 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) dsk[t][r] = (bf16)((float)pv[t][r] * (acc[t][r] - dsum));
-    const int kcol = t * 16 + g * 4;
-    if (qok && kcol < a.ldpr) *reinterpret_cast<bf16x4*>(a.dS + prow + kcol) = dsk[t];
+  }
+#pragma unroll
+  for (int s = 0; s < NT / 2; ++s) {
+    const int kcol = s * 32 + g * 8;
+    if (qok && kcol < a.ldpr) {
+      bf16x8 d8;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { d8[r] = dsk[2 * s][r]; d8[4 + r] = dsk[2 * s + 1][r]; }
+      *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
+    }
   }
   f32x4 o[4];
 #pragma unroll
