@@ -149,6 +149,52 @@ class FlatAdamW:
         return self.gnorm_sq.sqrt()
 
 
+class TensorAdamW:
+    """HF-AdamW over a handful of small tensors that stay where they are (one evlm_adamw_step launch per tensor, own
+    moment buffers) - the reference's l0_optimizer / lagrangian_optimizer (optim.py:4-21): the gate parameters and the
+    Lagrange multipliers are ALSO members of the main optimiser's groups (they are parameters of the model), so these
+    optimisers must not re-home them.  lr may be negative (gradient ascent on lambda_1 / lambda_2)."""
+
+    def __init__(self, named_params, lr, weight_decay=0.0, betas=(0.9, 0.98), eps=1e-8):
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        self.betas, self.eps = betas, eps
+        self.param_groups = [dict(params=self.params, lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)]
+        self.state = [dict(m=torch.zeros_like(p, dtype=torch.float32), v=torch.zeros_like(p, dtype=torch.float32))
+                      for p in self.params]
+        self.step_count = 0
+
+    def zero_grad(self):
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.zero_()
+
+    def step(self):
+        lib = L.load()
+        self.step_count += 1
+        b1, b2 = self.betas
+        g = self.param_groups[0]
+        c1, c2 = 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
+        for p, st in zip(self.params, self.state):
+            if p.grad is None:
+                continue
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+                raise RuntimeError("TensorAdamW: parameters must be contiguous fp32 CUDA tensors (no CPU fallback)")
+            L.check(lib.evlm_adamw_step(L.ptr(p.data), L.ptr(p.grad), L.ptr(st["m"]), L.ptr(st["v"]), p.numel(),
+                                        float(g["lr"]), b1, b2, self.eps, float(g["weight_decay"]), c1, c2, None, 0.0,
+                                        None, None, L.stream()), "adamw")
+
+
+def create_L0_optimizer(args, l0_module):
+    """optim.py:4-21 signature: (l0_optimizer over the gate log-alphas, lr = +reg_learning_rate;
+    lagrangian_optimizer over lambda_1 / lambda_2, lr = -reg_learning_rate)"""
+    get = (lambda k, d=None: args.get(k, d)) if isinstance(args, dict) else (lambda k, d=None: getattr(args, k, d))
+    reg = get("reg_learning_rate")
+    named = list(l0_module.named_parameters())
+    return (TensorAdamW([(n, p) for n, p in named if "lambda" not in n], lr=reg),
+            TensorAdamW([(n, p) for n, p in named if "lambda" in n], lr=-reg))
+
+
 def create_optimizer(args, model, max_grad_norm=1.0):
     """optim.py:23-69 signature (args.lr, args.weight_decay, args.lr_mult)"""
     get = (lambda k, d=None: args.get(k, d)) if isinstance(args, dict) else (lambda k, d=None: getattr(args, k, d))

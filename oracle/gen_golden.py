@@ -525,6 +525,42 @@ def gen_kd_helpers(seed):
     return fx
 
 
+def gen_optim(seed):
+    """parameter grouping of the reference's optimisers (optim.py:4-21 create_L0_optimizer, :23-69 create_optimizer) on
+    the tiny student models: which parameter NAME lands in which group with which lr / weight decay.  (The arithmetic of
+    the AdamW steps is transformers 4.12.5's, which this container does not have: the class is shimmed with
+    torch.optim.AdamW only to let the reference code build its groups.)"""
+    import utils
+    import optim as ref_optim
+    geom = synth.GEOMS["tiny"]
+    work = tempfile.mkdtemp(prefix="evlm_oracle_")
+    os.chdir(work)
+    scfg, tcfg = write_configs(work, geom)
+    FAKE.num_pos = (geom["image_res"] // 16) ** 2 + 1
+    FAKE.width = geom["hidden"]
+    from efficient_models.model_retrieval import EffXVLMforRetrieval
+    from models.model_pretrain import XVLM as PretrainXVLM
+    out = {}
+    args = utils.AttrDict(dict(lr=1e-4, weight_decay=0.01, lr_mult=2, reg_learning_rate=0.1))
+    for tag, model in (("itr_student", EffXVLMforRetrieval(scfg)), ("gd_student", PretrainXVLM(scfg))):
+        names = {id(p): n for n, p in model.named_parameters()}
+        opt = ref_optim.create_optimizer(args, model)
+        out[tag] = {"init_params": sorted(getattr(model, "init_params", []) or []),
+                    "groups": [{"lr": g["lr"], "weight_decay": g["weight_decay"],
+                                "names": [names[id(p)] for p in g["params"]]} for g in opt.param_groups]}
+        if hasattr(model, "l0_module"):
+            l0n = {id(p): n for n, p in model.l0_module.named_parameters()}
+            o1, o2 = ref_optim.create_L0_optimizer(args, model.l0_module)
+            out[tag + ".l0"] = [{"lr": g["lr"], "weight_decay": g["weight_decay"], "betas": list(g["betas"]), "eps": g["eps"],
+                                 "names": [l0n[id(p)] for p in g["params"]]} for g in o1.param_groups]
+            out[tag + ".lagrangian"] = [{"lr": g["lr"], "weight_decay": g["weight_decay"], "betas": list(g["betas"]),
+                                         "eps": g["eps"], "names": [l0n[id(p)] for p in g["params"]]}
+                                        for g in o2.param_groups]
+    main = ref_optim.create_optimizer(args, PretrainXVLM(scfg)).param_groups[0]
+    out["adamw_defaults"] = {"betas": list(main["betas"]), "eps": main["eps"]}
+    return out
+
+
 def save(name, fx):
     os.makedirs(OUT, exist_ok=True)
     p = os.path.join(OUT, name)
@@ -541,7 +577,12 @@ if __name__ == "__main__":
     os.environ.setdefault("MASTER_PORT", "29917")
     dist.init_process_group("gloo", rank=0, world_size=1)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["kd", "l0", "gd_tiny", "itr_tiny", "gd_full"]
+    which = sys.argv[1:] or ["kd", "l0", "gd_tiny", "itr_tiny", "gd_full", "optim"]
+    if "optim" in which:
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, "optim_groups.json"), "w") as f:
+            json.dump(gen_optim(7), f, indent=1, sort_keys=True)
+        print("wrote", os.path.join(OUT, "optim_groups.json"))
     if "kd" in which:
         save("kd_helpers.npz", gen_kd_helpers(5))
     if "l0" in which:
