@@ -191,3 +191,60 @@ class GDTrainer:
             g["m"].zero_()
             g["v"].zero_()
         self.opt.step_count = 0
+
+
+class ITRTrainer:
+    """Pruning fine-tune step of Eff_Retrieval.py:75-213 (image-text retrieval with hard-concrete L0 gates): student with
+    gates forward + backward, teacher forward, ITC + ITM + hidden / attention / cross-attention / logit KD, the Lagrangian
+    sparsity term, THREE optimisers (main AdamW over every student parameter - the gate parameters included, as in the
+    reference -, +reg_lr on the gate log-alphas, -reg_lr = ascent on lambda_1 / lambda_2; optim.py:4-69), no gradient
+    clipping (the reference calls optimizer.step() directly here), then constrain_parameters().  Eager launch: the
+    Lagrangian warm-up makes the step depend on a host-side counter."""
+
+    def __init__(self, student, teacher, lr=3e-5, weight_decay=0.01, lr_mult=2.0, reg_learning_rate=0.1,
+                 dtype=torch.float32, temperature=1.0):
+        import os
+        from .optim import create_L0_optimizer
+        self.student, self.teacher = student, teacher
+        self.dtype, self.temperature = dtype, temperature
+        for p in teacher.parameters():
+            p.requires_grad_(False)
+        teacher.eval()
+        student.train()
+        self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=0.0)
+        self.l0_opt, self.lagrangian_opt = create_L0_optimizer({"reg_learning_rate": reg_learning_rate}, student.l0_module)
+        self.reducer = GradReducer(self.opt.flat_grads)
+        self.defer_wgrad = dtype == torch.bfloat16 and not os.environ.get("EVLM_NO_DEFER_WGRAD")
+        self.global_step = 0
+
+    def step(self, batch, idx=None, lr_mult=1.0):
+        """batch: dict(image, text_ids, text_atts); idx: image ids for the soft ITC labels.  Returns a device tensor
+        [total, itc, itm, kd, lagrangian]."""
+        self.opt.zero_grad()
+        l0 = self.student.l0_module
+        with compute(self.dtype):
+            kw = dict(idx=idx, output_attentions=True, output_hidden_states=True)
+            S = self.student(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+            with torch.no_grad():
+                T = self.teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+            kd = distill.kd_terms(S, T, self.temperature, with_cross_attn=True)
+            lagrangian, _, _ = l0.lagrangian_regularization(self.global_step)
+            total, mix = distill.itr_loss_mix(S["loss"], kd, lagrangian)
+            ops.WGRAD_INPLACE = True
+            ops.WGRAD_DEFER = [] if self.defer_wgrad else None
+            try:
+                total.backward()
+                ops.flush_wgrad()
+            finally:
+                ops.WGRAD_INPLACE = False
+                ops.WGRAD_DEFER = None
+        self.reducer.reduce()
+        self.opt.set_schedule(lr_mult)
+        self.opt.step()
+        self.l0_opt.step()
+        self.lagrangian_opt.step()
+        l0.constrain_parameters()
+        self.global_step += 1
+        return torch.stack([total.detach().float(), S["loss"]["loss_itc"].detach().float(),
+                            S["loss"]["loss_itm"].detach().float(), mix["loss_kd"].detach().float(),
+                            lagrangian.detach().float().reshape(())])
