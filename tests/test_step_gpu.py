@@ -171,6 +171,20 @@ def test_itr_step_with_l0_fp32_matches_reference_vectors():
         itc_e, itm_e = student(batch["image"], batch["text_ids"], batch["text_atts"], idx=idx)
     close(itc_e, fx["eval.loss_itc"], 1e-4, 0, "eval itc")
     close(itm_e, fx["eval.loss_itm"], 1e-4, 0, "eval itm")
+    # physically pruned model: heads / FFN units with a zero gate removed, no gates at run time -> the
+    # REFERENCE's masked-dense eval losses
+    from efficientvlm_amd import pruning
+    n_before = sum(p.numel() for p in student.parameters())
+    with torch.no_grad():
+        pruning.update_params(student, zs)
+        pruning.prune_model_with_z(zs, student, pad_to=8)
+        student.injected_neg_idx = torch.from_numpy(fx["eval.neg_idx"])
+        itc_p, itm_p = pruning.retrieval_eval_losses(student, batch["image"], batch["text_ids"], batch["text_atts"], idx=idx)
+    assert sum(p.numel() for p in student.parameters()) < n_before
+    heads_kept = [l.self_attn.num_heads for l in student.vision_encoder.encoder.layers]
+    assert heads_kept == [int(fx["eval.z.vision_head_z"][i].sum()) for i in range(len(heads_kept))]
+    close(itc_p, fx["eval.loss_itc"], 1e-4, 0, "pruned itc")
+    close(itm_p, fx["eval.loss_itm"], 1e-4, 0, "pruned itm")
 
 
 def test_gd_step_matches_oracle_on_fresh_inputs():
