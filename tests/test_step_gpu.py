@@ -367,3 +367,45 @@ def test_itr_training_steps_match_oracle_forward_backward_plus_optimiser_restate
         assert float((d_mine - d_ref).norm()) <= 0.02 * float(d_ref.norm()), (n, float((d_mine - d_ref).norm()), float(d_ref.norm()))
         checked += 1
     assert checked == 6
+
+
+@pytest.mark.parametrize("with_gates", [False, True])
+def test_retrieval_evaluation_rerank_matches_oracle(with_gates):
+    """Eff_Retrieval.py:215-319 at tensor level (fp32, tiny geometry, 7 images x 11 texts, k_test = 4): score matrices of
+    the batched, K/V-sharing implementation against the oracle's one-query-at-a-time restatement, for one rank and for
+    the two shards of a 2-rank run (summed as the driver's all-reduce would)"""
+    from efficientvlm_amd.efficient_models.model_retrieval import EffXVLMforRetrieval
+    from efficientvlm_amd.retrieval_eval import evaluation_scores
+    from oracle import retrieval_eval_oracle as RO
+    geom = synth.GEOMS["tiny"]
+    s_cfg = O.model_cfg(geom, "s")
+    model = EffXVLMforRetrieval(model_config(geom, "s"))
+    sd = load_det_weights(model, schema.xvlm_schema(s_cfg, geom["max_pos"], mlm=False, bbox=False, l0=True), 21, geom["std"])
+    gen = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for n, p in model.l0_module.named_parameters():
+            if "lambda" not in n:
+                p.copy_(torch.randn(p.shape, generator=gen) * 3.0)
+            sd["l0_module." + n] = p.detach().clone()
+    model.to(DEV)
+    bi = synth.make_batch(geom, 7, seed=31, ragged=True)
+    bt = synth.make_batch(geom, 11, seed=32, ragged=True)
+    images, text_ids, text_atts = bi["image"], bt["text_ids"], bt["text_atts"]
+    zs_o = None
+    if with_gates:
+        logas = {k[len("l0_module."):]: v for k, v in sd.items() if k.endswith("_loga")}
+        zs_o = O.l0_forward(logas, False)
+    want = [RO.evaluation_scores(sd, s_cfg, images, text_ids, text_atts, 4, zs=zs_o, rank=r, world=w)
+            for r, w in ((0, 1), (0, 2), (1, 2))]
+    kw = dict(k_test=4, zs="auto" if with_gates else None, query_bs=3, reduce=False)
+    dimg, dids, datt = images.to(DEV), text_ids.to(DEV), text_atts.to(DEV)
+    got = [evaluation_scores(model, dimg, dids, datt, rank=r, world=w, **kw) for r, w in ((0, 1), (0, 2), (1, 2))]
+    for (wi, wt), (gi, gt) in zip(want, got):
+        assert torch.equal(gi.cpu() == -100.0, wi == -100.0) and torch.equal(gt.cpu() == -100.0, wt == -100.0)
+        assert torch.allclose(gi.cpu(), wi, rtol=2e-4, atol=2e-5) and torch.allclose(gt.cpu(), wt, rtol=2e-4, atol=2e-5)
+    # the driver's SUM all-reduce of the two shards
+    s_i, s_t = got[1][0] + got[2][0], got[1][1] + got[2][1]
+    full_i, full_t = want[0]
+    done = full_i != -100.0
+    assert torch.allclose(s_i.cpu()[done], full_i[done] - 100.0, rtol=2e-4, atol=1e-4)
+    assert torch.all(s_i.cpu()[~done] == -200.0) and torch.all(s_t.cpu()[full_t == -100.0] == -200.0)
