@@ -561,6 +561,36 @@ def gen_optim(seed):
     return out
 
 
+def gen_ckpt_remap(seed):
+    """checkpoint load / remap contract (efficient_models/xvlm.py:183-208 load_pretrained, models/vit.py:222-247
+    interpolate_pos_embed): a small synthetic checkpoint through the reference's own loader"""
+    import efficient_models.xvlm as rx
+    g = torch.Generator().manual_seed(seed)
+    ck = {"vision_encoder.position_ids": torch.arange(5)[None],
+          "vision_encoder.pos_embed.weight": torch.randn(5, 8, generator=g),            # 2x2 patches + cls
+          "vision_encoder.class_embedding": torch.randn(8, generator=g),
+          "text_encoder.bert.embeddings.word_embeddings.weight": torch.randn(11, 8, generator=g),
+          "text_encoder.bert.encoder.layer.0.attention.self.query.weight": torch.randn(8, 8, generator=g),
+          "text_encoder.cls.predictions.bias": torch.randn(11, generator=g),
+          "temp": torch.tensor(0.07)}
+    fx = {"in." + k: np_(v) for k, v in ck.items()}
+    work = tempfile.mkdtemp(prefix="evlm_oracle_")
+    path = os.path.join(work, "ckpt.th")
+    real_load = torch.load.__wrapped__ if hasattr(torch.load, "__wrapped__") else None
+    torch.save({"model": ck}, path)
+    cfg = {"image_res": 48, "patch_size": 16, "use_clip_vit": True}                     # 3x3 patches: 5 -> 10 tokens
+    out = rx.load_pretrained(path, cfg, is_eval=False, load_text=True)
+    for k, v in out.items():
+        fx["out." + k] = np_(v)
+    out_eval = rx.load_pretrained(path, cfg, is_eval=True, load_text=True)
+    fx["eval_keys"] = np.array(sorted(out_eval.keys()))
+    for n, res in ((9, "same"), (36, "up6")):
+        fx[f"interp.{res}"] = np_(rx.interpolate_pos_embed(torch.from_numpy(fx["in.vision_encoder.pos_embed.weight"])[None]
+                                                          if n != 9 else out["vision_encoder.pos_embed.weight"][None],
+                                                          num_patches=n, num_extra_tokens=1))
+    return fx
+
+
 def save(name, fx):
     os.makedirs(OUT, exist_ok=True)
     p = os.path.join(OUT, name)
@@ -577,7 +607,9 @@ if __name__ == "__main__":
     os.environ.setdefault("MASTER_PORT", "29917")
     dist.init_process_group("gloo", rank=0, world_size=1)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["kd", "l0", "gd_tiny", "itr_tiny", "gd_full", "optim"]
+    which = sys.argv[1:] or ["kd", "l0", "gd_tiny", "itr_tiny", "gd_full", "optim", "ckpt"]
+    if "ckpt" in which:
+        save("ckpt_remap.npz", gen_ckpt_remap(13))
     if "optim" in which:
         os.makedirs(OUT, exist_ok=True)
         with open(os.path.join(OUT, "optim_groups.json"), "w") as f:

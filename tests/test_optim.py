@@ -146,3 +146,28 @@ def test_l0_optimisers_descend_gates_and_ascend_multipliers():
     l0.constrain_parameters()
     assert abs(float(l0.vision_head_loga.max()) - math.log(1e2)) < 1e-6
     assert abs(float(l0.text_int_loga.min()) - math.log(1e-2)) < 1e-6
+
+
+def test_checkpoint_load_and_remap_match_the_reference_loader(tmp_path):
+    """efficient_models/xvlm.py:183-208 load_pretrained (drop position_ids, bicubic resize of the patch
+    position embeddings, strip `bert.` from text-encoder keys) and interpolate_pos_embed, against arrays produced by the
+    reference's own functions on a small synthetic checkpoint (tests/golden/ckpt_remap.npz)"""
+    import numpy as np
+    from helpers import load_fixture
+    from efficientvlm_amd.efficient_models.xvlm import interpolate_pos_embed, load_pretrained
+    fx = load_fixture("ckpt_remap.npz")
+    ck = {k[3:]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("in.")}
+    path = str(tmp_path / "ckpt.th")
+    torch.save({"model": ck}, path)
+    cfg = {"image_res": 48, "patch_size": 16, "use_clip_vit": True}
+    out = load_pretrained(path, cfg, is_eval=False, load_text=True)
+    want = {k[4:]: v for k, v in fx.items() if k.startswith("out.")}
+    assert sorted(out.keys()) == sorted(want.keys())
+    for k, v in want.items():
+        assert np.allclose(out[k].numpy(), v, rtol=1e-6, atol=1e-7), k
+    assert "text_encoder.embeddings.word_embeddings.weight" in out and out["vision_encoder.pos_embed.weight"].shape == (10, 8)
+    assert sorted(load_pretrained(path, cfg, is_eval=True, load_text=True).keys()) == list(fx["eval_keys"])
+    up = interpolate_pos_embed(ck["vision_encoder.pos_embed.weight"][None], num_patches=36, num_extra_tokens=1)
+    assert np.allclose(up.numpy(), fx["interp.up6"], rtol=1e-6, atol=1e-7)
+    same = interpolate_pos_embed(out["vision_encoder.pos_embed.weight"][None], num_patches=9, num_extra_tokens=1)
+    assert np.array_equal(same.numpy(), fx["interp.same"])
