@@ -232,6 +232,15 @@ template <bool FULL, int MODE>
 __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4], int b0, const PPRows& xr,
                                              bool need_h, bool need_r, int ic, int jb, int lane, char* sw, bf16* dst, int ldd) {
   const int il = lane & 15, jl = (lane >> 4) * 4;
+  f32x4 gz[4];                             // L0 FFN gate (per output column), fetched per chunk: L2-resident, 16 registers
+  const bool gated = MODE == 2 && g.gate != nullptr;
+  if (gated) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int j = jb + a * 16 + jl;
+      gz[a] = *reinterpret_cast<const f32x4*>(g.gate + (FULL ? j : min(j, g.J - 4)));
+    }
+  }
   if (need_h || need_r) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -252,9 +261,17 @@ __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4],
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = acc[a][b0 + bb][e] * g.alpha + bz[a][e];
       if (MODE == 2) {
+        if (gated && g.gate_pos == EVLM_GATE_PRE_ACT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= gz[a][e];
+        }
         if (g.act != EVLM_ACT_NONE) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = act_apply_fast(g.act, v[e]);
+        }
+        if (gated && g.gate_pos != EVLM_GATE_PRE_ACT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= gz[a][e];
         }
         if (need_h || need_r) {
           const bf16x4 xx = *reinterpret_cast<const bf16x4*>(cell);
@@ -568,7 +585,7 @@ bool evlm_gemm_pp256_eligible(const GemmP& g, int pt, int qt) {
   }
   if (g.psum) return false;
 #endif
-  if (pt || g.accumulate || g.gate) return false;
+  if (pt || g.accumulate) return false;
   if (g.dact != EVLM_ACT_NONE && g.residual) return false;
   if (g.J % 8 != 0 || g.ldc % 8 != 0) return false;
   if ((g.preact || g.aux || g.residual) && g.ldx % 8 != 0) return false;

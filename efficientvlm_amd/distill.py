@@ -103,6 +103,30 @@ def _tensors(obj):
             yield from _tensors(v)
 
 
+def student_and_teacher(student_call, teacher_call, ref_tensor, overlap):
+    """(student outputs, teacher outputs under no_grad); with `overlap` the teacher forward is issued on a second HIP
+    stream (joined before returning) so that it shares the chip with the student forward"""
+    if overlap and ref_tensor.is_cuda:
+        cur = torch.cuda.current_stream()
+        dev = ref_tensor.device
+        side = _SIDE.get(dev)
+        if side is None:
+            side = _SIDE[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            T = teacher_call()
+        S = student_call()
+        cur.wait_stream(side)
+        if not torch.cuda.is_current_stream_capturing():
+            for t in _tensors(T):          # allocated on the side stream, consumed on this one
+                t.record_stream(cur)
+        return S, T
+    S = student_call()
+    with torch.no_grad():
+        T = teacher_call()
+    return S, T
+
+
 def gd_forward(student, teacher, batch, temperature=1.0, overlap_teacher=False):
     """student forward (autograd on), teacher forward (no_grad), every KD term and the GD loss mix
     (GeneralDistill.py:289-376).  batch: dict(image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids).
@@ -112,24 +136,8 @@ def gd_forward(student, teacher, batch, temperature=1.0, overlap_teacher=False):
     share the chip with the student's instead of queueing behind them."""
     kw = dict(text_ids_masked=batch["text_ids_masked"], masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"],
               output_attentions=True, output_hidden_states=True)
-    if overlap_teacher and batch["image"].is_cuda:
-        cur = torch.cuda.current_stream()
-        dev = batch["image"].device
-        side = _SIDE.get(dev)
-        if side is None:
-            side = _SIDE[dev] = torch.cuda.Stream(device=dev)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side), torch.no_grad():
-            T = teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
-        S = student(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
-        cur.wait_stream(side)
-        if not torch.cuda.is_current_stream_capturing():
-            for t in _tensors(T):          # allocated on the side stream, consumed on this one
-                t.record_stream(cur)
-    else:
-        S = student(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
-        with torch.no_grad():
-            T = teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+    call = lambda m: m(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+    S, T = student_and_teacher(lambda: call(student), lambda: call(teacher), batch["image"], overlap_teacher)
     kd = kd_terms(S, T, temperature)
     total, mix = gd_loss_mix(S["loss"], kd)
     return total, S, T, kd, mix

@@ -215,6 +215,7 @@ class ITRTrainer:
         self.l0_opt, self.lagrangian_opt = create_L0_optimizer({"reg_learning_rate": reg_learning_rate}, student.l0_module)
         self.reducer = GradReducer(self.opt.flat_grads)
         self.defer_wgrad = dtype == torch.bfloat16 and not os.environ.get("EVLM_NO_DEFER_WGRAD")
+        self.overlap_teacher = not os.environ.get("EVLM_NO_OVERLAP_TEACHER")
         self.global_step = 0
 
     def step(self, batch, idx=None, lr_mult=1.0):
@@ -224,9 +225,10 @@ class ITRTrainer:
         l0 = self.student.l0_module
         with compute(self.dtype):
             kw = dict(idx=idx, output_attentions=True, output_hidden_states=True)
-            S = self.student(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
-            with torch.no_grad():
-                T = self.teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+            S, T = distill.student_and_teacher(
+                lambda: self.student(batch["image"], batch["text_ids"], batch["text_atts"], **kw),
+                lambda: self.teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw),
+                batch["image"], self.overlap_teacher)
             kd = distill.kd_terms(S, T, self.temperature, with_cross_attn=True)
             lagrangian, _, _ = l0.lagrangian_regularization(self.global_step)
             total, mix = distill.itr_loss_mix(S["loss"], kd, lagrangian)

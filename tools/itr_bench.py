@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2] on one GPU: the ITR pruning fine-tune step (Eff_Retrieval.py:train body = trainer.ITRTrainer:
+X-VLM-small student with L0 gates fwd+bwd, X-VLM-base teacher fwd, ITC + ITM + KD incl. cross-attention maps, Lagrangian,
+three optimisers), B = 64, 384x384 images (577 tokens), 30 text tokens, bf16, synthetic data, random init, eager launch."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from helpers import model_config
+from oracle import synth
+from efficientvlm_amd.trainer import ITRTrainer
+from efficientvlm_amd.efficient_models.model_retrieval import EffXVLMforRetrieval
+from efficientvlm_amd.models.model_retrieval import XVLM as TeacherITR
+res = int(sys.argv[1]) if len(sys.argv) > 1 else 384
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+geom = dict(synth.GEOMS["full"]); geom["image_res"] = res
+dev = torch.device("cuda")
+torch.manual_seed(0)
+student = EffXVLMforRetrieval(model_config(geom, "s", image_res=res)).to(dev)
+teacher = TeacherITR(model_config(geom, "t", image_res=res)).to(dev)
+student.l0_module.set_lagrangian_warmup_steps(100)
+tr = ITRTrainer(student, teacher, lr=3e-5, weight_decay=0.01, lr_mult=2, reg_learning_rate=0.1, dtype=torch.bfloat16)
+batch = {k: v.to(dev) for k, v in synth.make_batch(geom, B, seed=5).items()}
+idx = torch.arange(B, device=dev)
+for _ in range(3): out = tr.step(batch, idx=idx)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+K = 10
+for _ in range(K): out = tr.step(batch, idx=idx)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+print(json.dumps({"workload": "ITR pruning fine-tune step", "image_res": res, "batch": B, "ms_per_step": round(dt * 1e3, 2),
+                  "pairs_per_s": round(B / dt, 1), "losses[total,itc,itm,kd,lagrangian]": [round(float(x), 4) for x in out.tolist()]}))
