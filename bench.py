@@ -7,6 +7,11 @@ X-VLM-base teacher forward under no_grad, every KD loss, gradient reduction, glo
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W                  # N>1: one rank per GPU over RCCL
 
+The frozen teacher is pipelined one batch ahead of the student (GDTrainer(pipeline_teacher=True)): every
+timed step runs one teacher forward (on the next batch), one student forward + backward and one optimiser step; four
+distinct synthetic batches are fed round-robin and a priming call precedes the warm-up.  --no-pipeline runs both models on
+the same batch inside each step.
+
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     - the dominant kernel (the bf16 MFMA GEMM kernel with the largest share of the step): algorithmic FLOPs per
                  launch / its average launch duration, timed live with HIP events on the launch stream during one extra
@@ -157,6 +162,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE.json configs[1]: 64)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="teacher forward inside the same step as its student step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
@@ -182,20 +188,28 @@ def main():
     geom = synth.GEOMS["full"]
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     student, teacher = build(geom, dev, seed=1234)
+    pipelined = not args.no_pipeline
     trainer = GDTrainer(student, teacher, lr=1e-4, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=dtype,
-                        use_graph=not args.no_graph)
+                        use_graph=not args.no_graph, pipeline_teacher=pipelined)
     B = args.batch
-    batch = {k: v.to(dev) for k, v in synth.make_batch(geom, B, seed=42 + rank).items()}   # weak scaling: B per GPU
+    # weak scaling: B per GPU.  FOUR distinct synthetic batches, resident in HBM, fed round-robin: with the teacher
+    # pipelined one batch ahead of the student, every step runs the teacher on a batch the student has not seen yet
+    batches = [{k: v.to(dev) for k, v in synth.make_batch(geom, B, seed=42 + rank + 1000 * i).items()} for i in range(4)]
+    batch = batches[0]
+    it = 0
+    if pipelined:
+        trainer.step(batches[0])          # primes the pipeline (teacher outputs of the first batch); not a step
+        it = 1
 
     for _ in range(args.warmup):
-        out = trainer.step(batch)
+        out = trainer.step(batches[it % 4]); it += 1
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = trainer.step(batch)
+        out = trainer.step(batches[it % 4]); it += 1
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -219,6 +233,7 @@ def main():
                           "image": "224x224", "text_len": geom["L"], "masked": geom["M"], "batch_per_gpu": B,
                           "global_batch": B * world, "parallelism": f"dp{world}",
                           "launch": "eager" if (args.no_graph or world > 1 or force_dp) else "hipGraph replay",
+                          "teacher_pipelined": pipelined, "distinct_batches": 4,
                           "init": "random (reference init), no checkpoints"},
                "step_model_tflops": round(value * FLOPS_PER_PAIR / 1e12, 1),
                "step_mfma_frac": round(value * FLOPS_PER_PAIR / 1e12 / (PEAK_BF16_TFLOPS * world), 4),

@@ -103,6 +103,25 @@ def _tensors(obj):
             yield from _tensors(v)
 
 
+def kd_teacher_slots(T, S):
+    """[(dict name, key, index)] of the teacher tensors the GD KD terms read (kd_terms + get_cor_teacher), given the
+    student's output structure - what a pipelined trainer has to keep of a teacher forward"""
+    used = []
+    for hkey, akey in (("text_hidden_states", "text_attentions"), ("image_hidden_states", "image_attentions"),
+                       ("itm_pos_hidden_states", "itm_pos_attentions"), ("itm_neg_hidden_states", "itm_neg_attentions"),
+                       ("mlm_hidden_states", "mlm_attentions")):
+        if hkey not in S["hidden_dict"]:
+            continue
+        nt, ns = len(T["hidden_dict"][hkey]), len(S["hidden_dict"][hkey])
+        k = (nt - 1) // (ns - 1)
+        used += [("hidden_dict", hkey, i * k) for i in range(ns)]
+        nt, ns = len(T["attention_dict"][akey]), len(S["attention_dict"][akey])
+        k = nt // ns
+        used += [("attention_dict", akey, i * k + k - 1) for i in range(ns)]
+    used += [("logits_dict", key, None) for key in T["logits_dict"]]
+    return used
+
+
 def student_and_teacher(student_call, teacher_call, ref_tensor, overlap):
     """(student outputs, teacher outputs under no_grad); with `overlap` the teacher forward is issued on a second HIP
     stream (joined before returning) so that it shares the chip with the student forward"""
@@ -127,7 +146,7 @@ def student_and_teacher(student_call, teacher_call, ref_tensor, overlap):
     return S, T
 
 
-def gd_forward(student, teacher, batch, temperature=1.0, overlap_teacher=False):
+def gd_forward(student, teacher, batch, temperature=1.0, overlap_teacher=False, teacher_out=None):
     """student forward (autograd on), teacher forward (no_grad), every KD term and the GD loss mix
     (GeneralDistill.py:289-376).  batch: dict(image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids).
 
@@ -137,7 +156,10 @@ def gd_forward(student, teacher, batch, temperature=1.0, overlap_teacher=False):
     kw = dict(text_ids_masked=batch["text_ids_masked"], masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"],
               output_attentions=True, output_hidden_states=True)
     call = lambda m: m(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
-    S, T = student_and_teacher(lambda: call(student), lambda: call(teacher), batch["image"], overlap_teacher)
+    if teacher_out is not None:            # teacher outputs of THIS batch computed earlier (trainer: teacher pipelining)
+        S, T = call(student), teacher_out
+    else:
+        S, T = student_and_teacher(lambda: call(student), lambda: call(teacher), batch["image"], overlap_teacher)
     kd = kd_terms(S, T, temperature)
     total, mix = gd_loss_mix(S["loss"], kd)
     return total, S, T, kd, mix

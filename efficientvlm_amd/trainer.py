@@ -94,8 +94,15 @@ class GradReducer:
 
 class GDTrainer:
     def __init__(self, student, teacher, lr=1e-4, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, temperature=1.0,
-                 dtype=torch.bfloat16, use_graph=True, grad_compress=None):
+                 dtype=torch.bfloat16, use_graph=True, grad_compress=None, pipeline_teacher=False):
+        """pipeline_teacher: the frozen teacher's forward for batch i+1 runs (second stream) WHILE the student trains on
+        batch i - exact, since the teacher never changes; step(batch) then returns the losses of the batch passed to the
+        PREVIOUS call (None on the first call, which only primes the pipeline).  Every step still executes one teacher
+        forward, one student forward + backward and one optimiser step."""
         self.student, self.teacher = student, teacher
+        self.pipeline_teacher = pipeline_teacher
+        self._pipe = None
+        self._keep_ST, self._last_ST = False, None
         self.dtype, self.temperature = dtype, temperature
         for p in teacher.parameters():
             p.requires_grad_(False)
@@ -123,11 +130,13 @@ class GDTrainer:
                 dist.broadcast(g["p"], 0)
 
     # ---- the step body (pure device work) ----------------------------------------------------------
-    def _forward_backward(self, batch):
+    def _forward_backward(self, batch, teacher_out=None):
         self.opt.zero_grad()
         with compute(self.dtype):
             total, S, T, kd, mix = distill.gd_forward(self.student, self.teacher, batch, self.temperature,
-                                                      overlap_teacher=self.overlap_teacher)
+                                                      overlap_teacher=self.overlap_teacher, teacher_out=teacher_out)
+            if self._keep_ST:
+                self._last_ST = (S, T)
             ops.WGRAD_INPLACE = self.wgrad_inplace      # kernels sum parameter gradients straight into the flat slabs
             ops.WGRAD_DEFER = [] if (self.wgrad_inplace and self.defer_wgrad) else None   # ... dW products grouped per K
             try:
@@ -148,17 +157,124 @@ class GDTrainer:
             ops.flush_wgrad()                 # the queued text / fusion weight gradients must be in the slabs first
             self.reducer.reduce_async(self._early)
 
-    def _step_eager(self, batch):
+    def _step_eager(self, batch, teacher_out=None):
         self._early_sent = False
-        out = self._forward_backward(batch)
+        out = self._forward_backward(batch, teacher_out)
         if self.reducer.active:
             self.reducer.reduce_async(self._late if self._early_sent else self.opt.flat_grads)
             self.reducer.finish()
         self.opt.step()
         return out
 
+    # ---- teacher pipelining ------------------------------------------------------------------------
+    def _pipe_prime(self, batch):
+        """static batch buffers x2, two eager warm-up steps (lr 0), the teacher outputs of the first batch in persistent
+        buffers x2 (only the tensors the KD terms read; attention maps keep their padded rows)"""
+        B = [{k: v.clone() for k, v in batch.items()} for _ in range(2)]
+        self._keep_ST = True
+        warm = torch.cuda.Stream()                         # warm-up on a side stream, as torch.cuda.graph asks for
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):
+            for _ in range(2):
+                self.opt.set_schedule(0.0)
+                self._step_eager(B[0])
+        torch.cuda.current_stream().wait_stream(warm)
+        self._keep_ST = False
+        torch.cuda.synchronize()
+        for g in self.opt.groups:
+            g["m"].zero_(); g["v"].zero_()
+        self.opt.step_count = 0
+        S, T = self._last_ST
+        slots = distill.kd_teacher_slots(T, S)
+        dummy = torch.zeros(0, device=batch["image"].device)
+
+        def persist():
+            out = {"loss": {}, "hidden_dict": {k: [dummy] * len(v) for k, v in T["hidden_dict"].items()},
+                   "attention_dict": {k: [dummy] * len(v) for k, v in T["attention_dict"].items()},
+                   "cross_attention_dict": {}, "logits_dict": {}}
+            for d, key, i in slots:
+                t = T[d][key] if i is None else T[d][key][i]
+                base = ops._padded_base(t)
+                buf = torch.empty_like(base)[..., :t.shape[-1]] if base is not None else torch.empty_like(t.contiguous())
+                if i is None:
+                    out[d][key] = buf
+                else:
+                    out[d][key][i] = buf
+            return out
+        self._pipe = dict(B=B, T=[persist(), persist()], slots=slots, k=0, graphs=[None, None], out=[None, None],
+                          side=torch.cuda.Stream())
+        self._last_ST = None
+        del S, T
+        self._pipe_teacher(0, warm)                            # teacher outputs of the first batch
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+        if self.use_graph and not self.reducer.active:         # both parities captured now: later calls only replay
+            ops.CACHE.invalidate()
+            pool = None
+            for k in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    self._pipe["out"][k] = self._pipe_body(k)
+                self._pipe["graphs"][k] = g
+                pool = g.pool()
+
+    def _pipe_teacher(self, k, stream):
+        """teacher forward on batch buffer k -> persistent outputs k (runs on `stream`)"""
+        st = self._pipe
+        b = st["B"][k]
+        with torch.cuda.stream(stream), torch.no_grad(), compute(self.dtype):
+            T = self.teacher(b["image"], b["text_ids"], b["text_atts"], text_ids_masked=b["text_ids_masked"],
+                             masked_pos=b["masked_pos"], masked_ids=b["masked_ids"], output_attentions=True,
+                             output_hidden_states=True)
+            for d, key, i in st["slots"]:
+                src = T[d][key] if i is None else T[d][key][i]
+                dst = st["T"][k][d][key] if i is None else st["T"][k][d][key][i]
+                sb, db = ops._padded_base(src), ops._padded_base(dst)
+                if sb is not None and db is not None:
+                    db.copy_(sb)
+                else:
+                    dst.copy_(src)
+
+    def _pipe_body(self, k):
+        """student step on (batch k, teacher outputs k) with the teacher forward of batch 1-k in flight on the side stream"""
+        st = self._pipe
+        cur, side = torch.cuda.current_stream(), st["side"]
+        side.wait_stream(cur)
+        self._pipe_teacher(1 - k, side)
+        out = self._step_eager_no_opt(st["B"][k], st["T"][k])
+        cur.wait_stream(side)
+        self.opt.step()
+        return out
+
+    def _step_eager_no_opt(self, batch, teacher_out):
+        self._early_sent = False
+        out = self._forward_backward(batch, teacher_out)
+        if self.reducer.active:
+            self.reducer.reduce_async(self._late if self._early_sent else self.opt.flat_grads)
+            self.reducer.finish()
+        return out
+
+    def _step_pipelined(self, batch, lr_mult):
+        if self._pipe is None:
+            self._pipe_prime(batch)
+            return None
+        st = self._pipe
+        k = st["k"]
+        for name, v in batch.items():
+            st["B"][1 - k][name].copy_(v, non_blocking=True)
+        self.opt.set_schedule(lr_mult)
+        if not self.use_graph or self.reducer.active:
+            out = self._pipe_body(k)
+        else:
+            st["graphs"][k].replay()
+            out = st["out"][k]
+        st["k"] = 1 - k
+        return out
+
     def step(self, batch, lr_mult=1.0):
         """one GD step; returns a device tensor [total, itc, itm, mlm, kd] (no host sync)."""
+        if self.pipeline_teacher:
+            return self._step_pipelined(batch, lr_mult)
         if not self.use_graph or self.reducer.active:
             # multi-GPU: the step runs eagerly - RCCL collectives cannot be captured into a hipGraph on this stack
             # (tools/rccl_graph_probe.py crashes), and the eager step is GPU-bound anyway (same ms/step as the replay).
