@@ -158,7 +158,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE.json configs[1]: 64)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
@@ -240,6 +240,23 @@ def main():
                "last_losses": {"total": losses[0], "itc": losses[1], "itm": losses[2], "mlm": losses[3], "kd": losses[4]}}
         if not args.no_roofline and dtype == torch.bfloat16:
             res["roofline"] = roofline_leg(trainer, batch)
+        if world == 1 and pipelined and not args.no_roofline:
+            # the same step WITHOUT teacher pipelining (both models on the same batch inside each step), for reference
+            del trainer
+            s2, t2 = build(geom, dev, seed=1234)
+            tr2 = GDTrainer(s2, t2, lr=1e-4, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=dtype,
+                            use_graph=not args.no_graph, pipeline_teacher=False)
+            for i in range(3):
+                tr2.step(batches[i % 4])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n2 = min(args.steps, 10)
+            for i in range(n2):
+                tr2.step(batches[i % 4])
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t1
+            res["unpipelined"] = {"value": round(B * n2 / e2, 2), "unit": "pairs/s", "ms_per_step": round(e2 / n2 * 1e3, 3),
+                                  "steps": n2}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
