@@ -7,8 +7,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 bench.py > $OUT/bench_default.log 2>&1
 tail -1 $OUT/bench_default.log > $OUT/bench_1gpu.json
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/kt.log 2>&1
-python3 tools/rocpd_stats.py $OUT/kt/kt_results.db 14 $OUT/kernel_stats.csv 60 > $OUT/kernel_stats.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/kt.log 2>&1
+python3 tools/rocpd_stats.py $OUT/kt/kt_results.db 31 $OUT/kernel_stats.csv 60 > $OUT/kernel_stats.txt 2>&1
 grep -o "{\"metric.*" $OUT/kt.log > $OUT/bench_under_rocprof.json
 rm -rf $OUT/kt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf -o pf -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $OUT/pf.log 2>&1
