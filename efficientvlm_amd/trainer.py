@@ -128,6 +128,8 @@ class GDTrainer:
         if self.world > 1:
             for g in self.opt.groups:                     # broadcast params from rank 0 (apex_ddp_accelerator.py:75-77)
                 dist.broadcast(g["p"], 0)
+                if g.get("pb") is not None:               # ... and re-derive the bf16 mirror the GEMMs read
+                    ops.CACHE.refresh_slab(g["p"], g["pb"])
 
     # ---- the step body (pure device work) ----------------------------------------------------------
     def _forward_backward(self, batch, teacher_out=None):
