@@ -244,8 +244,8 @@ class GDTrainer:
         side.wait_stream(cur)
         self._pipe_teacher(1 - k, side)
         out = self._step_eager_no_opt(st["B"][k], st["T"][k])
+        self.opt.step()                       # touches student state only: the teacher may still be running beside it
         cur.wait_stream(side)
-        self.opt.step()
         return out
 
     def _step_eager_no_opt(self, batch, teacher_out):
