@@ -10,7 +10,7 @@ from . import ops
 
 def get_cor_teacher(teacher_reps, student_reps, is_attn=False):
     """GeneralDistill.py:91-104: teacher layer -> student layer map (every k-th state / last map of each block)"""
-    teacher_reps = [t.detach() for t in teacher_reps]
+    teacher_reps = [t.detach() if t is not None else None for t in teacher_reps]    # (None: a map the teacher skipped)
     nt, ns = len(teacher_reps), len(student_reps)
     if is_attn:
         assert nt % ns == 0

@@ -208,16 +208,19 @@ class BertLayer(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_value=None, output_attentions=False, head_z=None,
-                head_layer_z=None, mlp_z=None, encoder_batch_index=None):
+                head_layer_z=None, mlp_z=None, encoder_batch_index=None, keep_self_map=True, keep_cross_map=True):
+        """keep_self_map / keep_cross_map (extension, default = reference behaviour): with output_attentions set, a map
+        that is not kept is not materialised and its slot in the returned tuple holds None"""
         if self.has_cross_attention and head_z is not None:
             assert isinstance(head_z, tuple)
             head_z, cross_head_z = head_z
         else:
             cross_head_z = None
+        want_self = bool(output_attentions) and keep_self_map
         self_attention_outputs = self.attention(hidden_states, attention_mask, head_mask,
-                                                output_attentions=output_attentions, head_z=head_z, head_layer_z=head_layer_z)
+                                                output_attentions=want_self, head_z=head_z, head_layer_z=head_layer_z)
         attention_output = self_attention_outputs[0]
-        outputs = self_attention_outputs[1:-1]
+        outputs = self_attention_outputs[1:-1] if want_self else ((None,) if output_attentions else ())
         if self.has_cross_attention:
             assert encoder_hidden_states is not None, "encoder_hidden_states must be given for cross-attention layers"
             if type(encoder_hidden_states) == list:                               # eff_bert.py:517-527
@@ -225,11 +228,12 @@ class BertLayer(nn.Module):
                 enc, enc_mask = encoder_hidden_states[k], encoder_attention_mask[k]
             else:
                 enc, enc_mask = encoder_hidden_states, encoder_attention_mask
+            want_cross = bool(output_attentions) and keep_cross_map
             cross_attention_outputs = self.crossattention(attention_output, attention_mask, head_mask, enc, enc_mask,
-                                                          output_attentions=output_attentions, head_z=cross_head_z,
+                                                          output_attentions=want_cross, head_z=cross_head_z,
                                                           encoder_batch_index=encoder_batch_index)
             attention_output = cross_attention_outputs[0]
-            outputs = outputs + cross_attention_outputs[1:-1]
+            outputs = outputs + (cross_attention_outputs[1:-1] if want_cross else ((None,) if output_attentions else ()))
         self.mlp_z = mlp_z
         layer_output = self.feed_forward_chunk(attention_output)
         return (layer_output,) + outputs + (None,)
@@ -250,6 +254,10 @@ class BertEncoder(nn.Module):
         self.config = config
         self.layer = nn.ModuleList([BertLayer(config, i) for i in range(config.num_hidden_layers)])
         self.fusion_layer = self.config.fusion_layer
+        # extension (None = the reference's behaviour): absolute layer indices whose self- / cross-attention maps are
+        # materialised when output_attentions is set (see BertLayer.forward)
+        self.attn_keep = None
+        self.cross_keep = None
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_values=None, use_cache=None, output_attentions=False,
@@ -283,7 +291,9 @@ class BertEncoder(nn.Module):
             layer_outputs = layer_module(hidden_states, attention_mask, None, encoder_hidden_states, encoder_attention_mask,
                                          None, output_attentions, head_z=cur_head_z if head_z is not None else None,
                                          mlp_z=cur_mlp_z if mlp_z is not None else None,
-                                         encoder_batch_index=encoder_batch_index)
+                                         encoder_batch_index=encoder_batch_index,
+                                         keep_self_map=self.attn_keep is None or i in self.attn_keep,
+                                         keep_cross_map=self.cross_keep is None or i in self.cross_keep)
             hidden_states = layer_outputs[0]
             if output_attentions:
                 all_self_attentions = all_self_attentions + (layer_outputs[1],)

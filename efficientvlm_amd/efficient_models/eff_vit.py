@@ -159,6 +159,9 @@ class CLIPEncoder(nn.Module):
         super().__init__()
         self.depth = num_hidden_layers
         self.local_attn_depth = local_attn_depth
+        # extension (None = the reference's behaviour): the set of layers whose attention map is materialised when
+        # output_attentions is set; the others return None in their slot (a frozen teacher whose other maps nobody reads)
+        self.attn_keep = None
         self.layers = nn.ModuleList([CLIPEncoderLayer(hidden_size, hidden_act, num_attention_heads, attention_dropout,
                                                       intermediate_size) for _ in range(num_hidden_layers)])
 
@@ -178,7 +181,8 @@ class CLIPEncoder(nn.Module):
         for idx, encoder_layer in enumerate(self.layers):
             if output_hidden_states:
                 encoder_states = encoder_states + (hidden_states,)
-            kw = dict(output_attentions=output_attentions,
+            want_map = bool(output_attentions) and (self.attn_keep is None or idx in self.attn_keep)
+            kw = dict(output_attentions=want_map,
                       head_z=head_z[idx] if head_z is not None else None,
                       head_layer_z=head_layer_z[idx] if head_layer_z is not None else None,
                       mlp_z=mlp_z[idx] if mlp_z is not None else None)
@@ -192,7 +196,7 @@ class CLIPEncoder(nn.Module):
                 layer_outputs = encoder_layer(hidden_states, attention_mask=None, **kw)
             hidden_states = layer_outputs[0]
             if output_attentions:
-                all_attentions = all_attentions + (layer_outputs[1],)
+                all_attentions = all_attentions + ((layer_outputs[1] if want_map else None),)
         if output_hidden_states:
             encoder_states = encoder_states + (hidden_states,)
         return (hidden_states, encoder_states, all_attentions)

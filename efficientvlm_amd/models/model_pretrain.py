@@ -79,7 +79,7 @@ class XVLM(XVLMBase):
         t = core(torch.cat([text_ids, text_ids_masked], 0), attention_mask=torch.cat([text_atts, text_atts], 0),
                  return_dict=True, mode="text", output_attentions=True, output_hidden_states=True)
         # torch.split, not slices: its backward is ONE concatenation per tensor (a slice's is zero-fill + copy + add)
-        halves = lambda tup: tuple(zip(*[torch.split(x, [B, B], 0) for x in tup]))
+        halves = lambda tup: tuple(zip(*[torch.split(x, [B, B], 0) if x is not None else (None, None) for x in tup]))
         text_hidden_states, mlm_text_hidden = halves(t.hidden_states)
         if t.hidden_states[-1] is t.last_hidden_state:
             text_embeds, mlm_text = text_hidden_states[-1], mlm_text_hidden[-1]
@@ -100,7 +100,8 @@ class XVLM(XVLMBase):
         f = core(encoder_embeds=txt_all, attention_mask=atts_all, encoder_hidden_states=image_embeds,
                  encoder_attention_mask=torch.index_select(image_atts, 0, img_index), encoder_batch_index=img_index,
                  return_dict=True, mode="fusion", output_attentions=True, output_hidden_states=True)
-        thirds = lambda tup: tuple(zip(*[torch.split(x, [B, 2 * B, B], 0) for x in tup]))   # pos | neg | mlm
+        thirds = lambda tup: tuple(zip(*[torch.split(x, [B, 2 * B, B], 0) if x is not None else (None, None, None)
+                                         for x in tup]))                                       # pos | neg | mlm
         f_hid, f_att, f_cross = thirds(f.hidden_states), thirds(f.attentions), thirds(f.cross_attentions)
         last = f.last_hidden_state
         itm_logits = mlp_head_forward(self.itm_head, last[:3 * B, 0, :])

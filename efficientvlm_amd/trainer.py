@@ -92,6 +92,29 @@ class GradReducer:
         self.finish()
 
 
+def teacher_map_filter(student, teacher, with_cross):
+    """The KD terms read every k-th attention map of the (deeper) teacher (get_cor_teacher: map i*k + k-1 for student map i;
+    GD reads no cross-attention map, the ITR fine-tune does): tell the frozen teacher's encoders to materialise only those.
+    The other layers then run without writing their [B, H, Lq, Lk] probabilities to HBM (60 MB per ViT layer at B = 64)."""
+    sv, tv = getattr(student.vision_encoder, "encoder", None), getattr(teacher.vision_encoder, "encoder", None)
+    if sv is not None and tv is not None and hasattr(tv, "attn_keep"):
+        ns, nt = len(sv.layers), len(tv.layers)
+        if nt % ns == 0:
+            k = nt // ns
+            tv.attn_keep = {i * k + k - 1 for i in range(ns)}
+    sc = student.text_encoder.bert if hasattr(student.text_encoder, "bert") else student.text_encoder
+    tc = teacher.text_encoder.bert if hasattr(teacher.text_encoder, "bert") else teacher.text_encoder
+    se, te = sc.encoder, tc.encoder
+    if hasattr(te, "attn_keep"):
+        fs, ft = se.fusion_layer, te.fusion_layer
+        ls, lt = len(se.layer), len(te.layer)
+        if ft % fs == 0 and (lt - ft) % (ls - fs) == 0:
+            k1, k2 = ft // fs, (lt - ft) // (ls - fs)
+            keep = {i * k1 + k1 - 1 for i in range(fs)} | {ft + i * k2 + k2 - 1 for i in range(ls - fs)}
+            te.attn_keep = keep
+            te.cross_keep = ({l for l in keep if l >= ft} if with_cross else set())
+
+
 class GDTrainer:
     def __init__(self, student, teacher, lr=1e-4, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, temperature=1.0,
                  dtype=torch.bfloat16, use_graph=True, grad_compress=None, pipeline_teacher=False):
@@ -120,6 +143,8 @@ class GDTrainer:
         self.use_graph = use_graph
         self.wgrad_inplace = True
         import os
+        if not os.environ.get("EVLM_TEACHER_ALL_MAPS"):
+            teacher_map_filter(student, teacher, with_cross=False)
         self.defer_wgrad = self.dtype == torch.bfloat16 and not os.environ.get("EVLM_NO_DEFER_WGRAD")
         self.overlap_teacher = not os.environ.get("EVLM_NO_OVERLAP_TEACHER")     # teacher forward on a second stream
         self.graph = None
@@ -334,6 +359,8 @@ class ITRTrainer:
         self.reducer = GradReducer(self.opt.flat_grads)
         self.defer_wgrad = dtype == torch.bfloat16 and not os.environ.get("EVLM_NO_DEFER_WGRAD")
         self.overlap_teacher = not os.environ.get("EVLM_NO_OVERLAP_TEACHER")
+        if not os.environ.get("EVLM_TEACHER_ALL_MAPS"):
+            teacher_map_filter(student, teacher, with_cross=True)
         self.global_step = 0
 
     def step(self, batch, idx=None, lr_mult=1.0):
