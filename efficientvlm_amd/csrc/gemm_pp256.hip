@@ -16,15 +16,17 @@
 //     other group's wave on that SIMD issues its memory work - the MFMA pipe alternates between the two waves.
 //   * One K tile (64 deep) = 4 phases = the four 64x32 quadrants of the wave's C block (i-lo x j-lo, i-lo x j-hi,
 //     i-hi x j-hi, i-hi x j-lo): phase 0 reads the i-lo P fragments and the j-lo Q fragments, phase 1 the j-hi Q
-//     fragments, phase 2 the i-hi P fragments (over the i-lo registers), phase 3 nothing.
+//     fragments (over the j-lo registers), phase 2 the i-hi P fragments (over the i-lo registers), phase 3 the j-lo Q
+//     fragments again.
 //   * LDS: 2 buffers x 4 units of 16 KiB.  A unit is what ONE phase consumes - PL / PH: the i-lo / i-hi 64 rows of both
 //     wave groups, QL / QH: the j-lo / j-hi 32 columns of all four wave columns - as [128 rows][64 k] with the 16-byte
 //     chunks XOR-swizzled by (row >> 1) & 7 (conflict-free ds_read_b128).  It is filled by 2 global_load_lds_dwordx4 per
 //     wave (the swizzle is applied to the per-lane SOURCE address; the LDS image of a wave instruction is linear).
-//   * Staging order in time is PL(t) QL(t) QH(t) PH(t) PL(t+1) ... one unit per phase: phase 0 of K tile t issues QH(t+1),
-//     phase 1 PH(t+1), phase 2 PL(t+2), phase 3 QL(t+2) - each into the region whose last reader finished at least one
-//     full phase earlier (WAR: a unit read in phase r is free after both groups' reads retired, i.e. from phase r+2) and
-//     five phases before its consumer.  RAW: every wave waits `vmcnt(8)` (the four younger units stay in flight) in the
+//   * Staging order in time is PL(t) QH(t) PH(t) QL(t) PL(t+1) ... one unit per phase: phase 0 of K tile t issues PH(t+1),
+//     phase 1 QL(t+1), phase 2 PL(t+2), phase 3 QH(t+2) - each into the region whose last reader finished at least one
+//     full phase earlier (WAR: a unit read in phase r is free after both groups' reads retired, i.e. from phase r+2;
+//     QL is read in phases 0 AND 3) and 3-6 phases before its consumer (the short lead is QL's: the weight operand,
+//     L2-resident).  RAW: every wave waits a counted `vmcnt` (10, 10, -, 4: the younger units stay in flight) in the
 //     phase BEFORE the consuming one, ahead of that phase's first barrier, so both groups have passed a barrier that
 //     follows every wave's wait before either reads the unit.
 //
@@ -42,7 +44,10 @@
 #define OFF_QH (3 * PPU)
 #define PP_EPI_OFF (2 * PPB)          // 8 x 4 KiB epilogue windows behind the staging buffers (160 KiB of LDS in total)
 
-struct PPSrc { int pl[2], ph[2], ql[2], qh[2]; };   // per-lane source element offsets of the 2 x 16 bytes staged per unit
+// per-lane source BYTE offsets (unsigned 32-bit) of the 2 x 16 bytes staged per unit.  The LDS-DMA address is formed as
+// (wave-uniform 64-bit base: operand + K tile) + zero-extended per-lane offset, i.e. the SGPR-base + VGPR-offset form of
+// global_load_lds: no 64-bit vector address arithmetic in the K loop and no address registers carried through it
+struct PPSrc { uint32_t pl[2], ph[2], ql[2], qh[2]; };
 
 // tile row (P units) / tile column (Q units) of unit row u
 __device__ __forceinline__ int pp_prow(int u, int hi) { return (u >> 6) * 128 + (u & 63) + hi * 64; }
@@ -62,12 +67,12 @@ __device__ __forceinline__ void pp_src(const GemmP& g, int i0, int j0, int tid, 
       const int u = id >> 3, cp = id & 7;
       const int koff = (cp ^ ((u >> 1) & 7)) << 3;
       if (!PT) {
-        s.pl[c] = min(i0 + pp_prow(u, 0), g.I - 1) * g.ldp + koff;
-        s.ph[c] = min(i0 + pp_prow(u, 1), g.I - 1) * g.ldp + koff;
+        s.pl[c] = (uint32_t)(min(i0 + pp_prow(u, 0), g.I - 1) * g.ldp + koff) * 2u;
+        s.ph[c] = (uint32_t)(min(i0 + pp_prow(u, 1), g.I - 1) * g.ldp + koff) * 2u;
       }
       if (!QT) {
-        s.ql[c] = min(j0 + pp_qcol(u, 0), g.J - 1) * g.ldq + koff;
-        s.qh[c] = min(j0 + pp_qcol(u, 1), g.J - 1) * g.ldq + koff;
+        s.ql[c] = (uint32_t)(min(j0 + pp_qcol(u, 0), g.J - 1) * g.ldq + koff) * 2u;
+        s.qh[c] = (uint32_t)(min(j0 + pp_qcol(u, 1), g.J - 1) * g.ldq + koff) * 2u;
       }
     }
     {
@@ -75,23 +80,25 @@ __device__ __forceinline__ void pp_src(const GemmP& g, int i0, int j0, int tid, 
       const int u0 = (cp ^ pp_trswz(kr)) << 3;
       if (PT) {
         const int lim = ((g.I + 7) & ~7) - 8;
-        s.pl[c] = kr * g.ldp + min(i0 + pp_prow(u0, 0), lim);
-        s.ph[c] = kr * g.ldp + min(i0 + pp_prow(u0, 1), lim);
+        s.pl[c] = (uint32_t)(kr * g.ldp + min(i0 + pp_prow(u0, 0), lim)) * 2u;
+        s.ph[c] = (uint32_t)(kr * g.ldp + min(i0 + pp_prow(u0, 1), lim)) * 2u;
       }
       if (QT) {
         const int lim = ((g.J + 7) & ~7) - 8;
-        s.ql[c] = kr * g.ldq + min(j0 + pp_qcol(u0, 0), lim);
-        s.qh[c] = kr * g.ldq + min(j0 + pp_qcol(u0, 1), lim);
+        s.ql[c] = (uint32_t)(kr * g.ldq + min(j0 + pp_qcol(u0, 0), lim)) * 2u;
+        s.qh[c] = (uint32_t)(kr * g.ldq + min(j0 + pp_qcol(u0, 1), lim)) * 2u;
       }
     }
   }
 }
 
+// base: wave-uniform operand pointer, kel: wave-uniform element offset of the K tile, so: per-lane byte offsets
 #define PP_GLDS(base, so, kel, ldsoff)                                                                              \
   do {                                                                                                              \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((base) + ((so)[0] + (kel))),   \
+    const char* ub__ = reinterpret_cast<const char*>((base) + (size_t)(kel));                                       \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub__ + (so)[0]),               \
                                      (__attribute__((address_space(3))) void*)(smem + (ldsoff) + wave * 1024), 16, 0, 0); \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((base) + ((so)[1] + (kel))),   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub__ + (so)[1]),               \
                                      (__attribute__((address_space(3))) void*)(smem + (ldsoff) + (8 + wave) * 1024), 16, 0, 0); \
   } while (0)
 
@@ -158,8 +165,52 @@ __device__ __forceinline__ int pp_lane_base(int lane, int wsel) {
     _Pragma("unroll") for (int e = 0; e < 8; ++e) PS[(BO) + b] += (float)pf[b][ks][e];                     \
   }
 
-// one K tile out of buffer BUF (compile-time LDS offsets); K tile index t of nt, operands at Pk / Qk
+// one K tile out of buffer BUF (compile-time LDS offsets); K tile index t of nt, operands at Pk / Qk.
+// The j-lo Q fragments are read TWICE (phases 0 and 3) instead of being carried through phases 1-2: 16 registers less at
+// the peak, which is what keeps the kernel's long-lived values (next-tile offsets, epilogue pointers) out of scratch, and
+// phase 3 gets LDS reads of its own (it had none), evening out the memory sections the partner wave's MFMAs have to cover.
 #define PP_KTILE(BUF, t)                                                                                   \
+  do {                                                                                                     \
+    constexpr int B0 = (BUF) * PPB, B1 = ((BUF) ^ 1) * PPB;                                                \
+    const bool n1 = (t) + 1 < nt, n2 = (t) + 2 < nt;                                                       \
+    /* ---- phase 0: i-lo x j-lo ; stage PH(t+1) ---- */                                                   \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
+      qf[a][0] = pp_frag<QT>(smem, B0 + OFF_QL, qlb, a, 0);                                                \
+      qf[a][1] = pp_frag<QT>(smem, B0 + OFF_QL, qlb, a, 1); }                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                        \
+      pf[b][0] = pp_frag<PT>(smem, B0 + OFF_PL, plb, b, 0);                                                \
+      pf[b][1] = pp_frag<PT>(smem, B0 + OFF_PL, plb, b, 1); }                                              \
+    if (n1) PP_GLDS(Pk, src.ph, ((t) + 1) * kp, B1 + OFF_PH);                                              \
+    if (n1) PP_WAIT(10); else PP_WAIT(4);                                                                  \
+    PP_MFMA_BEGIN(); PP_QUAD(accL, 0, qf); PP_PSUM(ps, 0); PP_MFMA_END();                                  \
+    /* ---- phase 1: i-lo x j-hi ; stage QL(t+1) ---- */                                                   \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
+      qf[a][0] = pp_frag<QT>(smem, B0 + OFF_QH, qlb, a, 0);                                                \
+      qf[a][1] = pp_frag<QT>(smem, B0 + OFF_QH, qlb, a, 1); }                                              \
+    if (n1) PP_GLDS(Qk, src.ql, ((t) + 1) * kq, B1 + OFF_QL);                                              \
+    if (n1) PP_WAIT(10); else PP_WAIT(2);                                                                  \
+    PP_MFMA_BEGIN(); PP_QUAD(accL, 2, qf); PP_MFMA_END();                                                  \
+    /* ---- phase 2: i-hi x j-hi ; stage PL(t+2) ---- */                                                   \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                        \
+      pf[b][0] = pp_frag<PT>(smem, B0 + OFF_PH, plb, b, 0);                                                \
+      pf[b][1] = pp_frag<PT>(smem, B0 + OFF_PH, plb, b, 1); }                                              \
+    if (n2) PP_GLDS(Pk, src.pl, ((t) + 2) * kp, B0 + OFF_PL);                                              \
+    PP_MFMA_BEGIN(); PP_QUAD(accH, 2, qf); PP_PSUM(ps, 4); PP_MFMA_END();                                  \
+    /* ---- phase 3: i-hi x j-lo (j-lo fragments read again) ; stage QH(t+2) ---- */                       \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
+      qf[a][0] = pp_frag<QT>(smem, B0 + OFF_QL, qlb, a, 0);                                                \
+      qf[a][1] = pp_frag<QT>(smem, B0 + OFF_QL, qlb, a, 1); }                                              \
+    if (n2) PP_GLDS(Qk, src.qh, ((t) + 2) * kq, B0 + OFF_QH);                                              \
+    if (n2) PP_WAIT(4); else if (n1) PP_WAIT(0);                                                           \
+    PP_MFMA_BEGIN(); PP_QUAD(accH, 0, qf); PP_MFMA_END();                                                  \
+  } while (0)
+
+// Variant that HOLDS the j-lo Q fragments through phases 1-2 (no second read; staging order PL QL QH PH, vmcnt(8)): every
+// unit keeps a lead of five phases, which the weight-gradient kernels need - there BOTH operands are activations streamed
+// from HBM, and the three-phase lead the re-read schedule leaves QL is too short for them (measured: +3.5 % on the grouped
+// launch).  Their epilogue is small enough that the extra 16 registers do not spill.
+#define PP_KTILE_HOLD(BUF, t)                                                                                   \
   do {                                                                                                     \
     constexpr int B0 = (BUF) * PPB, B1 = ((BUF) ^ 1) * PPB;                                                \
     const bool n1 = (t) + 1 < nt, n2 = (t) + 2 < nt;                                                       \
@@ -228,12 +279,13 @@ __device__ __forceinline__ PPRows pp_epi_rows(const GemmP& g, const bf16* xb, in
 }
 
 // one 32-row chunk (i fragments b0, b0 + 1) of the wave's block through its LDS window
-template <bool FULL, int MODE>
+template <bool FULL, int MODE, bool GATED, int XM>
 __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4], int b0, const PPRows& xr,
-                                             bool need_h, bool need_r, int ic, int jb, int lane, char* sw, bf16* dst, int ldd) {
+                                             int ic, int jb, int lane, char* sw, bf16* dst, int ldd) {
+  constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && XM == 2;
   const int il = lane & 15, jl = (lane >> 4) * 4;
   f32x4 gz[4];                             // L0 FFN gate (per output column), fetched per chunk: L2-resident, 16 registers
-  const bool gated = MODE == 2 && g.gate != nullptr;
+  constexpr bool gated = MODE == 2 && GATED;   // (compile-time: the ungated instantiation carries no gate registers)
   if (gated) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -303,18 +355,27 @@ __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4],
 // MODE 1: the pre-activation output (alpha * acc + bias); MODE 2: C.  aux (activation backward) OR residual rows (the host
 // never routes both here) are fetched as FULL 128-byte row segments, both chunks of the half in one batch; they reach the
 // fragment layout through the wave's LDS window, where the result then overwrites them in place.
-template <bool FULL, int MODE>
+// XM (compile-time, so that the plain instantiation carries no row registers): 0 none, 1 aux (activation backward),
+// 2 residual
+template <bool FULL, int MODE, bool GATED, int XM>
 __device__ __forceinline__ void pp_epi_half(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4],
                                             int ib, int jb, int lane, char* sw, bf16* dst, int ldd) {
-  const bool need_h = MODE == 2 && g.dact != EVLM_ACT_NONE, need_r = MODE == 2 && g.residual != nullptr;
+  constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && XM == 2;
   PPRows x0, x1;
   if (need_h || need_r) {
     const bf16* xb = reinterpret_cast<const bf16*>(need_h ? g.aux : g.residual);
     x0 = pp_epi_rows<FULL>(g, xb, ib, jb, lane);
     x1 = pp_epi_rows<FULL>(g, xb, ib + 32, jb, lane);
   }
-  pp_epi_chunk<FULL, MODE>(g, acc, bz, 0, x0, need_h, need_r, ib, jb, lane, sw, dst, ldd);
-  pp_epi_chunk<FULL, MODE>(g, acc, bz, 2, x1, need_h, need_r, ib + 32, jb, lane, sw, dst, ldd);
+  pp_epi_chunk<FULL, MODE, GATED, XM>(g, acc, bz, 0, x0, ib, jb, lane, sw, dst, ldd);
+  pp_epi_chunk<FULL, MODE, GATED, XM>(g, acc, bz, 2, x1, ib + 32, jb, lane, sw, dst, ldd);
+}
+
+template <bool FULL, bool GATED, int XM>
+__device__ __forceinline__ void pp_epi_c(const GemmP& g, f32x4 (&accL)[4][4], f32x4 (&accH)[4][4], const f32x4 (&bz)[4], int ib,
+                                         int jb, int lane, char* sw) {
+  pp_epi_half<FULL, 2, GATED, XM>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
+  pp_epi_half<FULL, 2, GATED, XM>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
 }
 
 template <bool FULL>
@@ -323,11 +384,16 @@ __device__ __forceinline__ void pp_epilogue(const GemmP& g, f32x4 (&accL)[4][4],
   f32x4 bz[4];
   pp_epi_cols<FULL>(g, jb, lane, bz);
   if (g.preact) {
-    pp_epi_half<FULL, 1>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx);
-    pp_epi_half<FULL, 1>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx);
+    pp_epi_half<FULL, 1, false, 0>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx);
+    pp_epi_half<FULL, 1, false, 0>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx);
   }
-  pp_epi_half<FULL, 2>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
-  pp_epi_half<FULL, 2>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
+  // one instantiation per epilogue flavour (wave-uniform dispatch): the plain one carries neither gate nor row registers
+  if (g.gate) {                      // L0-gated FFN (pruning fine-tune only)
+    if (g.residual) pp_epi_c<FULL, true, 2>(g, accL, accH, bz, ib, jb, lane, sw);
+    else pp_epi_c<FULL, true, 0>(g, accL, accH, bz, ib, jb, lane, sw);
+  } else if (g.dact != EVLM_ACT_NONE) pp_epi_c<FULL, false, 1>(g, accL, accH, bz, ib, jb, lane, sw);
+  else if (g.residual) pp_epi_c<FULL, false, 2>(g, accL, accH, bz, ib, jb, lane, sw);
+  else pp_epi_c<FULL, false, 0>(g, accL, accH, bz, ib, jb, lane, sw);
 }
 
 // weight gradients: f32 tile out of the same 4 KiB window, 16 rows x 64 columns at a time.  Plain 16-byte stores when the
@@ -450,21 +516,24 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
   const bf16* Qk = reinterpret_cast<const bf16*>(g.Q) + (size_t)sp * g.kt_per_split * kq;
   PPSrc src;
   pp_src<PT, QT>(g, i0, j0, tid, src);
-  char* swin = smem + PP_EPI_OFF + wave * 4096;
   const int plb = pp_lane_base<PT, true>(lane, wr), qlb = pp_lane_base<QT, false>(lane, wc);
 
   f32x4 accL[4][4], accH[4][4];     // [j fragment][i fragment]; L: i rows 0..63 of the wave's block, H: 64..127
-  bf16x8 pf[4][2], ql[2][2], qh[2][2];
+  bf16x8 pf[4][2], qf[2][2];
+  bf16x8 ql[2][2], qh[2][2];        // PP_KTILE_HOLD only
   float ps[8];                      // OUT 1: per-lane partial row sums of P (bias gradient), i fragments 0..7
 
-  // prologue (host guarantees >= 2 K tiles per item): PL0 QL0 QH0 PH0 PL1 QL1 in flight
-  PP_GLDS(Pk, src.pl, 0, OFF_PL);
-  PP_GLDS(Qk, src.ql, 0, OFF_QL);
-  PP_GLDS(Qk, src.qh, 0, OFF_QH);
-  PP_GLDS(Pk, src.ph, 0, OFF_PH);
-  PP_GLDS(Pk, src.pl, kp, PPB + OFF_PL);
-  PP_GLDS(Qk, src.ql, kq, PPB + OFF_QL);
-  PP_WAIT(8);                                     // PL0, QL0 have landed (this wave's share)
+  // prologue (host guarantees >= 2 K tiles per item): six units in flight, in the steady-state issue order of the schedule
+  constexpr bool HOLD = OUT == 1;                 // weight gradients: PP_KTILE_HOLD (see there)
+  if (HOLD) {
+    PP_GLDS(Pk, src.pl, 0, OFF_PL); PP_GLDS(Qk, src.ql, 0, OFF_QL); PP_GLDS(Qk, src.qh, 0, OFF_QH);
+    PP_GLDS(Pk, src.ph, 0, OFF_PH); PP_GLDS(Pk, src.pl, kp, PPB + OFF_PL); PP_GLDS(Qk, src.ql, kq, PPB + OFF_QL);
+    PP_WAIT(8);                                   // PL0, QL0 have landed (this wave's share)
+  } else {
+    PP_GLDS(Pk, src.pl, 0, OFF_PL); PP_GLDS(Qk, src.qh, 0, OFF_QH); PP_GLDS(Pk, src.ph, 0, OFF_PH);
+    PP_GLDS(Qk, src.ql, 0, OFF_QL); PP_GLDS(Pk, src.pl, kp, PPB + OFF_PL); PP_GLDS(Qk, src.qh, kq, PPB + OFF_QH);
+    PP_WAIT(4);                                   // PL0, QL0 have landed
+  }
 #ifdef PP_STAMP
   unsigned long long stp[5]; int stn = 0;
   stp[4] = __builtin_amdgcn_s_memtime();
@@ -488,11 +557,19 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
     if (wr == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one barrier behind group 0
     __builtin_amdgcn_sched_barrier(0);
     int t = 0;
-    for (; t + 1 < nt; t += 2) {
-      PP_KTILE(0, t);
-      PP_KTILE(1, t + 1);
+    if (HOLD) {
+      for (; t + 1 < nt; t += 2) {
+        PP_KTILE_HOLD(0, t);
+        PP_KTILE_HOLD(1, t + 1);
+      }
+      if (t < nt) PP_KTILE_HOLD(0, t);
+    } else {
+      for (; t + 1 < nt; t += 2) {
+        PP_KTILE(0, t);
+        PP_KTILE(1, t + 1);
+      }
+      if (t < nt) PP_KTILE(0, t);
     }
-    if (t < nt) PP_KTILE(0, t);
     if (wr == 0) __builtin_amdgcn_s_barrier();    // re-align the groups: every LDS read of the K loop has retired
     __builtin_amdgcn_sched_barrier(0);
 #ifdef PP_STAMP
@@ -516,32 +593,41 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
       nt = min(nt_all - sp * g.kt_per_split, g.kt_per_split);
       Pk = reinterpret_cast<const bf16*>(g.P) + (size_t)sp * g.kt_per_split * kp;
       Qk = reinterpret_cast<const bf16*>(g.Q) + (size_t)sp * g.kt_per_split * kq;
-      pp_src<PT, QT>(g, i0, j0, tid, src);
-      PP_GLDS(Pk, src.pl, 0, OFF_PL);
-      PP_GLDS(Qk, src.ql, 0, OFF_QL);
-      PP_GLDS(Qk, src.qh, 0, OFF_QH);
-      PP_GLDS(Pk, src.ph, 0, OFF_PH);
-      PP_GLDS(Pk, src.pl, kp, PPB + OFF_PL);
-      PP_GLDS(Qk, src.ql, kq, PPB + OFF_QL);
+      int tid_p = tid;                          // (same reason as for the epilogue below: no hoisting of the lane terms)
+      asm volatile("" : "+v"(tid_p));
+      pp_src<PT, QT>(g, i0, j0, tid_p, src);
+      if (HOLD) {
+        PP_GLDS(Pk, src.pl, 0, OFF_PL); PP_GLDS(Qk, src.ql, 0, OFF_QL); PP_GLDS(Qk, src.qh, 0, OFF_QH);
+        PP_GLDS(Pk, src.ph, 0, OFF_PH); PP_GLDS(Pk, src.pl, kp, PPB + OFF_PL); PP_GLDS(Qk, src.ql, kq, PPB + OFF_QL);
+      } else {
+        PP_GLDS(Pk, src.pl, 0, OFF_PL); PP_GLDS(Qk, src.qh, 0, OFF_QH); PP_GLDS(Pk, src.ph, 0, OFF_PH);
+        PP_GLDS(Qk, src.ql, 0, OFF_QL); PP_GLDS(Pk, src.pl, kp, PPB + OFF_PL); PP_GLDS(Qk, src.qh, kq, PPB + OFF_QH);
+      }
     }
 #ifdef PP_STAMP
     stp[2] = __builtin_amdgcn_s_memtime();
 #endif
+    // the epilogue's per-lane address arithmetic must NOT be hoisted out of the persistent loop (it would sit in VGPRs -
+    // in scratch, in practice - through every K loop): launder the thread id it is derived from
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63;
+    char* swin_e = smem + PP_EPI_OFF + (tid_e >> 6) * 4096;
     if (OUT == 0) {
-      if (full) pp_epilogue<true>(gc, accL, accH, ib, jb, lane, swin);
-      else pp_epilogue<false>(gc, accL, accH, ib, jb, lane, swin);
+      if (full) pp_epilogue<true>(gc, accL, accH, ib, jb, lane_e, swin_e);
+      else pp_epilogue<false>(gc, accL, accH, ib, jb, lane_e, swin_e);
     } else {
       const int mode = GROUPED ? (grp->rmw ? 2 : 1) : ((gc.accumulate || splits > 1) ? 1 : 0);
-      if (full) { pp_epi_f32_half<true>(gc, accL, ib, jb, lane, swin, mode); pp_epi_f32_half<true>(gc, accH, ib + 64, jb, lane, swin, mode); }
-      else { pp_epi_f32_half<false>(gc, accL, ib, jb, lane, swin, mode); pp_epi_f32_half<false>(gc, accH, ib + 64, jb, lane, swin, mode); }
+      if (full) { pp_epi_f32_half<true>(gc, accL, ib, jb, lane_e, swin_e, mode); pp_epi_f32_half<true>(gc, accH, ib + 64, jb, lane_e, swin_e, mode); }
+      else { pp_epi_f32_half<false>(gc, accL, ib, jb, lane_e, swin_e, mode); pp_epi_f32_half<false>(gc, accH, ib + 64, jb, lane_e, swin_e, mode); }
       if (do_psum) {                              // lanes l, l+16, l+32, l+48 hold the four k quarters of row l
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
           float v = ps[b];
           v += __shfl_xor(v, 16, 64);
           v += __shfl_xor(v, 32, 64);
-          const int i = ib + b * 16 + lane;
-          if (lane < 16 && i < gc.I) atomicAdd(gc.psum + i, v);
+          const int i = ib + b * 16 + lane_e;
+          if (lane_e < 16 && i < gc.I) atomicAdd(gc.psum + i, v);
         }
       }
     }
@@ -586,7 +672,7 @@ bool evlm_gemm_pp256_eligible(const GemmP& g, int pt, int qt) {
   if (g.psum) return false;
 #endif
   if (pt || g.accumulate) return false;
-  if (g.dact != EVLM_ACT_NONE && g.residual) return false;
+  if (g.dact != EVLM_ACT_NONE && (g.residual || g.gate)) return false;
   if (g.J % 8 != 0 || g.ldc % 8 != 0) return false;
   if ((g.preact || g.aux || g.residual) && g.ldx % 8 != 0) return false;
   return true;

@@ -85,6 +85,9 @@ class WeightCache:
         vers = tuple(p._version for p in params)
         grad = any(p.requires_grad for p in params)
         ent = self._store.get(key)
+        # id() values are recycled once a parameter dies: an entry is only valid for the very objects it was built from
+        if ent is not None and not all(r() is p for r, p in zip(ent[4], params)):
+            ent = None
         if ent is not None and ent[1] == vers and (not grad or ent[2] == self.epoch) and ent[3] == params[0].data_ptr():
             return ent[0]
         if len(params) == 1 and params[0].dtype == dtype and params[0].is_contiguous():
@@ -102,7 +105,8 @@ class WeightCache:
                 dst = buf[r0:r0 + p.shape[0]]
                 L.check(lib.evlm_cast(L.dt(pd), L.ptr(pd), L.dt(dst), L.ptr(dst), pd.numel(), L.stream()), "cast")
                 r0 += p.shape[0]
-        self._store[key] = (buf, vers, self.epoch, params[0].data_ptr())
+        import weakref
+        self._store[key] = (buf, vers, self.epoch, params[0].data_ptr(), tuple(weakref.ref(p) for p in params))
         return buf
 
 
