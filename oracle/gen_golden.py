@@ -290,8 +290,10 @@ def grads_to(fx, tag, model, full):
 
 
 # --------------------------------------------------------------------------------------------
-def gen_gd(geom_name, B, seed, full):
-    """one GeneralDistill general step: student fwd, teacher fwd (no_grad), KD losses, backward."""
+def gen_gd(geom_name, B, seed, full, region_rows=0):
+    """one GeneralDistill general step: student fwd, teacher fwd (no_grad), KD losses, backward.
+    region_rows > 0: a REGION step instead (GeneralDistill.py:158-262) - B images expanded to region_rows (text, region)
+    rows, ret_bbox_loss=True, bbox + giou in the task loss."""
     geom = synth.GEOMS[geom_name]
     work = tempfile.mkdtemp(prefix="evlm_oracle_")
     os.chdir(work)
@@ -304,7 +306,13 @@ def gen_gd(geom_name, B, seed, full):
     teacher = XVLM(tcfg)
     student.load_state_dict(det_state_dict(student.state_dict(), seed=1000 + seed, std=geom["std"]), strict=True)
     teacher.load_state_dict(det_state_dict(teacher.state_dict(), seed=2000 + seed, std=geom["std"]), strict=True)
-    batch = synth.make_batch(geom, B, seed=seed, ragged=True)
+    if region_rows:
+        batch = synth.make_region_batch(geom, B, region_rows, seed=seed, ragged=True)
+        extra = dict(image_atts=batch["image_atts"], idx_to_group_img=batch["idx_to_group_img"],
+                     target_bbox=batch["target_bbox"], is_image=batch["is_image"], ret_bbox_loss=True)
+    else:
+        batch = synth.make_batch(geom, B, seed=seed, ragged=True)
+        extra = {}
     student.train()
     teacher.eval()
     get_kd_loss, soft_ce, get_cor = load_gd_helpers()
@@ -313,13 +321,16 @@ def gen_gd(geom_name, B, seed, full):
     with MultinomialRecorder() as rec_s:
         S = student(batch["image"], batch["text_ids"], batch["text_atts"],
                     text_ids_masked=batch["text_ids_masked"], masked_pos=batch["masked_pos"],
-                    masked_ids=batch["masked_ids"], output_attentions=True, output_hidden_states=True)
+                    masked_ids=batch["masked_ids"], output_attentions=True, output_hidden_states=True, **extra)
     with torch.no_grad(), MultinomialRecorder() as rec_t:
         T = teacher(batch["image"], batch["text_ids"], batch["text_atts"],
                     text_ids_masked=batch["text_ids_masked"], masked_pos=batch["masked_pos"],
-                    masked_ids=batch["masked_ids"], output_attentions=True, output_hidden_states=True)
+                    masked_ids=batch["masked_ids"], output_attentions=True, output_hidden_states=True, **extra)
     kd = kd_terms(get_kd_loss, soft_ce, get_cor, S, T)
     total, mix = gd_total(S["loss"], kd)
+    if region_rows:                                   # GeneralDistill.py:257-260
+        mix["loss_small"] = mix["loss_small"] + S["loss"]["loss_bbox"] + S["loss"]["loss_giou"]
+        total = 0.6 * mix["loss_small"] + 0.4 * mix["loss_kd"]
     total.backward()
 
     fx = {"meta.geom": np.array(geom_name), "meta.B": np.array(B), "meta.seed": np.array(seed)}
@@ -607,7 +618,8 @@ if __name__ == "__main__":
     os.environ.setdefault("MASTER_PORT", "29917")
     dist.init_process_group("gloo", rank=0, world_size=1)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["kd", "l0", "gd_tiny", "itr_tiny", "gd_full", "optim", "ckpt"]
+    which = sys.argv[1:] or ["kd", "l0", "gd_tiny", "itr_tiny", "gd_full", "optim", "ckpt", "gd_region_tiny",
+                              "gd_region_full"]
     if "ckpt" in which:
         save("ckpt_remap.npz", gen_ckpt_remap(13))
     if "optim" in which:
@@ -625,4 +637,8 @@ if __name__ == "__main__":
         save("itr_tiny.npz", gen_itr("tiny", B=4, seed=4))
     if "gd_full" in which:
         save("gd_full.npz", gen_gd("full", B=2, seed=2, full=False))
+    if "gd_region_tiny" in which:
+        save("gd_region_tiny.npz", gen_gd("tiny", B=3, seed=6, full=True, region_rows=6))
+    if "gd_region_full" in which:
+        save("gd_region_full.npz", gen_gd("full", B=2, seed=8, full=False, region_rows=4))
     dist.destroy_process_group()

@@ -46,3 +46,37 @@ def make_batch(geom, B, seed, ragged=False, image_res=None):
         ids_masked[b, perm] = geom["mask"]
     return dict(image=image, text_ids=ids, text_atts=atts, text_ids_masked=ids_masked,
                 masked_pos=masked_pos, masked_ids=masked_ids)
+
+
+def make_region_batch(geom, n_img, R, seed, ragged=True):
+    """a REGION batch of the GD recipe (dataset/pretrain_dataset.py:405-526 collate contract): `n_img` images expanded
+    to R (text, region) rows by idx_to_group_img (unsorted, as random.sample leaves it), per-row patch masks
+    image_atts [R, 1+P*P] (cls always 1; whole-image rows all ones), target boxes (cx, cy, w, h) in [0,1] and the
+    is_image flags that mask whole-image rows out of the box losses."""
+    g = torch.Generator().manual_seed(seed + 4242)
+    out = make_batch(geom, R, seed, ragged=ragged)
+    out["image"] = torch.randn(n_img, 3, geom["image_res"], geom["image_res"], generator=g)
+    P = geom["image_res"] // 16
+    idx = torch.cat([torch.arange(n_img), torch.randint(0, n_img, (max(R - n_img, 0),), generator=g)])[:R]
+    out["idx_to_group_img"] = idx[torch.randperm(R, generator=g)].long()
+    atts = torch.zeros(R, 1 + P * P, dtype=torch.long)
+    bbox = torch.zeros(R, 4)
+    is_image = torch.zeros(R, dtype=torch.long)
+    for r in range(R):
+        if r % 4 == 1:                                   # the image's own caption: full attention, box = whole image
+            is_image[r] = 1
+            atts[r] = 1
+            bbox[r] = torch.tensor([0.5, 0.5, 1.0, 1.0])
+            continue
+        x0, y0 = (int(v) for v in torch.randint(0, P, (2,), generator=g))
+        x1 = int(torch.randint(x0 + 1, P + 1, (1,), generator=g))
+        y1 = int(torch.randint(y0 + 1, P + 1, (1,), generator=g))
+        atts[r, 0] = 1
+        for i in range(y0, y1):
+            atts[r, 1 + P * i + x0:1 + P * i + x1] = 1
+        # the dataset's boxes are pixel-exact, its masks patch-rounded: keep the box a little inside the patch rectangle
+        jit = torch.rand(4, generator=g) * 0.3 / P
+        bx0, by0, bx1, by1 = x0 / P + jit[0], y0 / P + jit[1], x1 / P - jit[2], y1 / P - jit[3]
+        bbox[r] = torch.stack([(bx0 + bx1) / 2, (by0 + by1) / 2, bx1 - bx0, by1 - by0])
+    out.update(image_atts=atts, target_bbox=bbox, is_image=is_image)
+    return out

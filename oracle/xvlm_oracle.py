@@ -317,10 +317,57 @@ def _bert_prefix(sd):
     return "text_encoder.bert." if any(k.startswith("text_encoder.bert.") for k in sd) else "text_encoder."
 
 
+def box_cxcywh_to_xyxy(x):
+    """models/box_ops.py:8-12"""
+    cx, cy, w, h = x.unbind(-1)
+    return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+
+
+def giou_rowwise(b1, b2):
+    """diagonal of models/box_ops.py:41-56 generalized_box_iou(b1, b2) (the only part xvlm.py:559 reads), xyxy boxes"""
+    area1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    area2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    wh = (torch.min(b1[:, 2:], b2[:, 2:]) - torch.max(b1[:, :2], b2[:, :2])).clamp(min=0)      # :26-29
+    inter = wh[:, 0] * wh[:, 1]
+    union = area1 + area2 - inter
+    iou = inter / union
+    wh_c = (torch.max(b1[:, 2:], b2[:, 2:]) - torch.min(b1[:, :2], b2[:, :2])).clamp(min=0)    # :50-53
+    area_c = wh_c[:, 0] * wh_c[:, 1]
+    return iou - (area_c - union) / area_c
+
+
+def bbox_loss(output_coord, target_bbox, is_image=None):
+    """XVLMBase.get_bbox_loss, xvlm.py:544-569: L1 + (1 - GIoU), rows with is_image=1 masked out of both sums"""
+    l1 = (output_coord - target_bbox).abs()
+    b1, b2 = box_cxcywh_to_xyxy(output_coord), box_cxcywh_to_xyxy(target_bbox)
+    if (b1[:, 2:] < b1[:, :2]).any() or (b2[:, 2:] < b2[:, :2]).any():                         # :553-556
+        giou = torch.zeros(output_coord.size(0))
+    else:
+        giou = 1 - giou_rowwise(b1, b2)
+    if is_image is None:
+        n = target_bbox.size(0)
+    else:
+        n = torch.sum(1 - is_image)
+        l1 = l1 * (1 - is_image.view(-1, 1))
+        giou = giou * (1 - is_image)
+    return l1.sum() / n, giou.sum() / n
+
+
 def pretrain_forward(sd, cfg, batch, neg_idx):
-    """models/model_pretrain.py:11-82 XVLM.forward (general batch: no bbox branch)."""
-    image_embeds, image_hs, image_at = vit_forward(sd, "vision_encoder.", batch["image"], cfg)
-    image_atts = torch.ones(image_embeds.shape[:2], dtype=torch.long)
+    """models/model_pretrain.py:11-82 XVLM.forward.  A batch that carries `idx_to_group_img` is a REGION batch
+    (ret_bbox_loss=True, GeneralDistill.py:176-178): the ViT splits into per-region masked copies for its last
+    `local_attn_depth` layers, ITC / ITM / MLM run on the region embeddings with the region patch masks, and the bbox
+    head regresses the box from a fusion pass over the FULL-attention image embeddings."""
+    region = "idx_to_group_img" in batch
+    if region:
+        image_embeds, image_hs, image_at, full = vit_forward(
+            sd, "vision_encoder.", batch["image"], cfg, idx_to_group_img=batch["idx_to_group_img"],
+            image_atts=batch["image_atts"])
+        image_atts = batch["image_atts"]
+        image_embeds_fullatts = full[batch["idx_to_group_img"]]                          # xvlm.py:294-297
+    else:
+        image_embeds, image_hs, image_at = vit_forward(sd, "vision_encoder.", batch["image"], cfg)
+        image_atts = torch.ones(image_embeds.shape[:2], dtype=torch.long)
     bp = _bert_prefix(sd)
     text_embeds, text_hs, text_at, _ = bert_model(sd, bp, cfg, input_ids=batch["text_ids"],
                                                   attention_mask=batch["text_atts"], mode="text")
@@ -330,17 +377,27 @@ def pretrain_forward(sd, cfg, batch, neg_idx):
     itm = matching_loss(sd, cfg, image_embeds, image_atts, text_embeds, batch["text_atts"], neg_idx)
     mlm = bert_mlm(sd, "text_encoder.", cfg, batch["text_ids_masked"], batch["text_atts"], image_embeds,
                    image_atts, batch["masked_pos"], batch["masked_ids"])
+    loss = {"loss_itc": loss_itc, "loss_itm": itm["loss"], "loss_mlm": mlm[0]}
+    extra_h, extra_a, extra_c = {}, {}, {}
+    if region:                                                                           # model_pretrain.py:62-74
+        bb = bert_model(sd, bp, cfg, encoder_embeds=text_embeds, attention_mask=batch["text_atts"],
+                        encoder_hidden_states=image_embeds_fullatts,
+                        encoder_attention_mask=torch.ones(image_embeds_fullatts.shape[:2]), mode="fusion")
+        coord = torch.sigmoid(build_mlp_fwd(sd, "bbox_head.", bb[0][:, 0, :]))           # xvlm.py:540
+        loss["loss_bbox"], loss["loss_giou"] = bbox_loss(coord, batch["target_bbox"], batch.get("is_image"))
+        extra_h, extra_a, extra_c = ({"bbox_hidden_states": bb[1]}, {"bbox_attentions": bb[2]},
+                                     {"bbox_cross_attentions": bb[3]})
     return {
-        "loss": {"loss_itc": loss_itc, "loss_itm": itm["loss"], "loss_mlm": mlm[0]},
+        "loss": loss, "output_coord": coord if region else None,
         "hidden_dict": {"image_hidden_states": image_hs, "text_hidden_states": text_hs,
                         "itm_pos_hidden_states": itm["pos_hidden_states"],
-                        "itm_neg_hidden_states": itm["neg_hidden_states"], "mlm_hidden_states": mlm[2]},
+                        "itm_neg_hidden_states": itm["neg_hidden_states"], "mlm_hidden_states": mlm[2], **extra_h},
         "attention_dict": {"image_attentions": image_at, "text_attentions": text_at,
                            "itm_pos_attentions": itm["pos_attentions"],
-                           "itm_neg_attentions": itm["neg_attentions"], "mlm_attentions": mlm[3]},
+                           "itm_neg_attentions": itm["neg_attentions"], "mlm_attentions": mlm[3], **extra_a},
         "cross_attention_dict": {"itm_pos_cross_attentions": itm["pos_cross_attentions"],
                                  "itm_neg_cross_attentions": itm["neg_cross_attentions"],
-                                 "mlm_cross_attentions": mlm[4]},
+                                 "mlm_cross_attentions": mlm[4], **extra_c},
         "logits_dict": {"itm_head_logits": itm["logits"], "mlm_logits": mlm[1]},
         "features": (i_feat, t_feat),
     }
@@ -440,8 +497,10 @@ def kd_terms(S, T, temperature=1.0, with_cross_attn=False):
 
 
 def gd_loss_mix(loss, kd):
-    """GeneralDistill.py:369-376"""
+    """GeneralDistill.py:369-376 (general batch) / :252-260 (region batch: + bbox + giou in the task term)"""
     loss_small = loss["loss_itc"] + loss["loss_itm"] + loss["loss_mlm"]
+    if "loss_bbox" in loss:
+        loss_small = loss_small + loss["loss_bbox"] + loss["loss_giou"]
     loss_text_kd = kd["text_attn"] + kd["text_hidden"]
     loss_img_kd = kd["image_attn"] + 0.1 * kd["image_hidden"]
     loss_cross_kd = (kd["itm_neg_attn"] + kd["itm_neg_hidden"] + kd["itm_pos_attn"] + kd["itm_pos_hidden"]

@@ -109,8 +109,10 @@ def leafify(sd):
     return out
 
 
-@pytest.mark.parametrize("name,full", [("gd_tiny.npz", True), ("gd_full.npz", False)])
+@pytest.mark.parametrize("name,full", [("gd_tiny.npz", True), ("gd_full.npz", False),
+                                       ("gd_region_tiny.npz", True), ("gd_region_full.npz", False)])
 def test_gd_step_matches_reference(golden_dir, name, full):
+    """general steps (GeneralDistill.py:264-387) and REGION steps (:158-262: idx_to_group_img / image_atts / bbox)"""
     fx = load(golden_dir, name)
     geom = synth.GEOMS[str(fx["meta.geom"])]
     seed = int(fx["meta.seed"])
@@ -121,7 +123,11 @@ def test_gd_step_matches_reference(golden_dir, name, full):
     t_sd = tie(t_sd)
     batch = batch_from_fixture(fx)
     # the synthetic batch generator itself is part of the contract
-    regen = synth.make_batch(geom, int(fx["meta.B"]), seed=seed, ragged=True)
+    if "in.idx_to_group_img" in fx:
+        regen = synth.make_region_batch(geom, int(fx["meta.B"]), fx["in.text_ids"].shape[0], seed=seed, ragged=True)
+        assert "student.loss_bbox" in fx and "student.bbox_hidden_states.0" in fx or not full
+    else:
+        regen = synth.make_batch(geom, int(fx["meta.B"]), seed=seed, ragged=True)
     for k, v in regen.items():
         assert torch.equal(v, batch[k]), k
     s_neg = torch.from_numpy(fx["in.student_neg_idx"])
