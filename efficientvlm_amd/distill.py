@@ -66,8 +66,10 @@ def kd_terms(S, T, temperature=1.0, with_cross_attn=False):
 
 
 def gd_loss_mix(loss, kd):
-    """GeneralDistill.py:369-376"""
+    """GeneralDistill.py:369-376 (general step) / :252-260 (region step: + bbox + giou in the task term)"""
     loss_small = loss["loss_itc"] + loss["loss_itm"] + loss["loss_mlm"]
+    if "loss_bbox" in loss:
+        loss_small = loss_small + loss["loss_bbox"] + loss["loss_giou"]
     loss_text_kd = kd["text_attn"] + kd["text_hidden"]
     loss_img_kd = kd["image_attn"] + 0.1 * kd["image_hidden"]
     loss_cross_kd = (kd["itm_neg_attn"] + kd["itm_neg_hidden"] + kd["itm_pos_attn"] + kd["itm_pos_hidden"]
@@ -146,15 +148,26 @@ def student_and_teacher(student_call, teacher_call, ref_tensor, overlap):
     return S, T
 
 
+def model_kwargs(batch):
+    """keyword arguments of XVLM.forward for a general batch or - when the batch carries `idx_to_group_img` - a REGION
+    batch (GeneralDistill.py:176-183: image_atts, idx_to_group_img, target_bbox, is_image, ret_bbox_loss=True)"""
+    kw = dict(text_ids_masked=batch["text_ids_masked"], masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"],
+              output_attentions=True, output_hidden_states=True)
+    if "idx_to_group_img" in batch:
+        kw.update(image_atts=batch["image_atts"], idx_to_group_img=batch["idx_to_group_img"],
+                  target_bbox=batch["target_bbox"], is_image=batch.get("is_image"), ret_bbox_loss=True)
+    return kw
+
+
 def gd_forward(student, teacher, batch, temperature=1.0, overlap_teacher=False, teacher_out=None):
     """student forward (autograd on), teacher forward (no_grad), every KD term and the GD loss mix
-    (GeneralDistill.py:289-376).  batch: dict(image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids).
+    (GeneralDistill.py:289-376; region step :158-262).  batch: dict(image, text_ids, text_atts, text_ids_masked,
+    masked_pos, masked_ids [, idx_to_group_img, image_atts, target_bbox, is_image: a region batch]).
 
     overlap_teacher: the two forwards are independent (each draws its own hard negatives, as in the reference), so the
     teacher runs on a second HIP stream: its HBM-bound kernels (LayerNorm, attention maps) and partly-filled GEMM launches
     share the chip with the student's instead of queueing behind them."""
-    kw = dict(text_ids_masked=batch["text_ids_masked"], masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"],
-              output_attentions=True, output_hidden_states=True)
+    kw = model_kwargs(batch)
     call = lambda m: m(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
     if teacher_out is not None:            # teacher outputs of THIS batch computed earlier (trainer: teacher pipelining)
         S, T = call(student), teacher_out

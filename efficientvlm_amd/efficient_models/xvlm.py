@@ -424,11 +424,42 @@ class XVLMBase(nn.Module):
 
     def predict_bbox(self, image_embeds, text_embeds, text_atts, output_attentions=None, output_hidden_states=None,
                      head_z=None, head_layer_z=None, mlp_z=None):
-        """efficient_models/xvlm.py:520-542 — region batches are excluded from the BASELINE configs"""
-        raise NotImplementedError("the bbox / region branch is outside the benchmarked general-distillation path")
+        """efficient_models/xvlm.py:520-542: fusion pass over the FULL-attention image embeddings, bbox head on [CLS],
+        sigmoid -> (cx, cy, w, h).  Returns (coord,) or (coord, hidden_states, attentions, cross_attentions)."""
+        assert image_embeds.size(0) == text_embeds.size(0)
+        ones = torch.ones(image_embeds.shape[:2], device=image_embeds.device)
+        outputs = self.get_cross_embeds(image_embeds, ones, text_embeds=text_embeds, text_atts=text_atts,
+                                        output_attentions=output_attentions, output_hidden_states=output_hidden_states,
+                                        head_z=head_z, mlp_z=mlp_z)
+        last = outputs[0] if output_attentions else outputs
+        output_coord = self.bbox_coord(last[:, 0, :])
+        return ((output_coord,) + tuple(outputs[1:])) if output_attentions else (output_coord,)
+
+    def bbox_coord(self, cls_rows):
+        """bbox_head (HIP GEMMs / LayerNorm / GELU) + sigmoid in fp32 (<= 128 x 4 values)"""
+        return torch.sigmoid(ops.cast(mlp_head_forward(self.bbox_head, cls_rows), torch.float32))
 
     def get_bbox_loss(self, output_coord, target_bbox, is_image=None):
-        raise NotImplementedError("the bbox / region branch is outside the benchmarked general-distillation path")
+        """efficient_models/xvlm.py:544-569: L1 + (1 - GIoU), whole-image rows (is_image = 1) masked out of both sums.
+        The reference's degenerate-box early-out (:553-556, a host-side `if`) is a device-side select here, so the step
+        stays free of host synchronisation."""
+        from ..models import box_ops
+        output_coord = output_coord.float()
+        target_bbox = target_bbox.to(output_coord.dtype)
+        loss_bbox = (output_coord - target_bbox).abs()
+        boxes1 = box_ops.box_cxcywh_to_xyxy(output_coord)
+        boxes2 = box_ops.box_cxcywh_to_xyxy(target_bbox)
+        degenerate = (boxes1[:, 2:] < boxes1[:, :2]).any() | (boxes2[:, 2:] < boxes2[:, :2]).any()
+        loss_giou = 1 - box_ops.generalized_box_iou_rowwise(boxes1, boxes2)
+        loss_giou = torch.where(degenerate, torch.zeros_like(loss_giou), loss_giou)
+        if is_image is None:
+            num_boxes = target_bbox.size(0)
+        else:
+            keep = (1 - is_image).to(output_coord.dtype)
+            num_boxes = keep.sum()
+            loss_bbox = loss_bbox * keep.view(-1, 1)
+            loss_giou = loss_giou * keep
+        return loss_bbox.sum() / num_boxes, loss_giou.sum() / num_boxes
 
 
 def _matmul_nt(a, b):

@@ -28,12 +28,17 @@ class XVLM(XVLMBase):
                 idx_to_group_img=None, target_bbox=None, is_image=None, ret_bbox_loss=False, output_attentions=None,
                 output_hidden_states=None):
         assert output_attentions == output_hidden_states
-        if ret_bbox_loss:
-            raise NotImplementedError("region (bbox) batches are outside the benchmarked general-distillation path")
+        region = (image_atts, idx_to_group_img, target_bbox, is_image) if ret_bbox_loss else None
         if self.batched_passes and output_attentions:
-            return self._forward_batched(image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids)
-        out = self.get_vision_embeds(image, output_attentions=output_attentions, output_hidden_states=output_hidden_states)
-        image_embeds, image_atts, image_hidden_states, image_attentions = out
+            return self._forward_batched(image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids, region)
+        if ret_bbox_loss:                                                                 # model_pretrain.py:16-18
+            assert output_attentions, "the reference's region branch unpacks the 5-tuple of the output_attentions path"
+            image_embeds, image_atts, image_embeds_fullatts, image_hidden_states, image_attentions = self.get_vision_embeds(
+                image, image_atts=image_atts, idx_to_group_img=idx_to_group_img, output_attentions=output_attentions,
+                output_hidden_states=output_hidden_states)
+        else:
+            out = self.get_vision_embeds(image, output_attentions=output_attentions, output_hidden_states=output_hidden_states)
+            image_embeds, image_atts, image_hidden_states, image_attentions = out
         t = self.get_text_embeds(text_ids, text_atts, output_attentions=output_attentions, output_hidden_states=output_hidden_states)
         text_embeds, text_hidden_states, text_attentions = t if output_attentions else (t, None, None)
         hidden_dict = {"image_hidden_states": image_hidden_states, "text_hidden_states": text_hidden_states}
@@ -61,16 +66,37 @@ class XVLM(XVLMBase):
         logits_dict["mlm_logits"] = mlm[1]
         cross_attention_dict["mlm_cross_attentions"] = mlm[4]
         loss = {"loss_itc": loss_itc, "loss_itm": itm["loss"], "loss_mlm": mlm[0]}
+        if ret_bbox_loss:                                                                 # model_pretrain.py:62-74
+            bbox_output = self.predict_bbox(image_embeds_fullatts, text_embeds, text_atts,
+                                            output_attentions=output_attentions, output_hidden_states=output_hidden_states)
+            loss["loss_bbox"], loss["loss_giou"] = self.get_bbox_loss(bbox_output[0], target_bbox, is_image=is_image)
+            hidden_dict["bbox_hidden_states"], attention_dict["bbox_attentions"] = bbox_output[1], bbox_output[2]
+            cross_attention_dict["bbox_cross_attentions"] = bbox_output[3]
+            self.last_output_coord = bbox_output[0].detach()     # (never keep the autograd graph alive)
         return {"loss": loss, "hidden_dict": hidden_dict, "attention_dict": attention_dict,
                 "cross_attention_dict": cross_attention_dict, "logits_dict": logits_dict}
 
-    def _forward_batched(self, image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids):
+    def _forward_batched(self, image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids, region=None):
         """same outputs as the pass-by-pass forward above (reference model_pretrain.py:11-82), batched as described at
-        `batched_passes`."""
-        B = image.shape[0]
+        `batched_passes`.  region = (image_atts [R, N], idx_to_group_img [R], target_bbox [R, 4], is_image [R] | None)
+        for a REGION batch: the image encoder yields R region-masked embeddings + the full-attention embeddings of the
+        n_img images, ITC / ITM / MLM use the former with the region patch masks, and the bbox pass is a fifth block of
+        fusion rows that cross-attends to the full-attention embeddings through the same batch index."""
+        B = text_ids.shape[0]
         dev = image.device
-        image_embeds, image_atts, image_hidden_states, image_attentions = self.get_vision_embeds(
-            image, output_attentions=True, output_hidden_states=True)
+        if region is None:
+            image_embeds, image_atts, image_hidden_states, image_attentions = self.get_vision_embeds(
+                image, output_attentions=True, output_hidden_states=True)
+            enc_states, enc_atts = image_embeds, image_atts
+        else:
+            image_atts, idx_to_group_img, target_bbox, is_image = region
+            assert image_atts.size(0) == idx_to_group_img.size(0) == B
+            image_embeds, image_hidden_states, image_attentions, full = self.vision_encoder(
+                image, idx_to_group_img=idx_to_group_img, image_atts=image_atts, output_attentions=True,
+                output_hidden_states=True)
+            # cross-attention sources: rows 0..R-1 the region embeddings, rows R.. the full-attention ones
+            enc_states = torch.cat([image_embeds, full], 0)
+            enc_atts = torch.cat([image_atts, torch.ones(full.shape[:2], dtype=image_atts.dtype, device=dev)], 0)
         if self.on_vision_grad is not None and image_embeds.requires_grad:
             cb = self.on_vision_grad
             image_embeds.register_hook(lambda grad: (cb(), grad)[1])
@@ -97,11 +123,17 @@ class XVLM(XVLMBase):
         txt_all = torch.cat([text_embeds, text_embeds, torch.index_select(text_embeds, 0, txt_neg), mlm_text], 0)
         atts_all = torch.cat([text_atts, text_atts, torch.index_select(text_atts, 0, txt_neg), text_atts], 0)
         img_index = torch.cat([ar, img_neg, ar, ar], 0)
-        f = core(encoder_embeds=txt_all, attention_mask=atts_all, encoder_hidden_states=image_embeds,
-                 encoder_attention_mask=torch.index_select(image_atts, 0, img_index), encoder_batch_index=img_index,
+        sizes = [B, 2 * B, B]
+        if region is not None:                      # + bbox rows: the text again, attending to the un-masked image
+            txt_all = torch.cat([txt_all, text_embeds], 0)
+            atts_all = torch.cat([atts_all, text_atts], 0)
+            img_index = torch.cat([img_index, B + idx_to_group_img.view(-1)], 0)
+            sizes.append(B)
+        f = core(encoder_embeds=txt_all, attention_mask=atts_all, encoder_hidden_states=enc_states,
+                 encoder_attention_mask=torch.index_select(enc_atts, 0, img_index), encoder_batch_index=img_index,
                  return_dict=True, mode="fusion", output_attentions=True, output_hidden_states=True)
-        thirds = lambda tup: tuple(zip(*[torch.split(x, [B, 2 * B, B], 0) if x is not None else (None, None, None)
-                                         for x in tup]))                                       # pos | neg | mlm
+        thirds = lambda tup: tuple(zip(*[torch.split(x, sizes, 0) if x is not None else (None,) * len(sizes)
+                                         for x in tup]))                                       # pos | neg | mlm [| bbox]
         f_hid, f_att, f_cross = thirds(f.hidden_states), thirds(f.attentions), thirds(f.cross_attentions)
         last = f.last_hidden_state
         itm_logits = mlp_head_forward(self.itm_head, last[:3 * B, 0, :])
@@ -109,7 +141,7 @@ class XVLM(XVLMBase):
         loss_itm = ops.cross_entropy(itm_logits, itm_labels)
         # MLM head on the masked positions of the last quarter
         enc = self.text_encoder
-        mlm_last = f_hid[2][-1] if f.hidden_states[-1] is last else last[3 * B:]
+        mlm_last = f_hid[2][-1] if f.hidden_states[-1] is last else last[3 * B:4 * B]
         mlm_seq = enc.gather_seq_out_by_pos(mlm_last, masked_pos)
         mlm_logits = enc.cls(mlm_seq)
         loss_mlm = ops.cross_entropy(mlm_logits.reshape(-1, enc.config.vocab_size), masked_ids.reshape(-1))
@@ -124,5 +156,11 @@ class XVLM(XVLMBase):
                                 "mlm_cross_attentions": f_cross[2]}
         logits_dict = {"itm_head_logits": itm_logits, "mlm_logits": mlm_logits}
         loss = {"loss_itc": loss_itc, "loss_itm": loss_itm, "loss_mlm": loss_mlm}
+        if region is not None:                                                            # model_pretrain.py:62-74
+            coord = self.bbox_coord(last[4 * B:, 0, :])
+            loss["loss_bbox"], loss["loss_giou"] = self.get_bbox_loss(coord, target_bbox, is_image=is_image)
+            hidden_dict["bbox_hidden_states"], attention_dict["bbox_attentions"] = f_hid[3], f_att[3]
+            cross_attention_dict["bbox_cross_attentions"] = f_cross[3]
+            self.last_output_coord = coord.detach()
         return {"loss": loss, "hidden_dict": hidden_dict, "attention_dict": attention_dict,
                 "cross_attention_dict": cross_attention_dict, "logits_dict": logits_dict}

@@ -60,7 +60,6 @@ class FlatAdamW:
         dev = named[0][1].device
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.hyper = torch.ones(3, dtype=torch.float32, device=dev)       # {lr multiplier, bias_c1, bias_c2}
-        self._hyper_host = torch.ones(3, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.ones(3)
         lowp = dev.type == "cuda"
         for g in self.groups:
             n = sum((p.numel() + 7) // 8 * 8 for p in g["params"])          # 32-byte (fp32) / 16-byte (bf16) aligned segments
@@ -119,10 +118,13 @@ class FlatAdamW:
         """host-side per-step scalars -> device (call OUTSIDE a captured graph, before replay)"""
         self.step_count += 1
         b1, b2 = self.betas
-        self._hyper_host[0] = lr_mult
-        self._hyper_host[1] = 1.0 - b1 ** self.step_count
-        self._hyper_host[2] = 1.0 - b2 ** self.step_count
-        self.hyper.copy_(self._hyper_host, non_blocking=True)
+        # a FRESH pinned block per step: the host may run several (graph-replayed) steps ahead of the device, so a
+        # single staging buffer would be overwritten before its asynchronous upload has executed.  torch's pinned-memory
+        # cache recycles a block only after the copy that read it has completed.
+        host = torch.tensor([lr_mult, 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count], dtype=torch.float32)
+        if self.hyper.is_cuda:
+            host = host.pin_memory()
+        self.hyper.copy_(host, non_blocking=True)
 
     def step(self):
         """clip by global norm + AdamW; pure device work (capturable).  Gradients must live in the flat slabs."""

@@ -150,6 +150,8 @@ class GDTrainer:
         self.graph = None
         self.static = None
         self.out = None
+        self._graphs = {}
+        self._held = None
         if self.world > 1:
             for g in self.opt.groups:                     # broadcast params from rank 0 (apex_ddp_accelerator.py:75-77)
                 dist.broadcast(g["p"], 0)
@@ -198,6 +200,7 @@ class GDTrainer:
         """static batch buffers x2, two eager warm-up steps (lr 0), the teacher outputs of the first batch in persistent
         buffers x2 (only the tensors the KD terms read; attention maps keep their padded rows)"""
         B = [{k: v.clone() for k, v in batch.items()} for _ in range(2)]
+        state = [(g["m"].clone(), g["v"].clone()) for g in self.opt.groups], self.opt.step_count
         self._keep_ST = True
         warm = torch.cuda.Stream()                         # warm-up on a side stream, as torch.cuda.graph asks for
         warm.wait_stream(torch.cuda.current_stream())
@@ -208,9 +211,9 @@ class GDTrainer:
         torch.cuda.current_stream().wait_stream(warm)
         self._keep_ST = False
         torch.cuda.synchronize()
-        for g in self.opt.groups:
-            g["m"].zero_(); g["v"].zero_()
-        self.opt.step_count = 0
+        for g, (m, v) in zip(self.opt.groups, state[0]):       # the warm-up steps (lr 0) leave no trace
+            g["m"].copy_(m); g["v"].copy_(v)
+        self.opt.step_count = state[1]
         S, T = self._last_ST
         slots = distill.kd_teacher_slots(T, S)
         dummy = torch.zeros(0, device=batch["image"].device)
@@ -229,7 +232,7 @@ class GDTrainer:
                     out[d][key][i] = buf
             return out
         self._pipe = dict(B=B, T=[persist(), persist()], slots=slots, k=0, graphs=[None, None], out=[None, None],
-                          side=torch.cuda.Stream())
+                          side=torch.cuda.Stream(), pending=False)
         self._last_ST = None
         del S, T
         self._pipe_teacher(0, warm)                            # teacher outputs of the first batch
@@ -250,9 +253,7 @@ class GDTrainer:
         st = self._pipe
         b = st["B"][k]
         with torch.cuda.stream(stream), torch.no_grad(), compute(self.dtype):
-            T = self.teacher(b["image"], b["text_ids"], b["text_atts"], text_ids_masked=b["text_ids_masked"],
-                             masked_pos=b["masked_pos"], masked_ids=b["masked_ids"], output_attentions=True,
-                             output_hidden_states=True)
+            T = self.teacher(b["image"], b["text_ids"], b["text_atts"], **distill.model_kwargs(b))
             for d, key, i in st["slots"]:
                 src = T[d][key] if i is None else T[d][key][i]
                 dst = st["T"][k][d][key] if i is None else st["T"][k][d][key][i]
@@ -282,11 +283,32 @@ class GDTrainer:
         return out
 
     def _step_pipelined(self, batch, lr_mult):
-        if self._pipe is None:
-            self._pipe_prime(batch)
-            return None
+        """General batches flow through the teacher pipeline.  A REGION batch (GeneralDistill.py:158: drawn with
+        probability regions.iter_perc before a general step) keeps the reference's update order: the general batch
+        waiting in the pipeline is trained on first (eagerly, nothing to prefetch), then the region step runs through
+        the unpipelined path, and the next general batch re-primes the pipeline.  Either way a call returns the losses of
+        the batch handed to the PREVIOUS call."""
         st = self._pipe
+        if "idx_to_group_img" in batch:
+            prev = self._held
+            if st is not None and st["pending"]:
+                self.opt.set_schedule(lr_mult)                 # (advances the bias-correction step count: once per step)
+                prev = self._pipe_drain().clone()
+            self._held = self._step_unpipelined(batch, lr_mult).clone()
+            return prev
+        if st is None:
+            self._pipe_prime(batch)
+            self._pipe["pending"] = True
+            prev, self._held = self._held, None
+            return prev
         k = st["k"]
+        if not st["pending"]:                                  # re-prime after a region step: teacher only, on buffer k
+            for name, v in batch.items():
+                st["B"][k][name].copy_(v, non_blocking=True)
+            self._pipe_teacher(k, torch.cuda.current_stream())
+            st["pending"] = True
+            prev, self._held = self._held, None
+            return prev
         for name, v in batch.items():
             st["B"][1 - k][name].copy_(v, non_blocking=True)
         self.opt.set_schedule(lr_mult)
@@ -298,42 +320,60 @@ class GDTrainer:
         st["k"] = 1 - k
         return out
 
+    def _pipe_drain(self):
+        """student step on the batch waiting in the pipeline (its teacher outputs are ready), no prefetch"""
+        st = self._pipe
+        out = self._step_eager_no_opt(st["B"][st["k"]], st["T"][st["k"]])
+        self.opt.step()
+        st["pending"] = False
+        return out
+
     def step(self, batch, lr_mult=1.0):
-        """one GD step; returns a device tensor [total, itc, itm, mlm, kd] (no host sync)."""
+        """one GD step on a general or a region batch (the latter carries idx_to_group_img / image_atts / target_bbox /
+        is_image); returns a device tensor [total, itc, itm, mlm, kd] (no host sync)."""
         if self.pipeline_teacher:
             return self._step_pipelined(batch, lr_mult)
+        return self._step_unpipelined(batch, lr_mult)
+
+    def _step_unpipelined(self, batch, lr_mult):
         if not self.use_graph or self.reducer.active:
             # multi-GPU: the step runs eagerly - RCCL collectives cannot be captured into a hipGraph on this stack
             # (tools/rccl_graph_probe.py crashes), and the eager step is GPU-bound anyway (same ms/step as the replay).
             self.opt.set_schedule(lr_mult)
             return self._step_eager(batch)
-        if self.graph is None:
-            self._capture(batch)
+        sig = tuple(sorted((k, tuple(v.shape)) for k, v in batch.items()))     # one hipGraph per batch kind / shape
+        if sig not in self._graphs:
+            self._graphs[sig] = self._capture(batch)
+        graph, static, out = self._graphs[sig]
+        self.graph, self.static, self.out = graph, static, out
         self.opt.set_schedule(lr_mult)
         for k, v in batch.items():
-            self.static[k].copy_(v, non_blocking=True)
-        self.graph.replay()
-        return self.out
+            static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        return out
 
     def _capture(self, batch):
-        self.static = {k: v.clone() for k, v in batch.items()}
+        static = {k: v.clone() for k, v in batch.items()}
+        state = [(g["m"].clone(), g["v"].clone()) for g in self.opt.groups], self.opt.step_count
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):                             # warm-up on a side stream (allocator + weight caches);
                 self.opt.set_schedule(0.0)                 # lr multiplier 0: parameters are left untouched
-                self._step_eager(self.static)
+                self._step_eager(static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ops.CACHE.invalidate()                             # capture the casts of the trainable weights too
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = self._step_eager(self.static)
-        # the warm-up advanced Adam's step count and moments: reset them so replay k is optimiser step k
-        for g in self.opt.groups:
-            g["m"].zero_()
-            g["v"].zero_()
-        self.opt.step_count = 0
+        graph = torch.cuda.CUDAGraph()
+        pool = next(iter(self._graphs.values()))[0].pool() if self._graphs else None   # the kinds never run concurrently
+        with torch.cuda.graph(graph, pool=pool):
+            out = self._step_eager(static)
+        # the warm-up advanced Adam's step count and moments: restore them so replay k is optimiser step k
+        for g, (m, v) in zip(self.opt.groups, state[0]):
+            g["m"].copy_(m)
+            g["v"].copy_(v)
+        self.opt.step_count = state[1]
+        return graph, static, out
 
 
 class ITRTrainer:

@@ -56,5 +56,6 @@ def close(a, b, rtol, atol=0.0, what=""):
 
 
 def batch_from_fixture(fx, device):
-    keys = ("image", "text_ids", "text_atts", "text_ids_masked", "masked_pos", "masked_ids")
+    keys = ("image", "text_ids", "text_atts", "text_ids_masked", "masked_pos", "masked_ids",
+            "idx_to_group_img", "image_atts", "target_bbox", "is_image")           # the last four: region batches
     return {k: torch.from_numpy(fx["in." + k]).to(device) for k in keys if "in." + k in fx}

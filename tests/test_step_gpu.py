@@ -61,11 +61,16 @@ def check_against_fixture(fx, tag, out, full, rtol):
         close(t, fx[f"{tag}.{k}"], rtol, 0, f"{tag}.{k}")
 
 
-@pytest.mark.parametrize("name,full", [("gd_tiny.npz", True), ("gd_full.npz", False)])
-def test_gd_step_fp32_matches_reference_vectors(name, full):
+@pytest.mark.parametrize("name,full,batched", [("gd_tiny.npz", True, True), ("gd_full.npz", False, True),
+                                               ("gd_region_tiny.npz", True, True), ("gd_region_tiny.npz", True, False),
+                                               ("gd_region_full.npz", False, True)])
+def test_gd_step_fp32_matches_reference_vectors(name, full, batched):
+    """general steps and REGION steps (idx_to_group_img / image_atts / bbox + giou; GeneralDistill.py:158-262), the
+    latter through both the batched and the pass-by-pass forward"""
     fx = load_fixture(name)
     geom = synth.GEOMS[str(fx["meta.geom"])]
     student, teacher = build_gd(geom, int(fx["meta.seed"]), fx)
+    student.batched_passes = teacher.batched_passes = batched
     total, S, T, kd, mix = run_gd(student, teacher, fx, torch.float32)
     check_against_fixture(fx, "student", S, full, 1e-4)
     check_against_fixture(fx, "teacher", T, full, 1e-4)
@@ -445,3 +450,100 @@ def test_pipelined_teacher_reproduces_the_unpipelined_training_trajectory(use_gr
         del tr, student, teacher
     assert torch.allclose(outs[True], outs[False], rtol=5e-4, atol=1e-5), (outs[True], outs[False])
     assert float((outs[False][0] - outs[False][3]).abs().max()) > 1e-3      # the batches (and the training) do differ
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_region_steps_interleave_with_general_steps_in_reference_order(use_graph, monkeypatch):
+    """The GD recipe draws a REGION step (idx_to_group_img / image_atts / bbox + giou losses) before a general step with
+    probability 0.5 (GeneralDistill.py:157-262).  A mixed sequence G R G G R R G must give the same loss trajectory through
+    the unpipelined trainer (one hipGraph per batch kind) and the pipelined one (which trains on the waiting general batch
+    first, then the region batch, then re-primes) - i.e. the optimiser updates are applied in arrival order."""
+    from efficientvlm_amd.efficient_models.xvlm import XVLMBase
+    from efficientvlm_amd.trainer import GDTrainer
+
+    def fixed_negatives(self, image_feat, text_feat, idx):
+        bs = image_feat.size(0)
+        ar = torch.arange(bs, device=image_feat.device)
+        return (ar + 1) % bs, (ar + 2) % bs
+    monkeypatch.setattr(XVLMBase, "_sample_negatives", fixed_negatives)
+    geom = synth.GEOMS["tiny"]
+    dev = lambda b: {k: v.to(DEV) for k, v in b.items()}
+    G = [dev(synth.make_batch(geom, 4, seed=80 + i)) for i in range(4)]
+    R = [dev(synth.make_region_batch(geom, 3, 6, seed=90 + i)) for i in range(3)]
+    seq = [G[0], R[0], G[1], G[2], R[1], R[2], G[3]]
+    outs = {}
+    for pipe in (False, True):
+        student, teacher = build_gd(geom, 9)
+        tr = GDTrainer(student, teacher, lr=1e-3, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=torch.float32,
+                       use_graph=use_graph, pipeline_teacher=pipe)
+        got = []
+        for b in seq:
+            o = tr.step(b)
+            if o is not None:
+                got.append(o.clone())                       # (a graph replay returns its static output tensor)
+        if pipe:
+            assert len(got) == len(seq) - 1
+            got.append(tr.step(G[0]).clone())               # flushes the losses of the last batch of `seq`
+        torch.cuda.synchronize()
+        outs[pipe] = torch.stack(got).cpu()
+        w = torch.cat([p.detach().reshape(-1).float().cpu() for p in list(student.parameters())[:40]])
+        outs[pipe, "w"] = w
+        del tr, student, teacher
+    assert torch.allclose(outs[True], outs[False], rtol=5e-4, atol=1e-5), (outs[True], outs[False])
+    assert torch.isfinite(outs[False]).all()
+
+
+def test_region_training_steps_match_oracle_plus_optimiser_restatement():
+    """two REGION steps through GDTrainer (fp32, tiny geometry, same hard negatives on both sides) against oracle
+    forward/backward (bbox branch included) + the restated clip + HF-AdamW: losses of both steps and the parameter
+    UPDATES of large tensors, the bbox head (which only region steps train) among them"""
+    from efficientvlm_amd.models.model_pretrain import XVLM
+    from efficientvlm_amd.trainer import GDTrainer
+    from oracle import optim_oracle as OO
+    geom = synth.GEOMS["tiny"]
+    s_cfg, t_cfg = O.model_cfg(geom, "s"), O.model_cfg(geom, "t")
+    student, teacher = XVLM(model_config(geom, "s")), XVLM(model_config(geom, "t"))
+    s_sd = load_det_weights(student, schema.xvlm_schema(s_cfg, geom["max_pos"]), 31, geom["std"])
+    t_sd = load_det_weights(teacher, schema.xvlm_schema(t_cfg, geom["max_pos"]), 32, geom["std"])
+    student.to(DEV); teacher.to(DEV)
+    lr, wd, lr_mult = 1e-3, 0.01, 2.0
+    tr = GDTrainer(student, teacher, lr=lr, weight_decay=wd, lr_mult=lr_mult, max_grad_norm=1.0, dtype=torch.float32,
+                   use_graph=False)
+    W, DW, DB = ("text_encoder.bert.embeddings.word_embeddings.weight", "text_encoder.cls.predictions.decoder.weight",
+                 "text_encoder.cls.predictions.decoder.bias")
+    ref = {k: v.clone().float().requires_grad_(True) for k, v in s_sd.items() if torch.is_floating_point(v) and k not in (DW, DB)}
+    p0 = {k: v.detach().clone() for k, v in ref.items()}
+    tie = lambda sd: {**sd, DW: sd[W], DB: sd["text_encoder.cls.predictions.bias"]}
+    t_sd = tie(t_sd)
+    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in ref.items()}
+    groups = OO.param_groups([(n, p) for n, p in student.named_parameters()], student.init_params, lr, wd, lr_mult)
+    R = 6
+    for step in range(2):
+        batch = synth.make_region_batch(geom, 3, R, seed=70 + step)
+        s_neg = torch.tensor([(i + 1 + step) % R for i in range(2 * R)])
+        t_neg = torch.tensor([(i + 2) % R for i in range(2 * R)])
+        student.injected_neg_idx, teacher.injected_neg_idx = s_neg.clone(), t_neg.clone()
+        got = tr.step({k: v.to(DEV) for k, v in batch.items()}).cpu()
+        for v in ref.values():
+            v.grad = None
+        total, S, T, kd, mix = O.gd_step(tie({**s_sd, **ref}), t_sd, s_cfg, t_cfg, batch, s_neg, t_neg)
+        assert "loss_bbox" in S["loss"] and float(S["loss"]["loss_giou"]) > 0
+        total.backward()
+        want = torch.stack([total.detach(), S["loss"]["loss_itc"].detach(), S["loss"]["loss_itm"].detach(),
+                            S["loss"]["loss_mlm"].detach(), mix["loss_kd"].detach()])
+        assert torch.allclose(got, want, rtol=2e-4, atol=1e-6), (step, got, want)
+        with torch.no_grad():
+            names = [n for g in groups for n in g["names"]]
+            grads = {n: (ref[n].grad if ref[n].grad is not None else torch.zeros_like(ref[n])) for n in names}
+            OO.clip_grad_norm_(list(grads.values()), 1.0)
+            for g in groups:
+                for n in g["names"]:
+                    OO.hf_adamw_step(ref[n], grads[n], state[n][0], state[n][1], step + 1, g["lr"], (0.9, 0.98), 1e-8,
+                                     g["weight_decay"])
+    mine = {n: p.detach().cpu() for n, p in student.named_parameters()}
+    for n in ("vision_encoder.encoder.layers.5.mlp.fc1.weight", "vision_encoder.encoder.layers.0.self_attn.q_proj.weight",
+              "text_encoder.bert.encoder.layer.4.crossattention.self.key.weight", "bbox_head.0.weight", "bbox_head.3.weight",
+              "itm_head.0.weight", W):
+        d_ref, d_mine = ref[n].detach() - p0[n], mine[n] - p0[n]
+        assert float(d_ref.abs().max()) > 0, n
+        assert float((d_mine - d_ref).norm()) <= 0.02 * float(d_ref.norm()), (n, float((d_mine - d_ref).norm()), float(d_ref.norm()))
