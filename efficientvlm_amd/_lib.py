@@ -37,7 +37,7 @@ class AttnFwdArgs(C.Structure):
                 ("B", _i), ("H", _i), ("Lq", _i), ("Lk", _i), ("dh", _i),
                 ("ldq", _i), ("ldk", _i), ("ldv", _i), ("ldo", _i), ("ldpr", _i),
                 ("Q", _vp), ("K", _vp), ("V", _vp), ("kv_index", _vp), ("mask", _vp), ("head_gate", _vp),
-                ("scale", _f), ("O", _vp), ("P", _vp)]
+                ("scale", _f), ("O", _vp), ("P", _vp), ("causal", _i)]
 
 
 class AttnBwdArgs(C.Structure):

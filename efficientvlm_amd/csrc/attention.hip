@@ -18,6 +18,7 @@ struct AttnF {
   void* O; void* P;
   int B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, ldpr;
   float scale;
+  int causal;
 };
 
 // load rows [r0, r0+nrows) x dh of a [.., L, H, dh]-strided tensor (row stride ld) into LDS as fp32 [nrows][dh+1]
@@ -60,7 +61,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnF a) {
         float s = 0.f;
         for (int d = 0; d < dh; ++d) s = fmaf(Qs[r * (dh + 1) + d], KVs[key * (dh + 1) + d], s);
         s *= a.scale;
-        if (mk) s += mk[kb + key];
+        float add = mk ? mk[kb + key] : 0.f;
+        if (a.causal && kb + key > q0 + r) add = fminf(add, -10000.0f);      // (1 - causal * pad) * -10000: once, not twice
+        s += add;
         Ss[r * Lkp + kb + key] = s;
       }
     }
@@ -307,11 +310,12 @@ extern "C" int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream_) {
   EVLM_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0, "evlm_attention_fwd: bad shape");
   EVLM_REQUIRE((a->ldq | a->ldk | a->ldv) % 8 == 0, "evlm_attention_fwd: row strides must be multiples of 8");
   EVLM_REQUIRE(!a->P || (a->ldpr >= a->Lk && a->ldpr % 8 == 0), "evlm_attention_fwd: ldpr must be a multiple of 8 and >= Lk");
+  EVLM_REQUIRE(!a->causal || a->Lq == a->Lk, "evlm_attention_fwd: a causal mask needs Lq == Lk");
   int handled = 0;
   if (int e = evlm_attention_fwd_mfma(a, stream, &handled)) return e;
   if (handled) return 0;
   AttnF f;
-  f.Q = a->Q; f.K = a->K; f.V = a->V; f.kv_index = a->kv_index; f.mask = a->mask; f.gate = a->head_gate;
+  f.Q = a->Q; f.K = a->K; f.V = a->V; f.kv_index = a->kv_index; f.mask = a->mask; f.gate = a->head_gate; f.causal = a->causal;
   f.O = a->O; f.P = a->P; f.B = a->B; f.H = a->H; f.Lq = a->Lq; f.Lk = a->Lk; f.dh = a->dh;
   f.ldq = a->ldq; f.ldk = a->ldk; f.ldv = a->ldv; f.ldo = a->ldo; f.ldpr = a->ldpr; f.scale = a->scale;
   const int Lkp = (a->Lk + 3) & ~3;

@@ -13,6 +13,7 @@ struct MAttnF {
   bf16* O; bf16* P;
   int B, H, Lq, Lk, ldq, ldk, ldv, ldo, ldpr;
   float scale;
+  int causal;
 };
 
 #define DH 64
@@ -114,7 +115,9 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
     const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + tile_key0(t, g));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      acc[t][r] = acc[t][r] * sc + mk[r] * 1.44269504088896341f;
+      float add = mk[r];
+      if (a.causal && tile_key0(t, g) + r > q) add = fminf(add, -10000.0f);   // decoder: keys after the query
+      acc[t][r] = acc[t][r] * sc + add * 1.44269504088896341f;
       m = fmaxf(m, acc[t][r]);
     }
   }
@@ -417,7 +420,7 @@ int evlm_attention_fwd_mfma(const evlm_attn_fwd_args* a, hipStream_t stream, int
   f.Q = (const bf16*)a->Q; f.K = (const bf16*)a->K; f.V = (const bf16*)a->V; f.kv_index = a->kv_index;
   f.mask = a->mask; f.gate = a->head_gate; f.O = (bf16*)a->O; f.P = (bf16*)a->P;
   f.B = a->B; f.H = a->H; f.Lq = a->Lq; f.Lk = a->Lk; f.ldq = a->ldq; f.ldk = a->ldk; f.ldv = a->ldv; f.ldo = a->ldo;
-  f.ldpr = a->ldpr; f.scale = a->scale;
+  f.ldpr = a->ldpr; f.scale = a->scale; f.causal = a->causal;
   if (a->Lk <= 32) launch_fwd<2>(f, stream);
   else if (a->Lk <= 64) launch_fwd<4>(f, stream);
   else if (a->Lk <= 224) launch_fwd<14>(f, stream);

@@ -498,7 +498,7 @@ class _Attention(torch.autograd.Function):
     v_off (qbuf is kvbuf for self-attention).  Returns (O [B,Lq,H*dh], P [B,H,Lq,Lk])."""
 
     @staticmethod
-    def forward(ctx, qbuf, kvbuf, mask, gate, H, dh, q_off, k_off, v_off, scale, want_probs, kv_index=None):
+    def forward(ctx, qbuf, kvbuf, mask, gate, H, dh, q_off, k_off, v_off, scale, want_probs, kv_index=None, causal=False):
         L.require_cuda(qbuf, kvbuf)
         assert qbuf.is_contiguous() and kvbuf.is_contiguous()
         B, Lq, ldq = qbuf.shape
@@ -516,7 +516,7 @@ class _Attention(torch.autograd.Function):
                           ldo=H * dh, ldpr=Lkp, Q=C.c_void_p(qbuf.data_ptr() + q_off * es),
                           K=C.c_void_p(kvbuf.data_ptr() + k_off * es), V=C.c_void_p(kvbuf.data_ptr() + v_off * es),
                           kv_index=L.ptr(kv_index), mask=L.ptr(m32), head_gate=L.ptr(g32), scale=scale, O=L.ptr(O),
-                          P=L.ptr(Pbuf))
+                          P=L.ptr(Pbuf), causal=int(bool(causal)))
         L.check(_lib().evlm_attention_fwd(C.byref(a), L.stream()), "attention_fwd")
         ctx.set_materialize_grads(False)        # an unused probability map must not cost a zero tensor in backward
         ctx.save_for_backward(qbuf, kvbuf, Pbuf, g32, kv_index)
@@ -558,14 +558,15 @@ class _Attention(torch.autograd.Function):
         L.check(_lib().evlm_attention_bwd(C.byref(a), L.stream()), "attention_bwd")
         dg = dgate.view(gshape) if dgate is not None else None
         if self_attn:
-            return dqbuf, None, None, dg, None, None, None, None, None, None, None, None
-        return dqbuf, dkvbuf, None, dg, None, None, None, None, None, None, None, None
+            return dqbuf, None, None, dg, None, None, None, None, None, None, None, None, None
+        return dqbuf, dkvbuf, None, dg, None, None, None, None, None, None, None, None, None
 
 
-def self_attention(qkv, H, dh, scale, mask=None, gate=None, want_probs=True):
-    """qkv: [B, L, 3*H*dh] packed (q | k | v)"""
+def self_attention(qkv, H, dh, scale, mask=None, gate=None, want_probs=True, causal=False):
+    """qkv: [B, L, 3*H*dh] packed (q | k | v); causal: additionally -10000 on keys after the query (decoder self-attention:
+    the backward works from the saved probabilities, so only the forward kernel knows about masks)"""
     d = H * dh
-    return _Attention.apply(qkv, qkv, mask, gate, H, dh, 0, d, 2 * d, scale, want_probs)
+    return _Attention.apply(qkv, qkv, mask, gate, H, dh, 0, d, 2 * d, scale, want_probs, None, causal)
 
 
 def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True, kv_index=None):

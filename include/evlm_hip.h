@@ -132,6 +132,8 @@ typedef struct {
   const float* head_gate;       /* [H] f32 or NULL */
   float scale;
   void* O; void* P;
+  int causal;                   /* != 0: additionally add -10000 where key > query - the decoder's causal mask
+                                   (get_extended_attention_mask is_decoder branch, eff_bert.py:975-996); needs Lq == Lk */
 } evlm_attn_fwd_args;
 int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream);
 

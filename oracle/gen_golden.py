@@ -572,6 +572,136 @@ def gen_optim(seed):
     return out
 
 
+def load_vqa_helpers():
+    """ast-extract get_kd_loss / soft_cross_entropy / get_cor_teacher from Eff_VQA.py (it cannot be imported)"""
+    src = open(os.path.join(REF, "Eff_VQA.py")).read()
+    tree = ast.parse(src)
+    want = {"get_kd_loss", "soft_cross_entropy", "get_cor_teacher"}
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    ns = {"torch": torch, "KLDivLoss": torch.nn.KLDivLoss, "MSELoss": torch.nn.MSELoss}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "<vqa_helpers>", "exec"), ns)
+    return ns["get_kd_loss"], ns["soft_cross_entropy"], ns["get_cor_teacher"]
+
+
+def gen_vqa(geom_name, B, seed):
+    """one Eff_VQA.py training step (:95-176): EffXVLMForVQA student with VQAL0Module gates (decoder gates included)
+    against the XVLMForVQA teacher - weighted answer LM loss, text / cross / image / decoder hidden + attention KD, logit
+    KD, Lagrangian - and the backward."""
+    geom = synth.GEOMS[geom_name]
+    work = tempfile.mkdtemp(prefix="evlm_oracle_")
+    os.chdir(work)
+    scfg, tcfg = write_configs(work, geom)
+    nd_s = geom["s_text_layers"] - geom["s_text_layers"] // 2
+    nd_t = geom["t_text_layers"] - geom["t_text_layers"] // 2
+    scfg.update(pad_token_id=0, num_dec_layers=nd_s)
+    tcfg.update(pad_token_id=0, num_dec_layers=nd_t)
+    sys.modules["dataset"] = types.ModuleType("dataset")          # only build_tokenizer is imported (inference path)
+    sys.modules["dataset"].build_tokenizer = lambda *a, **k: None
+    from efficient_models.model_generation import EffXVLMForVQA
+    from models.model_generation import XVLMForVQA
+    torch.manual_seed(seed)
+    student = EffXVLMForVQA(scfg)
+    teacher = XVLMForVQA(tcfg)
+    student.load_state_dict(det_state_dict(student.state_dict(), seed=5000 + seed, std=geom["std"]), strict=True)
+    teacher.load_state_dict(det_state_dict(teacher.state_dict(), seed=6000 + seed, std=geom["std"]), strict=True)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(seed + 99)
+        l0 = student.l0_module
+        for nm in ("vision_head_loga", "text_head_loga", "cross_head_loga", "decoder_head_loga"):
+            getattr(l0, nm).copy_(torch.randn(getattr(l0, nm).shape, generator=g) + 0.5)
+        for nm in ("vision_int_loga", "text_int_loga", "cross_int_loga", "decoder_int_loga"):
+            getattr(l0, nm).copy_(torch.randn(getattr(l0, nm).shape, generator=g))
+        l0.lambda_1.fill_(0.3)
+        l0.lambda_2.fill_(-0.2)
+    l0.set_lagrangian_warmup_steps(10)
+    batch = synth.make_vqa_batch(geom, B, seed=seed)
+    NS = types.SimpleNamespace
+    question = NS(input_ids=batch["question_ids"], attention_mask=batch["question_atts"])
+    answer = NS(input_ids=batch["answer_ids"], attention_mask=batch["answer_atts"])
+    k = batch["k"].tolist()
+    student.train()
+    teacher.eval()
+    get_kd_loss, soft_ce, get_cor = load_vqa_helpers()
+    eps_log = []
+    real_get_eps = l0.get_eps
+
+    def rec_eps(size):
+        e = real_get_eps(size)
+        eps_log.append(e.clone())
+        return e
+    l0.get_eps = rec_eps
+    torch.manual_seed(seed + 7)
+    S = student(batch["image"], question, answer, train=True, k=k, weights=batch["weights"], output_attentions=True,
+                output_hidden_states=True, stop_prune=False)
+    with torch.no_grad():
+        T = teacher(batch["image"], question, answer, train=True, k=k, weights=batch["weights"], output_attentions=True,
+                    output_hidden_states=True)
+    mse = torch.nn.MSELoss()
+    sh, th, sa, ta = S["hidden_dict"], T["hidden_dict"], S["attention_dict"], T["attention_dict"]
+    sc, tc = S["cross_attention_dict"], T["cross_attention_dict"]
+    kd = {}
+    s_text_h, t_text_h = sh["text_hidden_states"], get_cor(th["text_hidden_states"], sh["text_hidden_states"])
+    s_text_a = sa["text_attentions"]
+    t_text_a = get_cor(ta["text_attentions"], s_text_a, is_attn=True)
+    t_cross_a = get_cor(tc["cross_attentions"], sc["cross_attentions"], is_attn=True)
+    # Eff_VQA.py:118-137 hard-codes the split of a (3 text + 3 fusion)-layer student: [:4] / [4:] states, [:3] / [3:] maps
+    kd["text_hidden"] = get_kd_loss(s_text_h[:4], t_text_h[:4], False, mse, "cpu")
+    kd["text_attn"] = get_kd_loss(s_text_a[:3], t_text_a[:3], True, mse, "cpu")
+    kd["cross_hidden"] = get_kd_loss(s_text_h[4:], t_text_h[4:], False, mse, "cpu")
+    kd["cross_self_attn"] = get_kd_loss(s_text_a[3:], t_text_a[3:], True, mse, "cpu")
+    kd["cross_attn"] = get_kd_loss(sc["cross_attentions"], t_cross_a, True, mse, "cpu")
+    kd["image_hidden"] = get_kd_loss(sh["image_hidden_states"], get_cor(th["image_hidden_states"], sh["image_hidden_states"]),
+                                     False, mse, "cpu", is_img=True)
+    kd["image_attn"] = get_kd_loss(sa["image_attentions"], get_cor(ta["image_attentions"], sa["image_attentions"], is_attn=True),
+                                   True, mse, "cpu")
+    kd["decoder_hidden"] = get_kd_loss(sh["decoder_hidden_states"],
+                                       get_cor(th["decoder_hidden_states"], sh["decoder_hidden_states"]), False, mse, "cpu",
+                                       is_img=True)
+    kd["decoder_attn"] = get_kd_loss(sa["decoder_attentions"],
+                                     get_cor(ta["decoder_attentions"], sa["decoder_attentions"], is_attn=True), True, mse, "cpu")
+    kd["decoder_cross"] = get_kd_loss(sc["decoder_cross_attentions"],
+                                      get_cor(tc["decoder_cross_attentions"], sc["decoder_cross_attentions"], is_attn=True),
+                                      True, mse, "cpu")
+    kd["logits"] = soft_ce(S["logits_dict"]["logits"] / 1.0, T["logits_dict"]["logits"] / 1.0)
+    # Eff_VQA.py:165-176
+    loss_text_kd = kd["text_attn"] + kd["text_hidden"]
+    loss_img_kd = kd["image_attn"] + kd["image_hidden"] * 0.2
+    loss_cross_kd = (kd["cross_hidden"] + kd["cross_self_attn"] + kd["cross_attn"]) * 0.5
+    loss_decoder_kd = kd["decoder_attn"] + kd["decoder_hidden"] + kd["decoder_cross"]
+    loss_kd = kd["logits"] + loss_text_kd + loss_img_kd + loss_cross_kd + loss_decoder_kd
+    lagr, exp_s, tgt_s = l0.lagrangian_regularization(3)
+    total = loss_kd * 0.4 + S["loss"] * 0.6 + lagr
+    total.backward()
+
+    fx = {"meta.geom": np.array(geom_name), "meta.B": np.array(B), "meta.seed": np.array(seed)}
+    for kk, v in batch.items():
+        fx[f"in.{kk}"] = np_(v)
+    for t, e in zip(l0.types, eps_log):
+        fx[f"in.eps.{t}"] = np_(e)
+    fx["meta.l0_types"] = np.array(list(l0.types))
+    for n, p in l0.named_parameters():
+        fx[f"in.l0.{n}"] = np_(p)
+    for tag, m in (("student", student), ("teacher", teacher)):
+        for n, (a, b) in checksums(m.state_dict()).items():
+            fx[f"{tag}.wchk.{n}"] = np.array([a, b])
+    for tag, out in (("student", S), ("teacher", T)):
+        for dn in ("hidden_dict", "attention_dict", "cross_attention_dict"):
+            for kk, tup in out[dn].items():
+                tuple_to(fx, f"{tag}.{kk}", tup)
+        fx[f"{tag}.logits"] = np_(out["logits_dict"]["logits"])
+        fx[f"{tag}.loss"] = np_(out["loss"])
+    for kk, v in kd.items():
+        fx[f"kd.{kk}"] = np_(v)
+    for kk, v in dict(loss_text_kd=loss_text_kd, loss_img_kd=loss_img_kd, loss_cross_kd=loss_cross_kd,
+                      loss_decoder_kd=loss_decoder_kd, loss_kd=loss_kd, total=total, lagrangian=lagr,
+                      expected_sparsity=exp_s).items():
+        fx[f"mix.{kk}"] = np_(v)
+    fx["mix.target_sparsity"] = np.array(float(tgt_s))
+    fx["meta.prunable_model_size"] = np.array(int(l0.prunable_model_size))
+    grads_to(fx, "student", student, True)
+    return fx
+
+
 def gen_ckpt_remap(seed):
     """checkpoint load / remap contract (efficient_models/xvlm.py:183-208 load_pretrained, models/vit.py:222-247
     interpolate_pos_embed): a small synthetic checkpoint through the reference's own loader"""
@@ -619,7 +749,7 @@ if __name__ == "__main__":
     dist.init_process_group("gloo", rank=0, world_size=1)
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["kd", "l0", "gd_tiny", "itr_tiny", "gd_full", "optim", "ckpt", "gd_region_tiny",
-                              "gd_region_full"]
+                              "gd_region_full", "vqa_tiny"]
     if "ckpt" in which:
         save("ckpt_remap.npz", gen_ckpt_remap(13))
     if "optim" in which:
@@ -637,6 +767,8 @@ if __name__ == "__main__":
         save("itr_tiny.npz", gen_itr("tiny", B=4, seed=4))
     if "gd_full" in which:
         save("gd_full.npz", gen_gd("full", B=2, seed=2, full=False))
+    if "vqa_tiny" in which:
+        save("vqa_tiny.npz", gen_vqa("tiny", B=3, seed=12))
     if "gd_region_tiny" in which:
         save("gd_region_tiny.npz", gen_gd("tiny", B=3, seed=6, full=True, region_rows=6))
     if "gd_region_full" in which:

@@ -89,6 +89,33 @@ def xvlm_schema(cfg, max_pos, mlm=True, bbox=True, l0=False):
     return d
 
 
+def vqa_schema(cfg, max_pos, l0=False):
+    """efficient_models/model_generation.py:23-55 EffXVLMForVQA / models/model_generation.py:228-255 XVLMForVQA: image encoder,
+    BertModel text encoder (no MLM head, no projection / matching heads), BertLMHeadModel decoder of
+    num_dec_layers = number of fusion layers whose EVERY layer cross-attends (fusion_layer 0, encoder_width = hidden)"""
+    h = cfg["hidden"]
+    d = vit_schema(cfg)
+    d.update(bert_schema(cfg, "text_encoder.", max_pos))
+    nd = cfg["text_layers"] - cfg["fusion_layer"]
+    d.update(bert_schema(dict(cfg, text_layers=nd, fusion_layer=0), "text_decoder.bert.", max_pos))
+    cp = "text_decoder.cls.predictions."
+    d[cp + "bias"] = (cfg["vocab"],)
+    _lin(d, cp + "transform.dense", h, h)
+    _ln(d, cp + "transform.LayerNorm", h)
+    d[cp + "decoder.weight"] = (cfg["vocab"], h)          # tied to the decoder's word_embeddings
+    d[cp + "decoder.bias"] = (cfg["vocab"],)
+    if l0:
+        nv, nt = cfg["vit_layers"], cfg["fusion_layer"]
+        nc = cfg["text_layers"] - nt
+        H, f = cfg["heads"], cfg["ffn"]
+        d.update({"l0_module.vision_head_loga": (nv, H), "l0_module.text_head_loga": (nt, H),
+                  "l0_module.cross_head_loga": (2 * nc, H), "l0_module.decoder_head_loga": (2 * nd, H),
+                  "l0_module.vision_int_loga": (nv, f), "l0_module.text_int_loga": (nt, f),
+                  "l0_module.cross_int_loga": (nc, f), "l0_module.decoder_int_loga": (nd, f),
+                  "l0_module.lambda_1": (), "l0_module.lambda_2": ()})
+    return d
+
+
 def det_weights(schema, seed, std):
     from .detinit import det_tensor
     return {k: det_tensor(k, shp, seed, std) for k, shp in schema.items()}

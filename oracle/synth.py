@@ -80,3 +80,24 @@ def make_region_batch(geom, n_img, R, seed, ragged=True):
         bbox[r] = torch.stack([(bx0 + bx1) / 2, (by0 + by1) / 2, bx1 - bx0, by1 - by0])
     out.update(image_atts=atts, target_bbox=bbox, is_image=is_image)
     return out
+
+
+def make_vqa_batch(geom, B, seed, La=6):
+    """a VQA fine-tune batch (Eff_VQA.py:95-99 after tokenisation, dataset/vqa_dataset.py collate): B (image, question)
+    pairs, k[b] candidate answers per question flattened to sum(k) answer rows with per-answer weights; answers are
+    [CLS] tokens [SEP] 0-padded to La (pad_token_id = 0)."""
+    g = torch.Generator().manual_seed(seed + 777)
+    base = make_batch(geom, B, seed, ragged=True)
+    k = [1 + (b * 2 + seed) % 3 for b in range(B)]
+    n = sum(k)
+    ids = torch.zeros(n, La, dtype=torch.long)
+    atts = torch.zeros(n, La, dtype=torch.long)
+    for r in range(n):
+        ln = 3 + (r * 5 + seed) % (La - 2)                 # 3 .. La tokens incl. [CLS] and [SEP]
+        ids[r, 0] = geom["cls"]
+        ids[r, 1:ln - 1] = torch.randint(geom["lo"], geom["vocab"], (ln - 2,), generator=g)
+        ids[r, ln - 1] = geom["sep"]
+        atts[r, :ln] = 1
+    weights = torch.rand(n, generator=g) * 0.8 + 0.2
+    return dict(image=base["image"], question_ids=base["text_ids"], question_atts=base["text_atts"],
+                answer_ids=ids, answer_atts=atts, k=torch.tensor(k, dtype=torch.long), weights=weights)

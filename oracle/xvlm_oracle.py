@@ -210,12 +210,20 @@ def ext_mask(m):
     return (1.0 - m[:, None, None, :].to(torch.float32)) * -10000.0
 
 
+def causal_ext_mask(m):
+    """get_extended_attention_mask, is_decoder branch (eff_bert.py:975-1012): (1 - causal * padding) * -10000, [B,1,L,L]"""
+    L = m.shape[1]
+    ids = torch.arange(L)
+    causal = (ids[None, None, :] <= ids[None, :, None]).to(torch.float32)                # key <= query
+    return (1.0 - causal[:, None, :, :] * m[:, None, None, :].to(torch.float32)) * -10000.0
+
+
 def bert_model(sd, p, cfg, input_ids=None, attention_mask=None, encoder_embeds=None,
                encoder_hidden_states=None, encoder_attention_mask=None, mode="multi_modal",
-               head_z=None, mlp_z=None):
+               head_z=None, mlp_z=None, is_decoder=False):
     """BertModel.forward, eff_bert.py:1015-1162"""
     x = bert_embeddings(sd, p + "embeddings.", input_ids, cfg["bert_eps"]) if encoder_embeds is None else encoder_embeds
-    mask = ext_mask(attention_mask)
+    mask = causal_ext_mask(attention_mask) if is_decoder else ext_mask(attention_mask)
     enc_mask = None
     if encoder_hidden_states is not None:
         if encoder_attention_mask is None:
@@ -534,6 +542,88 @@ def gd_step(s_sd, t_sd, s_cfg, t_cfg, batch, s_neg, t_neg, temperature=1.0):
 
 
 # ---------------------------------------------------------------------------------------------
+# VQA fine-tune  (efficient_models/model_generation.py:97-187, models/model_generation.py:301-377, Eff_VQA.py:95-176)
+# ---------------------------------------------------------------------------------------------
+def lm_head_decoder(sd, p, cfg, ids, atts, enc, enc_atts, labels, head_z=None, mlp_z=None):
+    """BertLMHeadModel.forward, eff_bert.py:1332-1443 with reduction='none', label_smoothing 0: causal decoder over the
+    answers, every layer cross-attending to `enc`; next-token CE summed per sequence (-100 labels contribute 0)."""
+    x, hs, at, cat = bert_model(sd, p + "bert.", cfg, input_ids=ids, attention_mask=atts, encoder_hidden_states=enc,
+                                encoder_attention_mask=enc_atts, mode="multi_modal", head_z=head_z, mlp_z=mlp_z,
+                                is_decoder=True)
+    logits = mlm_head(sd, p + "cls.predictions.", x, cfg["bert_eps"])
+    shifted, lab = logits[:, :-1, :], labels[:, 1:]                                      # :1419-1421
+    ce = F.cross_entropy(shifted.reshape(-1, shifted.shape[-1]), lab.reshape(-1), reduction="none", ignore_index=-100)
+    return ce.view(logits.shape[0], -1).sum(1), logits, hs, at, cat
+
+
+def vqa_forward(sd, cfg, batch, zs=None):
+    """EffXVLMForVQA.forward train branch (zs given; model_generation.py:97-187) / XVLMForVQA.forward (zs None;
+    models/model_generation.py:301-377).  batch: image, question_ids/atts [B, Lq], answer_ids/atts [sum k, La], k [B],
+    weights [sum k]; pad_token_id 0."""
+    z = lambda key: zs[key] if zs is not None else None
+    image_embeds, image_hs, image_at = vit_forward(sd, "vision_encoder.", batch["image"], cfg,
+                                                   head_z=z("vision_head_z"), mlp_z=z("vision_intermediate_z"))
+    image_atts = torch.ones(image_embeds.shape[:2], dtype=torch.long)
+    enc_hz = torch.cat((zs["text_head_z"], zs["cross_head_z"]), dim=0) if zs is not None else None       # :124
+    enc_mz = torch.cat((zs["text_intermediate_z"], zs["cross_intermediate_z"]), dim=0) if zs is not None else None
+    q_last, q_hs, q_at, q_cat = bert_model(sd, "text_encoder.", cfg, input_ids=batch["question_ids"],
+                                           attention_mask=batch["question_atts"], encoder_hidden_states=image_embeds,
+                                           encoder_attention_mask=image_atts, mode="multi_modal", head_z=enc_hz, mlp_z=enc_mz)
+    rep = torch.repeat_interleave(torch.arange(q_last.shape[0]), batch["k"])              # :126-131
+    targets = batch["answer_ids"].masked_fill(batch["answer_ids"] == 0, -100)             # :113
+    nd = cfg["text_layers"] - cfg["fusion_layer"]
+    dec_cfg = dict(cfg, text_layers=nd, fusion_layer=0)                                   # :36-40
+    per_seq, logits, d_hs, d_at, d_cat = lm_head_decoder(sd, "text_decoder.", dec_cfg, batch["answer_ids"],
+                                                         batch["answer_atts"], q_last[rep], batch["question_atts"][rep],
+                                                         targets, z("decoder_head_z"), z("decoder_intermediate_z"))
+    loss = (batch["weights"] * per_seq).sum() / batch["image"].shape[0]                   # :166-167
+    return {"loss": loss,
+            "hidden_dict": {"image_hidden_states": image_hs, "text_hidden_states": q_hs, "decoder_hidden_states": d_hs},
+            "attention_dict": {"image_attentions": image_at, "text_attentions": q_at, "decoder_attentions": d_at},
+            "cross_attention_dict": {"cross_attentions": q_cat, "decoder_cross_attentions": d_cat},
+            "logits_dict": {"logits": logits}}
+
+
+def vqa_kd_terms(S, T, temperature=1.0):
+    """Eff_VQA.py:113-163.  The split of the question encoder's lists at state 4 / map 3 is HARD-CODED there for the
+    (3 text + 3 fusion)-layer student; the decoder-hidden term passes is_img=True (skip of list index 6: a no-op on the
+    student's 4 states)."""
+    sh, th, sa, ta = S["hidden_dict"], T["hidden_dict"], S["attention_dict"], T["attention_dict"]
+    sc, tc = S["cross_attention_dict"], T["cross_attention_dict"]
+    s_h, s_a = sh["text_hidden_states"], sa["text_attentions"]
+    t_h, t_a = get_cor_teacher(th["text_hidden_states"], s_h), get_cor_teacher(ta["text_attentions"], s_a, True)
+    kd = {"text_hidden": get_kd_loss(s_h[:4], t_h[:4]), "text_attn": get_kd_loss(s_a[:3], t_a[:3], is_attn=True),
+          "cross_hidden": get_kd_loss(s_h[4:], t_h[4:]), "cross_self_attn": get_kd_loss(s_a[3:], t_a[3:], is_attn=True),
+          "cross_attn": get_kd_loss(sc["cross_attentions"], get_cor_teacher(tc["cross_attentions"], sc["cross_attentions"], True),
+                                    is_attn=True)}
+    kd["image_hidden"] = get_kd_loss(sh["image_hidden_states"], get_cor_teacher(th["image_hidden_states"], sh["image_hidden_states"]),
+                                     is_img=True)
+    kd["image_attn"] = get_kd_loss(sa["image_attentions"], get_cor_teacher(ta["image_attentions"], sa["image_attentions"], True),
+                                   is_attn=True)
+    kd["decoder_hidden"] = get_kd_loss(sh["decoder_hidden_states"],
+                                       get_cor_teacher(th["decoder_hidden_states"], sh["decoder_hidden_states"]), is_img=True)
+    kd["decoder_attn"] = get_kd_loss(sa["decoder_attentions"],
+                                     get_cor_teacher(ta["decoder_attentions"], sa["decoder_attentions"], True), is_attn=True)
+    kd["decoder_cross"] = get_kd_loss(sc["decoder_cross_attentions"],
+                                      get_cor_teacher(tc["decoder_cross_attentions"], sc["decoder_cross_attentions"], True),
+                                      is_attn=True)
+    kd["logits"] = soft_cross_entropy(S["logits_dict"]["logits"] / temperature, T["logits_dict"]["logits"] / temperature)
+    return kd
+
+
+def vqa_loss_mix(loss_small, kd, lagrangian):
+    """Eff_VQA.py:165-176"""
+    loss_text_kd = kd["text_attn"] + kd["text_hidden"]
+    loss_img_kd = kd["image_attn"] + kd["image_hidden"] * 0.2
+    loss_cross_kd = (kd["cross_hidden"] + kd["cross_self_attn"] + kd["cross_attn"]) * 0.5
+    loss_decoder_kd = kd["decoder_attn"] + kd["decoder_hidden"] + kd["decoder_cross"]
+    loss_kd = kd["logits"] + loss_text_kd + loss_img_kd + loss_cross_kd + loss_decoder_kd
+    return loss_kd * 0.4 + loss_small * 0.6 + lagrangian, dict(loss_text_kd=loss_text_kd, loss_img_kd=loss_img_kd,
+                                                              loss_cross_kd=loss_cross_kd, loss_decoder_kd=loss_decoder_kd,
+                                                              loss_kd=loss_kd)
+
+
+# ---------------------------------------------------------------------------------------------
 # hard-concrete L0 gates  (efficient_models/xvlm_l0_module.py)
 # ---------------------------------------------------------------------------------------------
 L0_TYPES = ("vision_head", "text_head", "cross_head", "vision_intermediate", "text_intermediate", "cross_intermediate")
@@ -542,13 +632,21 @@ L0_PARAM = {"vision_head": "vision_head_loga", "text_head": "text_head_loga", "c
             "cross_intermediate": "cross_int_loga"}
 
 
-def l0_constants(hidden, ffn, heads, n_vit, n_text, n_cross):
-    """xvlm_l0_module.py:46-56,116-166"""
+# efficient_models/generation_l0_module.py (VQAL0Module): the same module + gates for the answer decoder, whose every
+# layer has self- AND cross-attention (decoder_head_loga [2 * layers, heads], decoder_int_loga [layers, ffn])
+L0_TYPES_VQA = ("vision_head", "text_head", "cross_head", "decoder_head", "vision_intermediate", "text_intermediate",
+                "cross_intermediate", "decoder_intermediate")
+L0_PARAM.update({"decoder_head": "decoder_head_loga", "decoder_intermediate": "decoder_int_loga"})
+
+
+def l0_constants(hidden, ffn, heads, n_vit, n_text, n_cross, n_dec=0):
+    """xvlm_l0_module.py:46-56,116-166 (generation_l0_module.py:47-57,119-173 with n_dec decoder layers)"""
     per_head_layer = hidden * hidden * 4 + hidden * 4
     per_head = per_head_layer // heads
     per_mlp_layer = hidden * ffn * 2 + hidden + hidden * 4
     per_int = per_mlp_layer // ffn
-    prunable = per_head * heads * (n_vit + n_text + 2 * n_cross) + per_mlp_layer * (n_vit + n_text + n_cross)
+    prunable = (per_head * heads * (n_vit + n_text + 2 * n_cross + 2 * n_dec)
+                + per_mlp_layer * (n_vit + n_text + n_cross + n_dec))
     return dict(params_per_head=per_head, params_per_int=per_int, prunable=prunable, hidden=hidden)
 
 
@@ -579,9 +677,13 @@ def l0_deterministic_z(loga_row, temperature=2. / 3., magical_number=0.8):
     return torch.ones_like(soft)
 
 
+def _l0_types(logas):
+    return L0_TYPES_VQA if "decoder_head_loga" in logas else L0_TYPES
+
+
 def l0_shapes(logas):
     s = {}
-    for t in L0_TYPES:
+    for t in _l0_types(logas):
         n, m = logas[L0_PARAM[t]].shape
         s[t] = [n, 1, m, 1, 1] if t.endswith("head") else [n, 1, 1, m]
     return s
@@ -591,7 +693,7 @@ def l0_forward(logas, training, eps=None, temperature=2. / 3., magical_number=0.
     """XVLML0Module.forward, xvlm_l0_module.py:321-341.  eps: dict type -> uniform draws (train)."""
     shapes = l0_shapes(logas)
     zs = {}
-    for t in L0_TYPES:
+    for t in _l0_types(logas):
         la = logas[L0_PARAM[t]]
         if training:
             zs[t + "_z"] = l0_sample_z(la, eps[t], temperature).reshape(shapes[t])
@@ -605,7 +707,7 @@ def l0_lagrangian(logas, lambda_1, lambda_2, consts, pruned_steps, target_sparsi
                   lagrangian_warmup=0, temperature=2. / 3.):
     """lagrangian_regularization, xvlm_l0_module.py:198-237"""
     n = 0
-    for t in L0_TYPES:
+    for t in _l0_types(logas):
         per = consts["params_per_head"] if t.endswith("head") else consts["params_per_int"]
         n = n + torch.sum(1 - cdf_qz0(logas[L0_PARAM[t]], temperature)) * per
     expected_sparsity = 1 - n / consts["prunable"]

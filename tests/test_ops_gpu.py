@@ -192,6 +192,37 @@ def _ref_attention(q, k, v, mask, gate, scale):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,L,dh", [(3, 12, 7, 64), (2, 4, 11, 16), (2, 12, 40, 64)])
+def test_causal_self_attention(dtype, B, H, L, dh):
+    """decoder self-attention (BertLMHeadModel, eff_bert.py:975-996): key-padding mask AND -10000 on keys after the query,
+    forward and backward against the explicit [B, 1, L, L] additive mask in torch"""
+    o = ops()
+    g = torch.Generator().manual_seed(23 + L)
+    d = H * dh
+    qkv = rnd((B, L, 3 * d), dtype, g).requires_grad_(True)
+    mask = torch.zeros(B, L)
+    mask[0, L - 2:] = -10000.0
+    mask = mask.to(DEV)
+    scale = dh ** -0.5
+    O, P = o.self_attention(qkv, H, dh, scale, mask=mask, causal=True)
+    gO, gP = rnd(O.shape, dtype, g), rnd(P.shape, dtype, g, 0.1)
+    (O.float() * gO.float()).sum().add((P.float() * gP.float()).sum()).backward()
+    xr = qkv.detach().float().requires_grad_(True)
+    sp = lambda t: t.view(B, L, H, dh).transpose(1, 2)
+    q, k, v = sp(xr[..., :d]), sp(xr[..., d:2 * d]), sp(xr[..., 2 * d:])
+    tri = torch.tril(torch.ones(L, L, device=DEV))
+    full = (1.0 - tri[None, None] * (mask == 0).float()[:, None, None, :]) * -10000.0      # HF: (1 - causal*pad) * -10000
+    Pr = torch.softmax(q @ k.transpose(-1, -2) * scale + full, -1)
+    Or = (Pr @ v).transpose(1, 2).reshape(B, L, d)
+    ((Or * gO.float()).sum() + (Pr * gP.float()).sum()).backward()
+    t = tol(dtype)
+    assert float(P.float().triu(1).abs().max()) == 0.0
+    assert rel_err(P.float(), Pr) < t
+    assert rel_err(O.float(), Or) < t * 2
+    assert rel_err(qkv.grad.float(), xr.grad) < t * 4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,L,dh", [(2, 4, 5, 16), (2, 12, 197, 64), (3, 12, 30, 64), (1, 2, 70, 32)])
 def test_self_attention(dtype, B, H, L, dh):
     o = ops()

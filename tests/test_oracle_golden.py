@@ -251,3 +251,62 @@ def test_kd_helpers_match_reference(golden_dir):
     close(O.get_kd_loss(s_a, ca, is_attn=True), fx["out.attn"], what="attn")
     close(O.soft_cross_entropy(torch.from_numpy(fx["in.s_l"]) / 2.0, torch.from_numpy(fx["in.t_l"]) / 2.0),
           fx["out.soft_ce"], what="soft_ce")
+
+
+def test_vqa_step_with_l0_matches_reference(golden_dir):
+    """Eff_VQA.py:95-176 training step: EffXVLMForVQA (gates of VQAL0Module, decoder gates included) vs XVLMForVQA teacher -
+    causal answer decoder, weighted per-answer LM loss, every KD term, the Lagrangian, the loss mix and the gradients"""
+    fx = load(golden_dir, "vqa_tiny.npz")
+    geom = synth.GEOMS[str(fx["meta.geom"])]
+    seed = int(fx["meta.seed"])
+    s_cfg, t_cfg = O.model_cfg(geom, "s"), O.model_cfg(geom, "t")
+    s_sch = schema.vqa_schema(s_cfg, geom["max_pos"], l0=True)
+    assert {k[len("student.wchk."):] for k in fx if k.startswith("student.wchk.")} == set(s_sch)      # checkpoint keys
+    s_sd = schema.det_weights(s_sch, 5000 + seed, geom["std"])          # (the gate parameters are overwritten below)
+    t_sd = weights_from_fixture(fx, "teacher", schema.vqa_schema(t_cfg, geom["max_pos"]), 6000 + seed, geom["std"])
+    for k in list(s_sd):
+        if k.startswith("l0_module."):
+            s_sd[k] = torch.from_numpy(fx["in.l0." + k[len("l0_module."):]]).clone()
+
+    def tie_dec(sd):
+        sd["text_decoder.cls.predictions.decoder.weight"] = sd["text_decoder.bert.embeddings.word_embeddings.weight"]
+        sd["text_decoder.cls.predictions.decoder.bias"] = sd["text_decoder.cls.predictions.bias"]
+        return sd
+    s_sd = leafify(tie_dec(s_sd))
+    t_sd = tie_dec(t_sd)
+    batch = batch_from_fixture(fx)
+    regen = synth.make_vqa_batch(geom, int(fx["meta.B"]), seed=seed)
+    for k, v in regen.items():
+        assert torch.equal(v, batch[k]), k
+    assert list(fx["meta.l0_types"]) == list(O.L0_TYPES_VQA)
+    logas = {k[len("l0_module."):]: v for k, v in s_sd.items() if k.endswith("_loga")}
+    eps = {t: torch.from_numpy(fx[f"in.eps.{t}"]) for t in O.L0_TYPES_VQA}
+    zs = O.l0_forward(logas, True, eps)
+    S = O.vqa_forward(s_sd, s_cfg, batch, zs)
+    with torch.no_grad():
+        T = O.vqa_forward(t_sd, t_cfg, batch)
+    for tag, out in (("student", S), ("teacher", T)):
+        for dn in ("hidden_dict", "attention_dict", "cross_attention_dict"):
+            for k, tup in out[dn].items():
+                for i, t in enumerate(tup):
+                    close(t, fx[f"{tag}.{k}.{i}"], rtol=1e-5, what=f"{tag}.{k}.{i}")
+                assert f"{tag}.{k}.{len(tup)}" not in fx
+        close(out["logits_dict"]["logits"], fx[f"{tag}.logits"], rtol=1e-5, atol=1e-5, what="logits")
+        close(out["loss"], fx[f"{tag}.loss"], rtol=1e-5, what="loss")
+    kd = O.vqa_kd_terms(S, T)
+    for k, v in kd.items():
+        close(v, fx[f"kd.{k}"], rtol=1e-5, what=f"kd.{k}")
+    nd = s_cfg["text_layers"] - s_cfg["fusion_layer"]
+    consts = O.l0_constants(geom["hidden"], geom["ffn"], geom["heads"], s_cfg["vit_layers"], s_cfg["fusion_layer"], nd, nd)
+    assert consts["prunable"] == int(fx["meta.prunable_model_size"])
+    lagr, exp_s, tgt = O.l0_lagrangian(logas, s_sd["l0_module.lambda_1"], s_sd["l0_module.lambda_2"], consts, 3,
+                                       target_sparsity=0.25, lagrangian_warmup=10)
+    close(lagr, fx["mix.lagrangian"], rtol=1e-5, what="lagrangian")
+    close(exp_s, fx["mix.expected_sparsity"], rtol=1e-6, what="expected sparsity")
+    assert abs(tgt - float(fx["mix.target_sparsity"])) < 1e-9
+    total, mix = O.vqa_loss_mix(S["loss"], kd, lagr)
+    for k, v in mix.items():
+        close(v, fx[f"mix.{k}"], rtol=1e-5, what=f"mix.{k}")
+    close(total, fx["mix.total"], rtol=1e-5, what="total")
+    total.backward()
+    check_grads(fx, "student", s_sd, True, 2e-4)
