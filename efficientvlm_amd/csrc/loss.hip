@@ -117,27 +117,29 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const T* __restrict__ logit
     lse_out[R + r] = (lb == ignore_index) ? 0.f : lse - to_f(x[lb]);
   }
 }
+// roww == nullptr: mean over the non-ignored rows; else the WEIGHTED SUM  sum_r roww[r] * rowloss[r]  (no normalisation)
 __global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict__ rowloss, const int64_t* __restrict__ labels,
-                                                        int R, int ignore_index, float weight, int32_t* __restrict__ valid,
-                                                        float* __restrict__ loss) {
+                                                        int R, int ignore_index, float weight, const float* __restrict__ roww,
+                                                        int32_t* __restrict__ valid, float* __restrict__ loss) {
   __shared__ float red[16];
   float s = 0.f, n = 0.f;
   for (int r = threadIdx.x; r < R; r += blockDim.x) {
-    s += rowloss[r];
+    s += roww ? rowloss[r] * roww[r] : rowloss[r];
     n += (labels[r] != ignore_index) ? 1.f : 0.f;
   }
   s = block_sum(s, red);
   n = block_sum(n, red);
   if (threadIdx.x == 0) {
     valid[0] = (int32_t)n;
-    atomicAdd(loss, weight * s / n);   // all rows ignored -> NaN, as F.cross_entropy
+    atomicAdd(loss, roww ? weight * s : weight * s / n);   // mean form: all rows ignored -> NaN, as F.cross_entropy
   }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logits, int C, int ld,
                                                      const int64_t* __restrict__ labels, int ignore_index, float weight,
                                                      const float* __restrict__ lse, const int32_t* __restrict__ valid,
-                                                     const float* __restrict__ gout, T* __restrict__ dl, int ldd) {
+                                                     const float* __restrict__ gout, const float* __restrict__ roww,
+                                                     T* __restrict__ dl, int ldd) {
   const int r = blockIdx.x;
   const int64_t lb = labels[r];
   const T* x = logits + (size_t)r * ld;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
     for (int c = threadIdx.x; c < C; c += blockDim.x) d[c] = from_f<T>(0.f);
     return;
   }
-  const float g = gout[0] * weight / (float)valid[0];
+  const float g = roww ? gout[0] * weight * roww[r] : gout[0] * weight / (float)valid[0];
   const float l = lse[r];
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float p = __expf(to_f(x[c]) - l);
@@ -160,8 +162,29 @@ extern "C" int evlm_ce_fwd(int dtype, const void* logits, int R, int C, int ld, 
   EVLM_REQUIRE(logits && labels && lse && valid_count && loss && R > 0 && C > 0, "evlm_ce_fwd: bad args");
   EVLM_DISPATCH_DTYPE(dtype, "evlm_ce_fwd",
     hipLaunchKernelGGL((ce_row_kernel<T>), dim3(R), dim3(256), 0, stream, (const T*)logits, C, ld, labels, ignore_index, lse);)
-  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)(lse + R), labels, R, ignore_index, weight, valid_count, loss);
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)(lse + R), labels, R, ignore_index, weight, (const float*)nullptr, valid_count, loss);
   EVLM_LAUNCH_CHECK("evlm_ce_fwd");
+  return 0;
+}
+extern "C" int evlm_ce_weighted_fwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
+                                    float weight, const float* row_weight, float* lse, int32_t* valid_count, float* loss,
+                                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(logits && labels && row_weight && lse && valid_count && loss && R > 0 && C > 0, "evlm_ce_weighted_fwd: bad args");
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_ce_weighted_fwd",
+    hipLaunchKernelGGL((ce_row_kernel<T>), dim3(R), dim3(256), 0, stream, (const T*)logits, C, ld, labels, ignore_index, lse);)
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)(lse + R), labels, R, ignore_index, weight, row_weight, valid_count, loss);
+  EVLM_LAUNCH_CHECK("evlm_ce_weighted_fwd");
+  return 0;
+}
+extern "C" int evlm_ce_weighted_bwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
+                                    float weight, const float* row_weight, const float* lse, const float* gout,
+                                    void* dlogits, int ldd, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(logits && labels && row_weight && lse && gout && dlogits, "evlm_ce_weighted_bwd: bad args");
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_ce_weighted_bwd",
+    hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(R), dim3(256), 0, stream, (const T*)logits, C, ld, labels, ignore_index, weight, lse, (const int32_t*)nullptr, gout, row_weight, (T*)dlogits, ldd);)
+  EVLM_LAUNCH_CHECK("evlm_ce_weighted_bwd");
   return 0;
 }
 extern "C" int evlm_ce_bwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
@@ -170,7 +193,7 @@ extern "C" int evlm_ce_bwd(int dtype, const void* logits, int R, int C, int ld, 
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(logits && labels && lse && valid_count && gout && dlogits, "evlm_ce_bwd: bad args");
   EVLM_DISPATCH_DTYPE(dtype, "evlm_ce_bwd",
-    hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(R), dim3(256), 0, stream, (const T*)logits, C, ld, labels, ignore_index, weight, lse, valid_count, gout, (T*)dlogits, ldd);)
+    hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(R), dim3(256), 0, stream, (const T*)logits, C, ld, labels, ignore_index, weight, lse, valid_count, gout, (const float*)nullptr, (T*)dlogits, ldd);)
   EVLM_LAUNCH_CHECK("evlm_ce_bwd");
   return 0;
 }

@@ -1,5 +1,6 @@
 """Distillation losses and the general-distillation (GD) step — the loss helpers every reference driver
-duplicates (GeneralDistill.py:60-104) plus the loss mixes of GeneralDistill.py:369-376 and Eff_Retrieval.py:165-178,
+duplicates (GeneralDistill.py:60-104) plus the loss mixes of GeneralDistill.py:369-376, Eff_Retrieval.py:165-178 and
+Eff_VQA.py:165-176,
 with the same names and argument meaning.  MSE and the dual-softmax KL run as HIP reductions (evlm_mse_*, evlm_kl_*);
 each term is a device scalar, so a whole step issues no host synchronisation.
 """
@@ -89,6 +90,39 @@ def itr_loss_mix(loss, kd, lagrangian):
     loss_small = loss["loss_itc"] + loss["loss_itm"]
     return (loss_kd + loss_small) * 0.5 + lagrangian, dict(loss_text_kd=loss_text_kd, loss_img_kd=loss_img_kd,
                                                            loss_cross_kd=loss_cross_kd, loss_kd=loss_kd)
+
+
+def vqa_kd_terms(S, T, temperature=1.0):
+    """Eff_VQA.py:113-163.  The split of the question encoder's lists at state 4 / map 3 is hard-coded there for the
+    (3 text + 3 fusion)-layer student; the decoder-hidden term passes is_img=True (skip of list index 6: a no-op on the
+    student's 4 decoder states)."""
+    sh, th, sa, ta = S["hidden_dict"], T["hidden_dict"], S["attention_dict"], T["attention_dict"]
+    sc, tc = S["cross_attention_dict"], T["cross_attention_dict"]
+    s_h, s_a = sh["text_hidden_states"], sa["text_attentions"]
+    t_h, t_a = get_cor_teacher(th["text_hidden_states"], s_h), get_cor_teacher(ta["text_attentions"], s_a, True)
+    cor = lambda d_t, d_s, key, attn: get_cor_teacher(d_t[key], d_s[key], attn)
+    return {
+        "text_hidden": get_kd_loss(s_h[:4], t_h[:4]), "text_attn": get_kd_loss(s_a[:3], t_a[:3], is_attn=True),
+        "cross_hidden": get_kd_loss(s_h[4:], t_h[4:]), "cross_self_attn": get_kd_loss(s_a[3:], t_a[3:], is_attn=True),
+        "cross_attn": get_kd_loss(sc["cross_attentions"], cor(tc, sc, "cross_attentions", True), is_attn=True),
+        "image_hidden": get_kd_loss(sh["image_hidden_states"], cor(th, sh, "image_hidden_states", False), is_img=True),
+        "image_attn": get_kd_loss(sa["image_attentions"], cor(ta, sa, "image_attentions", True), is_attn=True),
+        "decoder_hidden": get_kd_loss(sh["decoder_hidden_states"], cor(th, sh, "decoder_hidden_states", False), is_img=True),
+        "decoder_attn": get_kd_loss(sa["decoder_attentions"], cor(ta, sa, "decoder_attentions", True), is_attn=True),
+        "decoder_cross": get_kd_loss(sc["decoder_cross_attentions"], cor(tc, sc, "decoder_cross_attentions", True), is_attn=True),
+        "logits": soft_cross_entropy(S["logits_dict"]["logits"], T["logits_dict"]["logits"], temperature)}
+
+
+def vqa_loss_mix(loss_small, kd, lagrangian):
+    """Eff_VQA.py:165-176"""
+    loss_text_kd = kd["text_attn"] + kd["text_hidden"]
+    loss_img_kd = kd["image_attn"] + kd["image_hidden"] * 0.2
+    loss_cross_kd = (kd["cross_hidden"] + kd["cross_self_attn"] + kd["cross_attn"]) * 0.5
+    loss_decoder_kd = kd["decoder_attn"] + kd["decoder_hidden"] + kd["decoder_cross"]
+    loss_kd = kd["logits"] + loss_text_kd + loss_img_kd + loss_cross_kd + loss_decoder_kd
+    return loss_kd * 0.4 + loss_small * 0.6 + lagrangian, dict(loss_text_kd=loss_text_kd, loss_img_kd=loss_img_kd,
+                                                              loss_cross_kd=loss_cross_kd, loss_decoder_kd=loss_decoder_kd,
+                                                              loss_kd=loss_kd)
 
 
 _SIDE = {}

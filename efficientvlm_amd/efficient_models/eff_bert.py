@@ -10,6 +10,7 @@ Arithmetic (all in libevlm_hip.so):
     BertSelfOutput dense + input     -> GEMM with residual epilogue, then LayerNorm        (:374-381)
     BertIntermediate gelu * mlp_z, BertOutput dense + input -> two GEMMs with fused epilogues, then LayerNorm (:445-462,:553-557)
     MLM head                         -> gather rows, dense+GELU epilogue, LayerNorm, tied-decoder GEMM, fused CE (:1691-1702)
+    causal LM head (VQA decoder)     -> causal flag of evlm_attention, tied-decoder GEMM, evlm_ce_weighted (:1332-1443)
 
 Dropout: the distillation recipe's parity configuration (and the bench) use p = 0; p > 0 raises rather than silently
 differing (RNG parity with the reference's CUDA dropout stream is not reproducible anyway).
@@ -26,7 +27,8 @@ from .eff_vit import find_pruneable_heads_and_indices, prune_linear_layer
 
 __all__ = ["BertConfig", "BertModel", "BertForMaskedLM", "BertEmbeddings", "BertSelfAttention", "BertSelfOutput",
            "BertAttention", "BertIntermediate", "BertOutput", "BertLayer", "BertEncoder", "BertLMPredictionHead",
-           "BertOnlyMLMHead", "BertPredictionHeadTransform", "BertPreTrainedModel", "MaskedLMOutput"]
+           "BertOnlyMLMHead", "BertPredictionHeadTransform", "BertPreTrainedModel", "MaskedLMOutput", "BertLMHeadModel",
+           "CausalLMOutputWithCrossAttentions", "CausalMask"]
 
 
 def _check_dropout(p, what):
@@ -102,18 +104,30 @@ class BertSelfAttention(nn.Module):
             qkv = ops.linear_packed(hidden_states, (self.query.weight, self.key.weight, self.value.weight),
                                     (self.query.bias, self.key.bias, self.value.bias))
             ctx, probs = ops.self_attention(qkv, H, dh, scale, mask=_key_mask(attention_mask), gate=head_z,
-                                            want_probs=bool(output_attentions))
+                                            want_probs=bool(output_attentions), causal=isinstance(attention_mask, CausalMask))
         outputs = (ctx, probs) if output_attentions else (ctx,)
         return outputs + (None,)
+
+
+class CausalMask:
+    """The decoder's additive [B,1,L,L] mask (1 - causal * padding) * -10000 of get_extended_attention_mask's is_decoder
+    branch (eff_bert.py:975-1012) in FACTORED form: `key` is the additive key-padding part [B,1,1,L]; the causal part
+    (keys after the query) is applied inside the attention kernel (evlm_attn_fwd_args.causal), so the [B,1,L,L] tensor
+    is never materialised."""
+
+    def __init__(self, key):
+        self.key = key
 
 
 def _key_mask(m):
     """additive [B,1,1,Lk] (or [B,Lk]) -> [B,Lk] fp32 for the attention kernel"""
     if m is None:
         return None
+    if isinstance(m, CausalMask):
+        m = m.key
     if m.dim() == 4:
         if m.shape[1] != 1 or m.shape[2] != 1:
-            raise NotImplementedError("per-query (causal) masks belong to the VQA decoder (BASELINE config 4), not built yet")
+            raise NotImplementedError("arbitrary per-query masks are not on the path (padding and causal masks are)")
         m = m[:, 0, 0, :]
     return m
 
@@ -427,8 +441,10 @@ class BertModel(BertPreTrainedModel):
         if attention_mask.dim() == 3:
             ext = attention_mask[:, None, :, :]
         elif attention_mask.dim() == 2:
-            if is_decoder:
-                raise NotImplementedError("causal decoder masks belong to the VQA decoder (BASELINE config 4), not built yet")
+            if is_decoder:                      # causal AND padding: see CausalMask
+                if attention_mask.shape[1] != input_shape[1]:
+                    raise NotImplementedError("prefix (past_key_values) masks are off the training path")
+                return CausalMask((1.0 - attention_mask[:, None, None, :].to(dtype=torch.float32)) * -10000.0)
             ext = attention_mask[:, None, None, :]
         else:
             raise ValueError("Wrong shape for input_ids (shape {}) or attention_mask (shape {})".format(
@@ -549,3 +565,75 @@ class BertForMaskedLM(BertPreTrainedModel):
             return ((masked_lm_loss,) + output) if masked_lm_loss is not None else output
         return MaskedLMOutput(loss=masked_lm_loss, logits=prediction_scores, hidden_states=outputs.hidden_states,
                               attentions=outputs.attentions, cross_attentions=outputs.cross_attentions)
+
+
+class CausalLMOutputWithCrossAttentions(ModelOutput):
+    """transformers.modeling_outputs.CausalLMOutputWithCrossAttentions (fields: loss, logits, past_key_values, hidden_states,
+    attentions, cross_attentions)"""
+
+
+class BertLMHeadModel(BertPreTrainedModel):
+    """eff_bert.py:1308-1443: BERT with a causal language-modelling head - the VQA answer decoder (every layer has self-
+    and cross-attention when config.fusion_layer == 0).  The next-token loss with reduction='none' is returned per sequence
+    (sum over its non-ignored positions), as the reference does."""
+
+    def __init__(self, config, label_smoothing=0.0):
+        super().__init__(config)
+        self.bert = BertModel(self.config, add_pooling_layer=False)
+        self.cls = BertOnlyMLMHead(self.config)
+        if label_smoothing:
+            raise NotImplementedError("label smoothing is 0 in every reference config (model_generation.py:41)")
+        self.label_smoothing = label_smoothing
+        self.init_weights()
+
+    def get_input_embeddings(self):
+        return self.bert.embeddings.word_embeddings
+
+    def get_output_embeddings(self):
+        return self.cls.predictions.decoder
+
+    def set_output_embeddings(self, new_embeddings):
+        self.cls.predictions.decoder = new_embeddings
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
+                inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None, labels=None,
+                past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
+                is_decoder=True, reduction="mean", mode="multi_modal", return_logits=False, head_z=None, mlp_z=None,
+                encoder_batch_index=None, sequence_weights=None):
+        """sequence_weights (extension, with reduction='none'): per-sequence weights w; the returned loss is then the
+        scalar sum_r w[r] * (summed next-token CE of sequence r), computed by one fused kernel pass over the logits
+        instead of materialising the shifted copy and the per-token loss vector."""
+        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        outputs = self.bert(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids, position_ids=position_ids,
+                            head_mask=head_mask, inputs_embeds=inputs_embeds, encoder_hidden_states=encoder_hidden_states,
+                            encoder_attention_mask=encoder_attention_mask, past_key_values=past_key_values,
+                            use_cache=False if labels is not None else use_cache, output_attentions=output_attentions,
+                            output_hidden_states=output_hidden_states, return_dict=return_dict, is_decoder=is_decoder,
+                            mode=mode, head_z=head_z, mlp_z=mlp_z, encoder_batch_index=encoder_batch_index)
+        sequence_output = outputs[0]
+        prediction_scores = self.cls(sequence_output)
+        if return_logits:
+            return prediction_scores[:, :-1, :].contiguous()
+        lm_loss = None
+        if labels is not None:
+            # next-token prediction (eff_bert.py:1419-1421) WITHOUT the shifted copy of the logits: position t is scored
+            # against label t+1, the last position against ignore_index
+            B, La = labels.shape
+            nxt = torch.cat([labels[:, 1:], labels.new_full((B, 1), -100)], dim=1)
+            flat = prediction_scores.reshape(B * La, self.config.vocab_size)
+            if reduction == "none":
+                w = sequence_weights if sequence_weights is not None else None
+                if w is None:
+                    raise NotImplementedError("reduction='none' is served through sequence_weights (the VQA loss is "
+                                              "sum(weights * per-sequence loss), model_generation.py:166)")
+                lm_loss = ops.cross_entropy_weighted_sum(flat, nxt.reshape(-1), w.reshape(B, 1).expand(B, La).reshape(-1))
+            elif reduction == "mean":
+                lm_loss = ops.cross_entropy(flat, nxt.reshape(-1))
+            else:
+                raise NotImplementedError(reduction)
+        if not return_dict:
+            output = (prediction_scores,) + tuple(outputs[2:])
+            return ((lm_loss,) + output) if lm_loss is not None else output
+        return CausalLMOutputWithCrossAttentions(loss=lm_loss, logits=prediction_scores, past_key_values=outputs.past_key_values,
+                                                 hidden_states=outputs.hidden_states, attentions=outputs.attentions,
+                                                 cross_attentions=outputs.cross_attentions)

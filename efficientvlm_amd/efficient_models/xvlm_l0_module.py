@@ -21,6 +21,8 @@ limit_a, limit_b, epsilon = -.1, 1.1, 1e-6
 
 
 class XVLML0Module(Module):
+    with_decoder = False       # generation_l0_module.VQAL0Module: + gates for the answer decoder's layers
+
     def __init__(self, config, droprate_init=0.5, temperature=2. / 3., lagrangian_warmup=0, start_sparsity=0.0,
                  target_sparsity=0.0, pruning_type="structured_heads+structured_mlp", magical_number=0.8):
         super().__init__()
@@ -32,7 +34,8 @@ class XVLML0Module(Module):
         vision_config = read_json(config["vision_config"])
         assert config["patch_size"] == vision_config["patch_size"]
         self.all_types = ["vision_intermediate_z", "vision_head_z", "text_intermediate_z", "text_head_z",
-                          "cross_intermediate_z", "cross_head_z"]
+                          "cross_intermediate_z", "cross_head_z"] + (["decoder_head_z", "decoder_intermediate_z"]
+                                                                     if self.with_decoder else [])
         self.pruning_type = pruning_type
         self.hidden_size = text_config.hidden_size
         self.intermediate_size = text_config.intermediate_size
@@ -41,6 +44,7 @@ class XVLML0Module(Module):
         self.vision_num_hidden_layers = vision_config["num_hidden_layers"]
         self.text_num_hidden_layers = text_config.fusion_layer
         self.cross_num_hidden_layers = text_config.num_hidden_layers - text_config.fusion_layer
+        self.decoder_num_hidden_layers = self.cross_num_hidden_layers if self.with_decoder else 0   # generation_l0_module.py:47
         self.mlp_num_per_layer = 1
         self.params_per_head_layer = self.hidden_size * self.hidden_size * 4 + self.hidden_size * 4
         self.params_per_head = self.params_per_head_layer // self.num_attention_heads
@@ -48,7 +52,8 @@ class XVLML0Module(Module):
         self.params_per_intermediate_dim = self.params_per_mlp_layer // self.intermediate_size
         self.full_model_size = (self.params_per_head_layer + self.params_per_mlp_layer) * self.vision_num_hidden_layers + \
                                (self.params_per_head_layer + self.params_per_mlp_layer) * self.text_num_hidden_layers + \
-                               (self.params_per_head_layer * 2 + self.params_per_mlp_layer) * self.cross_num_hidden_layers
+                               (self.params_per_head_layer * 2 + self.params_per_mlp_layer) * (self.cross_num_hidden_layers
+                                                                                              + self.decoder_num_hidden_layers)
         self.prunable_model_size = 0
         self.temperature = temperature
         self.droprate_init = droprate_init if droprate_init != 0. else 0.5
@@ -89,14 +94,21 @@ class XVLML0Module(Module):
         self.vision_head_loga = self.initialize_parameters(H, self.vision_num_hidden_layers)
         self.text_head_loga = self.initialize_parameters(H, self.text_num_hidden_layers)
         self.cross_head_loga = self.initialize_parameters(H, self.cross_num_hidden_layers * 2)
-        for p in (self.vision_head_loga, self.text_head_loga, self.cross_head_loga):
+        if self.with_decoder:
+            self.decoder_head_loga = self.initialize_parameters(H, self.decoder_num_hidden_layers * 2)
+        for p in (self.vision_head_loga, self.text_head_loga, self.cross_head_loga) + \
+                ((self.decoder_head_loga,) if self.with_decoder else ()):
             self.reset_loga(p, mean=10)
         self.add_one_module(self.vision_head_loga, "vision_head", self.params_per_head, H, [self.vision_num_hidden_layers, 1, H, 1, 1])
         self.add_one_module(self.text_head_loga, "text_head", self.params_per_head, H, [self.text_num_hidden_layers, 1, H, 1, 1])
         self.add_one_module(self.cross_head_loga, "cross_head", self.params_per_head, H, [self.cross_num_hidden_layers * 2, 1, H, 1, 1])
+        if self.with_decoder:
+            self.add_one_module(self.decoder_head_loga, "decoder_head", self.params_per_head, H,
+                                [self.decoder_num_hidden_layers * 2, 1, H, 1, 1])
         if add_prunable_model_size:
             self.prunable_model_size += self.params_per_head * H * (self.vision_num_hidden_layers + self.text_num_hidden_layers
-                                                                    + self.cross_num_hidden_layers * 2)
+                                                                    + self.cross_num_hidden_layers * 2
+                                                                    + self.decoder_num_hidden_layers * 2)
 
     def initialize_structured_mlp(self):
         f = self.intermediate_size
@@ -106,9 +118,14 @@ class XVLML0Module(Module):
         self.add_one_module(self.vision_int_loga, "vision_intermediate", self.params_per_intermediate_dim, f, [self.vision_num_hidden_layers, 1, 1, f])
         self.add_one_module(self.text_int_loga, "text_intermediate", self.params_per_intermediate_dim, f, [self.text_num_hidden_layers, 1, 1, f])
         self.add_one_module(self.cross_int_loga, "cross_intermediate", self.params_per_intermediate_dim, f, [self.cross_num_hidden_layers, 1, 1, f])
+        if self.with_decoder:
+            self.decoder_int_loga = self.initialize_parameters(f, self.decoder_num_hidden_layers)
+            self.add_one_module(self.decoder_int_loga, "decoder_intermediate", self.params_per_intermediate_dim, f,
+                                [self.decoder_num_hidden_layers, 1, 1, f])
         self.prunable_model_size += self.params_per_mlp_layer * (self.vision_num_hidden_layers + self.text_num_hidden_layers
-                                                                 + self.cross_num_hidden_layers)
-        for p in (self.vision_int_loga, self.text_int_loga, self.cross_int_loga):
+                                                                 + self.cross_num_hidden_layers + self.decoder_num_hidden_layers)
+        for p in (self.vision_int_loga, self.text_int_loga, self.cross_int_loga) + \
+                ((self.decoder_int_loga,) if self.with_decoder else ()):
             self.reset_loga(p)
 
     def reset_loga(self, tensor, mean=None):
@@ -127,7 +144,8 @@ class XVLML0Module(Module):
 
     def get_num_parameters_and_constraint(self):
         n = 0
-        for t in ("vision_head", "text_head", "cross_head", "vision_intermediate", "text_intermediate", "cross_intermediate"):
+        for t in ("vision_head", "text_head", "cross_head", "vision_intermediate", "text_intermediate", "cross_intermediate") \
+                + (("decoder_head", "decoder_intermediate") if self.with_decoder else ()):
             n = n + torch.sum(1 - self.cdf_qz(0, self.z_logas[t])) * self.parameters_per_dim[t]
         return n
 
@@ -179,10 +197,17 @@ class XVLML0Module(Module):
         r_ch = cnt("cross_head", self.cross_num_hidden_layers * 2, H)
         head_nums = sum(r_ch) + sum(r_th) + sum(r_vh)
         intermediate_nums = sum(r_vi) + sum(r_ti) + sum(r_ci)
+        extra = {}
+        if self.with_decoder:                                   # generation_l0_module.py:307-338
+            r_di = cnt("decoder_intermediate", self.decoder_num_hidden_layers, f)
+            r_dh = cnt("decoder_head", self.decoder_num_hidden_layers * 2, H)
+            head_nums += sum(r_dh)
+            intermediate_nums += sum(r_di)
+            extra = {"decoder_intermediate_dims": r_di, "decoder_head_nums": r_dh}
         remaining = head_nums * self.params_per_head + intermediate_nums * 2 * self.hidden_size
         pruned = self.prunable_model_size - remaining
         return {"vision_intermediate_dims": r_vi, "text_intermediate_dims": r_ti, "cross_intermediate_dims": r_ci,
-                "vision_head_nums": r_vh, "text_head_nums": r_th, "cross_head_nums": r_ch, "pruned_params": pruned,
+                "vision_head_nums": r_vh, "text_head_nums": r_th, "cross_head_nums": r_ch, **extra, "pruned_params": pruned,
                 "remaining_params": remaining, "pruned_model_sparsity": pruned / self.prunable_model_size}
 
     def forward(self, training=True):

@@ -737,6 +737,46 @@ def cross_entropy(logits, labels, ignore_index=-100):
     return _CE.apply(logits, labels, ignore_index)
 
 
+class _CEWeighted(torch.autograd.Function):
+    """sum_r w[r] * CE(logits[r], labels[r]) over the rows with labels != ignore_index (no normalisation)"""
+
+    @staticmethod
+    def forward(ctx, logits, labels, row_weight, ignore_index):
+        L.require_cuda(logits, labels, row_weight)
+        x2, R, Cn, ld = _rows2d(logits)
+        lab = labels.reshape(-1).to(torch.int64).contiguous()
+        rw = row_weight.detach().reshape(-1).to(torch.float32).contiguous()
+        assert lab.numel() == R and rw.numel() == R
+        out = torch.zeros((), dtype=torch.float32, device=logits.device)
+        lse = torch.empty(2 * R, dtype=torch.float32, device=logits.device)
+        valid = torch.zeros(1, dtype=torch.int32, device=logits.device)
+        L.check(_lib().evlm_ce_weighted_fwd(L.dt(x2), L.ptr(x2), R, Cn, ld, L.ptr(lab), ignore_index, 1.0, L.ptr(rw),
+                                            L.ptr(lse), L.ptr(valid), L.ptr(out), L.stream()), "ce_weighted_fwd")
+        ctx.save_for_backward(x2, lab, lse, rw)
+        ctx.meta = (R, Cn, ld, ignore_index, logits.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, lab, lse, rw = ctx.saved_tensors
+        R, Cn, ld, ignore_index, shape = ctx.meta
+        gc = g.to(torch.float32).contiguous()
+        ldd = _pad8(Cn)
+        dl = torch.empty((R, ldd), dtype=x2.dtype, device=x2.device) if ldd == Cn else \
+            torch.zeros((R, ldd), dtype=x2.dtype, device=x2.device)
+        L.check(_lib().evlm_ce_weighted_bwd(L.dt(x2), L.ptr(x2), R, Cn, ld, L.ptr(lab), ignore_index, 1.0, L.ptr(rw),
+                                            L.ptr(lse), L.ptr(gc), L.ptr(dl), ldd, L.stream()), "ce_weighted_bwd")
+        d = dl[:, :Cn] if ldd != Cn else dl
+        if len(shape) > 2:
+            d = d.unflatten(0, shape[:-1])
+        return d, None, None, None
+
+
+def cross_entropy_weighted_sum(logits, labels, row_weight, ignore_index=-100):
+    """sum over rows of row_weight * CE (rows with ignore_index skipped): the VQA decoder's weighted answer loss"""
+    return _CEWeighted.apply(logits, labels, row_weight, ignore_index)
+
+
 class _KL(torch.autograd.Function):
     """soft_cross_entropy(predicts, targets): KLDiv(log_softmax(s*inv_t), softmax(t*inv_t), batchmean)"""
 

@@ -435,3 +435,62 @@ class ITRTrainer:
         return torch.stack([total.detach().float(), S["loss"]["loss_itc"].detach().float(),
                             S["loss"]["loss_itm"].detach().float(), mix["loss_kd"].detach().float(),
                             lagrangian.detach().float().reshape(())])
+
+
+class VQATrainer:
+    """Pruning fine-tune step of Eff_VQA.py:74-200 (visual question answering with hard-concrete L0 gates on the image
+    encoder, question encoder AND answer decoder): student forward + backward, teacher forward, the weighted answer LM loss,
+    text / fusion / image / decoder hidden + attention KD, logit KD, the Lagrangian, THREE optimisers as in ITRTrainer, no
+    gradient clipping, constrain_parameters().  Eager launch (host-side Lagrangian warm-up counter; the number of answer
+    rows varies from batch to batch)."""
+
+    def __init__(self, student, teacher, lr=5e-5, weight_decay=0.01, lr_mult=2.0, reg_learning_rate=0.1,
+                 dtype=torch.float32, temperature=1.0):
+        import os
+        from .optim import create_L0_optimizer
+        self.student, self.teacher = student, teacher
+        self.dtype, self.temperature = dtype, temperature
+        for p in teacher.parameters():
+            p.requires_grad_(False)
+        teacher.eval()
+        student.train()
+        self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=0.0)
+        self.l0_opt, self.lagrangian_opt = create_L0_optimizer({"reg_learning_rate": reg_learning_rate}, student.l0_module)
+        self.reducer = GradReducer(self.opt.flat_grads)
+        self.defer_wgrad = dtype == torch.bfloat16 and not os.environ.get("EVLM_NO_DEFER_WGRAD")
+        self.overlap_teacher = not os.environ.get("EVLM_NO_OVERLAP_TEACHER")
+        self.global_step = 0
+
+    def step(self, batch, lr_mult=1.0, stop_prune=False):
+        """batch: dict(image [B], question_ids / question_atts [B, Lq], answer_ids / answer_atts [sum k, La], k [B] (tensor
+        or list), weights [sum k]).  Returns a device tensor [total, answer loss, kd, lagrangian]."""
+        from types import SimpleNamespace as NS
+        self.opt.zero_grad()
+        l0 = self.student.l0_module
+        question = NS(input_ids=batch["question_ids"], attention_mask=batch["question_atts"])
+        answer = NS(input_ids=batch["answer_ids"], attention_mask=batch["answer_atts"])
+        kw = dict(train=True, k=batch["k"], weights=batch["weights"], output_attentions=True, output_hidden_states=True)
+        with compute(self.dtype):
+            S, T = distill.student_and_teacher(
+                lambda: self.student(batch["image"], question, answer, stop_prune=stop_prune, **kw),
+                lambda: self.teacher(batch["image"], question, answer, **kw), batch["image"], self.overlap_teacher)
+            kd = distill.vqa_kd_terms(S, T, self.temperature)
+            lagrangian, _, _ = l0.lagrangian_regularization(self.global_step)
+            total, mix = distill.vqa_loss_mix(S["loss"], kd, lagrangian)
+            ops.WGRAD_INPLACE = True
+            ops.WGRAD_DEFER = [] if self.defer_wgrad else None
+            try:
+                total.backward()
+                ops.flush_wgrad()
+            finally:
+                ops.WGRAD_INPLACE = False
+                ops.WGRAD_DEFER = None
+        self.reducer.reduce()
+        self.opt.set_schedule(lr_mult)
+        self.opt.step()
+        self.l0_opt.step()
+        self.lagrangian_opt.step()
+        l0.constrain_parameters()
+        self.global_step += 1
+        return torch.stack([total.detach().float(), S["loss"].detach().float(), mix["loss_kd"].detach().float(),
+                            lagrangian.detach().float().reshape(())])

@@ -183,6 +183,14 @@ int evlm_ce_fwd(int dtype, const void* logits, int R, int C, int ld, const int64
 int evlm_ce_bwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
                 float weight, const float* lse, const int32_t* valid_count, const float* gout,
                 void* dlogits, int ldd, void* stream);
+/* weighted-SUM form: *loss += weight * sum_r row_weight[r] * ce[r] (ignored rows contribute 0, no normalisation) - the
+ * per-answer weighted next-token loss of the VQA decoder: BertLMHeadModel reduction='none' summed per sequence
+ * (eff_bert.py:1419-1431) times `weights`, summed (efficient_models/model_generation.py:166-167).  row_weight [R] f32. */
+int evlm_ce_weighted_fwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
+                         float weight, const float* row_weight, float* lse, int32_t* valid_count, float* loss, void* stream);
+int evlm_ce_weighted_bwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
+                         float weight, const float* row_weight, const float* lse, const float* gout,
+                         void* dlogits, int ldd, void* stream);
 
 /* soft_cross_entropy (GeneralDistill.py:84-89): KLDiv(log_softmax(s*inv_t), softmax(t*inv_t), batchmean)
  * over R rows of C classes.  lse_s/lse_t [R] f32 saved for backward.  d s = (p_s - p_t) * inv_t / R. */
