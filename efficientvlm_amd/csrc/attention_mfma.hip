@@ -69,25 +69,28 @@ __device__ __forceinline__ bf16x8 vcol_frag(const char* sm, int t0, int t1, int 
 // NT = number of 16-key tiles (even).  One workgroup = up to 16 waves x 16 queries of one (batch, head): with Lq <= 256
 // (the ViT's 197 tokens) a single workgroup covers every query, so K and V are staged into LDS exactly once per
 // (batch, head) instead of once per 64-query block on four different XCDs.
-template <int NT, int MAXW>
+// SEQ (long key sequences: 480x480 images = 901 tokens): K and V do not fit in LDS together, so they take turns in ONE
+// region - K for the scores, then (after the probabilities are in registers) V for P V.  Waves past the last query stay
+// for the barriers.
+template <int NT, int MAXW, bool SEQ>
 __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;                          // [NT*16][64] bf16, k_swz
-  char* Vs = smem + NT * 16 * 128;          // [NT*16][64] bf16, v_swz
-  float* Ms = reinterpret_cast<float*>(smem + 2 * NT * 16 * 128);   // [NT*16] additive mask (+ -1e30 beyond Lk)
+  char* Ks = smem;                                       // [NT*16][64] bf16, k_swz
+  char* Vs = SEQ ? smem : smem + NT * 16 * 128;          // [NT*16][64] bf16, v_swz
+  float* Ms = reinterpret_cast<float*>(smem + (SEQ ? 1 : 2) * NT * 16 * 128);   // [NT*16] additive mask (+ -1e30 beyond Lk)
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
   const int bkv = a.kv_index ? a.kv_index[b] : b;
   const bf16* Kb = a.K + (size_t)bkv * a.Lk * a.ldk + h * DH;
   const bf16* Vb = a.V + (size_t)bkv * a.Lk * a.ldv + h * DH;
   stage_rows<false>(Kb, a.ldk, a.Lk, NT * 16, Ks);
-  stage_rows<true>(Vb, a.ldv, a.Lk, NT * 16, Vs);
+  if (!SEQ) stage_rows<true>(Vb, a.ldv, a.Lk, NT * 16, Vs);
   for (int k = threadIdx.x; k < NT * 16; k += blockDim.x)
     Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
   __syncthreads();
 
   const int q0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 16;
-  if (q0 >= a.Lq) return;
+  if (!SEQ && q0 >= a.Lq) return;
   const int q = q0 + ql;
   const bool qok = q < a.Lq;
   // B operand = Q^T: 8 consecutive head-dim values of this lane's query
@@ -152,6 +155,11 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
       *reinterpret_cast<bf16x8*>(Pr + kcol) = pp;
     }
   }
+  if (SEQ) {                                             // the scores are done with K: V takes its place
+    __syncthreads();
+    stage_rows<true>(Vb, a.ldv, a.Lk, NT * 16, Vs);
+    __syncthreads();
+  }
   // O^T[d][q] = sum_key V[key][d] * P[q][key]
   f32x4 o[4];
 #pragma unroll
@@ -179,12 +187,13 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
 template <int NT>
 static int launch_fwd(const MAttnF& f, hipStream_t stream) {
   constexpr int MAXW = NT <= 14 ? 16 : 4;              // register budget: 16 waves/workgroup need <= 128 VGPRs
-  const size_t lds = (size_t)2 * NT * 16 * 128 + (size_t)NT * 16 * sizeof(float);
+  constexpr bool SEQ = NT > 38;                        // 2 x NT x 2 KiB of K and V no longer fit in 160 KiB of LDS
+  const size_t lds = (size_t)(SEQ ? 1 : 2) * NT * 16 * 128 + (size_t)NT * 16 * sizeof(float);
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT, MAXW, SEQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nw = imin(MAXW, (f.Lq + 15) / 16);         // waves per workgroup (16 queries each)
   dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
-  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT, MAXW>), grid, block, lds, stream, f);
+  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT, MAXW, SEQ>), grid, block, lds, stream, f);
   return 0;
 }
 
@@ -202,19 +211,19 @@ struct MAttnB {
 // kernel A: same shape as the forward (a wave owns 16 queries and ALL keys):
 //   dPo^T = V dO^T ;  dP = gate*dPo + E ;  delta = rowsum(P .* dP) ;  dS = P .* (dP - delta) -> HBM (for kernel B)
 //   dQ^T  = scale * K^T dS^T           (dS^T accumulators reused as the MFMA B operand, K^T through tr16 reads)
-template <int NT, int MAXW>
+template <int NT, int MAXW, bool SEQ>
 __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;                          // v_swz (column reads)
-  char* Vs = smem + NT * 16 * 128;          // k_swz (row reads)
+  char* Ks = smem;                                       // v_swz (column reads)
+  char* Vs = SEQ ? smem : smem + NT * 16 * 128;          // k_swz (row reads); SEQ: V first, then K in the same region
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
   const int bkv = a.kv_index ? a.kv_index[b] : b;
-  stage_rows<true>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
+  if (!SEQ) stage_rows<true>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
   stage_rows<false>(a.V + (size_t)bkv * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
   __syncthreads();
   const int q0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 16;
-  if (q0 >= a.Lq) return;
+  if (!SEQ && q0 >= a.Lq) return;
   const int q = q0 + ql;
   const bool qok = q < a.Lq;
   bf16x8 dof[2];
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   const size_t prow = (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr;
   const float gz = a.gate ? a.gate[h] : 1.0f;
   f32x4 acc[NT];
-  bf16x4 pv[NT];
+  bf16x4 pv[SEQ ? 1 : NT];                      // SEQ: P is read again below instead of being carried (register budget)
   float dsum = 0.f, gsum = 0.f;
 #pragma unroll
   for (int s = 0; s < NT / 2; ++s) {            // tile pair: this lane's 8 consecutive keys 32s + 8g .. + 7
@@ -249,14 +258,15 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, t, ks, lane), dof[ks], acc[t], 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pv[t][r] = p8[hh * 4 + r];
-        const float p = (float)pv[t][r], dpo = acc[t][r];
+        if (!SEQ) pv[t][r] = p8[hh * 4 + r];
+        const float p = (float)p8[hh * 4 + r], dpo = acc[t][r];
         gsum += p * dpo;
         const float dp = gz * dpo + (float)e8[hh * 4 + r];
         acc[t][r] = dp;
         dsum += p * dp;
       }
     }
+    if (SEQ && (s & 1)) __builtin_amdgcn_sched_barrier(0);     // keep the P / E loads of later tile pairs from being hoisted
   }
   dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
   if (a.dgate) {
@@ -264,10 +274,27 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
     if (lane == 0) atomicAdd(a.dgate + h, gs);
   }
   bf16x4 dsk[NT];
+  if (!SEQ) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dsk[t][r] = (bf16)((float)pv[t][r] * (acc[t][r] - dsum));
+      for (int r = 0; r < 4; ++r) dsk[t][r] = (bf16)((float)pv[t][r] * (acc[t][r] - dsum));
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < NT / 2; ++s) {
+      const int kcol = s * 32 + g * 8;
+      bf16x8 p8;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) p8[r] = (bf16)0.f;
+      if (qok && kcol < a.ldpr) p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dsk[2 * s][r] = (bf16)((float)p8[r] * (acc[2 * s][r] - dsum));
+        dsk[2 * s + 1][r] = (bf16)((float)p8[4 + r] * (acc[2 * s + 1][r] - dsum));
+      }
+      if (s & 1) __builtin_amdgcn_sched_barrier(0);
+    }
   }
 #pragma unroll
   for (int s = 0; s < NT / 2; ++s) {
@@ -278,6 +305,11 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
       for (int r = 0; r < 4; ++r) { d8[r] = dsk[2 * s][r]; d8[4 + r] = dsk[2 * s + 1][r]; }
       *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
     }
+  }
+  if (SEQ) {                                             // dP is done with V: K takes its place
+    __syncthreads();
+    stage_rows<true>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
+    __syncthreads();
   }
   f32x4 o[4];
 #pragma unroll
@@ -379,17 +411,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
 template <int NT>
 static void launch_bwd_dq(const MAttnB& f, hipStream_t stream) {
   constexpr int MAXW = NT <= 14 ? 8 : 4;
-  const size_t lds = (size_t)2 * NT * 16 * 128;
+  constexpr bool SEQ = NT > 38;
+  const size_t lds = (size_t)(SEQ ? 1 : 2) * NT * 16 * 128;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<NT, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<NT, MAXW, SEQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nw = imin(MAXW, (f.Lq + 15) / 16);
   dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
-  hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NT, MAXW>), grid, block, lds, stream, f);
+  hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NT, MAXW, SEQ>), grid, block, lds, stream, f);
 }
 
 int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int* handled) {
   *handled = 0;
-  if (a->dtype != EVLM_BF16 || a->p_dtype != EVLM_BF16 || a->dh != DH || a->Lk > 608) return 0;
+  if (a->dtype != EVLM_BF16 || a->p_dtype != EVLM_BF16 || a->dh != DH || a->Lk > 928) return 0;
   if ((a->ldq | a->ldk | a->ldv | a->ldo | a->lddq | a->lddk | a->lddv | a->ldpr) % 8 != 0) return 0;
   MAttnB f;
   f.Q = (const bf16*)a->Q; f.K = (const bf16*)a->K; f.V = (const bf16*)a->V; f.P = (const bf16*)a->P;
@@ -402,7 +435,8 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
   else if (a->Lk <= 64) launch_bwd_dq<4>(f, stream);
   else if (a->Lk <= 224) launch_bwd_dq<14>(f, stream);
   else if (a->Lk <= 416) launch_bwd_dq<26>(f, stream);
-  else launch_bwd_dq<38>(f, stream);
+  else if (a->Lk <= 608) launch_bwd_dq<38>(f, stream);
+  else launch_bwd_dq<58>(f, stream);
   dim3 gridB((a->Lk + 63) / 64, a->H, f.Bkv), block(256);
   hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, gridB, block, 0, stream, f);
   hipError_t e = hipGetLastError();
@@ -414,7 +448,7 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
 // returns 0 and sets *handled = 1 when a specialised kernel took the call
 int evlm_attention_fwd_mfma(const evlm_attn_fwd_args* a, hipStream_t stream, int* handled) {
   *handled = 0;
-  if (a->dtype != EVLM_BF16 || a->p_dtype != EVLM_BF16 || a->dh != DH || a->Lk > 608) return 0;
+  if (a->dtype != EVLM_BF16 || a->p_dtype != EVLM_BF16 || a->dh != DH || a->Lk > 928) return 0;
   if ((a->ldq | a->ldk | a->ldv | a->ldo) % 8 != 0 || (a->P && a->ldpr % 8 != 0)) return 0;
   MAttnF f;
   f.Q = (const bf16*)a->Q; f.K = (const bf16*)a->K; f.V = (const bf16*)a->V; f.kv_index = a->kv_index;
@@ -425,7 +459,8 @@ int evlm_attention_fwd_mfma(const evlm_attn_fwd_args* a, hipStream_t stream, int
   else if (a->Lk <= 64) launch_fwd<4>(f, stream);
   else if (a->Lk <= 224) launch_fwd<14>(f, stream);
   else if (a->Lk <= 416) launch_fwd<26>(f, stream);
-  else launch_fwd<38>(f, stream);
+  else if (a->Lk <= 608) launch_fwd<38>(f, stream);
+  else launch_fwd<58>(f, stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return evlm_set_error("evlm_attention_fwd(mfma): %s", hipGetErrorString(e));
   *handled = 1;

@@ -574,7 +574,7 @@ def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True, 
     row, so image tokens shared by several text batches are projected (and their gradient reduced) once."""
     d = H * dh
     if kv_index is not None:
-        if q.dtype == torch.bfloat16 and dh == 64 and kv.shape[1] <= 608:
+        if q.dtype == torch.bfloat16 and dh == 64 and kv.shape[1] <= 928:
             kv_index = kv_index.to(torch.int32).contiguous()
         else:                                   # exact-fp32 / generic path: materialise the gather (autograd scatters back)
             kv = torch.index_select(kv, 0, kv_index.long())

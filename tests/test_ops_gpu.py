@@ -223,7 +223,8 @@ def test_causal_self_attention(dtype, B, H, L, dh):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,H,L,dh", [(2, 4, 5, 16), (2, 12, 197, 64), (3, 12, 30, 64), (1, 2, 70, 32)])
+@pytest.mark.parametrize("B,H,L,dh", [(2, 4, 5, 16), (2, 12, 197, 64), (3, 12, 30, 64), (1, 2, 70, 32), (1, 3, 577, 64),
+                                      (2, 2, 901, 64)])          # 901 = 480x480 images: K and V take turns in LDS
 def test_self_attention(dtype, B, H, L, dh):
     o = ops()
     g = torch.Generator().manual_seed(19 + L)
@@ -252,7 +253,7 @@ def test_self_attention(dtype, B, H, L, dh):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,H,Lq,Lk,dh", [(2, 4, 8, 5, 16), (3, 12, 30, 197, 64)])
+@pytest.mark.parametrize("B,H,Lq,Lk,dh", [(2, 4, 8, 5, 16), (3, 12, 30, 197, 64), (2, 2, 30, 901, 64)])
 def test_cross_attention(dtype, B, H, Lq, Lk, dh):
     o = ops()
     g = torch.Generator().manual_seed(23)
