@@ -36,7 +36,28 @@ __device__ __forceinline__ int tile_key0(int t, int g) { return (t >> 1) * 32 + 
 // stage keys [0, nrows) of a [L][.. ld ..] tensor (64 columns at `base`) into a swizzled LDS tile; keys >= L are zero
 template <bool VSWZ>
 __device__ __forceinline__ void stage_rows(const bf16* base, int ld, int L, int nrows, char* sm) {
-  for (int id = threadIdx.x; id < nrows * 8; id += blockDim.x) {
+  // four 16-byte loads in flight per thread before the first LDS store: with few waves per workgroup (long sequences:
+  // 4 waves, up to 29 trips) a load -> wait -> store trip per element left the staging bound by global-load latency
+  constexpr int U = 4;
+  const int total = nrows * 8, step = blockDim.x;
+  int id = threadIdx.x;
+  for (; id + (U - 1) * step < total; id += U * step) {
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int key = (id + u * step) >> 3, c = (id + u * step) & 7;
+      v[u] = make_uint4(0, 0, 0, 0);
+      if (key < L) v[u] = *reinterpret_cast<const uint4*>(base + (size_t)key * ld + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int key = (id + u * step) >> 3, c = (id + u * step) & 7;
+      const int row = key_row(key);
+      const int cs = VSWZ ? v_swz(row, c) : k_swz(row, c);
+      *reinterpret_cast<uint4*>(sm + row * 128 + cs * 16) = v[u];
+    }
+  }
+  for (; id < total; id += step) {
     const int key = id >> 3, c = id & 7;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (key < L) v = *reinterpret_cast<const uint4*>(base + (size_t)key * ld + c * 8);

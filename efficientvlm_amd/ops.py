@@ -214,6 +214,21 @@ def _wgrad(dtype, d2, ldd, x2, ldp, M, K, params, rows, biases=None):
     """dW_i = dY[:, rows_i]^T X for every packed weight (and, when `biases` is given, db_i = column sums of dY riding
     on the same GEMM).  Returns (weight grads, bias grads); entries are None where accumulated in place."""
     gw, gb, r0 = [], [], 0
+    if dtype == L.BF16 and M % 64 != 0 and M > 64 and all(_inplace(w) for w in params):
+        # a reduction length that is not a multiple of the 64-row K tile (B x 901 image tokens at 480x480, odd batches):
+        # the first floor64(M) rows take the MFMA path (in place, grouped), the <= 63 remaining rows are zero-padded to
+        # one K tile and accumulated by a second, tiny product - instead of the whole product falling to the generic kernel
+        M0 = M - M % 64
+        gw, gb = _wgrad(dtype, d2, ldd, x2, ldp, M0, K, params, rows, biases)
+        N = sum(rows)
+        td = torch.zeros((64, N), dtype=d2.dtype, device=d2.device)
+        tx = torch.zeros((64, K), dtype=x2.dtype, device=x2.device)
+        tail = lambda t, ld, w: torch.as_strided(t, (M - M0, w), (ld, 1), t.storage_offset() + M0 * ld)
+        td[:M - M0].copy_(tail(d2, ldd, N))
+        tx[:M - M0].copy_(tail(x2, ldp, K))
+        _, gb_t = _wgrad(dtype, td, td.stride(0), tx, tx.stride(0), 64, K, params, rows, biases)
+        gb = [a if b is None else (b if a is None else a + b) for a, b in zip(gb, gb_t)]
+        return gw, gb
     fast = dtype == L.BF16 and M % 64 == 0
     has_b = biases is not None and len(biases) and biases[0] is not None
     if not (fast and all(_inplace(w) for w in params)):
