@@ -34,38 +34,30 @@ __device__ __forceinline__ int key_row(int key) {
 __device__ __forceinline__ int tile_key0(int t, int g) { return (t >> 1) * 32 + g * 8 + (t & 1) * 4; }
 
 // stage keys [0, nrows) of a [L][.. ld ..] tensor (64 columns at `base`) into a swizzled LDS tile; keys >= L are zero
+// inverse of key_row: the key held by LDS row `row`
+__device__ __forceinline__ int row_key(int row) {
+  const int t = row >> 4;
+  return (t >> 1) * 32 + ((row >> 2) & 3) * 8 + (t & 1) * 4 + (row & 3);
+}
+
+// Stage keys [0, nrows) of a [L][.. ld ..] tensor (64 columns at `base`) into a swizzled LDS tile by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, every instruction of a wave in flight at once).  One wave instruction
+// fills 8 consecutive 128-byte LDS rows, lane-linear; the key permutation and the chunk swizzle (XOR: its own inverse)
+// are applied to each lane's SOURCE address.  Keys >= L read key L-1: their scores carry the -1e30 of the mask row /
+// their probabilities are zero, so any finite value serves.  The caller waits (stage_wait) before its barrier.
 template <bool VSWZ>
 __device__ __forceinline__ void stage_rows(const bf16* base, int ld, int L, int nrows, char* sm) {
-  // four 16-byte loads in flight per thread before the first LDS store: with few waves per workgroup (long sequences:
-  // 4 waves, up to 29 trips) a load -> wait -> store trip per element left the staging bound by global-load latency
-  constexpr int U = 4;
-  const int total = nrows * 8, step = blockDim.x;
-  int id = threadIdx.x;
-  for (; id + (U - 1) * step < total; id += U * step) {
-    uint4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int key = (id + u * step) >> 3, c = (id + u * step) & 7;
-      v[u] = make_uint4(0, 0, 0, 0);
-      if (key < L) v[u] = *reinterpret_cast<const uint4*>(base + (size_t)key * ld + c * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int key = (id + u * step) >> 3, c = (id + u * step) & 7;
-      const int row = key_row(key);
-      const int cs = VSWZ ? v_swz(row, c) : k_swz(row, c);
-      *reinterpret_cast<uint4*>(sm + row * 128 + cs * 16) = v[u];
-    }
-  }
-  for (; id < total; id += step) {
-    const int key = id >> 3, c = id & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (key < L) v = *reinterpret_cast<const uint4*>(base + (size_t)key * ld + c * 8);
-    const int row = key_row(key);
-    const int cs = VSWZ ? v_swz(row, c) : k_swz(row, c);
-    *reinterpret_cast<uint4*>(sm + row * 128 + cs * 16) = v;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int r0 = wave * 8; r0 < nrows; r0 += nw * 8) {
+    const int row = r0 + (lane >> 3), cs = lane & 7;
+    const int c = VSWZ ? v_swz(row, cs) : k_swz(row, cs);
+    const int key = min(row_key(row), L - 1);
+    const bf16* src = base + (size_t)key * ld + c * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(sm + r0 * 128), 16, 0, 0);
   }
 }
+__device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // A/B operand fragment (rows = keys, k = head dim) from a k_swz tile: row = 16*t + (lane&15), k = 32*ks + 8*(lane>>4)..+7
 __device__ __forceinline__ bf16x8 krow_frag(const char* sm, int t, int ks, int lane) {
@@ -108,6 +100,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   if (!SEQ) stage_rows<true>(Vb, a.ldv, a.Lk, NT * 16, Vs);
   for (int k = threadIdx.x; k < NT * 16; k += blockDim.x)
     Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
+  stage_wait();
   __syncthreads();
 
   const int q0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 16;
@@ -179,6 +172,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   if (SEQ) {                                             // the scores are done with K: V takes its place
     __syncthreads();
     stage_rows<true>(Vb, a.ldv, a.Lk, NT * 16, Vs);
+    stage_wait();
     __syncthreads();
   }
   // O^T[d][q] = sum_key V[key][d] * P[q][key]
@@ -242,6 +236,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   const int bkv = a.kv_index ? a.kv_index[b] : b;
   if (!SEQ) stage_rows<true>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
   stage_rows<false>(a.V + (size_t)bkv * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
+  stage_wait();
   __syncthreads();
   const int q0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 16;
   if (!SEQ && q0 >= a.Lq) return;
@@ -330,6 +325,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   if (SEQ) {                                             // dP is done with V: K takes its place
     __syncthreads();
     stage_rows<true>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
+    stage_wait();
     __syncthreads();
   }
   f32x4 o[4];
