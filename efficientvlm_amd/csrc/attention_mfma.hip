@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
 
 template <int NT>
 static int launch_fwd(const MAttnF& f, hipStream_t stream) {
-  constexpr int MAXW = NT <= 14 ? 16 : 4;              // register budget: 16 waves/workgroup need <= 128 VGPRs
+  constexpr int MAXW = NT <= 14 ? 16 : (NT <= 26 ? 8 : 4);   // register budget: 16 (8) waves/workgroup need <= 128 (256) VGPRs
   constexpr bool SEQ = NT > 38;                        // 2 x NT x 2 KiB of K and V no longer fit in 160 KiB of LDS
   const size_t lds = (size_t)(SEQ ? 1 : 2) * NT * 16 * 128 + (size_t)NT * 16 * sizeof(float);
   if (lds > 64 * 1024)
