@@ -379,6 +379,9 @@ class XVLMBase(nn.Module):
         bs = image_embeds.size(0)
         img_neg, txt_neg = self._sample_negatives(image_feat, text_feat, idx)
         self.last_neg_idx = torch.cat([img_neg, txt_neg])
+        if output_hidden_states and self.batched_itm:
+            return self._matching_loss_batched(image_embeds, image_atts, text_embeds, text_atts, img_neg, txt_neg,
+                                               head_z, head_layer_z, mlp_z)
         image_embeds_neg = torch.index_select(image_embeds, 0, img_neg)
         image_atts_neg = torch.index_select(image_atts, 0, img_neg)
         text_embeds_neg = torch.index_select(text_embeds, 0, txt_neg)
@@ -408,6 +411,31 @@ class XVLMBase(nn.Module):
             return matching_loss
         return {"loss": matching_loss, "pos_hidden_states": pos_hs, "neg_hidden_states": neg_hs, "pos_attentions": pos_att,
                 "neg_attentions": neg_att, "pos_cross_attentions": pos_catt, "neg_cross_attentions": neg_catt, "logits": output}
+
+    # One fusion pass over [positive (B) ; negative (2B)] rows instead of the reference's two (xvlm.py:460-476): row-wise
+    # identical arithmetic; the hard-negative image copies are not materialised - their cross-attention K / V come from
+    # the B distinct images through the attention kernels' batch index (projected, and differentiated, once per image).
+    batched_itm = True
+
+    def _matching_loss_batched(self, image_embeds, image_atts, text_embeds, text_atts, img_neg, txt_neg, head_z,
+                               head_layer_z, mlp_z):
+        bs, dev = image_embeds.size(0), image_embeds.device
+        ar = torch.arange(bs, device=dev)
+        txt_all = torch.cat([text_embeds, text_embeds, torch.index_select(text_embeds, 0, txt_neg)], 0)
+        atts_all = torch.cat([text_atts, text_atts, torch.index_select(text_atts, 0, txt_neg)], 0)
+        img_index = torch.cat([ar, img_neg, ar], 0)            # pos | (text, image_neg) | (text_neg, image)
+        f = self._text_core()(encoder_embeds=txt_all, attention_mask=atts_all, encoder_hidden_states=image_embeds,
+                              encoder_attention_mask=torch.index_select(image_atts, 0, img_index),
+                              encoder_batch_index=img_index, return_dict=True, mode="fusion", output_attentions=True,
+                              output_hidden_states=True, head_z=head_z, head_layer_z=head_layer_z, mlp_z=mlp_z)
+        two = lambda tup: tuple(zip(*[torch.split(x, [bs, 2 * bs], 0) if x is not None else (None, None) for x in tup]))
+        (pos_hs, neg_hs), (pos_att, neg_att), (pos_catt, neg_catt) = two(f.hidden_states), two(f.attentions), \
+            two(f.cross_attentions)
+        output = mlp_head_forward(self.itm_head, f.last_hidden_state[:, 0, :])
+        itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)])
+        return {"loss": ops.cross_entropy(output, itm_labels), "pos_hidden_states": pos_hs, "neg_hidden_states": neg_hs,
+                "pos_attentions": pos_att, "neg_attentions": neg_att, "pos_cross_attentions": pos_catt,
+                "neg_cross_attentions": neg_catt, "logits": output}
 
     def get_mlm_loss(self, text_ids_masked, text_atts, image_embeds, image_atts, masked_pos, masked_ids,
                      output_attentions=None, output_hidden_states=None, head_z=None, head_layer_z=None, mlp_z=None):
