@@ -171,6 +171,11 @@ def main():
         cpu_baseline_child()
         return
 
+    # stdout carries exactly ONE line (the JSON result): anything libraries write to fd 1 meanwhile - RCCL prints a
+    # version / hostname block there when its first communicator is created - is sent to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -259,7 +264,8 @@ def main():
                                   "steps": n2}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()
