@@ -23,6 +23,11 @@ class XVLM(XVLMBase):
     # the gathered hard-negative copies.  Row-wise identical arithmetic, 3-4x larger GEMMs, ~1/3 of the launches.
     batched_passes = True
     on_vision_grad = None      # optional callback: fired (tensor hook) when backward has produced d(loss)/d(image_embeds)
+    # extension (False = the reference's behaviour): a frozen TEACHER's task losses are never read by the distillation
+    # loss (GeneralDistill.py:300-376 uses its hidden states, attention maps and logits only); with this set the batched
+    # forward skips ITC / ITM / MLM cross-entropies - and with them the ITC feature all-gather, the teacher forward's only
+    # collective, so that forward can be captured into a hipGraph on multi-GPU runs too.  `loss` is then an empty dict.
+    skip_task_losses = False
 
     def forward(self, image, text_ids, text_atts, text_ids_masked=None, masked_pos=None, masked_ids=None, image_atts=None,
                 idx_to_group_img=None, target_bbox=None, is_image=None, ret_bbox_loss=False, output_attentions=None,
@@ -115,7 +120,8 @@ class XVLM(XVLMBase):
         with torch.no_grad():
             self.temp.clamp_(0.001, 0.5)
         image_feat, text_feat = self.get_features(image_embeds, text_embeds)
-        loss_itc = self.get_contrastive_loss(image_feat, text_feat)
+        skip = self.skip_task_losses and not torch.is_grad_enabled()
+        loss_itc = None if skip else self.get_contrastive_loss(image_feat, text_feat)
         img_neg, txt_neg = self._sample_negatives(image_feat, text_feat, None)
         self.last_neg_idx = torch.cat([img_neg, txt_neg])
         # fusion layers on [pos (B) ; neg (2B: text|text_neg x img_neg|img) ; mlm (B)]
@@ -138,13 +144,13 @@ class XVLM(XVLMBase):
         last = f.last_hidden_state
         itm_logits = mlp_head_forward(self.itm_head, last[:3 * B, 0, :])
         itm_labels = torch.cat([torch.ones(B, dtype=torch.long, device=dev), torch.zeros(2 * B, dtype=torch.long, device=dev)])
-        loss_itm = ops.cross_entropy(itm_logits, itm_labels)
+        loss_itm = None if skip else ops.cross_entropy(itm_logits, itm_labels)
         # MLM head on the masked positions of the last quarter
         enc = self.text_encoder
         mlm_last = f_hid[2][-1] if f.hidden_states[-1] is last else last[3 * B:4 * B]
         mlm_seq = enc.gather_seq_out_by_pos(mlm_last, masked_pos)
         mlm_logits = enc.cls(mlm_seq)
-        loss_mlm = ops.cross_entropy(mlm_logits.reshape(-1, enc.config.vocab_size), masked_ids.reshape(-1))
+        loss_mlm = None if skip else ops.cross_entropy(mlm_logits.reshape(-1, enc.config.vocab_size), masked_ids.reshape(-1))
         nF = len(t.attentions)
         hidden_dict = {"image_hidden_states": image_hidden_states, "text_hidden_states": text_hidden_states,
                        "itm_pos_hidden_states": f_hid[0], "itm_neg_hidden_states": f_hid[1],
@@ -155,10 +161,11 @@ class XVLM(XVLMBase):
         cross_attention_dict = {"itm_pos_cross_attentions": f_cross[0], "itm_neg_cross_attentions": f_cross[1],
                                 "mlm_cross_attentions": f_cross[2]}
         logits_dict = {"itm_head_logits": itm_logits, "mlm_logits": mlm_logits}
-        loss = {"loss_itc": loss_itc, "loss_itm": loss_itm, "loss_mlm": loss_mlm}
+        loss = {} if skip else {"loss_itc": loss_itc, "loss_itm": loss_itm, "loss_mlm": loss_mlm}
         if region is not None:                                                            # model_pretrain.py:62-74
             coord = self.bbox_coord(last[4 * B:, 0, :])
-            loss["loss_bbox"], loss["loss_giou"] = self.get_bbox_loss(coord, target_bbox, is_image=is_image)
+            if not skip:
+                loss["loss_bbox"], loss["loss_giou"] = self.get_bbox_loss(coord, target_bbox, is_image=is_image)
             hidden_dict["bbox_hidden_states"], attention_dict["bbox_attentions"] = f_hid[3], f_att[3]
             cross_attention_dict["bbox_cross_attentions"] = f_cross[3]
             self.last_output_coord = coord.detach()
