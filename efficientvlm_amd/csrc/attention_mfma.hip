@@ -226,20 +226,20 @@ struct MAttnB {
 // kernel A: same shape as the forward (a wave owns 16 queries and ALL keys):
 //   dPo^T = V dO^T ;  dP = gate*dPo + E ;  delta = rowsum(P .* dP) ;  dS = P .* (dP - delta) -> HBM (for kernel B)
 //   dQ^T  = scale * K^T dS^T           (dS^T accumulators reused as the MFMA B operand, K^T through tr16 reads)
-template <int NT, int MAXW, bool SEQ>
+template <int NT, int MAXW>
 __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;                                       // v_swz (column reads)
-  char* Vs = SEQ ? smem : smem + NT * 16 * 128;          // k_swz (row reads); SEQ: V first, then K in the same region
+  char* Ks = smem;                          // v_swz (column reads)
+  char* Vs = smem + NT * 16 * 128;          // k_swz (row reads)
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
   const int bkv = a.kv_index ? a.kv_index[b] : b;
-  if (!SEQ) stage_rows<true>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
+  stage_rows<true>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
   stage_rows<false>(a.V + (size_t)bkv * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
   stage_wait();
   __syncthreads();
   const int q0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 16;
-  if (!SEQ && q0 >= a.Lq) return;
+  if (q0 >= a.Lq) return;
   const int q = q0 + ql;
   const bool qok = q < a.Lq;
   bf16x8 dof[2];
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   const size_t prow = (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr;
   const float gz = a.gate ? a.gate[h] : 1.0f;
   f32x4 acc[NT];
-  bf16x4 pv[SEQ ? 1 : NT];                      // SEQ: P is read again below instead of being carried (register budget)
+  bf16x4 pv[NT];
   float dsum = 0.f, gsum = 0.f;
 #pragma unroll
   for (int s = 0; s < NT / 2; ++s) {            // tile pair: this lane's 8 consecutive keys 32s + 8g .. + 7
@@ -274,15 +274,14 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, t, ks, lane), dof[ks], acc[t], 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (!SEQ) pv[t][r] = p8[hh * 4 + r];
-        const float p = (float)p8[hh * 4 + r], dpo = acc[t][r];
+        pv[t][r] = p8[hh * 4 + r];
+        const float p = (float)pv[t][r], dpo = acc[t][r];
         gsum += p * dpo;
         const float dp = gz * dpo + (float)e8[hh * 4 + r];
         acc[t][r] = dp;
         dsum += p * dp;
       }
     }
-    if (SEQ && (s & 1)) __builtin_amdgcn_sched_barrier(0);     // keep the P / E loads of later tile pairs from being hoisted
   }
   dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
   if (a.dgate) {
@@ -290,27 +289,10 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
     if (lane == 0) atomicAdd(a.dgate + h, gs);
   }
   bf16x4 dsk[NT];
-  if (!SEQ) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dsk[t][r] = (bf16)((float)pv[t][r] * (acc[t][r] - dsum));
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < NT / 2; ++s) {
-      const int kcol = s * 32 + g * 8;
-      bf16x8 p8;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) p8[r] = (bf16)0.f;
-      if (qok && kcol < a.ldpr) p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        dsk[2 * s][r] = (bf16)((float)p8[r] * (acc[2 * s][r] - dsum));
-        dsk[2 * s + 1][r] = (bf16)((float)p8[4 + r] * (acc[2 * s + 1][r] - dsum));
-      }
-      if (s & 1) __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int r = 0; r < 4; ++r) dsk[t][r] = (bf16)((float)pv[t][r] * (acc[t][r] - dsum));
   }
 #pragma unroll
   for (int s = 0; s < NT / 2; ++s) {
@@ -321,12 +303,6 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
       for (int r = 0; r < 4; ++r) { d8[r] = dsk[2 * s][r]; d8[4 + r] = dsk[2 * s + 1][r]; }
       *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
     }
-  }
-  if (SEQ) {                                             // dP is done with V: K takes its place
-    __syncthreads();
-    stage_rows<true>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
-    stage_wait();
-    __syncthreads();
   }
   f32x4 o[4];
 #pragma unroll
@@ -339,6 +315,116 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
       o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Ks, 2 * s, 2 * s + 1, dt, lane), pb, o[dt], 0, 0, 0);
+  }
+  if (qok) {
+    bf16* dQr = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 ov = {(bf16)(o[dt][0] * a.scale), (bf16)(o[dt][1] * a.scale), (bf16)(o[dt][2] * a.scale), (bf16)(o[dt][3] * a.scale)};
+      *reinterpret_cast<bf16x4*>(dQr + dt * 16 + g * 4) = ov;
+    }
+  }
+}
+
+// kernel A for LONG key sequences (608 < Lk <= 960: 480x480 images are 901 tokens).  Holding a whole row of dP / P / dS
+// in registers (kernel A above) needs ~460 VGPRs at this length and spilled ~1 KiB per lane, so this variant makes two
+// passes over the keys and keeps nothing but the running sums:
+//   pass 1: V (all keys, one 120 KiB LDS tile) -> delta = rowsum(P .* dP), gate gradient
+//   pass 2: per key HALF, V_h and K_h side by side in the same LDS space: dP recomputed (2 MFMAs per tile), dS = P .* (dP -
+//           delta) stored for kernel B and consumed at once by dQ^T += K_h^T dS^T.
+// P and E are read twice (the second time mostly from the last-level cache); ~70 VGPRs, 8 waves = 128 queries per workgroup.
+template <int NT, int MAXW>
+__global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HT = NT / 2;                               // key tiles per half (even: tile pairs stay together)
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
+  const int bkv = a.kv_index ? a.kv_index[b] : b;
+  const bf16* Kb = a.K + (size_t)bkv * a.Lk * a.ldk + h * DH;
+  const bf16* Vb = a.V + (size_t)bkv * a.Lk * a.ldv + h * DH;
+  stage_rows<false>(Vb, a.ldv, a.Lk, NT * 16, smem);
+  stage_wait();
+  __syncthreads();
+  const int q = (blockIdx.x * (blockDim.x >> 6) + wave) * 16 + ql;
+  const bool qok = q < a.Lq;                               // (waves past the last query stay for the barriers)
+  bf16x8 dof[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (qok) v = *reinterpret_cast<const uint4*>(a.dO + ((size_t)b * a.Lq + q) * a.ldo + h * DH + ks * 32 + g * 8);
+    dof[ks] = *reinterpret_cast<bf16x8*>(&v);
+  }
+  const size_t prow = (((size_t)b * a.H + h) * a.Lq + (qok ? q : 0)) * a.ldpr;
+  const float gz = a.gate ? a.gate[h] : 1.0f;
+  float dsum = 0.f, gsum = 0.f;
+#pragma unroll 2
+  for (int s = 0; s < NT / 2; ++s) {
+    const int kcol = s * 32 + g * 8;
+    bf16x8 p8, e8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { p8[r] = (bf16)0.f; e8[r] = (bf16)0.f; }
+    if (qok && kcol < a.ldpr) {
+      p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
+      if (a.E) e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(smem, 2 * s + hh, ks, lane), dof[ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = (float)p8[hh * 4 + r];
+        gsum += p * acc[r];
+        dsum += p * (gz * acc[r] + (float)e8[hh * 4 + r]);
+      }
+    }
+  }
+  dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
+  if (a.dgate) {
+    const float gs = wave_sum(gsum);
+    if (lane == 0) atomicAdd(a.dgate + h, gs);
+  }
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  char* Vs = smem;                                         // k_swz rows (dP = V dO^T)
+  char* Ks = smem + HT * 16 * 128;                         // v_swz columns (dQ^T = K^T dS^T)
+  for (int half = 0; half < 2; ++half) {
+    const int key0 = half * HT * 16;
+    __syncthreads();                                       // every wave is done with the previous contents
+    stage_rows<false>(Vb + (size_t)key0 * a.ldv, a.ldv, a.Lk - key0, HT * 16, Vs);
+    stage_rows<true>(Kb + (size_t)key0 * a.ldk, a.ldk, a.Lk - key0, HT * 16, Ks);
+    stage_wait();
+    __syncthreads();
+#pragma unroll 2
+    for (int s = 0; s < HT / 2; ++s) {
+      const int kcol = key0 + s * 32 + g * 8;
+      const bool ok = qok && kcol < a.ldpr;
+      bf16x8 p8, e8;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { p8[r] = (bf16)0.f; e8[r] = (bf16)0.f; }
+      if (ok) {
+        p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
+        if (a.E) e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
+      }
+      bf16x8 d8;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, 2 * s + hh, ks, lane), dof[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          d8[hh * 4 + r] = (bf16)((float)p8[hh * 4 + r] * (gz * acc[r] + (float)e8[hh * 4 + r] - dsum));
+      }
+      if (ok) *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Ks, 2 * s, 2 * s + 1, dt, lane), d8, o[dt], 0, 0, 0);
+    }
   }
   if (qok) {
     bf16* dQr = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + h * DH;
@@ -428,13 +514,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
 template <int NT>
 static void launch_bwd_dq(const MAttnB& f, hipStream_t stream) {
   constexpr int MAXW = NT <= 14 ? 8 : 4;
-  constexpr bool SEQ = NT > 38;
-  const size_t lds = (size_t)(SEQ ? 1 : 2) * NT * 16 * 128;
+  const size_t lds = (size_t)2 * NT * 16 * 128;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<NT, MAXW, SEQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<NT, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nw = imin(MAXW, (f.Lq + 15) / 16);
   dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
-  hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NT, MAXW, SEQ>), grid, block, lds, stream, f);
+  hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NT, MAXW>), grid, block, lds, stream, f);
+}
+
+template <int NT>
+static void launch_bwd_dq_long(const MAttnB& f, hipStream_t stream) {
+  constexpr int MAXW = 8;
+  const size_t lds = (size_t)NT * 16 * 128;
+  (void)hipFuncSetAttribute((const void*)attn_bwd_dq_long_kernel<NT, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int nw = imin(MAXW, (f.Lq + 15) / 16);
+  dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
+  hipLaunchKernelGGL((attn_bwd_dq_long_kernel<NT, MAXW>), grid, block, lds, stream, f);
 }
 
 int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int* handled) {
@@ -452,8 +547,8 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
   else if (a->Lk <= 64) launch_bwd_dq<4>(f, stream);
   else if (a->Lk <= 224) launch_bwd_dq<14>(f, stream);
   else if (a->Lk <= 416) launch_bwd_dq<26>(f, stream);
-  else if (a->Lk <= 608) launch_bwd_dq<38>(f, stream);
-  else launch_bwd_dq<58>(f, stream);
+  else if (a->Lk <= 640) launch_bwd_dq_long<40>(f, stream);      // long sequences: two passes over the keys, nothing spilled
+  else launch_bwd_dq_long<60>(f, stream);
   dim3 gridB((a->Lk + 63) / 64, a->H, f.Bkv), block(256);
   hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, gridB, block, 0, stream, f);
   hipError_t e = hipGetLastError();
