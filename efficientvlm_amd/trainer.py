@@ -128,7 +128,6 @@ class GDTrainer:
         forward, one student forward + backward and one optimiser step."""
         self.student, self.teacher = student, teacher
         self.pipeline_teacher = pipeline_teacher
-        self._pipe = None
         self._keep_ST, self._last_ST = False, None
         self.dtype, self.temperature = dtype, temperature
         for p in teacher.parameters():
@@ -157,7 +156,9 @@ class GDTrainer:
         self.static = None
         self.out = None
         self._graphs = {}
-        self._held = None
+        self._pipes, self._pending = {}, None
+        self._side = torch.cuda.Stream() if next(student.parameters()).is_cuda else None
+        self._tpool = self._spool = None
         if self.world > 1:
             for g in self.opt.groups:                     # broadcast params from rank 0 (apex_ddp_accelerator.py:75-77)
                 dist.broadcast(g["p"], 0)
@@ -202,19 +203,28 @@ class GDTrainer:
         return out
 
     # ---- teacher pipelining ------------------------------------------------------------------------
-    def _pipe_prime(self, batch):
-        """static batch buffers x2, two eager warm-up steps (lr 0), the teacher outputs of the first batch in persistent
-        buffers x2 (only the tensors the KD terms read; attention maps keep their padded rows)"""
+    # The frozen teacher's forward for the batch handed to step() runs on a SIDE stream while the main stream trains the
+    # student on the batch of the previous call (whose teacher outputs are waiting in persistent buffers).  Per batch KIND
+    # (general / region, i.e. per set of input shapes) there are two parities of static buffers - inputs and the teacher
+    # tensors the KD terms read - and, when graphs are on, two teacher hipGraphs (side stream, one memory pool for all of
+    # them) and two student-step hipGraphs (main stream, another pool); on multi-GPU runs the student step stays eager
+    # (RCCL is not capturable here) and only the teacher replays a graph.  A step therefore costs the host two graph
+    # launches, kinds may alternate freely, and optimiser updates are applied in arrival order, one call late.
+    def _pipe_create(self, batch):
+        """state of one batch kind: static buffers x2, two eager warm-up steps (lr 0, optimiser state restored), the
+        persistent teacher-output buffers x2 (only the tensors the KD terms read; attention maps keep their padded rows),
+        the graphs"""
         B = [{k: v.clone() for k, v in batch.items()} for _ in range(2)]
         state = [(g["m"].clone(), g["v"].clone()) for g in self.opt.groups], self.opt.step_count
+        cur = torch.cuda.current_stream()
         self._keep_ST = True
         warm = torch.cuda.Stream()                         # warm-up on a side stream, as torch.cuda.graph asks for
-        warm.wait_stream(torch.cuda.current_stream())
+        warm.wait_stream(cur)
         with torch.cuda.stream(warm):
             for _ in range(2):
                 self.opt.set_schedule(0.0)
                 self._step_eager(B[0])
-        torch.cuda.current_stream().wait_stream(warm)
+        cur.wait_stream(warm)
         self._keep_ST = False
         torch.cuda.synchronize()
         for g, (m, v) in zip(self.opt.groups, state[0]):       # the warm-up steps (lr 0) leave no trace
@@ -237,121 +247,87 @@ class GDTrainer:
                 else:
                     out[d][key][i] = buf
             return out
-        self._pipe = dict(B=B, T=[persist(), persist()], slots=slots, k=0, graphs=[None, None], out=[None, None],
-                          side=torch.cuda.Stream(), pending=False)
+        pipe = dict(B=B, T=[persist(), persist()], slots=slots, par=0, tgraphs=None, sgraphs=None, out=[None, None])
         self._last_ST = None
         del S, T
-        self._pipe_teacher(0, warm)                            # teacher outputs of the first batch
-        torch.cuda.current_stream().wait_stream(warm)
-        torch.cuda.synchronize()
-        if self.use_graph and not self.reducer.active:         # both parities captured now: later calls only replay
-            ops.CACHE.invalidate()
-            pool = None
+        side = self._side
+        if self.use_graph and not os.environ.get("EVLM_NO_TEACHER_GRAPH"):
+            # the frozen teacher's forward holds no collective (skip_task_losses): capturable on multi-GPU runs too
+            side.wait_stream(cur)
+            tg = []
             for k in (0, 1):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
-                    self._pipe["out"][k] = self._pipe_body(k)
-                self._pipe["graphs"][k] = g
-                pool = g.pool()
-        elif self.use_graph and not os.environ.get("EVLM_NO_TEACHER_GRAPH"):
-            # multi-GPU: the student step stays eager (RCCL collectives cannot be captured on this stack), but the frozen
-            # teacher's forward holds no collective (skip_task_losses) - as a hipGraph on the side stream it costs the
-            # host one launch instead of ~400, which keeps the eager student step GPU-bound
-            side, pool, tg = self._pipe["side"], None, []
-            side.wait_stream(torch.cuda.current_stream())
-            for k in (0, 1):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, stream=side):
-                    self._pipe_teacher(k, side)
+                with torch.cuda.graph(g, pool=self._tpool, stream=side):
+                    self._teacher_eager(pipe, k)
                 tg.append(g)
-                pool = g.pool()
-            self._pipe["tgraphs"] = tg
-            self._pipe_teacher(0, side)                        # (capturing executed nothing: keep parity 0's outputs valid)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
+                self._tpool = g.pool()
+            pipe["tgraphs"] = tg
+            cur.wait_stream(side)
+        if self.use_graph and not self.reducer.active:
+            ops.CACHE.invalidate()                             # capture the casts of the trainable weights too
+            sg = []
+            for k in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self._spool):
+                    pipe["out"][k] = self._student_eager(pipe, k)
+                sg.append(g)
+                self._spool = g.pool()
+            pipe["sgraphs"] = sg
+        torch.cuda.synchronize()
+        return pipe
 
-    def _pipe_teacher(self, k, stream):
-        """teacher forward on batch buffer k -> persistent outputs k (runs on `stream`)"""
-        st = self._pipe
-        if st.get("tgraphs") and not torch.cuda.is_current_stream_capturing():
-            with torch.cuda.stream(stream):
-                st["tgraphs"][k].replay()
-            return
-        b = st["B"][k]
-        with torch.cuda.stream(stream), torch.no_grad(), compute(self.dtype):
+    def _teacher_eager(self, pipe, k):
+        """teacher forward on batch buffer k -> persistent outputs k (current stream)"""
+        b = pipe["B"][k]
+        with torch.no_grad(), compute(self.dtype):
             T = self.teacher(b["image"], b["text_ids"], b["text_atts"], **distill.model_kwargs(b))
-            for d, key, i in st["slots"]:
+            for d, key, i in pipe["slots"]:
                 src = T[d][key] if i is None else T[d][key][i]
-                dst = st["T"][k][d][key] if i is None else st["T"][k][d][key][i]
+                dst = pipe["T"][k][d][key] if i is None else pipe["T"][k][d][key][i]
                 sb, db = ops._padded_base(src), ops._padded_base(dst)
                 if sb is not None and db is not None:
                     db.copy_(sb)
                 else:
                     dst.copy_(src)
 
-    def _pipe_body(self, k):
-        """student step on (batch k, teacher outputs k) with the teacher forward of batch 1-k in flight on the side stream"""
-        st = self._pipe
-        cur, side = torch.cuda.current_stream(), st["side"]
-        side.wait_stream(cur)
-        self._pipe_teacher(1 - k, side)
-        out = self._step_eager_no_opt(st["B"][k], st["T"][k])
-        self.opt.step()                       # touches student state only: the teacher may still be running beside it
-        cur.wait_stream(side)
-        return out
-
-    def _step_eager_no_opt(self, batch, teacher_out):
+    def _student_eager(self, pipe, k):
+        """student forward + backward on (batch k, teacher outputs k), gradient reduction, optimiser step"""
         self._early_sent = False
-        out = self._forward_backward(batch, teacher_out)
+        out = self._forward_backward(pipe["B"][k], pipe["T"][k])
         if self.reducer.active:
             self.reducer.reduce_async(self._late if self._early_sent else self.opt.flat_grads)
             self.reducer.finish()
+        self.opt.step()
         return out
 
     def _step_pipelined(self, batch, lr_mult):
-        """General batches flow through the teacher pipeline.  A REGION batch (GeneralDistill.py:158: drawn with
-        probability regions.iter_perc before a general step) keeps the reference's update order: the general batch
-        waiting in the pipeline is trained on first (eagerly, nothing to prefetch), then the region step runs through
-        the unpipelined path, and the next general batch re-primes the pipeline.  Either way a call returns the losses of
-        the batch handed to the PREVIOUS call."""
-        st = self._pipe
-        if "idx_to_group_img" in batch:
-            prev = self._held
-            if st is not None and st["pending"]:
-                self.opt.set_schedule(lr_mult)                 # (advances the bias-correction step count: once per step)
-                prev = self._pipe_drain().clone()
-            self._held = self._step_unpipelined(batch, lr_mult).clone()
-            return prev
-        if st is None:
-            self._pipe_prime(batch)
-            self._pipe["pending"] = True
-            prev, self._held = self._held, None
-            return prev
-        k = st["k"]
-        if not st["pending"]:                                  # re-prime after a region step: teacher only, on buffer k
-            for name, v in batch.items():
-                st["B"][k][name].copy_(v, non_blocking=True)
-            self._pipe_teacher(k, torch.cuda.current_stream())
-            st["pending"] = True
-            prev, self._held = self._held, None
-            return prev
+        """teacher forward of `batch` on the side stream || student step on the batch of the previous call; returns the
+        losses of THAT batch (None on the first call, which only starts the pipeline)"""
+        sig = tuple(sorted((k, tuple(v.shape)) for k, v in batch.items()))
+        pipe = self._pipes.get(sig)
+        if pipe is None:
+            pipe = self._pipes[sig] = self._pipe_create(batch)
+        cur, side = torch.cuda.current_stream(), self._side
+        cur.wait_stream(side)                     # the waiting batch's teacher outputs are complete
+        p = pipe["par"] = 1 - pipe["par"]
         for name, v in batch.items():
-            st["B"][1 - k][name].copy_(v, non_blocking=True)
-        self.opt.set_schedule(lr_mult)
-        if not self.use_graph or self.reducer.active:
-            out = self._pipe_body(k)
-        else:
-            st["graphs"][k].replay()
-            out = st["out"][k]
-        st["k"] = 1 - k
-        return out
-
-    def _pipe_drain(self):
-        """student step on the batch waiting in the pipeline (its teacher outputs are ready), no prefetch"""
-        st = self._pipe
-        out = self._step_eager_no_opt(st["B"][st["k"]], st["T"][st["k"]])
-        self.opt.step()
-        st["pending"] = False
+            pipe["B"][p][name].copy_(v, non_blocking=True)
+        side.wait_stream(cur)                     # inputs copied; every earlier reader of this parity's buffers is done
+        with torch.cuda.stream(side):
+            if pipe["tgraphs"] is not None:
+                pipe["tgraphs"][p].replay()
+            else:
+                self._teacher_eager(pipe, p)
+        out = None
+        if self._pending is not None:
+            pp, pk = self._pending
+            self.opt.set_schedule(lr_mult)
+            if pp["sgraphs"] is not None:
+                pp["sgraphs"][pk].replay()
+                out = pp["out"][pk]
+            else:
+                out = self._student_eager(pp, pk)
+        self._pending = (pipe, p)
         return out
 
     def step(self, batch, lr_mult=1.0):
