@@ -135,7 +135,6 @@ class GDTrainer:
         teacher.eval()
         student.train()
         self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=max_grad_norm)
-        import os
         self.reducer = GradReducer(self.opt.flat_grads, compress=grad_compress,
                                    force=bool(os.environ.get("EVLM_FORCE_REDUCE")))
         self.world = self.reducer.world
@@ -145,7 +144,6 @@ class GDTrainer:
             student.on_vision_grad = self._on_vision_grad      # fires when backward enters the image encoder
         self.use_graph = use_graph
         self.wgrad_inplace = True
-        import os
         if not os.environ.get("EVLM_TEACHER_ALL_MAPS"):
             teacher_map_filter(student, teacher, with_cross=False)
         if hasattr(teacher, "skip_task_losses"):
@@ -340,7 +338,7 @@ class GDTrainer:
     def _step_unpipelined(self, batch, lr_mult):
         if not self.use_graph or self.reducer.active:
             # multi-GPU: the step runs eagerly - RCCL collectives cannot be captured into a hipGraph on this stack
-            # (tools/rccl_graph_probe.py crashes), and the eager step is GPU-bound anyway (same ms/step as the replay).
+            # (a capture probe core-dumped); with pipeline_teacher the teacher half still replays a graph
             self.opt.set_schedule(lr_mult)
             return self._step_eager(batch)
         sig = tuple(sorted((k, tuple(v.shape)) for k, v in batch.items()))     # one hipGraph per batch kind / shape
@@ -388,7 +386,6 @@ class ITRTrainer:
 
     def __init__(self, student, teacher, lr=3e-5, weight_decay=0.01, lr_mult=2.0, reg_learning_rate=0.1,
                  dtype=torch.float32, temperature=1.0):
-        import os
         from .optim import create_L0_optimizer
         self.student, self.teacher = student, teacher
         self.dtype, self.temperature = dtype, temperature
@@ -448,7 +445,6 @@ class VQATrainer:
 
     def __init__(self, student, teacher, lr=5e-5, weight_decay=0.01, lr_mult=2.0, reg_learning_rate=0.1,
                  dtype=torch.float32, temperature=1.0):
-        import os
         from .optim import create_L0_optimizer
         self.student, self.teacher = student, teacher
         self.dtype, self.temperature = dtype, temperature
