@@ -223,6 +223,48 @@ __global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ s, TD*
   }
   if (blockIdx.x == 0) for (int64_t i = (nv << 3) + threadIdx.x; i < n; i += blockDim.x) d[i] = from_f<TD>(to_f(s[i]));
 }
+// ---------------------------------------------------------------------------------------------
+// grouped bf16 transposes: unit u is a row-major [R_u][C_u] matrix copied to [C_u][R_u].  One launch covers every unit
+// (64 x 64 tiles through LDS, both sides move as 16-byte pieces); the descriptor table lives in device memory:
+//   table[5u .. 5u+4] = { src pointer, dst pointer, R, C, index of the unit's first tile }
+// Used for the W^T copies of the trainable weights (dX = dY W then reads a K-contiguous operand like the forward).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_grouped_kernel(const int64_t* __restrict__ table, int n_units) {
+  __shared__ bf16 tile[64][72];                            // 72: rows stay 16-byte aligned, column reads spread over banks
+  int u = 0;
+  while (u + 1 < n_units && (int64_t)blockIdx.x >= table[5 * (u + 1) + 4]) ++u;      // (block-uniform scan)
+  const bf16* src = reinterpret_cast<const bf16*>(table[5 * u]);
+  bf16* dst = reinterpret_cast<bf16*>(table[5 * u + 1]);
+  const int R = (int)table[5 * u + 2], C = (int)table[5 * u + 3];
+  const int t = blockIdx.x - (int)table[5 * u + 4], tc = (C + 63) >> 6;
+  const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+  for (int id = threadIdx.x; id < 64 * 8; id += 256) {     // 64 rows x 8 chunks of 8 columns
+    const int r = id >> 3, c = (id & 7) * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+    if (r0 + r < R && c0 + c < C) v = *reinterpret_cast<const bf16x8*>(src + (size_t)(r0 + r) * C + c0 + c);
+    *reinterpret_cast<bf16x8*>(&tile[r][c]) = v;
+  }
+  __syncthreads();
+  for (int id = threadIdx.x; id < 64 * 8; id += 256) {     // 64 output rows (source columns) x 8 chunks of 8 source rows
+    const int c = id >> 3, r = (id & 7) * 8;
+    if (c0 + c < C && r0 + r < R) {
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[r + e][c];
+      *reinterpret_cast<bf16x8*>(dst + (size_t)(c0 + c) * R + r0 + r) = v;
+    }
+  }
+}
+extern "C" int evlm_transpose_grouped(const int64_t* table, int n_units, int total_tiles, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(table && n_units > 0 && total_tiles > 0, "evlm_transpose_grouped: bad args");
+  hipLaunchKernelGGL(transpose_grouped_kernel, dim3(total_tiles), dim3(256), 0, stream, table, n_units);
+  EVLM_LAUNCH_CHECK("evlm_transpose_grouped");
+  return 0;
+}
+
 extern "C" int evlm_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(src && dst && n > 0, "evlm_cast: bad args");

@@ -34,10 +34,61 @@ class WeightCache:
     def __init__(self):
         self._store = {}
         self._slab = {}         # id(param) -> [fp32 slab, bf16 slab, offset, numel, version, weakref]
+        self._t_units = {}      # (bf16 view pointer, rows, cols) -> (bf16 slab view [N, K], transposed copy [K, N])
+        self._t_table = None    # (device descriptor table, tiles, units) of the grouped transpose launch
+        self._t_keep = []
         self.epoch = 0          # bump to force a re-cast of trainable weights (e.g. before graph capture)
 
     def invalidate(self):
         self.epoch += 1
+
+    # ---- transposed bf16 copies of slab-backed weights (W^T for dX = dY W) --------------------------------------------
+    def get_t(self, params):
+        """[K, sum N_i] bf16 = transpose of the packed bf16 weight of `params`, or None when they are not adjacent members
+        of an optimiser slab.  Created (and filled) on first use, afterwards kept current by refresh_transposed(), which
+        the optimiser calls after every parameter update."""
+        if not self._slab or not params[0].is_cuda:
+            return None
+        src = self._from_slab(params, torch.bfloat16)
+        if src is None or src.dim() != 2 or src.shape[0] % 8 or src.shape[1] % 8:
+            return None
+        key = (src.data_ptr(), src.shape[0], src.shape[1])
+        u = self._t_units.get(key)
+        if u is not None and u[2]() is not params[0]:          # the slab memory was recycled by another model
+            u = None
+        if u is None:
+            import weakref
+            dst = torch.empty((src.shape[1], src.shape[0]), dtype=torch.bfloat16, device=src.device)
+            u = self._t_units[key] = (src, dst, weakref.ref(params[0]))
+            self._t_table = None
+            self._t_keep.append(self._transpose([u])[0])
+        return u[1]
+
+    def _transpose(self, units):
+        rows, tiles = [], 0
+        for src, dst, _ in units:
+            rows += [src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], tiles]
+            tiles += ((src.shape[0] + 63) // 64) * ((src.shape[1] + 63) // 64)
+        table = torch.tensor(rows, dtype=torch.int64).to(units[0][0].device)
+        L.check(_lib().evlm_transpose_grouped(L.ptr(table), len(units), tiles, L.stream()), "transpose_grouped")
+        return table, tiles
+
+    def refresh_transposed(self):
+        """re-derive every W^T copy from the bf16 mirror: ONE grouped launch (capturable: the table is a device tensor)"""
+        if not self._t_units:
+            return
+        if any(u[2]() is None for u in self._t_units.values()):           # models that are gone
+            self._t_units = {k: u for k, u in self._t_units.items() if u[2]() is not None}
+            self._t_table = None
+            if not self._t_units:
+                return
+        if self._t_table is None:
+            units = list(self._t_units.values())
+            self._t_table = self._transpose(units) + (len(units),)
+            self._t_keep.append(self._t_table[0])     # a captured graph may hold an older table: tables are never freed
+            return
+        table, tiles, n = self._t_table
+        L.check(_lib().evlm_transpose_grouped(L.ptr(table), n, tiles, L.stream()), "transpose_grouped")
 
     # ---- optimiser-owned parameter slabs (optim.FlatAdamW): the bf16 mirror is kept current by the AdamW kernel ----
     def register_slab(self, p, slab32, slab16, off):
@@ -47,6 +98,7 @@ class WeightCache:
     def refresh_slab(self, slab32, slab16):
         """re-cast a whole slab (construction; or a parameter was modified outside the optimiser)"""
         L.check(_lib().evlm_cast(L.F32, L.ptr(slab32), L.BF16, L.ptr(slab16), slab32.numel(), L.stream()), "cast")
+        self.refresh_transposed()
         for ent in self._slab.values():
             if ent[0] is slab32:
                 pr = ent[5]()
@@ -380,7 +432,11 @@ class _Linear(torch.autograd.Function):
                 dxb = cast(d32, x2.dtype)
             else:
                 dxb = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
-                _gemm(dtype, d2, W, dxb, M, K, N, ldd, K, K, p_trans=0, q_trans=1)     # dX = dY W
+                Wt = CACHE.get_t(ctx.params[0]) if (dtype == L.BF16 and N % 64 == 0) else None
+                if Wt is not None:      # dX = dY (W^T)^T: both operands K-contiguous, like the forward product
+                    _gemm(dtype, d2, Wt, dxb, M, K, N, ldd, N, K, p_trans=0, q_trans=0)
+                else:
+                    _gemm(dtype, d2, W, dxb, M, K, N, ldd, K, K, p_trans=0, q_trans=1)     # dX = dY W
             dx = dxb.view(xshape)
         weights, biases = ctx.params
         gw, gb = _wgrad(dtype, d2, ldd, x2, ldp, M, K, weights, rows, biases if has_bias else None)   # dW = dY^T X, db
@@ -439,12 +495,18 @@ class _MLP(torch.autograd.Function):
         dev = x2.device
         dh = torch.empty((M, Fh), dtype=x2.dtype, device=dev)
         dgate = None
+        bf = dtype == L.BF16
+        # W^T copies (kept current by the optimiser): the input-gradient products then read K-contiguous operands
+        W2t = CACHE.get_t((ctx.params[2],)) if (bf and N % 64 == 0) else None
+        W1t = CACHE.get_t((ctx.params[0],)) if (bf and Fh % 64 == 0) else None
+        q2 = dict(p_trans=0, q_trans=0) if W2t is not None else dict(p_trans=0, q_trans=1)
+        Q2, ld2 = (W2t, N) if W2t is not None else (W2, Fh)
         if g32 is None:
             # dH = (dY W2) .* act'(h), fused into the GEMM epilogue
-            _gemm(dtype, d2, W2, dh, M, Fh, N, N, Fh, Fh, p_trans=0, q_trans=1, aux=h, ldx=Fh, dact=act)
+            _gemm(dtype, d2, Q2, dh, M, Fh, N, N, ld2, Fh, aux=h, ldx=Fh, dact=act, **q2)
         else:
             da = torch.empty((M, Fh), dtype=x2.dtype, device=dev)
-            _gemm(dtype, d2, W2, da, M, Fh, N, N, Fh, Fh, p_trans=0, q_trans=1)
+            _gemm(dtype, d2, Q2, da, M, Fh, N, N, ld2, Fh, **q2)
             dg = torch.zeros(Fh, dtype=torch.float32, device=dev)
             L.check(lib.evlm_gated_act_bwd(dtype, L.ptr(da), L.ptr(h), L.ptr(g32), M, Fh, Fh, act, gate_pos, L.ptr(dh),
                                            L.ptr(dg), L.stream()), "gated_act_bwd")
@@ -454,7 +516,10 @@ class _MLP(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dxb = torch.empty((M, K), dtype=x2.dtype, device=dev)
-            _gemm(dtype, dh, W1, dxb, M, K, Fh, Fh, K, K, p_trans=0, q_trans=1)
+            if W1t is not None:
+                _gemm(dtype, dh, W1t, dxb, M, K, Fh, Fh, Fh, K, p_trans=0, q_trans=0)
+            else:
+                _gemm(dtype, dh, W1, dxb, M, K, Fh, Fh, K, K, p_trans=0, q_trans=1)
             dx = dxb.view(xshape)
         (dW1,), (db1,) = _wgrad(dtype, dh, Fh, x2, ldp, M, K, (w1,), (Fh,), (b1,))
         return dx, dW1, db1, dW2, db2, dgate, (dy if has_res else None), None, None

@@ -146,6 +146,7 @@ class FlatAdamW:
                                         g["lr"], b1, b2, self.eps, g["weight_decay"], 1.0, 1.0, L.ptr(self.gnorm_sq),
                                         float(self.max_grad_norm or 0.0), L.ptr(g["pb"]), L.ptr(self.hyper), L.stream()), "adamw")
         ops.CACHE.invalidate()
+        ops.CACHE.refresh_transposed()      # W^T copies of the bf16 mirror (one grouped launch; no-op in fp32 runs)
 
     def grad_norm(self):
         return self.gnorm_sq.sqrt()

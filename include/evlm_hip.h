@@ -230,6 +230,11 @@ int evlm_gather_rows_bwd(int dtype, const void* dout, const int64_t* pos, int B,
  * x rows have stride ldx (the CLS-token slice), y is dense [rows,d]; inv_norm [rows] f32 saved for backward. */
 int evlm_l2norm_fwd(int dtype, const void* x, int rows, int d, int ldx, float eps, void* y, float* inv_norm, void* stream);
 int evlm_l2norm_bwd(int dtype, const void* y, const void* dy, const float* inv_norm, int rows, int d, void* dx, void* stream);
+/* Grouped bf16 transposes in one launch: unit u = row-major [R][C] (R, C multiples of 8, 16-byte aligned pointers)
+ * copied to [C][R].  `table` is a DEVICE array of 5 int64 per unit {src, dst, R, C, first tile index}, tiles are 64 x 64,
+ * total_tiles = sum of ceil(R/64)*ceil(C/64).  Keeps W^T copies of the trainable nn.Linear weights current so that the
+ * input gradient of every Linear (grad_input = grad_output @ weight, torch autograd) reads a K-contiguous operand. */
+int evlm_transpose_grouped(const int64_t* table, int n_units, int total_tiles, void* stream);
 /* dst = cast(src) between f32 and bf16; n elements.  (master f32 weights -> bf16 compute copies, grads back) */
 int evlm_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
 /* y[i,j] = a[i,j] * dact(h[i,j]) * gate-aware backward of the gated activations (used when gates are present):

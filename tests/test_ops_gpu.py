@@ -605,3 +605,48 @@ def test_grouped_weight_gradients_match_per_layer_products():
     launch(probs)                                          # single owner per C: load / add / store mode
     for n, (dY, X, Cm, ps) in enumerate(probs):
         assert rel_err(Cm, dY.float().t() @ X.float() + 0.25) < 2e-5, ("C rmw", n)
+
+
+def test_grouped_transposes_and_weight_transposes_follow_the_optimiser():
+    """evlm_transpose_grouped (ragged edge tiles included) and the W^T copies FlatAdamW keeps for dX = dY W"""
+    o = ops()
+    from efficientvlm_amd import _lib as L
+    from efficientvlm_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(61)
+    mats = [rnd((r, c), torch.bfloat16, g) for r, c in ((768, 768), (2304, 768), (72, 136), (8, 200))]
+    outs = [torch.empty((m.shape[1], m.shape[0]), dtype=torch.bfloat16, device=DEV) for m in mats]
+    rows, tiles = [], 0
+    for m, t in zip(mats, outs):
+        rows += [m.data_ptr(), t.data_ptr(), m.shape[0], m.shape[1], tiles]
+        tiles += ((m.shape[0] + 63) // 64) * ((m.shape[1] + 63) // 64)
+    table = torch.tensor(rows, dtype=torch.int64).to(DEV)
+    L.check(L.load().evlm_transpose_grouped(L.ptr(table), len(mats), tiles, L.stream()), "transpose")
+    for m, t in zip(mats, outs):
+        assert torch.equal(t, m.t().contiguous())
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q, self.k, self.v = (torch.nn.Linear(128, 192) for _ in range(3))
+            self.fc = torch.nn.Linear(192, 128)
+    net = Net().to(DEV)
+    opt = FlatAdamW(net, lr=1e-2, weight_decay=0.0, lr_mult=1.0, max_grad_norm=0.0)
+    packed = (net.q.weight, net.k.weight, net.v.weight)
+    for step in range(2):
+        wt = o.CACHE.get_t(packed)
+        assert wt is not None and wt.shape == (128, 576)
+        ref = torch.cat([p.detach() for p in packed], 0).to(torch.bfloat16).t().contiguous()
+        assert torch.equal(wt, ref), step
+        assert torch.equal(o.CACHE.get_t((net.fc.weight,)), net.fc.weight.detach().to(torch.bfloat16).t().contiguous())
+        x = rnd((64, 128), torch.bfloat16, g).requires_grad_(True)
+        opt.zero_grad()
+        o.WGRAD_INPLACE = True
+        try:
+            y = o.linear(o.linear_packed(x, packed, (net.q.bias, net.k.bias, net.v.bias))[..., :192], net.fc.weight, net.fc.bias)
+            y.float().square().mean().backward()
+        finally:
+            o.WGRAD_INPLACE = False
+        W = torch.cat([p.detach() for p in packed], 0).to(torch.bfloat16).float()
+        assert x.grad is not None and torch.isfinite(x.grad.float()).all()
+        opt.set_schedule(1.0)
+        opt.step()                       # parameters move -> the copies must follow
