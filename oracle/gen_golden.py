@@ -732,6 +732,40 @@ def gen_ckpt_remap(seed):
     return fx
 
 
+def gen_vqa_remap(seed):
+    """EffXVLMForVQA.load_pretrained (efficient_models/model_generation.py:57-96, non-eval): a GD-style pre-training checkpoint
+    (text encoder under `text_encoder.bert.*`) loaded into the VQA student - its text layers feed the question encoder,
+    its fusion layers are MOVED into the answer decoder (layer indices re-based).  Records, per parameter of the VQA model,
+    the (sum, abs-sum) checksum after loading and which keys kept their construction-time value."""
+    geom = synth.GEOMS["tiny"]
+    work = tempfile.mkdtemp(prefix="evlm_oracle_")
+    os.chdir(work)
+    scfg, _ = write_configs(work, geom)
+    scfg.update(pad_token_id=0, num_dec_layers=geom["s_text_layers"] - geom["s_text_layers"] // 2)
+    sys.modules["dataset"] = types.ModuleType("dataset")
+    sys.modules["dataset"].build_tokenizer = lambda *a, **k: None
+    from efficient_models.model_generation import EffXVLMForVQA
+    from models.model_pretrain import XVLM
+    FAKE.num_pos = (geom["image_res"] // 16) ** 2 + 1
+    FAKE.width = geom["hidden"]
+    torch.manual_seed(seed)
+    pre = XVLM(scfg)
+    ck = det_state_dict(pre.state_dict(), seed=7000 + seed, std=geom["std"])
+    path = os.path.join(work, "pretrain.th")
+    torch.save({"model": ck}, path)
+    vqa = EffXVLMForVQA(scfg)
+    vqa.load_state_dict(det_state_dict(vqa.state_dict(), seed=8000 + seed, std=geom["std"]), strict=True)
+    before = {k: v.clone() for k, v in vqa.state_dict().items()}
+    vqa.load_pretrained(path, scfg, is_eval=False)
+    fx = {"meta.seed": np.array(seed)}
+    for n, (a, b) in checksums(vqa.state_dict()).items():
+        fx[f"after.{n}"] = np.array([a, b])
+    fx["untouched"] = np.array(sorted(k for k, v in vqa.state_dict().items()
+                                      if torch.is_floating_point(v) and torch.equal(v, before[k])))
+    fx["ckpt_keys"] = np.array(sorted(ck.keys()))
+    return fx
+
+
 def save(name, fx):
     os.makedirs(OUT, exist_ok=True)
     p = os.path.join(OUT, name)
@@ -749,7 +783,7 @@ if __name__ == "__main__":
     dist.init_process_group("gloo", rank=0, world_size=1)
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["kd", "l0", "gd_tiny", "itr_tiny", "gd_full", "optim", "ckpt", "gd_region_tiny",
-                              "gd_region_full", "vqa_tiny"]
+                              "gd_region_full", "vqa_tiny", "vqa_remap"]
     if "ckpt" in which:
         save("ckpt_remap.npz", gen_ckpt_remap(13))
     if "optim" in which:
@@ -767,6 +801,8 @@ if __name__ == "__main__":
         save("itr_tiny.npz", gen_itr("tiny", B=4, seed=4))
     if "gd_full" in which:
         save("gd_full.npz", gen_gd("full", B=2, seed=2, full=False))
+    if "vqa_remap" in which:
+        save("vqa_remap.npz", gen_vqa_remap(17))
     if "vqa_tiny" in which:
         save("vqa_tiny.npz", gen_vqa("tiny", B=3, seed=12))
     if "gd_region_tiny" in which:

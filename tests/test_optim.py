@@ -171,3 +171,41 @@ def test_checkpoint_load_and_remap_match_the_reference_loader(tmp_path):
     assert np.allclose(up.numpy(), fx["interp.up6"], rtol=1e-6, atol=1e-7)
     same = interpolate_pos_embed(out["vision_encoder.pos_embed.weight"][None], num_patches=9, num_extra_tokens=1)
     assert np.array_equal(same.numpy(), fx["interp.same"])
+
+
+def test_vqa_checkpoint_remap_matches_the_reference_loader(tmp_path):
+    """EffXVLMForVQA.load_pretrained (efficient_models/model_generation.py:57-96): a GD pre-training checkpoint loaded into the
+    VQA student - text-encoder tensors lose their `bert.` prefix, the fusion layers are additionally MOVED into the answer
+    decoder with re-based layer indices.  Per-parameter checksums after loading, and the set of parameters the checkpoint
+    leaves untouched, against what the reference's own loader produced (tests/golden/vqa_remap.npz)."""
+    import numpy as np
+    from helpers import load_fixture, model_config
+    from oracle import schema, synth
+    from oracle import xvlm_oracle as O
+    from oracle.detinit import checksums
+    from efficientvlm_amd.efficient_models.model_generation import EffXVLMForVQA
+    fx = load_fixture("vqa_remap.npz")
+    seed = int(fx["meta.seed"])
+    geom = synth.GEOMS["tiny"]
+    s_cfg = O.model_cfg(geom, "s")
+    ck = schema.det_weights(schema.xvlm_schema(s_cfg, geom["max_pos"]), 7000 + seed, geom["std"])
+    ck["vision_encoder.position_ids"] = torch.arange((geom["image_res"] // 16) ** 2 + 1)[None]
+    ck["text_encoder.bert.embeddings.position_ids"] = torch.arange(geom["max_pos"])[None]
+    assert sorted(ck.keys()) == list(fx["ckpt_keys"])
+    path = str(tmp_path / "pretrain.th")
+    torch.save({"model": ck}, path)
+    cfg = dict(model_config(geom, "s"), pad_token_id=0, num_dec_layers=s_cfg["text_layers"] - s_cfg["fusion_layer"])
+    vqa = EffXVLMForVQA(cfg)
+    init = schema.det_weights(schema.vqa_schema(s_cfg, geom["max_pos"], l0=True), 8000 + seed, geom["std"])
+    full = {k: init.get(k, v) for k, v in vqa.state_dict().items()}
+    vqa.load_state_dict(full, strict=True)
+    before = {k: v.clone() for k, v in vqa.state_dict().items()}
+    vqa.load_pretrained(path, cfg, is_eval=False)
+    after = vqa.state_dict()
+    got = checksums({k: v for k, v in after.items() if torch.is_floating_point(v)})
+    want = {k[len("after."):]: v for k, v in fx.items() if k.startswith("after.")}
+    assert set(got) == {k for k in want if k in got} and len(got) > 150
+    for k, (a, b) in got.items():
+        np.testing.assert_allclose([a, b], want[k], rtol=1e-9, atol=1e-9, err_msg=k)
+    untouched = sorted(k for k, v in after.items() if torch.is_floating_point(v) and torch.equal(v, before[k]))
+    assert untouched == list(fx["untouched"])
