@@ -376,6 +376,60 @@ class GDTrainer:
         return graph, static, out
 
 
+class TeacherPrefetch:
+    """The frozen teacher's forward, one batch ahead of its consumer, on a side stream.  submit(batch) copies the batch
+    into a static buffer, starts the teacher on it and returns (static batch, teacher outputs) of the PREVIOUS submit
+    (None the first time); the caller trains the student on that pair while the new teacher forward shares the chip.
+    With graphs on, each parity of each batch shape replays its own hipGraph from its OWN memory pool: a graph's output
+    tensors then stay valid until that same graph is replayed two submits later - exactly as long as they are needed -
+    so nothing is copied."""
+
+    def __init__(self, run_teacher, use_graph=True):
+        self.run_teacher = run_teacher          # fn(batch dict) -> teacher outputs (any nest of tensors)
+        self.use_graph = use_graph
+        self.side = torch.cuda.Stream()
+        self.states, self.pending = {}, None
+
+    def _create(self, batch):
+        cur = torch.cuda.current_stream()
+        st = dict(B=[{k: v.clone() for k, v in batch.items()} for _ in range(2)], T=[None, None], graphs=None, par=0)
+        if self.use_graph:
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                self.run_teacher(st["B"][0])                   # warm-up: allocator, cached weight casts
+            torch.cuda.synchronize()
+            st["graphs"] = []
+            for k in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.side):    # (no shared pool: see the class docstring)
+                    st["T"][k] = self.run_teacher(st["B"][k])
+                st["graphs"].append(g)
+            torch.cuda.synchronize()
+        return st
+
+    def submit(self, batch):
+        batch = {k: v for k, v in batch.items() if torch.is_tensor(v)}
+        sig = tuple(sorted((k, tuple(v.shape)) for k, v in batch.items()))
+        st = self.states.get(sig)
+        if st is None:
+            st = self.states[sig] = self._create(batch)
+        cur, side = torch.cuda.current_stream(), self.side
+        cur.wait_stream(side)                     # the waiting batch's teacher outputs are complete
+        p = st["par"] = 1 - st["par"]
+        for name, v in batch.items():
+            st["B"][p][name].copy_(v, non_blocking=True)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            if st["graphs"] is not None:
+                st["graphs"][p].replay()
+            else:
+                st["T"][p] = self.run_teacher(st["B"][p])
+                for t in distill._tensors(st["T"][p]):     # allocated on the side stream, consumed on the main one
+                    t.record_stream(cur)
+        prev, self.pending = self.pending, (st, p)
+        return None if prev is None else (prev[0]["B"][prev[1]], prev[0]["T"][prev[1]])
+
+
 class ITRTrainer:
     """Pruning fine-tune step of Eff_Retrieval.py:75-213 (image-text retrieval with hard-concrete L0 gates): student with
     gates forward + backward, teacher forward, ITC + ITM + hidden / attention / cross-attention / logit KD, the Lagrangian
@@ -385,7 +439,9 @@ class ITRTrainer:
     Lagrangian warm-up makes the step depend on a host-side counter."""
 
     def __init__(self, student, teacher, lr=3e-5, weight_decay=0.01, lr_mult=2.0, reg_learning_rate=0.1,
-                 dtype=torch.float32, temperature=1.0):
+                 dtype=torch.float32, temperature=1.0, pipeline_teacher=False, use_graph=True):
+        """pipeline_teacher: as in GDTrainer - the frozen teacher runs one batch ahead (TeacherPrefetch: hipGraph on a side
+        stream) and step() returns the losses of the batch of the PREVIOUS call (None on the first)."""
         from .optim import create_L0_optimizer
         self.student, self.teacher = student, teacher
         self.dtype, self.temperature = dtype, temperature
@@ -401,18 +457,34 @@ class ITRTrainer:
         if not os.environ.get("EVLM_TEACHER_ALL_MAPS"):
             teacher_map_filter(student, teacher, with_cross=True)
         self.global_step = 0
+        self.prefetch = TeacherPrefetch(self._teacher_forward, use_graph) if pipeline_teacher else None
+
+    def _teacher_forward(self, b):
+        with torch.no_grad(), compute(self.dtype):
+            return self.teacher(b["image"], b["text_ids"], b["text_atts"], idx=b.get("idx"), output_attentions=True,
+                                output_hidden_states=True)
 
     def step(self, batch, idx=None, lr_mult=1.0):
         """batch: dict(image, text_ids, text_atts); idx: image ids for the soft ITC labels.  Returns a device tensor
         [total, itc, itm, kd, lagrangian]."""
+        T_ready = None
+        if self.prefetch is not None:
+            prev = self.prefetch.submit(dict(batch, idx=idx) if idx is not None else dict(batch))
+            if prev is None:
+                return None
+            batch, T_ready = prev
+            idx = batch.get("idx")
         self.opt.zero_grad()
         l0 = self.student.l0_module
         with compute(self.dtype):
             kw = dict(idx=idx, output_attentions=True, output_hidden_states=True)
-            S, T = distill.student_and_teacher(
-                lambda: self.student(batch["image"], batch["text_ids"], batch["text_atts"], **kw),
-                lambda: self.teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw),
-                batch["image"], self.overlap_teacher)
+            if T_ready is not None:
+                S, T = self.student(batch["image"], batch["text_ids"], batch["text_atts"], **kw), T_ready
+            else:
+                S, T = distill.student_and_teacher(
+                    lambda: self.student(batch["image"], batch["text_ids"], batch["text_atts"], **kw),
+                    lambda: self.teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw),
+                    batch["image"], self.overlap_teacher)
             kd = distill.kd_terms(S, T, self.temperature, with_cross_attn=True)
             lagrangian, _, _ = l0.lagrangian_regularization(self.global_step)
             total, mix = distill.itr_loss_mix(S["loss"], kd, lagrangian)
@@ -444,7 +516,7 @@ class VQATrainer:
     rows varies from batch to batch)."""
 
     def __init__(self, student, teacher, lr=5e-5, weight_decay=0.01, lr_mult=2.0, reg_learning_rate=0.1,
-                 dtype=torch.float32, temperature=1.0):
+                 dtype=torch.float32, temperature=1.0, pipeline_teacher=False, use_graph=True):
         from .optim import create_L0_optimizer
         self.student, self.teacher = student, teacher
         self.dtype, self.temperature = dtype, temperature
@@ -458,20 +530,38 @@ class VQATrainer:
         self.defer_wgrad = dtype == torch.bfloat16 and not os.environ.get("EVLM_NO_DEFER_WGRAD")
         self.overlap_teacher = not os.environ.get("EVLM_NO_OVERLAP_TEACHER")
         self.global_step = 0
+        self.prefetch = TeacherPrefetch(self._teacher_forward, use_graph) if pipeline_teacher else None
+
+    def _teacher_forward(self, b):
+        from types import SimpleNamespace as NS
+        with torch.no_grad(), compute(self.dtype):
+            return self.teacher(b["image"], NS(input_ids=b["question_ids"], attention_mask=b["question_atts"]),
+                                NS(input_ids=b["answer_ids"], attention_mask=b["answer_atts"]), train=True, k=b["k"],
+                                weights=b["weights"], output_attentions=True, output_hidden_states=True)
 
     def step(self, batch, lr_mult=1.0, stop_prune=False):
         """batch: dict(image [B], question_ids / question_atts [B, Lq], answer_ids / answer_atts [sum k, La], k [B] (tensor
         or list), weights [sum k]).  Returns a device tensor [total, answer loss, kd, lagrangian]."""
         from types import SimpleNamespace as NS
+        T_ready = None
+        if self.prefetch is not None:
+            batch = dict(batch, k=torch.as_tensor(batch["k"], device=batch["image"].device))
+            prev = self.prefetch.submit(batch)
+            if prev is None:
+                return None
+            batch, T_ready = prev
         self.opt.zero_grad()
         l0 = self.student.l0_module
         question = NS(input_ids=batch["question_ids"], attention_mask=batch["question_atts"])
         answer = NS(input_ids=batch["answer_ids"], attention_mask=batch["answer_atts"])
         kw = dict(train=True, k=batch["k"], weights=batch["weights"], output_attentions=True, output_hidden_states=True)
         with compute(self.dtype):
-            S, T = distill.student_and_teacher(
-                lambda: self.student(batch["image"], question, answer, stop_prune=stop_prune, **kw),
-                lambda: self.teacher(batch["image"], question, answer, **kw), batch["image"], self.overlap_teacher)
+            if T_ready is not None:
+                S, T = self.student(batch["image"], question, answer, stop_prune=stop_prune, **kw), T_ready
+            else:
+                S, T = distill.student_and_teacher(
+                    lambda: self.student(batch["image"], question, answer, stop_prune=stop_prune, **kw),
+                    lambda: self.teacher(batch["image"], question, answer, **kw), batch["image"], self.overlap_teacher)
             kd = distill.vqa_kd_terms(S, T, self.temperature)
             lagrangian, _, _ = l0.lagrangian_regularization(self.global_step)
             total, mix = distill.vqa_loss_mix(S["loss"], kd, lagrangian)

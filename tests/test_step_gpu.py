@@ -656,3 +656,55 @@ def test_vqa_training_steps_bf16_track_the_fp32_oracle():
     assert torch.isfinite(got1).all()
     la = student.l0_module.decoder_int_loga.detach()
     assert float((la - loga0.to(DEV)).abs().max()) > 0 and float(la.min()) >= math.log(1e-2) - 1e-6 and float(la.max()) <= math.log(1e2) + 1e-6
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_itr_trainer_with_pipelined_teacher_reproduces_the_unpipelined_trajectory(use_graph, monkeypatch):
+    """ITRTrainer(pipeline_teacher=True): the frozen teacher runs one batch ahead on a side stream (TeacherPrefetch; a
+    hipGraph per parity whose outputs are consumed in place).  Same gate noise and (deterministic) hard negatives on both
+    sides: the loss trajectory over three distinct batches equals the unpipelined trainer's, one call later."""
+    from efficientvlm_amd.efficient_models.model_retrieval import EffXVLMforRetrieval
+    from efficientvlm_amd.efficient_models.xvlm import XVLMBase
+    from efficientvlm_amd.models.model_retrieval import XVLM as TeacherITR
+    from efficientvlm_amd.trainer import ITRTrainer
+
+    def fixed_negatives(self, image_feat, text_feat, idx):
+        bs = image_feat.size(0)
+        ar = torch.arange(bs, device=image_feat.device)
+        return (ar + 1) % bs, (ar + 2) % bs
+    monkeypatch.setattr(XVLMBase, "_sample_negatives", fixed_negatives)
+    geom = synth.GEOMS["tiny"]
+    s_cfg, t_cfg = O.model_cfg(geom, "s"), O.model_cfg(geom, "t")
+    B = 4
+    batches = [{k: v.to(DEV) for k, v in synth.make_batch(geom, B, seed=30 + i, ragged=True).items()
+                if k in ("image", "text_ids", "text_atts")} for i in range(3)]
+    idx = torch.arange(B, device=DEV)
+    outs = {}
+    for pipe in (False, True):
+        student, teacher = EffXVLMforRetrieval(model_config(geom, "s")), TeacherITR(model_config(geom, "t"))
+        load_det_weights(student, schema.xvlm_schema(s_cfg, geom["max_pos"], mlm=False, bbox=False, l0=True), 51, geom["std"])
+        load_det_weights(teacher, schema.xvlm_schema(t_cfg, geom["max_pos"], mlm=False, bbox=False), 52, geom["std"])
+        gen = torch.Generator().manual_seed(8)
+        with torch.no_grad():
+            for n, p in student.l0_module.named_parameters():
+                p.copy_(torch.full_like(p, 0.3) if "lambda" in n else torch.randn(p.shape, generator=gen) + 0.5)
+        student.l0_module.set_lagrangian_warmup_steps(10)
+        student.to(DEV); teacher.to(DEV)
+        eps = [{t: torch.rand(getattr(student.l0_module, O.L0_PARAM[t]).shape, generator=gen).clamp(1e-6, 1 - 1e-6)
+                for t in O.L0_TYPES} for _ in range(3)]
+        tr = ITRTrainer(student, teacher, lr=1e-3, reg_learning_rate=0.05, dtype=torch.float32, pipeline_teacher=pipe,
+                        use_graph=use_graph)
+        seq = []
+        calls = batches + ([batches[0]] if pipe else [])
+        for c, b in enumerate(calls):
+            i = c - 1 if pipe else c                        # index of the batch whose student step runs in this call
+            if i >= 0:
+                student.l0_module.injected_eps = {t: e.clone() for t, e in eps[i].items()}
+            o = tr.step(b, idx=idx)
+            assert (o is None) == (pipe and c == 0)
+            if o is not None:
+                seq.append(o.clone())
+        torch.cuda.synchronize()
+        outs[pipe] = torch.stack(seq).cpu()
+    assert torch.allclose(outs[True], outs[False], rtol=5e-4, atol=1e-5), (outs[True], outs[False])
+    assert float((outs[False][0] - outs[False][2]).abs().max()) > 1e-3

@@ -22,7 +22,9 @@ cfg = lambda role, nd: dict(model_config(geom, role, image_res=res), pad_token_i
 student = EffXVLMForVQA(cfg("s", 3)).to(dev)
 teacher = XVLMForVQA(cfg("t", 6)).to(dev)
 student.l0_module.set_lagrangian_warmup_steps(100)
-tr = VQATrainer(student, teacher, lr=5e-5, weight_decay=0.01, lr_mult=2, reg_learning_rate=0.1, dtype=torch.bfloat16)
+pipe = not os.environ.get("EVLM_NO_PIPELINE")
+tr = VQATrainer(student, teacher, lr=5e-5, weight_decay=0.01, lr_mult=2, reg_learning_rate=0.1, dtype=torch.bfloat16,
+                pipeline_teacher=pipe)
 batch = synth.make_vqa_batch(geom, B, seed=5, La=8)
 batch["k"] = torch.full((B,), 4, dtype=torch.long)                 # 4 answers per question
 n = 4 * B
@@ -35,6 +37,6 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 K = 8
 for _ in range(K): out = tr.step(batch)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
-print(json.dumps({"workload": "VQA pruning fine-tune step", "image_res": res, "batch": B, "answers": n,
+print(json.dumps({"workload": "VQA pruning fine-tune step", "teacher_pipelined": pipe, "image_res": res, "batch": B, "answers": n,
                   "ms_per_step": round(dt * 1e3, 2), "questions_per_s": round(B / dt, 1),
                   "losses[total,answer,kd,lagrangian]": [round(float(x), 4) for x in out.tolist()]}))
