@@ -255,7 +255,8 @@ class GDTrainer:
             tg = []
             for k in (0, 1):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self._tpool, stream=side):
+                # (thread_local: on multi-GPU runs the RCCL watchdog thread may query events while this captures)
+                with torch.cuda.graph(g, pool=self._tpool, stream=side, capture_error_mode="thread_local"):
                     self._teacher_eager(pipe, k)
                 tg.append(g)
                 self._tpool = g.pool()
@@ -401,7 +402,7 @@ class TeacherPrefetch:
             st["graphs"] = []
             for k in (0, 1):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.side):    # (no shared pool: see the class docstring)
+                with torch.cuda.graph(g, stream=self.side, capture_error_mode="thread_local"):    # (no shared pool: see the class docstring)
                     st["T"][k] = self.run_teacher(st["B"][k])
                 st["graphs"].append(g)
             torch.cuda.synchronize()
