@@ -253,14 +253,23 @@ class GDTrainer:
             # the frozen teacher's forward holds no collective (skip_task_losses): capturable on multi-GPU runs too
             side.wait_stream(cur)
             tg = []
-            for k in (0, 1):
-                g = torch.cuda.CUDAGraph()
-                # (thread_local: on multi-GPU runs the RCCL watchdog thread may query events while this captures)
-                with torch.cuda.graph(g, pool=self._tpool, stream=side, capture_error_mode="thread_local"):
-                    self._teacher_eager(pipe, k)
-                tg.append(g)
-                self._tpool = g.pool()
-            pipe["tgraphs"] = tg
+            try:
+                for k in (0, 1):
+                    g = torch.cuda.CUDAGraph()
+                    # (thread_local: on multi-GPU runs the RCCL watchdog thread may query events while this captures)
+                    with torch.cuda.graph(g, pool=self._tpool, stream=side, capture_error_mode="thread_local"):
+                        self._teacher_eager(pipe, k)
+                    tg.append(g)
+                    self._tpool = g.pool()
+                pipe["tgraphs"] = tg
+            except RuntimeError as e:        # same kernels, launched one by one: slower on the host, never wrong
+                if not self.reducer.active:
+                    raise
+                import sys
+                print(f"[efficientvlm_amd] teacher hipGraph capture failed on the multi-GPU path ({e}); "
+                      "the teacher forward stays eager", file=sys.stderr)
+                pipe["tgraphs"] = None
+                torch.cuda.synchronize()
             cur.wait_stream(side)
         if self.use_graph and not self.reducer.active:
             ops.CACHE.invalidate()                             # capture the casts of the trainable weights too
