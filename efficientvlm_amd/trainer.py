@@ -157,6 +157,7 @@ class GDTrainer:
         self._pipes, self._pending = {}, None
         self._side = torch.cuda.Stream() if next(student.parameters()).is_cuda else None
         self._tpool = self._spool = None
+        self._joint = {}
         if self.world > 1:
             for g in self.opt.groups:                     # broadcast params from rank 0 (apex_ddp_accelerator.py:75-77)
                 dist.broadcast(g["p"], 0)
@@ -249,7 +250,7 @@ class GDTrainer:
         self._last_ST = None
         del S, T
         side = self._side
-        if self.use_graph and not os.environ.get("EVLM_NO_TEACHER_GRAPH"):
+        if self.use_graph and self.reducer.active and not os.environ.get("EVLM_NO_TEACHER_GRAPH"):
             # the frozen teacher's forward holds no collective (skip_task_losses): capturable on multi-GPU runs too
             side.wait_stream(cur)
             tg = []
@@ -271,16 +272,6 @@ class GDTrainer:
                 pipe["tgraphs"] = None
                 torch.cuda.synchronize()
             cur.wait_stream(side)
-        if self.use_graph and not self.reducer.active:
-            ops.CACHE.invalidate()                             # capture the casts of the trainable weights too
-            sg = []
-            for k in (0, 1):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self._spool):
-                    pipe["out"][k] = self._student_eager(pipe, k)
-                sg.append(g)
-                self._spool = g.pool()
-            pipe["sgraphs"] = sg
         torch.cuda.synchronize()
         return pipe
 
@@ -320,22 +311,46 @@ class GDTrainer:
         p = pipe["par"] = 1 - pipe["par"]
         for name, v in batch.items():
             pipe["B"][p][name].copy_(v, non_blocking=True)
-        side.wait_stream(cur)                     # inputs copied; every earlier reader of this parity's buffers is done
-        with torch.cuda.stream(side):
-            if pipe["tgraphs"] is not None:
-                pipe["tgraphs"][p].replay()
-            else:
-                self._teacher_eager(pipe, p)
         out = None
-        if self._pending is not None:
+        if self.use_graph and not self.reducer.active and self._pending is not None:
+            # single GPU: ONE hipGraph per (waiting batch, new batch) combination holds both halves - the teacher forward
+            # of the new batch forked onto the side stream, the student step of the waiting batch on the capture stream,
+            # joined at the end.  (Two separately launched graphs - one per stream - ran 1.5 % faster but aborted with a
+            # hardware exception in ~15 % of runs on this stack; eager launches beside a graph do not.)
             pp, pk = self._pending
             self.opt.set_schedule(lr_mult)
-            if pp["sgraphs"] is not None:
-                pp["sgraphs"][pk].replay()
-                out = pp["out"][pk]
-            else:
+            key = (id(pipe), p, id(pp), pk)
+            jg = self._joint.get(key)
+            if jg is None:
+                ops.CACHE.invalidate()                             # capture the casts of the trainable weights too
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self._spool):
+                    res = self._joint_body(pipe, p, pp, pk)
+                self._spool = g.pool()
+                jg = self._joint[key] = (g, res)
+            jg[0].replay()
+            out = jg[1]
+        else:
+            side.wait_stream(cur)                 # inputs copied; every earlier reader of this parity's buffers is done
+            with torch.cuda.stream(side):
+                if pipe["tgraphs"] is not None:
+                    pipe["tgraphs"][p].replay()
+                else:
+                    self._teacher_eager(pipe, p)
+            if self._pending is not None:
+                pp, pk = self._pending
+                self.opt.set_schedule(lr_mult)
                 out = self._student_eager(pp, pk)
         self._pending = (pipe, p)
+        return out
+
+    def _joint_body(self, pipe, p, pp, pk):
+        cur, side = torch.cuda.current_stream(), self._side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._teacher_eager(pipe, p)
+        out = self._student_eager(pp, pk)
+        cur.wait_stream(side)
         return out
 
     def step(self, batch, lr_mult=1.0):
