@@ -205,10 +205,10 @@ class GDTrainer:
     # The frozen teacher's forward for the batch handed to step() runs on a SIDE stream while the main stream trains the
     # student on the batch of the previous call (whose teacher outputs are waiting in persistent buffers).  Per batch KIND
     # (general / region, i.e. per set of input shapes) there are two parities of static buffers - inputs and the teacher
-    # tensors the KD terms read - and, when graphs are on, two teacher hipGraphs (side stream, one memory pool for all of
-    # them) and two student-step hipGraphs (main stream, another pool); on multi-GPU runs the student step stays eager
-    # (RCCL is not capturable here) and only the teacher replays a graph.  A step therefore costs the host two graph
-    # launches, kinds may alternate freely, and optimiser updates are applied in arrival order, one call late.
+    # tensors the KD terms read.  Single GPU with graphs: ONE hipGraph per (waiting batch, new batch) combination holds
+    # both halves (teacher forked onto the side stream, joined at the end), captured lazily into one memory pool.
+    # Multi-GPU: the student step stays eager (RCCL is not capturable here) and only the teacher replays a graph.  Kinds
+    # may alternate freely; optimiser updates are applied in arrival order, one call late.
     def _pipe_create(self, batch):
         """state of one batch kind: static buffers x2, two eager warm-up steps (lr 0, optimiser state restored), the
         persistent teacher-output buffers x2 (only the tensors the KD terms read; attention maps keep their padded rows),
