@@ -246,7 +246,7 @@ class GDTrainer:
                 else:
                     out[d][key][i] = buf
             return out
-        pipe = dict(B=B, T=[persist(), persist()], slots=slots, par=0, tgraphs=None, sgraphs=None, out=[None, None])
+        pipe = dict(B=B, T=[persist(), persist()], slots=slots, par=0, tgraphs=None)
         self._last_ST = None
         del S, T
         side = self._side
