@@ -15,4 +15,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf -o pf -- python3 bench.py -
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pw -o pw -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $OUT/pw.log 2>&1
 python3 tools/pmc_traffic.py $OUT/pf/pf_results.db $OUT/pw/pw_results.db $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1
 rm -rf $OUT/pf $OUT/pw
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pm -o pm -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $OUT/pm.log 2>&1
+python3 tools/pmc_mfma.py $OUT/pm/pm_results.db $OUT/pmc_mfma.json > $OUT/pmc_mfma.txt 2>&1
+rm -rf $OUT/pm
 ls -la $OUT
