@@ -15,13 +15,22 @@ the same batch inside each step.
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     - the dominant kernel (the bf16 MFMA GEMM kernel with the largest share of the step): algorithmic FLOPs per
                  launch / its average launch duration, timed live with HIP events on the launch stream during one extra
-                 instrumented step;
+                 instrumented step (run by EVERY rank: the step holds collectives); `traffic` is the HBM byte count per
+                 launch from the committed rocprofv3 PMC pass of this command, stamped with the commit it was taken at;
+  executed     - FLOPs the step actually executes (every GEMM launch 2IJK + the attention cores), counted in that same
+                 instrumented step: `step_mfma_frac` is computed from THESE, not from the reference's 161.4 GF / pair
+                 (cross-attention K/V are projected once per image and shared: the skipped FLOPs are stated);
+  oracle_check - losses of one batch-64 step of the benchmarked configuration (bf16, hipGraph, pipelined teacher) against
+                 oracle/ (fp32, CPU) on the same weights, batch and hard negatives;
   cpu_baseline - oracle/ (the CPU restatement of the reference) timed on this box's host cores on a bounded sample.
+Only the last two legs touch oracle/ (checker and reported baseline; never the thing measured).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -29,23 +38,32 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-FLOPS_PER_PAIR = 161.4e9         # 3 x student fwd (32.41 GF) + teacher fwd (64.20 GF)
+REF_FLOPS_PER_PAIR = 161.4e9     # 3 x student fwd (32.41 GF) + teacher fwd (64.20 GF), reference op list
+SEED = 1234
 
 
 def build(geom, dev, seed):
-    from helpers import model_config
     from efficientvlm_amd.models.model_pretrain import XVLM
+    from efficientvlm_amd.workload import model_config
     torch.manual_seed(seed)
     student = XVLM(model_config(geom, "s")).to(dev)
     teacher = XVLM(model_config(geom, "t")).to(dev)
     return student, teacher
 
 
+def make_trainer(student, teacher, dtype, use_graph, pipelined):
+    from efficientvlm_amd.trainer import GDTrainer
+    return GDTrainer(student, teacher, lr=1e-4, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=dtype,
+                     use_graph=use_graph, pipeline_teacher=pipelined)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU legs (child processes that never touch the GPU): the reported CPU baseline and the oracle side of the loss check
+# ---------------------------------------------------------------------------------------------------------------------
 def _cpu_threads():
-    """threads the CPU baseline may use: the cores this process is actually allowed on, capped at 32 (an oversubscribed
+    """threads the CPU legs may use: the cores this process is actually allowed on, capped at 32 (an oversubscribed
     torch thread pool on a quota-limited container is slower than a few threads)"""
     try:
         n = len(os.sched_getaffinity(0))
@@ -54,78 +72,187 @@ def _cpu_threads():
     return max(1, min(n, 32))
 
 
-def cpu_baseline_child(B=2, budget_s=25.0):
-    """oracle (kind='port') GD step, fp32, on the host cores; runs in a CHILD process (never touches the GPU) so the
-    parent can bound it with a timeout.  Prints one JSON object."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _oracle_state(seed_s, seed_t):
     from oracle import schema, synth
     from oracle import xvlm_oracle as O
     geom = synth.GEOMS["full"]
+    s_cfg, t_cfg = O.model_cfg(geom, "s"), O.model_cfg(geom, "t")
+    s_sd = schema.det_weights(schema.xvlm_schema(s_cfg, geom["max_pos"]), seed_s, geom["std"])
+    t_sd = schema.det_weights(schema.xvlm_schema(t_cfg, geom["max_pos"]), seed_t, geom["std"])
+    return geom, s_cfg, t_cfg, s_sd, t_sd
+
+
+def _tie(sd):
+    sd = dict(sd)
+    sd["text_encoder.cls.predictions.decoder.weight"] = sd["text_encoder.bert.embeddings.word_embeddings.weight"]
+    sd["text_encoder.cls.predictions.decoder.bias"] = sd["text_encoder.cls.predictions.bias"]
+    return sd
+
+
+def cpu_baseline_child(budget_s=30.0):
+    """oracle (kind='port') GD step, fp32, on the host cores: BASELINE.json configs[0] (batch 4), 3 warm-up + 5 timed steps
+    (SURVEY.md §8d), then batch 16 while the time budget lasts.  Prints one JSON object."""
+    from oracle import synth
+    from oracle import xvlm_oracle as O
     nthreads = _cpu_threads()
     torch.set_num_threads(nthreads)
-    s_cfg, t_cfg = O.model_cfg(geom, "s"), O.model_cfg(geom, "t")
-    s_sd = schema.det_weights(schema.xvlm_schema(s_cfg, geom["max_pos"]), 1, geom["std"])
-    t_sd = schema.det_weights(schema.xvlm_schema(t_cfg, geom["max_pos"]), 2, geom["std"])
-    for sd in (s_sd, t_sd):
-        sd["text_encoder.cls.predictions.decoder.weight"] = sd["text_encoder.bert.embeddings.word_embeddings.weight"]
-        sd["text_encoder.cls.predictions.decoder.bias"] = sd["text_encoder.cls.predictions.bias"]
+    geom, s_cfg, t_cfg, s_sd, t_sd = _oracle_state(1, 2)
+    s_sd, t_sd = _tie(s_sd), _tie(t_sd)
     leaves = {}
     for k, v in s_sd.items():
         leaves.setdefault(id(v), v.clone().requires_grad_(True))
     s_sd = {k: leaves[id(v)] for k, v in s_sd.items()}
-    batch = synth.make_batch(geom, B, seed=42)
-    neg = torch.tensor([(i + 1) % B for i in range(2 * B)])
-    times = []
+
+    def run(B, warm, timed, deadline):
+        batch = synth.make_batch(geom, B, seed=42)
+        neg = torch.tensor([(i + 1) % B for i in range(2 * B)])
+        times = []
+        for it in range(warm + timed):
+            t0 = time.time()
+            total, *_ = O.gd_step(s_sd, t_sd, s_cfg, t_cfg, batch, neg, neg)
+            total.backward()
+            for p in leaves.values():
+                p.grad = None
+            if it >= warm:
+                times.append(time.time() - t0)
+            if time.time() > deadline and times:
+                break
+        return times
+
     t_start = time.time()
-    for it in range(8):
-        t0 = time.time()
-        total, *_ = O.gd_step(s_sd, t_sd, s_cfg, t_cfg, batch, neg, neg)
-        total.backward()
-        for p in leaves.values():
-            p.grad = None
-        dt = time.time() - t0
-        if it > 0 or dt > budget_s / 2:
-            times.append(dt)
-        if time.time() - t_start > budget_s and times:
-            break
-    t = sorted(times)[len(times) // 2]
-    print(json.dumps({"value": round(B / t, 3), "unit": "pairs/s", "cores": nthreads, "kind": "port",
-                      "sample": f"{len(times)} timed GD steps of batch {B} (224x224, 30 tokens), fp32, "
-                                f"oracle/xvlm_oracle.py on {nthreads} host threads, median step {t:.2f} s"}), flush=True)
+    t4 = run(4, 3, 5, t_start + budget_s)
+    med4 = sorted(t4)[len(t4) // 2]
+    res = {"value": round(4 / med4, 3), "unit": "pairs/s", "cores": nthreads, "kind": "port", "cpu": _cpu_model(),
+           "sample": f"BASELINE configs[0]: GD step of batch 4 (224x224, 30 tokens), fp32, oracle/xvlm_oracle.py on "
+                     f"{nthreads} host threads, 3 warm-up + {len(t4)} timed steps, median {med4:.2f} s"}
+    if time.time() - t_start < budget_s * 0.6:
+        t16 = run(16, 1, 2, t_start + budget_s)
+        med16 = sorted(t16)[len(t16) // 2]
+        res["batch16"] = {"value": round(16 / med16, 3), "unit": "pairs/s",
+                          "sample": f"1 warm-up + {len(t16)} timed steps of batch 16, median {med16:.2f} s"}
+    print(json.dumps(res), flush=True)
 
 
-def cpu_baseline(timeout_s=150):
-    """run the CPU baseline in a child process with a hard time limit"""
-    import subprocess
+def oracle_check_child(path):
+    """oracle side of the loss check: fp32 CPU GD step on the state dicts / batch / negatives the parent saved"""
+    from oracle import xvlm_oracle as O
+    torch.set_num_threads(_cpu_threads())
+    blob = torch.load(path)
+    geom, s_cfg, t_cfg, _, _ = _oracle_state(1, 2)
+    with torch.no_grad():
+        total, S, _, kd, mix = O.gd_step(_tie(blob["s_sd"]), _tie(blob["t_sd"]), s_cfg, t_cfg, blob["batch"],
+                                         blob["neg_s"], blob["neg_t"])
+    print(json.dumps({"total": float(total), "itc": float(S["loss"]["loss_itc"]), "itm": float(S["loss"]["loss_itm"]),
+                      "mlm": float(S["loss"]["loss_mlm"]), "kd": float(mix["loss_kd"])}), flush=True)
+
+
+def _run_child(flag, extra=(), timeout_s=240):
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child"], capture_output=True,
-                           text=True, timeout=timeout_s, env=env, cwd=ROOT)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), flag, *extra], capture_output=True, text=True,
+                           timeout=timeout_s, env=env, cwd=ROOT)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if lines:
-            return json.loads(lines[-1])
-        return {"value": None, "unit": "pairs/s", "cores": _cpu_threads(), "kind": "port",
-                "sample": "child failed: " + (r.stderr.strip().splitlines() or ["?"])[-1][:200]}
+            return json.loads(lines[-1]), None
+        return None, "child failed: " + (r.stderr.strip().splitlines() or ["?"])[-1][:200]
     except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "pairs/s", "cores": _cpu_threads(), "kind": "port",
-                "sample": f"one batch-2 oracle GD step did not finish in {timeout_s} s on this host"}
+        return None, f"child did not finish in {timeout_s} s on this host"
+
+
+def cpu_baseline():
+    res, err = _run_child("--cpu-baseline-child")
+    if res is None:
+        res = {"value": None, "unit": "pairs/s", "cores": _cpu_threads(), "kind": "port", "cpu": _cpu_model(), "sample": err}
+    return res
+
+
+def oracle_check(geom, dev, dtype, B, use_graph):
+    """one step of the BENCHMARKED configuration (compute dtype, hipGraph replay, pipelined teacher, batch B) on fresh
+    models, with the hard negatives injected on both sides, against the fp32 CPU oracle on the same weights and batch.
+    bf16 tolerance: 3e-2 relative on every loss (tests/test_step_gpu.py holds the same configuration to the oracle in
+    more detail: KD terms and gradients)."""
+    from efficientvlm_amd.workload import make_batch
+    student, teacher = build(geom, dev, SEED + 1)
+    s_sd = {k: v.detach().float().cpu().clone() for k, v in student.state_dict().items() if torch.is_floating_point(v)}
+    t_sd = {k: v.detach().float().cpu().clone() for k, v in teacher.state_dict().items() if torch.is_floating_point(v)}
+    batch = make_batch(geom, B, seed=4242)
+    g = torch.Generator().manual_seed(7)
+    # a derangement per direction (image->text negatives first, then text->image): never the positive pair
+    neg = torch.cat([(torch.arange(B) + 1 + torch.randint(0, B - 1, (B,), generator=g)) % B for _ in range(2)])
+    student.injected_neg_idx, teacher.injected_neg_idx = neg, neg
+    tr = make_trainer(student, teacher, dtype, use_graph, True)
+    gb = {k: v.to(dev) for k, v in batch.items()}
+    tr.step(gb)                                   # primes the teacher pipeline
+    out = tr.step(gb)                             # student step on the first batch (weights still the initial ones)
+    torch.cuda.synchronize()
+    got = dict(zip(("total", "itc", "itm", "mlm", "kd"), (float(x) for x in out.tolist())))
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "blob.pt")
+        torch.save({"s_sd": s_sd, "t_sd": t_sd, "batch": batch, "neg_s": neg, "neg_t": neg}, path)
+        ref, err = _run_child("--oracle-check-child", (path,), timeout_s=400)
+    if ref is None:
+        return {"ok": None, "error": err, "hip": got}
+    tol = 3e-2 if dtype == torch.bfloat16 else 1e-4
+    rel = {k: abs(got[k] - ref[k]) / max(abs(ref[k]), 1e-12) for k in ref}
+    return {"ok": all(v <= tol for v in rel.values()), "tolerance_rel": tol, "batch": B,
+            "path": f"GDTrainer({str(dtype).split('.')[-1]}, use_graph={use_graph}, pipeline_teacher=True), injected negatives",
+            "hip": {k: round(v, 6) for k, v in got.items()}, "oracle_fp32": {k: round(v, 6) for k, v in ref.items()},
+            "rel_err": {k: float(f"{v:.3e}") for k, v in rel.items()}}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# roofline leg
+# ---------------------------------------------------------------------------------------------------------------------
+def _traffic(dom):
+    """HBM bytes per launch of kernel `dom` from the newest committed PMC summary (profiles/rNN_pmc_traffic.json: FETCH_SIZE
+    x2 gfx950 correction + WRITE_SIZE, separate passes), with the commit that summary was measured at"""
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        names = sorted(n for n in os.listdir(pdir) if n.endswith("_pmc_traffic.json"))
+    except OSError:
+        return None, None
+    for name in reversed(names):
+        try:
+            with open(os.path.join(pdir, name)) as f:
+                pmc = json.load(f)
+        except (OSError, ValueError):
+            continue
+        base, targs = dom.split("<")[0], (dom.split("<")[1] if "<" in dom else "").replace(" ", "")
+        ent = next((v for k, v in pmc.get("kernels", {}).items() if base in k and targs in k.replace(" ", "")), None)
+        if ent:
+            return ent["hbm_bytes_per_launch"], {"file": "profiles/" + name, "commit": pmc.get("commit"),
+                                                  "note": "rocprofv3 PMC pass of this command, not re-measured in this run"}
+    return None, None
 
 
 def roofline_leg(trainer, batch):
-    """one extra eager step with every GEMM launch bracketed by HIP events on its launch stream; launches are attributed to
-    the kernel that served them (evlm_gemm_last_kernel).  `traffic` = HBM bytes per launch of the dominant kernel from the
-    rocprofv3 PMC passes of this same command (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-    KiB -> bytes), null when that summary is absent."""
+    """one extra eager step with every GEMM launch (grouped weight-gradient launches included) bracketed by HIP events on
+    its launch stream; launches are attributed to the kernel that served them (evlm_gemm_last_kernel).  Also counts the
+    FLOPs the step executes (GEMMs 2IJK + attention cores 4 B H Lq Lk dh per forward, x2.5 with the backward)."""
     from efficientvlm_amd import ops
     from efficientvlm_amd._lib import BF16
-    ops.GEMM_PROFILE = []
+    ops.GEMM_PROFILE, ops.ATTN_FLOPS = [], [0.0]
     trainer.opt.set_schedule(0.0)
     overlap, trainer.overlap_teacher = trainer.overlap_teacher, False     # one stream: a launch is timed with the chip to itself
     trainer._step_eager(batch)
     trainer.overlap_teacher = overlap
     torch.cuda.synchronize()
     recs, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
-    groups = {}
+    attn_flops, ops.ATTN_FLOPS = ops.ATTN_FLOPS[0], None
+    groups, all_fl = {}, 0.0
     for dtype, pt, qt, I, J, K, e0, e1, kern in recs:
+        all_fl += 2.0 * I * J * K
         if dtype != BF16:
             continue
         g = groups.setdefault(kern, [0, 0.0, 0.0])
@@ -136,22 +263,14 @@ def roofline_leg(trainer, batch):
     n, fl, tm = groups[dom]
     allfl, alltm = sum(g[1] for g in groups.values()), sum(g[2] for g in groups.values())
     ach = fl / tm / 1e12
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        ent = next((v for k, v in pmc.get("kernels", {}).items() if dom.split("<")[0] in k and
-                    dom.split("<")[1].replace(" ", "") in k.replace(" ", "")), None)
-        if ent:
-            traffic = ent["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError, IndexError):
-        pass
-    return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches": n,
+    traffic, src = _traffic(dom)
+    roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": src, "launches": n,
             "avg_launch_us": round(tm / n * 1e6, 2), "flop_per_launch": round(fl / n / 1e9, 3),
             "all_gemm_kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
                                      "time_ms": round(v[2] * 1e3, 3)} for k, v in groups.items()},
             "all_gemm_tflops": round(allfl / alltm / 1e12, 1), "gemm_time_ms_per_step": round(alltm * 1e3, 2)}
+    return roof, all_fl + attn_flops
 
 
 def main():
@@ -165,10 +284,15 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="teacher forward inside the same step as its student step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-oracle-check", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--oracle-check-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
         cpu_baseline_child()
+        return
+    if args.oracle_check_child:
+        oracle_check_child(args.oracle_check_child)
         return
 
     # stdout carries exactly ONE line (the JSON result): anything libraries write to fd 1 meanwhile - RCCL prints a
@@ -188,19 +312,16 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     dev = torch.device("cuda", local_rank)
 
-    from oracle import synth
-    from efficientvlm_amd.trainer import GDTrainer
-    geom = synth.GEOMS["full"]
+    from efficientvlm_amd.workload import GEOMS, make_batch
+    geom = GEOMS["full"]
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    student, teacher = build(geom, dev, seed=1234)
+    student, teacher = build(geom, dev, seed=SEED)
     pipelined = not args.no_pipeline
-    trainer = GDTrainer(student, teacher, lr=1e-4, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=dtype,
-                        use_graph=not args.no_graph, pipeline_teacher=pipelined)
+    trainer = make_trainer(student, teacher, dtype, not args.no_graph, pipelined)
     B = args.batch
     # weak scaling: B per GPU.  FOUR distinct synthetic batches, resident in HBM, fed round-robin: with the teacher
     # pipelined one batch ahead of the student, every step runs the teacher on a batch the student has not seen yet
-    batches = [{k: v.to(dev) for k, v in synth.make_batch(geom, B, seed=42 + rank + 1000 * i).items()} for i in range(4)]
-    batch = batches[0]
+    batches = [{k: v.to(dev) for k, v in make_batch(geom, B, seed=42 + rank + 1000 * i).items()} for i in range(4)]
     it = 0
     if pipelined:
         trainer.step(batches[0])          # primes the pipeline (teacher outputs of the first batch); not a step
@@ -226,6 +347,13 @@ def main():
         elapsed = float(t.item())
     losses = [float(x) for x in out.tolist()]
 
+    # the instrumented step issues the step's collectives (ITC all-gather, gradient all-reduce): EVERY rank runs it
+    roof = executed = None
+    if not args.no_roofline and dtype == torch.bfloat16:
+        roof, executed = roofline_leg(trainer, batches[0])
+        if world > 1:
+            dist.barrier()
+
     if rank == 0:
         pairs = B * world * args.steps
         value = pairs / elapsed
@@ -237,20 +365,26 @@ def main():
                                       "teacher fwd, ITC+ITM+MLM + hidden/attention/logit KD, grad all-reduce, clip 1.0, AdamW",
                           "image": "224x224", "text_len": geom["L"], "masked": geom["M"], "batch_per_gpu": B,
                           "global_batch": B * world, "parallelism": f"dp{world}",
-                          "launch": "eager" if (args.no_graph or world > 1 or force_dp) else "hipGraph replay",
+                          "launch": "eager" if (args.no_graph or force_dp) else
+                                    ("hipGraph segments around the collectives" if world > 1 else "hipGraph replay"),
                           "teacher_pipelined": pipelined, "distinct_batches": 4,
                           "init": "random (reference init), no checkpoints"},
-               "step_model_tflops": round(value * FLOPS_PER_PAIR / 1e12, 1),
-               "step_mfma_frac": round(value * FLOPS_PER_PAIR / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
                "last_losses": {"total": losses[0], "itc": losses[1], "itm": losses[2], "mlm": losses[3], "kd": losses[4]}}
-        if not args.no_roofline and dtype == torch.bfloat16:
-            res["roofline"] = roofline_leg(trainer, batch)
+        if roof is not None:
+            res["roofline"] = roof
+            ex_pair = executed / B
+            res["executed"] = {
+                "gflop_per_pair": round(ex_pair / 1e9, 2), "reference_gflop_per_pair": REF_FLOPS_PER_PAIR / 1e9,
+                "skipped_gflop_per_pair": round((REF_FLOPS_PER_PAIR - ex_pair) / 1e9, 2),
+                "why": "cross-attention K/V projected once per image and shared by the 4 fusion passes (kv_index); "
+                       "frozen-teacher task heads nobody reads are not run",
+                "step_tflops": round(value / world * ex_pair / 1e12, 1)}
+            res["step_mfma_frac"] = round(value / world * ex_pair / 1e12 / PEAK_BF16_TFLOPS, 4)
         if world == 1 and pipelined and not args.no_roofline:
             # the same step WITHOUT teacher pipelining (both models on the same batch inside each step), for reference
             del trainer
-            s2, t2 = build(geom, dev, seed=1234)
-            tr2 = GDTrainer(s2, t2, lr=1e-4, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=dtype,
-                            use_graph=not args.no_graph, pipeline_teacher=False)
+            s2, t2 = build(geom, dev, seed=SEED)
+            tr2 = make_trainer(s2, t2, dtype, not args.no_graph, False)
             for i in range(3):
                 tr2.step(batches[i % 4])
             torch.cuda.synchronize()
@@ -262,6 +396,9 @@ def main():
             e2 = time.perf_counter() - t1
             res["unpipelined"] = {"value": round(B * n2 / e2, 2), "unit": "pairs/s", "ms_per_step": round(e2 / n2 * 1e3, 3),
                                   "steps": n2}
+            del tr2, s2, t2
+        if world == 1 and not args.no_oracle_check:
+            res["oracle_check"] = oracle_check(geom, dev, dtype, B, not args.no_graph)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

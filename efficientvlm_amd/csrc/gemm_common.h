@@ -52,10 +52,13 @@ __device__ __forceinline__ int ctile_off(int r, int c) {
 
 // MODE 0: pre-activation and C in one pass; 1: only the pre-activation (into sH); 2: only C (the 256x256 kernel has one
 // LDS tile to stage through, so it runs the two outputs as two passes)
-template <typename T, int NA, int NB, bool FULL, bool LDS_OUT = false, int MT = 4, int MODE = 0>
-__device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][NB], int ibase, int jbase, int lane,
-                                              char* sC = nullptr, char* sH = nullptr, int i0 = 0, int j0 = 0) {
+// ACT / DACT: compile-time activation codes, -1 = read g.act / g.dact at run time (tile_epilogue below dispatches ONCE per
+// tile: with run-time codes hipcc keeps scalar compares and branches around every single element)
+template <typename T, int NA, int NB, bool FULL, bool LDS_OUT, int MT, int MODE, int ACT, int DACT>
+__device__ __forceinline__ void tile_epilogue_impl(const GemmP& g, f32x4 (&acc)[NA][NB], int ibase, int jbase, int lane,
+                                                   char* sC, char* sH, int i0, int j0) {
   const int il = lane & 15, jl = (lane >> 4) * 4;
+  const int act = ACT >= 0 ? ACT : g.act, dact = DACT >= 0 ? DACT : g.dact;
   constexpr bool LOWP = sizeof(T) == 2;      // bf16 path: fast activation math (common.h); the f32 parity path stays exact
 #pragma unroll
   for (int a = 0; a < NA; ++a) {
@@ -66,7 +69,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][N
     if (g.bias) ld4<float>(g.bias + j, nv, bz);
     if (g.gate) ld4<float>(g.gate + j, nv, gz);
     float hx[NB][4], rx[NB][4];
-    if (FULL && MODE != 1 && g.dact != EVLM_ACT_NONE) {
+    if (FULL && MODE != 1 && dact != EVLM_ACT_NONE) {
 #pragma unroll
       for (int b = 0; b < NB; ++b)
         ld4<T>(reinterpret_cast<const T*>(g.aux) + (size_t)(ibase + b * 16 + il) * g.ldx + j, 4, hx[b]);
@@ -81,7 +84,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][N
       const int i = ibase + b * 16 + il;
       if (!FULL && i >= g.I) continue;
       if (!FULL && MODE != 1) {   // edge tiles: fetch per element block (rare; keeps the register budget of the interior path)
-        if (g.dact != EVLM_ACT_NONE) ld4<T>(reinterpret_cast<const T*>(g.aux) + (size_t)i * g.ldx + j, nv, hx[b]);
+        if (dact != EVLM_ACT_NONE) ld4<T>(reinterpret_cast<const T*>(g.aux) + (size_t)i * g.ldx + j, nv, hx[b]);
         if (g.residual) ld4<T>(reinterpret_cast<const T*>(g.residual) + (size_t)i * g.ldx + j, nv, rx[b]);
       }
       float v[4];
@@ -92,21 +95,21 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][N
         else st4<T>(reinterpret_cast<T*>(g.preact) + (size_t)i * g.ldx + j, nv, v);
       }
       if (MODE == 1) continue;
-      if (g.act != EVLM_ACT_NONE) {
+      if (act != EVLM_ACT_NONE) {
         if (g.gate_pos == EVLM_GATE_PRE_ACT) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = LOWP ? act_apply_fast(g.act, v[e] * gz[e]) : act_apply(g.act, v[e] * gz[e]);
+          for (int e = 0; e < 4; ++e) v[e] = LOWP ? act_apply_fast(act, v[e] * gz[e]) : act_apply(act, v[e] * gz[e]);
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (LOWP ? act_apply_fast(g.act, v[e]) : act_apply(g.act, v[e])) * gz[e];
+          for (int e = 0; e < 4; ++e) v[e] = (LOWP ? act_apply_fast(act, v[e]) : act_apply(act, v[e])) * gz[e];
         }
       } else if (g.gate) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= gz[e];
       }
-      if (g.dact != EVLM_ACT_NONE) {
+      if (dact != EVLM_ACT_NONE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= LOWP ? act_grad_fast(g.dact, hx[b][e]) : act_grad(g.dact, hx[b][e]);
+        for (int e = 0; e < 4; ++e) v[e] *= LOWP ? act_grad_fast(dact, hx[b][e]) : act_grad(dact, hx[b][e]);
       }
       if (g.residual) {
 #pragma unroll
@@ -118,6 +121,24 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][N
       else st4<T>(reinterpret_cast<T*>(g.C) + co, nv, v);
     }
   }
+}
+
+template <typename T, int NA, int NB, bool FULL, bool LDS_OUT = false, int MT = 4, int MODE = 0>
+__device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][NB], int ibase, int jbase, int lane,
+                                              char* sC = nullptr, char* sH = nullptr, int i0 = 0, int j0 = 0) {
+#define EVLM_EPI(A_, D_) tile_epilogue_impl<T, NA, NB, FULL, LDS_OUT, MT, MODE, A_, D_>(g, acc, ibase, jbase, lane, sC, sH, i0, j0)
+  constexpr int G = EVLM_ACT_GELU, QG = EVLM_ACT_QUICK_GELU, N = EVLM_ACT_NONE;
+  if (sizeof(T) == 2 && FULL && !g.gate) {           // interior bf16 tiles of the training path: compile-time activation codes
+    if (g.dact == N) {
+      if (g.act == N) EVLM_EPI(N, N);
+      else if (g.act == G) EVLM_EPI(G, N);
+      else EVLM_EPI(QG, N);
+    } else if (g.act == N) {
+      if (g.dact == G) EVLM_EPI(N, G);
+      else EVLM_EPI(N, QG);
+    } else EVLM_EPI(-1, -1);
+  } else EVLM_EPI(-1, -1);
+#undef EVLM_EPI
 }
 
 // XCD-aware, bijective block -> tile map: blocks b and b+8 share an XCD (and its L2), so give each

@@ -278,12 +278,17 @@ __device__ __forceinline__ PPRows pp_epi_rows(const GemmP& g, const bf16* xb, in
   return x;
 }
 
-// one 32-row chunk (i fragments b0, b0 + 1) of the wave's block through its LDS window
-template <bool FULL, int MODE, bool GATED, int XM>
+// one 32-row chunk (i fragments b0, b0 + 1) of the wave's block through its LDS window.
+// ACT / DACT are COMPILE-TIME activation codes (-1: read g.act / g.dact at run time - the L0-gated flavours of the pruning
+// fine-tune only).  With the run-time form hipcc keeps a chain of scalar compares and branches around every single element
+// (128 per lane and tile): the bias-only epilogue took 7.6 k cycles per tile with or without its global stores
+// (in-kernel stamps), most of it branch issue.
+template <bool FULL, int MODE, bool GATED, int XM, int ACT, int DACT>
 __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4], int b0, const PPRows& xr,
                                              int ic, int jb, int lane, char* sw, bf16* dst, int ldd) {
   constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && XM == 2;
   const int il = lane & 15, jl = (lane >> 4) * 4;
+  const int act = ACT >= 0 ? ACT : g.act, dact = DACT >= 0 ? DACT : g.dact;
   f32x4 gz[4];                             // L0 FFN gate (per output column), fetched per chunk: L2-resident, 16 registers
   constexpr bool gated = MODE == 2 && GATED;   // (compile-time: the ungated instantiation carries no gate registers)
   if (gated) {
@@ -317,9 +322,9 @@ __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4],
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= gz[a][e];
         }
-        if (g.act != EVLM_ACT_NONE) {
+        if (ACT != EVLM_ACT_NONE) {        // (ACT < 0: run-time code, may be NONE)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = act_apply_fast(g.act, v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = act_apply_fast(act, v[e]);
         }
         if (gated && g.gate_pos != EVLM_GATE_PRE_ACT) {
 #pragma unroll
@@ -329,7 +334,7 @@ __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4],
           const bf16x4 xx = *reinterpret_cast<const bf16x4*>(cell);
           if (need_h) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= act_grad_fast(g.dact, (float)xx[e]);
+            for (int e = 0; e < 4; ++e) v[e] *= act_grad_fast(dact, (float)xx[e]);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)xx[e];
@@ -346,36 +351,42 @@ __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4],
     const int r = k * 8 + (lane >> 3), ch = lane & 7;
     const uint4 v16 = *reinterpret_cast<const uint4*>(sw + r * 128 + ((ch ^ (r & 7)) << 4));
     const int i = ic + r, j = jb + ch * 8;
+#if defined(PP_EXP_NOSTORE)        // diagnostic builds only (tools/): what the epilogue costs without its global stores
+    if (g.alpha == 12345.f) *reinterpret_cast<uint4*>(dst + (size_t)i * ldd + j) = v16;
+#else
     if (FULL || (i < g.I && j < g.J)) *reinterpret_cast<uint4*>(dst + (size_t)i * ldd + j) = v16;
+#endif
   }
   asm volatile("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 
 // MODE 1: the pre-activation output (alpha * acc + bias); MODE 2: C.  aux (activation backward) OR residual rows (the host
-// never routes both here) are fetched as FULL 128-byte row segments, both chunks of the half in one batch; they reach the
-// fragment layout through the wave's LDS window, where the result then overwrites them in place.
+// never routes both here) are fetched as FULL 128-byte row segments; they reach the fragment layout through the wave's LDS
+// window, where the result then overwrites them in place.
 // XM (compile-time, so that the plain instantiation carries no row registers): 0 none, 1 aux (activation backward),
 // 2 residual
-template <bool FULL, int MODE, bool GATED, int XM>
+template <bool FULL, int MODE, bool GATED, int XM, int ACT, int DACT>
 __device__ __forceinline__ void pp_epi_half(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4],
                                             int ib, int jb, int lane, char* sw, bf16* dst, int ldd) {
   constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && XM == 2;
+  // (rows are requested per 64-row half: requesting all four chunks of the tile up front - 64 registers - was measured
+  // SLOWER, 12.7 k against 10.6 k cycles per tile, the extra registers spill around the epilogue)
   PPRows x0, x1;
   if (need_h || need_r) {
     const bf16* xb = reinterpret_cast<const bf16*>(need_h ? g.aux : g.residual);
     x0 = pp_epi_rows<FULL>(g, xb, ib, jb, lane);
     x1 = pp_epi_rows<FULL>(g, xb, ib + 32, jb, lane);
   }
-  pp_epi_chunk<FULL, MODE, GATED, XM>(g, acc, bz, 0, x0, ib, jb, lane, sw, dst, ldd);
-  pp_epi_chunk<FULL, MODE, GATED, XM>(g, acc, bz, 2, x1, ib + 32, jb, lane, sw, dst, ldd);
+  pp_epi_chunk<FULL, MODE, GATED, XM, ACT, DACT>(g, acc, bz, 0, x0, ib, jb, lane, sw, dst, ldd);
+  pp_epi_chunk<FULL, MODE, GATED, XM, ACT, DACT>(g, acc, bz, 2, x1, ib + 32, jb, lane, sw, dst, ldd);
 }
 
-template <bool FULL, bool GATED, int XM>
+template <bool FULL, bool GATED, int XM, int ACT, int DACT>
 __device__ __forceinline__ void pp_epi_c(const GemmP& g, f32x4 (&accL)[4][4], f32x4 (&accH)[4][4], const f32x4 (&bz)[4], int ib,
                                          int jb, int lane, char* sw) {
-  pp_epi_half<FULL, 2, GATED, XM>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
-  pp_epi_half<FULL, 2, GATED, XM>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
+  pp_epi_half<FULL, 2, GATED, XM, ACT, DACT>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
+  pp_epi_half<FULL, 2, GATED, XM, ACT, DACT>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
 }
 
 template <bool FULL>
@@ -384,16 +395,23 @@ __device__ __forceinline__ void pp_epilogue(const GemmP& g, f32x4 (&accL)[4][4],
   f32x4 bz[4];
   pp_epi_cols<FULL>(g, jb, lane, bz);
   if (g.preact) {
-    pp_epi_half<FULL, 1, false, 0>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx);
-    pp_epi_half<FULL, 1, false, 0>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx);
+    pp_epi_half<FULL, 1, false, 0, 0, 0>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx);
+    pp_epi_half<FULL, 1, false, 0, 0, 0>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx);
   }
-  // one instantiation per epilogue flavour (wave-uniform dispatch): the plain one carries neither gate nor row registers
-  if (g.gate) {                      // L0-gated FFN (pruning fine-tune only)
-    if (g.residual) pp_epi_c<FULL, true, 2>(g, accL, accH, bz, ib, jb, lane, sw);
-    else pp_epi_c<FULL, true, 0>(g, accL, accH, bz, ib, jb, lane, sw);
-  } else if (g.dact != EVLM_ACT_NONE) pp_epi_c<FULL, false, 1>(g, accL, accH, bz, ib, jb, lane, sw);
-  else if (g.residual) pp_epi_c<FULL, false, 2>(g, accL, accH, bz, ib, jb, lane, sw);
-  else pp_epi_c<FULL, false, 0>(g, accL, accH, bz, ib, jb, lane, sw);
+  // one instantiation per epilogue flavour (ONE wave-uniform dispatch per tile): the plain one carries neither gate nor
+  // row registers, and every flavour of the training path has its activation code as a compile-time constant
+  constexpr int G = EVLM_ACT_GELU, QG = EVLM_ACT_QUICK_GELU, N = EVLM_ACT_NONE;
+  if (g.gate) {                      // L0-gated FFN (pruning fine-tune only): activation code read at run time
+    if (g.residual) pp_epi_c<FULL, true, 2, -1, N>(g, accL, accH, bz, ib, jb, lane, sw);
+    else pp_epi_c<FULL, true, 0, -1, N>(g, accL, accH, bz, ib, jb, lane, sw);
+  } else if (g.dact == G) pp_epi_c<FULL, false, 1, N, G>(g, accL, accH, bz, ib, jb, lane, sw);
+  else if (g.dact == QG) pp_epi_c<FULL, false, 1, N, QG>(g, accL, accH, bz, ib, jb, lane, sw);
+  else if (g.residual) {
+    if (g.act == N) pp_epi_c<FULL, false, 2, N, N>(g, accL, accH, bz, ib, jb, lane, sw);
+    else pp_epi_c<FULL, false, 2, -1, N>(g, accL, accH, bz, ib, jb, lane, sw);
+  } else if (g.act == G) pp_epi_c<FULL, false, 0, G, N>(g, accL, accH, bz, ib, jb, lane, sw);
+  else if (g.act == QG) pp_epi_c<FULL, false, 0, QG, N>(g, accL, accH, bz, ib, jb, lane, sw);
+  else pp_epi_c<FULL, false, 0, N, N>(g, accL, accH, bz, ib, jb, lane, sw);
 }
 
 // weight gradients: f32 tile out of the same 4 KiB window, 16 rows x 64 columns at a time.  Plain 16-byte stores when the

@@ -165,6 +165,8 @@ class WeightCache:
 CACHE = WeightCache()
 # set to a list to time every GEMM launch with HIP events on the launch stream (bench.py roofline leg)
 GEMM_PROFILE = None
+# set to [0.0] to count the FLOPs of the attention cores that are launched (QK^T + PV forward, 5 products backward)
+ATTN_FLOPS = None
 
 
 def _as2d(x):
@@ -254,7 +256,17 @@ def flush_wgrad():
             arr[k].C = cgrad.data_ptr()
             arr[k].psum = ps.data_ptr() if ps is not None else None
             arr[k].I, arr[k].J, arr[k].ldp, arr[k].ldq, arr[k].ldc = I, J, ldd, ldp, J
+        if GEMM_PROFILE is None:
+            L.check(lib.evlm_wgrad_grouped(arr, len(recs), K, L.stream()), "wgrad_grouped")
+            continue
+        # profiled as ONE record: the launch computes sum_n 2 I_n J_n K flops, reported as a product with I = sum of
+        # I_n J_n / J_0 so that 2 I J K is exact
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         L.check(lib.evlm_wgrad_grouped(arr, len(recs), K, L.stream()), "wgrad_grouped")
+        e1.record()
+        ij = sum(r[5] * r[6] for r in recs)
+        GEMM_PROFILE.append((L.BF16, 1, 1, ij, 1, K, e0, e1, "gemm_bf16_pp256_grouped_kernel"))
 
 
 def _inplace(p):
@@ -598,6 +610,8 @@ class _Attention(torch.autograd.Function):
                           kv_index=L.ptr(kv_index), mask=L.ptr(m32), head_gate=L.ptr(g32), scale=scale, O=L.ptr(O),
                           P=L.ptr(Pbuf), causal=int(bool(causal)))
         L.check(_lib().evlm_attention_fwd(C.byref(a), L.stream()), "attention_fwd")
+        if ATTN_FLOPS is not None:
+            ATTN_FLOPS[0] += 4.0 * B * H * Lq * Lk * dh
         ctx.set_materialize_grads(False)        # an unused probability map must not cost a zero tensor in backward
         ctx.save_for_backward(qbuf, kvbuf, Pbuf, g32, kv_index)
         ctx.meta = (H, dh, q_off, k_off, v_off, scale, qbuf is kvbuf or qbuf.data_ptr() == kvbuf.data_ptr(),
@@ -636,6 +650,8 @@ class _Attention(torch.autograd.Function):
                           dQ=C.c_void_p(dqbuf.data_ptr() + q_off * es), dK=C.c_void_p(dkvbuf.data_ptr() + k_off * es),
                           dV=C.c_void_p(dkvbuf.data_ptr() + v_off * es), dgate=L.ptr(dgate))
         L.check(_lib().evlm_attention_bwd(C.byref(a), L.stream()), "attention_bwd")
+        if ATTN_FLOPS is not None:
+            ATTN_FLOPS[0] += 8.0 * B * H * Lq * Lk * dh          # dP, dV, dQ, dK (P is read back, not recomputed)
         dg = dgate.view(gshape) if dgate is not None else None
         if self_attn:
             return dqbuf, None, None, dg, None, None, None, None, None, None, None, None, None

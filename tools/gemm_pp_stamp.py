@@ -49,4 +49,5 @@ def run_tt(I, J, K, acc=True):
         print(f"   item#{n} ({m.sum():3d} wgs): kloop {np.median(v[:,1]-v[:,0]):6.0f}  next-issue {np.median(v[:,2]-v[:,1]):5.0f}"
               f"  epilogue-issue {np.median(v[:,3]-v[:,2]):6.0f}  drain {np.median(v[:,4]-v[:,3]):6.0f}")
 pass
-run(12608, 2304, 768); run(12608, 768, 768, res=True)
+for shp in [(12608, 2304, 768, False), (12608, 768, 768, True), (12608, 3072, 768, False), (12608, 768, 3072, True), (7680, 768, 768, True), (7680, 3072, 768, False)]:
+    run(shp[0], shp[1], shp[2], res=shp[3])
