@@ -37,7 +37,8 @@ class AttnFwdArgs(C.Structure):
                 ("B", _i), ("H", _i), ("Lq", _i), ("Lk", _i), ("dh", _i),
                 ("ldq", _i), ("ldk", _i), ("ldv", _i), ("ldo", _i), ("ldpr", _i),
                 ("Q", _vp), ("K", _vp), ("V", _vp), ("kv_index", _vp), ("mask", _vp), ("head_gate", _vp),
-                ("scale", _f), ("O", _vp), ("P", _vp), ("causal", _i)]
+                ("scale", _f), ("O", _vp), ("P", _vp), ("causal", _i),
+                ("dropout_p", _f), ("rng_state", _vp), ("call_id", C.c_uint32)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -47,7 +48,8 @@ class AttnBwdArgs(C.Structure):
                 ("lddq", _i), ("lddk", _i), ("lddv", _i), ("ldpr", _i),
                 ("Q", _vp), ("K", _vp), ("V", _vp), ("P", _vp), ("dO", _vp), ("dP_ext", _vp),
                 ("kv_index", _vp), ("head_gate", _vp), ("scale", _f),
-                ("dS", _vp), ("dQ", _vp), ("dK", _vp), ("dV", _vp), ("dgate", _vp)]
+                ("dS", _vp), ("dQ", _vp), ("dK", _vp), ("dV", _vp), ("dgate", _vp),
+                ("dropout_p", _f), ("rng_state", _vp), ("call_id", C.c_uint32)]
 
 
 # name -> argtypes (every symbol include/evlm_hip.h declares; tests check the library exports all of them)
@@ -86,6 +88,8 @@ SIGNATURES = {
     "evlm_l0_sample_fwd": [_vp, _vp, _i64, _f, _vp, _vp],
     "evlm_l0_sample_bwd": [_vp, _vp, _vp, _i64, _f, _vp, _vp],
     "evlm_l0_deterministic": [_vp, _i, _i, _f, _f, _vp, _vp],
+    "evlm_dropout": [_i, _vp, _vp, _i64, _f, _vp, C.c_uint32, _vp, _vp],
+    "evlm_dropout_mask": [_i64, _f, _vp, C.c_uint32, _vp, _vp],
     "evlm_sumsq": [_vp, _i64, _vp, _vp],
     "evlm_adamw_step": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _vp, _vp, _vp],
 }

@@ -19,6 +19,7 @@ struct AttnF {
   int B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, ldpr;
   float scale;
   int causal;
+  float drop_p; const int64_t* rng; uint32_t call;      // attention-probability dropout (0: off)
 };
 
 // load rows [r0, r0+nrows) x dh of a [.., L, H, dh]-strided tensor (row stride ld) into LDS as fp32 [nrows][dh+1]
@@ -86,9 +87,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnF a) {
     const float inv = 1.0f / sum;
     const bool rowok = (q0 + r < a.Lq);
     TP* Pr = reinterpret_cast<TP*>(a.P) + (((size_t)b * a.H + h) * a.Lq + (q0 + r)) * a.ldpr;
+    // the map is returned BEFORE dropout (eff_bert.py:338-361); the context uses the dropped probabilities (:346-352)
+    const bool drop = a.drop_p > 0.f;
+    DropRng rng;
+    if (drop) rng = drop_rng(a.rng, a.call, a.drop_p);
+    const uint64_t drow = (((uint64_t)b * a.H + h) * a.Lq + (q0 + r)) * (uint64_t)Lk;
     for (int k = kl; k < Lk; k += 16) {
       const float p = Ss[r * Lkp + k] * inv;
-      Ss[r * Lkp + k] = p;
+      Ss[r * Lkp + k] = (drop && rowok) ? p * drop_factor(rng, drow + k) : p;
       if (rowok && a.P) Pr[k] = from_f<TP>(p);
     }
     if (rowok && a.P) for (int k = Lk + kl; k < a.ldpr; k += 16) Pr[k] = from_f<TP>(0.f);
@@ -129,6 +135,7 @@ struct AttnB {
   void* dS; void* dQ; void* dK; void* dV; float* dK32; float* dV32; float* dgate;
   int B, H, Lq, Lk, dh, ldq, ldk, ldv, ldo, lddq, lddk, lddv, ldpr;
   float scale;
+  float drop_p; const int64_t* rng; uint32_t call;
 };
 
 template <typename T, typename TP>
@@ -168,10 +175,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnB a) {
   {
     const float gz = a.gate ? a.gate[h] : 1.0f;
     float dsum = 0.f, gsum = 0.f;
+    const bool drop = a.drop_p > 0.f;
+    DropRng rng;
+    if (drop) rng = drop_rng(a.rng, a.call, a.drop_p);
+    const uint64_t drow = (((uint64_t)b * a.H + h) * a.Lq + (q0 + r)) * (uint64_t)Lk;
     if (rowok) {
       for (int k = kl; k < Lk; k += 16) {
         const float p = to_f(Pr[k]);
-        const float dpo = Ss[r * Lkp + k];
+        // O = gate * (P .* M) V: the gradient reaches P through the same (regenerated) mask M = keep / (1 - p)
+        const float dpo = drop ? Ss[r * Lkp + k] * drop_factor(rng, drow + k) : Ss[r * Lkp + k];
         gsum += p * dpo;
         const float dp = gz * dpo + (Er ? to_f(Er[k]) : 0.f);
         Ss[r * Lkp + k] = dp;
@@ -242,6 +254,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnB a) {
   float ak[32], av[32];
 #pragma unroll
   for (int e = 0; e < 32; ++e) { ak[e] = 0.f; av[e] = 0.f; }
+  const bool drop = a.drop_p > 0.f;
+  DropRng rng;
+  if (drop) rng = drop_rng(a.rng, a.call, a.drop_p);
   for (int q0 = 0; q0 < a.Lq; q0 += AQ) {
     __syncthreads();
     load_rows<T>(Qb, a.ldq, q0, AQ, a.Lq, dh, Qs);
@@ -252,6 +267,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnB a) {
       if (q0 + rr < a.Lq && k0 + kk < Lk) {
         ds = to_f(dSb[(size_t)(q0 + rr) * a.ldpr + k0 + kk]);
         p = to_f(Pb[(size_t)(q0 + rr) * a.ldpr + k0 + kk]);
+        if (drop) p *= drop_factor(rng, (((uint64_t)b * a.H + h) * a.Lq + (q0 + rr)) * (uint64_t)Lk + k0 + kk);   // dV = gate (P .* M)^T dO
       }
       dSs[rr * (AKC + 1) + kk] = ds;
       Ps[rr * (AKC + 1) + kk] = p;
@@ -311,10 +327,15 @@ extern "C" int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream_) {
   EVLM_REQUIRE((a->ldq | a->ldk | a->ldv) % 8 == 0, "evlm_attention_fwd: row strides must be multiples of 8");
   EVLM_REQUIRE(!a->P || (a->ldpr >= a->Lk && a->ldpr % 8 == 0), "evlm_attention_fwd: ldpr must be a multiple of 8 and >= Lk");
   EVLM_REQUIRE(!a->causal || a->Lq == a->Lk, "evlm_attention_fwd: a causal mask needs Lq == Lk");
+  EVLM_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f && (a->dropout_p == 0.f || a->rng_state),
+               "evlm_attention_fwd: dropout_p = %f needs 0 <= p < 1 and an rng_state", (double)a->dropout_p);
   int handled = 0;
-  if (int e = evlm_attention_fwd_mfma(a, stream, &handled)) return e;
+  if (a->dropout_p == 0.f) {          // probability dropout runs on the shape-generic kernels (text-side problems)
+    if (int e = evlm_attention_fwd_mfma(a, stream, &handled)) return e;
+  }
   if (handled) return 0;
   AttnF f;
+  f.drop_p = a->dropout_p; f.rng = a->rng_state; f.call = a->call_id;
   f.Q = a->Q; f.K = a->K; f.V = a->V; f.kv_index = a->kv_index; f.mask = a->mask; f.gate = a->head_gate; f.causal = a->causal;
   f.O = a->O; f.P = a->P; f.B = a->B; f.H = a->H; f.Lq = a->Lq; f.Lk = a->Lk; f.dh = a->dh;
   f.ldq = a->ldq; f.ldk = a->ldk; f.ldv = a->ldv; f.ldo = a->ldo; f.ldpr = a->ldpr; f.scale = a->scale;
@@ -339,12 +360,15 @@ extern "C" int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream_) {
   EVLM_REQUIRE(a->dK && a->dV, "evlm_attention_bwd: dK/dV required (f32 accumulators when kv_index is set)");
   if (int e = attn_check(a->dtype, a->p_dtype, a->dh, "evlm_attention_bwd")) return e;
   EVLM_REQUIRE(a->ldpr >= a->Lk && a->ldpr % 8 == 0, "evlm_attention_bwd: ldpr must be a multiple of 8 and >= Lk");
-  {
+  EVLM_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f && (a->dropout_p == 0.f || a->rng_state),
+               "evlm_attention_bwd: dropout_p = %f needs 0 <= p < 1 and an rng_state", (double)a->dropout_p);
+  if (a->dropout_p == 0.f) {
     int handled = 0;
     if (int e = evlm_attention_bwd_mfma(a, stream, &handled)) return e;
     if (handled) return 0;
   }
   AttnB g;
+  g.drop_p = a->dropout_p; g.rng = a->rng_state; g.call = a->call_id;
   g.Q = a->Q; g.K = a->K; g.V = a->V; g.P = a->P; g.dO = a->dO; g.dPext = a->dP_ext; g.kv_index = a->kv_index;
   g.gate = a->head_gate; g.dS = a->dS; g.dQ = a->dQ; g.dgate = a->dgate;
   if (a->kv_index) { g.dK32 = (float*)a->dK; g.dV32 = (float*)a->dV; g.dK = nullptr; g.dV = nullptr; }

@@ -126,6 +126,41 @@ __device__ __forceinline__ float act_grad(int act, float x) {
   return act == EVLM_ACT_GELU ? gelu_erf_grad(x) : (act == EVLM_ACT_QUICK_GELU ? quick_gelu_grad(x) : 1.0f);
 }
 
+// ---- counter-based dropout masks (Philox4x32-10) ---------------------------------------------
+// A dropout site is identified by (seed, step, call id); element `idx` of that site keeps its value iff word (idx & 3) of
+// Philox(counter = {idx >> 2 lo, idx >> 2 hi, call, step}, key = seed) is >= p * 2^32.  The mask is a pure function of
+// those numbers, so the backward kernels REGENERATE it: no mask tensor ever exists in HBM.  rng_state is a DEVICE
+// int64[2] = {seed, step}: a captured hipGraph draws fresh masks on every replay once the host (or a one-word kernel)
+// has bumped `step`; the call id is a host constant of each call site.
+struct DropRng { uint32_t k0, k1, call, step; uint32_t thresh; float scale; };
+__device__ __forceinline__ DropRng drop_rng(const int64_t* __restrict__ state, uint32_t call, float p) {
+  DropRng r;
+  const uint64_t seed = (uint64_t)state[0], step = (uint64_t)state[1];
+  r.k0 = (uint32_t)seed; r.k1 = (uint32_t)(seed >> 32); r.call = call; r.step = (uint32_t)step;
+  const double t = (double)p * 4294967296.0;
+  r.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  r.scale = 1.0f / (1.0f - p);
+  return r;
+}
+__device__ __forceinline__ void philox4(const DropRng& r, uint64_t block, uint32_t (&o)[4]) {
+  uint32_t c0 = (uint32_t)block, c1 = (uint32_t)(block >> 32), c2 = r.call, c3 = r.step, k0 = r.k0, k1 = r.k1;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+// keep / (1 - p) of ONE element (attention kernels: elements of a thread are not consecutive)
+__device__ __forceinline__ float drop_factor(const DropRng& r, uint64_t idx) {
+  uint32_t o[4];
+  philox4(r, idx >> 2, o);
+  const uint32_t w = (idx & 2) ? ((idx & 1) ? o[3] : o[2]) : ((idx & 1) ? o[1] : o[0]);
+  return w >= r.thresh ? r.scale : 0.f;
+}
+
 // ---- wave / block reductions (64-lane waves) ------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

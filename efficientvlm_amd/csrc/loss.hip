@@ -102,7 +102,9 @@ __device__ __forceinline__ float row_lse(const T* __restrict__ x, int C, float m
   return M + __logf(s);
 }
 
-// hard-label CE:  rowloss[r] = lse - logit[label]   (0 for ignored rows)
+// hard-label CE:  rowloss[r] = lse - logit[label]   (0 for ignored rows).  A label outside [0, C) that is not the ignore
+// index (a corrupt masked_ids entry, a vocabulary-size mismatch) never indexes the row: its loss - and with it the step's
+// total and, in ce_bwd_kernel, its gradient row - becomes NaN, where F.cross_entropy would trip a device assert.
 template <typename T>
 __global__ __launch_bounds__(256) void ce_row_kernel(const T* __restrict__ logits, int C, int ld,
                                                      const int64_t* __restrict__ labels, int ignore_index,
@@ -114,7 +116,8 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const T* __restrict__ logit
   if (threadIdx.x == 0) {
     const int64_t lb = labels[r];
     lse_out[r] = lse;
-    lse_out[R + r] = (lb == ignore_index) ? 0.f : lse - to_f(x[lb]);
+    const bool bad = lb != ignore_index && (lb < 0 || lb >= C);
+    lse_out[R + r] = (lb == ignore_index) ? 0.f : (bad ? __builtin_nanf("") : lse - to_f(x[bad ? 0 : lb]));
   }
 }
 // roww == nullptr: mean over the non-ignored rows; else the WEIGHTED SUM  sum_r roww[r] * rowloss[r]  (no normalisation)
@@ -148,7 +151,8 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
     for (int c = threadIdx.x; c < C; c += blockDim.x) d[c] = from_f<T>(0.f);
     return;
   }
-  const float g = roww ? gout[0] * weight * roww[r] : gout[0] * weight / (float)valid[0];
+  float g = roww ? gout[0] * weight * roww[r] : gout[0] * weight / (float)valid[0];
+  if (lb < 0 || lb >= C) g = __builtin_nanf("");          // out-of-range label: a loud gradient row (see ce_row_kernel)
   const float l = lse[r];
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float p = __expf(to_f(x[c]) - l);

@@ -13,7 +13,7 @@ int evlm_set_error(const char* fmt, ...) {
   return 1;
 }
 extern "C" const char* evlm_last_error(void) { return g_err; }
-extern "C" int evlm_abi_version(void) { return 1; }
+extern "C" int evlm_abi_version(void) { return 2; }
 
 // ---- BERT embeddings -------------------------------------------------------------------------
 template <typename T>
@@ -486,5 +486,58 @@ extern "C" int evlm_l2norm_bwd(int dtype, const void* y, const void* dy, const f
   EVLM_DISPATCH_DTYPE(dtype, "evlm_l2norm_bwd",
     hipLaunchKernelGGL((l2norm_bwd_kernel<T>), dim3(ceil_div(rows, 4)), dim3(256), 0, stream, (const T*)y, (const T*)dy, inv_norm, d, (T*)dx, rows);)
   EVLM_LAUNCH_CHECK("evlm_l2norm_bwd");
+  return 0;
+}
+
+// ---- dropout (hidden states): y = x .* keep / (1 - p) (+ residual) --------------------------------
+// The same kernel is its own backward (dx = dy .* the regenerated mask).  8 elements per thread = two Philox blocks.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, const T* __restrict__ res, int64_t n, float p,
+                                                      const int64_t* __restrict__ state, uint32_t call, T* __restrict__ y) {
+  const DropRng r = drop_rng(state, call, p);
+  const int64_t nv = n >> 3;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nv; c += (int64_t)gridDim.x * blockDim.x) {
+    float v[8], rr[8];
+    load8<T>(x + c * 8, v);
+    if (res) load8<T>(res + c * 8, rr);
+    uint32_t o0[4], o1[4];
+    philox4(r, (uint64_t)c * 2, o0);
+    philox4(r, (uint64_t)c * 2 + 1, o1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = (o0[e] >= r.thresh ? v[e] * r.scale : 0.f) + (res ? rr[e] : 0.f);
+      v[4 + e] = (o1[e] >= r.thresh ? v[4 + e] * r.scale : 0.f) + (res ? rr[4 + e] : 0.f);
+    }
+    store8<T>(y + c * 8, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 7)) {
+    const int64_t i = (nv << 3) + threadIdx.x;
+    y[i] = from_f<T>(to_f(x[i]) * drop_factor(r, (uint64_t)i) + (res ? to_f(res[i]) : 0.f));
+  }
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(int64_t n, float p, const int64_t* __restrict__ state, uint32_t call,
+                                                           float* __restrict__ mask) {
+  const DropRng r = drop_rng(state, call, p);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    mask[i] = drop_factor(r, (uint64_t)i);
+}
+extern "C" int evlm_dropout(int dtype, const void* x, const void* residual, int64_t n, float p, const int64_t* rng_state,
+                            uint32_t call_id, void* y, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(x && y && rng_state && n > 0, "evlm_dropout: bad args");
+  EVLM_REQUIRE(p >= 0.f && p < 1.f, "evlm_dropout: p = %f outside [0, 1)", (double)p);
+  EVLM_REQUIRE(((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) % 16 == 0, "evlm_dropout: 16-byte alignment");
+  const int blocks = imin(ceil_div(ceil_div(n, 8), 256), 2048);
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_dropout",
+    hipLaunchKernelGGL((dropout_kernel<T>), dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, (const T*)x, (const T*)residual,
+                       n, p, rng_state, call_id, (T*)y);)
+  EVLM_LAUNCH_CHECK("evlm_dropout");
+  return 0;
+}
+extern "C" int evlm_dropout_mask(int64_t n, float p, const int64_t* rng_state, uint32_t call_id, float* mask, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(mask && rng_state && n > 0 && p >= 0.f && p < 1.f, "evlm_dropout_mask: bad args");
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(imin(ceil_div(n, 256), 2048)), dim3(256), 0, stream, n, p, rng_state, call_id, mask);
+  EVLM_LAUNCH_CHECK("evlm_dropout_mask");
   return 0;
 }

@@ -12,8 +12,12 @@ Arithmetic (all in libevlm_hip.so):
     MLM head                         -> gather rows, dense+GELU epilogue, LayerNorm, tied-decoder GEMM, fused CE (:1691-1702)
     causal LM head (VQA decoder)     -> causal flag of evlm_attention, tied-decoder GEMM, evlm_ce_weighted (:1332-1443)
 
-Dropout: the distillation recipe's parity configuration (and the bench) use p = 0; p > 0 raises rather than silently
-differing (RNG parity with the reference's CUDA dropout stream is not reproducible anyway).
+Dropout (hidden_dropout_prob / attention_probs_dropout_prob, eff_bert.py:180,214,242,346,372-379,456-460): in training
+mode with p > 0 the hidden-state sites run evlm_dropout (fused with the "+ input_tensor" that feeds the LayerNorm) and
+the attention kernels drop the probabilities that form the context; masks are counter-based (Philox, keyed by a device
+{seed, step} word and a per-site call id) and regenerated in backward - no mask tensor exists.  eval() models and p = 0
+take the fully fused p = 0 path.  The reference's CUDA RNG stream is not reproducible: parity tests feed
+the SAME masks to the oracle (ops.dropout_mask).
 """
 import math
 
@@ -31,10 +35,11 @@ __all__ = ["BertConfig", "BertModel", "BertForMaskedLM", "BertEmbeddings", "Bert
            "CausalLMOutputWithCrossAttentions", "CausalMask"]
 
 
-def _check_dropout(p, what):
-    if p and p > 0:
-        raise NotImplementedError(f"{what} = {p}: the HIP path implements the p = 0 configuration used for parity and "
-                                  "benchmarking; set hidden_dropout_prob = attention_probs_dropout_prob = 0")
+def _p(config, name):
+    p = float(getattr(config, name, 0.0) or 0.0)
+    if not 0.0 <= p < 1.0:
+        raise ValueError(f"{name} = {p} must lie in [0, 1)")
+    return p
 
 
 class BertEmbeddings(nn.Module):
@@ -46,7 +51,7 @@ class BertEmbeddings(nn.Module):
         self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)
         self.token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size)
         self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
-        _check_dropout(config.hidden_dropout_prob, "hidden_dropout_prob")
+        self.hidden_dropout_prob = _p(config, "hidden_dropout_prob")
         self.register_buffer("position_ids", torch.arange(config.max_position_embeddings).expand((1, -1)))
         self.position_embedding_type = getattr(config, "position_embedding_type", "absolute")
         if self.position_embedding_type != "absolute":
@@ -61,7 +66,8 @@ class BertEmbeddings(nn.Module):
         L = input_ids.shape[1]
         e = ops.bert_embed(input_ids, self.word_embeddings.weight, self.position_embeddings.weight[:L],
                            self.token_type_embeddings.weight, self.config.pad_token_id, compute_dtype())
-        return ops.layer_norm(e, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+        e = ops.layer_norm(e, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+        return ops.dropout(e, self.hidden_dropout_prob, self.training)                  # eff_bert.py:214
 
 
 class BertSelfAttention(nn.Module):
@@ -81,7 +87,7 @@ class BertSelfAttention(nn.Module):
         kv_in = config.encoder_width if is_cross_attention else config.hidden_size
         self.key = nn.Linear(kv_in, self.all_head_size)
         self.value = nn.Linear(kv_in, self.all_head_size)
-        _check_dropout(config.attention_probs_dropout_prob, "attention_probs_dropout_prob")
+        self.attention_probs_dropout_prob = _p(config, "attention_probs_dropout_prob")
         self.is_cross_attention = is_cross_attention
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
@@ -95,16 +101,18 @@ class BertSelfAttention(nn.Module):
             raise NotImplementedError("head_mask / past_key_value are off the distillation path")
         H, dh = self.num_attention_heads, self.attention_head_size
         scale = 1.0 / math.sqrt(dh)
+        drop = self.attention_probs_dropout_prob if self.training else 0.0          # eff_bert.py:346 (probs returned un-dropped)
         if encoder_hidden_states is not None:
             q = ops.linear(hidden_states, self.query.weight, self.query.bias)
             kv = ops.linear_packed(encoder_hidden_states, (self.key.weight, self.value.weight), (self.key.bias, self.value.bias))
             ctx, probs = ops.cross_attention(q, kv, H, dh, scale, mask=_key_mask(encoder_attention_mask), gate=head_z,
-                                             want_probs=bool(output_attentions), kv_index=encoder_batch_index)
+                                             want_probs=bool(output_attentions), kv_index=encoder_batch_index, dropout_p=drop)
         else:
             qkv = ops.linear_packed(hidden_states, (self.query.weight, self.key.weight, self.value.weight),
                                     (self.query.bias, self.key.bias, self.value.bias))
             ctx, probs = ops.self_attention(qkv, H, dh, scale, mask=_key_mask(attention_mask), gate=head_z,
-                                            want_probs=bool(output_attentions), causal=isinstance(attention_mask, CausalMask))
+                                            want_probs=bool(output_attentions), causal=isinstance(attention_mask, CausalMask),
+                                            dropout_p=drop)
         outputs = (ctx, probs) if output_attentions else (ctx,)
         return outputs + (None,)
 
@@ -139,12 +147,16 @@ class BertSelfOutput(nn.Module):
         super().__init__()
         self.dense = nn.Linear(config.hidden_size, config.hidden_size)
         self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
-        _check_dropout(config.hidden_dropout_prob, "hidden_dropout_prob")
+        self.hidden_dropout_prob = _p(config, "hidden_dropout_prob")
 
     def forward(self, hidden_states, input_tensor, head_layer_z=None):
         if head_layer_z is not None:
             raise NotImplementedError("head_layer_z is dead plumbing in the reference (BertEncoder never forwards it)")
-        h = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor)
+        if self.training and self.hidden_dropout_prob > 0.0:         # LayerNorm(dropout(dense(h)) + input), eff_bert.py:374-381
+            h = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
+            h = ops.dropout(h, self.hidden_dropout_prob, True, residual=input_tensor)
+        else:                                                        # p = 0 / eval: the residual rides on the GEMM epilogue
+            h = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor)
         return ops.layer_norm(h, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
 
 
@@ -199,10 +211,14 @@ class BertOutput(nn.Module):
         super().__init__()
         self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
         self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
-        _check_dropout(config.hidden_dropout_prob, "hidden_dropout_prob")
+        self.hidden_dropout_prob = _p(config, "hidden_dropout_prob")
 
     def forward(self, hidden_states, input_tensor):
-        h = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor)
+        if self.training and self.hidden_dropout_prob > 0.0:         # eff_bert.py:458-462
+            h = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
+            h = ops.dropout(h, self.hidden_dropout_prob, True, residual=input_tensor)
+        else:
+            h = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor)
         return ops.layer_norm(h, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
 
 
@@ -255,8 +271,12 @@ class BertLayer(nn.Module):
     def feed_forward_chunk(self, attention_output):
         """eff_bert.py:552-560: gelu(dense(x)) * mlp_z -> dense -> +x -> LayerNorm (the gate comes AFTER the activation)"""
         o = self.output
+        drop = o.hidden_dropout_prob if self.training else 0.0
         h = ops.mlp(attention_output, self.intermediate.dense.weight, self.intermediate.dense.bias, o.dense.weight,
-                    o.dense.bias, ACT_GELU, gate=self.mlp_z, gate_pos=GATE_POST, residual=attention_output)
+                    o.dense.bias, ACT_GELU, gate=self.mlp_z, gate_pos=GATE_POST,
+                    residual=None if drop > 0.0 else attention_output)
+        if drop > 0.0:                                               # BertOutput: LayerNorm(dropout(dense(h)) + input), :458-462
+            h = ops.dropout(h, drop, True, residual=attention_output)
         return ops.layer_norm(h, o.LayerNorm.weight, o.LayerNorm.bias, o.LayerNorm.eps)
 
 

@@ -590,7 +590,8 @@ class _Attention(torch.autograd.Function):
     v_off (qbuf is kvbuf for self-attention).  Returns (O [B,Lq,H*dh], P [B,H,Lq,Lk])."""
 
     @staticmethod
-    def forward(ctx, qbuf, kvbuf, mask, gate, H, dh, q_off, k_off, v_off, scale, want_probs, kv_index=None, causal=False):
+    def forward(ctx, qbuf, kvbuf, mask, gate, H, dh, q_off, k_off, v_off, scale, want_probs, kv_index=None, causal=False,
+                dropout_p=0.0):
         L.require_cuda(qbuf, kvbuf)
         assert qbuf.is_contiguous() and kvbuf.is_contiguous()
         B, Lq, ldq = qbuf.shape
@@ -609,6 +610,10 @@ class _Attention(torch.autograd.Function):
                           K=C.c_void_p(kvbuf.data_ptr() + k_off * es), V=C.c_void_p(kvbuf.data_ptr() + v_off * es),
                           kv_index=L.ptr(kv_index), mask=L.ptr(m32), head_gate=L.ptr(g32), scale=scale, O=L.ptr(O),
                           P=L.ptr(Pbuf), causal=int(bool(causal)))
+        drop = None
+        if dropout_p and dropout_p > 0.0:
+            drop = (float(dropout_p), dropout_state(dev), _next_drop_call("attention_probs", (B, H, Lq, Lk), dropout_p))
+            a.dropout_p, a.rng_state, a.call_id = drop[0], L.ptr(drop[1]), drop[2]
         L.check(_lib().evlm_attention_fwd(C.byref(a), L.stream()), "attention_fwd")
         if ATTN_FLOPS is not None:
             ATTN_FLOPS[0] += 4.0 * B * H * Lq * Lk * dh
@@ -616,6 +621,7 @@ class _Attention(torch.autograd.Function):
         ctx.save_for_backward(qbuf, kvbuf, Pbuf, g32, kv_index)
         ctx.meta = (H, dh, q_off, k_off, v_off, scale, qbuf is kvbuf or qbuf.data_ptr() == kvbuf.data_ptr(),
                     gate.shape if gate is not None else None)
+        ctx.drop = drop
         return O, P
 
     @staticmethod
@@ -649,33 +655,130 @@ class _Attention(torch.autograd.Function):
                           kv_index=L.ptr(kv_index), head_gate=L.ptr(g32), scale=scale, dS=L.ptr(dS),
                           dQ=C.c_void_p(dqbuf.data_ptr() + q_off * es), dK=C.c_void_p(dkvbuf.data_ptr() + k_off * es),
                           dV=C.c_void_p(dkvbuf.data_ptr() + v_off * es), dgate=L.ptr(dgate))
+        if ctx.drop is not None:          # the keep-mask is regenerated from the same (state, call id), never stored
+            a.dropout_p, a.rng_state, a.call_id = ctx.drop[0], L.ptr(ctx.drop[1]), ctx.drop[2]
+            if kv_index is not None:      # generic kernels accumulate shared K/V gradients with f32 atomics
+                raise RuntimeError("attention-probability dropout with a shared K/V index: materialise the gather first")
         L.check(_lib().evlm_attention_bwd(C.byref(a), L.stream()), "attention_bwd")
         if ATTN_FLOPS is not None:
             ATTN_FLOPS[0] += 8.0 * B * H * Lq * Lk * dh          # dP, dV, dQ, dK (P is read back, not recomputed)
         dg = dgate.view(gshape) if dgate is not None else None
         if self_attn:
-            return dqbuf, None, None, dg, None, None, None, None, None, None, None, None, None
-        return dqbuf, dkvbuf, None, dg, None, None, None, None, None, None, None, None, None
+            return (dqbuf, None, None, dg) + (None,) * 10
+        return (dqbuf, dkvbuf, None, dg) + (None,) * 10
 
 
-def self_attention(qkv, H, dh, scale, mask=None, gate=None, want_probs=True, causal=False):
+def self_attention(qkv, H, dh, scale, mask=None, gate=None, want_probs=True, causal=False, dropout_p=0.0):
     """qkv: [B, L, 3*H*dh] packed (q | k | v); causal: additionally -10000 on keys after the query (decoder self-attention:
-    the backward works from the saved probabilities, so only the forward kernel knows about masks)"""
+    the backward works from the saved probabilities, so only the forward kernel knows about masks); dropout_p: dropout of
+    the probabilities that form the context (the returned map stays un-dropped, eff_bert.py:338-361)"""
     d = H * dh
-    return _Attention.apply(qkv, qkv, mask, gate, H, dh, 0, d, 2 * d, scale, want_probs, None, causal)
+    return _Attention.apply(qkv, qkv, mask, gate, H, dh, 0, d, 2 * d, scale, want_probs, None, causal, dropout_p)
 
 
-def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True, kv_index=None):
+def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True, kv_index=None, dropout_p=0.0):
     """q: [B, Lq, H*dh]; kv: [Bkv, Lk, 2*H*dh] packed (k | v).  kv_index (int32 [B]) maps each query batch to its K/V
     row, so image tokens shared by several text batches are projected (and their gradient reduced) once."""
     d = H * dh
     if kv_index is not None:
-        if q.dtype == torch.bfloat16 and dh == 64 and kv.shape[1] <= 928:
+        if q.dtype == torch.bfloat16 and dh == 64 and kv.shape[1] <= 928 and not dropout_p:
             kv_index = kv_index.to(torch.int32).contiguous()
         else:                                   # exact-fp32 / generic path: materialise the gather (autograd scatters back)
             kv = torch.index_select(kv, 0, kv_index.long())
             kv_index = None
-    return _Attention.apply(q, kv, mask, gate, H, dh, 0, 0, d, scale, want_probs, kv_index)
+    return _Attention.apply(q, kv, mask, gate, H, dh, 0, 0, d, scale, want_probs, kv_index, False, dropout_p)
+
+
+# ---------------------------------------------------------------------------------------------------
+# dropout (counter-based masks: regenerated in backward, never stored)
+# ---------------------------------------------------------------------------------------------------
+_DROP_STATE = {}
+_DROP_CALL = [0]
+DROPOUT_LOG = None        # tests: set to a list to collect (call id, kind, shape, p) of every dropout site of a forward
+DROPOUT_USED = False      # a trainer bumps the device-side step word once per step while this is set
+
+
+def dropout_state(device):
+    """device int64[2] {seed, step} every dropout site of this device draws from (evlm_dropout, include/evlm_hip.h)"""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = str(device)
+    st = _DROP_STATE.get(key)
+    if st is None:
+        st = _DROP_STATE[key] = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+    return st
+
+
+def dropout_seed(seed, device="cuda"):
+    """re-seed the dropout stream of `device` (step counter back to 0)"""
+    st = dropout_state(torch.device(device))
+    st.copy_(torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
+
+
+def dropout_tick(device="cuda"):
+    """advance the step word ON THE DEVICE (capturable): masks of a replayed hipGraph change from replay to replay"""
+    st = dropout_state(torch.device(device))
+    st[1:].add_(1)
+
+
+def _next_drop_call(kind, shape, p):
+    global DROPOUT_USED
+    DROPOUT_USED = True
+    _DROP_CALL[0] = (_DROP_CALL[0] + 1) & 0xFFFFFFFF
+    if DROPOUT_LOG is not None:
+        DROPOUT_LOG.append((_DROP_CALL[0], kind, tuple(shape), float(p)))
+    return _DROP_CALL[0]
+
+
+def dropout_mask(call_id, shape, p, device="cuda"):
+    """keep / (1 - p) of dropout site `call_id` as an f32 tensor of `shape` (what the kernels regenerate on the fly; tests
+    hand it to the CPU oracle)"""
+    n = 1
+    for v in shape:
+        n *= v
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    L.check(_lib().evlm_dropout_mask(n, float(p), L.ptr(dropout_state(torch.device(device))), call_id, L.ptr(out), L.stream()),
+            "dropout_mask")
+    return out.view(*shape)
+
+
+class _Dropout(torch.autograd.Function):
+    """y = x .* keep / (1 - p) (+ residual); backward is the same kernel on dy"""
+
+    @staticmethod
+    def forward(ctx, x, residual, p):
+        L.require_cuda(x)
+        xc = x if x.is_contiguous() else x.contiguous()
+        rc = None
+        if residual is not None:
+            rc = residual if residual.is_contiguous() else residual.contiguous()
+            if rc.shape != xc.shape or rc.dtype != xc.dtype:
+                raise RuntimeError("dropout: residual must match the input")
+        st = dropout_state(x.device)
+        call = _next_drop_call("hidden", xc.shape, p)
+        y = torch.empty_like(xc)
+        L.check(_lib().evlm_dropout(L.dt(xc), L.ptr(xc), L.ptr(rc), xc.numel(), float(p), L.ptr(st), call, L.ptr(y), L.stream()),
+                "dropout")
+        ctx.meta = (float(p), st, call, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, st, call, has_res = ctx.meta
+        dyc = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty_like(dyc)
+        L.check(_lib().evlm_dropout(L.dt(dyc), L.ptr(dyc), None, dyc.numel(), p, L.ptr(st), call, L.ptr(dx), L.stream()), "dropout")
+        return dx, (dy if has_res else None), None
+
+
+def dropout(x, p, training=True, residual=None):
+    """nn.Dropout(p)(x) [+ residual]: identity (plus the residual) when p == 0 or not training"""
+    if not training or not p or p <= 0.0:
+        if residual is not None:
+            raise RuntimeError("dropout(p = 0) with a residual: fuse the residual into the producing GEMM instead")
+        return x
+    return _Dropout.apply(x, residual, float(p))
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -57,6 +57,7 @@ class FlatAdamW:
             groups[gi]["names"].append(n)
         self.groups = [g for g in groups if g["params"]]
         self.step_count = 0
+        self._scheduled, self._last_mult = False, 1.0      # has set_schedule() run since the last step()?
         dev = named[0][1].device
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.hyper = torch.ones(3, dtype=torch.float32, device=dev)       # {lr multiplier, bias_c1, bias_c2}
@@ -116,6 +117,7 @@ class FlatAdamW:
 
     def set_schedule(self, lr_mult=1.0):
         """host-side per-step scalars -> device (call OUTSIDE a captured graph, before replay)"""
+        self._scheduled, self._last_mult = True, lr_mult
         self.step_count += 1
         b1, b2 = self.betas
         # a FRESH pinned block per step: the host may run several (graph-replayed) steps ahead of the device, so a
@@ -127,8 +129,18 @@ class FlatAdamW:
         self.hyper.copy_(host, non_blocking=True)
 
     def step(self):
-        """clip by global norm + AdamW; pure device work (capturable).  Gradients must live in the flat slabs."""
+        """clip by global norm + AdamW; pure device work (capturable).  Gradients must live in the flat slabs.
+        A reference-style loop (optimizer.step() with no scheduler call, optim.py:67 + GeneralDistill.py:386) never calls
+        set_schedule(): the step then advances the count itself with the last lr multiplier, so Adam's bias corrections
+        are never silently left at 1.  Under hipGraph capture the scalars cannot be staged from here: that is an error."""
         lib = L.load()
+        if not self._scheduled:
+            if self.hyper.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FlatAdamW.step() captured into a hipGraph without set_schedule(): call "
+                                   "set_schedule(lr_mult) before every replay (it stages the step's lr multiplier and "
+                                   "bias corrections on the device)")
+            self.set_schedule(self._last_mult)
+        self._scheduled = False
         for g in self.groups:               # autograd may have re-pointed .grad if a view was replaced: re-anchor
             off = 0
             for p in g["params"]:

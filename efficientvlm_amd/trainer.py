@@ -96,6 +96,19 @@ class GradReducer:
         self.finish()
 
 
+def broadcast_parameters(opt, src=0):
+    """rank `src`'s student parameters to every rank, slab by slab (apex_ddp_accelerator.py:75-77 broadcasts every
+    state-dict tensor at set-up; torch DDP - Eff_Retrieval.py:449, Eff_VQA.py:327 - does it at construction).  The drivers
+    seed with args.seed + rank and the L0 log-alphas are drawn with normal_(), so without this the replicas start - and,
+    with only gradients averaged, stay - different.  The bf16 mirrors the GEMMs read are re-derived."""
+    if not dist_ready():
+        return
+    for g in opt.groups:
+        dist.broadcast(g["p"], src)
+        if g.get("pb") is not None:
+            ops.CACHE.refresh_slab(g["p"], g["pb"])
+
+
 def teacher_map_filter(student, teacher, with_cross):
     """The KD terms read every k-th attention map of the (deeper) teacher (get_cor_teacher: map i*k + k-1 for student map i;
     GD reads no cross-attention map, the ITR fine-tune does): tell the frozen teacher's encoders to materialise only those.
@@ -129,6 +142,7 @@ class GDTrainer:
         self.student, self.teacher = student, teacher
         self.pipeline_teacher = pipeline_teacher
         self._keep_ST, self._last_ST = False, None
+        self.last_kd = {}
         self.dtype, self.temperature = dtype, temperature
         for p in teacher.parameters():
             p.requires_grad_(False)
@@ -159,10 +173,7 @@ class GDTrainer:
         self._tpool = self._spool = None
         self._joint = {}
         if self.world > 1:
-            for g in self.opt.groups:                     # broadcast params from rank 0 (apex_ddp_accelerator.py:75-77)
-                dist.broadcast(g["p"], 0)
-                if g.get("pb") is not None:               # ... and re-derive the bf16 mirror the GEMMs read
-                    ops.CACHE.refresh_slab(g["p"], g["pb"])
+            broadcast_parameters(self.opt)
 
     # ---- the step body (pure device work) ----------------------------------------------------------
     def _forward_backward(self, batch, teacher_out=None):
@@ -172,6 +183,8 @@ class GDTrainer:
                                                       overlap_teacher=self.overlap_teacher, teacher_out=teacher_out)
             if self._keep_ST:
                 self._last_ST = (S, T)
+            # the individual KD terms of this step (device scalars; under capture: static tensors of that graph)
+            self.last_kd = {k: v.detach() for k, v in kd.items() if torch.is_tensor(v)}
             ops.WGRAD_INPLACE = self.wgrad_inplace      # kernels sum parameter gradients straight into the flat slabs
             ops.WGRAD_DEFER = [] if (self.wgrad_inplace and self.defer_wgrad) else None   # ... dW products grouped per K
             try:
@@ -180,6 +193,8 @@ class GDTrainer:
             finally:
                 ops.WGRAD_INPLACE = False
                 ops.WGRAD_DEFER = None
+        if ops.DROPOUT_USED:              # p > 0 configurations: next step (next graph replay) draws new masks
+            ops.dropout_tick(total.device)
         return torch.stack([total.detach().float(), S["loss"]["loss_itc"].detach().float(),
                             S["loss"]["loss_itm"].detach().float(), S["loss"]["loss_mlm"].detach().float(),
                             mix["loss_kd"].detach().float()])
@@ -327,9 +342,9 @@ class GDTrainer:
                 with torch.cuda.graph(g, pool=self._spool):
                     res = self._joint_body(pipe, p, pp, pk)
                 self._spool = g.pool()
-                jg = self._joint[key] = (g, res)
+                jg = self._joint[key] = (g, res, self.last_kd)
             jg[0].replay()
-            out = jg[1]
+            out, self.last_kd = jg[1], jg[2]
         else:
             side.wait_stream(cur)                 # inputs copied; every earlier reader of this parity's buffers is done
             with torch.cuda.stream(side):
@@ -369,7 +384,7 @@ class GDTrainer:
         sig = tuple(sorted((k, tuple(v.shape)) for k, v in batch.items()))     # one hipGraph per batch kind / shape
         if sig not in self._graphs:
             self._graphs[sig] = self._capture(batch)
-        graph, static, out = self._graphs[sig]
+        graph, static, out, self.last_kd = self._graphs[sig]
         self.graph, self.static, self.out = graph, static, out
         self.opt.set_schedule(lr_mult)
         for k, v in batch.items():
@@ -389,6 +404,7 @@ class GDTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ops.CACHE.invalidate()                             # capture the casts of the trainable weights too
+        self.opt.set_schedule(0.0)                         # (the captured optimiser step reads the staged scalars at replay)
         graph = torch.cuda.CUDAGraph()
         pool = next(iter(self._graphs.values()))[0].pool() if self._graphs else None   # the kinds never run concurrently
         with torch.cuda.graph(graph, pool=pool):
@@ -398,7 +414,7 @@ class GDTrainer:
             g["m"].copy_(m)
             g["v"].copy_(v)
         self.opt.step_count = state[1]
-        return graph, static, out
+        return graph, static, out, self.last_kd
 
 
 class TeacherPrefetch:
@@ -475,8 +491,10 @@ class ITRTrainer:
         teacher.eval()
         student.train()
         self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=0.0)
-        self.l0_opt, self.lagrangian_opt = create_L0_optimizer({"reg_learning_rate": reg_learning_rate}, student.l0_module)
         self.reducer = GradReducer(self.opt.flat_grads)
+        if self.reducer.active:
+            broadcast_parameters(self.opt)      # gates and multipliers included: they are members of the main groups
+        self.l0_opt, self.lagrangian_opt = create_L0_optimizer({"reg_learning_rate": reg_learning_rate}, student.l0_module)
         self.defer_wgrad = dtype == torch.bfloat16 and not os.environ.get("EVLM_NO_DEFER_WGRAD")
         self.overlap_teacher = not os.environ.get("EVLM_NO_OVERLAP_TEACHER")
         if not os.environ.get("EVLM_TEACHER_ALL_MAPS"):
@@ -550,8 +568,10 @@ class VQATrainer:
         teacher.eval()
         student.train()
         self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=0.0)
-        self.l0_opt, self.lagrangian_opt = create_L0_optimizer({"reg_learning_rate": reg_learning_rate}, student.l0_module)
         self.reducer = GradReducer(self.opt.flat_grads)
+        if self.reducer.active:
+            broadcast_parameters(self.opt)      # gates and multipliers included: they are members of the main groups
+        self.l0_opt, self.lagrangian_opt = create_L0_optimizer({"reg_learning_rate": reg_learning_rate}, student.l0_module)
         self.defer_wgrad = dtype == torch.bfloat16 and not os.environ.get("EVLM_NO_DEFER_WGRAD")
         self.overlap_teacher = not os.environ.get("EVLM_NO_OVERLAP_TEACHER")
         self.global_step = 0

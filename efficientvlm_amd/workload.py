@@ -47,15 +47,15 @@ def make_batch(geom, B, seed, ragged=False, image_res=None):
                 masked_pos=masked_pos, masked_ids=masked_ids)
 
 
-def model_config(geom, role, image_res=None, sparsity=0.25):
+def model_config(geom, role, image_res=None, sparsity=0.25, dropout=0.0):
     """the config dict the reference constructors take (Pretrain_XVLM_small_4m.yaml keys), with the json files inlined"""
     vit_layers, text_layers = geom[f"{role}_vit_layers"], geom[f"{role}_text_layers"]
     vision = {"ckpt": "none", "vision_width": geom["hidden"], "patch_size": 16, "hidden_act": "quick_gelu",
               "num_attention_heads": geom["heads"], "attention_dropout": 0.0, "intermediate_size": geom["ffn"],
               "num_hidden_layers": vit_layers, "local_attn_depth": 2 if vit_layers == 6 else 4}
     bert = {"hidden_size": geom["hidden"], "num_attention_heads": geom["heads"], "intermediate_size": geom["ffn"],
-            "num_hidden_layers": 12, "hidden_act": "gelu", "hidden_dropout_prob": 0.0,
-            "attention_probs_dropout_prob": 0.0, "layer_norm_eps": 1e-12, "max_position_embeddings": geom["max_pos"],
+            "num_hidden_layers": 12, "hidden_act": "gelu", "hidden_dropout_prob": dropout,
+            "attention_probs_dropout_prob": dropout, "layer_norm_eps": 1e-12, "max_position_embeddings": geom["max_pos"],
             "type_vocab_size": 2, "vocab_size": geom["vocab"], "pad_token_id": 0, "initializer_range": 0.02}
     return {"use_clip_vit": True, "use_swin": False, "vision_config": vision, "image_res": image_res or geom["image_res"],
             "patch_size": 16, "text_encoder": bert, "text_num_hidden_layers": text_layers, "embed_dim": geom["embed_dim"],

@@ -134,6 +134,10 @@ typedef struct {
   void* O; void* P;
   int causal;                   /* != 0: additionally add -10000 where key > query - the decoder's causal mask
                                    (get_extended_attention_mask is_decoder branch, eff_bert.py:975-996); needs Lq == Lk */
+  float dropout_p;              /* attention_probs_dropout_prob (eff_bert.py:242,346): O = ((P .* keep / (1-p)) V) * gate, while
+                                   the map written to P stays the un-dropped softmax (:338-361).  0 = off */
+  const int64_t* rng_state;     /* device int64[2] {seed, step} (see evlm_dropout); required when dropout_p > 0 */
+  uint32_t call_id;             /* identifies this dropout site; the backward call passes the same triple */
 } evlm_attn_fwd_args;
 int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream);
 
@@ -158,8 +162,25 @@ typedef struct {
   void* dS;
   void* dQ; void* dK; void* dV;
   float* dgate;
+  float dropout_p;              /* as in the forward call: the keep-mask is regenerated, never stored */
+  const int64_t* rng_state;
+  uint32_t call_id;
 } evlm_attn_bwd_args;
 int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dropout of hidden states:  y = x .* keep / (1 - p)  (+ residual),  keep ~ Bernoulli(1 - p) per element.
+ * Replaces nn.Dropout(hidden_dropout_prob) in BertEmbeddings (eff_bert.py:180,214), BertSelfOutput (:372,:379) and
+ * BertOutput (:456,:460); with `residual` it also forms the "+ input_tensor" the LayerNorm that follows consumes.
+ * The keep-mask is a pure function of (rng_state = device int64[2] {seed, step}, call_id, element index) - Philox4x32-10,
+ * counter {index / 4, call_id, step}, key seed - so the backward pass is THE SAME CALL on dy (residual NULL) and no mask
+ * tensor exists in HBM; a captured hipGraph draws new masks on every replay once `step` has been bumped on the device.
+ * evlm_dropout_mask writes keep / (1 - p) as f32 (tests feed it to the CPU oracle; the attention kernels index their
+ * mask by ((b*H + h)*Lq + q)*Lk + k).
+ * ---------------------------------------------------------------------------------------------- */
+int evlm_dropout(int dtype, const void* x, const void* residual, int64_t n, float p, const int64_t* rng_state,
+                 uint32_t call_id, void* y, void* stream);
+int evlm_dropout_mask(int64_t n, float p, const int64_t* rng_state, uint32_t call_id, float* mask, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Distillation / task losses.  Scalars are f32 DEVICE words; forward ACCUMULATES weight*term into

@@ -125,13 +125,28 @@ def vit_forward(sd, p, image, cfg, head_z=None, head_layer_z=None, mlp_z=None,
 # ---------------------------------------------------------------------------------------------
 # BERT text / fusion encoder  (efficient_models/eff_bert.py == models/xbert.py with z=None)
 # ---------------------------------------------------------------------------------------------
+# Dropout (eff_bert.py:214,346,379,460).  None = the p = 0 configuration of the fixtures.  Tests of the p > 0 path set this
+# to an iterator of keep / (1 - p) masks, one per dropout site in the order the reference module tree visits them
+# (embeddings; per layer: self-attention probabilities, self-output, [cross-attention probabilities, cross-output],
+# FFN output): the reference's CUDA RNG stream cannot be reproduced, the SAME mask on both sides can.
+DROPOUT_MASKS = None
+
+
+def _drop(x):
+    if DROPOUT_MASKS is None:
+        return x
+    m = next(DROPOUT_MASKS)
+    assert m.numel() == x.numel(), f"dropout site order mismatch: mask {tuple(m.shape)} vs {tuple(x.shape)}"
+    return x * m.view(x.shape)
+
+
 def bert_embeddings(sd, p, ids, eps):
-    """BertEmbeddings.forward, eff_bert.py:188-215 (token_type 0, absolute positions, dropout 0)"""
+    """BertEmbeddings.forward, eff_bert.py:188-215 (token_type 0, absolute positions; dropout :214 through _drop)"""
     L = ids.shape[1]
     # nn.Embedding(..., padding_idx=pad_token_id=0), eff_bert.py:171: the pad row gets no lookup gradient
     e = F.embedding(ids, sd[p + "word_embeddings.weight"], padding_idx=0) + sd[p + "token_type_embeddings.weight"][0]
     e = e + sd[p + "position_embeddings.weight"][:L][None]
-    return F.layer_norm(e, (e.shape[-1],), sd[p + "LayerNorm.weight"], sd[p + "LayerNorm.bias"], eps)
+    return _drop(F.layer_norm(e, (e.shape[-1],), sd[p + "LayerNorm.weight"], sd[p + "LayerNorm.bias"], eps))
 
 
 def bert_attention(sd, p, x, mask, heads, eps, enc=None, enc_mask=None, head_z=None):
@@ -151,11 +166,11 @@ def bert_attention(sd, p, x, mask, heads, eps, enc=None, enc_mask=None, head_z=N
     if m is not None:
         s = s + m                                                                        # :335
     probs = torch.softmax(s, dim=-1)
-    ctx = probs @ sh(v)
+    ctx = _drop(probs) @ sh(v)                                                           # :346-352 (probs returned un-dropped)
     if head_z is not None:
         ctx = ctx * head_z
     ctx = ctx.permute(0, 2, 1, 3).reshape(B, Lq, d)
-    o = F.linear(ctx, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+    o = _drop(F.linear(ctx, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"]))   # :375-379
     o = F.layer_norm(o + x, (d,), sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], eps)
     return o, probs
 
@@ -175,7 +190,7 @@ def bert_layer(sd, p, x, mask, cfg, has_cross, enc=None, enc_mask=None, head_z=N
     h = F.gelu(F.linear(a, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
     if mlp_z is not None:
         h = h * mlp_z
-    o = F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+    o = _drop(F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"]))   # :459-460
     o = F.layer_norm(o + a, (o.shape[-1],), sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], eps)
     return o, probs, cprobs
 

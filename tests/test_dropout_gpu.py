@@ -1,0 +1,214 @@
+"""Dropout with p > 0 (reference: efficient_models/eff_bert.py:180,214,242,346,372-379,456-460; the stock BERT config
+trains with 0.1).  The reference's CUDA RNG stream cannot be reproduced, so parity is established by feeding the SAME
+keep-masks to both sides: the HIP kernels regenerate their masks from (device {seed, step} word, call id, element index);
+ops.dropout_mask materialises exactly that function for the CPU oracle (oracle.xvlm_oracle.DROPOUT_MASKS)."""
+import math
+
+import pytest
+import torch
+
+from helpers import close, load_det_weights, model_config
+from oracle import schema, synth
+from oracle import xvlm_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hidden_dropout_kernel_is_its_own_backward_and_never_stores_a_mask(dtype):
+    from efficientvlm_amd import ops
+    ops.dropout_seed(1234)
+    g = torch.Generator().manual_seed(1)
+    for shape, p in (((7, 30, 768), 0.1), ((5, 13), 0.5), ((3, 8, 64), 0.25)):
+        x = torch.randn(shape, generator=g).to(DEV, dtype).requires_grad_(True)
+        r = torch.randn(shape, generator=g).to(DEV, dtype).requires_grad_(True)
+        ops.DROPOUT_LOG = []
+        y = ops.dropout(x, p, True, residual=r)
+        (call, kind, shp, pp), = ops.DROPOUT_LOG
+        ops.DROPOUT_LOG = None
+        m = ops.dropout_mask(call, shape, p)
+        assert set(torch.unique(m).tolist()) <= {0.0, float(torch.tensor(1.0 / (1.0 - p), dtype=torch.float32))}
+        keep = float((m > 0).float().mean())
+        n = m.numel()
+        assert abs(keep - (1 - p)) < 5 * math.sqrt(p * (1 - p) / n) + 1e-3, (keep, p)
+        ref = (x.detach().float() * m + r.detach().float()).to(dtype)
+        assert torch.equal(y.detach(), ref)
+        gy = torch.randn(shape, generator=g).to(DEV, dtype)
+        y.backward(gy)
+        assert torch.equal(x.grad, (gy.float() * m).to(dtype)) and torch.equal(r.grad, gy)
+        # another site (call id) and another step draw other masks; the same triple reproduces the mask
+        y2 = ops.dropout(x.detach(), p, True)
+        assert not torch.equal((y2 != 0), (m != 0) & (x.detach() != 0))
+        assert torch.equal(ops.dropout_mask(call, shape, p), m)
+        ops.dropout_tick()
+        assert not torch.equal(ops.dropout_mask(call, shape, p), m)
+    # identity outside training / at p = 0
+    x = torch.randn(4, 8, device=DEV)
+    assert ops.dropout(x, 0.1, False) is x and ops.dropout(x, 0.0, True) is x
+
+
+@pytest.mark.parametrize("dtype,cross", [(torch.float32, False), (torch.float32, True), (torch.bfloat16, False),
+                                         (torch.bfloat16, True)])
+def test_attention_probability_dropout_against_torch_with_the_same_mask(dtype, cross):
+    """O = ((P .* M) V) * gate with the map P returned un-dropped; dQ / dK / dV (and the map's external gradient) through
+    the regenerated mask"""
+    from efficientvlm_amd import ops
+    ops.dropout_seed(99)
+    g = torch.Generator().manual_seed(3)
+    B, H, dh, Lq, Lk, p = 3, 4, 16, 9, (21 if cross else 9), 0.2
+    d = H * dh
+    tol = 2e-5 if dtype == torch.float32 else 2.5e-2
+    mask = torch.zeros(B, Lk)
+    mask[1, Lk - 3:] = -10000.0
+    gate = torch.rand(H, generator=g) + 0.5
+    if cross:
+        q = (torch.randn(B, Lq, d, generator=g) * 0.5).to(DEV, dtype).requires_grad_(True)
+        kv = (torch.randn(B, Lk, 2 * d, generator=g) * 0.5).to(DEV, dtype).requires_grad_(True)
+        ops.DROPOUT_LOG = []
+        Oo, P = ops.cross_attention(q, kv, H, dh, 1.0 / math.sqrt(dh), mask=mask.to(DEV), gate=gate.to(DEV), dropout_p=p)
+        qr, kr, vr = q.detach().float(), kv.detach().float()[..., :d], kv.detach().float()[..., d:]
+    else:
+        qkv = (torch.randn(B, Lq, 3 * d, generator=g) * 0.5).to(DEV, dtype).requires_grad_(True)
+        ops.DROPOUT_LOG = []
+        Oo, P = ops.self_attention(qkv, H, dh, 1.0 / math.sqrt(dh), mask=mask.to(DEV), gate=gate.to(DEV), dropout_p=p)
+        x = qkv.detach().float()
+        qr, kr, vr = x[..., :d], x[..., d:2 * d], x[..., 2 * d:]
+    (call, kind, shp, pp), = ops.DROPOUT_LOG
+    ops.DROPOUT_LOG = None
+    assert kind == "attention_probs" and shp == (B, H, Lq, Lk)
+    M = ops.dropout_mask(call, (B, H, Lq, Lk), p)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (qr, kr, vr))
+    sp = lambda t, Ln: t.reshape(B, Ln, H, dh).transpose(1, 2)
+    S = sp(qr, Lq) @ sp(kr, Lk).transpose(-1, -2) / math.sqrt(dh) + mask.to(DEV)[:, None, None, :]
+    Pr = torch.softmax(S, -1)
+    Or = ((Pr * M) @ sp(vr, Lk) * gate.to(DEV)[None, :, None, None]).transpose(1, 2).reshape(B, Lq, d)
+    assert rel_err(P.float(), Pr) < tol and rel_err(Oo.float(), Or) < 2 * tol
+    gO = torch.randn(B, Lq, d, generator=g).to(DEV, dtype)
+    gP = (torch.randn(B, H, Lq, Lk, generator=g) * 0.1).to(DEV, dtype)
+    ((Oo * gO).sum() + (P * gP).sum()).backward()
+    ((Or * gO.float()).sum() + (Pr * gP.float()).sum()).backward()
+    if cross:
+        assert rel_err(q.grad.float(), qr.grad) < 4 * tol
+        assert rel_err(kv.grad.float(), torch.cat([kr.grad, vr.grad], -1)) < 4 * tol
+    else:
+        assert rel_err(qkv.grad.float(), torch.cat([qr.grad, kr.grad, vr.grad], -1)) < 4 * tol
+
+
+def _models(p, seed=0):
+    from efficientvlm_amd.models.model_pretrain import XVLM
+    geom = synth.GEOMS["tiny"]
+    s_cfg = O.model_cfg(geom, "s")
+    student = XVLM(model_config(geom, "s", dropout=p))
+    s_sd = load_det_weights(student, schema.xvlm_schema(s_cfg, geom["max_pos"]), 400 + seed, geom["std"])
+    return geom, s_cfg, student.to(DEV), s_sd
+
+
+def _tie(sd):
+    return {**sd, "text_encoder.cls.predictions.decoder.weight": sd["text_encoder.bert.embeddings.word_embeddings.weight"],
+            "text_encoder.cls.predictions.decoder.bias": sd["text_encoder.cls.predictions.bias"]}
+
+
+def test_pretrain_forward_backward_with_dropout_matches_the_oracle_given_the_same_masks():
+    """X-VLM pre-training forward (text pass, ITM positive + hard-negative fusion passes, MLM pass) with the stock BERT
+    dropout 0.1 in train mode, pass by pass as the reference issues it, fp32: every loss, the MLM logits and the parameter
+    gradients against the oracle that multiplies by the SAME masks at the SAME sites (eff_bert.py:214,346,379,460)."""
+    from efficientvlm_amd import ops
+    from efficientvlm_amd.runtime import compute
+    geom, s_cfg, student, s_sd = _models(0.1)
+    student.train()
+    student.batched_passes = False                 # the reference's pass order = the oracle's dropout-site order
+    student.batched_itm = False                    # (positive and hard-negative fusion passes as two passes, xvlm.py:460-476)
+    ops.dropout_seed(7)
+    batch = synth.make_batch(geom, 4, seed=5, ragged=True)
+    neg = torch.tensor([1, 2, 3, 0, 2, 3, 0, 1])
+    student.injected_neg_idx = neg
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    ops.DROPOUT_LOG = []
+    with compute(torch.float32):
+        S = student(gb["image"], gb["text_ids"], gb["text_atts"], text_ids_masked=gb["text_ids_masked"],
+                    masked_pos=gb["masked_pos"], masked_ids=gb["masked_ids"], output_attentions=True, output_hidden_states=True)
+        total = S["loss"]["loss_itc"] + S["loss"]["loss_itm"] + S["loss"]["loss_mlm"]
+        total.backward()
+    log, ops.DROPOUT_LOG = ops.DROPOUT_LOG, None
+    n_layers_text, n_fusion = s_cfg["fusion_layer"], s_cfg["text_layers"] - s_cfg["fusion_layer"]
+    # text pass: 1 + 3 per text layer; each fusion pass: 5 per fusion layer; MLM pass: 1 + 3 per text layer + 5 per fusion layer
+    want = (1 + 3 * n_layers_text) + 2 * 5 * n_fusion + (1 + 3 * n_layers_text + 5 * n_fusion)
+    assert len(log) == want, (len(log), want)
+    masks = [ops.dropout_mask(c, shp, p).cpu() for c, kind, shp, p in log]
+    leaves = {k: v.clone().requires_grad_(True) for k, v in s_sd.items()}
+    O.DROPOUT_MASKS = iter(masks)
+    try:
+        oS = O.pretrain_forward(_tie(leaves), s_cfg, batch, neg)
+        assert next(O.DROPOUT_MASKS, None) is None, "the oracle visited fewer dropout sites than the HIP path"
+    finally:
+        O.DROPOUT_MASKS = None
+    ototal = oS["loss"]["loss_itc"] + oS["loss"]["loss_itm"] + oS["loss"]["loss_mlm"]
+    ototal.backward()
+    for k in S["loss"]:
+        close(S["loss"][k], oS["loss"][k], 1e-4, 0, k)
+    close(S["logits_dict"]["mlm_logits"].float(), oS["logits_dict"]["mlm_logits"], 1e-4, 1e-5, "mlm_logits")
+    for k, tup in S["attention_dict"].items():
+        for i, t in enumerate(tup):
+            close(t.float(), oS["attention_dict"][k][i], 1e-4, 1e-6, f"{k}.{i}")
+    n = 0
+    for name, p in student.named_parameters():
+        if p.grad is None or leaves[name].grad is None:
+            continue
+        ref = leaves[name].grad
+        close(p.grad, ref, 0, 1e-3 * float(ref.norm()) + 2e-6, f"grad {name}")
+        n += 1
+    assert n > 100
+    # and dropout really is active: the p = 0 losses differ
+    with torch.no_grad():
+        o0 = O.pretrain_forward(_tie(s_sd), s_cfg, batch, neg)
+    assert abs(float(o0["loss"]["loss_mlm"]) - float(oS["loss"]["loss_mlm"])) > 1e-4
+
+
+def test_eval_mode_and_frozen_teachers_build_from_the_stock_bert_config_and_ignore_dropout():
+    """a model built from a config with dropout 0.1 (runtime.BertConfig's defaults are the stock ones) runs in eval mode
+    exactly as the p = 0 model: dropout is an identity there (and nothing raises at construction any more)"""
+    from efficientvlm_amd.runtime import compute
+    geom, s_cfg, m1, _ = _models(0.1, seed=1)
+    _, _, m0, _ = _models(0.0, seed=1)
+    m1.eval(); m0.eval()
+    batch = {k: v.to(DEV) for k, v in synth.make_batch(geom, 3, seed=9).items()}
+    neg = torch.tensor([1, 2, 0, 2, 0, 1])
+    m1.injected_neg_idx = m0.injected_neg_idx = neg
+    kw = dict(text_ids_masked=batch["text_ids_masked"], masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"],
+              output_attentions=True, output_hidden_states=True)
+    with torch.no_grad(), compute(torch.float32):
+        a = m1(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+        b = m0(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+    for k in a["loss"]:
+        assert torch.equal(a["loss"][k], b["loss"][k]), k
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_gd_trainer_with_stock_dropout_draws_new_masks_every_step(use_graph):
+    """GDTrainer (bf16) with the stock BERT dropout 0.1 on the student: steps run, losses are finite, and with the
+    learning rate at 0 two steps on the SAME batch differ (new masks per step - also across hipGraph replays, through the
+    device-side step word) while the p = 0 student repeats its losses exactly"""
+    from efficientvlm_amd.models.model_pretrain import XVLM
+    from efficientvlm_amd.trainer import GDTrainer
+    geom = synth.GEOMS["tiny"]
+    batch = {k: v.to(DEV) for k, v in synth.make_batch(geom, 4, seed=2).items()}
+    outs = {}
+    for p in (0.1, 0.0):
+        torch.manual_seed(0)
+        student = XVLM(model_config(geom, "s", dropout=p)).to(DEV)
+        teacher = XVLM(model_config(geom, "t", dropout=0.1)).to(DEV)      # frozen / eval: dropout is an identity
+        neg = torch.tensor([1, 2, 3, 0, 2, 3, 0, 1])
+        student.injected_neg_idx = teacher.injected_neg_idx = neg
+        tr = GDTrainer(student, teacher, lr=0.0, dtype=torch.bfloat16, use_graph=use_graph)
+        outs[p] = torch.stack([tr.step(batch).clone() for _ in range(3)]).cpu()
+        assert torch.isfinite(outs[p]).all()
+    # column 3 = the MLM loss (no atomically accumulated sums in it: bit-stable when nothing changes)
+    assert float((outs[0.0][1, 3] - outs[0.0][2, 3]).abs()) <= 1e-6 * float(outs[0.0][1, 3].abs())
+    assert float((outs[0.1][1, 3] - outs[0.1][2, 3]).abs()) > 1e-4 * float(outs[0.1][1, 3].abs())
+    assert float((outs[0.1][0, 3] - outs[0.1][1, 3]).abs()) > 1e-4 * float(outs[0.1][1, 3].abs())
+    assert abs(float(outs[0.1][1, 0]) - float(outs[0.0][1, 0])) < 0.2 * abs(float(outs[0.0][1, 0]))

@@ -320,6 +320,24 @@ def test_losses(dtype):
     assert rel_err(y.float(), yr) < tol(dtype) and rel_err(x.grad.float(), xr.grad) < tol(dtype) * 2
 
 
+def test_cross_entropy_with_an_out_of_range_label_is_loud_not_out_of_bounds():
+    """a label outside [0, C) that is not the ignore index (corrupt masked_ids, vocabulary mismatch) must not index the
+    logits row: the loss and that row's gradient are NaN (F.cross_entropy would trip a device assert), the other rows'
+    gradients stay finite"""
+    o = ops()
+    g = torch.Generator().manual_seed(31)
+    R, Cn = 6, 40
+    for bad in (Cn, Cn + 100000, -7):
+        logits = rnd((R, Cn), torch.float32, g, 2.0).requires_grad_(True)
+        labels = torch.randint(0, Cn, (R,), generator=g)
+        labels[2] = bad
+        l = o.cross_entropy(logits, labels.to(DEV))
+        l.backward()
+        torch.cuda.synchronize()
+        assert torch.isnan(l)
+        assert torch.isnan(logits.grad[2]).all()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_embeddings_and_movement(dtype):
     o = ops()
@@ -511,6 +529,9 @@ def _pp256_case(o, L, g, I, J, K, qt=0, bias=False, res=False, act=0, dact=0):
     if dact:
         aux = rnd((I, J), dtype, g); kw.update(dact=dact, aux=aux, ldx=J)
     o._gemm(L.dt(dtype), Pm, Qm, Cm, I, J, K, Pm.stride(0), Qm.stride(0), J, q_trans=qt, **kw)
+    # the case must have been served by the kernel it is meant to test (a routing change would otherwise test another one)
+    served = L.load().evlm_gemm_last_kernel().decode()
+    assert served == f"gemm_bf16_pp256_kernel<false,{'true' if qt else 'false'},0>", served
     ref = Pm.float() @ (Qm.float() if qt else Qm.float().t())
     if bias:
         ref = ref + b
@@ -521,6 +542,9 @@ def _pp256_case(o, L, g, I, J, K, qt=0, bias=False, res=False, act=0, dact=0):
         ref = ref * torch.sigmoid(1.702 * ref)
     if dact == L.ACT_QUICK_GELU:
         x = aux.float(); s = torch.sigmoid(1.702 * x); ref = ref * (s + 1.702 * x * s * (1 - s))
+    if dact == L.ACT_GELU:
+        x = aux.float()
+        ref = ref * (0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * math.pi) ** 0.5)
     if res:
         ref = ref + r.float()
     assert rel_err(Cm.float(), ref) < tol(dtype), (I, J, K, qt, bias, res, act, dact)
@@ -540,6 +564,9 @@ def test_gemm_pp256_persistent_tiles_and_epilogues():
     _pp256_case(o, L, g, 6144, 2560, 320, bias=True, act=L.ACT_QUICK_GELU)       # pre-activation second output, odd K tiles
     _pp256_case(o, L, g, 4100, 4096, 256, bias=True, act=L.ACT_GELU)
     _pp256_case(o, L, g, 4096, 4096, 256, dact=L.ACT_QUICK_GELU)
+    _pp256_case(o, L, g, 4096 + 8, 4096, 192, dact=L.ACT_GELU)                   # text-side FFN backward (erf-GELU), ragged rows
+    _pp256_case(o, L, g, 4096, 4096 + 16, 192, qt=1, dact=L.ACT_GELU)
+    _pp256_case(o, L, g, 7680, 768, 768, bias=True, res=True)                    # the 4B-row fusion output projection (90 tiles)
     _pp256_case(o, L, g, 12608, 768, 768, bias=True, res=True)                   # the ViT out-projection shape (150 tiles)
     _pp256_case(o, L, g, 4096 + 24, 4096, 192, qt=1)                             # dX = dY W, W reduction-major
     _pp256_case(o, L, g, 12608, 768, 2304, qt=1)

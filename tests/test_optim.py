@@ -120,6 +120,40 @@ def test_flat_adamw_kernels_match_the_oracle():
 
 
 @pytest.mark.gpu
+def test_flat_adamw_reference_style_loop_without_scheduler_calls():
+    """optimizer.step() with no set_schedule() in between (the reference's loop shape, GeneralDistill.py:385-387 with a
+    constant factor): the step count and Adam's bias corrections still advance - three steps against the oracle - and a
+    step captured into a hipGraph without staged scalars is an error, not a silent bias-correction-free update"""
+    from efficientvlm_amd.optim import FlatAdamW
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.Linear(96, 8)).cuda()
+    ref = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    state = {n: (torch.zeros_like(v), torch.zeros_like(v)) for n, v in ref.items()}
+    groups = OO.param_groups(model.named_parameters(), None, 2e-3, 0.01, 1)
+    opt = FlatAdamW(model, lr=2e-3, weight_decay=0.01, lr_mult=1, max_grad_norm=0.0)
+    gen = torch.Generator().manual_seed(4)
+    for t in (1, 2, 3):
+        grads = {n: torch.randn(v.shape, generator=gen) for n, v in ref.items()}
+        opt.zero_grad()
+        for n, p in model.named_parameters():
+            p.grad.copy_(grads[n])
+        opt.step()                                   # no set_schedule()
+        assert opt.step_count == t
+        for g in groups:
+            for n in g["names"]:
+                OO.hf_adamw_step(ref[n], grads[n], state[n][0], state[n][1], t, g["lr"], (0.9, 0.98), 1e-8, g["weight_decay"])
+        for n, p in model.named_parameters():
+            assert float((p.detach().cpu() - ref[n]).abs().max()) <= 1e-6 * (1.0 + float(ref[n].abs().max())), (t, n)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="set_schedule"):
+        with torch.cuda.graph(graph, stream=side):
+            opt.step()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 def test_l0_optimisers_descend_gates_and_ascend_multipliers():
     """create_L0_optimizer (optim.py:4-21): +reg_lr on the log-alphas, -reg_lr on lambda_1/2, against the oracle;
     constrain_parameters clamps to [log 1e-2, log 1e2] (xvlm_l0_module.py:168-172)"""
