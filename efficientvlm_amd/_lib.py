@@ -38,7 +38,8 @@ class AttnFwdArgs(C.Structure):
                 ("ldq", _i), ("ldk", _i), ("ldv", _i), ("ldo", _i), ("ldpr", _i),
                 ("Q", _vp), ("K", _vp), ("V", _vp), ("kv_index", _vp), ("mask", _vp), ("head_gate", _vp),
                 ("scale", _f), ("O", _vp), ("P", _vp), ("causal", _i),
-                ("dropout_p", _f), ("rng_state", _vp), ("call_id", C.c_uint32)]
+                ("dropout_p", _f), ("rng_state", _vp), ("call_id", C.c_uint32),
+                ("kd_teacher", _vp), ("kd_loss", _vp), ("kd_weight", _f)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -49,7 +50,8 @@ class AttnBwdArgs(C.Structure):
                 ("Q", _vp), ("K", _vp), ("V", _vp), ("P", _vp), ("dO", _vp), ("dP_ext", _vp),
                 ("kv_index", _vp), ("head_gate", _vp), ("scale", _f),
                 ("dS", _vp), ("dQ", _vp), ("dK", _vp), ("dV", _vp), ("dgate", _vp),
-                ("dropout_p", _f), ("rng_state", _vp), ("call_id", C.c_uint32)]
+                ("dropout_p", _f), ("rng_state", _vp), ("call_id", C.c_uint32),
+                ("kd_teacher", _vp), ("kd_gout", _vp), ("kd_weight", _f)]
 
 
 # name -> argtypes (every symbol include/evlm_hip.h declares; tests check the library exports all of them)

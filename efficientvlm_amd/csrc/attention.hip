@@ -334,6 +334,8 @@ extern "C" int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream_) {
     if (int e = evlm_attention_fwd_mfma(a, stream, &handled)) return e;
   }
   if (handled) return 0;
+  EVLM_REQUIRE(!a->kd_teacher, "evlm_attention_fwd: the fused map distillation exists on the bf16 MFMA path only "
+               "(head dim 64, Lk <= 928, no dropout); use evlm_mse_fwd on the returned map");
   AttnF f;
   f.drop_p = a->dropout_p; f.rng = a->rng_state; f.call = a->call_id;
   f.Q = a->Q; f.K = a->K; f.V = a->V; f.kv_index = a->kv_index; f.mask = a->mask; f.gate = a->head_gate; f.causal = a->causal;
@@ -367,6 +369,7 @@ extern "C" int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream_) {
     if (int e = evlm_attention_bwd_mfma(a, stream, &handled)) return e;
     if (handled) return 0;
   }
+  EVLM_REQUIRE(!a->kd_teacher, "evlm_attention_bwd: the fused map distillation exists on the bf16 MFMA path only");
   AttnB g;
   g.drop_p = a->dropout_p; g.rng = a->rng_state; g.call = a->call_id;
   g.Q = a->Q; g.K = a->K; g.V = a->V; g.P = a->P; g.dO = a->dO; g.dPext = a->dP_ext; g.kv_index = a->kv_index;

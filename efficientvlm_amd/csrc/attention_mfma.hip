@@ -14,6 +14,7 @@ struct MAttnF {
   int B, H, Lq, Lk, ldq, ldk, ldv, ldo, ldpr;
   float scale;
   int causal;
+  const bf16* Pt; float* kd; float kd_coef;      // fused map distillation: *kd += kd_coef * sum((P - Pt)^2)
 };
 
 #define DH 64
@@ -100,6 +101,8 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   if (!SEQ) stage_rows<true>(Vb, a.ldv, a.Lk, NT * 16, Vs);
   for (int k = threadIdx.x; k < NT * 16; k += blockDim.x)
     Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
+  float* kdw = Ms + NT * 16;                     // {partial sum, arrived waves} of the fused map distillation
+  if (threadIdx.x < 2) kdw[threadIdx.x] = 0.f;
   stage_wait();
   __syncthreads();
 
@@ -197,13 +200,43 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
       *reinterpret_cast<bf16x4*>(Or + dt * 16 + g * 4) = ov;
     }
   }
+  if (a.Pt) {
+    // attention-map distillation while the (bf16-rounded, as stored) probabilities are still in registers
+    // (placed after the P V product: fewest live registers): the teacher's map is
+    // read once, the student's not at all; one atomic per WORKGROUP (the waves meet in LDS, last arriver publishes)
+    float sq = 0.f;
+    if (qok) {
+      const bf16* Tr = a.Pt + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr;
+#pragma unroll
+      for (int s = 0; s < NT / 2; ++s) {
+        const int kcol = s * 32 + g * 8;
+        if (kcol < a.ldpr) {
+          const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(Tr + kcol);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d0 = (float)pk[2 * s][r] - (float)t8[r], d1 = (float)pk[2 * s + 1][r] - (float)t8[4 + r];
+            sq = fmaf(d0, d0, sq);
+            sq = fmaf(d1, d1, sq);
+          }
+        }
+      }
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) {
+      const int qb = blockIdx.x * (blockDim.x >> 6) * 16;
+      const int active = SEQ ? (int)(blockDim.x >> 6) : min((int)(blockDim.x >> 6), (a.Lq - qb + 15) / 16);
+      atomicAdd(&kdw[0], sq);                    // (LDS operations of one wave execute in order: the sum lands before the count)
+      const float before = atomicAdd(&kdw[1], 1.0f);
+      if ((int)before == active - 1) atomicAdd(a.kd, atomicAdd(&kdw[0], 0.f) * a.kd_coef);
+    }
+  }
 }
 
 template <int NT>
 static int launch_fwd(const MAttnF& f, hipStream_t stream) {
   constexpr int MAXW = NT <= 14 ? 16 : (NT <= 26 ? 8 : 4);   // register budget: 16 (8) waves/workgroup need <= 128 (256) VGPRs
   constexpr bool SEQ = NT > 38;                        // 2 x NT x 2 KiB of K and V no longer fit in 160 KiB of LDS
-  const size_t lds = (size_t)(SEQ ? 1 : 2) * NT * 16 * 128 + (size_t)NT * 16 * sizeof(float);
+  const size_t lds = (size_t)(SEQ ? 1 : 2) * NT * 16 * 128 + (size_t)NT * 16 * sizeof(float) + 16;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT, MAXW, SEQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nw = imin(MAXW, (f.Lq + 15) / 16);         // waves per workgroup (16 queries each)
@@ -221,6 +254,7 @@ struct MAttnB {
   bf16* dS; bf16* dQ; bf16* dK; bf16* dV; float* dgate;
   int B, Bkv, H, Lq, Lk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, ldpr;
   float scale;
+  const bf16* Pt; const float* kd_gout; float kd_coef;   // fused map distillation: dP += kd_coef * (*kd_gout) * (P - Pt)
 };
 
 // kernel A: same shape as the forward (a wave owns 16 queries and ALL keys):
@@ -251,6 +285,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   }
   const size_t prow = (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr;
   const float gz = a.gate ? a.gate[h] : 1.0f;
+  const float kdc = a.Pt ? a.kd_coef * a.kd_gout[0] : 0.f;
   f32x4 acc[NT];
   bf16x4 pv[NT];
   float dsum = 0.f, gsum = 0.f;
@@ -261,9 +296,21 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
     bf16x8 p8, e8;
 #pragma unroll
     for (int r = 0; r < 8; ++r) { p8[r] = (bf16)0.f; e8[r] = (bf16)0.f; }
+    float ex[8];                                 // external gradient on the map: dP_ext and / or the fused distillation term
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ex[r] = 0.f;
     if (ok) {
       p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
-      if (a.E) e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
+      if (a.E) {
+        e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ex[r] = (float)e8[r];
+      }
+      if (a.Pt) {
+        const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(a.Pt + prow + kcol);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ex[r] += kdc * ((float)p8[r] - (float)t8[r]);
+      }
     }
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
@@ -277,7 +324,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
         pv[t][r] = p8[hh * 4 + r];
         const float p = (float)pv[t][r], dpo = acc[t][r];
         gsum += p * dpo;
-        const float dp = gz * dpo + (float)e8[hh * 4 + r];
+        const float dp = gz * dpo + ex[hh * 4 + r];
         acc[t][r] = dp;
         dsum += p * dp;
       }
@@ -356,6 +403,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
   }
   const size_t prow = (((size_t)b * a.H + h) * a.Lq + (qok ? q : 0)) * a.ldpr;
   const float gz = a.gate ? a.gate[h] : 1.0f;
+  const float kdc = a.Pt ? a.kd_coef * a.kd_gout[0] : 0.f;
   float dsum = 0.f, gsum = 0.f;
 #pragma unroll 2
   for (int s = 0; s < NT / 2; ++s) {
@@ -363,9 +411,21 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
     bf16x8 p8, e8;
 #pragma unroll
     for (int r = 0; r < 8; ++r) { p8[r] = (bf16)0.f; e8[r] = (bf16)0.f; }
+    float ex[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ex[r] = 0.f;
     if (qok && kcol < a.ldpr) {
       p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
-      if (a.E) e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
+      if (a.E) {
+        e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ex[r] = (float)e8[r];
+      }
+      if (a.Pt) {
+        const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(a.Pt + prow + kcol);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ex[r] += kdc * ((float)p8[r] - (float)t8[r]);
+      }
     }
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
@@ -377,7 +437,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
       for (int r = 0; r < 4; ++r) {
         const float p = (float)p8[hh * 4 + r];
         gsum += p * acc[r];
-        dsum += p * (gz * acc[r] + (float)e8[hh * 4 + r]);
+        dsum += p * (gz * acc[r] + ex[hh * 4 + r]);
       }
     }
   }
@@ -405,9 +465,21 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
       bf16x8 p8, e8;
 #pragma unroll
       for (int r = 0; r < 8; ++r) { p8[r] = (bf16)0.f; e8[r] = (bf16)0.f; }
+      float ex[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ex[r] = 0.f;
       if (ok) {
         p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
-        if (a.E) e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
+        if (a.E) {
+          e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) ex[r] = (float)e8[r];
+        }
+        if (a.Pt) {
+          const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(a.Pt + prow + kcol);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) ex[r] += kdc * ((float)p8[r] - (float)t8[r]);
+        }
       }
       bf16x8 d8;
 #pragma unroll
@@ -418,7 +490,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, 2 * s + hh, ks, lane), dof[ks], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          d8[hh * 4 + r] = (bf16)((float)p8[hh * 4 + r] * (gz * acc[r] + (float)e8[hh * 4 + r] - dsum));
+          d8[hh * 4 + r] = (bf16)((float)p8[hh * 4 + r] * (gz * acc[r] + ex[hh * 4 + r] - dsum));
       }
       if (ok) *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
 #pragma unroll
@@ -543,6 +615,9 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
   f.dS = (bf16*)a->dS; f.dQ = (bf16*)a->dQ; f.dK = (bf16*)a->dK; f.dV = (bf16*)a->dV; f.dgate = a->dgate;
   f.B = a->B; f.H = a->H; f.Lq = a->Lq; f.Lk = a->Lk; f.ldq = a->ldq; f.ldk = a->ldk; f.ldv = a->ldv; f.ldo = a->ldo;
   f.lddq = a->lddq; f.lddk = a->lddk; f.lddv = a->lddv; f.ldpr = a->ldpr; f.scale = a->scale;
+  f.Pt = (const bf16*)a->kd_teacher; f.kd_gout = a->kd_gout;
+  f.kd_coef = a->kd_teacher ? 2.0f * a->kd_weight / ((float)a->B * a->H * a->Lq * a->Lk) : 0.f;
+  if (a->kd_teacher && !a->kd_gout) return evlm_set_error("evlm_attention_bwd: kd_teacher without kd_gout");
   if (a->Lk <= 32) launch_bwd_dq<2>(f, stream);
   else if (a->Lk <= 64) launch_bwd_dq<4>(f, stream);
   else if (a->Lk <= 224) launch_bwd_dq<14>(f, stream);
@@ -567,6 +642,9 @@ int evlm_attention_fwd_mfma(const evlm_attn_fwd_args* a, hipStream_t stream, int
   f.mask = a->mask; f.gate = a->head_gate; f.O = (bf16*)a->O; f.P = (bf16*)a->P;
   f.B = a->B; f.H = a->H; f.Lq = a->Lq; f.Lk = a->Lk; f.ldq = a->ldq; f.ldk = a->ldk; f.ldv = a->ldv; f.ldo = a->ldo;
   f.ldpr = a->ldpr; f.scale = a->scale; f.causal = a->causal;
+  f.Pt = (const bf16*)a->kd_teacher; f.kd = a->kd_loss;
+  f.kd_coef = a->kd_teacher ? a->kd_weight / ((float)a->B * a->H * a->Lq * a->Lk) : 0.f;
+  if (a->kd_teacher && !a->kd_loss) return evlm_set_error("evlm_attention_fwd: kd_teacher without kd_loss");
   if (a->Lk <= 32) launch_fwd<2>(f, stream);
   else if (a->Lk <= 64) launch_fwd<4>(f, stream);
   else if (a->Lk <= 224) launch_fwd<14>(f, stream);

@@ -41,14 +41,20 @@ def soft_cross_entropy(predicts, targets, temperature=1.0):
     return ops.soft_cross_entropy(predicts, targets, temperature)
 
 
-def kd_terms(S, T, temperature=1.0, with_cross_attn=False):
-    """the per-pair KD scalars of GeneralDistill.py:300-366 (+ cross-attention maps, Eff_Retrieval.py:141-159)"""
+def kd_terms(S, T, temperature=1.0, with_cross_attn=False, fused=None):
+    """the per-pair KD scalars of GeneralDistill.py:300-366 (+ cross-attention maps, Eff_Retrieval.py:141-159).
+    fused: {term name: scalar} of terms the attention kernels already produced (fuse_image_map_kd) - same arithmetic,
+    no separate pass over the maps."""
     sh, th, sa, ta = S["hidden_dict"], T["hidden_dict"], S["attention_dict"], T["attention_dict"]
     out = {}
+    fused = fused or {}
 
     def pair(name, hkey, akey, is_img=False):
         out[name + "_hidden"] = get_kd_loss(sh[hkey], get_cor_teacher(th[hkey], sh[hkey]), is_img=is_img)
-        out[name + "_attn"] = get_kd_loss(sa[akey], get_cor_teacher(ta[akey], sa[akey], True), is_attn=True)
+        if name + "_attn" in fused:
+            out[name + "_attn"] = fused[name + "_attn"]
+        else:
+            out[name + "_attn"] = get_kd_loss(sa[akey], get_cor_teacher(ta[akey], sa[akey], True), is_attn=True)
 
     pair("text", "text_hidden_states", "text_attentions")
     pair("image", "image_hidden_states", "image_attentions", is_img=True)
@@ -193,6 +199,41 @@ def model_kwargs(batch):
     return kw
 
 
+def fuse_image_map_kd(student, teacher_out, batch):
+    """Arm the student's image encoder for the FUSED attention-map distillation: when the teacher's maps of this batch
+    already exist (pipelined trainer), each student ViT layer's attention kernel compares its probabilities - still in
+    registers - with the corresponding teacher map (get_cor_teacher: map i*k + k-1) and returns the layer's term; the
+    backward forms dP from the teacher map in-kernel.  Returns the encoder (call collect_fused_kd after the forward) or
+    None when the problem does not qualify (fp32 parity path, region batches, missing maps)."""
+    from .runtime import compute_dtype
+    enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
+    if enc is None or not hasattr(enc, "kd_teacher_maps") or teacher_out is None or "idx_to_group_img" in batch:
+        return None
+    if compute_dtype() != torch.bfloat16:
+        return None
+    maps = teacher_out["attention_dict"].get("image_attentions")
+    ns = len(enc.layers)
+    if maps is None or len(maps) % ns != 0:
+        return None
+    cor = get_cor_teacher(maps, [None] * ns, is_attn=True)
+    attn = enc.layers[0].self_attn
+    if any(m is None or ops._padded_base(m) is None for m in cor):
+        return None
+    if not ops.attention_kd_fusable(cor[0], attn.num_heads, attn.head_dim, cor[0].shape[-1]):
+        return None
+    enc.kd_teacher_maps = cor
+    return enc
+
+
+def collect_fused_kd(enc):
+    """{'image_attn': sum of the per-layer terms} produced during the forward the encoder was armed for"""
+    terms, enc.kd_teacher_maps = enc.kd_fused, None
+    enc.kd_fused = None
+    if not terms or any(t is None for t in terms) or len(terms) != len(enc.layers):
+        raise RuntimeError("fused attention-map distillation: a ViT layer did not report its term")
+    return {"image_attn": torch.stack(terms).sum()}
+
+
 def gd_forward(student, teacher, batch, temperature=1.0, overlap_teacher=False, teacher_out=None):
     """student forward (autograd on), teacher forward (no_grad), every KD term and the GD loss mix
     (GeneralDistill.py:289-376; region step :158-262).  batch: dict(image, text_ids, text_atts, text_ids_masked,
@@ -203,10 +244,16 @@ def gd_forward(student, teacher, batch, temperature=1.0, overlap_teacher=False, 
     share the chip with the student's instead of queueing behind them."""
     kw = model_kwargs(batch)
     call = lambda m: m(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+    fused = {}
     if teacher_out is not None:            # teacher outputs of THIS batch computed earlier (trainer: teacher pipelining)
-        S, T = call(student), teacher_out
+        enc = fuse_image_map_kd(student, teacher_out, batch)
+        try:
+            S, T = call(student), teacher_out
+        finally:
+            if enc is not None:
+                fused = collect_fused_kd(enc)
     else:
         S, T = student_and_teacher(lambda: call(student), lambda: call(teacher), batch["image"], overlap_teacher)
-    kd = kd_terms(S, T, temperature)
+    kd = kd_terms(S, T, temperature, fused=fused)
     total, mix = gd_loss_mix(S["loss"], kd)
     return total, S, T, kd, mix

@@ -88,10 +88,13 @@ class CLIPAttention(nn.Module):
         self.pruned_heads = self.pruned_heads.union(heads)
 
     def forward(self, hidden_states, attention_mask=None, causal_attention_mask=None, output_attentions=False,
-                head_z=None, head_layer_z=None, residual=None):
+                head_z=None, head_layer_z=None, residual=None, kd_teacher=None, kd_word=None):
         """hidden_states [B,N,C] -> (attn_output [B,N,C], probs [B,H,N,N] | None).
 
-        `residual` (extension): added in the out_proj GEMM epilogue; the layer passes the block input."""
+        `residual` (extension): added in the out_proj GEMM epilogue; the layer passes the block input.
+        `kd_teacher` (extension): the frozen teacher's map of the corresponding layer; the attention kernel then also
+        returns MSELoss(probs, kd_teacher) * probs.shape[-1] (GeneralDistill.py:63-69) as a third output, computed while
+        the probabilities are in registers."""
         bsz, tgt_len, _ = hidden_states.shape
         if causal_attention_mask is not None:
             raise NotImplementedError("causal masks are never passed on the vision path (eff_vit.py:254)")
@@ -104,6 +107,12 @@ class CLIPAttention(nn.Module):
             raise NotImplementedError("head_layer_z is never produced by the reference L0 modules (SURVEY.md §3.4)")
         qkv = ops.linear_packed(hidden_states, (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight),
                                 (self.q_proj.bias, self.k_proj.bias, self.v_proj.bias))
+        if kd_teacher is not None:
+            out, probs, kd = ops.self_attention(qkv, self.num_heads, self.head_dim, self.scale, mask=mask2d, gate=head_z,
+                                                want_probs=True, kd_teacher=kd_teacher,
+                                                kd_weight=float(tgt_len) if kd_word is None else ops.KdSlot(kd_word, tgt_len))
+            out = ops.linear(out, self.out_proj.weight, self.out_proj.bias, residual=residual)
+            return out, (probs if output_attentions else None), kd
         out, probs = ops.self_attention(qkv, self.num_heads, self.head_dim, self.scale, mask=mask2d, gate=head_z,
                                         want_probs=bool(output_attentions))
         out = ops.linear(out, self.out_proj.weight, self.out_proj.bias, residual=residual)
@@ -136,12 +145,15 @@ class CLIPEncoderLayer(nn.Module):
         self.layer_norm2 = nn.LayerNorm(hidden_size)
 
     def forward(self, hidden_states, attention_mask: None, output_attentions: Optional[bool] = False, head_z=None,
-                head_layer_z=None, mlp_z=None):
+                head_layer_z=None, mlp_z=None, kd_teacher=None, kd_word=None):
         residual = hidden_states
         h = ops.layer_norm(hidden_states, self.layer_norm1.weight, self.layer_norm1.bias, self.layer_norm1.eps)
-        hidden_states, attn_weights = self.self_attn(hidden_states=h, attention_mask=attention_mask,
-                                                     causal_attention_mask=None, output_attentions=output_attentions,
-                                                     head_z=head_z, head_layer_z=head_layer_z, residual=residual)
+        attn_out = self.self_attn(hidden_states=h, attention_mask=attention_mask,
+                                  causal_attention_mask=None, output_attentions=output_attentions,
+                                  head_z=head_z, head_layer_z=head_layer_z, residual=residual, kd_teacher=kd_teacher,
+                                  kd_word=kd_word)
+        hidden_states, attn_weights = attn_out[0], attn_out[1]
+        self.kd_term = attn_out[2] if kd_teacher is not None else None
         residual = hidden_states
         h = ops.layer_norm(hidden_states, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps)
         hidden_states = self.mlp(h, mlp_z=mlp_z, residual=residual)
@@ -162,6 +174,10 @@ class CLIPEncoder(nn.Module):
         # extension (None = the reference's behaviour): the set of layers whose attention map is materialised when
         # output_attentions is set; the others return None in their slot (a frozen teacher whose other maps nobody reads)
         self.attn_keep = None
+        # extension: per-layer teacher maps for the FUSED attention-map distillation (set by distill.gd_forward when the
+        # teacher's outputs of this batch already exist - the pipelined trainer); the per-layer terms land in kd_fused
+        self.kd_teacher_maps = None
+        self.kd_fused = None
         self.layers = nn.ModuleList([CLIPEncoderLayer(hidden_size, hidden_act, num_attention_heads, attention_dropout,
                                                       intermediate_size) for _ in range(num_hidden_layers)])
 
@@ -178,6 +194,9 @@ class CLIPEncoder(nn.Module):
         encoder_states = () if output_hidden_states else None
         all_attentions = () if output_attentions else None
         hidden_states = inputs_embeds
+        kd_maps = self.kd_teacher_maps if (self.kd_teacher_maps is not None and not do_gather and output_attentions) else None
+        self.kd_fused = [] if kd_maps is not None else None
+        kd_words = torch.zeros(len(self.layers), dtype=torch.float32, device=inputs_embeds.device) if kd_maps is not None else None
         for idx, encoder_layer in enumerate(self.layers):
             if output_hidden_states:
                 encoder_states = encoder_states + (hidden_states,)
@@ -186,14 +205,17 @@ class CLIPEncoder(nn.Module):
                       head_z=head_z[idx] if head_z is not None else None,
                       head_layer_z=head_layer_z[idx] if head_layer_z is not None else None,
                       mlp_z=mlp_z[idx] if mlp_z is not None else None)
+            kdkw = dict(kd_teacher=kd_maps[idx], kd_word=kd_words[idx]) if kd_maps is not None else {}
             if (self.local_attn_depth > 0) and (idx >= self.depth - self.local_attn_depth):
                 if do_gather:                                                           # :354-357
                     do_gather = False
                     hidden_states_bs = torch.index_select(hidden_states, 0, idx_to_group_img.view(-1))
                     hidden_states = torch.cat([hidden_states_bs, hidden_states], dim=0)
-                layer_outputs = encoder_layer(hidden_states, attention_mask=image_atts_blk, **kw)
+                layer_outputs = encoder_layer(hidden_states, attention_mask=image_atts_blk, **kw, **kdkw)
             else:
-                layer_outputs = encoder_layer(hidden_states, attention_mask=None, **kw)
+                layer_outputs = encoder_layer(hidden_states, attention_mask=None, **kw, **kdkw)
+            if kd_maps is not None:
+                self.kd_fused.append(encoder_layer.kd_term)
             hidden_states = layer_outputs[0]
             if output_attentions:
                 all_attentions = all_attentions + ((layer_outputs[1] if want_map else None),)

@@ -591,7 +591,7 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qbuf, kvbuf, mask, gate, H, dh, q_off, k_off, v_off, scale, want_probs, kv_index=None, causal=False,
-                dropout_p=0.0):
+                dropout_p=0.0, kd_teacher=None, kd_weight=1.0):
         L.require_cuda(qbuf, kvbuf)
         assert qbuf.is_contiguous() and kvbuf.is_contiguous()
         B, Lq, ldq = qbuf.shape
@@ -610,6 +610,18 @@ class _Attention(torch.autograd.Function):
                           K=C.c_void_p(kvbuf.data_ptr() + k_off * es), V=C.c_void_p(kvbuf.data_ptr() + v_off * es),
                           kv_index=L.ptr(kv_index), mask=L.ptr(m32), head_gate=L.ptr(g32), scale=scale, O=L.ptr(O),
                           P=L.ptr(Pbuf), causal=int(bool(causal)))
+        kd = kd_base = None
+        if kd_teacher is not None:                # fused map distillation: the teacher's (padded) map, read once in-kernel
+            kd_base = _padded_base(kd_teacher, Lkp) if kd_teacher.shape[-1] != Lkp else kd_teacher
+            if (kd_base is None or not kd_base.is_contiguous() or tuple(kd_base.shape) != (B, H, Lq, Lkp)
+                    or kd_base.dtype != tdt or tdt != torch.bfloat16 or Pbuf is None):
+                raise RuntimeError("fused attention-map distillation needs the teacher map as a [B, H, Lq, Lk] view of a "
+                                   "row-padded contiguous bf16 buffer (what the attention kernels return)")
+            if isinstance(kd_weight, KdSlot):     # caller-provided zeroed f32 word (one fill for all layers of an encoder)
+                kd, kd_weight = kd_weight.word, kd_weight.weight
+            else:
+                kd = torch.zeros((), dtype=torch.float32, device=dev)
+            a.kd_teacher, a.kd_loss, a.kd_weight = L.ptr(kd_base), L.ptr(kd), float(kd_weight)
         drop = None
         if dropout_p and dropout_p > 0.0:
             drop = (float(dropout_p), dropout_state(dev), _next_drop_call("attention_probs", (B, H, Lq, Lk), dropout_p))
@@ -618,15 +630,16 @@ class _Attention(torch.autograd.Function):
         if ATTN_FLOPS is not None:
             ATTN_FLOPS[0] += 4.0 * B * H * Lq * Lk * dh
         ctx.set_materialize_grads(False)        # an unused probability map must not cost a zero tensor in backward
-        ctx.save_for_backward(qbuf, kvbuf, Pbuf, g32, kv_index)
+        ctx.save_for_backward(qbuf, kvbuf, Pbuf, g32, kv_index, kd_base)
         ctx.meta = (H, dh, q_off, k_off, v_off, scale, qbuf is kvbuf or qbuf.data_ptr() == kvbuf.data_ptr(),
                     gate.shape if gate is not None else None)
         ctx.drop = drop
-        return O, P
+        ctx.kd_weight = float(kd_weight) if kd_teacher is not None else 0.0
+        return O, P, kd
 
     @staticmethod
-    def backward(ctx, dO, dP):
-        qbuf, kvbuf, P, g32, kv_index = ctx.saved_tensors
+    def backward(ctx, dO, dP, dkd):
+        qbuf, kvbuf, P, g32, kv_index, kd_base = ctx.saved_tensors
         H, dh, q_off, k_off, v_off, scale, self_attn, gshape = ctx.meta
         B, Lq, ldq = qbuf.shape
         Bkv, Lk, ldk = kvbuf.shape
@@ -655,6 +668,9 @@ class _Attention(torch.autograd.Function):
                           kv_index=L.ptr(kv_index), head_gate=L.ptr(g32), scale=scale, dS=L.ptr(dS),
                           dQ=C.c_void_p(dqbuf.data_ptr() + q_off * es), dK=C.c_void_p(dkvbuf.data_ptr() + k_off * es),
                           dV=C.c_void_p(dkvbuf.data_ptr() + v_off * es), dgate=L.ptr(dgate))
+        if kd_base is not None and dkd is not None:       # dP of the fused distillation term is formed in-kernel from P_t
+            gk = dkd.to(torch.float32).contiguous()
+            a.kd_teacher, a.kd_gout, a.kd_weight = L.ptr(kd_base), L.ptr(gk), ctx.kd_weight
         if ctx.drop is not None:          # the keep-mask is regenerated from the same (state, call id), never stored
             a.dropout_p, a.rng_state, a.call_id = ctx.drop[0], L.ptr(ctx.drop[1]), ctx.drop[2]
             if kv_index is not None:      # generic kernels accumulate shared K/V gradients with f32 atomics
@@ -664,16 +680,32 @@ class _Attention(torch.autograd.Function):
             ATTN_FLOPS[0] += 8.0 * B * H * Lq * Lk * dh          # dP, dV, dQ, dK (P is read back, not recomputed)
         dg = dgate.view(gshape) if dgate is not None else None
         if self_attn:
-            return (dqbuf, None, None, dg) + (None,) * 10
-        return (dqbuf, dkvbuf, None, dg) + (None,) * 10
+            return (dqbuf, None, None, dg) + (None,) * 12
+        return (dqbuf, dkvbuf, None, dg) + (None,) * 12
 
 
-def self_attention(qkv, H, dh, scale, mask=None, gate=None, want_probs=True, causal=False, dropout_p=0.0):
+def self_attention(qkv, H, dh, scale, mask=None, gate=None, want_probs=True, causal=False, dropout_p=0.0,
+                   kd_teacher=None, kd_weight=1.0):
     """qkv: [B, L, 3*H*dh] packed (q | k | v); causal: additionally -10000 on keys after the query (decoder self-attention:
     the backward works from the saved probabilities, so only the forward kernel knows about masks); dropout_p: dropout of
     the probabilities that form the context (the returned map stays un-dropped, eff_bert.py:338-361)"""
     d = H * dh
-    return _Attention.apply(qkv, qkv, mask, gate, H, dh, 0, d, 2 * d, scale, want_probs, None, causal, dropout_p)
+    O, P, kd = _Attention.apply(qkv, qkv, mask, gate, H, dh, 0, d, 2 * d, scale, want_probs, None, causal, dropout_p,
+                                kd_teacher, kd_weight)
+    return (O, P) if kd_teacher is None else (O, P, kd)
+
+
+class KdSlot:
+    """weight of a fused map-distillation term + the (already zeroed) device f32 word its kernel accumulates into; a plain
+    object, so autograd does not see the word as an input of the attention Function"""
+
+    def __init__(self, word, weight):
+        self.word, self.weight = word, float(weight)
+
+
+def attention_kd_fusable(x, H, dh, Lk):
+    """can the attention-map distillation of this problem run inside the attention kernels (bf16 MFMA path)?"""
+    return x.is_cuda and x.dtype == torch.bfloat16 and dh == 64 and Lk <= 928
 
 
 def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True, kv_index=None, dropout_p=0.0):
@@ -686,7 +718,7 @@ def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True, 
         else:                                   # exact-fp32 / generic path: materialise the gather (autograd scatters back)
             kv = torch.index_select(kv, 0, kv_index.long())
             kv_index = None
-    return _Attention.apply(q, kv, mask, gate, H, dh, 0, 0, d, scale, want_probs, kv_index, False, dropout_p)
+    return _Attention.apply(q, kv, mask, gate, H, dh, 0, 0, d, scale, want_probs, kv_index, False, dropout_p)[:2]
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -138,6 +138,13 @@ typedef struct {
                                    the map written to P stays the un-dropped softmax (:338-361).  0 = off */
   const int64_t* rng_state;     /* device int64[2] {seed, step} (see evlm_dropout); required when dropout_p > 0 */
   uint32_t call_id;             /* identifies this dropout site; the backward call passes the same triple */
+  /* fused attention-map distillation (GeneralDistill.py:63-69: MSELoss(student_att, teacher_att) * att.shape[-1]): with
+     kd_teacher = the teacher's map [B, H, Lq, ldpr] (bf16, padding zero - the frozen teacher ran a batch ahead), the kernel
+     adds  kd_weight * sum((P - P_t)^2) / (B H Lq Lk)  to *kd_loss while P is still in registers, instead of a separate
+     reduction re-reading both maps from HBM.  bf16 MFMA path only (NULL elsewhere). */
+  const void* kd_teacher;
+  float* kd_loss;
+  float kd_weight;
 } evlm_attn_fwd_args;
 int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream);
 
@@ -165,6 +172,11 @@ typedef struct {
   float dropout_p;              /* as in the forward call: the keep-mask is regenerated, never stored */
   const int64_t* rng_state;
   uint32_t call_id;
+  /* backward of the fused map distillation: dP += (*kd_gout) * kd_weight * 2 (P - P_t) / (B H Lq Lk), formed in
+     registers from P_t - no dP_ext tensor is written or read for it (dP_ext may still carry other gradients) */
+  const void* kd_teacher;
+  const float* kd_gout;         /* device f32 word: dL/d(kd term) */
+  float kd_weight;
 } evlm_attn_bwd_args;
 int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream);
 

@@ -513,6 +513,33 @@ def test_cross_attention_shared_kv_index(dtype):
     assert rel_err(kv.grad.float(), kvr.grad) < t * 4
 
 
+@pytest.mark.parametrize("B,H,L", [(3, 12, 197), (2, 4, 30), (2, 2, 577)])
+def test_fused_attention_map_distillation_equals_the_separate_reduction(B, H, L):
+    """evlm_attn_fwd_args.kd_teacher: MSELoss(P, P_t) * P.shape[-1] (GeneralDistill.py:63-69) accumulated inside the attention
+    forward kernel, and its gradient formed from P_t inside the backward kernel, against the separate path (the map read
+    back by evlm_mse_fwd / evlm_mse_bwd and handed to the attention backward as dP_ext)"""
+    o = ops()
+    g = torch.Generator().manual_seed(61)
+    dh, d = 64, H * 64
+    qkv0 = rnd((B, L, 3 * d), torch.bfloat16, g, 0.7)
+    with torch.no_grad():
+        _, Pt = o.self_attention(rnd((B, L, 3 * d), torch.bfloat16, g, 0.7), H, dh, 0.125)       # a "teacher" map (padded rows)
+    gO = rnd((B, L, d), torch.bfloat16, g)
+    coef = 0.4
+    a = qkv0.clone().requires_grad_(True)
+    O1, P1, kd1 = o.self_attention(a, H, dh, 0.125, kd_teacher=Pt, kd_weight=float(L))
+    ((O1 * gO).sum() + coef * kd1).backward()
+    b = qkv0.clone().requires_grad_(True)
+    O2, P2 = o.self_attention(b, H, dh, 0.125)
+    kd2 = o.mse(P2, Pt, weight=float(L))
+    ((O2 * gO).sum() + coef * kd2).backward()
+    ref = torch.nn.functional.mse_loss(P2.detach().float(), Pt.float()) * L
+    assert torch.equal(O1, O2) and torch.equal(P1, P2)
+    assert rel_err(kd1, ref) < 1e-4 and rel_err(kd2, ref) < 1e-4
+    # the fused path keeps dP in fp32 where the separate one rounds it to bf16 on its way through HBM
+    assert rel_err(a.grad.float(), b.grad.float()) < 6e-3
+
+
 def _pp256_case(o, L, g, I, J, K, qt=0, bias=False, res=False, act=0, dact=0):
     dtype = torch.bfloat16
     Pm = rnd((I, K), dtype, g, 0.5)

@@ -2,7 +2,7 @@
 # Round profile bundle (run on the GPU box from the repo root): default bench line, rocprofv3 kernel stats of the bench
 # command, and the two PMC passes (FETCH_SIZE / WRITE_SIZE) summarised per kernel.  Only small summaries are kept.
 set -u
-OUT=gpurun_out/r01
+OUT=${OUT:-gpurun_out/r02}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 bench.py > $OUT/bench_default.log 2>&1
