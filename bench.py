@@ -191,6 +191,7 @@ def oracle_check(geom, dev, dtype, B, use_graph):
     # a derangement per direction (image->text negatives first, then text->image): never the positive pair
     neg = torch.cat([(torch.arange(B) + 1 + torch.randint(0, B - 1, (B,), generator=g)) % B for _ in range(2)])
     student.injected_neg_idx, teacher.injected_neg_idx = neg, neg
+    student.keep_injected_neg = teacher.keep_injected_neg = True      # warm-up steps and the captured graphs included
     tr = make_trainer(student, teacher, dtype, use_graph, True)
     gb = {k: v.to(dev) for k, v in batch.items()}
     tr.step(gb)                                   # primes the teacher pipeline

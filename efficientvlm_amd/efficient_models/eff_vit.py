@@ -178,6 +178,9 @@ class CLIPEncoder(nn.Module):
         # teacher's outputs of this batch already exist - the pipelined trainer); the per-layer terms land in kd_fused
         self.kd_teacher_maps = None
         self.kd_fused = None
+        # extension: {layer index: callback} - a tensor hook on the INPUT of that layer: it fires when backward has finished
+        # with layers >= index (their parameter gradients are complete): the data-parallel trainer reduces them right then
+        self.grad_hooks = None
         self.layers = nn.ModuleList([CLIPEncoderLayer(hidden_size, hidden_act, num_attention_heads, attention_dropout,
                                                       intermediate_size) for _ in range(num_hidden_layers)])
 
@@ -206,6 +209,9 @@ class CLIPEncoder(nn.Module):
                       head_layer_z=head_layer_z[idx] if head_layer_z is not None else None,
                       mlp_z=mlp_z[idx] if mlp_z is not None else None)
             kdkw = dict(kd_teacher=kd_maps[idx], kd_word=kd_words[idx]) if kd_maps is not None else {}
+            if self.grad_hooks and idx in self.grad_hooks and hidden_states.requires_grad:
+                cb = self.grad_hooks[idx]
+                hidden_states.register_hook(lambda grad, cb=cb: (cb(), grad)[1])
             if (self.local_attn_depth > 0) and (idx >= self.depth - self.local_attn_depth):
                 if do_gather:                                                           # :354-357
                     do_gather = False

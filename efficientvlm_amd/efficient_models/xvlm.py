@@ -48,13 +48,22 @@ def load_params_choose_layers(prefix: str, state_dict: dict, mapper: dict):
     return state_dict
 
 
+# set by trainer.GDTrainer while it captures / replays a multi-GPU step as hipGraph segments: called INSTEAD of
+# dist.all_gather(output_list, tensor) - it ends the running capture, issues the collective eagerly, starts the next one
+GATHER_HOOK = None
+
+
 class AllGather(torch.autograd.Function):
     """efficient_models/xvlm.py:54-74: all_gather forward; backward keeps ONLY the local slice (no reduction)."""
 
     @staticmethod
     def forward(ctx, tensor, rank, world_size):
         output = [torch.empty_like(tensor) for _ in range(world_size)]
-        dist.all_gather(output, tensor.contiguous())
+        src = tensor.contiguous()
+        if GATHER_HOOK is not None:          # a trainer that captures the step in hipGraph SEGMENTS around its collectives
+            GATHER_HOOK(output, src)
+        else:
+            dist.all_gather(output, src)
         ctx.rank = rank
         ctx.batch_size = tensor.shape[0]
         return torch.cat(output, 0)
@@ -70,7 +79,7 @@ def allgather(tensor, rank=None, world_size=None):
         return tensor
     rank = dist.get_rank() if rank is None else rank
     world_size = dist.get_world_size() if world_size is None else world_size
-    if world_size == 1:
+    if world_size == 1 and not os.environ.get("EVLM_FORCE_REDUCE"):     # (forced: exercise the collective path on one GPU)
         return tensor
     return AllGather.apply(tensor, rank, world_size)
 
@@ -329,8 +338,11 @@ class XVLMBase(nn.Module):
         assert image_feat.size(-1) == self.embed_dim
         assert text_feat.size(-1) == self.embed_dim
         # similarity logits are formed in exact fp32 whatever the compute dtype ([B,256] x [B,256]: negligible cost)
-        image_feat_all = ops.cast(allgather(image_feat), torch.float32)
-        text_feat_all = ops.cast(allgather(text_feat), torch.float32)
+        # ONE all-gather of [B, 2E] for both feature sets (latency-bound message: SURVEY.md 2.2); the slice-only backward of
+        # the reference's two gathers (xvlm.py:54-74) is unchanged - it acts row-wise
+        both = allgather(torch.cat([image_feat, text_feat], dim=1))
+        image_feat_all = ops.cast(both[:, :self.embed_dim], torch.float32)
+        text_feat_all = ops.cast(both[:, self.embed_dim:], torch.float32)
         logits = _matmul_nt(image_feat_all, text_feat_all).float() / self.temp
         logits_t = _matmul_nt(text_feat_all, image_feat_all).float() / self.temp
         bsz = image_feat_all.shape[0]
@@ -354,10 +366,12 @@ class XVLMBase(nn.Module):
         bs = image_feat.size(0)
         if self.injected_neg_idx is not None:
             neg = self.injected_neg_idx.to(image_feat.device).long()
-            self.injected_neg_idx = None
+            # consumed by ONE forward unless keep_injected_neg is set (parity tests of trainers that run warm-up steps and
+            # capture graphs: every forward, captured ones included, then uses the same - device-resident - indices)
+            self.injected_neg_idx = neg if getattr(self, "keep_injected_neg", False) else None
             assert neg.numel() == 2 * bs
             return neg[:bs], neg[bs:]
-        sim_i2t = image_feat.float() @ text_feat.float().t() / self.temp
+        sim_i2t = _matmul_nt(image_feat.float(), text_feat.float()) / self.temp        # (the HIP fp32 GEMM, not a vendor one)
         weights_i2t = F.softmax(sim_i2t, dim=1) + 1e-5
         weights_t2i = F.softmax(sim_i2t.t(), dim=1) + 1e-5
         if idx is None:

@@ -111,6 +111,23 @@ class FlatAdamW:
                 early.append(g["g"][pos:n])
         return early, late
 
+    def grad_ranges(self, pred):
+        """gradient-slab views covering exactly the parameters whose name satisfies `pred` (adjacent members merged): the
+        data-parallel reducer sends a layer group's gradients the moment backward has finished with it"""
+        out = []
+        for g in self.groups:
+            off, cur = 0, None
+            for p, nme in zip(g["params"], g["names"]):
+                seg = (p.numel() + 7) // 8 * 8
+                if pred(nme):
+                    if cur is not None and cur[1] == off:
+                        cur[1] = off + seg
+                    else:
+                        cur = [off, off + seg]
+                        out.append((g, cur))
+                off += seg
+        return [g["g"][lo:hi] for g, (lo, hi) in out]
+
     def zero_grad(self):
         for g in self.groups:
             g["g"].zero_()

@@ -149,13 +149,37 @@ class GDTrainer:
         teacher.eval()
         student.train()
         self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=max_grad_norm)
-        self.reducer = GradReducer(self.opt.flat_grads, compress=grad_compress,
-                                   force=bool(os.environ.get("EVLM_FORCE_REDUCE")))
+        force = bool(os.environ.get("EVLM_FORCE_REDUCE"))
+        if (grad_compress is None and dtype == torch.bfloat16 and (dist_ready() or force)
+                and not os.environ.get("EVLM_FP32_WIRE")):
+            grad_compress = torch.bfloat16           # bf16 runs: bf16 on the wire too (xGMI rings are per-link bound)
+        self.reducer = GradReducer(self.opt.flat_grads, compress=grad_compress, force=force)
         self.world = self.reducer.world
         self._early, self._late = self.opt.grad_segments()
         self._early_sent = False
+        self._vit_segments, self._vit_sent = [], 0
+        self._defer_reduce, self._seg, self._seg_pool, self._cap_stream = False, {}, None, None
         if self.reducer.active and hasattr(student, "on_vision_grad"):
             student.on_vision_grad = self._on_vision_grad      # fires when backward enters the image encoder
+            enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
+            if enc is not None and hasattr(enc, "grad_hooks") and len(enc.layers) >= 4:
+                # the image-encoder slab goes out in three pieces while its backward is still running: a hook on the input
+                # of layer b fires when layers >= b are done (their queued weight gradients are flushed first)
+                n = len(enc.layers)
+                cuts = [n - n // 3, n - 2 * (n // 3)]              # 6 layers: hooks at 4 and 2 -> {4,5}, {2,3}, {0,1}+embeddings
+                layer_of = lambda nme: int(nme.split("encoder.layers.")[1].split(".")[0]) if "encoder.layers." in nme else None
+                in_vit = lambda nme: nme.startswith("vision_encoder.")
+                hi = n
+                for b in cuts:
+                    pred = (lambda lo_, hi_: lambda nme: in_vit(nme) and (
+                        (layer_of(nme) is not None and lo_ <= layer_of(nme) < hi_) or
+                        (hi_ == n and layer_of(nme) is None and "post_layernorm" in nme)))(b, hi)
+                    self._vit_segments.append(self.opt.grad_ranges(pred))
+                    hi = b
+                rest = (lambda hi_: lambda nme: in_vit(nme) and not (
+                    (layer_of(nme) is not None and layer_of(nme) >= hi_) or (layer_of(nme) is None and "post_layernorm" in nme)))(hi)
+                self._vit_segments.append(self.opt.grad_ranges(rest))      # sent after backward
+                enc.grad_hooks = {b: (lambda k: lambda: self._on_vit_layers_done(k))(k) for k, b in enumerate(cuts)}
         self.use_graph = use_graph
         self.wgrad_inplace = True
         if not os.environ.get("EVLM_TEACHER_ALL_MAPS"):
@@ -202,17 +226,38 @@ class GDTrainer:
     def _on_vision_grad(self):
         """tensor hook on the ViT output: text / fusion / head gradients are all enqueued -> reduce them under the ViT
         backward"""
+        if self._defer_reduce:            # segmented-graph step: no collective inside the captured backward
+            return
         if not self._early_sent:
             self._early_sent = True
             ops.flush_wgrad()                 # the queued text / fusion weight gradients must be in the slabs first
             self.reducer.reduce_async(self._early)
 
+    def _on_vit_layers_done(self, k):
+        """tensor hook inside the image encoder: ViT segment k (layers >= its cut) is complete"""
+        if self._defer_reduce:
+            return
+        if self._early_sent and self._vit_sent == k:
+            ops.flush_wgrad()
+            self.reducer.reduce_async(self._vit_segments[k])
+            self._vit_sent = k + 1
+
+    def _reduce_rest(self):
+        """what backward has not sent from its hooks: the remaining image-encoder segments (or everything)"""
+        if not self._early_sent:
+            self.reducer.reduce_async(self.opt.flat_grads)
+        elif self._vit_segments:
+            for k in range(self._vit_sent, len(self._vit_segments)):
+                self.reducer.reduce_async(self._vit_segments[k])
+        else:
+            self.reducer.reduce_async(self._late)
+        self.reducer.finish()
+
     def _step_eager(self, batch, teacher_out=None):
-        self._early_sent = False
+        self._early_sent, self._vit_sent = False, 0
         out = self._forward_backward(batch, teacher_out)
         if self.reducer.active:
-            self.reducer.reduce_async(self._late if self._early_sent else self.opt.flat_grads)
-            self.reducer.finish()
+            self._reduce_rest()
         self.opt.step()
         return out
 
@@ -306,11 +351,10 @@ class GDTrainer:
 
     def _student_eager(self, pipe, k):
         """student forward + backward on (batch k, teacher outputs k), gradient reduction, optimiser step"""
-        self._early_sent = False
+        self._early_sent, self._vit_sent = False, 0
         out = self._forward_backward(pipe["B"][k], pipe["T"][k])
         if self.reducer.active:
-            self.reducer.reduce_async(self._late if self._early_sent else self.opt.flat_grads)
-            self.reducer.finish()
+            self._reduce_rest()
         self.opt.step()
         return out
 
@@ -345,6 +389,14 @@ class GDTrainer:
                 jg = self._joint[key] = (g, res, self.last_kd)
             jg[0].replay()
             out, self.last_kd = jg[1], jg[2]
+        elif (self.use_graph and self.reducer.active and self._pending is not None
+              and not os.environ.get("EVLM_NO_SEGMENT_GRAPHS")):
+            # multi-GPU: hipGraph segments around the collectives; the new batch's teacher forward is forked onto the side
+            # stream INSIDE the longest segment (as in the single-GPU joint graph: two separately launched graphs overlap
+            # only when their start times happen to line up - measured 19 vs 24 ms from run to run)
+            pp, pk = self._pending
+            self.opt.set_schedule(lr_mult)
+            out = self._student_segmented(pipe, p, pp, pk)
         else:
             side.wait_stream(cur)                 # inputs copied; every earlier reader of this parity's buffers is done
             with torch.cuda.stream(side):
@@ -358,6 +410,100 @@ class GDTrainer:
                 out = self._student_eager(pp, pk)
         self._pending = (pipe, p)
         return out
+
+    # ---- multi-GPU: the student step as hipGraph SEGMENTS around its collectives --------------------------------------
+    # RCCL collectives cannot be captured on this stack, and an eager step costs the host ~1 100 launches (20+ ms: more than
+    # the GPU needs).  So the step is captured as a chain: [graph: forward up to the ITC feature gather] all_gather (eager)
+    # [graph: rest of the forward, the whole backward, the grouped weight gradients] all-reduce of the gradient slabs (eager,
+    # bf16 on the wire, on the side stream) [graph: clip + AdamW].  The capture is cut INSIDE the model's forward by
+    # efficient_models.xvlm.GATHER_HOOK, which the ITC all-gather calls instead of dist.all_gather.  The gradient exchange
+    # is not overlapped with backward in this form (a capture cannot be cut from an autograd hook): at 240 MB of bf16
+    # gradients over xGMI that is ~1-3 ms per step against ~5 ms of host-bound launch time saved.
+    def _capture_segments(self, tpipe, tp, pipe, k):
+        """segments of: student step on (pipe, k) with the teacher forward of (tpipe, tp) forked beside its longest part"""
+        from .efficient_models import xvlm as X
+        if self._cap_stream is None:
+            self._cap_stream, self._seg_pool = torch.cuda.Stream(), torch.cuda.graph_pool_handle()
+        cur, cs, side = torch.cuda.current_stream(), self._cap_stream, self._side
+        torch.cuda.synchronize()
+        segs, state = [], {"g": None, "forked": False}
+
+        def fork_teacher():
+            side.wait_stream(cs)
+            with torch.cuda.stream(side):
+                self._teacher_eager(tpipe, tp)
+            state["forked"] = True
+
+        def begin():
+            state["g"] = torch.cuda.CUDAGraph()
+            # (thread_local: the RCCL watchdog thread queries events while this thread captures)
+            state["g"].capture_begin(pool=self._seg_pool, capture_error_mode="thread_local")
+
+        def end():
+            state["g"].capture_end()
+            segs.append(("graph", state["g"]))
+            state["g"] = None
+
+        def gather(out_list, src):
+            # (no collective is issued during the capture pass - nothing executes in it anyway: the watchdog thread of the
+            # process group must not find an event of in-flight RCCL work tied to a capturing stream)
+            end()
+            segs.append(("gather", (out_list, src)))
+            begin()
+            if not state["forked"]:                  # the segment behind the ITC gather: rest of forward + whole backward
+                fork_teacher()
+
+        ops.CACHE.invalidate()
+        cs.wait_stream(cur)
+        self._defer_reduce = True
+        try:
+            with torch.cuda.stream(cs):
+                X.GATHER_HOOK = gather
+                try:
+                    begin()
+                    if not (dist_ready() or os.environ.get("EVLM_FORCE_REDUCE")):
+                        fork_teacher()                   # (no gather will cut the capture: fork at once)
+                    out = self._forward_backward(pipe["B"][k], pipe["T"][k])
+                    if not state["forked"]:
+                        fork_teacher()
+                    cs.wait_stream(side)                 # the teacher branch joins before its segment ends
+                    end()
+                finally:
+                    X.GATHER_HOOK = None
+                    if state["g"] is not None:           # an exception inside a capture: close it before re-raising
+                        try:
+                            state["g"].capture_end()
+                        except RuntimeError:
+                            pass
+                kd = self.last_kd
+                gopt = torch.cuda.CUDAGraph()
+                gopt.capture_begin(pool=self._seg_pool, capture_error_mode="thread_local")
+                self.opt.step()
+                gopt.capture_end()
+        finally:
+            self._defer_reduce = False
+        cur.wait_stream(cs)
+        torch.cuda.synchronize()
+        return dict(segs=segs, opt=gopt, out=out, kd=kd)
+
+    def _student_segmented(self, tpipe, tp, pipe, k):
+        key = (id(tpipe), tp, id(pipe), k)
+        sg = self._seg.get(key)
+        if sg is None:
+            scheduled = self.opt._scheduled
+            sg = self._seg[key] = self._capture_segments(tpipe, tp, pipe, k)
+            self.opt._scheduled = scheduled              # the captured optimiser step consumed the flag, not the schedule
+        for kind, item in sg["segs"]:
+            if kind == "graph":
+                item.replay()
+            else:
+                dist.all_gather(item[0], item[1])
+        self.reducer.reduce_async(self.opt.flat_grads)
+        self.reducer.finish()
+        sg["opt"].replay()
+        self.opt._scheduled = False
+        self.last_kd = sg["kd"]
+        return sg["out"]
 
     def _joint_body(self, pipe, p, pp, pk):
         cur, side = torch.cuda.current_stream(), self._side

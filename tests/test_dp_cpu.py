@@ -234,3 +234,40 @@ def test_parameter_broadcast_aligns_differently_seeded_replicas():
     with rank 0's parameters, still as views of the optimiser slabs"""
     (b0, a0, ok0), (b1, a1, ok1) = run2(_broadcast_case)
     assert not torch.equal(b0, b1) and torch.equal(a0, b0) and torch.equal(a1, b0) and ok0 and ok1
+
+
+def _segments_case(rank, world):
+    """GDTrainer at world 2 (CPU tensors, gloo): the gradient slabs are cut into the text / fusion / head part (sent when
+    backward enters the image encoder), two image-encoder layer groups (sent from hooks inside its backward) and the rest
+    (sent after backward) - together they must cover every gradient element exactly once"""
+    from efficientvlm_amd.models.model_pretrain import XVLM
+    from efficientvlm_amd.trainer import GDTrainer
+    from efficientvlm_amd.workload import GEOMS, model_config
+    torch.manual_seed(5 + rank)
+    geom = GEOMS["tiny"]
+    student, teacher = XVLM(model_config(geom, "s")), XVLM(model_config(geom, "t"))
+    tr = GDTrainer(student, teacher, dtype=torch.float32, use_graph=False)
+    assert tr.reducer.active and len(tr._vit_segments) == 3
+    enc = student.vision_encoder.encoder
+    assert sorted(enc.grad_hooks) == [2, 4]
+    for g in tr.opt.flat_grads:
+        g.zero_()
+    for seg in [tr._early] + tr._vit_segments:
+        for v in seg:
+            v.add_(1.0)
+    covered_once = all(bool((g == 1.0).all()) for g in tr.opt.flat_grads)
+    # the slabs' padding words (segments are rounded up to 8 elements) are covered too, so == 1 everywhere
+    names = {n: p for n, p in student.named_parameters()}
+    p45 = names["vision_encoder.encoder.layers.5.mlp.fc1.weight"].grad
+    p01 = names["vision_encoder.encoder.layers.0.mlp.fc1.weight"].grad
+    inside = lambda t, seg: any(v.data_ptr() <= t.data_ptr() < v.data_ptr() + v.numel() * 4 for v in seg)
+    order_ok = inside(p45, tr._vit_segments[0]) and inside(p01, tr._vit_segments[2]) and not inside(p01, tr._vit_segments[0])
+    # replicas were built from different seeds: after construction they hold rank 0's parameters
+    flat = torch.cat([g["p"] for g in tr.opt.groups])
+    return covered_once, order_ok, flat.clone()
+
+
+def test_trainer_gradient_segments_partition_the_slabs_and_replicas_start_equal():
+    (c0, o0, f0), (c1, o1, f1) = run2(_segments_case)
+    assert c0 and c1 and o0 and o1
+    assert torch.equal(f0, f1)

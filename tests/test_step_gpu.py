@@ -248,6 +248,7 @@ def test_benchmarked_configuration_matches_the_oracle(B):
     s_neg = torch.cat([(torch.arange(B) + 1 + torch.randint(0, B - 1, (B,), generator=g)) % B for _ in range(2)])
     t_neg = torch.cat([(torch.arange(B) + 1 + torch.randint(0, B - 1, (B,), generator=g)) % B for _ in range(2)])
     student.injected_neg_idx, teacher.injected_neg_idx = s_neg, t_neg
+    student.keep_injected_neg = teacher.keep_injected_neg = True      # warm-up steps and captured graphs included
     tr = GDTrainer(student, teacher, lr=1e-4, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=torch.bfloat16,
                    use_graph=True, pipeline_teacher=True)
     gb = {k: v.to(DEV) for k, v in batch.items()}
@@ -354,6 +355,62 @@ def test_data_parallel_code_path_on_one_gpu_matches_plain_step():
 
     a, b = run(False), run(True)
     assert np.allclose(a, b, rtol=2e-4, atol=1e-5), (a, b)
+
+
+_DP_SEG_SCRIPT = r"""
+import os, sys, json, torch
+sys.path.insert(0, os.environ["EVLM_REPO"]); sys.path.insert(0, os.path.join(os.environ["EVLM_REPO"], "tests"))
+import torch.distributed as dist
+from oracle import synth
+from test_step_gpu import build_gd
+from efficientvlm_amd.trainer import GDTrainer
+dp = bool(os.environ.get("EVLM_FORCE_REDUCE"))
+if dp:
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+geom = synth.GEOMS["tiny"]
+student, teacher = build_gd(geom, 9)
+neg = torch.tensor([1, 2, 3, 0, 2, 3, 0, 1])
+student.injected_neg_idx = teacher.injected_neg_idx = neg
+student.keep_injected_neg = teacher.keep_injected_neg = True
+tr = GDTrainer(student, teacher, lr=1e-3, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=torch.float32,
+               use_graph=True, pipeline_teacher=True)
+batches = [{k: v.cuda() for k, v in synth.make_batch(geom, 4, seed=3 + i).items()} for i in range(3)]
+out = []
+for i in range(6):
+    o = tr.step(batches[i % 3])
+    if o is not None:
+        out.append(o.tolist())
+torch.cuda.synchronize()
+if dp:
+    assert tr._seg and all(len([s for s in sg["segs"] if s[0] == "gather"]) == 1 for sg in tr._seg.values()), "no segmented graphs"
+    dist.destroy_process_group()
+else:
+    assert tr._joint
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_segmented_graph_step_of_the_multi_gpu_path_matches_the_single_gpu_graph():
+    """N > 1 code path with world_size 1 (RCCL group of one rank, the ITC all-gather forced through the collective): the
+    student step replayed as hipGraph segments around the gather and the gradient all-reduce (trainer._student_segmented)
+    must train exactly like the single-GPU joint graph - same losses over five optimiser steps on rotating batches"""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(dp):
+        env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        env.pop("EVLM_FORCE_REDUCE", None)
+        if dp:
+            env["EVLM_FORCE_REDUCE"] = "1"
+        r = subprocess.run([sys.executable, "-c", _DP_SEG_SCRIPT], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+        return np.array(json.loads(line[7:]))
+
+    a, b = run(False), run(True)
+    assert a.shape == b.shape and a.shape[0] == 5
+    assert np.allclose(a, b, rtol=3e-4, atol=1e-5), (a, b)
 
 
 def test_deferred_grouped_weight_gradients_match_immediate_ones():
