@@ -54,6 +54,13 @@ class AttnBwdArgs(C.Structure):
                 ("kd_teacher", _vp), ("kd_gout", _vp), ("kd_weight", _f)]
 
 
+class XAttnFusedArgs(C.Structure):
+    _fields_ = [("dtype", _i), ("Bimg", _i), ("Bq", _i), ("N", _i), ("Lq", _i), ("d", _i), ("H", _i), ("dh", _i),
+                ("ldx", _i), ("ldq", _i), ("ldo", _i), ("ldpr", _i),
+                ("X", _vp), ("Wkv", _vp), ("bias_kv", _vp), ("Q", _vp), ("kv_index", _vp), ("mask", _vp),
+                ("head_gate", _vp), ("scale", _f), ("O", _vp), ("P", _vp)]
+
+
 # name -> argtypes (every symbol include/evlm_hip.h declares; tests check the library exports all of them)
 SIGNATURES = {
     "evlm_gemm": [C.POINTER(GemmArgs), _vp],
@@ -64,6 +71,7 @@ SIGNATURES = {
     "evlm_layernorm_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "evlm_attention_fwd": [C.POINTER(AttnFwdArgs), _vp],
     "evlm_attention_bwd": [C.POINTER(AttnBwdArgs), _vp],
+    "evlm_xattn_fused_fwd": [C.POINTER(XAttnFusedArgs), _vp],
     "evlm_mse_fwd": [_i, _vp, _i, _vp, _i64, _f, _vp, _vp],
     "evlm_mse_bwd": [_i, _vp, _i, _vp, _i64, _f, _vp, _vp, _vp],
     "evlm_ce_fwd": [_i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp],

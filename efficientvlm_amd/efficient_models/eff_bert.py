@@ -35,6 +35,11 @@ __all__ = ["BertConfig", "BertModel", "BertForMaskedLM", "BertEmbeddings", "Bert
            "CausalLMOutputWithCrossAttentions", "CausalMask"]
 
 
+# the no-grad cross-attention forward through the fused kernel (evlm_xattn_fused_fwd); False = always the two-launch form
+# (packed K/V GEMM + attention kernel).  Set from the measured comparison in profiles/r02_xattn_fused.md.
+FUSED_CROSS_ATTENTION = False
+
+
 def _p(config, name):
     p = float(getattr(config, name, 0.0) or 0.0)
     if not 0.0 <= p < 1.0:
@@ -104,6 +109,14 @@ class BertSelfAttention(nn.Module):
         drop = self.attention_probs_dropout_prob if self.training else 0.0          # eff_bert.py:346 (probs returned un-dropped)
         if encoder_hidden_states is not None:
             q = ops.linear(hidden_states, self.query.weight, self.query.bias)
+            if (FUSED_CROSS_ATTENTION and drop == 0.0 and
+                    ops.xattn_fusable(q, encoder_hidden_states, (self.key.weight, self.value.weight), H, dh)):
+                # no-grad forward (frozen teacher, inference): K/V projection + attention in ONE launch, K/V never in HBM
+                ctx, probs = ops.cross_attention_fused(q, encoder_hidden_states, (self.key.weight, self.value.weight),
+                                                       (self.key.bias, self.value.bias), H, dh, scale,
+                                                       mask=_key_mask(encoder_attention_mask), gate=head_z,
+                                                       want_probs=bool(output_attentions), kv_index=encoder_batch_index)
+                return ((ctx, probs) if output_attentions else (ctx,)) + (None,)
             kv = ops.linear_packed(encoder_hidden_states, (self.key.weight, self.value.weight), (self.key.bias, self.value.bias))
             ctx, probs = ops.cross_attention(q, kv, H, dh, scale, mask=_key_mask(encoder_attention_mask), gate=head_z,
                                              want_probs=bool(output_attentions), kv_index=encoder_batch_index, dropout_p=drop)

@@ -721,6 +721,46 @@ def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True, 
     return _Attention.apply(q, kv, mask, gate, H, dh, 0, 0, d, scale, want_probs, kv_index, False, dropout_p)[:2]
 
 
+def xattn_fusable(q, x_img, weights, H, dh):
+    """does the fused cross-attention forward (evlm_xattn_fused_fwd: K/V projection + attention in one launch, nothing
+    kept for a backward) apply?  no-grad forwards only - the frozen teacher, inference"""
+    if torch.is_grad_enabled() and (q.requires_grad or x_img.requires_grad or any(w.requires_grad for w in weights)):
+        return False
+    d = H * dh
+    return (q.is_cuda and q.dtype == torch.bfloat16 and x_img.dtype == torch.bfloat16 and dh == 64 and H % 2 == 0
+            and x_img.shape[-1] == d and weights[0].shape == (d, d) and x_img.shape[1] <= 224 and d >= 128)
+
+
+def cross_attention_fused(q, x_img, weights, biases, H, dh, scale, mask=None, gate=None, want_probs=False, kv_index=None):
+    """q [Bq, Lq, d] (projected queries), x_img [Bimg, N, d] image tokens, weights = (Wk, Wv), biases = (bk, bv).
+    Returns (O [Bq, Lq, d], P [Bq, H, Lq, N] | None) like cross_attention(q, linear_packed(x_img, ...), ...) - same
+    arithmetic (the K/V tiles are rounded to bf16 exactly where the two-launch path rounds them), no K/V in HBM."""
+    L.require_cuda(q, x_img)
+    Bq, Lq, d = q.shape
+    Bimg, N, _ = x_img.shape
+    qc = q if q.is_contiguous() else q.contiguous()
+    xc = x_img if x_img.is_contiguous() else x_img.contiguous()
+    W = CACHE.get(tuple(weights), torch.bfloat16)
+    b = CACHE.get(tuple(biases), torch.float32) if biases and biases[0] is not None else None
+    O = torch.empty((Bq, Lq, d), dtype=torch.bfloat16, device=q.device)
+    Lkp = _pad8(N)
+    Pbuf = torch.empty((Bq, H, Lq, Lkp), dtype=torch.bfloat16, device=q.device) if want_probs else None
+    m32 = mask.detach().to(torch.float32).contiguous() if mask is not None else None
+    g32 = gate.detach().reshape(-1).to(torch.float32).contiguous() if gate is not None else None
+    idx = kv_index.to(torch.int32).contiguous() if kv_index is not None else None
+    if idx is None and Bq != Bimg:
+        raise RuntimeError("cross_attention_fused: without kv_index every query batch needs its own image")
+    a = L.XAttnFusedArgs(dtype=L.BF16, Bimg=Bimg, Bq=Bq, N=N, Lq=Lq, d=d, H=H, dh=dh, ldx=d, ldq=d, ldo=d, ldpr=Lkp,
+                         X=L.ptr(xc), Wkv=L.ptr(W), bias_kv=L.ptr(b), Q=L.ptr(qc), kv_index=L.ptr(idx), mask=L.ptr(m32),
+                         head_gate=L.ptr(g32), scale=scale, O=L.ptr(O), P=L.ptr(Pbuf))
+    L.check(_lib().evlm_xattn_fused_fwd(C.byref(a), L.stream()), "xattn_fused_fwd")
+    if GEMM_PROFILE is not None or ATTN_FLOPS is not None:
+        if ATTN_FLOPS is not None:
+            ATTN_FLOPS[0] += 4.0 * Bq * H * Lq * N * dh + 2.0 * Bimg * N * d * 2 * d
+    P = (Pbuf[..., :N] if Lkp != N else Pbuf) if Pbuf is not None else None
+    return O, P
+
+
 # ---------------------------------------------------------------------------------------------------
 # dropout (counter-based masks: regenerated in backward, never stored)
 # ---------------------------------------------------------------------------------------------------

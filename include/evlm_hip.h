@@ -181,6 +181,33 @@ typedef struct {
 int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused cross-attention FORWARD: K/V projection of the image tokens + Q K^T + softmax + P V (+ the map) in one launch.
+ *   K = X Wk^T + bk, V = X Wv^T + bv  (Wkv: [2d, d] rows Wk then Wv, bias_kv [2d] likewise - the packed layout the
+ *   two-launch path uses);  S = scale * Q K^T + mask[bq, k];  P = softmax(S);  O = (P V) * head_gate[h].
+ *   X [Bimg, N, ldx] (N <= 224 tokens: 224 x 224 images), Q [Bq, Lq, ldq] ALREADY projected queries, kv_index (int32 [Bq] or
+ *   NULL: identity, Bq == Bimg) maps each query batch to its image, mask additive f32 [Bq, N] or NULL,
+ *   O [Bq, Lq, ldo], P [Bq, H, Lq, ldpr] or NULL.  bf16, head dim 64, even H, d = 64 H.
+ * One workgroup per (image, head pair): the image tokens are read once per workgroup, K and V never reach HBM - which
+ * is also why there is no backward for it: this entry point serves forwards that keep nothing (the frozen teacher's
+ * fusion layers, inference).  Replaces BertSelfAttention.forward with encoder_hidden_states
+ * (efficient_models/eff_bert.py:277-364: key / value Linear :284-287, matmul :317, /sqrt(d) :330, + mask :335, softmax :338,
+ * matmul :352, *= head_z :354-355) for all text rows that attend to one image.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int dtype;                    /* EVLM_BF16 */
+  int Bimg, Bq, N, Lq, d, H, dh;
+  int ldx, ldq, ldo, ldpr;
+  const void* X; const void* Wkv; const float* bias_kv;
+  const void* Q;
+  const int32_t* kv_index;
+  const float* mask;
+  const float* head_gate;
+  float scale;
+  void* O; void* P;
+} evlm_xattn_fused_args;
+int evlm_xattn_fused_fwd(const evlm_xattn_fused_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Dropout of hidden states:  y = x .* keep / (1 - p)  (+ residual),  keep ~ Bernoulli(1 - p) per element.
  * Replaces nn.Dropout(hidden_dropout_prob) in BertEmbeddings (eff_bert.py:180,214), BertSelfOutput (:372,:379) and
  * BertOutput (:456,:460); with `residual` it also forms the "+ input_tensor" the LayerNorm that follows consumes.

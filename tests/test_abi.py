@@ -32,7 +32,7 @@ def test_struct_layout_matches_header():
     from efficientvlm_amd import _lib
     src = open(os.path.join(ROOT, "include", "evlm_hip.h")).read()
     for cname, st in (("evlm_gemm_args", _lib.GemmArgs), ("evlm_attn_fwd_args", _lib.AttnFwdArgs),
-                      ("evlm_attn_bwd_args", _lib.AttnBwdArgs)):
+                      ("evlm_attn_bwd_args", _lib.AttnBwdArgs), ("evlm_xattn_fused_args", _lib.XAttnFusedArgs)):
         body = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\}\s*" + cname, src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []

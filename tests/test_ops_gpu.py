@@ -540,6 +540,48 @@ def test_fused_attention_map_distillation_equals_the_separate_reduction(B, H, L)
     assert rel_err(a.grad.float(), b.grad.float()) < 6e-3
 
 
+@pytest.mark.parametrize("Bimg,rows,Lq,N,H", [(6, 4, 30, 197, 12), (5, 1, 30, 197, 12), (3, 3, 17, 100, 4), (2, 5, 40, 224, 2)])
+def test_fused_cross_attention_forward_is_bit_identical_to_the_two_launch_path(Bimg, rows, Lq, N, H):
+    """evlm_xattn_fused_fwd (K/V projection + QK^T + softmax + PV in one launch, K/V never in HBM; eff_bert.py:277-364 with
+    encoder_hidden_states) against the training path's two launches (packed K/V GEMM + MFMA attention through kv_index):
+    the projection runs the same K loop and the tiles are rounded to bf16 at the same point, so context AND probability
+    map must agree BIT FOR BIT - with key masks, head gates, shared images in arbitrary order and ragged query tiles"""
+    o = ops()
+    g = torch.Generator().manual_seed(71)
+    dh, d = 64, H * 64
+    Bq = Bimg * rows
+    x = rnd((Bimg, N, d), torch.bfloat16, g, 0.6)
+    q = rnd((Bq, Lq, d), torch.bfloat16, g, 0.6)
+    Wk, Wv = [torch.nn.Parameter(rnd((d, d), torch.float32, g, 0.04), requires_grad=False) for _ in range(2)]
+    bk, bv = [torch.nn.Parameter(rnd((d,), torch.float32, g, 0.2), requires_grad=False) for _ in range(2)]
+    idx = None
+    if rows > 1:
+        idx = torch.arange(Bimg).repeat(rows)[torch.randperm(Bq, generator=g)].to(DEV)
+    mask = torch.zeros(Bq, N)
+    mask[1, N - 7:] = -10000.0
+    mask[Bq - 1, :3] = -10000.0
+    gate = (torch.rand(H, generator=g) + 0.5).to(DEV)
+    with torch.no_grad():
+        assert o.xattn_fusable(q, x, (Wk, Wv), H, dh)
+        kv = o.linear_packed(x, (Wk, Wv), (bk, bv))
+        O1, P1 = o.cross_attention(q, kv, H, dh, 0.125, mask=mask.to(DEV), gate=gate, want_probs=True, kv_index=idx)
+        O2, P2 = o.cross_attention_fused(q, x, (Wk, Wv), (bk, bv), H, dh, 0.125, mask=mask.to(DEV), gate=gate,
+                                         want_probs=True, kv_index=idx)
+        O3, P3 = o.cross_attention_fused(q, x, (Wk, Wv), (bk, bv), H, dh, 0.125, mask=mask.to(DEV), gate=gate,
+                                         want_probs=False, kv_index=idx)
+    assert torch.equal(O1, O2) and torch.equal(P1, P2) and torch.equal(O1, O3) and P3 is None
+    # and against plain fp32 math (the bf16 tolerance of the attention tests)
+    kvr = (x.float() @ torch.cat([Wk, Wv], 0).t() + torch.cat([bk, bv]))
+    kvr = kvr if idx is None else kvr[idx]
+    sp = lambda t, Ln: t.reshape(Bq, Ln, H, dh).transpose(1, 2)
+    S = sp(q.float(), Lq) @ sp(kvr[..., :d], N).transpose(-1, -2) * 0.125 + mask.to(DEV)[:, None, None, :]
+    Pr = torch.softmax(S, -1)
+    Or = ((Pr @ sp(kvr[..., d:], N)) * gate[None, :, None, None]).transpose(1, 2).reshape(Bq, Lq, d)
+    assert rel_err(P2.float(), Pr) < tol(torch.bfloat16) and rel_err(O2.float(), Or) < 2 * tol(torch.bfloat16)
+    # a forward that needs gradients is never routed to the fused kernel
+    assert not o.xattn_fusable(q.clone().requires_grad_(True), x, (Wk, Wv), H, dh)
+
+
 def _pp256_case(o, L, g, I, J, K, qt=0, bias=False, res=False, act=0, dact=0):
     dtype = torch.bfloat16
     Pm = rnd((I, K), dtype, g, 0.5)
