@@ -94,6 +94,7 @@ class BertSelfAttention(nn.Module):
         self.value = nn.Linear(kv_in, self.all_head_size)
         self.attention_probs_dropout_prob = _p(config, "attention_probs_dropout_prob")
         self.is_cross_attention = is_cross_attention
+        self.input_alias = None        # set by forward: alias of its input for the residual of BertSelfOutput (see forward)
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_value=None, output_attentions=False, head_z=None,
@@ -107,8 +108,10 @@ class BertSelfAttention(nn.Module):
         H, dh = self.num_attention_heads, self.attention_head_size
         scale = 1.0 / math.sqrt(dh)
         drop = self.attention_probs_dropout_prob if self.training else 0.0          # eff_bert.py:346 (probs returned un-dropped)
+        # (linear_fork: the BertSelfOutput residual gets an ALIAS of the block input, whose gradient the projection's dX GEMM
+        # adds in its epilogue - one use of the input for autograd, no element-wise gradient add per block)
         if encoder_hidden_states is not None:
-            q = ops.linear(hidden_states, self.query.weight, self.query.bias)
+            q, self.input_alias = ops.linear_fork(hidden_states, (self.query.weight,), (self.query.bias,))
             if (FUSED_CROSS_ATTENTION and drop == 0.0 and
                     ops.xattn_fusable(q, encoder_hidden_states, (self.key.weight, self.value.weight), H, dh)):
                 # no-grad forward (frozen teacher, inference): K/V projection + attention in ONE launch, K/V never in HBM
@@ -121,8 +124,8 @@ class BertSelfAttention(nn.Module):
             ctx, probs = ops.cross_attention(q, kv, H, dh, scale, mask=_key_mask(encoder_attention_mask), gate=head_z,
                                              want_probs=bool(output_attentions), kv_index=encoder_batch_index, dropout_p=drop)
         else:
-            qkv = ops.linear_packed(hidden_states, (self.query.weight, self.key.weight, self.value.weight),
-                                    (self.query.bias, self.key.bias, self.value.bias))
+            qkv, self.input_alias = ops.linear_fork(hidden_states, (self.query.weight, self.key.weight, self.value.weight),
+                                                    (self.query.bias, self.key.bias, self.value.bias))
             ctx, probs = ops.self_attention(qkv, H, dh, scale, mask=_key_mask(attention_mask), gate=head_z,
                                             want_probs=bool(output_attentions), causal=isinstance(attention_mask, CausalMask),
                                             dropout_p=drop)
@@ -200,7 +203,9 @@ class BertAttention(nn.Module):
                 encoder_batch_index=None):
         self_outputs = self.self(hidden_states, attention_mask, head_mask, encoder_hidden_states, encoder_attention_mask,
                                  past_key_value, output_attentions, head_z=head_z, encoder_batch_index=encoder_batch_index)
-        attention_output = self.output(self_outputs[0], hidden_states, head_layer_z=head_layer_z)
+        residual, self.self.input_alias = self.self.input_alias, None
+        attention_output = self.output(self_outputs[0], residual if residual is not None else hidden_states,
+                                       head_layer_z=head_layer_z)
         return (attention_output,) + self_outputs[1:]
 
 

@@ -146,16 +146,16 @@ class CLIPEncoderLayer(nn.Module):
 
     def forward(self, hidden_states, attention_mask: None, output_attentions: Optional[bool] = False, head_z=None,
                 head_layer_z=None, mlp_z=None, kd_teacher=None, kd_word=None):
-        residual = hidden_states
-        h = ops.layer_norm(hidden_states, self.layer_norm1.weight, self.layer_norm1.bias, self.layer_norm1.eps)
+        # (layer_norm_fork: the residual branch gets an ALIAS of the block input, so that the LayerNorm backward kernel sums
+        # the two gradients of the input itself - evlm_layernorm_bwd_add - instead of autograd adding them element-wise)
+        h, residual = ops.layer_norm_fork(hidden_states, self.layer_norm1.weight, self.layer_norm1.bias, self.layer_norm1.eps)
         attn_out = self.self_attn(hidden_states=h, attention_mask=attention_mask,
                                   causal_attention_mask=None, output_attentions=output_attentions,
                                   head_z=head_z, head_layer_z=head_layer_z, residual=residual, kd_teacher=kd_teacher,
                                   kd_word=kd_word)
         hidden_states, attn_weights = attn_out[0], attn_out[1]
         self.kd_term = attn_out[2] if kd_teacher is not None else None
-        residual = hidden_states
-        h = ops.layer_norm(hidden_states, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps)
+        h, residual = ops.layer_norm_fork(hidden_states, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps)
         hidden_states = self.mlp(h, mlp_z=mlp_z, residual=residual)
         outputs = (hidden_states,)
         if output_attentions:

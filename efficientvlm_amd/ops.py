@@ -16,6 +16,7 @@ import torch
 from . import _lib as L
 
 _EMPTY = {}
+_NO_FORK = bool(__import__("os").environ.get("EVLM_NO_FORK"))      # measurement aid: residual-gradient adds left to autograd
 
 
 def _lib():
@@ -411,6 +412,13 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        return _linear_backward(ctx, dy, None)
+
+
+def _linear_backward(ctx, dy, dx_add):
+    """backward of _Linear; dx_add (optional, [.., K]): a gradient that reaches x along another branch (the residual that
+    bypasses this projection) - it rides on the dX GEMM's residual epilogue instead of a separate element-wise add"""
+    if True:
         x2, W, preact = ctx.saved_tensors
         M, N, K, ldp, ldc, act, nw, rows, has_bias, has_res, xshape, out_f32 = ctx.meta
         dtype = L.dt(x2)
@@ -445,14 +453,39 @@ class _Linear(torch.autograd.Function):
             else:
                 dxb = torch.empty((M, K), dtype=x2.dtype, device=x2.device)
                 Wt = CACHE.get_t(ctx.params[0]) if (dtype == L.BF16 and N % 64 == 0) else None
+                rkw = {}
+                if dx_add is not None:
+                    r2 = dx_add.reshape(M, K)
+                    if not r2.is_contiguous() or r2.dtype != x2.dtype:
+                        r2 = r2.to(x2.dtype).contiguous()
+                    rkw, dx_add = dict(residual=r2, ldx=K), None
                 if Wt is not None:      # dX = dY (W^T)^T: both operands K-contiguous, like the forward product
-                    _gemm(dtype, d2, Wt, dxb, M, K, N, ldd, N, K, p_trans=0, q_trans=0)
+                    _gemm(dtype, d2, Wt, dxb, M, K, N, ldd, N, K, p_trans=0, q_trans=0, **rkw)
                 else:
-                    _gemm(dtype, d2, W, dxb, M, K, N, ldd, K, K, p_trans=0, q_trans=1)     # dX = dY W
+                    _gemm(dtype, d2, W, dxb, M, K, N, ldd, K, K, p_trans=0, q_trans=1, **rkw)     # dX = dY W
             dx = dxb.view(xshape)
+            if dx_add is not None:          # (the padded-vocabulary branch above has no epilogue to ride on)
+                dx = dx + dx_add.view(xshape)
         weights, biases = ctx.params
         gw, gb = _wgrad(dtype, d2, ldd, x2, ldp, M, K, weights, rows, biases if has_bias else None)   # dW = dY^T X, db
         return (dx, dres, None, None, None, *gw, *gb)
+
+
+class _LinearFork(torch.autograd.Function):
+    """(linear(x), alias of x): the alias feeds the residual branch that bypasses this projection (post-LN BERT blocks:
+    a = LayerNorm(x + dense(attention(x)))), so autograd sees one use of x and the gradient of the alias is added in the
+    dX GEMM's epilogue (no element-wise add over [rows, d] per block)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, act, out_f32, nw, *wb):
+        y = _Linear.forward(ctx, x, residual, act, out_f32, nw, *wb)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dxa):
+        if dy is None:
+            return (dxa,) + (None,) * (4 + 2 * ctx.meta[6])
+        return _linear_backward(ctx, dy, dxa)
 
 
 def linear(x, weight, bias=None, act=L.ACT_NONE, residual=None, out_f32=False):
@@ -462,6 +495,14 @@ def linear(x, weight, bias=None, act=L.ACT_NONE, residual=None, out_f32=False):
 def linear_packed(x, weights, biases):
     """one GEMM for several Linear layers sharing the input: returns [.., sum N_i]"""
     return _Linear.apply(x, None, L.ACT_NONE, False, len(weights), *weights, *biases)
+
+
+def linear_fork(x, weights, biases):
+    """(packed linear(x), alias of x for a residual branch that bypasses it): see _LinearFork"""
+    weights, biases = tuple(weights), tuple(biases)
+    if not (torch.is_grad_enabled() and x.requires_grad) or _NO_FORK:
+        return _Linear.apply(x, None, L.ACT_NONE, False, len(weights), *weights, *biases), x
+    return _LinearFork.apply(x, None, L.ACT_NONE, False, len(weights), *weights, *biases)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -491,6 +532,9 @@ class _MLP(torch.autograd.Function):
         _gemm(dtype, a, W2, y, M, N, Fh, Fh, Fh, N, bias=b2.detach(), residual=r2, ldx=N)
         ctx.save_for_backward(x2, W1, W2, h, a, g32)
         ctx.params = (w1, b1, w2, b2)
+        # residual IS the input (post-LN BERT FFN: LayerNorm(x + FFN(x))): the backward then adds dy in the dX GEMM's
+        # epilogue and returns ONE gradient for x, instead of autograd summing the two with an element-wise add
+        ctx.res_is_x = residual is x and N == K and not _NO_FORK
         ctx.meta = (M, K, Fh, N, ldp, act, gate_pos, x.shape, gate.shape if gate is not None else None,
                     residual is not None)
         return y.view(*x.shape[:-1], N)
@@ -528,13 +572,15 @@ class _MLP(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dxb = torch.empty((M, K), dtype=x2.dtype, device=dev)
+            rkw = dict(residual=d2, ldx=K) if ctx.res_is_x else {}
             if W1t is not None:
-                _gemm(dtype, dh, W1t, dxb, M, K, Fh, Fh, Fh, K, p_trans=0, q_trans=0)
+                _gemm(dtype, dh, W1t, dxb, M, K, Fh, Fh, Fh, K, p_trans=0, q_trans=0, **rkw)
             else:
-                _gemm(dtype, dh, W1, dxb, M, K, Fh, Fh, K, K, p_trans=0, q_trans=1)
+                _gemm(dtype, dh, W1, dxb, M, K, Fh, Fh, K, K, p_trans=0, q_trans=1, **rkw)
             dx = dxb.view(xshape)
         (dW1,), (db1,) = _wgrad(dtype, dh, Fh, x2, ldp, M, K, (w1,), (Fh,), (b1,))
-        return dx, dW1, db1, dW2, db2, dgate, (dy if has_res else None), None, None
+        dres = None if (ctx.res_is_x and dx is not None) else (dy if has_res else None)
+        return dx, dW1, db1, dW2, db2, dgate, dres, None, None
 
 
 def mlp(x, w1, b1, w2, b2, act, gate=None, gate_pos=L.GATE_PRE, residual=None):
@@ -559,6 +605,7 @@ class _LayerNorm(torch.autograd.Function):
                                           L.ptr(y), L.ptr(mean), L.ptr(rstd), L.stream()), "layernorm_fwd")
         ctx.save_for_backward(xc, gamma, mean, rstd)
         ctx.params = (gamma, beta)
+        ctx.xshape = x.shape
         return y
 
     @staticmethod
@@ -578,8 +625,50 @@ class _LayerNorm(torch.autograd.Function):
         return (dx, None, None, None) if inplace else (dx, dg, db, None)
 
 
+class _LayerNormFork(torch.autograd.Function):
+    """(LayerNorm(x), x) - the second output is an alias of x for the residual branch that bypasses the norm (pre-LN blocks:
+    h = x + f(LN(x))).  Autograd then sees ONE use of x, and the backward kernel sums both incoming gradients itself
+    (evlm_layernorm_bwd_add) instead of autograd issuing an element-wise add over [rows, d] per block."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y = _LayerNorm.forward(ctx, x, gamma, beta, eps)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        xc, gamma, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None
+        d = xc.shape[-1]
+        rows = xc.numel() // d
+        dyc = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty_like(xc)
+        pg, pb = ctx.params
+        inplace = _inplace(pg) and _inplace(pb)
+        dg = pg.grad if inplace else torch.zeros(d, dtype=torch.float32, device=xc.device)
+        db = pb.grad if inplace else torch.zeros(d, dtype=torch.float32, device=xc.device)
+        ws = torch.empty(_lib().evlm_layernorm_bwd_blocks(rows) * 2 * d, dtype=torch.float32, device=xc.device)
+        if dres is not None:
+            rc = dres if (dres.is_contiguous() and dres.dtype == xc.dtype) else dres.to(xc.dtype).contiguous()
+            L.check(_lib().evlm_layernorm_bwd_add(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(rc), L.ptr(gamma.detach()), L.ptr(mean),
+                                                  L.ptr(rstd), rows, d, L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(ws), L.stream()),
+                    "layernorm_bwd_add")
+        else:
+            L.check(_lib().evlm_layernorm_bwd(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd),
+                                              rows, d, L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(ws), L.stream()), "layernorm_bwd")
+        return (dx.view(ctx.xshape), None, None, None) if inplace else (dx.view(ctx.xshape), dg, db, None)
+
+
 def layer_norm(x, gamma, beta, eps):
     return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+def layer_norm_fork(x, gamma, beta, eps):
+    """(LayerNorm(x), alias of x for the residual branch): see _LayerNormFork"""
+    if not (torch.is_grad_enabled() and x.requires_grad) or _NO_FORK:
+        return _LayerNorm.apply(x, gamma, beta, eps), x
+    return _LayerNormFork.apply(x, gamma, beta, eps)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -109,6 +109,12 @@ int evlm_layernorm_bwd_blocks(int rows);
 int evlm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
                        const float* rstd, int rows, int d, void* dx, float* dgamma, float* dbeta, float* partials,
                        void* stream);
+/* the same with  dx += addend  ([rows, d], dtype): the gradient arriving at x along the residual branch that bypasses this
+ * LayerNorm (CLIPEncoderLayer: hidden = residual + f(layer_norm(residual)), eff_vit.py:250-266) is summed in the kernel,
+ * replacing the element-wise add autograd would issue for the two uses of x. */
+int evlm_layernorm_bwd_add(int dtype, const void* dy, const void* x, const void* addend, const float* gamma,
+                           const float* mean, const float* rstd, int rows, int d, void* dx, float* dgamma,
+                           float* dbeta, float* partials, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-head attention core with the probability map as an OUTPUT (the KD losses consume it).
