@@ -441,6 +441,89 @@ def gen_itr(geom_name, B, seed):
     return fx
 
 
+def load_reference_evaluation():
+    """ast-extract Eff_Retrieval.evaluation (the driver cannot be imported: ruamel / apex / dataset at module level)"""
+    src = open(os.path.join(REF, "Eff_Retrieval.py")).read()
+    tree = ast.parse(src)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "evaluation")
+    fn.decorator_list = []                                  # (@torch.no_grad(): applied by the caller below)
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    return compile(mod, "<Eff_Retrieval.evaluation>", "exec")
+
+
+def gen_rerank(seed):
+    """the retrieval evaluation / rerank loop of Eff_Retrieval.py:215-319, run by the REFERENCE's own function on the
+    reference's EffXVLMforRetrieval (tiny geometry, deterministic gates): score matrices for one rank and for the two
+    shards of a 2-rank run"""
+    import datetime, time
+    geom = synth.GEOMS["tiny"]
+    work = tempfile.mkdtemp(prefix="evlm_oracle_")
+    os.chdir(work)
+    scfg, _ = write_configs(work, geom)
+    from efficient_models.model_retrieval import EffXVLMforRetrieval
+    torch.manual_seed(seed)
+    model = EffXVLMforRetrieval(scfg)
+    model.load_state_dict(det_state_dict(model.state_dict(), seed=5000 + seed, std=geom["std"]), strict=True)
+    g = torch.Generator().manual_seed(seed + 5)
+    with torch.no_grad():
+        for n, p in model.l0_module.named_parameters():
+            if "lambda" not in n:
+                p.copy_(torch.randn(p.shape, generator=g) * 3.0)
+    n_img, n_txt, k_test = 7, 11, 4
+    bi = synth.make_batch(geom, n_img, seed=seed + 31, ragged=True)
+    bt = synth.make_batch(geom, n_txt, seed=seed + 32, ragged=True)
+    images, text_ids, text_atts = bi["image"], bt["text_ids"], bt["text_atts"]
+
+    class Enc:
+        def __init__(self, ids, atts):
+            self.input_ids, self.attention_mask = ids, atts
+
+        def to(self, device):
+            return self
+
+    def tokenizer(text, **kw):                             # "texts" are row indices into the pre-tokenised tensors
+        rows = torch.tensor(list(text), dtype=torch.long)
+        return Enc(text_ids[rows], text_atts[rows])
+
+    class DS:
+        text = list(range(n_txt))
+        image = list(range(n_img))
+
+    class Loader:
+        dataset = DS()
+
+        def __iter__(self):
+            for i in range(0, n_img, 3):
+                yield images[i:i + 3], torch.arange(i, min(n_img, i + 3))
+
+    class Meter:
+        def __init__(self, delimiter="  "):
+            pass
+
+        def log_every(self, it, freq, header=None):
+            return it
+
+    code = load_reference_evaluation()
+    fx = {"meta.seed": np.array(seed), "meta.k_test": np.array(k_test), "in.image": np_(images), "in.text_ids": np_(text_ids),
+          "in.text_atts": np_(text_atts)}
+    for n, p in model.l0_module.named_parameters():
+        fx[f"in.l0.{n}"] = np_(p)
+    for n, (a, b) in checksums(model.state_dict()).items():
+        fx[f"wchk.{n}"] = np.array([a, b])
+    for rank, world in ((0, 1), (0, 2), (1, 2)):
+        rw = types.SimpleNamespace(MetricLogger=Meter, get_world_size=lambda w=world: w, get_rank=lambda r=rank: r)
+        ns = dict(torch=torch, utils=rw, time=time, datetime=datetime, dist=None, args=types.SimpleNamespace(distributed=False),
+                  print=lambda *a, **k: None)
+        exec(code, ns)
+        with torch.no_grad():
+            i2t, t2i, _ = ns["evaluation"](model, Loader(), tokenizer, "cpu",
+                                           {"batch_size_test_text": 4, "max_tokens": geom["L"], "k_test": k_test})
+        fx[f"out.r{rank}w{world}.i2t"] = np.asarray(i2t)
+        fx[f"out.r{rank}w{world}.t2i"] = np.asarray(t2i)
+    return fx
+
+
 def gen_l0(seed):
     """XVLML0Module standalone at FULL size (heads 12, ffn 3072; 6/3/3 layers)."""
     geom = synth.GEOMS["full"]
@@ -799,6 +882,8 @@ if __name__ == "__main__":
         save("gd_tiny.npz", gen_gd("tiny", B=3, seed=3, full=True))
     if "itr_tiny" in which:
         save("itr_tiny.npz", gen_itr("tiny", B=4, seed=4))
+    if "rerank_tiny" in which:
+        save("rerank_tiny.npz", gen_rerank(seed=6))
     if "gd_full" in which:
         save("gd_full.npz", gen_gd("full", B=2, seed=2, full=False))
     if "vqa_remap" in which:

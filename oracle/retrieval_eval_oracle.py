@@ -2,9 +2,10 @@
 smoke() and bench.py's cpu_baseline leg may import this package).
 
 Tensor-level: the reference's tokenizer / dataset plumbing is replaced by already-tokenised `text_ids`, `text_atts` and an
-`images` tensor.  Built from the fixture-pinned forward functions of oracle/xvlm_oracle.py; the reference driver itself
-cannot be imported (top-level ruamel / apex / dataset imports), so this composition has no captured vectors of its own:
-"parity unpinned" for the loop structure, pinned for every forward it calls.
+`images` tensor.  Built from the fixture-pinned forward functions of oracle/xvlm_oracle.py.  PINNED: the reference driver cannot be imported
+(top-level ruamel / apex / dataset imports), but its `evaluation` function can be ast-extracted and run on the reference's
+own model - oracle/gen_golden.py gen_rerank did, and tests/test_oracle_golden.py holds this restatement to those score
+matrices (tests/golden/rerank_tiny.npz: one rank and both shards of a 2-rank run).
 """
 import torch
 

@@ -310,3 +310,34 @@ def test_vqa_step_with_l0_matches_reference(golden_dir):
     close(total, fx["mix.total"], rtol=1e-5, what="total")
     total.backward()
     check_grads(fx, "student", s_sd, True, 2e-4)
+
+
+def test_retrieval_rerank_loop_matches_the_reference_evaluation_function(golden_dir):
+    """oracle/retrieval_eval_oracle.py against score matrices produced by the REFERENCE's own Eff_Retrieval.evaluation
+    (ast-extracted and run on the reference's EffXVLMforRetrieval by oracle/gen_golden.py: tests/golden/rerank_tiny.npz) -
+    one rank and both shards of a 2-rank run, the -100 fill of never-rescored pairs included"""
+    from oracle import retrieval_eval_oracle as RO
+    fx = load(golden_dir, "rerank_tiny.npz")
+    geom = synth.GEOMS["tiny"]
+    seed = int(fx["meta.seed"])
+    cfg = O.model_cfg(geom, "s")
+    sch = schema.xvlm_schema(cfg, geom["max_pos"], mlm=False, bbox=False, l0=True)
+    sd = schema.det_weights(sch, 5000 + seed, geom["std"])
+    for n in list(sd):
+        if n.startswith("l0_module."):
+            sd[n] = torch.from_numpy(fx["in.l0." + n[len("l0_module."):]]).clone()
+    ref_names = {k[5:] for k in fx if k.startswith("wchk.")}
+    assert ref_names == set(sd), sorted(ref_names ^ set(sd))[:8]
+    for n, (s, a) in checksums(sd).items():
+        if not n.startswith("l0_module."):
+            np.testing.assert_allclose([s, a], fx[f"wchk.{n}"], rtol=1e-9, atol=1e-9, err_msg=n)
+    images, ids, atts = (torch.from_numpy(fx["in." + k]) for k in ("image", "text_ids", "text_atts"))
+    logas = {k[len("l0_module."):]: v for k, v in sd.items() if k.endswith("_loga")}
+    zs = O.l0_forward(logas, False)
+    for rank, world in ((0, 1), (0, 2), (1, 2)):
+        i2t, t2i = RO.evaluation_scores(sd, cfg, images, ids, atts, int(fx["meta.k_test"]), zs=zs, rank=rank, world=world,
+                                        text_bs=4)
+        for got, name in ((i2t, "i2t"), (t2i, "t2i")):
+            want = fx[f"out.r{rank}w{world}.{name}"]
+            assert np.array_equal(got.numpy() == -100.0, want == -100.0), (rank, world, name)
+            close(got, want, rtol=1e-5, atol=1e-6, what=f"r{rank}w{world}.{name}")

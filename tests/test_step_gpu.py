@@ -560,6 +560,31 @@ def test_retrieval_evaluation_rerank_matches_oracle(with_gates):
     assert torch.all(s_i.cpu()[~done] == -200.0) and torch.all(s_t.cpu()[full_t == -100.0] == -200.0)
 
 
+def test_retrieval_evaluation_rerank_matches_the_reference_vectors():
+    """retrieval_eval.evaluation_scores (batched queries, shared image K/V) against the score matrices of the REFERENCE's
+    own Eff_Retrieval.evaluation (tests/golden/rerank_tiny.npz), fp32: same rescored pairs, scores within 2e-4"""
+    from efficientvlm_amd.efficient_models.model_retrieval import EffXVLMforRetrieval
+    from efficientvlm_amd.retrieval_eval import evaluation_scores
+    fx = load_fixture("rerank_tiny.npz")
+    geom = synth.GEOMS["tiny"]
+    seed = int(fx["meta.seed"])
+    cfg = O.model_cfg(geom, "s")
+    model = EffXVLMforRetrieval(model_config(geom, "s"))
+    load_det_weights(model, schema.xvlm_schema(cfg, geom["max_pos"], mlm=False, bbox=False, l0=True), 5000 + seed, geom["std"])
+    with torch.no_grad():
+        for n, p in model.l0_module.named_parameters():
+            p.copy_(torch.from_numpy(fx["in.l0." + n]))
+    model.to(DEV)
+    images, ids, atts = (torch.from_numpy(fx["in." + k]).to(DEV) for k in ("image", "text_ids", "text_atts"))
+    for rank, world in ((0, 1), (0, 2), (1, 2)):
+        gi, gt = evaluation_scores(model, images, ids, atts, k_test=int(fx["meta.k_test"]), zs="auto", query_bs=3, reduce=False,
+                                   rank=rank, world=world)
+        for got, name in ((gi, "i2t"), (gt, "t2i")):
+            want = torch.from_numpy(fx[f"out.r{rank}w{world}.{name}"])
+            assert torch.equal(got.cpu() == -100.0, want == -100.0), (rank, world, name)
+            assert torch.allclose(got.cpu(), want, rtol=2e-4, atol=2e-5), (rank, world, name)
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_pipelined_teacher_reproduces_the_unpipelined_training_trajectory(use_graph, monkeypatch):
     """GDTrainer(pipeline_teacher=True) runs the frozen teacher one batch ahead of the student.  With the hard negatives
