@@ -877,3 +877,134 @@ def test_itr_trainer_with_pipelined_teacher_reproduces_the_unpipelined_trajector
         outs[pipe] = torch.stack(seq).cpu()
     assert torch.allclose(outs[True], outs[False], rtol=5e-4, atol=1e-5), (outs[True], outs[False])
     assert float((outs[False][0] - outs[False][2]).abs().max()) > 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# full-width steps of BASELINE configs[2] / [3] / [4] (per-GPU shards, long image sequences) against the oracle
+# ---------------------------------------------------------------------------------------------------------------------
+def test_itr_384_step_full_width_bf16_tracks_the_fp32_oracle():
+    """BASELINE configs[2] on one GPU at full width: EffXVLMforRetrieval student + base teacher, 384 x 384 images = 577
+    image tokens (MFMA attention with 26-tile / long-sequence kernels, ragged weight-gradient reductions 8 x 577), L0 gates
+    sampled with injected noise, ITRTrainer step in bf16 - step-0 losses against the fp32 CPU oracle on the same weights,
+    batch, gate noise and hard negatives (reference: Eff_Retrieval.py:75-213)"""
+    from efficientvlm_amd.efficient_models.model_retrieval import EffXVLMforRetrieval
+    from efficientvlm_amd.models.model_retrieval import XVLM as TeacherITR
+    from efficientvlm_amd.trainer import ITRTrainer
+    geom = dict(synth.GEOMS["full"], image_res=384)
+    B = 8
+    s_cfg, t_cfg = O.model_cfg(geom, "s"), O.model_cfg(geom, "t")
+    s_sch = schema.xvlm_schema(s_cfg, geom["max_pos"], mlm=False, bbox=False, l0=True)
+    t_sch = schema.xvlm_schema(t_cfg, geom["max_pos"], mlm=False, bbox=False)
+    student = EffXVLMforRetrieval(model_config(geom, "s", image_res=384))
+    teacher = TeacherITR(model_config(geom, "t", image_res=384))
+    s_sd = load_det_weights(student, s_sch, 91, geom["std"])
+    t_sd = load_det_weights(teacher, t_sch, 92, geom["std"])
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for n, p in student.l0_module.named_parameters():
+            p.copy_(torch.full_like(p, 0.3) if "lambda" in n else torch.randn(p.shape, generator=gen) + 0.5)
+            s_sd["l0_module." + n] = p.detach().clone()
+    student.l0_module.set_lagrangian_warmup_steps(10)
+    student.to(DEV); teacher.to(DEV)
+    batch = synth.make_batch(geom, B, seed=19, ragged=True, image_res=384)
+    idx = torch.arange(B)
+    idx[2] = idx[1]
+    tr = ITRTrainer(student, teacher, lr=3e-5, reg_learning_rate=0.05, dtype=torch.bfloat16)
+    eps = {t: torch.rand(s_sd["l0_module." + O.L0_PARAM[t]].shape, generator=gen).clamp(1e-6, 1 - 1e-6) for t in O.L0_TYPES}
+    s_neg = torch.tensor([(i + 3) % B for i in range(2 * B)])
+    t_neg = torch.tensor([(i + 5) % B for i in range(2 * B)])
+    student.l0_module.injected_eps = {t: e.clone() for t, e in eps.items()}
+    student.injected_neg_idx, teacher.injected_neg_idx = s_neg.clone(), t_neg.clone()
+    got = tr.step({k: v.to(DEV) for k, v in batch.items()}, idx=idx.to(DEV)).cpu()
+    with torch.no_grad():
+        logas = {k[len("l0_module."):]: v for k, v in s_sd.items() if k.endswith("_loga")}
+        S = O.retrieval_forward(s_sd, s_cfg, batch, idx, s_neg, O.l0_forward(logas, True, eps))
+        T = O.retrieval_forward(t_sd, t_cfg, batch, idx, t_neg)
+        kd = O.kd_terms(S, T, with_cross_attn=True)
+        consts = O.l0_constants(geom["hidden"], geom["ffn"], geom["heads"], s_cfg["vit_layers"], s_cfg["fusion_layer"],
+                                s_cfg["text_layers"] - s_cfg["fusion_layer"])
+        lagr, _, _ = O.l0_lagrangian(logas, s_sd["l0_module.lambda_1"], s_sd["l0_module.lambda_2"], consts, 0,
+                                     target_sparsity=0.25, lagrangian_warmup=10)
+        total, mix = O.itr_loss_mix(S["loss"], kd, lagr)
+    want = torch.stack([total, S["loss"]["loss_itc"], S["loss"]["loss_itm"], mix["loss_kd"], lagr.reshape(())])
+    assert torch.isfinite(got).all()
+    assert torch.allclose(got, want, rtol=3e-2, atol=2e-3), (got, want)
+
+
+def test_vqa_480_step_full_width_bf16_tracks_the_fp32_oracle():
+    """BASELINE configs[3] on one GPU at full width: 480 x 480 images = 901 image tokens (the two-pass long-sequence dQ
+    kernel, K / V taking turns in LDS), causal answer decoder, VQAL0Module gates; VQATrainer step in bf16 against the fp32
+    CPU oracle (reference: Eff_VQA.py:74-200)"""
+    from efficientvlm_amd.trainer import VQATrainer
+    geom = dict(synth.GEOMS["full"], image_res=480)
+    student, teacher, s_sd, t_sd, s_cfg, t_cfg = _vqa_models(geom, 51, 52)
+    gen = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for n, p in student.l0_module.named_parameters():
+            p.copy_(torch.full_like(p, 0.3) if "lambda" in n else torch.randn(p.shape, generator=gen) + 0.5)
+            s_sd["l0_module." + n] = p.detach().clone()
+    student.l0_module.set_lagrangian_warmup_steps(10)
+    student.to(DEV); teacher.to(DEV)
+    batch = synth.make_vqa_batch(geom, 3, seed=23)
+    batch["image"] = torch.randn(3, 3, 480, 480, generator=gen)
+    tr = VQATrainer(student, teacher, lr=5e-5, reg_learning_rate=0.05, dtype=torch.bfloat16)
+    eps = {t: torch.rand(s_sd["l0_module." + O.L0_PARAM[t]].shape, generator=gen).clamp(1e-6, 1 - 1e-6) for t in O.L0_TYPES_VQA}
+    student.l0_module.injected_eps = {t: e.clone() for t, e in eps.items()}
+    got = tr.step({k: v.to(DEV) for k, v in batch.items()}).cpu()
+    tie = lambda sd: {**sd, "text_decoder.cls.predictions.decoder.weight": sd["text_decoder.bert.embeddings.word_embeddings.weight"],
+                      "text_decoder.cls.predictions.decoder.bias": sd["text_decoder.cls.predictions.bias"]}
+    with torch.no_grad():
+        logas = {k[len("l0_module."):]: v for k, v in s_sd.items() if k.endswith("_loga")}
+        S = O.vqa_forward(tie(s_sd), s_cfg, batch, O.l0_forward(logas, True, eps))
+        T = O.vqa_forward(tie(t_sd), t_cfg, batch)
+        kd = O.vqa_kd_terms(S, T)
+        nd = s_cfg["text_layers"] - s_cfg["fusion_layer"]
+        consts = O.l0_constants(geom["hidden"], geom["ffn"], geom["heads"], s_cfg["vit_layers"], s_cfg["fusion_layer"], nd, nd)
+        lagr, _, _ = O.l0_lagrangian(logas, s_sd["l0_module.lambda_1"], s_sd["l0_module.lambda_2"], consts, 0,
+                                     target_sparsity=0.25, lagrangian_warmup=10)
+        total, mix = O.vqa_loss_mix(S["loss"], kd, lagr)
+    want = torch.stack([total, S["loss"], mix["loss_kd"], lagr.reshape(())])
+    assert torch.isfinite(got).all()
+    assert torch.allclose(got, want, rtol=4e-2, atol=2e-3), (got, want)
+
+
+@pytest.mark.parametrize("keep", [0.75, 0.5, 0.25])
+def test_pruned_inference_equals_masked_dense_at_every_sparsity_of_the_sweep(keep):
+    """BASELINE configs[4] (25 / 50 / 75 % retained heads + FFN units): the physically pruned model (utils/xvlm_utils.py:37-145:
+    heads and FFN units with a zero gate removed) must score exactly what the masked-dense model scores with the same 0/1
+    gates - retrieval losses of the eval forward, fp32, tiny geometry, the gates drawn so that `keep` of every gate
+    vector survives"""
+    from efficientvlm_amd import pruning
+    from efficientvlm_amd.efficient_models.model_retrieval import EffXVLMforRetrieval
+    from efficientvlm_amd.runtime import compute
+    geom = synth.GEOMS["tiny"]
+    s_cfg = O.model_cfg(geom, "s")
+    model = EffXVLMforRetrieval(model_config(geom, "s"))
+    load_det_weights(model, schema.xvlm_schema(s_cfg, geom["max_pos"], mlm=False, bbox=False, l0=True), 33, geom["std"])
+    model.to(DEV).eval()
+    gen = torch.Generator().manual_seed(int(keep * 100))
+    zs = {}
+    with torch.no_grad():
+        ref = model.l0_module.forward(training=False)
+        for k, v in ref.items():
+            flat = v.reshape(v.shape[0], -1)
+            n = flat.shape[1]
+            nk = max(1, int(round(n * keep)))
+            z = torch.zeros_like(flat)
+            for r in range(flat.shape[0]):
+                z[r, torch.randperm(n, generator=gen)[:nk].to(z.device)] = 1.0
+            zs[k] = z.view_as(v)
+    batch = {k: v.to(DEV) for k, v in synth.make_batch(geom, 5, seed=3, ragged=True).items()}
+    idx = torch.arange(5, device=DEV)
+    neg = torch.tensor([1, 2, 3, 4, 0, 2, 3, 4, 0, 1])
+    with torch.no_grad(), compute(torch.float32):
+        model.injected_neg_idx = neg.clone()
+        dense = pruning.retrieval_eval_losses(model, batch["image"], batch["text_ids"], batch["text_atts"], idx=idx, zs=zs)
+        n_before = sum(p.numel() for p in model.parameters())
+        pruning.update_params(model, zs)
+        pruning.prune_model_with_z(zs, model, pad_to=8)
+        model.injected_neg_idx = neg.clone()
+        pruned = pruning.retrieval_eval_losses(model, batch["image"], batch["text_ids"], batch["text_atts"], idx=idx)
+    assert sum(p.numel() for p in model.parameters()) < n_before * (0.55 + 0.5 * keep)
+    for a, b in zip(dense, pruned):
+        close(b, a, 1e-4, 1e-6, f"keep {keep}")
