@@ -22,8 +22,9 @@ def per_kernel(dbpath, counter):
 
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {"note": "bytes per launch; fetch = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB; separate --pmc passes "
-               "of `python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-graph`", "kernels": {}}
+import os
+out = {"commit": os.environ.get("EVLM_COMMIT"), "note": "bytes per launch; fetch = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB; separate --pmc passes "
+               "of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-oracle-check --no-graph`", "kernels": {}}
 for k in sorted(fetch, key=lambda k: -fetch[k][1]):
     n, f = fetch[k]; nw, w = write.get(k, (0, 0.0))
     fb = 2.0 * f * 1024 / max(n, 1); wb = w * 1024 / max(nw, 1)
