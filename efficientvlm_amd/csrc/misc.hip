@@ -541,3 +541,28 @@ extern "C" int evlm_dropout_mask(int64_t n, float p, const int64_t* rng_state, u
   EVLM_LAUNCH_CHECK("evlm_dropout_mask");
   return 0;
 }
+
+// ---- grouped copy: many (src, dst, bytes) pairs in ONE launch -------------------------------------------------------
+// table: int64 [n][4] = {src, dst, bytes (a multiple of 16; both pointers 16-byte aligned), first block of the unit};
+// a block copies 64 KiB (256 threads x 16 x 16 bytes).  The teacher pipeline parks ~45 small tensors per step in
+// persistent buffers: one launch instead of 45 copy launches.
+__global__ __launch_bounds__(256) void copy_grouped_kernel(const int64_t* __restrict__ table, int n_units) {
+  int u = 0;
+  while (u + 1 < n_units && (int64_t)blockIdx.x >= table[4 * (u + 1) + 3]) ++u;      // (block-uniform scan)
+  const uint4* src = reinterpret_cast<const uint4*>(table[4 * u]);
+  uint4* dst = reinterpret_cast<uint4*>(table[4 * u + 1]);
+  const int64_t nvec = table[4 * u + 2] >> 4;
+  const int64_t v0 = ((int64_t)blockIdx.x - table[4 * u + 3]) * 4096;
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int64_t i = v0 + k * 256 + threadIdx.x;
+    if (i < nvec) dst[i] = src[i];
+  }
+}
+extern "C" int evlm_copy_grouped(const int64_t* table, int n_units, int total_blocks, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(table && n_units > 0 && total_blocks > 0, "evlm_copy_grouped: bad args");
+  hipLaunchKernelGGL(copy_grouped_kernel, dim3(total_blocks), dim3(256), 0, stream, table, n_units);
+  EVLM_LAUNCH_CHECK("evlm_copy_grouped");
+  return 0;
+}

@@ -88,7 +88,7 @@ class CLIPAttention(nn.Module):
         self.pruned_heads = self.pruned_heads.union(heads)
 
     def forward(self, hidden_states, attention_mask=None, causal_attention_mask=None, output_attentions=False,
-                head_z=None, head_layer_z=None, residual=None, kd_teacher=None, kd_word=None):
+                head_z=None, head_layer_z=None, residual=None, kd_teacher=None, kd_word=None, p_out=None):
         """hidden_states [B,N,C] -> (attn_output [B,N,C], probs [B,H,N,N] | None).
 
         `residual` (extension): added in the out_proj GEMM epilogue; the layer passes the block input.
@@ -114,7 +114,7 @@ class CLIPAttention(nn.Module):
             out = ops.linear(out, self.out_proj.weight, self.out_proj.bias, residual=residual)
             return out, (probs if output_attentions else None), kd
         out, probs = ops.self_attention(qkv, self.num_heads, self.head_dim, self.scale, mask=mask2d, gate=head_z,
-                                        want_probs=bool(output_attentions))
+                                        want_probs=bool(output_attentions), p_out=p_out if output_attentions else None)
         out = ops.linear(out, self.out_proj.weight, self.out_proj.bias, residual=residual)
         return out, (probs if output_attentions else None)
 
@@ -145,14 +145,14 @@ class CLIPEncoderLayer(nn.Module):
         self.layer_norm2 = nn.LayerNorm(hidden_size)
 
     def forward(self, hidden_states, attention_mask: None, output_attentions: Optional[bool] = False, head_z=None,
-                head_layer_z=None, mlp_z=None, kd_teacher=None, kd_word=None):
+                head_layer_z=None, mlp_z=None, kd_teacher=None, kd_word=None, p_out=None):
         # (layer_norm_fork: the residual branch gets an ALIAS of the block input, so that the LayerNorm backward kernel sums
         # the two gradients of the input itself - evlm_layernorm_bwd_add - instead of autograd adding them element-wise)
         h, residual = ops.layer_norm_fork(hidden_states, self.layer_norm1.weight, self.layer_norm1.bias, self.layer_norm1.eps)
         attn_out = self.self_attn(hidden_states=h, attention_mask=attention_mask,
                                   causal_attention_mask=None, output_attentions=output_attentions,
                                   head_z=head_z, head_layer_z=head_layer_z, residual=residual, kd_teacher=kd_teacher,
-                                  kd_word=kd_word)
+                                  kd_word=kd_word, p_out=p_out)
         hidden_states, attn_weights = attn_out[0], attn_out[1]
         self.kd_term = attn_out[2] if kd_teacher is not None else None
         h, residual = ops.layer_norm_fork(hidden_states, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps)
@@ -181,6 +181,9 @@ class CLIPEncoder(nn.Module):
         # extension: {layer index: callback} - a tensor hook on the INPUT of that layer: it fires when backward has finished
         # with layers >= index (their parameter gradients are complete): the data-parallel trainer reduces them right then
         self.grad_hooks = None
+        # extension: {layer index: caller-owned padded map buffer} - the layer's attention kernel writes its probability map
+        # there (a pipelined frozen teacher parks its maps in persistent buffers: written in place, never copied)
+        self.attn_out = None
         self.layers = nn.ModuleList([CLIPEncoderLayer(hidden_size, hidden_act, num_attention_heads, attention_dropout,
                                                       intermediate_size) for _ in range(num_hidden_layers)])
 
@@ -209,6 +212,8 @@ class CLIPEncoder(nn.Module):
                       head_layer_z=head_layer_z[idx] if head_layer_z is not None else None,
                       mlp_z=mlp_z[idx] if mlp_z is not None else None)
             kdkw = dict(kd_teacher=kd_maps[idx], kd_word=kd_words[idx]) if kd_maps is not None else {}
+            if self.attn_out and idx in self.attn_out and want_map and not do_gather and image_atts_blk is None:
+                kdkw["p_out"] = self.attn_out[idx]
             if self.grad_hooks and idx in self.grad_hooks and hidden_states.requires_grad:
                 cb = self.grad_hooks[idx]
                 hidden_states.register_hook(lambda grad, cb=cb: (cb(), grad)[1])

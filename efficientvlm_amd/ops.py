@@ -680,7 +680,7 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qbuf, kvbuf, mask, gate, H, dh, q_off, k_off, v_off, scale, want_probs, kv_index=None, causal=False,
-                dropout_p=0.0, kd_teacher=None, kd_weight=1.0):
+                dropout_p=0.0, kd_teacher=None, kd_weight=1.0, p_out=None):
         L.require_cuda(qbuf, kvbuf)
         assert qbuf.is_contiguous() and kvbuf.is_contiguous()
         B, Lq, ldq = qbuf.shape
@@ -690,6 +690,10 @@ class _Attention(torch.autograd.Function):
         need = any(ctx.needs_input_grad)
         Lkp = _pad8(Lk)          # probability rows are padded to 16 bytes; the kernels zero the padding
         Pbuf = torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev) if (want_probs or need) else None
+        if p_out is not None and Pbuf is not None:         # caller-owned (persistent) buffer for the map: no copy later
+            if tuple(p_out.shape) != (B, H, Lq, Lkp) or p_out.dtype != tdt or not p_out.is_contiguous():
+                raise RuntimeError("p_out must be a contiguous [B, H, Lq, pad8(Lk)] buffer of the activation dtype")
+            Pbuf = p_out
         P = (Pbuf[..., :Lk] if Lkp != Lk else Pbuf) if Pbuf is not None else None
         m32 = mask.detach().to(torch.float32).contiguous() if mask is not None else None
         g32 = gate.detach().reshape(-1).to(torch.float32).contiguous() if gate is not None else None
@@ -769,18 +773,18 @@ class _Attention(torch.autograd.Function):
             ATTN_FLOPS[0] += 8.0 * B * H * Lq * Lk * dh          # dP, dV, dQ, dK (P is read back, not recomputed)
         dg = dgate.view(gshape) if dgate is not None else None
         if self_attn:
-            return (dqbuf, None, None, dg) + (None,) * 12
-        return (dqbuf, dkvbuf, None, dg) + (None,) * 12
+            return (dqbuf, None, None, dg) + (None,) * 13
+        return (dqbuf, dkvbuf, None, dg) + (None,) * 13
 
 
 def self_attention(qkv, H, dh, scale, mask=None, gate=None, want_probs=True, causal=False, dropout_p=0.0,
-                   kd_teacher=None, kd_weight=1.0):
+                   kd_teacher=None, kd_weight=1.0, p_out=None):
     """qkv: [B, L, 3*H*dh] packed (q | k | v); causal: additionally -10000 on keys after the query (decoder self-attention:
     the backward works from the saved probabilities, so only the forward kernel knows about masks); dropout_p: dropout of
     the probabilities that form the context (the returned map stays un-dropped, eff_bert.py:338-361)"""
     d = H * dh
     O, P, kd = _Attention.apply(qkv, qkv, mask, gate, H, dh, 0, d, 2 * d, scale, want_probs, None, causal, dropout_p,
-                                kd_teacher, kd_weight)
+                                kd_teacher, kd_weight, p_out)
     return (O, P) if kd_teacher is None else (O, P, kd)
 
 
@@ -808,6 +812,46 @@ def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True, 
             kv = torch.index_select(kv, 0, kv_index.long())
             kv_index = None
     return _Attention.apply(q, kv, mask, gate, H, dh, 0, 0, d, scale, want_probs, kv_index, False, dropout_p)[:2]
+
+
+_PIN_POOL, _PIN_USED = None, 0
+
+
+def _pin_pool():
+    global _PIN_POOL
+    if _PIN_POOL is None:
+        _PIN_POOL = torch.empty(1 << 17, dtype=torch.int64).pin_memory()      # 1 MiB: ~700 tables of 45 copies
+    return _PIN_POOL
+
+
+def copy_grouped(pairs):
+    """[(src, dst)] contiguous same-size tensors -> ONE copy launch (evlm_copy_grouped); returns the device table (keep it
+    alive while a captured graph may replay the launch)"""
+    rows, blocks = [], 0
+    for src, dst in pairs:
+        nb = src.numel() * src.element_size()
+        if (nb != dst.numel() * dst.element_size() or nb % 16 or src.data_ptr() % 16 or dst.data_ptr() % 16
+                or not src.is_contiguous() or not dst.is_contiguous()):
+            raise RuntimeError("copy_grouped: contiguous, 16-byte aligned tensors of equal byte size (multiple of 16)")
+        rows += [src.data_ptr(), dst.data_ptr(), nb, blocks]
+        blocks += (nb + 65535) // 65536
+    dev = pairs[0][0].device
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture: the table goes up as a memcpy node out of a PINNED block that is never rewritten (a
+        # slice of a pool allocated outside any capture: pinning memory is not a capturable operation)
+        global _PIN_USED
+        if _PIN_POOL is None or _PIN_USED + len(rows) > _PIN_POOL.numel():
+            raise RuntimeError("copy_grouped: pinned table pool missing / exhausted (run one eager step before capturing)")
+        host = _PIN_POOL[_PIN_USED:_PIN_USED + len(rows)]
+        _PIN_USED += len(rows)
+        host.copy_(torch.tensor(rows, dtype=torch.int64))
+        table = torch.empty(len(rows), dtype=torch.int64, device=dev)
+        table.copy_(host, non_blocking=True)
+    else:
+        _pin_pool()
+        table = torch.tensor(rows, dtype=torch.int64).to(dev)
+    L.check(_lib().evlm_copy_grouped(L.ptr(table), len(pairs), blocks, L.stream()), "copy_grouped")
+    return table
 
 
 def xattn_fusable(q, x_img, weights, H, dh):

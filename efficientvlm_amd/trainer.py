@@ -336,18 +336,42 @@ class GDTrainer:
         return pipe
 
     def _teacher_eager(self, pipe, k):
-        """teacher forward on batch buffer k -> persistent outputs k (current stream)"""
+        """teacher forward on batch buffer k -> persistent outputs k (current stream).  The image encoder's attention maps
+        (most of the bytes: 60 MB per kept layer) are WRITTEN into the persistent buffers by the attention kernels
+        themselves; everything else is parked by ONE grouped copy launch."""
         b = pipe["B"][k]
-        with torch.no_grad(), compute(self.dtype):
-            T = self.teacher(b["image"], b["text_ids"], b["text_atts"], **distill.model_kwargs(b))
-            for d, key, i in pipe["slots"]:
-                src = T[d][key] if i is None else T[d][key][i]
-                dst = pipe["T"][k][d][key] if i is None else pipe["T"][k][d][key][i]
-                sb, db = ops._padded_base(src), ops._padded_base(dst)
-                if sb is not None and db is not None:
-                    db.copy_(sb)
-                else:
-                    dst.copy_(src)
+        enc = getattr(getattr(self.teacher, "vision_encoder", None), "encoder", None)
+        region = "idx_to_group_img" in b
+        if enc is not None and hasattr(enc, "attn_out") and not region:
+            maps = pipe["T"][k]["attention_dict"].get("image_attentions", [])
+            enc.attn_out = {i: ops._padded_base(m) if ops._padded_base(m) is not None else m
+                            for i, m in enumerate(maps) if torch.is_tensor(m) and m.numel() > 0}
+        try:
+            with torch.no_grad(), compute(self.dtype):
+                T = self.teacher(b["image"], b["text_ids"], b["text_atts"], **distill.model_kwargs(b))
+        finally:
+            if enc is not None and hasattr(enc, "attn_out"):
+                enc.attn_out = None
+        pairs = []
+        for d, key, i in pipe["slots"]:
+            src = T[d][key] if i is None else T[d][key][i]
+            dst = pipe["T"][k][d][key] if i is None else pipe["T"][k][d][key][i]
+            sb, db = ops._padded_base(src), ops._padded_base(dst)
+            if sb is not None and db is not None:
+                src, dst = sb, db
+            if src.data_ptr() == dst.data_ptr():
+                continue                                   # written in place
+            if not src.is_contiguous():
+                src = src.contiguous()
+            nb = src.numel() * src.element_size()
+            if nb % 16 or src.data_ptr() % 16 or dst.data_ptr() % 16 or not dst.is_contiguous():
+                dst.copy_(src)
+            else:
+                pairs.append((src, dst))
+        if pairs:
+            pipe.setdefault("copy_tables", []).append(ops.copy_grouped(pairs))      # (kept alive: captured launches read it)
+            if len(pipe["copy_tables"]) > 16 and not torch.cuda.is_current_stream_capturing():
+                del pipe["copy_tables"][:-16]
 
     def _student_eager(self, pipe, k):
         """student forward + backward on (batch k, teacher outputs k), gradient reduction, optimiser step"""

@@ -186,6 +186,12 @@ typedef struct {
 } evlm_attn_bwd_args;
 int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream);
 
+/* many device-to-device copies in ONE launch.  table: DEVICE int64 [n_units][4] = {source pointer, destination pointer, bytes,
+ * index of the unit's first workgroup}; bytes a multiple of 16, pointers 16-byte aligned, one workgroup per 64 KiB;
+ * total_blocks = sum over units of ceil(bytes / 65536).  Plumbing of the teacher pipeline (the frozen teacher's outputs,
+ * computed one batch ahead, are parked in persistent buffers: GeneralDistill.py:295-298 consumes them in the same step). */
+int evlm_copy_grouped(const int64_t* table, int n_units, int total_blocks, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused cross-attention FORWARD: K/V projection of the image tokens + Q K^T + softmax + P V (+ the map) in one launch.
  *   K = X Wk^T + bk, V = X Wv^T + bv  (Wkv: [2d, d] rows Wk then Wv, bias_kv [2d] likewise - the packed layout the
