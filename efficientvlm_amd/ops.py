@@ -360,6 +360,29 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
+# Loss kernels accumulate into f32 device words that must start at zero.  A trainer calls begin_step() once per step: ONE
+# fill of a small block, the ~30 loss scalars of a step are then views of it (instead of ~30 one-element fill launches).
+_ZERO_BLOCK = [None, 0]
+
+
+def begin_step(device):
+    """fresh zeroed block of loss accumulators for this step (capturable: a plain allocation + fill)"""
+    _ZERO_BLOCK[0] = torch.zeros(256, dtype=torch.float32, device=device)
+    _ZERO_BLOCK[1] = 0
+
+
+def end_step():
+    _ZERO_BLOCK[0] = None
+
+
+def zero_scalar(device):
+    blk, used = _ZERO_BLOCK
+    if blk is None or used >= blk.numel() or blk.device != torch.device(device):
+        return torch.zeros((), dtype=torch.float32, device=device)
+    _ZERO_BLOCK[1] = used + 1
+    return blk[used]
+
+
 _SCRATCH = {}
 
 
@@ -713,7 +736,7 @@ class _Attention(torch.autograd.Function):
             if isinstance(kd_weight, KdSlot):     # caller-provided zeroed f32 word (one fill for all layers of an encoder)
                 kd, kd_weight = kd_weight.word, kd_weight.weight
             else:
-                kd = torch.zeros((), dtype=torch.float32, device=dev)
+                kd = zero_scalar(dev)
             a.kd_teacher, a.kd_loss, a.kd_weight = L.ptr(kd_base), L.ptr(kd), float(kd_weight)
         drop = None
         if dropout_p and dropout_p > 0.0:
@@ -1025,7 +1048,7 @@ class _MSE(torch.autograd.Function):
             bc = b if b.is_contiguous() else b.contiguous()
             padded = False
         w = weight * (ac.numel() / n_true)        # kernels divide by the element count they sweep
-        out = torch.zeros((), dtype=torch.float32, device=a.device)
+        out = zero_scalar(a.device)
         L.check(_lib().evlm_mse_fwd(L.dt(ac), L.ptr(ac), L.dt(bc), L.ptr(bc), ac.numel(), w, L.ptr(out), L.stream()), "mse_fwd")
         ctx.save_for_backward(ac, bc)
         ctx.meta = (w, padded, a.shape)
@@ -1052,7 +1075,7 @@ class _MSESum(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weights, n, *tensors):
-        out = torch.zeros((), dtype=torch.float32, device=tensors[0].device)
+        out = zero_scalar(tensors[0].device)
         saved, meta = [], []
         for i in range(n):
             a, b = tensors[i], tensors[n + i]
@@ -1112,7 +1135,7 @@ class _CE(torch.autograd.Function):
         L.require_cuda(logits, labels)
         x2, R, Cn, ld = _rows2d(logits)
         lab = labels.reshape(-1).to(torch.int64).contiguous()
-        out = torch.zeros((), dtype=torch.float32, device=logits.device)
+        out = zero_scalar(logits.device)
         lse = torch.empty(2 * R, dtype=torch.float32, device=logits.device)
         valid = torch.zeros(1, dtype=torch.int32, device=logits.device)
         L.check(_lib().evlm_ce_fwd(L.dt(x2), L.ptr(x2), R, Cn, ld, L.ptr(lab), ignore_index, 1.0, L.ptr(lse), L.ptr(valid),
@@ -1151,7 +1174,7 @@ class _CEWeighted(torch.autograd.Function):
         lab = labels.reshape(-1).to(torch.int64).contiguous()
         rw = row_weight.detach().reshape(-1).to(torch.float32).contiguous()
         assert lab.numel() == R and rw.numel() == R
-        out = torch.zeros((), dtype=torch.float32, device=logits.device)
+        out = zero_scalar(logits.device)
         lse = torch.empty(2 * R, dtype=torch.float32, device=logits.device)
         valid = torch.zeros(1, dtype=torch.int32, device=logits.device)
         L.check(_lib().evlm_ce_weighted_fwd(L.dt(x2), L.ptr(x2), R, Cn, ld, L.ptr(lab), ignore_index, 1.0, L.ptr(rw),
@@ -1190,7 +1213,7 @@ class _KL(torch.autograd.Function):
         s2, R, Cn, lds = _rows2d(s)
         t2, Rt, Ct, ldt = _rows2d(t)
         assert (R, Cn) == (Rt, Ct)
-        out = torch.zeros((), dtype=torch.float32, device=s.device)
+        out = zero_scalar(s.device)
         ls = torch.empty(R, dtype=torch.float32, device=s.device)
         lt = torch.empty(R, dtype=torch.float32, device=s.device)
         L.check(_lib().evlm_kl_fwd(L.dt(s2), L.ptr(s2), lds, L.dt(t2), L.ptr(t2), ldt, R, Cn, inv_t, 1.0, L.ptr(ls), L.ptr(lt),

@@ -202,6 +202,13 @@ class GDTrainer:
     # ---- the step body (pure device work) ----------------------------------------------------------
     def _forward_backward(self, batch, teacher_out=None):
         self.opt.zero_grad()
+        ops.begin_step(batch["image"].device)
+        try:
+            return self._forward_backward_body(batch, teacher_out)
+        finally:
+            ops.end_step()
+
+    def _forward_backward_body(self, batch, teacher_out=None):
         with compute(self.dtype):
             total, S, T, kd, mix = distill.gd_forward(self.student, self.teacher, batch, self.temperature,
                                                       overlap_teacher=self.overlap_teacher, teacher_out=teacher_out)
