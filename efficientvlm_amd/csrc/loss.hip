@@ -385,3 +385,69 @@ extern "C" int evlm_adamw_step(float* p, const float* g, float* m, float* v, int
   EVLM_LAUNCH_CHECK("evlm_adamw_step");
   return 0;
 }
+
+// ---- ITM hard-negative sampling (reference efficient_models/xvlm.py:422-458) ----------------------------------------
+// The reference draws, per text, one image from  softmax_i(sim[i,t] / temp) + 1e-5  with the positives zeroed, and per
+// image one text likewise - 2B host-synchronising torch.multinomial(...).item() calls.  Here: ONE launch, one wave per
+// draw.  Row r < B is the draw for text r (over column r of sim), row B + r the draw for image r (over row r of sim).
+// The draw is the inverse CDF of those weights at u = Philox(seed, step, call_id, row) in (0,1): a categorical sample
+// with exactly the reference's probabilities (not torch's stream of random numbers - DESIGN.md §2, known deviations).
+__global__ __launch_bounds__(256) void sample_neg_kernel(const float* __restrict__ sim, int B, int ld,
+                                                         const float* __restrict__ temp, const int64_t* __restrict__ group,
+                                                         const int64_t* __restrict__ rng_state, uint32_t call,
+                                                         int64_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= 2 * B) return;
+  const bool t2i = row < B;
+  const int r = t2i ? row : row - B;
+  const int64_t stride = t2i ? ld : 1;
+  const float* s = t2i ? sim + r : sim + (int64_t)r * ld;
+  const float it = 1.0f / temp[0];
+  const int64_t gr = group ? group[r] : 0;
+  float m = -INFINITY;
+  for (int j = lane; j < B; j += 64) m = fmaxf(m, s[j * stride] * it);
+  m = wave_max(m);
+  float z = 0.f;
+  for (int j = lane; j < B; j += 64) z += __expf(s[j * stride] * it - m);
+  z = wave_sum(z);
+  const float iz = 1.0f / z;
+  auto weight = [&](int j) -> float {
+    if (j >= B) return 0.f;
+    const bool pos = group ? group[j] == gr : j == r;
+    return pos ? 0.f : __expf(s[j * stride] * it - m) * iz + 1e-5f;
+  };
+  float W = 0.f;
+  for (int j = lane; j < B; j += 64) W += weight(j);
+  W = wave_sum(W);
+  const DropRng rng = drop_rng(rng_state, call, 0.f);
+  uint32_t o[4];
+  philox4(rng, (uint64_t)row, o);
+  const float u = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f) * W;
+  float acc = 0.f;
+  int pick = -1, last = 0;
+  for (int c = 0; c < B && pick < 0; c += 64) {
+    const float w = weight(c + lane);
+    float inc = w;                                            // inclusive scan over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float v = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += v;
+    }
+    const unsigned long long hit = __ballot(acc + inc > u && w > 0.f);
+    const unsigned long long any = __ballot(w > 0.f);
+    if (any) last = c + 63 - __clzll(any);
+    if (hit) pick = c + __ffsll(hit) - 1;
+    acc += __shfl(inc, 63, 64);
+  }
+  if (pick < 0) pick = last;                                  // u rounded onto the total: the last admissible index
+  if (lane == 0) out[row] = pick;
+}
+extern "C" int evlm_sample_negatives(const float* sim, int B, int ld, const float* temp, const int64_t* group,
+                                     const int64_t* rng_state, uint32_t call_id, int64_t* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(sim && temp && rng_state && out && B > 0 && ld >= B, "evlm_sample_negatives: bad args");
+  hipLaunchKernelGGL(sample_neg_kernel, dim3(ceil_div(2 * B, 4)), dim3(256), 0, stream, sim, B, ld, temp, group, rng_state,
+                     call_id, out);
+  EVLM_LAUNCH_CHECK("evlm_sample_negatives");
+  return 0;
+}

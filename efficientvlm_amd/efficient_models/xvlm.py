@@ -6,7 +6,7 @@ state-dict keys.
 Kernel use: vision/text encoders are the HIP-backed eff_vit / eff_bert; projection heads, ITM head, L2
 normalisation, similarity matrices and the ITC / ITM / MLM cross-entropies are HIP ops.  What stays in PyTorch is
 plumbing only: the all-gather collective (RCCL), index_select/cat for the hard-negative batches, the [B,B] no-grad
-sampling weights + torch.multinomial, label tensors, and scalar glue (division by `temp`).
+the hard-negative draw (one evlm_sample_negatives launch), label tensors, and scalar glue (division by `temp`).
 """
 import os
 
@@ -362,7 +362,7 @@ class XVLMBase(nn.Module):
 
     @torch.no_grad()
     def _sample_negatives(self, image_feat, text_feat, idx):
-        """efficient_models/xvlm.py:422-458, batched: one device-side multinomial per direction, no host syncs."""
+        """efficient_models/xvlm.py:422-458, batched: one device-side sampling launch for both directions, no host syncs."""
         bs = image_feat.size(0)
         if self.injected_neg_idx is not None:
             neg = self.injected_neg_idx.to(image_feat.device).long()
@@ -371,21 +371,10 @@ class XVLMBase(nn.Module):
             self.injected_neg_idx = neg if getattr(self, "keep_injected_neg", False) else None
             assert neg.numel() == 2 * bs
             return neg[:bs], neg[bs:]
-        sim_i2t = _matmul_nt(image_feat.float(), text_feat.float()) / self.temp        # (the HIP fp32 GEMM, not a vendor one)
-        weights_i2t = F.softmax(sim_i2t, dim=1) + 1e-5
-        weights_t2i = F.softmax(sim_i2t.t(), dim=1) + 1e-5
-        if idx is None:
-            weights_i2t.fill_diagonal_(0)
-            weights_t2i.fill_diagonal_(0)
-        else:
-            idx = idx.view(-1, 1)
-            assert idx.size(0) == bs
-            mask = torch.eq(idx, idx.t())
-            weights_i2t.masked_fill_(mask, 0)
-            weights_t2i.masked_fill_(mask, 0)
-        img_neg = torch.multinomial(weights_t2i, 1).view(-1)
-        txt_neg = torch.multinomial(weights_i2t, 1).view(-1)
-        return img_neg, txt_neg
+        sim_i2t = _matmul_nt(image_feat.float(), text_feat.float())                   # (the HIP fp32 GEMM, not a vendor one)
+        # softmax(sim / temp) + 1e-5, positives zeroed, one categorical draw per row and per column: ONE launch
+        neg = ops.sample_negatives(sim_i2t, self.temp, None if idx is None else idx.view(-1))
+        return neg[:bs], neg[bs:]
 
     def get_matching_loss(self, image_embeds, image_atts, image_feat, text_embeds, text_atts, text_feat, idx=None,
                           output_attentions=None, output_hidden_states=None, head_z=None, head_layer_z=None, mlp_z=None):

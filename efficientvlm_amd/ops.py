@@ -939,7 +939,9 @@ def dropout_state(device):
 
 
 def dropout_seed(seed, device="cuda"):
-    """re-seed the dropout stream of `device` (step counter back to 0)"""
+    """re-seed the device random stream of `device` (dropout masks, hard-negative draws): step word and call-site counter
+    back to 0, so two runs issuing the same calls draw the same numbers"""
+    _DROP_CALL[0] = 0
     st = dropout_state(torch.device(device))
     st.copy_(torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
 
@@ -957,6 +959,27 @@ def _next_drop_call(kind, shape, p):
     if DROPOUT_LOG is not None:
         DROPOUT_LOG.append((_DROP_CALL[0], kind, tuple(shape), float(p)))
     return _DROP_CALL[0]
+
+
+def sample_negatives(sim, temp, group=None):
+    """ITM hard negatives in one launch (evlm_sample_negatives; reference efficient_models/xvlm.py:422-458): sim f32 [B, B]
+    image x text similarities, temp the (device) temperature, group optional int64 [B] positive-group ids.  Returns int64
+    [2B]: for every text an image index, then for every image a text index.  Draws from the device Philox stream of
+    dropout_state() - fresh on every step (and every graph replay) once the trainer ticks the step word."""
+    global DROPOUT_USED
+    L.require_cuda(sim)
+    B = sim.shape[0]
+    assert sim.dim() == 2 and sim.shape[1] == B and sim.dtype == torch.float32 and sim.stride(1) == 1
+    t = temp.detach().reshape(-1)[:1].to(torch.float32) if torch.is_tensor(temp) else \
+        torch.full((1,), float(temp), dtype=torch.float32, device=sim.device)
+    g = None if group is None else group.reshape(-1).to(torch.int64).contiguous()
+    DROPOUT_USED = True
+    _DROP_CALL[0] = (_DROP_CALL[0] + 1) & 0xFFFFFFFF
+    out = torch.empty(2 * B, dtype=torch.int64, device=sim.device)
+    L.check(_lib().evlm_sample_negatives(L.ptr(sim), B, sim.stride(0), L.ptr(t), L.ptr(g) if g is not None else None,
+                                         L.ptr(dropout_state(sim.device)), _DROP_CALL[0], L.ptr(out), L.stream()),
+            "sample_negatives")
+    return out
 
 
 def dropout_mask(call_id, shape, p, device="cuda"):

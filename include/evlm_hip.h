@@ -331,6 +331,16 @@ int evlm_l0_deterministic(const float* loga, int rows, int size, float temperatu
                           float* z, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * ITM hard negatives (efficient_models/xvlm.py:422-458 - there 2B host-synchronising torch.multinomial calls).
+ * sim: f32 [B, ld] image x text similarities (un-scaled), temp: device f32 word, group: optional int64 [B] ids whose
+ * equal entries are positives of each other (NULL: only the diagonal).  out int64 [2B]: out[t] = image drawn for text t
+ * from softmax_i(sim[i,t]/temp) + 1e-5 with positives zeroed, out[B+i] = text drawn for image i likewise.  The draw is
+ * the inverse CDF at a Philox(rng_state {seed, step}, call_id, row) uniform: one launch, no host sync, replayable.
+ * ---------------------------------------------------------------------------------------------- */
+int evlm_sample_negatives(const float* sim, int B, int ld, const float* temp, const int64_t* group,
+                          const int64_t* rng_state, uint32_t call_id, int64_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimiser-side helpers (next-tier row §8f-1; kept minimal here)
  * ---------------------------------------------------------------------------------------------- */
 /* *out += sum(x^2) over n f32 values (global grad norm, apex_ddp_accelerator.py:99-102) */

@@ -746,3 +746,102 @@ def test_grouped_transposes_and_weight_transposes_follow_the_optimiser():
         assert x.grad is not None and torch.isfinite(x.grad.float()).all()
         opt.set_schedule(1.0)
         opt.step()                       # parameters move -> the copies must follow
+
+
+# ---- ITM hard-negative sampler (evlm_sample_negatives; reference efficient_models/xvlm.py:422-458) -------------------
+def _neg_weights(sim, temp, group=None):
+    """the reference's sampling weights, in float64: softmax(sim / temp) + 1e-5 with the positives zeroed"""
+    s = sim.double().cpu().numpy() / temp
+    B = s.shape[0]
+
+    def w(mat):
+        e = np.exp(mat - mat.max(1, keepdims=True))
+        p = e / e.sum(1, keepdims=True) + 1e-5
+        if group is None:
+            p[np.arange(B), np.arange(B)] = 0
+        else:
+            g = np.asarray(group)
+            p[g[:, None] == g[None, :]] = 0
+        return p / p.sum(1, keepdims=True)
+    return w(s.T), w(s)           # per text over images, per image over texts
+
+
+def test_negative_sampler_draws_from_the_reference_distribution():
+    ops = globals()['ops']()
+    torch.manual_seed(3)
+    B, temp, n = 6, 0.7, 6000
+    sim = (torch.randn(B, B, device="cuda") * 1.5).contiguous()
+    t = torch.tensor(temp, device="cuda")
+    ops.dropout_seed(11)
+    draws = []
+    for _ in range(n):
+        draws.append(ops.sample_negatives(sim, t))
+        ops.dropout_tick()
+    d = torch.stack(draws).cpu().numpy()                                   # [n, 2B]
+    p_t2i, p_i2t = _neg_weights(sim, temp)
+    for row in range(2 * B):
+        p = p_t2i[row] if row < B else p_i2t[row - B]
+        freq = np.bincount(d[:, row], minlength=B) / n
+        assert freq[row % B] == 0                                          # the positive is never drawn
+        assert np.all(np.abs(freq - p) < 4.5 * np.sqrt(p * (1 - p) / n) + 1e-3), (row, freq, p)
+
+
+def test_negative_sampler_groups_determinism_and_long_rows():
+    ops = globals()['ops']()
+    torch.manual_seed(4)
+    B = 300                                                                # several 64-wide chunks per row
+    sim = torch.randn(B, B, device="cuda")
+    group = torch.arange(B, device="cuda") // 3                            # triples of mutual positives
+    t = torch.tensor(0.5, device="cuda")
+    ops.dropout_seed(5)
+    call0 = ops._DROP_CALL[0]
+    a = ops.sample_negatives(sim, t, group)
+    assert a.dtype == torch.int64 and a.shape == (2 * B,) and int(a.min()) >= 0 and int(a.max()) < B
+    rows = torch.arange(B, device="cuda").repeat(2)
+    assert not bool((group[a] == group[rows]).any())                       # never a member of the own group
+    ops._DROP_CALL[0] = call0                                              # same (seed, step, call id) -> same draw
+    assert torch.equal(ops.sample_negatives(sim, t, group), a)
+    ops.dropout_tick()
+    ops._DROP_CALL[0] = call0
+    assert not torch.equal(ops.sample_negatives(sim, t, group), a)         # next step: new draws
+    # one overwhelming candidate per row / column, placed beyond the first chunk
+    sim2 = torch.zeros(B, B, device="cuda")
+    tgt = (torch.arange(B, device="cuda") + 170) % B
+    sim2[torch.arange(B), tgt] = 60.0                                      # image i -> text tgt[i]
+    out = ops.sample_negatives(sim2, torch.tensor(1.0, device="cuda"))
+    # (the +1e-5 floor leaves the other 298 candidates 0.3 % of the mass: ~2 of the 600 draws may land elsewhere)
+    assert int((out[B:] != tgt).sum()) <= 8
+    inv = torch.empty_like(tgt); inv[tgt] = torch.arange(B, device="cuda")
+    assert int((out[:B] != inv).sum()) <= 8                                # text t -> the image whose target it is
+    # a padded (strided) similarity buffer, as _matmul_nt returns it
+    buf = torch.zeros(B, B + 4, device="cuda"); buf[:, :B] = sim2
+    ops._DROP_CALL[0] -= 1                                                 # the same random numbers as for `out`
+    assert torch.equal(ops.sample_negatives(buf[:, :B], torch.tensor(1.0, device="cuda")), out)
+
+
+def test_model_forward_samples_its_negatives_with_the_device_sampler():
+    """no injected indices: XVLM._sample_negatives -> evlm_sample_negatives; admissible, positive-free, fresh per step"""
+    from helpers import load_fixture, batch_from_fixture, model_config
+    from oracle import synth
+    from efficientvlm_amd.models.model_pretrain import XVLM
+    from efficientvlm_amd.runtime import compute
+    ops = globals()['ops']()
+    fx = load_fixture("gd_tiny.npz")
+    geom = synth.GEOMS["tiny"]
+    torch.manual_seed(0)
+    model = XVLM(model_config(geom, "s")).to("cuda").eval()
+    batch = batch_from_fixture(fx, "cuda")
+    B = batch["image"].shape[0]
+    ops.dropout_seed(9)
+    seen = set()
+    for _ in range(12):
+        with torch.no_grad(), compute(torch.float32):
+            model(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
+                  masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"], output_attentions=True,
+                  output_hidden_states=True)
+        neg = model.last_neg_idx.cpu()
+        assert neg.shape == (2 * B,) and int(neg.min()) >= 0 and int(neg.max()) < B
+        assert not bool((neg == torch.arange(B).repeat(2)).any())
+        seen.add(tuple(neg.tolist()))
+        ops.dropout_tick()
+    assert B <= 2 or len(seen) > 1

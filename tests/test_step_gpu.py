@@ -317,6 +317,7 @@ sys.path.insert(0, os.environ["EVLM_REPO"]); sys.path.insert(0, os.path.join(os.
 import torch.distributed as dist
 from oracle import synth
 from test_step_gpu import build_gd
+from efficientvlm_amd import ops
 from efficientvlm_amd.trainer import GDTrainer
 dp = bool(os.environ.get("EVLM_FORCE_REDUCE"))
 if dp:
@@ -327,7 +328,7 @@ student, teacher = build_gd(geom, 7)
 tr = GDTrainer(student, teacher, lr=1e-3, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=torch.float32,
                use_graph=False)
 batch = {k: v.cuda() for k, v in synth.make_batch(geom, 4, seed=3).items()}
-torch.manual_seed(0)       # hard-negative multinomial draws
+ops.dropout_seed(0)        # hard-negative draws (device Philox stream)
 out = [tr.step(batch).tolist() for _ in range(3)]
 assert tr.reducer.active == dp and (tr._early_sent or not dp)
 torch.cuda.synchronize()
@@ -416,6 +417,7 @@ def test_segmented_graph_step_of_the_multi_gpu_path_matches_the_single_gpu_graph
 def test_deferred_grouped_weight_gradients_match_immediate_ones():
     """GDTrainer (bf16, B = 64, full geometry): gradients with the dW products queued and flushed as grouped launches
     against the same step with every dW launched in place (split-K kernels)"""
+    from efficientvlm_amd import ops
     from efficientvlm_amd.trainer import GDTrainer
     geom = synth.GEOMS["full"]
     batch = {k: v.to(DEV) for k, v in synth.make_batch(geom, 64, seed=11).items()}
@@ -424,7 +426,7 @@ def test_deferred_grouped_weight_gradients_match_immediate_ones():
         student, teacher = build_gd(geom, 5)
         tr = GDTrainer(student, teacher, dtype=torch.bfloat16, use_graph=False)
         tr.defer_wgrad = defer
-        torch.manual_seed(0)
+        ops.dropout_seed(0)           # hard-negative draws (device Philox stream): the same in both runs
         tr._forward_backward(batch)
         torch.cuda.synchronize()
         slabs.append([g.clone() for g in tr.opt.flat_grads])
