@@ -5,8 +5,8 @@ state-dict keys.
 
 Kernel use: vision/text encoders are the HIP-backed eff_vit / eff_bert; projection heads, ITM head, L2
 normalisation, similarity matrices and the ITC / ITM / MLM cross-entropies are HIP ops.  What stays in PyTorch is
-plumbing only: the all-gather collective (RCCL), index_select/cat for the hard-negative batches, the [B,B] no-grad
-the hard-negative draw (one evlm_sample_negatives launch), label tensors, and scalar glue (division by `temp`).
+plumbing only: the all-gather collective (RCCL), index_select/cat for the hard-negative batches, label tensors, and
+scalar glue (division by `temp`).  The hard-negative draw itself is one evlm_sample_negatives launch.
 """
 import os
 
