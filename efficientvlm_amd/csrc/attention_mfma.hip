@@ -583,6 +583,209 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
   }
 }
 
+// =============================================================================================
+// single-pass backward: every query and every key of one (batch, head) in ONE workgroup (self-attention with Lq, Lk <= 16 NT:
+// the ViT's 197 tokens, the 30-token text passes).  dS never goes to HBM and P / dO / Q are read once:
+//   phase 1  (kernel A's arithmetic, a wave owns 16 queries x all keys, G query tiles per wave): dS^T, P^T in registers,
+//            dQ written; dS^T is transposed into LDS as [32 q][32 key] tiles;
+//   phase 2  K and V are dead: Q and dO are staged in their place; wave w owns key tile w:
+//            dK^T[d][key] = scale * sum_q Q[q][d] dS[q][key]   (both operands by column reads, as in kernel B);
+//   phase 3  the P^T registers replace dS in the same LDS tiles:  dV^T[d][key] = gate * sum_q dO[q][d] P[q][key].
+// LDS: (NT/2)^2 tiles of 2 KiB + 2 x NT x 2 KiB = 154 KiB at NT = 14 (one workgroup per CU; the kernel is HBM-bound and
+// moves ~half the bytes of kernels A + B).
+// =============================================================================================
+__device__ __forceinline__ int s_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 3); }
+// B operand from a [32 q][32 key] tile (64-byte rows): k-slot j <-> tile row 8g + j, column = key 16*ct + (lane&15)
+__device__ __forceinline__ bf16x8 scol_frag(const char* tile, int ct, int lane) {
+  const int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3;
+  bf16x8 out;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = g * 8 + h * 4 + q;
+    const int off = row * 64 + s_swz(row, ct * 2 + (p >> 1)) * 16 + ((p & 1) << 3);
+    bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(tile + off));
+    out[4 * h + 0] = t[0]; out[4 * h + 1] = t[1]; out[4 * h + 2] = t[2]; out[4 * h + 3] = t[3];
+  }
+  return out;
+}
+
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
+  constexpr int G = (NT + NW - 1) / NW, KC = NT / 2, QC = NT / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ss = smem;                          // [QC][KC] tiles of [32 q][32 key]: dS, then P
+  char* Ks = smem + QC * KC * 2048;         // phase 1: K (v_swz);  phases 2-3: Q as [QC] tiles of [32 q][64] (p_swz)
+  char* Vs = Ks + NT * 16 * 128;            // phase 1: V (k_swz);  phases 2-3: dO likewise
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ql = lane & 15;
+  stage_rows<true>(a.K + (size_t)b * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
+  stage_rows<false>(a.V + (size_t)b * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
+  stage_wait();
+  __syncthreads();
+  const float gz = a.gate ? a.gate[h] : 1.0f;
+  const float kdc = a.Pt ? a.kd_coef * a.kd_gout[0] : 0.f;
+  bf16x4 pvg[G][NT];
+  float gsum = 0.f;
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) {
+    const int qt = gi * NW + wave;
+    if (qt >= NT) continue;                         // wave-uniform
+    const int q = qt * 16 + ql;
+    const bool qok = q < a.Lq;
+    bf16x8 dof[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qok) v = *reinterpret_cast<const uint4*>(a.dO + ((size_t)b * a.Lq + q) * a.ldo + h * DH + ks * 32 + g * 8);
+      dof[ks] = *reinterpret_cast<bf16x8*>(&v);
+    }
+    const size_t prow = (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr;
+    f32x4 acc[NT];
+    float dsum = 0.f;
+#pragma unroll
+    for (int s = 0; s < NT / 2; ++s) {
+      const int kcol = s * 32 + g * 8;
+      const bool ok = qok && kcol < a.ldpr;
+      bf16x8 p8;
+      float ex[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { p8[r] = (bf16)0.f; ex[r] = 0.f; }
+      if (ok) {
+        p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
+        if (a.E) {
+          const bf16x8 e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) ex[r] = (float)e8[r];
+        }
+        if (a.Pt) {
+          const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(a.Pt + prow + kcol);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) ex[r] += kdc * ((float)p8[r] - (float)t8[r]);
+        }
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int t = 2 * s + hh;
+        acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, t, ks, lane), dof[ks], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pvg[gi][t][r] = p8[hh * 4 + r];
+          const float p = (float)p8[hh * 4 + r], dpo = acc[t][r];
+          gsum += p * dpo;
+          const float dp = gz * dpo + ex[hh * 4 + r];
+          acc[t][r] = dp;
+          dsum += p * dp;
+        }
+      }
+    }
+    dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    char* srow = Ss + (size_t)((qt >> 1) * KC) * 2048 + ((qt & 1) * 16 + ql) * 64;
+    const int sr = (qt & 1) * 16 + ql;
+#pragma unroll
+    for (int s = 0; s < NT / 2; ++s) {
+      bf16x8 d8;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d8[r] = (bf16)((float)pvg[gi][2 * s][r] * (acc[2 * s][r] - dsum));
+        d8[4 + r] = (bf16)((float)pvg[gi][2 * s + 1][r] * (acc[2 * s + 1][r] - dsum));
+      }
+      *reinterpret_cast<bf16x8*>(srow + s * 2048 + s_swz(sr, g) * 16) = d8;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Ks, 2 * s, 2 * s + 1, dt, lane), d8, o[dt], 0, 0, 0);
+    }
+    if (qok) {
+      bf16* dQr = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 ov = {(bf16)(o[dt][0] * a.scale), (bf16)(o[dt][1] * a.scale), (bf16)(o[dt][2] * a.scale), (bf16)(o[dt][3] * a.scale)};
+        *reinterpret_cast<bf16x4*>(dQr + dt * 16 + g * 4) = ov;
+      }
+    }
+  }
+  if (a.dgate) {
+    const float gs = wave_sum(gsum);
+    if (lane == 0) atomicAdd(a.dgate + h, gs);
+  }
+  __syncthreads();                                   // K and V are dead, dS is complete
+  for (int i = tid; i < QC * 256; i += 64 * NW) {    // Q -> Ks, dO -> Vs as [32 q][64] tiles (rows >= Lq zero)
+    const int tile = i >> 8, row = (i >> 3) & 31, c = i & 7, q = tile * 32 + row;
+    uint4 vq = make_uint4(0, 0, 0, 0), vo = make_uint4(0, 0, 0, 0);
+    if (q < a.Lq) {
+      vq = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + c * 8);
+      vo = *reinterpret_cast<const uint4*>(a.dO + ((size_t)b * a.Lq + q) * a.ldo + h * DH + c * 8);
+    }
+    const int off = tile * 4096 + row * 128 + p_swz(row, c) * 16;
+    *reinterpret_cast<uint4*>(Ks + off) = vq;
+    *reinterpret_cast<uint4*>(Vs + off) = vo;
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {             // 0: dK from dS and Q;  1: dV from P and dO
+    if (pass == 1) {
+      __syncthreads();                               // every wave has read its dS columns
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi) {
+        const int qt = gi * NW + wave;
+        if (qt >= NT) continue;
+        const int sr = (qt & 1) * 16 + ql;
+        char* srow = Ss + (size_t)((qt >> 1) * KC) * 2048 + sr * 64;
+#pragma unroll
+        for (int s = 0; s < NT / 2; ++s) {
+          bf16x8 d8;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { d8[r] = pvg[gi][2 * s][r]; d8[4 + r] = pvg[gi][2 * s + 1][r]; }
+          *reinterpret_cast<bf16x8*>(srow + s * 2048 + s_swz(sr, g) * 16) = d8;
+        }
+      }
+      __syncthreads();
+    }
+    const char* Xs = pass ? Vs : Ks;
+    const float mul = pass ? gz : a.scale;
+    bf16* out = pass ? a.dV : a.dK;
+    const int ldx = pass ? a.lddv : a.lddk;
+    for (int kt = wave; kt < NT; kt += NW) {
+      f32x4 d[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) d[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qc = 0; qc < QC; ++qc) {
+        const bf16x8 bS = scol_frag(Ss + (qc * KC + (kt >> 1)) * 2048, kt & 1, lane);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          d[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qcol_frag(Xs + qc * 4096, dt, lane), bS, d[dt], 0, 0, 0);
+      }
+      const int key = kt * 16 + (lane & 15);
+      if (key < a.Lk) {
+        bf16* r = out + ((size_t)b * a.Lk + key) * ldx + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          bf16x4 v = {(bf16)(d[dt][0] * mul), (bf16)(d[dt][1] * mul), (bf16)(d[dt][2] * mul), (bf16)(d[dt][3] * mul)};
+          *reinterpret_cast<bf16x4*>(r + dt * 16 + g * 4) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+static bool launch_bwd_fused(const MAttnB& f, hipStream_t stream) {
+  constexpr int NW = NT < 8 ? NT : 8;
+  const char* env = getenv("EVLM_ATTN_BWD_SPLIT");          // (debug / A-B switch: force kernels A + B)
+  if ((env && atoi(env)) || f.kv_index || f.Lq > NT * 16 || f.Lk > NT * 16) return false;
+  const size_t lds = (size_t)(NT / 2) * (NT / 2) * 2048 + (size_t)2 * NT * 16 * 128;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<NT, NW>), dim3(f.H, f.B), dim3(64 * NW), lds, stream, f);
+  return true;
+}
+
 template <int NT>
 static void launch_bwd_dq(const MAttnB& f, hipStream_t stream) {
   constexpr int MAXW = NT <= 14 ? 8 : 4;
@@ -618,6 +821,16 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
   f.Pt = (const bf16*)a->kd_teacher; f.kd_gout = a->kd_gout;
   f.kd_coef = a->kd_teacher ? 2.0f * a->kd_weight / ((float)a->B * a->H * a->Lq * a->Lk) : 0.f;
   if (a->kd_teacher && !a->kd_gout) return evlm_set_error("evlm_attention_bwd: kd_teacher without kd_gout");
+  bool fused = false;                       // whole (batch, head) problems that fit one workgroup: one launch, no dS in HBM
+  if (a->Lk <= 32) fused = launch_bwd_fused<2>(f, stream);
+  else if (a->Lk <= 64) fused = launch_bwd_fused<4>(f, stream);
+  else if (a->Lk <= 224) fused = launch_bwd_fused<14>(f, stream);
+  if (fused) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return evlm_set_error("evlm_attention_bwd(mfma, fused): %s", hipGetErrorString(e));
+    *handled = 1;
+    return 0;
+  }
   if (a->Lk <= 32) launch_bwd_dq<2>(f, stream);
   else if (a->Lk <= 64) launch_bwd_dq<4>(f, stream);
   else if (a->Lk <= 224) launch_bwd_dq<14>(f, stream);

@@ -429,7 +429,7 @@ class XVLMBase(nn.Module):
         img_index = torch.cat([ar, img_neg, ar], 0)            # pos | (text, image_neg) | (text_neg, image)
         f = self._text_core()(encoder_embeds=txt_all, attention_mask=atts_all, encoder_hidden_states=image_embeds,
                               encoder_attention_mask=torch.index_select(image_atts, 0, img_index),
-                              encoder_batch_index=img_index, return_dict=True, mode="fusion", output_attentions=True,
+                              encoder_batch_index=img_index.to(torch.int32), return_dict=True, mode="fusion", output_attentions=True,
                               output_hidden_states=True, head_z=head_z, head_layer_z=head_layer_z, mlp_z=mlp_z)
         two = lambda tup: tuple(zip(*[torch.split(x, [bs, 2 * bs], 0) if x is not None else (None, None) for x in tup]))
         (pos_hs, neg_hs), (pos_att, neg_att), (pos_catt, neg_catt) = two(f.hidden_states), two(f.attentions), \

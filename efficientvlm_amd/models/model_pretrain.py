@@ -136,7 +136,8 @@ class XVLM(XVLMBase):
             img_index = torch.cat([img_index, B + idx_to_group_img.view(-1)], 0)
             sizes.append(B)
         f = core(encoder_embeds=txt_all, attention_mask=atts_all, encoder_hidden_states=enc_states,
-                 encoder_attention_mask=torch.index_select(enc_atts, 0, img_index), encoder_batch_index=img_index,
+                 encoder_attention_mask=torch.index_select(enc_atts, 0, img_index),
+                 encoder_batch_index=img_index.to(torch.int32),      # (cast once here, not in every cross-attention)
                  return_dict=True, mode="fusion", output_attentions=True, output_hidden_states=True)
         thirds = lambda tup: tuple(zip(*[torch.split(x, sizes, 0) if x is not None else (None,) * len(sizes)
                                          for x in tup]))                                       # pos | neg | mlm [| bbox]

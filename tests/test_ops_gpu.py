@@ -845,3 +845,52 @@ def test_model_forward_samples_its_negatives_with_the_device_sampler():
         seen.add(tuple(neg.tolist()))
         ops.dropout_tick()
     assert B <= 2 or len(seen) > 1
+
+
+@pytest.mark.parametrize("B,H,L", [(2, 3, 17), (2, 2, 30), (1, 2, 33), (2, 2, 64), (1, 3, 197), (2, 2, 208), (1, 2, 224)])
+@pytest.mark.parametrize("kd", [False, True])
+def test_single_pass_attention_backward_equals_the_two_kernel_path(B, H, L, kd, monkeypatch):
+    """attn_bwd_fused_kernel (dS kept in LDS, one launch) against kernels A + B (dS through HBM): same arithmetic in the
+    same order - identical packed gradients; and both against the fp32 reference"""
+    o = ops()
+    dh, d = 64, H * 64
+    g = torch.Generator().manual_seed(300 + L)
+    base = rnd((B, L, 3 * d), torch.bfloat16, g)
+    gate0 = torch.rand(1, H, 1, 1, generator=g).to(DEV)
+    mask = torch.zeros(B, L); mask[0, L - 3:] = -10000.0
+    mask = mask.to(DEV)
+    scale = dh ** -0.5
+    with torch.no_grad():
+        _, Pt = o.self_attention(rnd((B, L, 3 * d), torch.bfloat16, g), H, dh, scale, mask=mask)
+    gO = rnd((B, L, d), torch.bfloat16, g)
+    gP = rnd((B, H, L, L), torch.bfloat16, g, 0.1)
+
+    def run(split):
+        monkeypatch.setenv("EVLM_ATTN_BWD_SPLIT", "1" if split else "0")
+        qkv = base.clone().requires_grad_(True)
+        gate = gate0.clone().requires_grad_(True)
+        if kd:
+            O, P, term = o.self_attention(qkv, H, dh, scale, mask=mask, gate=gate, kd_teacher=Pt, kd_weight=3.0)
+            loss = (O.float() * gO.float()).sum() + term * 0.7
+        else:
+            O, P = o.self_attention(qkv, H, dh, scale, mask=mask, gate=gate)
+            loss = (O.float() * gO.float()).sum() + (P.float() * gP.float()).sum()
+        loss.backward()
+        return qkv.grad.clone(), gate.grad.clone()
+
+    (ga, gga), (gb, ggb) = run(False), run(True)
+    assert torch.equal(ga, gb)
+    assert rel_err(gga, ggb) < 1e-5                     # (atomics: order of the per-wave partial sums)
+    # fp32 reference
+    xr = base.float().requires_grad_(True)
+    gr = gate0.clone().requires_grad_(True)
+    sp = lambda t: t.view(B, L, H, dh).transpose(1, 2)
+    Or, Pr = _ref_attention(sp(xr[..., :d]), sp(xr[..., d:2 * d]), sp(xr[..., 2 * d:]), mask, gr, scale)
+    Or = Or.transpose(1, 2).reshape(B, L, d)
+    if kd:
+        lossr = (Or * gO.float()).sum() + 0.7 * 3.0 * (Pr - Pt.float()).pow(2).mean()
+    else:
+        lossr = (Or * gO.float()).sum() + (Pr * gP.float()).sum()
+    lossr.backward()
+    assert rel_err(ga.float(), xr.grad) < 5e-2
+    assert rel_err(gga, gr.grad) < 5e-2
