@@ -547,9 +547,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
   for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   // every query batch that attends to this K/V row (one without kv_index; the positive / hard-negative / MLM passes
   // that share an image with it): their contributions are summed here, in registers, in batch order (deterministic)
-  const int b_lo = a.kv_index ? 0 : bkv, b_hi = a.kv_index ? a.B : bkv + 1;
-  for (int b = b_lo; b < b_hi; ++b) {
-    if (a.kv_index && a.kv_index[b] != bkv) continue;       // block-uniform
+  // (the index is scanned 64 entries at a time: one vector load + ballot per wave instead of B dependent scalar loads)
+  const int nscan = a.kv_index ? a.B : 1;
+  for (int b0 = 0; b0 < nscan; b0 += 64) {
+   unsigned long long hits = 1ull;
+   if (a.kv_index) hits = __ballot(b0 + lane < a.B && a.kv_index[min(b0 + lane, a.B - 1)] == bkv);
+   while (hits) {                                            // wave-uniform, identical in every wave of the block
+    const int b = a.kv_index ? b0 + __builtin_amdgcn_readfirstlane(__ffsll((long long)hits) - 1) : bkv;
+    hits &= hits - 1;
     const bf16* Qb = a.Q + (size_t)b * a.Lq * a.ldq + h * DH;
     const bf16* dOb = a.dO + (size_t)b * a.Lq * a.ldo + h * DH;
     const size_t pbase = ((size_t)b * a.H + h) * a.Lq * a.ldpr;
@@ -567,6 +572,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
         dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qcol_frag(dOs, dt, lane), bP, dv[dt], 0, 0, 0);
       }
     }
+   }
   }
   const int key = k0 + wave * 16 + (lane & 15);
   if (key < a.Lk) {
@@ -613,13 +619,30 @@ template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
   constexpr int G = (NT + NW - 1) / NW, KC = NT / 2, QC = NT / 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool EARLY = NT <= 4;           // short sequences: LDS to spare - Q and dO get their own tiles, staged up front
   char* Ss = smem;                          // [QC][KC] tiles of [32 q][32 key]: dS, then P
   char* Ks = smem + QC * KC * 2048;         // phase 1: K (v_swz);  phases 2-3: Q as [QC] tiles of [32 q][64] (p_swz)
   char* Vs = Ks + NT * 16 * 128;            // phase 1: V (k_swz);  phases 2-3: dO likewise
+  char* Qs = EARLY ? Vs + NT * 16 * 128 : Ks;
+  char* dOs = EARLY ? Qs + NT * 16 * 128 : Vs;
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ql = lane & 15;
+  auto stage_q_do = [&]() {                          // Q, dO as [32 q][64] tiles (p_swz), rows >= Lq zero
+    for (int i = tid; i < QC * 256; i += 64 * NW) {
+      const int tile = i >> 8, row = (i >> 3) & 31, c = i & 7, q = tile * 32 + row;
+      uint4 vq = make_uint4(0, 0, 0, 0), vo = make_uint4(0, 0, 0, 0);
+      if (q < a.Lq) {
+        vq = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + c * 8);
+        vo = *reinterpret_cast<const uint4*>(a.dO + ((size_t)b * a.Lq + q) * a.ldo + h * DH + c * 8);
+      }
+      const int off = tile * 4096 + row * 128 + p_swz(row, c) * 16;
+      *reinterpret_cast<uint4*>(Qs + off) = vq;
+      *reinterpret_cast<uint4*>(dOs + off) = vo;
+    }
+  };
   stage_rows<true>(a.K + (size_t)b * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
   stage_rows<false>(a.V + (size_t)b * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
+  if (EARLY) stage_q_do();
   stage_wait();
   __syncthreads();
   const float gz = a.gate ? a.gate[h] : 1.0f;
@@ -714,18 +737,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
     if (lane == 0) atomicAdd(a.dgate + h, gs);
   }
   __syncthreads();                                   // K and V are dead, dS is complete
-  for (int i = tid; i < QC * 256; i += 64 * NW) {    // Q -> Ks, dO -> Vs as [32 q][64] tiles (rows >= Lq zero)
-    const int tile = i >> 8, row = (i >> 3) & 31, c = i & 7, q = tile * 32 + row;
-    uint4 vq = make_uint4(0, 0, 0, 0), vo = make_uint4(0, 0, 0, 0);
-    if (q < a.Lq) {
-      vq = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + c * 8);
-      vo = *reinterpret_cast<const uint4*>(a.dO + ((size_t)b * a.Lq + q) * a.ldo + h * DH + c * 8);
-    }
-    const int off = tile * 4096 + row * 128 + p_swz(row, c) * 16;
-    *reinterpret_cast<uint4*>(Ks + off) = vq;
-    *reinterpret_cast<uint4*>(Vs + off) = vo;
+  if (!EARLY) {
+    stage_q_do();
+    __syncthreads();
   }
-  __syncthreads();
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {             // 0: dK from dS and Q;  1: dV from P and dO
     if (pass == 1) {
@@ -746,7 +761,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
       }
       __syncthreads();
     }
-    const char* Xs = pass ? Vs : Ks;
+    const char* Xs = pass ? dOs : Qs;
     const float mul = pass ? gz : a.scale;
     bf16* out = pass ? a.dV : a.dK;
     const int ldx = pass ? a.lddv : a.lddk;
@@ -779,7 +794,7 @@ static bool launch_bwd_fused(const MAttnB& f, hipStream_t stream) {
   constexpr int NW = NT < 8 ? NT : 8;
   const char* env = getenv("EVLM_ATTN_BWD_SPLIT");          // (debug / A-B switch: force kernels A + B)
   if ((env && atoi(env)) || f.kv_index || f.Lq > NT * 16 || f.Lk > NT * 16) return false;
-  const size_t lds = (size_t)(NT / 2) * (NT / 2) * 2048 + (size_t)2 * NT * 16 * 128;
+  const size_t lds = (size_t)(NT / 2) * (NT / 2) * 2048 + (size_t)(NT <= 4 ? 4 : 2) * NT * 16 * 128;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((attn_bwd_fused_kernel<NT, NW>), dim3(f.H, f.B), dim3(64 * NW), lds, stream, f);
