@@ -89,6 +89,94 @@ extern "C" int evlm_mse_bwd(int dtype_a, const void* a, int dtype_b, const void*
   return 0;
 }
 
+// ---- grouped MSE: every (student, teacher) pair of a distillation step in ONE launch per direction --------------------
+// A GD step holds ~40 pairs (hidden states and attention maps of GeneralDistill.py:300-366), most of them a few MB: 40
+// forward + 40 backward launches of 5-8 us each.  table: int64 [n][8] =
+//   {a, b, n (elements), first block of the unit, blocks of the unit, loss word (fwd) / gout word (bwd), grad_a (bwd),
+//    coef as f32 bits}   with coef = weight / n (fwd), 2 weight / n (bwd).
+// A block finds its unit with one vector load + ballot per 64 units (first blocks ascend), then runs the single-pair loop
+// on its share of the unit.
+__device__ __forceinline__ int grouped_unit(const int64_t* __restrict__ table, int n_units) {
+  const int lane = threadIdx.x & 63;
+  int u = -1;
+  for (int u0 = 0; u0 < n_units; u0 += 64) {
+    const bool le = u0 + lane < n_units && table[8 * (int64_t)(u0 + lane) + 3] <= (int64_t)blockIdx.x;
+    const unsigned long long m = __ballot(le);
+    if (!m) break;
+    u = u0 + __popcll(m) - 1;
+  }
+  return __builtin_amdgcn_readfirstlane(u);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void mse_grouped_fwd_kernel(const int64_t* __restrict__ table, int n_units) {
+  __shared__ float red[16];
+  const int64_t* e = table + 8 * (int64_t)grouped_unit(table, n_units);
+  const T* a = reinterpret_cast<const T*>(e[0]);
+  const T* b = reinterpret_cast<const T*>(e[1]);
+  const int64_t n = e[2], nv = n >> 3;
+  const int blk = (int)(blockIdx.x - e[3]);
+  const int64_t stride = e[4] * 256;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int64_t c = blk * 256 + threadIdx.x;
+  for (; c + 3 * stride < nv; c += 4 * stride) {
+    float x0[8], y0[8], x1[8], y1[8], x2[8], y2[8], x3[8], y3[8];
+    load8<T>(a + c * 8, x0); load8<T>(b + c * 8, y0);
+    load8<T>(a + (c + stride) * 8, x1); load8<T>(b + (c + stride) * 8, y1);
+    load8<T>(a + (c + 2 * stride) * 8, x2); load8<T>(b + (c + 2 * stride) * 8, y2);
+    load8<T>(a + (c + 3 * stride) * 8, x3); load8<T>(b + (c + 3 * stride) * 8, y3);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float d0 = x0[k] - y0[k], d1 = x1[k] - y1[k], d2 = x2[k] - y2[k], d3 = x3[k] - y3[k];
+      s0 = fmaf(d0, d0, s0); s1 = fmaf(d1, d1, s1); s2 = fmaf(d2, d2, s2); s3 = fmaf(d3, d3, s3);
+    }
+  }
+  for (; c < nv; c += stride) {
+    float x[8], y[8];
+    load8<T>(a + c * 8, x);
+    load8<T>(b + c * 8, y);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float d = x[k] - y[k]; s0 = fmaf(d, d, s0); }
+  }
+  float s = (s0 + s1) + (s2 + s3);
+  if (blk == 0)
+    for (int64_t i = (nv << 3) + threadIdx.x; i < n; i += 256) { const float d = to_f(a[i]) - to_f(b[i]); s = fmaf(d, d, s); }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(reinterpret_cast<float*>(e[5]), s * __int_as_float((int)e[7]));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void mse_grouped_bwd_kernel(const int64_t* __restrict__ table, int n_units) {
+  const int64_t* e = table + 8 * (int64_t)grouped_unit(table, n_units);
+  const T* a = reinterpret_cast<const T*>(e[0]);
+  const T* b = reinterpret_cast<const T*>(e[1]);
+  T* ga = reinterpret_cast<T*>(e[6]);
+  const int64_t n = e[2], nv = n >> 3;
+  const int blk = (int)(blockIdx.x - e[3]);
+  const float c2 = __int_as_float((int)e[7]) * reinterpret_cast<const float*>(e[5])[0];
+  for (int64_t c = blk * 256 + threadIdx.x; c < nv; c += e[4] * 256) {
+    float x[8], y[8];
+    load8<T>(a + c * 8, x);
+    load8<T>(b + c * 8, y);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = c2 * (x[k] - y[k]);
+    store8<T>(ga + c * 8, x);
+  }
+  if (blk == 0)
+    for (int64_t i = (nv << 3) + threadIdx.x; i < n; i += 256) ga[i] = from_f<T>(c2 * (to_f(a[i]) - to_f(b[i])));
+}
+extern "C" int evlm_mse_grouped(int dtype, int backward, const int64_t* table, int n_units, int total_blocks, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(table && n_units > 0 && total_blocks > 0, "evlm_mse_grouped: bad args");
+  if (dtype == EVLM_BF16) {
+    if (backward) hipLaunchKernelGGL(mse_grouped_bwd_kernel<bf16>, dim3(total_blocks), dim3(256), 0, stream, table, n_units);
+    else hipLaunchKernelGGL(mse_grouped_fwd_kernel<bf16>, dim3(total_blocks), dim3(256), 0, stream, table, n_units);
+  } else if (dtype == EVLM_F32) {
+    if (backward) hipLaunchKernelGGL(mse_grouped_bwd_kernel<float>, dim3(total_blocks), dim3(256), 0, stream, table, n_units);
+    else hipLaunchKernelGGL(mse_grouped_fwd_kernel<float>, dim3(total_blocks), dim3(256), 0, stream, table, n_units);
+  } else return evlm_set_error("evlm_mse_grouped: bad dtype");
+  EVLM_LAUNCH_CHECK("evlm_mse_grouped");
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // row-wise log-sum-exp helper: one 256-thread block per row
 // ---------------------------------------------------------------------------------------------

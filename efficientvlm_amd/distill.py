@@ -22,9 +22,8 @@ def get_cor_teacher(teacher_reps, student_reps, is_attn=False):
     return [teacher_reps[i * k] for i in range(ns)]
 
 
-def get_kd_loss(student_reps=None, teacher_reps=None, is_attn=False, loss=None, device="cuda", is_img=False):
-    """GeneralDistill.py:60-82.  `loss`/`device` are accepted for signature compatibility; the MSE is the HIP kernel.
-    The reference's torch.where(att <= -1e2, 0, att) is a no-op on probabilities (SURVEY.md A.4) and is not issued."""
+def _kd_pairs(student_reps, teacher_reps, is_attn=False, is_img=False):
+    """the (student, teacher) pairs and weights of one get_kd_loss call (GeneralDistill.py:60-82)"""
     pairs, weights = [], []
     for layer, (s, t) in enumerate(zip(student_reps, teacher_reps)):
         if is_attn:
@@ -33,6 +32,13 @@ def get_kd_loss(student_reps=None, teacher_reps=None, is_attn=False, loss=None, 
             continue
         else:
             pairs.append((s, t)); weights.append(1.0)
+    return pairs, weights
+
+
+def get_kd_loss(student_reps=None, teacher_reps=None, is_attn=False, loss=None, device="cuda", is_img=False):
+    """GeneralDistill.py:60-82.  `loss`/`device` are accepted for signature compatibility; the MSE is the HIP kernel.
+    The reference's torch.where(att <= -1e2, 0, att) is a no-op on probabilities (SURVEY.md A.4) and is not issued."""
+    pairs, weights = _kd_pairs(student_reps, teacher_reps, is_attn, is_img)
     return ops.mse_sum(pairs, weights) if pairs else 0
 
 
@@ -49,12 +55,16 @@ def kd_terms(S, T, temperature=1.0, with_cross_attn=False, fused=None):
     out = {}
     fused = fused or {}
 
+    names, terms = [], []            # every MSE term of the step goes into ONE grouped launch (ops.mse_terms)
+
     def pair(name, hkey, akey, is_img=False):
-        out[name + "_hidden"] = get_kd_loss(sh[hkey], get_cor_teacher(th[hkey], sh[hkey]), is_img=is_img)
+        names.append(name + "_hidden")
+        terms.append(_kd_pairs(sh[hkey], get_cor_teacher(th[hkey], sh[hkey]), is_img=is_img))
         if name + "_attn" in fused:
             out[name + "_attn"] = fused[name + "_attn"]
         else:
-            out[name + "_attn"] = get_kd_loss(sa[akey], get_cor_teacher(ta[akey], sa[akey], True), is_attn=True)
+            names.append(name + "_attn")
+            terms.append(_kd_pairs(sa[akey], get_cor_teacher(ta[akey], sa[akey], True), is_attn=True))
 
     pair("text", "text_hidden_states", "text_attentions")
     pair("image", "image_hidden_states", "image_attentions", is_img=True)
@@ -68,7 +78,10 @@ def kd_terms(S, T, temperature=1.0, with_cross_attn=False, fused=None):
         sc, tc = S["cross_attention_dict"], T["cross_attention_dict"]
         for nm in ("itm_pos", "itm_neg"):
             k = nm + "_cross_attentions"
-            out[nm + "_cross"] = get_kd_loss(sc[k], get_cor_teacher(tc[k], sc[k], True), is_attn=True)
+            names.append(nm + "_cross")
+            terms.append(_kd_pairs(sc[k], get_cor_teacher(tc[k], sc[k], True), is_attn=True))
+    for name, value in zip(names, ops.mse_terms(terms)):
+        out[name] = value
     return out
 
 

@@ -847,6 +847,23 @@ def _pin_pool():
     return _PIN_POOL
 
 
+def _upload_table(rows, dev):
+    """flat list of int64 -> device tensor.  Inside a hipGraph capture the table goes up as a memcpy node out of a PINNED
+    block that is never rewritten (a slice of a pool allocated outside any capture: pinning memory is not capturable)."""
+    global _PIN_USED
+    if torch.cuda.is_current_stream_capturing():
+        if _PIN_POOL is None or _PIN_USED + len(rows) > _PIN_POOL.numel():
+            raise RuntimeError("pinned table pool missing / exhausted (run one eager step before capturing)")
+        host = _PIN_POOL[_PIN_USED:_PIN_USED + len(rows)]
+        _PIN_USED += len(rows)
+        host.copy_(torch.tensor(rows, dtype=torch.int64))
+        table = torch.empty(len(rows), dtype=torch.int64, device=dev)
+        table.copy_(host, non_blocking=True)
+        return table
+    _pin_pool()
+    return torch.tensor(rows, dtype=torch.int64).to(dev)
+
+
 def copy_grouped(pairs):
     """[(src, dst)] contiguous same-size tensors -> ONE copy launch (evlm_copy_grouped); returns the device table (keep it
     alive while a captured graph may replay the launch)"""
@@ -859,20 +876,7 @@ def copy_grouped(pairs):
         rows += [src.data_ptr(), dst.data_ptr(), nb, blocks]
         blocks += (nb + 65535) // 65536
     dev = pairs[0][0].device
-    if torch.cuda.is_current_stream_capturing():
-        # inside a hipGraph capture: the table goes up as a memcpy node out of a PINNED block that is never rewritten (a
-        # slice of a pool allocated outside any capture: pinning memory is not a capturable operation)
-        global _PIN_USED
-        if _PIN_POOL is None or _PIN_USED + len(rows) > _PIN_POOL.numel():
-            raise RuntimeError("copy_grouped: pinned table pool missing / exhausted (run one eager step before capturing)")
-        host = _PIN_POOL[_PIN_USED:_PIN_USED + len(rows)]
-        _PIN_USED += len(rows)
-        host.copy_(torch.tensor(rows, dtype=torch.int64))
-        table = torch.empty(len(rows), dtype=torch.int64, device=dev)
-        table.copy_(host, non_blocking=True)
-    else:
-        _pin_pool()
-        table = torch.tensor(rows, dtype=torch.int64).to(dev)
+    table = _upload_table(rows, dev)
     L.check(_lib().evlm_copy_grouped(L.ptr(table), len(pairs), blocks, L.stream()), "copy_grouped")
     return table
 
@@ -1142,6 +1146,91 @@ def mse_sum(pairs, weights=None):
     n = len(pairs)
     ws = [1.0] * n if weights is None else [float(w) for w in weights]
     return _MSESum.apply(ws, n, *[a for a, _ in pairs], *[b.detach() for _, b in pairs])
+
+
+def _f32_bits(x):
+    import struct
+    return struct.unpack("<i", struct.pack("<f", float(x)))[0] & 0xFFFFFFFF
+
+
+class _MSETerms(torch.autograd.Function):
+    """T distillation terms, term t = sum over its pairs of weight * mean((a - b)^2), in ONE launch per direction
+    (evlm_mse_grouped).  spec: [(term index, weight)] per pair; tensors: the a's, then the b's.  Returns T scalars."""
+
+    @staticmethod
+    def forward(ctx, spec, n_terms, *tensors):
+        n = len(spec)
+        dev = tensors[0].device
+        outs = [zero_scalar(dev) for _ in range(n_terms)]
+        saved, meta, rows, blocks = [], [], [], 0
+        for i, (term, weight) in enumerate(spec):
+            a, b = tensors[i], tensors[n + i]
+            L.require_cuda(a, b)
+            n_true = a.numel()
+            pa, pb = _padded_base(a), _padded_base(b)
+            if pa is not None and pb is not None and pa.shape == pb.shape:
+                ac, bc, padded = pa, pb, True
+            else:
+                ac = a if a.is_contiguous() else a.contiguous()
+                bc = b if b.is_contiguous() else b.contiguous()
+                padded = False
+            ne = ac.numel()
+            w = weight * (ne / n_true)
+            nb = max(1, min(256, (ne // 8 + 1023) // 1024))      # (each block ends in one atomic on the term word)
+            rows += [ac.data_ptr(), bc.data_ptr(), ne, blocks, nb, outs[term].data_ptr(), 0, _f32_bits(w / ne)]
+            blocks += nb
+            saved += [ac, bc]
+            meta.append((term, w, padded, a.shape))
+        table = _upload_table(rows, dev)
+        L.check(_lib().evlm_mse_grouped(L.dt(saved[0].dtype), 0, L.ptr(table), n, blocks, L.stream()), "mse_grouped")
+        ctx.save_for_backward(*saved)
+        ctx.meta, ctx.n, ctx.n_terms = meta, n, n_terms
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        grads, rows, blocks, units = [None] * ctx.n, [], 0, 0
+        keep = []
+        for i, (term, w, padded, shape) in enumerate(ctx.meta):
+            g = gs[term]
+            if g is None or not ctx.needs_input_grad[2 + i]:
+                continue
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.to(torch.float32).contiguous()
+            keep.append(g)
+            ac, bc = ctx.saved_tensors[2 * i], ctx.saved_tensors[2 * i + 1]
+            ga = torch.empty_like(ac)
+            ne = ac.numel()
+            nb = max(1, min(2048, (ne // 8 + 255) // 256))
+            rows += [ac.data_ptr(), bc.data_ptr(), ne, blocks, nb, g.data_ptr(), ga.data_ptr(), _f32_bits(2.0 * w / ne)]
+            blocks += nb
+            units += 1
+            grads[i] = ga[..., :shape[-1]] if padded else ga.view(shape)
+        if units:
+            table = _upload_table(rows, ctx.saved_tensors[0].device)
+            L.check(_lib().evlm_mse_grouped(L.dt(ctx.saved_tensors[0].dtype), 1, L.ptr(table), units, blocks, L.stream()),
+                    "mse_grouped")
+        return (None, None) + tuple(grads) + (None,) * ctx.n
+
+
+def mse_terms(terms):
+    """terms: [(pairs, weights)] with pairs = [(a, b)]; returns the list of scalars  sum_i weights_i * mse(a_i, b_i), one per
+    term (0 for an empty term).  All pairs of all terms run in one launch forward and one backward when they share a
+    dtype (bf16 or f32); gradient flows to the a's only."""
+    spec, A, Bt = [], [], []
+    for t, (pairs, weights) in enumerate(terms):
+        ws = [1.0] * len(pairs) if weights is None else [float(w) for w in weights]
+        for (a, b), w in zip(pairs, ws):
+            spec.append((t, w)); A.append(a); Bt.append(b.detach())
+    if not spec:
+        return [0 for _ in terms]
+    dts = {x.dtype for x in A} | {x.dtype for x in Bt}
+    if len(dts) != 1 or next(iter(dts)) not in (torch.bfloat16, torch.float32):
+        return [mse_sum(pairs, weights) if pairs else 0 for pairs, weights in terms]
+    outs = _MSETerms.apply(spec, len(terms), *A, *Bt)
+    used = {t for t, _ in spec}
+    return [outs[t] if t in used else 0 for t in range(len(terms))]
 
 
 def _rows2d(x):

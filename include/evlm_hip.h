@@ -245,6 +245,12 @@ int evlm_mse_fwd(int dtype_a, const void* a, int dtype_b, const void* b, int64_t
 /* grad_a = (*gout) * weight * 2 (a-b) / n */
 int evlm_mse_bwd(int dtype_a, const void* a, int dtype_b, const void* b, int64_t n, float weight,
                  const float* gout, void* grad_a, void* stream);
+/* Every (a, b) pair of a distillation step in ONE launch per direction (a GD step has ~40, most of a few MB).
+ * table: device int64 [n_units][8] = {a, b, n, first block of the unit, blocks of the unit,
+ *   loss word (forward: += coef * sum (a-b)^2) | gout word (backward), grad_a (backward: = coef * gout * (a-b)),
+ *   coef as f32 bits (forward: weight / n, backward: 2 weight / n)};  a and b share `dtype`, are contiguous and 16-byte
+ * aligned; first blocks ascend from 0 and total_blocks is their sum.  backward != 0 selects the gradient kernel. */
+int evlm_mse_grouped(int dtype, int backward, const int64_t* table, int n_units, int total_blocks, void* stream);
 
 /* hard-label cross entropy, mean over rows with label != ignore_index (F.cross_entropy: MLM loss
  * eff_bert.py:1697-1699, ITM xvlm.py:484, ITC :399-400).  logits [R,C] (ld), labels int64.

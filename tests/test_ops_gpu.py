@@ -894,3 +894,47 @@ def test_single_pass_attention_backward_equals_the_two_kernel_path(B, H, L, kd, 
     lossr.backward()
     assert rel_err(ga.float(), xr.grad) < 5e-2
     assert rel_err(gga, gr.grad) < 5e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_grouped_mse_terms_equal_the_per_pair_reductions(dtype):
+    """ops.mse_terms (evlm_mse_grouped: all pairs of all terms in one launch per direction) against ops.mse_sum per term:
+    values and gradients, padded attention-map views, an odd-sized pair, an empty term, a term nobody differentiates"""
+    o = ops()
+    g = torch.Generator().manual_seed(77)
+    mk = lambda *shape: rnd(shape, dtype, g)
+    Pbuf_s, Pbuf_t = torch.zeros(4, 3, 30, 32, device=DEV, dtype=dtype), torch.zeros(4, 3, 30, 32, device=DEV, dtype=dtype)
+    Pbuf_s[..., :30], Pbuf_t[..., :30] = mk(4, 3, 30, 30), mk(4, 3, 30, 30)
+    shapes = [[(64, 197, 96)] * 3, [(8, 30, 96), (8, 30, 96)], [], [(5, 7, 3)], [(16, 33)]]
+    weights = [[1.0, 1.0, 0.5], [2.0, 1.0], [], [30.0], [1.0]]
+
+    def build():
+        terms = []
+        for shp, ws in zip(shapes, weights):
+            terms.append(([(mk(*s).requires_grad_(True), mk(*s)) for s in shp], list(ws)))
+        a = Pbuf_s.clone().requires_grad_(True)
+        terms[1][0].append((a[..., :30], Pbuf_t[..., :30])); terms[1][1].append(30.0)       # padded map views
+        return terms, a
+
+    g.manual_seed(5); terms_a, pa = build()
+    g.manual_seed(5); terms_b, pb = build()
+    coef = [0.3, 1.0, 1.0, 2.0, 0.0]
+    va = o.mse_terms(terms_a)
+    vb = [o.mse_sum(p, w) if p else 0 for p, w in terms_b]
+    assert va[2] == 0 and len(va) == 5
+    la = sum(c * v for c, v in zip(coef[:4], va[:4]))             # term 4 takes no part in the loss
+    lb = sum(c * v for c, v in zip(coef[:4], vb[:4]))
+    la.backward(); lb.backward()
+    t = 1e-5 if dtype == torch.float32 else 2e-3
+    for x, y in zip(va, vb):
+        if torch.is_tensor(x):
+            assert rel_err(x, y) < t
+    for (pa_, _), (pb_, _) in zip(terms_a, terms_b):
+        for (xa, _), (xb, _) in zip(pa_, pb_):
+            if not xa.is_leaf:
+                continue                                          # (the padded views: checked through their base below)
+            if xa.grad is None or xb.grad is None:
+                assert xa.grad is None and xb.grad is None
+            else:
+                assert rel_err(xa.grad.float(), xb.grad.float()) < t
+    assert rel_err(pa.grad.float(), pb.grad.float()) < t and float(pa.grad[..., 30:].abs().max()) == 0.0
