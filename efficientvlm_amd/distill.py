@@ -56,15 +56,18 @@ def kd_terms(S, T, temperature=1.0, with_cross_attn=False, fused=None):
     fused = fused or {}
 
     names, terms = [], []            # every MSE term of the step goes into ONE grouped launch (ops.mse_terms)
+    # student operands: where the batched forward reports its lists as row ranges of un-split tensors, take those
+    rows = S.get("batched") or {}
+    s_list = lambda d, key: rows[key] if (key in rows and all(x is not None for x in rows[key])) else d[key]
 
     def pair(name, hkey, akey, is_img=False):
         names.append(name + "_hidden")
-        terms.append(_kd_pairs(sh[hkey], get_cor_teacher(th[hkey], sh[hkey]), is_img=is_img))
+        terms.append(_kd_pairs(s_list(sh, hkey), get_cor_teacher(th[hkey], sh[hkey]), is_img=is_img))
         if name + "_attn" in fused:
             out[name + "_attn"] = fused[name + "_attn"]
         else:
             names.append(name + "_attn")
-            terms.append(_kd_pairs(sa[akey], get_cor_teacher(ta[akey], sa[akey], True), is_attn=True))
+            terms.append(_kd_pairs(s_list(sa, akey), get_cor_teacher(ta[akey], sa[akey], True), is_attn=True))
 
     pair("text", "text_hidden_states", "text_attentions")
     pair("image", "image_hidden_states", "image_attentions", is_img=True)

@@ -163,6 +163,15 @@ class XVLM(XVLMBase):
                                 "mlm_cross_attentions": f_cross[2]}
         logits_dict = {"itm_head_logits": itm_logits, "mlm_logits": mlm_logits}
         loss = {} if skip else {"loss_itc": loss_itc, "loss_itm": loss_itm, "loss_mlm": loss_mlm}
+        # extension: the same lists as row ranges of the UN-split batched tensors (keys of hidden_dict / attention_dict):
+        # the distillation losses take these, so their gradients reach each batched tensor as one buffer instead of
+        # autograd concatenating per-chunk gradients (distill.kd_terms, ops.RowSlice)
+        rs = lambda tup, r0, r1: [ops.RowSlice(x, r0, r1) if x is not None else None for x in tup]
+        batched = {"text_hidden_states": rs(t.hidden_states, 0, B), "text_attentions": rs(t.attentions, 0, B),
+                   "itm_pos_hidden_states": rs(f.hidden_states, 0, B), "itm_pos_attentions": rs(f.attentions, 0, B),
+                   "itm_neg_hidden_states": rs(f.hidden_states, B, 3 * B), "itm_neg_attentions": rs(f.attentions, B, 3 * B),
+                   "mlm_hidden_states": rs(t.hidden_states[:nF], B, 2 * B) + rs(f.hidden_states, 3 * B, 4 * B),
+                   "mlm_attentions": rs(t.attentions, B, 2 * B) + rs(f.attentions, 3 * B, 4 * B)}
         if region is not None:                                                            # model_pretrain.py:62-74
             coord = self.bbox_coord(last[4 * B:, 0, :])
             if not skip:
@@ -171,4 +180,4 @@ class XVLM(XVLMBase):
             cross_attention_dict["bbox_cross_attentions"] = f_cross[3]
             self.last_output_coord = coord.detach()
         return {"loss": loss, "hidden_dict": hidden_dict, "attention_dict": attention_dict,
-                "cross_attention_dict": cross_attention_dict, "logits_dict": logits_dict}
+                "cross_attention_dict": cross_attention_dict, "logits_dict": logits_dict, "batched": batched}

@@ -1153,83 +1153,135 @@ def _f32_bits(x):
     return struct.unpack("<i", struct.pack("<f", float(x)))[0] & 0xFFFFFFFF
 
 
+class RowSlice:
+    """rows [r0, r1) of the leading dimension of `full`, as a distillation operand (mse_terms): the batched forward keeps
+    its hidden states / attention maps un-split, and every term names its rows - the backward then writes each term's
+    gradient straight into ONE full-size (row-padded) buffer instead of autograd concatenating per-chunk gradients."""
+
+    def __init__(self, full, r0, r1):
+        self.full, self.r0, self.r1 = full, int(r0), int(r1)
+
+    @property
+    def shape(self):
+        return (self.r1 - self.r0,) + tuple(self.full.shape[1:])
+
+    @property
+    def dtype(self):
+        return self.full.dtype
+
+    def tensor(self):
+        return self.full[self.r0:self.r1]
+
+
+def _mse_operand(x):
+    """(buffer, padded?) the kernels sweep for x: the row-padded base of a map view, or x made contiguous"""
+    base = _padded_base(x)
+    if base is not None:
+        return base, True
+    return (x if x.is_contiguous() else x.contiguous()), False
+
+
 class _MSETerms(torch.autograd.Function):
     """T distillation terms, term t = sum over its pairs of weight * mean((a - b)^2), in ONE launch per direction
-    (evlm_mse_grouped).  spec: [(term index, weight)] per pair; tensors: the a's, then the b's.  Returns T scalars."""
+    (evlm_mse_grouped).  spec: per pair (term, weight, index of its `a` tensor, r0, r1); tensors: the distinct a's, then one
+    b per pair.  Returns T scalars; each a receives ONE gradient buffer (rows no term covers are zero)."""
 
     @staticmethod
-    def forward(ctx, spec, n_terms, *tensors):
-        n = len(spec)
+    def forward(ctx, spec, n_terms, n_a, *tensors):
         dev = tensors[0].device
         outs = [zero_scalar(dev) for _ in range(n_terms)]
-        saved, meta, rows, blocks = [], [], [], 0
-        for i, (term, weight) in enumerate(spec):
-            a, b = tensors[i], tensors[n + i]
-            L.require_cuda(a, b)
-            n_true = a.numel()
-            pa, pb = _padded_base(a), _padded_base(b)
-            if pa is not None and pb is not None and pa.shape == pb.shape:
-                ac, bc, padded = pa, pb, True
-            else:
-                ac = a if a.is_contiguous() else a.contiguous()
-                bc = b if b.is_contiguous() else b.contiguous()
-                padded = False
-            ne = ac.numel()
+        A = [_mse_operand(t) for t in tensors[:n_a]]
+        saved, meta, rows, blocks = [a for a, _ in A], [], [], 0
+        for i, (term, weight, ai, r0, r1) in enumerate(spec):
+            abuf, padded = A[ai]
+            full = tensors[ai]
+            b = tensors[n_a + i]
+            L.require_cuda(abuf, b)
+            bbuf, bpad = _mse_operand(b)
+            if bpad != padded or tuple(bbuf.shape[1:]) != tuple(abuf.shape[1:]) or bbuf.shape[0] != r1 - r0:
+                raise RuntimeError("mse_terms: operands of a pair must have the same (row-padded) layout")
+            per_row = abuf[0].numel()
+            ne, n_true = (r1 - r0) * per_row, (r1 - r0) * full[0].numel()
             w = weight * (ne / n_true)
             nb = max(1, min(256, (ne // 8 + 1023) // 1024))      # (each block ends in one atomic on the term word)
-            rows += [ac.data_ptr(), bc.data_ptr(), ne, blocks, nb, outs[term].data_ptr(), 0, _f32_bits(w / ne)]
+            rows += [abuf.data_ptr() + r0 * per_row * abuf.element_size(), bbuf.data_ptr(), ne, blocks, nb,
+                     outs[term].data_ptr(), 0, _f32_bits(w / ne)]
             blocks += nb
-            saved += [ac, bc]
-            meta.append((term, w, padded, a.shape))
+            saved.append(bbuf)
+            meta.append((term, w, ai, r0, r1))
         table = _upload_table(rows, dev)
-        L.check(_lib().evlm_mse_grouped(L.dt(saved[0].dtype), 0, L.ptr(table), n, blocks, L.stream()), "mse_grouped")
+        L.check(_lib().evlm_mse_grouped(L.dt(saved[0].dtype), 0, L.ptr(table), len(spec), blocks, L.stream()), "mse_grouped")
         ctx.save_for_backward(*saved)
-        ctx.meta, ctx.n, ctx.n_terms = meta, n, n_terms
+        ctx.meta, ctx.n_a = meta, n_a
+        ctx.a_info = [(padded, tuple(t.shape)) for (_, padded), t in zip(A, tensors[:n_a])]
         ctx.set_materialize_grads(False)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gs):
-        grads, rows, blocks, units = [None] * ctx.n, [], 0, 0
-        keep = []
-        for i, (term, w, padded, shape) in enumerate(ctx.meta):
-            g = gs[term]
-            if g is None or not ctx.needs_input_grad[2 + i]:
+        n_a = ctx.n_a
+        abufs, bbufs = ctx.saved_tensors[:n_a], ctx.saved_tensors[n_a:]
+        live = [[] for _ in range(n_a)]                       # per a: the pairs whose term received a gradient
+        for i, (term, w, ai, r0, r1) in enumerate(ctx.meta):
+            if gs[term] is not None and ctx.needs_input_grad[3 + ai]:
+                live[ai].append(i)
+        grads, rows, blocks, units, keep = [None] * n_a, [], 0, 0, []
+        for ai in range(n_a):
+            if not live[ai]:
                 continue
-            if g.dtype != torch.float32 or not g.is_contiguous():
-                g = g.to(torch.float32).contiguous()
-            keep.append(g)
-            ac, bc = ctx.saved_tensors[2 * i], ctx.saved_tensors[2 * i + 1]
-            ga = torch.empty_like(ac)
-            ne = ac.numel()
-            nb = max(1, min(2048, (ne // 8 + 255) // 256))
-            rows += [ac.data_ptr(), bc.data_ptr(), ne, blocks, nb, g.data_ptr(), ga.data_ptr(), _f32_bits(2.0 * w / ne)]
-            blocks += nb
-            units += 1
-            grads[i] = ga[..., :shape[-1]] if padded else ga.view(shape)
+            abuf = abufs[ai]
+            cover = sorted((ctx.meta[i][3], ctx.meta[i][4]) for i in live[ai])
+            end, full_cover = 0, True
+            for r0, r1 in cover:
+                if r0 < end:
+                    raise RuntimeError("mse_terms: terms overlap on rows of one operand")
+                full_cover &= r0 == end
+                end = r1
+            ga = torch.empty_like(abuf) if (full_cover and end == abuf.shape[0]) else torch.zeros_like(abuf)
+            per_row = abuf[0].numel()
+            for i in live[ai]:
+                term, w, _, r0, r1 = ctx.meta[i]
+                g = gs[term]
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.to(torch.float32).contiguous()
+                keep.append(g)
+                ne = (r1 - r0) * per_row
+                off = r0 * per_row * abuf.element_size()
+                nb = max(1, min(2048, (ne // 8 + 255) // 256))
+                rows += [abuf.data_ptr() + off, bbufs[i].data_ptr(), ne, blocks, nb, g.data_ptr(), ga.data_ptr() + off,
+                         _f32_bits(2.0 * w / ne)]
+                blocks += nb
+                units += 1
+            padded, shape = ctx.a_info[ai]
+            grads[ai] = ga[..., :shape[-1]] if padded else ga.view(shape)
         if units:
-            table = _upload_table(rows, ctx.saved_tensors[0].device)
-            L.check(_lib().evlm_mse_grouped(L.dt(ctx.saved_tensors[0].dtype), 1, L.ptr(table), units, blocks, L.stream()),
-                    "mse_grouped")
-        return (None, None) + tuple(grads) + (None,) * ctx.n
+            table = _upload_table(rows, abufs[0].device)
+            L.check(_lib().evlm_mse_grouped(L.dt(abufs[0].dtype), 1, L.ptr(table), units, blocks, L.stream()), "mse_grouped")
+        return (None, None, None) + tuple(grads) + (None,) * len(bbufs)
 
 
 def mse_terms(terms):
     """terms: [(pairs, weights)] with pairs = [(a, b)]; returns the list of scalars  sum_i weights_i * mse(a_i, b_i), one per
-    term (0 for an empty term).  All pairs of all terms run in one launch forward and one backward when they share a
-    dtype (bf16 or f32); gradient flows to the a's only."""
-    spec, A, Bt = [], [], []
-    for t, (pairs, weights) in enumerate(terms):
-        ws = [1.0] * len(pairs) if weights is None else [float(w) for w in weights]
-        for (a, b), w in zip(pairs, ws):
-            spec.append((t, w)); A.append(a); Bt.append(b.detach())
-    if not spec:
+    term (0 for an empty term).  An `a` may be a RowSlice of a larger tensor.  All pairs of all terms run in one launch
+    forward and one backward when they share a dtype (bf16 or f32); gradient flows to the a's only."""
+    flat = [(t, a, b.detach(), 1.0 if weights is None else float(weights[i]))
+            for t, (pairs, weights) in enumerate(terms) for i, (a, b) in enumerate(pairs)]
+    if not flat:
         return [0 for _ in terms]
-    dts = {x.dtype for x in A} | {x.dtype for x in Bt}
+    dts = {a.dtype for _, a, _, _ in flat} | {b.dtype for _, _, b, _ in flat}
     if len(dts) != 1 or next(iter(dts)) not in (torch.bfloat16, torch.float32):
-        return [mse_sum(pairs, weights) if pairs else 0 for pairs, weights in terms]
-    outs = _MSETerms.apply(spec, len(terms), *A, *Bt)
-    used = {t for t, _ in spec}
+        plain = lambda a: a.tensor() if isinstance(a, RowSlice) else a
+        return [mse_sum([(plain(a), b) for a, b in pairs], weights) if pairs else 0 for pairs, weights in terms]
+    fulls, index, spec, Bt = [], {}, [], []
+    for t, a, b, w in flat:
+        full, r0, r1 = (a.full, a.r0, a.r1) if isinstance(a, RowSlice) else (a, 0, a.shape[0])
+        ai = index.setdefault(id(full), len(fulls))
+        if ai == len(fulls):
+            fulls.append(full)
+        spec.append((t, w, ai, r0, r1))
+        Bt.append(b)
+    outs = _MSETerms.apply(spec, len(terms), len(fulls), *fulls, *Bt)
+    used = {t for t, _, _, _ in flat}
     return [outs[t] if t in used else 0 for t in range(len(terms))]
 
 
