@@ -47,6 +47,61 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   }
 }
 
+// d % 8 == 0 and d <= 512 * DCH: the row is read ONCE and kept in registers (chunk c of lane l: l + 64 c), gamma / beta
+// chunks are loaded once per wave, and a wave walks rows  first, first + stride, ...  - same sums in the same order as
+// ln_fwd_kernel (bit-identical output), one pass over memory instead of three dependent ones (-10 % on [12608, 768]).
+template <typename T, int DCH>
+__global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, int rows, int d,
+                                                         T* __restrict__ y, float* __restrict__ mean_out,
+                                                         float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63, nchunk = d >> 3;
+  float gm[DCH][8], bt[DCH][8];
+#pragma unroll
+  for (int k = 0; k < DCH; ++k) {
+    const int c = lane + 64 * k;
+    if (c < nchunk) { load8<float>(gamma + c * 8, gm[k]); load8<float>(beta + c * 8, bt[k]); }
+  }
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+    const T* xr = x + (size_t)row * d;
+    float v[DCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < DCH; ++k) {
+      const int c = lane + 64 * k;
+      if (c < nchunk) {
+        load8<T>(xr + c * 8, v[k]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[k][e];
+      }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < DCH; ++k)
+      if (lane + 64 * k < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float t = v[k][e] - mean; q += t * t; }
+      }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+    T* yr = y + (size_t)row * d;
+#pragma unroll
+    for (int k = 0; k < DCH; ++k) {
+      const int c = lane + 64 * k;
+      if (c < nchunk) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mean) * rstd * gm[k][e] + bt[k][e];
+        store8<T>(yr + c * 8, o);
+      }
+    }
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+  }
+}
+
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma += sum_rows dy*xhat;  dbeta += sum_rows dy.
 // One wave per row, the row (x, dy) is read ONCE and kept in registers (DCH 16-byte chunks per lane: d <= 512*DCH).
 // Each block walks rows blockIdx.x*4 + w, += gridDim.x*4 and keeps per-lane partial dgamma/dbeta for the columns it
@@ -170,6 +225,16 @@ extern "C" int evlm_layernorm_fwd(int dtype, const void* x, const float* gamma, 
   EVLM_REQUIRE(x && y && gamma && beta && rows > 0 && d > 0, "evlm_layernorm_fwd: bad args");
   EVLM_REQUIRE(d % 8 == 0, "evlm_layernorm_fwd: d=%d must be a multiple of 8", d);
   dim3 grid(ceil_div(rows, 4)), block(256);
+  const char* env = getenv("EVLM_LN_FWD_3PASS");      // (debug / A-B switch)
+  if (d <= 2048 && !(env && atoi(env))) {     // the row fits the registers of one wave: single pass, 3 rows per wave
+    dim3 rgrid(rows >= 4096 ? ceil_div(rows, 12) : ceil_div(rows, 4));
+#define LN_FWD(DCH_) hipLaunchKernelGGL((ln_fwd_reg_kernel<T, DCH_>), rgrid, block, 0, stream, (const T*)x, gamma, beta, eps, rows, d, (T*)y, mean, rstd)
+    EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_fwd",
+      if (d <= 512) LN_FWD(1); else if (d <= 1024) LN_FWD(2); else if (d <= 1536) LN_FWD(3); else LN_FWD(4);)
+#undef LN_FWD
+    EVLM_LAUNCH_CHECK("evlm_layernorm_fwd");
+    return 0;
+  }
   EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_fwd",
     hipLaunchKernelGGL((ln_fwd_kernel<T>), grid, block, 0, stream, (const T*)x, gamma, beta, eps, rows, d, (T*)y, mean, rstd);)
   EVLM_LAUNCH_CHECK("evlm_layernorm_fwd");

@@ -1,19 +1,32 @@
-import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""LayerNorm forward / backward kernel times on the step's shapes: python tools/ln_bench.py"""
+import os, sys
 import torch
-from efficientvlm_amd import _lib as L
-lib = L.load(); dev = "cuda"
-for rows, d in [(12608, 768), (7680, 768), (3840, 768), (1920, 768)]:
-    x = torch.randn(rows, d, device=dev).bfloat16(); dy = torch.randn(rows, d, device=dev).bfloat16(); dx = torch.empty_like(x)
-    g = torch.ones(d, device=dev); mean = torch.zeros(rows, device=dev); rstd = torch.ones(rows, device=dev)
-    dg = torch.zeros(d, device=dev); db = torch.zeros(d, device=dev)
-    ws = torch.empty(lib.evlm_layernorm_bwd_blocks(rows) * 2 * d, device=dev)
-    f = lambda: L.check(lib.evlm_layernorm_bwd(L.BF16, L.ptr(dy), L.ptr(x), L.ptr(g), L.ptr(mean), L.ptr(rstd), rows, d, L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(ws), L.stream()), "ln")
-    for _ in range(5): f()
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from efficientvlm_amd import ops
+
+def timeit(f, n=100):
+    """us per call, launches replayed from a hipGraph (host launch cost out of the picture)"""
+    for _ in range(3):
+        f()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(50): f()
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 50 * 1e3
-    print(f"rows={rows} d={d}: {us:.1f} us  {rows*d*2*3/us/1e6:.2f} TB/s")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            f()
+    g.replay(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        g.replay()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / (5 * n) * 1e3
+
+for rows in (12608, 7680, 3840):
+  for old in ("0", "1"):
+    os.environ["EVLM_LN_FWD_3PASS"] = old
+    x = torch.randn(rows, 768, device="cuda", dtype=torch.bfloat16)
+    w = torch.randn(768, device="cuda"); b = torch.randn(768, device="cuda")
+    with torch.no_grad():
+        t = timeit(lambda: ops.layer_norm(x, w, b, 1e-5))
+    mb = rows * 768 * 2 * 2 / 1e6
+    print(f"ln_fwd rows={rows} three_pass={old}: {t:.2f} us  ({mb / t:.2f} TB/s of r+w, cache-resident input)")
