@@ -23,6 +23,7 @@
 int evlm_gemm_pp256_launch(GemmP& g, int pt, int qt, hipStream_t stream);
 int evlm_gemm_pp256_splits(const GemmP& g);
 bool evlm_gemm_pp256_eligible(const GemmP& g, int pt, int qt);
+bool evlm_gemm_pp256_streamk(const GemmP& g, int pt);
 
 
 // =============================================================================================
@@ -817,6 +818,7 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
   g.c_f32 = (a->dtype == EVLM_F32) ? 1 : a->c_f32;
   g.accumulate = a->accumulate;
   g.psum = a->psum;
+  g.sk_ws = a->sk_workspace; g.sk = 0;
   EVLM_REQUIRE(!a->psum || (a->dtype == EVLM_BF16 && a->K % 64 == 0), "evlm_gemm: psum needs bf16 operands and K a multiple of 64");
   EVLM_REQUIRE(!a->accumulate || (a->dtype == EVLM_BF16 && a->c_f32 && !a->bias && !a->gate && !a->preact && !a->aux &&
                                    !a->residual && a->act == EVLM_ACT_NONE && a->K % 64 == 0),
@@ -834,14 +836,15 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
     static const int pp_pct = getenv("EVLM_PP256_PCT") ? atoi(getenv("EVLM_PP256_PCT")) : 30;   // tuning aid; > 100 disables
     if (evlm_gemm_pp256_eligible(g, pt, qt)) {
       const int items = ceil_div(g.I, 256) * ceil_div(g.J, 256) * evlm_gemm_pp256_splits(g);
-      if (items * 100 >= pp_pct * ceil_div(items, 256) * 256) {
+      if (items * 100 >= pp_pct * ceil_div(items, 256) * 256 || evlm_gemm_pp256_streamk(g, pt)) {
         if (g.c_f32 && evlm_gemm_pp256_splits(g) > 1 && !g.accumulate) {
           hipError_t me = hipMemsetAsync(g.C, 0, (size_t)g.I * g.ldc * sizeof(float), stream);
           if (me != hipSuccess) return evlm_set_error("evlm_gemm: memset failed: %s", hipGetErrorString(me));
         }
         if (evlm_gemm_pp256_launch(g, pt, qt, stream)) return -1;
-        g_last_kernel = g.c_f32 ? "gemm_bf16_pp256_kernel<true,true,1>" : (qt ? "gemm_bf16_pp256_kernel<false,true,0>"
-                                                                           : "gemm_bf16_pp256_kernel<false,false,0>");
+        g_last_kernel = g.sk ? (qt ? "gemm_bf16_pp256_sk_kernel<true>" : "gemm_bf16_pp256_sk_kernel<false>")
+                             : g.c_f32 ? "gemm_bf16_pp256_kernel<true,true,1>"
+                                       : (qt ? "gemm_bf16_pp256_kernel<false,true,0>" : "gemm_bf16_pp256_kernel<false,false,0>");
         EVLM_LAUNCH_CHECK("evlm_gemm");
         return 0;
       }

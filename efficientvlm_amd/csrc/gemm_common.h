@@ -14,6 +14,8 @@ struct GemmP {
   int bare_f32;       // f32 output with no epilogue terms (weight gradients): LDS-staged coalesced store / atomics
   int accumulate;     // C += result (f32 atomics), no zero-fill
   float* psum;        // [I] += sum_k P(i,k) (bias gradient), or nullptr
+  void* sk_ws;        // stream-K workspace (gemm_pp256.hip): 256 flag words, then 256 f32 tile slots of 256 KiB; or nullptr
+  int sk;             // launch form chosen by the host: 1 = stream-K
 };
 
 // ---------------------------------------------------------------------------------------------

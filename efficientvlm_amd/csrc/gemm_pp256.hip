@@ -77,9 +77,30 @@ __device__ __forceinline__ PPRows pp_epi_rows(const GemmP& g, const bf16* xb, in
 // fine-tune only).  With the run-time form hipcc keeps a chain of scalar compares and branches around every single element
 // (128 per lane and tile): the bias-only epilogue took 7.6 k cycles per tile with or without its global stores
 // (in-kernel stamps), most of it branch issue.
-template <bool FULL, int MODE, bool GATED, int XM, int ACT, int DACT>
+// stream-K owner (SKP): up to two partial tiles parked by other workgroups are ADDED HERE, where the accumulators are only
+// read - eight 16-byte system-scope loads per chunk and producer (slot layout [wave][half][b][a][lane]).  Summing them into
+// the accumulator registers ahead of the epilogue (VALU adds, f32 MFMAs against the identity: both tried) made the
+// register allocator spill 250-500 VGPRs, reloaded inside the K loop.
+struct PPSk { const char* p0; int np; };     // per-lane address of this half's registers in the FIRST producer's slot; producers
+#define PP_SK_NEXT (8 * 262144)               // (they are consecutive workgroups of one XCD: slots 8 apart)
+__device__ __forceinline__ void pp_sk_load8(const char* base, f32x4 (&v)[2][4]) {
+  asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
+               "global_load_dwordx4 %1, %8, off offset:1024 sc0 sc1\n\t"
+               "global_load_dwordx4 %2, %8, off offset:2048 sc0 sc1\n\t"
+               "global_load_dwordx4 %3, %8, off offset:3072 sc0 sc1\n\t"
+               "global_load_dwordx4 %4, %9, off sc0 sc1\n\t"
+               "global_load_dwordx4 %5, %9, off offset:1024 sc0 sc1\n\t"
+               "global_load_dwordx4 %6, %9, off offset:2048 sc0 sc1\n\t"
+               "global_load_dwordx4 %7, %9, off offset:3072 sc0 sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[0][3]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[1][2]),
+                 "=&v"(v[1][3])
+               : "v"(base), "v"(base + 4096) : "memory");
+}
+
+template <bool FULL, int MODE, bool GATED, int XM, int ACT, int DACT, bool SKP>
 __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4], int b0, const PPRows& xr,
-                                             int ic, int jb, int lane, char* sw, bf16* dst, int ldd) {
+                                             int ic, int jb, int lane, char* sw, bf16* dst, int ldd, const PPSk& sk) {
   constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && XM == 2;
   const int il = lane & 15, jl = (lane >> 4) * 4;
   const int act = ACT >= 0 ? ACT : g.act, dact = DACT >= 0 ? DACT : g.dact;
@@ -101,6 +122,18 @@ __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4],
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
+  f32x4 pk[2][4];                          // SKP: [bb][a] partial sums of the other workgroups for this chunk
+  if (SKP) {
+    pp_sk_load8(sk.p0 + b0 * 4096, pk);
+    for (int k = 1; k < sk.np; ++k) {      // (wave-uniform)
+      f32x4 pk1[2][4];
+      pp_sk_load8(sk.p0 + (size_t)k * PP_SK_NEXT + b0 * 4096, pk1);
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) pk[bb][a] += pk1[bb][a];
+    }
+  }
 #pragma unroll
   for (int bb = 0; bb < 2; ++bb) {
     const int r = bb * 16 + il;
@@ -110,7 +143,7 @@ __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4],
       bf16* cell = reinterpret_cast<bf16*>(sw + r * 128 + ((ch ^ (r & 7)) << 4) + ((jl & 4) << 1));
       float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc[a][b0 + bb][e] * g.alpha + bz[a][e];
+      for (int e = 0; e < 4; ++e) v[e] = (SKP ? acc[a][b0 + bb][e] + pk[bb][a][e] : acc[a][b0 + bb][e]) * g.alpha + bz[a][e];
       if (MODE == 2) {
         if (gated && g.gate_pos == EVLM_GATE_PRE_ACT) {
 #pragma unroll
@@ -160,9 +193,9 @@ __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4],
 // window, where the result then overwrites them in place.
 // XM (compile-time, so that the plain instantiation carries no row registers): 0 none, 1 aux (activation backward),
 // 2 residual
-template <bool FULL, int MODE, bool GATED, int XM, int ACT, int DACT>
+template <bool FULL, int MODE, bool GATED, int XM, int ACT, int DACT, bool SKP>
 __device__ __forceinline__ void pp_epi_half(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4],
-                                            int ib, int jb, int lane, char* sw, bf16* dst, int ldd) {
+                                            int ib, int jb, int lane, char* sw, bf16* dst, int ldd, const PPSk& sk) {
   constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && XM == 2;
   // (rows are requested per 64-row half: requesting all four chunks of the tile up front - 64 registers - was measured
   // SLOWER, 12.7 k against 10.6 k cycles per tile, the extra registers spill around the epilogue)
@@ -172,40 +205,47 @@ __device__ __forceinline__ void pp_epi_half(const GemmP& g, f32x4 (&acc)[4][4], 
     x0 = pp_epi_rows<FULL>(g, xb, ib, jb, lane);
     x1 = pp_epi_rows<FULL>(g, xb, ib + 32, jb, lane);
   }
-  pp_epi_chunk<FULL, MODE, GATED, XM, ACT, DACT>(g, acc, bz, 0, x0, ib, jb, lane, sw, dst, ldd);
-  pp_epi_chunk<FULL, MODE, GATED, XM, ACT, DACT>(g, acc, bz, 2, x1, ib + 32, jb, lane, sw, dst, ldd);
+  pp_epi_chunk<FULL, MODE, GATED, XM, ACT, DACT, SKP>(g, acc, bz, 0, x0, ib, jb, lane, sw, dst, ldd, sk);
+  pp_epi_chunk<FULL, MODE, GATED, XM, ACT, DACT, SKP>(g, acc, bz, 2, x1, ib + 32, jb, lane, sw, dst, ldd, sk);
 }
 
-template <bool FULL, bool GATED, int XM, int ACT, int DACT>
+__device__ __forceinline__ PPSk pp_sk_high(const PPSk& sk) {      // the slot addresses of the H half (i rows 64..127)
+  PPSk h;
+  h.p0 = sk.p0 + 16384; h.np = sk.np;
+  return h;
+}
+template <bool FULL, bool GATED, int XM, int ACT, int DACT, bool SKP>
 __device__ __forceinline__ void pp_epi_c(const GemmP& g, f32x4 (&accL)[4][4], f32x4 (&accH)[4][4], const f32x4 (&bz)[4], int ib,
-                                         int jb, int lane, char* sw) {
-  pp_epi_half<FULL, 2, GATED, XM, ACT, DACT>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
-  pp_epi_half<FULL, 2, GATED, XM, ACT, DACT>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
+                                         int jb, int lane, char* sw, const PPSk& sk) {
+  pp_epi_half<FULL, 2, GATED, XM, ACT, DACT, SKP>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc, sk);
+  pp_epi_half<FULL, 2, GATED, XM, ACT, DACT, SKP>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc,
+                                                  pp_sk_high(sk));
 }
 
-template <bool FULL>
+template <bool FULL, bool SKP = false>
 __device__ __forceinline__ void pp_epilogue(const GemmP& g, f32x4 (&accL)[4][4], f32x4 (&accH)[4][4], int ib, int jb, int lane,
-                                            char* sw) {
+                                            char* sw, const PPSk& sk = PPSk{nullptr, 0}) {
   f32x4 bz[4];
   pp_epi_cols<FULL>(g, jb, lane, bz);
   if (g.preact) {
-    pp_epi_half<FULL, 1, false, 0, 0, 0>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx);
-    pp_epi_half<FULL, 1, false, 0, 0, 0>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx);
+    pp_epi_half<FULL, 1, false, 0, 0, 0, SKP>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx, sk);
+    pp_epi_half<FULL, 1, false, 0, 0, 0, SKP>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx,
+                                              pp_sk_high(sk));
   }
   // one instantiation per epilogue flavour (ONE wave-uniform dispatch per tile): the plain one carries neither gate nor
   // row registers, and every flavour of the training path has its activation code as a compile-time constant
   constexpr int G = EVLM_ACT_GELU, QG = EVLM_ACT_QUICK_GELU, N = EVLM_ACT_NONE;
   if (g.gate) {                      // L0-gated FFN (pruning fine-tune only): activation code read at run time
-    if (g.residual) pp_epi_c<FULL, true, 2, -1, N>(g, accL, accH, bz, ib, jb, lane, sw);
-    else pp_epi_c<FULL, true, 0, -1, N>(g, accL, accH, bz, ib, jb, lane, sw);
-  } else if (g.dact == G) pp_epi_c<FULL, false, 1, N, G>(g, accL, accH, bz, ib, jb, lane, sw);
-  else if (g.dact == QG) pp_epi_c<FULL, false, 1, N, QG>(g, accL, accH, bz, ib, jb, lane, sw);
+    if (g.residual) pp_epi_c<FULL, true, 2, -1, N, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+    else pp_epi_c<FULL, true, 0, -1, N, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+  } else if (g.dact == G) pp_epi_c<FULL, false, 1, N, G, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+  else if (g.dact == QG) pp_epi_c<FULL, false, 1, N, QG, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
   else if (g.residual) {
-    if (g.act == N) pp_epi_c<FULL, false, 2, N, N>(g, accL, accH, bz, ib, jb, lane, sw);
-    else pp_epi_c<FULL, false, 2, -1, N>(g, accL, accH, bz, ib, jb, lane, sw);
-  } else if (g.act == G) pp_epi_c<FULL, false, 0, G, N>(g, accL, accH, bz, ib, jb, lane, sw);
-  else if (g.act == QG) pp_epi_c<FULL, false, 0, QG, N>(g, accL, accH, bz, ib, jb, lane, sw);
-  else pp_epi_c<FULL, false, 0, N, N>(g, accL, accH, bz, ib, jb, lane, sw);
+    if (g.act == N) pp_epi_c<FULL, false, 2, N, N, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+    else pp_epi_c<FULL, false, 2, -1, N, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+  } else if (g.act == G) pp_epi_c<FULL, false, 0, G, N, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+  else if (g.act == QG) pp_epi_c<FULL, false, 0, QG, N, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+  else pp_epi_c<FULL, false, 0, N, N, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
 }
 
 // weight gradients: f32 tile out of the same 4 KiB window, 16 rows x 64 columns at a time.  Plain 16-byte stores when the
@@ -301,16 +341,53 @@ __device__ __forceinline__ int pp_group_select(const PPGroup& grp, int vb0, Gemm
 // persistent: gridDim.x = min(work items, CUs); workgroup b runs items b, b + grid, ...  An item is (K split, tile);
 // split s covers K tiles [s * kt_per_split, ...).  The next item's first six staging units are issued BEFORE the epilogue
 // of the current one.   OUT 0: bf16 through the fused epilogue;  OUT 1: bare f32 (weight gradients).
-template <bool PT, bool QT, int OUT, bool GROUPED>
+//
+// SK (stream-K, bf16 output): a launch whose tiles fill only part of one round of the 256 workgroups is cut along K
+// instead.  The tiles are first dealt to the 8 XCDs in contiguous runs (as pp_tile_ij does); inside an XCD the (tile, K
+// tile) iterations are laid end to end and split evenly - in even chunks of sk_q K tiles - over its 32 workgroups
+// (blockIdx.x = xcd + 8 m).  A workgroup whose chunk ends inside a tile stores its f32 accumulators in ITS slot of the
+// workspace (lane-linear: 32 coalesced 16-byte stores per lane) and raises ITS flag; the workgroup that finishes the
+// tile's last K tile - always a later one of the same XCD, so one that was dispatched after its producers - waits for
+// them in ascending order, adds their slots to its registers, clears their flags and runs the normal fused epilogue.
+// Sums are formed in a fixed order (deterministic), nothing is zero-filled between launches.
+#define PP_SK_FLAGS_BYTES 4096
+#define PP_SK_SLOT_F4 (32 * 512)                    /* float4 per slot: 32 accumulator registers x 512 lanes */
+// this workgroup's share under stream-K: first tile of its XCD, iterations per workgroup (even), end of its range.
+// Recomputed where needed instead of being carried through the K loop (every scalar held there costs: the kernel is
+// at the SGPR limit, and spilled SGPRs live in VGPR lanes)
+struct PPSkRange { int t0, q, end; };
+__device__ __forceinline__ PPSkRange pp_sk_range(int ntiles, int nt_all) {
+  const int qt = ntiles >> 3, r = ntiles & 7, x = blockIdx.x & 7, m = blockIdx.x >> 3;
+  PPSkRange o;
+  o.t0 = x < r ? x * (qt + 1) : r * (qt + 1) + (x - r) * qt;
+  const int tot = (x < r ? qt + 1 : qt) * nt_all;
+  o.q = (((tot + 31) >> 5) + 1) & ~1;             // even: every segment holds >= 2 K tiles (nt_all is even)
+  o.end = min((m + 1) * o.q, tot);
+  return o;
+}
+
+template <bool PT, bool QT, int OUT, bool GROUPED, bool SK = false>
 __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 64 KiB staging + 8 x 4 KiB epilogue windows; ALL LDS
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (SK: the wave index as a SCALAR - the LDS destinations of the staging DMA (m0) and the wave-group branches then cost no
+  // VGPRs; the plain kernels keep the code they were tuned with)
+  const int tid = threadIdx.x, lane = tid & 63, wave = SK ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int nt_all = g.K >> 6;
   const int splits = GROUPED ? 1 : (nt_all + g.kt_per_split - 1) / g.kt_per_split;
   int vb = blockIdx.x;
   int ntiles, nitems, ti, tj, sp = 0;
-  if (GROUPED) {
+  int sk_it = 0, sk_k0 = 0;                          // SK: cursor in the XCD's iteration space, first K tile of the segment
+  if (SK) {
+    ntiles = g.tiles_i * g.tiles_j;
+    nitems = 0;
+    const PPSkRange rg = pp_sk_range(ntiles, nt_all);
+    sk_it = (int)(blockIdx.x >> 3) * rg.q;
+    if (sk_it >= rg.end) return;                      // (whole workgroup, before any barrier)
+    const int tl_ = sk_it / nt_all;
+    sk_k0 = sk_it - tl_ * nt_all;
+    ti = (rg.t0 + tl_) / g.tiles_j; tj = (rg.t0 + tl_) - ti * g.tiles_j;
+  } else if (GROUPED) {
     nitems = grp->tile0[grp->n];
     const int t = pp_group_select(*grp, vb, g);
     ntiles = g.tiles_i * g.tiles_j;
@@ -323,12 +400,13 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
   }
   int kp = PT ? 64 * g.ldp : 64, kq = QT ? 64 * g.ldq : 64;           // elements per K tile step
   int i0 = ti * 256, j0 = tj * 256;
-  int nt = min(nt_all - sp * g.kt_per_split, g.kt_per_split);
-  const bf16* Pk = reinterpret_cast<const bf16*>(g.P) + (size_t)sp * g.kt_per_split * kp;
-  const bf16* Qk = reinterpret_cast<const bf16*>(g.Q) + (size_t)sp * g.kt_per_split * kq;
+  int nt = SK ? min(nt_all - sk_k0, pp_sk_range(g.tiles_i * g.tiles_j, nt_all).end - sk_it)
+              : min(nt_all - sp * g.kt_per_split, g.kt_per_split);
+  const bf16* Pk = reinterpret_cast<const bf16*>(g.P) + (size_t)(SK ? sk_k0 : sp * g.kt_per_split) * kp;
+  const bf16* Qk = reinterpret_cast<const bf16*>(g.Q) + (size_t)(SK ? sk_k0 : sp * g.kt_per_split) * kq;
   PPSrc src;
   pp_src<PT, QT>(g, i0, j0, tid, src);
-  const int plb = pp_lane_base<PT, true>(lane, wr), qlb = pp_lane_base<QT, false>(lane, wc);
+  int plb = pp_lane_base<PT, true>(lane, wr), qlb = pp_lane_base<QT, false>(lane, wc);
 
   f32x4 accL[4][4], accH[4][4];     // [j fragment][i fragment]; L: i rows 0..63 of the wave's block, H: 64..127
   bf16x8 pf[4][2], qf[2][2];
@@ -351,6 +429,17 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
   stp[4] = __builtin_amdgcn_s_memtime();
 #endif
   while (true) {
+    if (SK) {
+      // the per-lane K-loop values (LDS fragment bases, staging source offsets) are RE-DERIVED here from a laundered thread
+      // id: kept live across the stream-K epilogue (64 more registers than the plain one) they were the allocator's
+      // spill candidates, and ONE scratch reload inside the K loop (its s_waitcnt vmcnt(0) drains the whole staging
+      // pipeline) costs more than the stream-K cut saves
+      int tid_k = tid;
+      asm volatile("" : "+v"(tid_k));
+      plb = pp_lane_base<PT, true>(tid_k & 63, wr);
+      qlb = pp_lane_base<QT, false>(tid_k & 63, wc);
+      pp_src<PT, QT>(g, i0, j0, tid_k, src);
+    }
 #ifdef PP_STAMP
     stp[0] = __builtin_amdgcn_s_memtime();
 #endif
@@ -390,10 +479,22 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
     const int ib = i0 + wr * 128, jb = j0 + wc * 64;
     const bool full = (i0 + 256 <= g.I) && (j0 + 256 <= g.J);
     GemmP gc = g;                                 // the finished item's problem (the grouped form switches g below)
-    vb += gridDim.x;
-    const bool more = vb < nitems;
+    const int seg_k0 = sk_k0, seg_nt = nt, seg_first_it = sk_it - sk_k0;     // SK: the finished segment
+    const PPSkRange rg = SK ? pp_sk_range(ntiles, nt_all) : PPSkRange{0, 2, 0};
+    bool more;
+    if (SK) {
+      sk_it += nt;
+      more = sk_it < rg.end;
+    } else {
+      vb += gridDim.x;
+      more = vb < nitems;
+    }
     if (more) {                                   // next item: its first six units fly under this item's epilogue
-      if (GROUPED) {
+      if (SK) {                                   // (a later segment of a workgroup always starts a tile)
+        const int tl_ = sk_it / nt_all;
+        sk_k0 = 0;
+        ti = (rg.t0 + tl_) / g.tiles_j; tj = (rg.t0 + tl_) - ti * g.tiles_j;
+      } else if (GROUPED) {
         const int t = pp_group_select(*grp, vb, g);
         ti = t / g.tiles_j; tj = t - ti * g.tiles_j;
         kp = PT ? 64 * g.ldp : 64; kq = QT ? 64 * g.ldq : 64;
@@ -402,9 +503,9 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
         pp_tile_ij(g, vb - sp * ntiles, ntiles, ti, tj);
       }
       i0 = ti * 256; j0 = tj * 256;
-      nt = min(nt_all - sp * g.kt_per_split, g.kt_per_split);
-      Pk = reinterpret_cast<const bf16*>(g.P) + (size_t)sp * g.kt_per_split * kp;
-      Qk = reinterpret_cast<const bf16*>(g.Q) + (size_t)sp * g.kt_per_split * kq;
+      nt = SK ? min(nt_all, rg.end - sk_it) : min(nt_all - sp * g.kt_per_split, g.kt_per_split);
+      Pk = reinterpret_cast<const bf16*>(g.P) + (size_t)(SK ? 0 : sp * g.kt_per_split) * kp;
+      Qk = reinterpret_cast<const bf16*>(g.Q) + (size_t)(SK ? 0 : sp * g.kt_per_split) * kq;
       int tid_p = tid;                          // (same reason as for the epilogue below: no hoisting of the lane terms)
       asm volatile("" : "+v"(tid_p));
       pp_src<PT, QT>(g, i0, j0, tid_p, src);
@@ -425,8 +526,66 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
     asm volatile("" : "+v"(tid_e));
     const int lane_e = tid_e & 63;
     char* swin_e = smem + PP_EPI_OFF + (tid_e >> 6) * 4096;
+    bool sk_partial = false;
+    if (SK) {
+      int* flags = reinterpret_cast<int*>(gc.sk_ws);
+      // The partial sums and flags move with SYSTEM-scope accesses (sc0 sc1: written through to memory, read past L1 and
+      // L2), not with agent-scope fences: a release / acquire pair at agent scope writes back and invalidates the whole
+      // L2 under every other workgroup's operand panels (measured: 10x on the launch).  Slot layout: [wave][register]
+      // [lane] x 16 bytes, so four registers of a lane sit within one 13-bit instruction offset of each other; the
+      // accesses are hand-written in groups of 4 / 8 (the register allocator otherwise spills INTO THE K LOOP).
+      // Slot layout: [wave][half L/H][b][a][lane] x 16 bytes (a lane's four a-registers of one b sit within one 13-bit
+      // instruction offset).  Partial sums and flags move with SYSTEM-scope accesses (sc0 sc1: written through to memory,
+      // read past L1 and L2), not with agent-scope fences: a release / acquire pair at agent scope writes back and
+      // invalidates the whole L2 under every other workgroup's operand panels (measured: 10x on the launch).
+      char* lane_base = reinterpret_cast<char*>(gc.sk_ws) + PP_SK_FLAGS_BYTES + (size_t)(tid_e >> 6) * 32768 + lane_e * 16;
+      if (seg_k0 + seg_nt < nt_all) {             // the tile ends in a later workgroup: park the accumulators, raise the flag
+        sk_partial = true;
+        char* A = lane_base + (size_t)blockIdx.x * 262144;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\t"
+                       "global_store_dwordx4 %0, %2, off offset:1024 sc0 sc1\n\t"
+                       "global_store_dwordx4 %0, %3, off offset:2048 sc0 sc1\n\t"
+                       "global_store_dwordx4 %0, %4, off offset:3072 sc0 sc1"
+                       :: "v"(A + b * 4096), "v"(accL[0][b]), "v"(accL[1][b]), "v"(accL[2][b]), "v"(accL[3][b]) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\t"
+                       "global_store_dwordx4 %0, %2, off offset:1024 sc0 sc1\n\t"
+                       "global_store_dwordx4 %0, %3, off offset:2048 sc0 sc1\n\t"
+                       "global_store_dwordx4 %0, %4, off offset:3072 sc0 sc1"
+                       :: "v"(A + 16384 + b * 4096), "v"(accH[0][b]), "v"(accH[1][b]), "v"(accH[2][b]), "v"(accH[3][b]) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores are acknowledged
+        __syncthreads();
+        if (tid_e == 0) __hip_atomic_store(flags + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else if (seg_k0 > 0) {                    // owner of a tile other workgroups started: wait for their parts
+        const int m_first = seg_first_it / rg.q, m_own = (int)(blockIdx.x >> 3);
+        if (tid_e == 0) {
+          for (int m = m_first; m < m_own; ++m) {
+            int spins = 0;
+            while (__hip_atomic_load(flags + (blockIdx.x & 7) + 8 * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+              __builtin_amdgcn_s_sleep(8);
+              if (++spins > (1 << 22)) break;     // (a producer that never arrives: wrong numbers rather than a hung GPU)
+            }
+          }
+        }
+        __syncthreads();
+        PPSk skp;
+        skp.p0 = lane_base + (size_t)((blockIdx.x & 7) + 8 * m_first) * 262144;
+        skp.np = m_own - m_first;
+        if (full) pp_epilogue<true, true>(gc, accL, accH, ib, jb, lane_e, swin_e, skp);
+        else pp_epilogue<false, true>(gc, accL, accH, ib, jb, lane_e, swin_e, skp);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                          // every wave has read the slots: hand them back
+        if (tid_e == 0)
+          for (int m = m_first; m < m_own; ++m)
+            __hip_atomic_store(flags + (blockIdx.x & 7) + 8 * m, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        sk_partial = true;                        // (= nothing left to do below)
+      }
+    }
     if (OUT == 0) {
-      if (full) pp_epilogue<true>(gc, accL, accH, ib, jb, lane_e, swin_e);
+      if (sk_partial) {}
+      else if (full) pp_epilogue<true>(gc, accL, accH, ib, jb, lane_e, swin_e);
       else pp_epilogue<false>(gc, accL, accH, ib, jb, lane_e, swin_e);
     } else {
       const int mode = GROUPED ? (grp->rmw ? 2 : 1) : ((gc.accumulate || splits > 1) ? 1 : 0);
@@ -460,6 +619,10 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
 template <bool PT, bool QT, int OUT>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
   pp256_body<PT, QT, OUT, false>(g, nullptr);
+}
+template <bool QT>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_sk_kernel(GemmP g) {
+  pp256_body<false, QT, 0, false, true>(g, nullptr);
 }
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_grouped_kernel(GemmP g, PPGroup grp) {
   pp256_body<true, true, 1, true>(g, &grp);
@@ -503,9 +666,36 @@ int evlm_gemm_pp256_splits(const GemmP& g) {
   return splits;
 }
 
+// stream-K pays when one round of 256x256 tiles leaves a good part of the chip idle and K is long enough to cut
+bool evlm_gemm_pp256_streamk(const GemmP& g, int pt) {
+  // OPT-IN (EVLM_PP256_SK=1): correct and deterministic (tests), but not yet faster - profiles/r02_streamk.md
+  static const int on = getenv("EVLM_PP256_SK") ? atoi(getenv("EVLM_PP256_SK")) : 0;
+  if (!on || !g.sk_ws || g.c_f32 || pt) return false;
+  const int tiles = ceil_div(g.I, 256) * ceil_div(g.J, 256), nt = g.K / 64;
+  return nt % 2 == 0 && nt >= 8 && tiles >= 16 && tiles <= 200;
+}
+
 int evlm_gemm_pp256_launch(GemmP& g, int pt, int qt, hipStream_t stream) {
   const int lds = 2 * PPB + 8 * 4096;
   g.tiles_i = ceil_div(g.I, 256); g.tiles_j = ceil_div(g.J, 256); g.bare_f32 = g.c_f32;
+  g.sk = evlm_gemm_pp256_streamk(g, pt) ? 1 : 0;
+  if (g.sk) {
+    g.kt_per_split = g.K / 64;
+#define PP_LAUNCH_SK(QT_)                                                                                     \
+  do {                                                                                                        \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set) {                                                                                          \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp256_sk_kernel<QT_>),       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);                    \
+      if (e != hipSuccess) return evlm_set_error("evlm_gemm: cannot reserve 160 KiB LDS: %s", hipGetErrorString(e)); \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL((gemm_bf16_pp256_sk_kernel<QT_>), dim3(256), dim3(512), lds, stream, g);               \
+  } while (0)
+    if (qt) PP_LAUNCH_SK(true); else PP_LAUNCH_SK(false);
+#undef PP_LAUNCH_SK
+    return 0;
+  }
   const int tiles = g.tiles_i * g.tiles_j, nt = g.K / 64;
   const int splits = evlm_gemm_pp256_splits(g);
   g.kt_per_split = ceil_div(nt, splits);

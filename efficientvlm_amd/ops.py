@@ -9,6 +9,7 @@ torch.bfloat16 (fast path: bf16 storage, fp32 accumulate).  Parameters stay fp32
 bf16 path reads packed bf16 compute copies from `WeightCache`.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -194,6 +195,23 @@ def _collapsible(x):
         return False
 
 
+SK_WORKSPACE_BYTES = 4096 + 256 * 262144        # EVLM_GEMM_SK_WORKSPACE_BYTES (include/evlm_hip.h)
+_SK_WS = {}
+_SK_ON = os.environ.get("EVLM_PP256_SK", "0") not in ("", "0")     # stream-K GEMM launches: opt-in (gemm_pp256.hip)
+
+
+def _sk_workspace(dev):
+    """the stream-K workspace of the CURRENT stream of `dev` (flags + partial-tile slots, evlm_gemm_args.sk_workspace):
+    launches of one stream run one after the other and may share it; launches of different streams may overlap and may
+    not.  Zero on first use; the kernels leave the flags zero.  (Inside a hipGraph capture a new stream's workspace comes
+    from the graph's pool, its zero-fill replayed with the graph.)"""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _SK_WS.get(key)
+    if ws is None:
+        ws = _SK_WS[key] = torch.zeros(SK_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
+    return ws
+
+
 def _gemm(dtype, P, Q, Cm, I, J, K, ldp, ldq, ldc, p_trans=0, q_trans=0, bias=None, gate=None, preact=None,
           aux=None, residual=None, ldx=0, alpha=1.0, act=L.ACT_NONE, gate_pos=L.GATE_PRE, dact=L.ACT_NONE, c_f32=0,
           accumulate=0, p_off=0, psum=None):
@@ -202,6 +220,8 @@ def _gemm(dtype, P, Q, Cm, I, J, K, ldp, ldq, ldc, p_trans=0, q_trans=0, bias=No
                    ldc=ldc, ldx=ldx, P=Pp, Q=L.ptr(Q), C=L.ptr(Cm), bias=L.ptr(bias), gate=L.ptr(gate),
                    preact=L.ptr(preact), aux=L.ptr(aux), residual=L.ptr(residual), alpha=alpha, act=act,
                    gate_pos=gate_pos, dact=dact, accumulate=accumulate, psum=L.ptr(psum))
+    if _SK_ON and dtype == L.BF16 and not c_f32 and not p_trans and K >= 512 and I * J >= 16 * 65536:
+        a.sk_workspace = L.ptr(_sk_workspace(P.device))     # (shapes stream-K can apply to: gemm_pp256.hip)
     if GEMM_PROFILE is None:
         L.check(_lib().evlm_gemm(C.byref(a), L.stream()), "gemm")
         return

@@ -73,7 +73,12 @@ typedef struct {
   float* psum;          /* optional [I] f32: psum[i] += sum_k P(i,k)  (bias gradient = column sums of dY, produced by the
                            dW GEMM itself from the dY tile it already holds: one extra MFMA against a ones fragment).
                            bf16, K % 64 == 0 only; ACCUMULATED with f32 atomics */
+  void* sk_workspace;   /* optional, EVLM_GEMM_SK_WORKSPACE_BYTES, 16-byte aligned, ZERO when first handed over and owned by
+                           the calls of ONE stream at a time: lets bf16 products whose 256x256 tiles fill only part of
+                           the chip be cut along K as well (stream-K: partial accumulators + flags live here; the
+                           kernel leaves the flags zero again).  NULL: never cut */
 } evlm_gemm_args;
+#define EVLM_GEMM_SK_WORKSPACE_BYTES (4096 + 256 * 262144)
 
 int evlm_gemm(const evlm_gemm_args* args, void* stream);
 

@@ -582,7 +582,7 @@ def test_fused_cross_attention_forward_is_bit_identical_to_the_two_launch_path(B
     assert not o.xattn_fusable(q.clone().requires_grad_(True), x, (Wk, Wv), H, dh)
 
 
-def _pp256_case(o, L, g, I, J, K, qt=0, bias=False, res=False, act=0, dact=0):
+def _pp256_case(o, L, g, I, J, K, qt=0, bias=False, res=False, act=0, dact=0, sk=False):
     dtype = torch.bfloat16
     Pm = rnd((I, K), dtype, g, 0.5)
     Qm = rnd((K, J) if qt else (J, K), dtype, g, 0.1)
@@ -600,7 +600,8 @@ def _pp256_case(o, L, g, I, J, K, qt=0, bias=False, res=False, act=0, dact=0):
     o._gemm(L.dt(dtype), Pm, Qm, Cm, I, J, K, Pm.stride(0), Qm.stride(0), J, q_trans=qt, **kw)
     # the case must have been served by the kernel it is meant to test (a routing change would otherwise test another one)
     served = L.load().evlm_gemm_last_kernel().decode()
-    assert served == f"gemm_bf16_pp256_kernel<false,{'true' if qt else 'false'},0>", served
+    qts = "true" if qt else "false"
+    assert served == (f"gemm_bf16_pp256_sk_kernel<{qts}>" if sk else f"gemm_bf16_pp256_kernel<false,{qts},0>"), served
     ref = Pm.float() @ (Qm.float() if qt else Qm.float().t())
     if bias:
         ref = ref + b
@@ -639,6 +640,59 @@ def test_gemm_pp256_persistent_tiles_and_epilogues():
     _pp256_case(o, L, g, 12608, 768, 768, bias=True, res=True)                   # the ViT out-projection shape (150 tiles)
     _pp256_case(o, L, g, 4096 + 24, 4096, 192, qt=1)                             # dX = dY W, W reduction-major
     _pp256_case(o, L, g, 12608, 768, 2304, qt=1)
+    _pp256_case(o, L, g, 12608, 2304, 768)                                       # ViT QKV: 450 tiles, 1.76 rounds
+
+
+def _stream_k_cases():
+    """body of test_gemm_pp256_stream_k_partial_rounds (runs in a child process with EVLM_PP256_SK=1)"""
+    from efficientvlm_amd import ops as o, _lib as L
+    g = torch.Generator().manual_seed(59)
+    for rep in range(2):
+        _pp256_case(o, L, g, 7680, 768, 768, bias=True, res=True, sk=True)       # 4B-row fusion output projection (90 tiles)
+        _pp256_case(o, L, g, 12608, 768, 768, bias=True, res=True, sk=True)      # ViT out-projection (150 tiles, ragged rows)
+        _pp256_case(o, L, g, 12608, 768, 3072, bias=True, res=True, sk=True)     # ViT FC2: 48 K tiles per tile
+        _pp256_case(o, L, g, 7680, 768, 3072, bias=True, res=True, sk=True)
+        _pp256_case(o, L, g, 3840, 768, 3072, bias=True, res=True, sk=True)      # 45 tiles: up to 7 workgroups per tile
+        _pp256_case(o, L, g, 3840, 3072, 768, bias=True, act=L.ACT_GELU, sk=True)
+        _pp256_case(o, L, g, 12608, 768, 2304, qt=1, sk=True)                    # dX of the QKV projection
+        _pp256_case(o, L, g, 7680, 768, 3072, qt=1, dact=L.ACT_GELU, sk=True)
+        _pp256_case(o, L, g, 1024 + 8, 1024 + 16, 512, bias=True, sk=True)       # 25 tiles, ragged both ways, 8 K tiles
+        _pp256_case(o, L, g, 4096, 1024, 640, bias=True, act=L.ACT_QUICK_GELU, sk=True)   # 64 tiles, 10 K tiles
+    # determinism: same inputs, same bits (fixed summation order)
+    Pm, Qm = rnd((7680, 3072), torch.bfloat16, g, 0.5), rnd((768, 3072), torch.bfloat16, g, 0.1)
+    outs = []
+    for _ in range(3):
+        Cm = torch.empty((7680, 768), dtype=torch.bfloat16, device=DEV)
+        o._gemm(L.BF16, Pm, Qm, Cm, 7680, 768, 3072, 3072, 3072, 768)
+        outs.append(Cm)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # two streams at once: each has its own workspace
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    res = {}
+    for st in (s1, s2):
+        with torch.cuda.stream(st):
+            for k in range(4):
+                Cm = torch.empty((7680, 768), dtype=torch.bfloat16, device=DEV)
+                o._gemm(L.BF16, Pm, Qm, Cm, 7680, 768, 3072, 3072, 3072, 768)
+                res[(st, k)] = Cm
+    torch.cuda.synchronize()
+    assert all(torch.equal(v, outs[0]) for v in res.values())
+
+
+def test_gemm_pp256_stream_k_partial_rounds():
+    """opt-in (EVLM_PP256_SK=1) stream-K form of the 256x256 kernel: launches whose tiles fill only part of one round are
+    cut along K as well (gemm_bf16_pp256_sk_kernel) - partial accumulators through the per-stream workspace, the tile's
+    last workgroup adds them in its epilogue.  Every step shape that would take this path, ragged edges, each epilogue
+    flavour, both Q layouts; run twice (the kernel must leave the workspace flags clean); bit-identical from run to run;
+    two streams at once.  In a child process: the switch is read once per process."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_ops_gpu as t; t._stream_k_cases(); print('SK_OK')" \
+        % (os.path.dirname(here), here)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EVLM_PP256_SK="1"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "SK_OK" in r.stdout, r.stderr[-3000:]
 
 
 def test_gemm_pp256_weight_gradient_variant_subprocess():
