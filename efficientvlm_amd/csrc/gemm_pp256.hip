@@ -369,9 +369,9 @@ __device__ __forceinline__ PPSkRange pp_sk_range(int ntiles, int nt_all) {
 template <bool PT, bool QT, int OUT, bool GROUPED, bool SK = false>
 __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 64 KiB staging + 8 x 4 KiB epilogue windows; ALL LDS
-  // (SK: the wave index as a SCALAR - the LDS destinations of the staging DMA (m0) and the wave-group branches then cost no
-  // VGPRs; the plain kernels keep the code they were tuned with)
-  const int tid = threadIdx.x, lane = tid & 63, wave = SK ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+  // (the wave index as a SCALAR: the LDS destinations of the staging DMA (m0) and the wave-group branches then cost no
+  // VGPRs - every kernel of this file compiles without a spill; GD step -0.27 ms in a same-box A/B)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int nt_all = g.K >> 6;
   const int splits = GROUPED ? 1 : (nt_all + g.kt_per_split - 1) / g.kt_per_split;
