@@ -103,6 +103,7 @@ SIGNATURES = {
     "evlm_l0_deterministic": [_vp, _i, _i, _f, _f, _vp, _vp],
     "evlm_dropout": [_i, _vp, _vp, _i64, _f, _vp, C.c_uint32, _vp, _vp],
     "evlm_dropout_mask": [_i64, _f, _vp, C.c_uint32, _vp, _vp],
+    "evlm_layernorm_bwd_reduce_grouped": [_vp, _i, _i, _vp],
     "evlm_mse_grouped": [_i, _i, _vp, _i, _i, _vp],
     "evlm_sample_negatives": [_vp, _i, _i, _vp, _vp, _vp, C.c_uint32, _vp, _vp],
     "evlm_sumsq": [_vp, _i64, _vp, _vp],

@@ -219,6 +219,36 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   if (r1 > r0) atomicAdd((i < d ? dgamma + i : dbeta + (i - d)), (a0 + a1) + (a2 + a3));
 }
 
+// the same reduction for MANY LayerNorms in one launch (blockIdx.z = unit): a backward pass leaves ~30 workspaces behind,
+// each worth a 6 us launch.  table: int64 [n][5] = {partials, nblk, d, dgamma, dbeta}
+__global__ __launch_bounds__(256) void ln_bwd_reduce_grouped_kernel(const int64_t* __restrict__ table) {
+  const int64_t* e = table + 5 * (int64_t)blockIdx.z;
+  const float* partials = reinterpret_cast<const float*>(e[0]);
+  const int nblk = (int)e[1], d = (int)e[2];
+  float* dgamma = reinterpret_cast<float*>(e[3]);
+  float* dbeta = reinterpret_cast<float*>(e[4]);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * d) return;
+  const int per = (nblk + LN_RED_SLICES - 1) / LN_RED_SLICES;
+  const int r0 = blockIdx.y * per, r1 = min(nblk, r0 + per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    a0 += partials[(size_t)r * 2 * d + i]; a1 += partials[(size_t)(r + 1) * 2 * d + i];
+    a2 += partials[(size_t)(r + 2) * 2 * d + i]; a3 += partials[(size_t)(r + 3) * 2 * d + i];
+  }
+  for (; r < r1; ++r) a0 += partials[(size_t)r * 2 * d + i];
+  if (r1 > r0) atomicAdd((i < d ? dgamma + i : dbeta + (i - d)), (a0 + a1) + (a2 + a3));
+}
+extern "C" int evlm_layernorm_bwd_reduce_grouped(const int64_t* table, int n_units, int d_max, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(table && n_units > 0 && d_max > 0, "evlm_layernorm_bwd_reduce_grouped: bad args");
+  hipLaunchKernelGGL(ln_bwd_reduce_grouped_kernel, dim3(ceil_div(2 * d_max, 256), LN_RED_SLICES, n_units), dim3(256), 0, stream,
+                     table);
+  EVLM_LAUNCH_CHECK("evlm_layernorm_bwd_reduce_grouped");
+  return 0;
+}
+
 extern "C" int evlm_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, float eps,
                                   int rows, int d, void* y, float* mean, float* rstd, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -249,7 +279,10 @@ static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const vo
                                   const float* rstd, int rows, int d, void* dx, float* dgamma, float* dbeta,
                                   float* partials, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  EVLM_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "evlm_layernorm_bwd: bad args");
+  EVLM_REQUIRE(dy && x && gamma && mean && rstd && dx && rows > 0, "evlm_layernorm_bwd: bad args");
+  // dgamma == dbeta == NULL with a workspace: the column sums stay in the workspace, the caller reduces them later
+  // (evlm_layernorm_bwd_reduce_grouped: one launch for all the LayerNorms of a backward pass)
+  EVLM_REQUIRE((dgamma && dbeta) || (partials && !dgamma && !dbeta), "evlm_layernorm_bwd: dgamma / dbeta missing");
   EVLM_REQUIRE(d % 8 == 0 && d <= 2048, "evlm_layernorm_bwd: d=%d unsupported (multiple of 8, <= 2048)", d);
   const int nblk = ln_bwd_blocks(rows);                // row pairs per wave
   dim3 grid(nblk), block(256);
@@ -258,7 +291,7 @@ static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const vo
   EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_bwd",
     if (d <= 512) LN_BWD(1); else if (d <= 1024) LN_BWD(2); else if (d <= 1536) LN_BWD(3); else LN_BWD(4);)
 #undef LN_BWD
-  if (partials)
+  if (partials && dgamma)
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(2 * d, 256), LN_RED_SLICES), dim3(256), 0, stream, partials, nblk, d,
                        dgamma, dbeta);
   EVLM_LAUNCH_CHECK("evlm_layernorm_bwd");

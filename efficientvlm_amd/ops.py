@@ -256,9 +256,26 @@ WGRAD_DEFER = None
 WGRAD_DEFER_MIN_K = 1024
 
 
+LN_DEFER = []          # (workspace, blocks, d, dgamma, dbeta) of LayerNorm backwards whose column sums wait for flush_wgrad
+
+
+def _flush_ln():
+    """the queued LayerNorm-backward workspaces -> dgamma / dbeta, ONE launch (evlm_layernorm_bwd_reduce_grouped)"""
+    global LN_DEFER
+    q, LN_DEFER = LN_DEFER, []
+    if not q:
+        return
+    rows = []
+    for ws, nblk, d, dg, db in q:
+        rows += [ws.data_ptr(), nblk, d, dg.data_ptr(), db.data_ptr()]
+    table = _upload_table(rows, q[0][0].device)
+    L.check(_lib().evlm_layernorm_bwd_reduce_grouped(L.ptr(table), len(q), max(r[2] for r in q), L.stream()), "ln_reduce_grouped")
+
+
 def flush_wgrad():
-    """launch the queued weight-gradient products (no-op when nothing is queued)"""
+    """launch the queued weight-gradient products and LayerNorm column-sum reductions (no-op when nothing is queued)"""
     global WGRAD_DEFER
+    _flush_ln()
     q = WGRAD_DEFER
     if not q:
         return
@@ -662,9 +679,14 @@ class _LayerNorm(torch.autograd.Function):
         inplace = _inplace(pg) and _inplace(pb)
         dg = pg.grad if inplace else torch.zeros(d, dtype=torch.float32, device=xc.device)
         db = pb.grad if inplace else torch.zeros(d, dtype=torch.float32, device=xc.device)
-        ws = torch.empty(_lib().evlm_layernorm_bwd_blocks(rows) * 2 * d, dtype=torch.float32, device=xc.device)
+        nblk = _lib().evlm_layernorm_bwd_blocks(rows)
+        ws = torch.empty(nblk * 2 * d, dtype=torch.float32, device=xc.device)
+        defer = inplace and WGRAD_DEFER is not None          # column sums reduced with the grouped weight gradients
+        if defer:
+            LN_DEFER.append((ws, nblk, d, dg, db))
         L.check(_lib().evlm_layernorm_bwd(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd),
-                                          rows, d, L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(ws), L.stream()), "layernorm_bwd")
+                                          rows, d, L.ptr(dx), None if defer else L.ptr(dg), None if defer else L.ptr(db),
+                                          L.ptr(ws), L.stream()), "layernorm_bwd")
         return (dx, None, None, None) if inplace else (dx, dg, db, None)
 
 
@@ -691,15 +713,20 @@ class _LayerNormFork(torch.autograd.Function):
         inplace = _inplace(pg) and _inplace(pb)
         dg = pg.grad if inplace else torch.zeros(d, dtype=torch.float32, device=xc.device)
         db = pb.grad if inplace else torch.zeros(d, dtype=torch.float32, device=xc.device)
-        ws = torch.empty(_lib().evlm_layernorm_bwd_blocks(rows) * 2 * d, dtype=torch.float32, device=xc.device)
+        nblk = _lib().evlm_layernorm_bwd_blocks(rows)
+        ws = torch.empty(nblk * 2 * d, dtype=torch.float32, device=xc.device)
+        defer = inplace and WGRAD_DEFER is not None          # column sums reduced with the grouped weight gradients
+        if defer:
+            LN_DEFER.append((ws, nblk, d, dg, db))
+        pdg, pdb = (None, None) if defer else (L.ptr(dg), L.ptr(db))
         if dres is not None:
             rc = dres if (dres.is_contiguous() and dres.dtype == xc.dtype) else dres.to(xc.dtype).contiguous()
             L.check(_lib().evlm_layernorm_bwd_add(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(rc), L.ptr(gamma.detach()), L.ptr(mean),
-                                                  L.ptr(rstd), rows, d, L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(ws), L.stream()),
+                                                  L.ptr(rstd), rows, d, L.ptr(dx), pdg, pdb, L.ptr(ws), L.stream()),
                     "layernorm_bwd_add")
         else:
             L.check(_lib().evlm_layernorm_bwd(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd),
-                                              rows, d, L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(ws), L.stream()), "layernorm_bwd")
+                                              rows, d, L.ptr(dx), pdg, pdb, L.ptr(ws), L.stream()), "layernorm_bwd")
         return (dx.view(ctx.xshape), None, None, None) if inplace else (dx.view(ctx.xshape), dg, db, None)
 
 

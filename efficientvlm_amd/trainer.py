@@ -224,6 +224,7 @@ class GDTrainer:
             finally:
                 ops.WGRAD_INPLACE = False
                 ops.WGRAD_DEFER = None
+                ops.LN_DEFER.clear()             # (empty after a flush; stale only when backward raised)
         if ops.DROPOUT_USED:              # p > 0 configurations: next step (next graph replay) draws new masks
             ops.dropout_tick(total.device)
         return torch.stack([total.detach().float(), S["loss"]["loss_itc"].detach().float(),
@@ -716,6 +717,7 @@ class ITRTrainer:
             finally:
                 ops.WGRAD_INPLACE = False
                 ops.WGRAD_DEFER = None
+                ops.LN_DEFER.clear()             # (empty after a flush; stale only when backward raised)
         self.reducer.reduce()
         self.opt.set_schedule(lr_mult)
         self.opt.step()
@@ -795,6 +797,7 @@ class VQATrainer:
             finally:
                 ops.WGRAD_INPLACE = False
                 ops.WGRAD_DEFER = None
+                ops.LN_DEFER.clear()             # (empty after a flush; stale only when backward raised)
         self.reducer.reduce()
         self.opt.set_schedule(lr_mult)
         self.opt.step()

@@ -120,6 +120,10 @@ int evlm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* ga
 int evlm_layernorm_bwd_add(int dtype, const void* dy, const void* x, const void* addend, const float* gamma,
                            const float* mean, const float* rstd, int rows, int d, void* dx, float* dgamma,
                            float* dbeta, float* partials, void* stream);
+/* dgamma == dbeta == NULL (workspace given): the per-block column sums stay in `partials`; reduce the workspaces of many
+ * LayerNorms at once with  table: device int64 [n][5] = {partials, blocks (evlm_layernorm_bwd_blocks(rows)), d, dgamma,
+ * dbeta}  (accumulated), d_max = largest d in the table. */
+int evlm_layernorm_bwd_reduce_grouped(const int64_t* table, int n_units, int d_max, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-head attention core with the probability map as an OUTPUT (the KD losses consume it).
