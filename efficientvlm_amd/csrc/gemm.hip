@@ -24,6 +24,8 @@ int evlm_gemm_pp256_launch(GemmP& g, int pt, int qt, hipStream_t stream);
 int evlm_gemm_pp256_splits(const GemmP& g);
 bool evlm_gemm_pp256_eligible(const GemmP& g, int pt, int qt);
 bool evlm_gemm_pp256_streamk(const GemmP& g, int pt);
+bool evlm_gemm_pp128_eligible(const GemmP& g, int pt, int qt);
+int evlm_gemm_pp128_launch(GemmP& g, int qt, hipStream_t stream);
 
 
 // =============================================================================================
@@ -834,6 +836,12 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
     // 55 % (tools/gemm_pp256.py), but the step keeps two streams busy (student + pipelined teacher), so CUs a launch
     // leaves free are taken by the other stream's kernels and the per-tile efficiency decides (measured: +1.3 % step)
     static const int pp_pct = getenv("EVLM_PP256_PCT") ? atoi(getenv("EVLM_PP256_PCT")) : 30;   // tuning aid; > 100 disables
+    if (evlm_gemm_pp128_eligible(g, pt, qt) && !evlm_gemm_pp256_streamk(g, pt)) {   // 128 x 256 tiles: thinly filled launches
+      if (evlm_gemm_pp128_launch(g, qt, stream)) return -1;
+      g_last_kernel = qt ? "gemm_bf16_pp128_kernel<true>" : "gemm_bf16_pp128_kernel<false>";
+      EVLM_LAUNCH_CHECK("evlm_gemm");
+      return 0;
+    }
     if (evlm_gemm_pp256_eligible(g, pt, qt)) {
       const int items = ceil_div(g.I, 256) * ceil_div(g.J, 256) * evlm_gemm_pp256_splits(g);
       if (items * 100 >= pp_pct * ceil_div(items, 256) * 256 || evlm_gemm_pp256_streamk(g, pt)) {

@@ -214,38 +214,41 @@ __device__ __forceinline__ PPSk pp_sk_high(const PPSk& sk) {      // the slot ad
   h.p0 = sk.p0 + 16384; h.np = sk.np;
   return h;
 }
-template <bool FULL, bool GATED, int XM, int ACT, int DACT, bool SKP>
+template <bool FULL, bool GATED, int XM, int ACT, int DACT, bool SKP, bool HI>
 __device__ __forceinline__ void pp_epi_c(const GemmP& g, f32x4 (&accL)[4][4], f32x4 (&accH)[4][4], const f32x4 (&bz)[4], int ib,
                                          int jb, int lane, char* sw, const PPSk& sk) {
   pp_epi_half<FULL, 2, GATED, XM, ACT, DACT, SKP>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc, sk);
-  pp_epi_half<FULL, 2, GATED, XM, ACT, DACT, SKP>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc,
-                                                  pp_sk_high(sk));
+  if (HI)
+    pp_epi_half<FULL, 2, GATED, XM, ACT, DACT, SKP>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc,
+                                                    pp_sk_high(sk));
 }
 
-template <bool FULL, bool SKP = false>
+// HI = false: the wave owns a 64 x 64 block only (128 x 256 tile flavour): accH is not touched
+template <bool FULL, bool SKP = false, bool HI = true>
 __device__ __forceinline__ void pp_epilogue(const GemmP& g, f32x4 (&accL)[4][4], f32x4 (&accH)[4][4], int ib, int jb, int lane,
                                             char* sw, const PPSk& sk = PPSk{nullptr, 0}) {
   f32x4 bz[4];
   pp_epi_cols<FULL>(g, jb, lane, bz);
   if (g.preact) {
     pp_epi_half<FULL, 1, false, 0, 0, 0, SKP>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx, sk);
-    pp_epi_half<FULL, 1, false, 0, 0, 0, SKP>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx,
-                                              pp_sk_high(sk));
+    if (HI)
+      pp_epi_half<FULL, 1, false, 0, 0, 0, SKP>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx,
+                                                pp_sk_high(sk));
   }
   // one instantiation per epilogue flavour (ONE wave-uniform dispatch per tile): the plain one carries neither gate nor
   // row registers, and every flavour of the training path has its activation code as a compile-time constant
   constexpr int G = EVLM_ACT_GELU, QG = EVLM_ACT_QUICK_GELU, N = EVLM_ACT_NONE;
   if (g.gate) {                      // L0-gated FFN (pruning fine-tune only): activation code read at run time
-    if (g.residual) pp_epi_c<FULL, true, 2, -1, N, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
-    else pp_epi_c<FULL, true, 0, -1, N, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
-  } else if (g.dact == G) pp_epi_c<FULL, false, 1, N, G, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
-  else if (g.dact == QG) pp_epi_c<FULL, false, 1, N, QG, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+    if (g.residual) pp_epi_c<FULL, true, 2, -1, N, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+    else pp_epi_c<FULL, true, 0, -1, N, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+  } else if (g.dact == G) pp_epi_c<FULL, false, 1, N, G, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+  else if (g.dact == QG) pp_epi_c<FULL, false, 1, N, QG, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
   else if (g.residual) {
-    if (g.act == N) pp_epi_c<FULL, false, 2, N, N, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
-    else pp_epi_c<FULL, false, 2, -1, N, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
-  } else if (g.act == G) pp_epi_c<FULL, false, 0, G, N, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
-  else if (g.act == QG) pp_epi_c<FULL, false, 0, QG, N, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
-  else pp_epi_c<FULL, false, 0, N, N, SKP>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+    if (g.act == N) pp_epi_c<FULL, false, 2, N, N, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+    else pp_epi_c<FULL, false, 2, -1, N, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+  } else if (g.act == G) pp_epi_c<FULL, false, 0, G, N, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+  else if (g.act == QG) pp_epi_c<FULL, false, 0, QG, N, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+  else pp_epi_c<FULL, false, 0, N, N, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
 }
 
 // weight gradients: f32 tile out of the same 4 KiB window, 16 rows x 64 columns at a time.  Plain 16-byte stores when the
@@ -616,6 +619,119 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
   }
 }
 
+// =============================================================================================
+// 128 x 256 tile flavour (gemm_bf16_pp128_kernel): for products whose 256 x 256 tiles would fill well under half of one
+// round of the chip (the 7 680-row text-side products x 768 columns: 90 tiles on 256 CUs).  Same eight waves in two
+// groups one barrier apart, same staging units and fragment reads, but a wave owns a 64 x 64 block: a K tile is TWO phases
+// (i x j-lo, i x j-hi), its three 16 KiB units (P: 128 rows; QL, QH) sit in one of THREE 48 KiB stages, each unit issued two
+// K tiles ahead (a four-phase lead).  One tile per workgroup (no persistence), so the epilogue windows alias stage 0.
+//   issue order   PL(t+2) QL(t+2) in phase A of K tile t, QH(t+2) in phase B
+//   waits         phase A: QH(t) landed   -> vmcnt(10)  [PL QL QH(t+1), PL QL(t+2) may be in flight];  6 / 0 in the tail
+//                 phase B: PL QL(t+1)     -> vmcnt(8)   [QH(t+1), PL QL QH(t+2)];                      2 in the tail
+// =============================================================================================
+#define PPH_STAGE (3 * PPU)
+#define HOFF_PL 0
+#define HOFF_QL PPU
+#define HOFF_QH (2 * PPU)
+template <bool QT>
+__device__ __forceinline__ void pp_src_half(const GemmP& g, int i0, int j0, int tid, int wave, PPSrc& s) {
+  const int lane = tid & 63;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int id = (c * 8 + wave) * 64 + lane;
+    {
+      const int u = id >> 3, cp = id & 7;
+      const int koff = (cp ^ ((u >> 1) & 7)) << 3;
+      s.pl[c] = (uint32_t)(min(i0 + u, g.I - 1) * g.ldp + koff) * 2u;       // unit row u IS tile row u
+      s.ph[c] = 0;
+      if (!QT) {
+        s.ql[c] = (uint32_t)(min(j0 + pp_qcol(u, 0), g.J - 1) * g.ldq + koff) * 2u;
+        s.qh[c] = (uint32_t)(min(j0 + pp_qcol(u, 1), g.J - 1) * g.ldq + koff) * 2u;
+      }
+    }
+    if (QT) {
+      const int kr = id >> 4, cp = id & 15;
+      const int u0 = (cp ^ pp_trswz(kr)) << 3;
+      const int lim = ((g.J + 7) & ~7) - 8;
+      s.ql[c] = (uint32_t)(kr * g.ldq + min(j0 + pp_qcol(u0, 0), lim)) * 2u;
+      s.qh[c] = (uint32_t)(kr * g.ldq + min(j0 + pp_qcol(u0, 1), lim)) * 2u;
+    }
+  }
+}
+
+#define PPH_KTILE(S, t)                                                                                    \
+  do {                                                                                                     \
+    constexpr int B0 = (S) * PPH_STAGE, B2 = (((S) + 2) % 3) * PPH_STAGE;                                  \
+    const bool n1 = (t) + 1 < nt, n2 = (t) + 2 < nt;                                                       \
+    /* ---- phase A: i x j-lo ; stage PL(t+2), QL(t+2) ---- */                                             \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
+      qf[a][0] = pp_frag<QT>(smem, B0 + HOFF_QL, qlb, a, 0);                                               \
+      qf[a][1] = pp_frag<QT>(smem, B0 + HOFF_QL, qlb, a, 1); }                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                        \
+      pf[b][0] = pp_frag<false>(smem, B0 + HOFF_PL, plb, b, 0);                                            \
+      pf[b][1] = pp_frag<false>(smem, B0 + HOFF_PL, plb, b, 1); }                                          \
+    if (n2) { PP_GLDS(Pk, src.pl, ((t) + 2) * kp, B2 + HOFF_PL); PP_GLDS(Qk, src.ql, ((t) + 2) * kq, B2 + HOFF_QL); } \
+    if (n2) PP_WAIT(10); else if (n1) PP_WAIT(6); else PP_WAIT(0);                                         \
+    PP_MFMA_BEGIN(); PP_QUAD(accL, 0, qf); PP_MFMA_END();                                                  \
+    /* ---- phase B: i x j-hi ; stage QH(t+2) ---- */                                                      \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
+      qf[a][0] = pp_frag<QT>(smem, B0 + HOFF_QH, qlb, a, 0);                                               \
+      qf[a][1] = pp_frag<QT>(smem, B0 + HOFF_QH, qlb, a, 1); }                                             \
+    if (n2) PP_GLDS(Qk, src.qh, ((t) + 2) * kq, B2 + HOFF_QH);                                             \
+    if (n2) PP_WAIT(8); else if (n1) PP_WAIT(2);                                                           \
+    PP_MFMA_BEGIN(); PP_QUAD(accL, 2, qf); PP_MFMA_END();                                                  \
+  } while (0)
+
+template <bool QT>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_pp128_kernel(GemmP g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 stages x 48 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nt = g.K >> 6;
+  int ti, tj;
+  pp_tile_ij(g, blockIdx.x, g.tiles_i * g.tiles_j, ti, tj);
+  const int i0 = ti * 128, j0 = tj * 256;
+  const int kp = 64, kq = QT ? 64 * g.ldq : 64;
+  const bf16* Pk = reinterpret_cast<const bf16*>(g.P);
+  const bf16* Qk = reinterpret_cast<const bf16*>(g.Q);
+  PPSrc src;
+  pp_src_half<QT>(g, i0, j0, tid, wave, src);
+  const int plb = pp_lane_base<false, true>(lane, wr), qlb = pp_lane_base<QT, false>(lane, wc);
+  f32x4 accL[4][4], accH[4][4];
+  bf16x8 pf[4][2], qf[2][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) accL[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // prologue: K tiles 0 and 1 (the host guarantees nt >= 2)
+  PP_GLDS(Pk, src.pl, 0, HOFF_PL); PP_GLDS(Qk, src.ql, 0, HOFF_QL); PP_GLDS(Qk, src.qh, 0, HOFF_QH);
+  PP_GLDS(Pk, src.pl, kp, PPH_STAGE + HOFF_PL); PP_GLDS(Qk, src.ql, kq, PPH_STAGE + HOFF_QL);
+  PP_GLDS(Qk, src.qh, kq, PPH_STAGE + HOFF_QH);
+  PP_WAIT(8);                                   // PL0, QL0 have landed (this wave's share)
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one barrier behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+  int t = 0;
+  for (; t + 2 < nt; t += 3) {
+    PPH_KTILE(0, t);
+    PPH_KTILE(1, t + 1);
+    PPH_KTILE(2, t + 2);
+  }
+  if (t < nt) PPH_KTILE(0, t);
+  if (t + 1 < nt) PPH_KTILE(1, t + 1);
+  if (wr == 0) __builtin_amdgcn_s_barrier();    // re-align the groups: every LDS read of the K loop has retired
+  __builtin_amdgcn_sched_barrier(0);
+  const int ib = i0 + wr * 64, jb = j0 + wc * 64;
+  const bool full = (i0 + 128 <= g.I) && (j0 + 256 <= g.J);
+  int tid_e = tid;
+  asm volatile("" : "+v"(tid_e));
+  const int lane_e = tid_e & 63;
+  char* swin = smem + wave * 4096;              // (stage 0 is dead: one tile per workgroup)
+  if (full) pp_epilogue<true, false, false>(g, accL, accH, ib, jb, lane_e, swin);
+  else pp_epilogue<false, false, false>(g, accL, accH, ib, jb, lane_e, swin);
+}
+
 template <bool PT, bool QT, int OUT>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
   pp256_body<PT, QT, OUT, false>(g, nullptr);
@@ -673,6 +789,37 @@ bool evlm_gemm_pp256_streamk(const GemmP& g, int pt) {
   if (!on || !g.sk_ws || g.c_f32 || pt) return false;
   const int tiles = ceil_div(g.I, 256) * ceil_div(g.J, 256), nt = g.K / 64;
   return nt % 2 == 0 && nt >= 8 && tiles >= 16 && tiles <= 200;
+}
+
+// 128 x 256 flavour: bf16 output, K-contiguous P, products whose 256 x 256 tiles fill less than ~40 % of one round
+bool evlm_gemm_pp128_eligible(const GemmP& g, int pt, int qt) {
+  static const int on = getenv("EVLM_PP128") ? atoi(getenv("EVLM_PP128")) : 1;
+  if (!on || pt || g.c_f32 || g.accumulate || g.psum) return false;
+  if (!evlm_gemm_pp256_eligible(g, pt, qt)) return false;
+  const int t256 = ceil_div(g.I, 256) * ceil_div(g.J, 256), t128 = ceil_div(g.I, 128) * ceil_div(g.J, 256);
+  // (measured, tools/step_gemm_breakdown.py: 180 half tiles - the 7 680-row products - gain 1.35-1.5x over 90 full tiles;
+  // 90 half tiles - the 3 840-row text pass - do not beat the 64 x 64 persistent kernel)
+  static const int tmin = getenv("EVLM_PP128_MIN") ? atoi(getenv("EVLM_PP128_MIN")) : 128;     // (tuning aid)
+  return t256 <= 100 && t128 >= tmin && t128 <= 256;
+}
+int evlm_gemm_pp128_launch(GemmP& g, int qt, hipStream_t stream) {
+  const int lds = 3 * PPH_STAGE;
+  g.tiles_i = ceil_div(g.I, 128); g.tiles_j = ceil_div(g.J, 256); g.bare_f32 = 0; g.sk = 0; g.kt_per_split = g.K / 64;
+  const dim3 grid(g.tiles_i * g.tiles_j), block(512);
+#define PP_LAUNCH_H(QT_)                                                                                      \
+  do {                                                                                                        \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set) {                                                                                          \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp128_kernel<QT_>),          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);                    \
+      if (e != hipSuccess) return evlm_set_error("evlm_gemm: cannot reserve 144 KiB LDS: %s", hipGetErrorString(e)); \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL((gemm_bf16_pp128_kernel<QT_>), grid, block, lds, stream, g);                           \
+  } while (0)
+  if (qt) PP_LAUNCH_H(true); else PP_LAUNCH_H(false);
+#undef PP_LAUNCH_H
+  return 0;
 }
 
 int evlm_gemm_pp256_launch(GemmP& g, int pt, int qt, hipStream_t stream) {
