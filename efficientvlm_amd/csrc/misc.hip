@@ -122,21 +122,29 @@ __global__ __launch_bounds__(256) void vit_embed_fwd_kernel(const T* __restrict_
     store8<T>(x + row * d + c * 8, v);
   }
 }
-// one block per token position n: dpos[n] += sum_b dx[b,n]; n==0 -> dcls too; n>=1 -> dtok copy
+// block (n, q): token position n, a quarter of the batch; a thread owns 8 channels (16-byte loads / stores):
+// dpos[n] += sum_b dx[b,n]; n==0 -> dcls too; n>=1 -> dtok copy.  (One 2-byte access per thread and a serial loop over the
+// whole batch - the first version - took 70 us on [64, 197, 768].)
 template <typename T>
-__global__ __launch_bounds__(256) void vit_embed_bwd_kernel(const T* __restrict__ dx, int B, int Tn, int d,
+__global__ __launch_bounds__(128) void vit_embed_bwd_kernel(const T* __restrict__ dx, int B, int Tn, int d,
                                                             T* __restrict__ dtok, float* __restrict__ dcls,
                                                             float* __restrict__ dpos) {
-  const int n = blockIdx.x, N = Tn + 1;
-  for (int j = threadIdx.x; j < d; j += blockDim.x) {
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const T g = dx[((size_t)b * N + n) * d + j];
-      acc += to_f(g);
-      if (n > 0) dtok[((size_t)b * Tn + n - 1) * d + j] = g;
+  const int n = blockIdx.x, N = Tn + 1, nq = gridDim.y;
+  const int b0 = (int)(((int64_t)B * blockIdx.y) / nq), b1 = (int)(((int64_t)B * (blockIdx.y + 1)) / nq);
+  for (int c = threadIdx.x; c < (d >> 3); c += blockDim.x) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = b0; b < b1; ++b) {
+      float v[8];
+      load8<T>(dx + ((size_t)b * N + n) * d + c * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      if (n > 0) store8<T>(dtok + ((size_t)b * Tn + n - 1) * d + c * 8, v);
     }
-    dpos[(size_t)n * d + j] += acc;
-    if (n == 0) dcls[j] += acc;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(dpos + (size_t)n * d + c * 8 + e, acc[e]);
+      if (n == 0) atomicAdd(dcls + c * 8 + e, acc[e]);
+    }
   }
 }
 extern "C" int evlm_vit_embed_fwd(int dtype, const void* tok, const float* cls, const float* pos, int B, int T_, int d,
@@ -153,9 +161,9 @@ extern "C" int evlm_vit_embed_fwd(int dtype, const void* tok, const float* cls, 
 extern "C" int evlm_vit_embed_bwd(int dtype, const void* dx, int B, int T_, int d, void* dtok, float* dcls, float* dpos,
                                   void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  EVLM_REQUIRE(dx && dtok && dcls && dpos, "evlm_vit_embed_bwd: bad args");
+  EVLM_REQUIRE(dx && dtok && dcls && dpos && d % 8 == 0, "evlm_vit_embed_bwd: bad args");
   EVLM_DISPATCH_DTYPE(dtype, "evlm_vit_embed_bwd",
-    hipLaunchKernelGGL((vit_embed_bwd_kernel<T>), dim3(T_ + 1), dim3(256), 0, stream, (const T*)dx, B, T_, d, (T*)dtok, dcls, dpos);)
+    hipLaunchKernelGGL((vit_embed_bwd_kernel<T>), dim3(T_ + 1, B >= 8 ? 4 : 1), dim3(128), 0, stream, (const T*)dx, B, T_, d, (T*)dtok, dcls, dpos);)
   EVLM_LAUNCH_CHECK("evlm_vit_embed_bwd");
   return 0;
 }
