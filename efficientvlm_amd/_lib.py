@@ -11,6 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVLM_LIB", os.path.join(_HERE, "libevlm_hip.so"))
 
+ABI_VERSION = 3      # evlm_abi_version() of the library this binding was written against (struct layouts, entry points)
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2
 GATE_PRE, GATE_POST = 0, 1
@@ -127,6 +128,9 @@ def load():
     lib.evlm_last_error.restype = C.c_char_p
     lib.evlm_abi_version.restype = _i
     lib.evlm_gemm_last_kernel.restype = C.c_char_p
+    if lib.evlm_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.evlm_abi_version()}, this package expects {ABI_VERSION}: "
+                           "rebuild it (`make -C efficientvlm_amd/csrc`)")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library drift
         fn.argtypes = argtypes
