@@ -26,6 +26,8 @@ bool evlm_gemm_pp256_eligible(const GemmP& g, int pt, int qt);
 bool evlm_gemm_pp256_streamk(const GemmP& g, int pt);
 bool evlm_gemm_pp128_eligible(const GemmP& g, int pt, int qt);
 int evlm_gemm_pp128_launch(GemmP& g, int qt, hipStream_t stream);
+bool evlm_gemm_pp192_eligible(const GemmP& g, int pt, int qt);
+int evlm_gemm_pp192_launch(GemmP& g, int qt, hipStream_t stream);
 
 
 // =============================================================================================
@@ -839,6 +841,12 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
     if (evlm_gemm_pp128_eligible(g, pt, qt) && !evlm_gemm_pp256_streamk(g, pt)) {   // 128 x 256 tiles: thinly filled launches
       if (evlm_gemm_pp128_launch(g, qt, stream)) return -1;
       g_last_kernel = qt ? "gemm_bf16_pp128_kernel<true>" : "gemm_bf16_pp128_kernel<false>";
+      EVLM_LAUNCH_CHECK("evlm_gemm");
+      return 0;
+    }
+    if (evlm_gemm_pp192_eligible(g, pt, qt) && !evlm_gemm_pp256_streamk(g, pt)) {   // 192 x 256 tiles: one round filled 50-80 %
+      if (evlm_gemm_pp192_launch(g, qt, stream)) return -1;
+      g_last_kernel = qt ? "gemm_bf16_pp192_kernel<true>" : "gemm_bf16_pp192_kernel<false>";
       EVLM_LAUNCH_CHECK("evlm_gemm");
       return 0;
     }

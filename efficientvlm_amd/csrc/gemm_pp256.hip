@@ -214,26 +214,40 @@ __device__ __forceinline__ PPSk pp_sk_high(const PPSk& sk) {      // the slot ad
   h.p0 = sk.p0 + 16384; h.np = sk.np;
   return h;
 }
-template <bool FULL, bool GATED, int XM, int ACT, int DACT, bool SKP, bool HI>
+// 32 more rows (i fragments 0, 1 of `acc`): the 192 x 256 tile flavour's third piece
+template <bool FULL, int MODE, bool GATED, int XM, int ACT, int DACT>
+__device__ __forceinline__ void pp_epi_third(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4],
+                                             int ib, int jb, int lane, char* sw, bf16* dst, int ldd) {
+  constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && XM == 2;
+  PPRows x0;
+  if (need_h || need_r) x0 = pp_epi_rows<FULL>(g, reinterpret_cast<const bf16*>(need_h ? g.aux : g.residual), ib, jb, lane);
+  pp_epi_chunk<FULL, MODE, GATED, XM, ACT, DACT, false>(g, acc, bz, 0, x0, ib, jb, lane, sw, dst, ldd, PPSk{nullptr, 0});
+}
+// HI: 0 = the wave owns 64 rows (accL), 1 = 128 rows (accL, accH), 2 = 96 rows (accL + i fragments 0, 1 of accH)
+template <bool FULL, bool GATED, int XM, int ACT, int DACT, bool SKP, int HI>
 __device__ __forceinline__ void pp_epi_c(const GemmP& g, f32x4 (&accL)[4][4], f32x4 (&accH)[4][4], const f32x4 (&bz)[4], int ib,
                                          int jb, int lane, char* sw, const PPSk& sk) {
   pp_epi_half<FULL, 2, GATED, XM, ACT, DACT, SKP>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc, sk);
-  if (HI)
+  if (HI == 1)
     pp_epi_half<FULL, 2, GATED, XM, ACT, DACT, SKP>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc,
                                                     pp_sk_high(sk));
+  if (HI == 2)
+    pp_epi_third<FULL, 2, GATED, XM, ACT, DACT>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
 }
 
-// HI = false: the wave owns a 64 x 64 block only (128 x 256 tile flavour): accH is not touched
-template <bool FULL, bool SKP = false, bool HI = true>
+// HI = 0: the wave owns a 64 x 64 block only (128 x 256 tile flavour: accH is not touched); 2: 96 x 64 (192 x 256 flavour)
+template <bool FULL, bool SKP = false, int HI = 1>
 __device__ __forceinline__ void pp_epilogue(const GemmP& g, f32x4 (&accL)[4][4], f32x4 (&accH)[4][4], int ib, int jb, int lane,
                                             char* sw, const PPSk& sk = PPSk{nullptr, 0}) {
   f32x4 bz[4];
   pp_epi_cols<FULL>(g, jb, lane, bz);
   if (g.preact) {
     pp_epi_half<FULL, 1, false, 0, 0, 0, SKP>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx, sk);
-    if (HI)
+    if (HI == 1)
       pp_epi_half<FULL, 1, false, 0, 0, 0, SKP>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx,
                                                 pp_sk_high(sk));
+    if (HI == 2)
+      pp_epi_third<FULL, 1, false, 0, 0, 0>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.preact), g.ldx);
   }
   // one instantiation per epilogue flavour (ONE wave-uniform dispatch per tile): the plain one carries neither gate nor
   // row registers, and every flavour of the training path has its activation code as a compile-time constant
@@ -728,8 +742,145 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp128_kernel(GemmP g) {
   asm volatile("" : "+v"(tid_e));
   const int lane_e = tid_e & 63;
   char* swin = smem + wave * 4096;              // (stage 0 is dead: one tile per workgroup)
-  if (full) pp_epilogue<true, false, false>(g, accL, accH, ib, jb, lane_e, swin);
-  else pp_epilogue<false, false, false>(g, accL, accH, ib, jb, lane_e, swin);
+  if (full) pp_epilogue<true, false, 0>(g, accL, accH, ib, jb, lane_e, swin);
+  else pp_epilogue<false, false, 0>(g, accL, accH, ib, jb, lane_e, swin);
+}
+
+// =============================================================================================
+// 192 x 256 tile flavour (gemm_bf16_pp192_kernel): for products whose 256 x 256 tiles fill 50-80 % of ONE round (the ViT's
+// 12 608 rows x 768 columns: 150 tiles -> 198; the 3 840-row text pass x 3 072 / 2 304: 180 / 135 -> 240 / 180).  A wave
+// owns a 96 x 64 block, a K tile is THREE phases of 16 MFMAs:  A  i[0..63] x j-lo,  B  i[0..63] x j-hi,  C  i[64..95] x
+// (j-lo, j-hi: both Q fragment sets are held from A / B).  Units per K tile: PL (2 x 64 rows, 16 KiB), PX (2 x 32 rows,
+// 8 KiB), QL, QH: 56 KiB, two stages.  Every unit is issued two K tiles - four phases - ahead, into the buffer its
+// predecessor was read out of one phase earlier:
+//   A(t): PX(t+1)            wait QH(t)          -> vmcnt(8)   [PX(t), PL QL QH(t+1), PX(t+1) may be in flight]
+//   B(t): PL(t+2), QL(t+2)   wait PX(t)          -> vmcnt(11)  [PL QL QH PX(t+1), PL QL(t+2)]
+//   C(t): QH(t+2)            wait PL(t+1) QL(t+1)-> vmcnt(9)   [QH PX(t+1), PL QL QH(t+2)]
+// One tile per workgroup: the epilogue windows alias stage 0.
+// =============================================================================================
+#define PPX_STAGE 57344
+#define XOFF_PL 0
+#define XOFF_PX 16384
+#define XOFF_QL 24576
+#define XOFF_QH 40960
+template <bool QT>
+__device__ __forceinline__ void pp_src_192(const GemmP& g, int i0, int j0, int tid, int wave, PPSrc& s) {
+  const int lane = tid & 63;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int id = (c * 8 + wave) * 64 + lane;
+    {
+      const int u = id >> 3, cp = id & 7;
+      const int koff = (cp ^ ((u >> 1) & 7)) << 3;
+      s.pl[c] = (uint32_t)(min(i0 + (u >> 6) * 96 + (u & 63), g.I - 1) * g.ldp + koff) * 2u;
+      // PX: 64 unit rows only (c = 0): unit row u -> tile row (u >> 5) * 96 + 64 + (u & 31)
+      s.ph[c] = (uint32_t)(min(i0 + ((u & 63) >> 5) * 96 + 64 + (u & 31), g.I - 1) * g.ldp + koff) * 2u;
+      if (!QT) {
+        s.ql[c] = (uint32_t)(min(j0 + pp_qcol(u, 0), g.J - 1) * g.ldq + koff) * 2u;
+        s.qh[c] = (uint32_t)(min(j0 + pp_qcol(u, 1), g.J - 1) * g.ldq + koff) * 2u;
+      }
+    }
+    if (QT) {
+      const int kr = id >> 4, cp = id & 15;
+      const int u0 = (cp ^ pp_trswz(kr)) << 3;
+      const int lim = ((g.J + 7) & ~7) - 8;
+      s.ql[c] = (uint32_t)(kr * g.ldq + min(j0 + pp_qcol(u0, 0), lim)) * 2u;
+      s.qh[c] = (uint32_t)(kr * g.ldq + min(j0 + pp_qcol(u0, 1), lim)) * 2u;
+    }
+  }
+}
+// one 8 KiB unit: ONE LDS-DMA instruction per wave
+#define PP_GLDS1(base, so, kel, ldsoff)                                                                             \
+  do {                                                                                                              \
+    const char* ub__ = reinterpret_cast<const char*>((base) + (size_t)(kel));                                       \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub__ + (so)[0]),               \
+                                     (__attribute__((address_space(3))) void*)(smem + (ldsoff) + wave * 1024), 16, 0, 0); \
+  } while (0)
+
+#define PPX_KTILE(BUF, t)                                                                                  \
+  do {                                                                                                     \
+    constexpr int B0 = (BUF) * PPX_STAGE, B1 = ((BUF) ^ 1) * PPX_STAGE;                                    \
+    const bool n1 = (t) + 1 < nt, n2 = (t) + 2 < nt;                                                       \
+    /* ---- phase A: i[0..63] x j-lo ; stage PX(t+1) ---- */                                               \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
+      qlo[a][0] = pp_frag<QT>(smem, B0 + XOFF_QL, qlb, a, 0);                                              \
+      qlo[a][1] = pp_frag<QT>(smem, B0 + XOFF_QL, qlb, a, 1); }                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                        \
+      pf[b][0] = pp_frag<false>(smem, B0 + XOFF_PL, plb, b, 0);                                            \
+      pf[b][1] = pp_frag<false>(smem, B0 + XOFF_PL, plb, b, 1); }                                          \
+    if (n1) PP_GLDS1(Pk, src.ph, ((t) + 1) * kp, B1 + XOFF_PX);                                            \
+    if (n1) PP_WAIT(8); else PP_WAIT(1);                                                                   \
+    PP_MFMA_BEGIN(); PP_QUAD(accL, 0, qlo); PP_MFMA_END();                                                 \
+    /* ---- phase B: i[0..63] x j-hi ; stage PL(t+2), QL(t+2) ---- */                                      \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
+      qhi[a][0] = pp_frag<QT>(smem, B0 + XOFF_QH, qlb, a, 0);                                              \
+      qhi[a][1] = pp_frag<QT>(smem, B0 + XOFF_QH, qlb, a, 1); }                                            \
+    if (n2) { PP_GLDS(Pk, src.pl, ((t) + 2) * kp, B0 + XOFF_PL); PP_GLDS(Qk, src.ql, ((t) + 2) * kq, B0 + XOFF_QL); } \
+    if (n2) PP_WAIT(11); else if (n1) PP_WAIT(7); else PP_WAIT(0);                                         \
+    PP_MFMA_BEGIN(); PP_QUAD(accL, 2, qhi); PP_MFMA_END();                                                 \
+    /* ---- phase C: i[64..95] x (j-lo, j-hi) ; stage QH(t+2) ---- */                                      \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                        \
+      px[b][0] = pp_frag<false>(smem, B0 + XOFF_PX, pxb, b, 0);                                            \
+      px[b][1] = pp_frag<false>(smem, B0 + XOFF_PX, pxb, b, 1); }                                          \
+    if (n2) PP_GLDS(Qk, src.qh, ((t) + 2) * kq, B0 + XOFF_QH);                                             \
+    if (n2) PP_WAIT(9); else if (n1) PP_WAIT(3);                                                           \
+    PP_MFMA_BEGIN();                                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                          \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                        \
+      accH[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qlo[a][ks], px[b][ks], accH[a][b], 0, 0, 0);    \
+      accH[2 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qhi[a][ks], px[b][ks], accH[2 + a][b], 0, 0, 0); } \
+    PP_MFMA_END();                                                                                         \
+  } while (0)
+
+template <bool QT>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_pp192_kernel(GemmP g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x 56 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nt = g.K >> 6;
+  int ti, tj;
+  pp_tile_ij(g, blockIdx.x, g.tiles_i * g.tiles_j, ti, tj);
+  const int i0 = ti * 192, j0 = tj * 256;
+  const int kp = 64, kq = QT ? 64 * g.ldq : 64;
+  const bf16* Pk = reinterpret_cast<const bf16*>(g.P);
+  const bf16* Qk = reinterpret_cast<const bf16*>(g.Q);
+  PPSrc src;
+  pp_src_192<QT>(g, i0, j0, tid, wave, src);
+  const int plb = pp_lane_base<false, true>(lane, wr), qlb = pp_lane_base<QT, false>(lane, wc);
+  const int pxb = pp_lane_base<false, false>(lane, wr);          // PX: 2 x 32 unit rows, as a Q unit's wave columns
+  f32x4 accL[4][4], accH[4][4];                                   // accH[.][0..1]: i fragments 4, 5
+  bf16x8 pf[4][2], px[2][2], qlo[2][2], qhi[2][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { accL[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; accH[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  // prologue: K tile 0 whole, K tile 1 without its PX (issued in phase A of tile 0); nt >= 2
+  PP_GLDS(Pk, src.pl, 0, XOFF_PL); PP_GLDS(Qk, src.ql, 0, XOFF_QL); PP_GLDS(Qk, src.qh, 0, XOFF_QH);
+  PP_GLDS1(Pk, src.ph, 0, XOFF_PX);
+  PP_GLDS(Pk, src.pl, kp, PPX_STAGE + XOFF_PL); PP_GLDS(Qk, src.ql, kq, PPX_STAGE + XOFF_QL);
+  PP_GLDS(Qk, src.qh, kq, PPX_STAGE + XOFF_QH);
+  PP_WAIT(9);                                   // PL0, QL0 have landed (this wave's share)
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one barrier behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    PPX_KTILE(0, t);
+    PPX_KTILE(1, t + 1);
+  }
+  if (t < nt) PPX_KTILE(0, t);
+  if (wr == 0) __builtin_amdgcn_s_barrier();    // re-align the groups: every LDS read of the K loop has retired
+  __builtin_amdgcn_sched_barrier(0);
+  const int ib = i0 + wr * 96, jb = j0 + wc * 64;
+  const bool full = (i0 + 192 <= g.I) && (j0 + 256 <= g.J);
+  int tid_e = tid;
+  asm volatile("" : "+v"(tid_e));
+  const int lane_e = tid_e & 63;
+  char* swin = smem + wave * 4096;              // (stage 0 is dead: one tile per workgroup)
+  if (full) pp_epilogue<true, false, 2>(g, accL, accH, ib, jb, lane_e, swin);
+  else pp_epilogue<false, false, 2>(g, accL, accH, ib, jb, lane_e, swin);
 }
 
 template <bool PT, bool QT, int OUT>
@@ -819,6 +970,34 @@ int evlm_gemm_pp128_launch(GemmP& g, int qt, hipStream_t stream) {
   } while (0)
   if (qt) PP_LAUNCH_H(true); else PP_LAUNCH_H(false);
 #undef PP_LAUNCH_H
+  return 0;
+}
+
+// 192 x 256 flavour: one round of 256 x 256 tiles filled 50-80 %, and 192-row tiles still fit one round
+bool evlm_gemm_pp192_eligible(const GemmP& g, int pt, int qt) {
+  static const int on = getenv("EVLM_PP192") ? atoi(getenv("EVLM_PP192")) : 1;
+  if (!on || pt || g.c_f32 || g.accumulate || g.psum) return false;
+  if (!evlm_gemm_pp256_eligible(g, pt, qt)) return false;
+  const int t256 = ceil_div(g.I, 256) * ceil_div(g.J, 256), t192 = ceil_div(g.I, 192) * ceil_div(g.J, 256);
+  return t256 > 100 && t256 <= 200 && t192 <= 256 && t192 * 10 >= t256 * 12;
+}
+int evlm_gemm_pp192_launch(GemmP& g, int qt, hipStream_t stream) {
+  const int lds = 2 * PPX_STAGE;
+  g.tiles_i = ceil_div(g.I, 192); g.tiles_j = ceil_div(g.J, 256); g.bare_f32 = 0; g.sk = 0; g.kt_per_split = g.K / 64;
+  const dim3 grid(g.tiles_i * g.tiles_j), block(512);
+#define PP_LAUNCH_X(QT_)                                                                                      \
+  do {                                                                                                        \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set) {                                                                                          \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp192_kernel<QT_>),          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);                    \
+      if (e != hipSuccess) return evlm_set_error("evlm_gemm: cannot reserve 112 KiB LDS: %s", hipGetErrorString(e)); \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL((gemm_bf16_pp192_kernel<QT_>), grid, block, lds, stream, g);                           \
+  } while (0)
+  if (qt) PP_LAUNCH_X(true); else PP_LAUNCH_X(false);
+#undef PP_LAUNCH_X
   return 0;
 }
 

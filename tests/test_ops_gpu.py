@@ -582,7 +582,7 @@ def test_fused_cross_attention_forward_is_bit_identical_to_the_two_launch_path(B
     assert not o.xattn_fusable(q.clone().requires_grad_(True), x, (Wk, Wv), H, dh)
 
 
-def _pp256_case(o, L, g, I, J, K, qt=0, bias=False, res=False, act=0, dact=0, sk=False, half=False):
+def _pp256_case(o, L, g, I, J, K, qt=0, bias=False, res=False, act=0, dact=0, sk=False, half=False, x192=False):
     dtype = torch.bfloat16
     Pm = rnd((I, K), dtype, g, 0.5)
     Qm = rnd((K, J) if qt else (J, K), dtype, g, 0.1)
@@ -601,8 +601,8 @@ def _pp256_case(o, L, g, I, J, K, qt=0, bias=False, res=False, act=0, dact=0, sk
     # the case must have been served by the kernel it is meant to test (a routing change would otherwise test another one)
     served = L.load().evlm_gemm_last_kernel().decode()
     qts = "true" if qt else "false"
-    want = f"gemm_bf16_pp256_sk_kernel<{qts}>" if sk else (f"gemm_bf16_pp128_kernel<{qts}>" if half else
-                                                             f"gemm_bf16_pp256_kernel<false,{qts},0>")
+    want = (f"gemm_bf16_pp256_sk_kernel<{qts}>" if sk else f"gemm_bf16_pp128_kernel<{qts}>" if half else
+            f"gemm_bf16_pp192_kernel<{qts}>" if x192 else f"gemm_bf16_pp256_kernel<false,{qts},0>")
     assert served == want, (served, want)
     ref = Pm.float() @ (Qm.float() if qt else Qm.float().t())
     if bias:
@@ -638,9 +638,7 @@ def test_gemm_pp256_persistent_tiles_and_epilogues():
     _pp256_case(o, L, g, 4096, 4096, 256, dact=L.ACT_QUICK_GELU)
     _pp256_case(o, L, g, 4096 + 8, 4096, 192, dact=L.ACT_GELU)                   # text-side FFN backward (erf-GELU), ragged rows
     _pp256_case(o, L, g, 4096, 4096 + 16, 192, qt=1, dact=L.ACT_GELU)
-    _pp256_case(o, L, g, 12608, 768, 768, bias=True, res=True)                   # the ViT out-projection shape (150 tiles)
     _pp256_case(o, L, g, 4096 + 24, 4096, 192, qt=1)                             # dX = dY W, W reduction-major
-    _pp256_case(o, L, g, 12608, 768, 2304, qt=1)
     _pp256_case(o, L, g, 12608, 2304, 768)                                       # ViT QKV: 450 tiles, 1.76 rounds
 
 
@@ -661,6 +659,25 @@ def test_gemm_pp128_half_tiles_for_thinly_filled_launches():
     _pp256_case(o, L, g, 6000, 1024, 320, dact=L.ACT_QUICK_GELU, half=True)      # 5 K tiles
     _pp256_case(o, L, g, 12288, 512, 448, bias=True, res=True, half=True)        # 192 half tiles, 7 K tiles
     _pp256_case(o, L, g, 16384, 256, 384, bias=True, half=True)                  # one tile column, 6 K tiles
+
+
+def test_gemm_pp192_tiles_for_part_filled_rounds():
+    """gemm_bf16_pp192_kernel (192 x 256 tiles, three-phase K tile, 96 x 64 wave blocks): products whose 256 x 256 tiles
+    fill 50-80 % of one round.  Step shapes, ragged rows / columns, odd / even / minimal K-tile counts, each epilogue
+    flavour (incl. the pre-activation second output), both Q layouts"""
+    o = ops()
+    from efficientvlm_amd import _lib as L
+    g = torch.Generator().manual_seed(67)
+    _pp256_case(o, L, g, 12608, 768, 768, bias=True, res=True, x192=True)        # ViT out-projection: 150 -> 198 tiles
+    _pp256_case(o, L, g, 12608, 768, 3072, bias=True, res=True, x192=True)       # ViT FC2
+    _pp256_case(o, L, g, 12608, 768, 2304, qt=1, x192=True)                      # dX of the QKV projection
+    _pp256_case(o, L, g, 12608, 768, 3072, qt=1, dact=L.ACT_QUICK_GELU, x192=True)
+    _pp256_case(o, L, g, 3840, 3072, 768, bias=True, act=L.ACT_GELU, x192=True)  # text FC1: 180 -> 240 tiles, pre-activation
+    _pp256_case(o, L, g, 3840, 2304, 768, bias=True, x192=True)
+    _pp256_case(o, L, g, 12544, 768, 768, bias=True, x192=True)
+    _pp256_case(o, L, g, 9000 + 8, 1024 + 16, 128, bias=True, x192=True)         # ragged both ways, 2 K tiles
+    _pp256_case(o, L, g, 9000, 1024, 192, bias=True, act=L.ACT_QUICK_GELU, x192=True)    # 3 K tiles
+    _pp256_case(o, L, g, 9000, 1024, 320, dact=L.ACT_GELU, x192=True)            # 5 K tiles
 
 
 def _stream_k_cases():
