@@ -979,7 +979,13 @@ bool evlm_gemm_pp192_eligible(const GemmP& g, int pt, int qt) {
   if (!on || pt || g.c_f32 || g.accumulate || g.psum) return false;
   if (!evlm_gemm_pp256_eligible(g, pt, qt)) return false;
   const int t256 = ceil_div(g.I, 256) * ceil_div(g.J, 256), t192 = ceil_div(g.I, 192) * ceil_div(g.J, 256);
-  return t256 > 100 && t256 <= 200 && t192 <= 256 && t192 * 10 >= t256 * 12;
+  if (t256 <= 100) return false;
+  const int r256 = ceil_div(t256, 256), r192 = ceil_div(t192, 256);
+  if (r256 == 1) return t256 <= 200 && t192 <= 256 && t192 * 10 >= t256 * 12;
+  // several rounds: a 192-row tile costs ~0.85 of a 256-row one (measured), so it pays when it does not add a round -
+  // 270 / 300 / 360 tiles (1.05-1.4 rounds, run as 2) become 360 / 396 / 480 (2 rounds of cheaper tiles)
+  static const int multi = getenv("EVLM_PP192_MULTI") ? atoi(getenv("EVLM_PP192_MULTI")) : 1;
+  return multi && r192 * 85 < r256 * 100;
 }
 int evlm_gemm_pp192_launch(GemmP& g, int qt, hipStream_t stream) {
   const int lds = 2 * PPX_STAGE;

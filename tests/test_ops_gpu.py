@@ -675,6 +675,8 @@ def test_gemm_pp192_tiles_for_part_filled_rounds():
     _pp256_case(o, L, g, 3840, 3072, 768, bias=True, act=L.ACT_GELU, x192=True)  # text FC1: 180 -> 240 tiles, pre-activation
     _pp256_case(o, L, g, 3840, 2304, 768, bias=True, x192=True)
     _pp256_case(o, L, g, 12544, 768, 768, bias=True, x192=True)
+    _pp256_case(o, L, g, 7680, 2304, 768, bias=True, x192=True)                  # 270 full tiles (1.05 rounds) -> 360: two rounds
+    _pp256_case(o, L, g, 12608, 1536, 768, bias=True, res=True, x192=True)       # 300 -> 396
     _pp256_case(o, L, g, 9000 + 8, 1024 + 16, 128, bias=True, x192=True)         # ragged both ways, 2 K tiles
     _pp256_case(o, L, g, 9000, 1024, 192, bias=True, act=L.ACT_QUICK_GELU, x192=True)    # 3 K tiles
     _pp256_case(o, L, g, 9000, 1024, 320, dact=L.ACT_GELU, x192=True)            # 5 K tiles
