@@ -631,14 +631,14 @@ def test_gemm_pp256_persistent_tiles_and_epilogues():
     o = ops()
     from efficientvlm_amd import _lib as L
     g = torch.Generator().manual_seed(47)
-    _pp256_case(o, L, g, 4096 + 40, 4096 + 8, 192, bias=True)                    # 289 tiles: 2 per workgroup, ragged edges
+    _pp256_case(o, L, g, 6144 + 40, 4096 + 8, 192, bias=True)                    # 425 tiles: 2 per workgroup, ragged edges
     _pp256_case(o, L, g, 5120, 3072, 128, bias=True, res=True)                   # 240 tiles, minimal K (2 K tiles)
     _pp256_case(o, L, g, 6144, 2560, 320, bias=True, act=L.ACT_QUICK_GELU)       # pre-activation second output, odd K tiles
-    _pp256_case(o, L, g, 4100, 4096, 256, bias=True, act=L.ACT_GELU)
+    _pp256_case(o, L, g, 6148, 4096, 256, bias=True, act=L.ACT_GELU)
     _pp256_case(o, L, g, 4096, 4096, 256, dact=L.ACT_QUICK_GELU)
-    _pp256_case(o, L, g, 4096 + 8, 4096, 192, dact=L.ACT_GELU)                   # text-side FFN backward (erf-GELU), ragged rows
-    _pp256_case(o, L, g, 4096, 4096 + 16, 192, qt=1, dact=L.ACT_GELU)
-    _pp256_case(o, L, g, 4096 + 24, 4096, 192, qt=1)                             # dX = dY W, W reduction-major
+    _pp256_case(o, L, g, 6144 + 8, 4096, 192, dact=L.ACT_GELU)                   # text-side FFN backward (erf-GELU), ragged rows
+    _pp256_case(o, L, g, 6144, 4096 + 16, 192, qt=1, dact=L.ACT_GELU)
+    _pp256_case(o, L, g, 6144 + 24, 4096, 192, qt=1)                             # dX = dY W, W reduction-major
     _pp256_case(o, L, g, 12608, 2304, 768)                                       # ViT QKV: 450 tiles, 1.76 rounds
 
 
