@@ -307,7 +307,10 @@ def test_benchmarked_configuration_matches_the_oracle(B):
     served = {}
     for rec in recs:
         served[rec[-1]] = served.get(rec[-1], 0) + 1
-    assert served.get("gemm_bf16_pp256_kernel<false,false,0>", 0) >= 150, served
+    # (the three tile flavours of the ping-pong GEMM - 256 / 192 / 128 rows, picked per shape - serve the large products)
+    pp = {k: served.get(k, 0) for k in ("gemm_bf16_pp256_kernel<false,false,0>", "gemm_bf16_pp192_kernel<false>",
+                                        "gemm_bf16_pp128_kernel<false>")}
+    assert sum(pp.values()) >= 190 and all(v >= 30 for v in pp.values()), served
     assert served.get("gemm_bf16_pp256_grouped_kernel", 0) >= 2, served
 
 
