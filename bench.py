@@ -271,6 +271,14 @@ def roofline_leg(trainer, batch):
             "all_gemm_kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
                                      "time_ms": round(v[2] * 1e3, 3)} for k, v in groups.items()},
             "all_gemm_tflops": round(allfl / alltm / 1e12, 1), "gemm_time_ms_per_step": round(alltm * 1e3, 2)}
+    # the ping-pong GEMM in its three tile flavours (256 / 192 / 128 rows, one picked per shape) taken together: the
+    # same 203 forward / dX products that round 1 served with the 256-row kernel alone
+    fam = [v for k, v in groups.items() if k.startswith(("gemm_bf16_pp256_kernel", "gemm_bf16_pp192_kernel",
+                                                          "gemm_bf16_pp128_kernel"))]
+    if fam:
+        ffl, ftm = sum(v[1] for v in fam), sum(v[2] for v in fam)
+        roof["pingpong_family"] = {"launches": sum(v[0] for v in fam), "tflops": round(ffl / ftm / 1e12, 1),
+                                   "frac": round(ffl / ftm / 1e12 / PEAK_BF16_TFLOPS, 4), "time_ms": round(ftm * 1e3, 3)}
     return roof, all_fl + attn_flops
 
 
