@@ -403,6 +403,7 @@ class GDTrainer:
         for name, v in batch.items():
             pipe["B"][p][name].copy_(v, non_blocking=True)
         out = None
+        done = False                              # both halves of this call issued (joint graph / graph segments)?
         if self.use_graph and not self.reducer.active and self._pending is not None:
             # single GPU: ONE hipGraph per (waiting batch, new batch) combination holds both halves - the teacher forward
             # of the new batch forked onto the side stream, the student step of the waiting batch on the capture stream,
@@ -421,15 +422,25 @@ class GDTrainer:
                 jg = self._joint[key] = (g, res, self.last_kd)
             jg[0].replay()
             out, self.last_kd = jg[1], jg[2]
+            done = True
         elif (self.use_graph and self.reducer.active and self._pending is not None
-              and not os.environ.get("EVLM_NO_SEGMENT_GRAPHS")):
+              and not os.environ.get("EVLM_NO_SEGMENT_GRAPHS") and not getattr(self, "_segments_broken", False)):
             # multi-GPU: hipGraph segments around the collectives; the new batch's teacher forward is forked onto the side
             # stream INSIDE the longest segment (as in the single-GPU joint graph: two separately launched graphs overlap
             # only when their start times happen to line up - measured 19 vs 24 ms from run to run)
             pp, pk = self._pending
             self.opt.set_schedule(lr_mult)
-            out = self._student_segmented(pipe, p, pp, pk)
-        else:
+            try:
+                out = self._student_segmented(pipe, p, pp, pk)
+                done = True
+            except RuntimeError as e:             # a capture this stack refuses: same kernels launched one by one from here on
+                import sys
+                print(f"[efficientvlm_amd] hipGraph segments of the multi-GPU student step failed ({e}); "
+                      "the student step stays eager", file=sys.stderr)
+                self._segments_broken = True
+                self._seg.clear()
+                torch.cuda.synchronize()
+        if not done:
             side.wait_stream(cur)                 # inputs copied; every earlier reader of this parity's buffers is done
             with torch.cuda.stream(side):
                 if pipe["tgraphs"] is not None:
