@@ -846,6 +846,7 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
     *handled = 1;
     return 0;
   }
+  if (!f.dS) return evlm_set_error("evlm_attention_bwd: the two-kernel path needs the dS workspace");
   if (a->Lk <= 32) launch_bwd_dq<2>(f, stream);
   else if (a->Lk <= 64) launch_bwd_dq<4>(f, stream);
   else if (a->Lk <= 224) launch_bwd_dq<14>(f, stream);

@@ -822,7 +822,11 @@ class _Attention(torch.autograd.Function):
         assert ldq == (3 * d if self_attn else d) and ldk == (3 * d if self_attn else 2 * d), "packed buffers must be exact"
         dqbuf = torch.empty_like(qbuf)                       # the kernels write every element of the packed grads
         dkvbuf = dqbuf if self_attn else torch.empty_like(kvbuf)
-        dS = torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev)
+        # dS workspace of the two-kernel path; the single-pass kernel (self-attention problems that fit one workgroup,
+        # attention_mfma.hip) keeps dS in LDS and takes none
+        single_pass = (tdt == torch.bfloat16 and dh == 64 and kv_index is None and Lq <= 224 and Lk <= 224
+                       and ctx.drop is None and os.environ.get("EVLM_ATTN_BWD_SPLIT", "0") in ("", "0"))
+        dS = None if single_pass else torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev)
         dgate = torch.zeros(H, dtype=torch.float32, device=dev) if g32 is not None else None
         a = L.AttnBwdArgs(dtype=L.dt(tdt), p_dtype=L.dt(tdt), B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, Bkv=Bkv, ldq=ldq, ldk=ldk, ldv=ldk,
                           ldo=H * dh, lddq=ldq, lddk=ldk, lddv=ldk, ldpr=Lkp,

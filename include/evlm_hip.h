@@ -165,7 +165,8 @@ int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream);
 
 /* backward: given dO and (optionally) an external gradient dP_ext on the probability map (from the
  * attention-map KD loss), produce dQ, dK, dV (+ dgate[H] accumulated, f32).  dS ([B,H,Lq,Lk], dtype) is a
- * caller-provided workspace.  With kv_index (several query batches sharing one K/V row: the image tokens of the
+ * caller-provided workspace; it may be NULL for bf16 self-attention problems (no kv_index, head dim 64, no dropout) with
+ * Lq, Lk <= 224, which run in one pass with dS kept in LDS (any other problem then fails with an error, never a fault).  With kv_index (several query batches sharing one K/V row: the image tokens of the
  * positive, hard-negative and MLM fusion passes) dK/dV are [Bkv,Lk,H,dh]: the bf16 MFMA path sums the sharing query
  * batches inside one workgroup per K/V row (deterministic); the generic path ACCUMULATES with f32 atomics and then
  * expects dK/dV to be caller-zeroed f32 buffers. */
