@@ -63,13 +63,15 @@ def make_trainer(student, teacher, dtype, use_graph, pipelined):
 # CPU legs (child processes that never touch the GPU): the reported CPU baseline and the oracle side of the loss check
 # ---------------------------------------------------------------------------------------------------------------------
 def _cpu_threads():
-    """threads the CPU legs may use: the cores this process is actually allowed on, capped at 32 (an oversubscribed
-    torch thread pool on a quota-limited container is slower than a few threads)"""
+    """threads the CPU legs use: every core this process is allowed on (all host cores; EVLM_CPU_THREADS
+    overrides, e.g. on a quota-limited container whose affinity mask is wider than its CPU quota)"""
+    if os.environ.get("EVLM_CPU_THREADS"):
+        return max(1, int(os.environ["EVLM_CPU_THREADS"]))
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(n, 32))
+    return max(1, n)
 
 
 def _cpu_model():
@@ -100,9 +102,10 @@ def _tie(sd):
     return sd
 
 
-def cpu_baseline_child(budget_s=30.0):
+def cpu_baseline_child(budget_s=60.0):
     """oracle (kind='port') GD step, fp32, on the host cores: BASELINE.json configs[0] (batch 4), 3 warm-up + 5 timed steps
-    (SURVEY.md §8d), then batch 16 while the time budget lasts.  Prints one JSON object."""
+    (SURVEY.md §8d), then batch 16 with the same 3 + 5 steps (cut short only if the time budget runs out: the sample
+    string says how many were timed).  Prints one JSON object."""
     from oracle import synth
     from oracle import xvlm_oracle as O
     nthreads = _cpu_threads()
@@ -137,10 +140,10 @@ def cpu_baseline_child(budget_s=30.0):
            "sample": f"BASELINE configs[0]: GD step of batch 4 (224x224, 30 tokens), fp32, oracle/xvlm_oracle.py on "
                      f"{nthreads} host threads, 3 warm-up + {len(t4)} timed steps, median {med4:.2f} s"}
     if time.time() - t_start < budget_s * 0.6:
-        t16 = run(16, 1, 2, t_start + budget_s)
+        t16 = run(16, 3, 5, t_start + budget_s)
         med16 = sorted(t16)[len(t16) // 2]
         res["batch16"] = {"value": round(16 / med16, 3), "unit": "pairs/s",
-                          "sample": f"1 warm-up + {len(t16)} timed steps of batch 16, median {med16:.2f} s"}
+                          "sample": f"3 warm-up + {len(t16)} timed steps of batch 16, median {med16:.2f} s"}
     print(json.dumps(res), flush=True)
 
 
@@ -180,8 +183,8 @@ def cpu_baseline():
 def oracle_check(geom, dev, dtype, B, use_graph):
     """one step of the BENCHMARKED configuration (compute dtype, hipGraph replay, pipelined teacher, batch B) on fresh
     models, with the hard negatives injected on both sides, against the fp32 CPU oracle on the same weights and batch.
-    bf16 tolerance: 3e-2 relative on every loss (tests/test_step_gpu.py holds the same configuration to the oracle in
-    more detail: KD terms and gradients)."""
+    bf16 tolerance: 1e-3 relative on every loss (measured 1e-5 ... 2e-4; tests/test_step_gpu.py holds the same
+    configuration to the oracle in more detail: KD terms and gradients)."""
     from efficientvlm_amd.workload import make_batch
     student, teacher = build(geom, dev, SEED + 1)
     s_sd = {k: v.detach().float().cpu().clone() for k, v in student.state_dict().items() if torch.is_floating_point(v)}
@@ -204,7 +207,7 @@ def oracle_check(geom, dev, dtype, B, use_graph):
         ref, err = _run_child("--oracle-check-child", (path,), timeout_s=400)
     if ref is None:
         return {"ok": None, "error": err, "hip": got}
-    tol = 3e-2 if dtype == torch.bfloat16 else 1e-4
+    tol = 1e-3 if dtype == torch.bfloat16 else 1e-4
     rel = {k: abs(got[k] - ref[k]) / max(abs(ref[k]), 1e-12) for k in ref}
     return {"ok": all(v <= tol for v in rel.values()), "tolerance_rel": tol, "batch": B,
             "path": f"GDTrainer({str(dtype).split('.')[-1]}, use_graph={use_graph}, pipeline_teacher=True), injected negatives",

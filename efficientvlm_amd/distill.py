@@ -265,9 +265,12 @@ def gd_forward(student, teacher, batch, temperature=1.0, overlap_teacher=False, 
         enc = fuse_image_map_kd(student, teacher_out, batch)
         try:
             S, T = call(student), teacher_out
-        finally:
-            if enc is not None:
-                fused = collect_fused_kd(enc)
+        except BaseException:
+            if enc is not None:                # disarm the encoder; the forward's own exception is the one to report
+                enc.kd_teacher_maps = enc.kd_fused = None
+            raise
+        if enc is not None:
+            fused = collect_fused_kd(enc)      # (validates the terms: only after a forward that completed)
     else:
         S, T = student_and_teacher(lambda: call(student), lambda: call(teacher), batch["image"], overlap_teacher)
     kd = kd_terms(S, T, temperature, fused=fused)

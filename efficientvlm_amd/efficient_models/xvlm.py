@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops
-from ..runtime import BertConfig, read_json
+from ..runtime import BertConfig, log_collective, read_json
 from .eff_bert import BertForMaskedLM, BertModel
 from .eff_vit import CLIPVisionTransformer
 
@@ -63,6 +63,7 @@ class AllGather(torch.autograd.Function):
         if GATHER_HOOK is not None:          # a trainer that captures the step in hipGraph SEGMENTS around its collectives
             GATHER_HOOK(output, src)
         else:
+            log_collective("all_gather", src)
             dist.all_gather(output, src)
         ctx.rank = rank
         ctx.batch_size = tensor.shape[0]

@@ -888,30 +888,36 @@ def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True, 
     return _Attention.apply(q, kv, mask, gate, H, dh, 0, 0, d, scale, want_probs, kv_index, False, dropout_p)[:2]
 
 
-_PIN_POOL, _PIN_USED = None, 0
+_PIN_CHUNKS, _PIN_USED = [], 0            # pinned int64 chunks (every one stays alive: captured memcpy nodes read them)
+_PIN_CHUNK_WORDS = 1 << 17                # 1 MiB each: ~700 tables of 45 copies
 
 
-def _pin_pool():
-    global _PIN_POOL
-    if _PIN_POOL is None:
-        _PIN_POOL = torch.empty(1 << 17, dtype=torch.int64).pin_memory()      # 1 MiB: ~700 tables of 45 copies
-    return _PIN_POOL
+def reserve_tables(min_words=1 << 14):
+    """make sure the pinned table pool has `min_words` free int64 words - call OUTSIDE a hipGraph capture, before one
+    starts (pinning memory is not capturable; a capture consumes a few KiB of tables and the words are never reclaimed,
+    because the graph's memcpy nodes keep reading them).  Grows the pool by another chunk when the current one is short."""
+    global _PIN_USED
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("reserve_tables() inside a hipGraph capture")
+    if not _PIN_CHUNKS or _PIN_USED + min_words > _PIN_CHUNKS[-1].numel():
+        _PIN_CHUNKS.append(torch.empty(max(_PIN_CHUNK_WORDS, min_words), dtype=torch.int64).pin_memory())
+        _PIN_USED = 0
 
 
 def _upload_table(rows, dev):
     """flat list of int64 -> device tensor.  Inside a hipGraph capture the table goes up as a memcpy node out of a PINNED
-    block that is never rewritten (a slice of a pool allocated outside any capture: pinning memory is not capturable)."""
+    block that is never rewritten (a slice of a pool chunk allocated outside any capture, see reserve_tables)."""
     global _PIN_USED
     if torch.cuda.is_current_stream_capturing():
-        if _PIN_POOL is None or _PIN_USED + len(rows) > _PIN_POOL.numel():
-            raise RuntimeError("pinned table pool missing / exhausted (run one eager step before capturing)")
-        host = _PIN_POOL[_PIN_USED:_PIN_USED + len(rows)]
+        if not _PIN_CHUNKS or _PIN_USED + len(rows) > _PIN_CHUNKS[-1].numel():
+            raise RuntimeError("pinned table pool missing / exhausted (ops.reserve_tables() before the capture starts)")
+        host = _PIN_CHUNKS[-1][_PIN_USED:_PIN_USED + len(rows)]
         _PIN_USED += len(rows)
         host.copy_(torch.tensor(rows, dtype=torch.int64))
         table = torch.empty(len(rows), dtype=torch.int64, device=dev)
         table.copy_(host, non_blocking=True)
         return table
-    _pin_pool()
+    reserve_tables()
     return torch.tensor(rows, dtype=torch.int64).to(dev)
 
 

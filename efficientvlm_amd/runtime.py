@@ -30,6 +30,14 @@ def compute(dtype):
         _STATE["dtype"] = old
 
 
+COLLECTIVES = None      # tests: set to a list -> every collective of a step is appended as (kind, numel, dtype)
+
+
+def log_collective(kind, tensor):
+    if COLLECTIVES is not None:
+        COLLECTIVES.append((kind, int(tensor.numel()), str(tensor.dtype)))
+
+
 def read_json(rpath):
     """utils/__init__.py read_json (plain local file; the reference's HDFS branch is out of scope)."""
     if isinstance(rpath, dict):

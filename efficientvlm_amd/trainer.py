@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 from . import distill, ops
 from .optim import FlatAdamW
-from .runtime import compute
+from .runtime import compute, log_collective
 
 
 def dist_ready():
@@ -29,22 +29,26 @@ def dist_ready():
 class GradReducer:
     """mean all-reduce of flat gradient slabs in <= bucket_bytes pieces on a dedicated stream.
 
-    Works on any backend (RCCL on GPU, gloo in the CPU tests).  `compress` = torch.bfloat16 halves the wire bytes
-    (the slabs stay fp32: cast -> all-reduce -> cast back).
+    Works on any backend (RCCL on GPU, gloo in the CPU tests).  The wire carries fp32 by default - what the reference's
+    DDP wrappers reduce (apex_ddp_accelerator.py:87, Eff_Retrieval.py:449).  `compress` = torch.bfloat16 is an OPT-IN that
+    halves the wire bytes (the slabs stay fp32: divide by world in fp32 -> cast -> sum all-reduce -> cast back); its error
+    against the fp32 wire is bounded in tests/test_dp_cpu.py.
 
-    Overlap with backward: the image encoder's parameters form one range of each slab, so `reduce_async(early)` (the
-    rest: text / fusion encoder and heads, optim.FlatAdamW.grad_segments) can be launched
-    from a tensor hook the moment backward crosses into the image encoder (every text / fusion / head gradient is then
-    enqueued) and runs on the side stream under the ViT backward; `reduce_async(late)` + `finish()` follow after
-    backward.  Few, large messages: xGMI is point-to-point, rings are per-link bound."""
+    Overlap with backward: the slab ranges of a layer group are handed to `reduce_async` the moment backward has
+    finished with the group (GDTrainer: tensor hooks in the eager step, cuts between hipGraph segments in the captured
+    one); the collectives run on the side stream under the rest of backward, `finish()` joins them before the optimiser.
+    Few, large messages: xGMI is point-to-point, rings are per-link bound."""
 
     def __init__(self, flat_grads, bucket_bytes=64 << 20, compress=None, group=None, force=False):
         self.flat = list(flat_grads)
         self.group = group
         self.compress = compress
         self.bucket_bytes = bucket_bytes
-        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
+        ready = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if ready else 1
+        self.active = self.world > 1 or (force and ready)
+        # RCCL averages in the collective itself (one pass over the slabs less); gloo has no AVG
+        self.native_avg = bool(ready and dist.get_backend(group) == "nccl" and hasattr(dist.ReduceOp, "AVG"))
         self.buckets = self._buckets(self.flat)
         self.stream = torch.cuda.Stream() if (self.flat and self.flat[0].is_cuda) else None
         self._pending = []
@@ -69,13 +73,18 @@ class GradReducer:
             ctx = contextlib.nullcontext()
         with ctx:
             for b in self._buckets(tensors):
-                if self.compress is not None and b.is_cuda:
-                    w = ops.cast(b, self.compress)
-                    w.div_(self.world)
+                if self.compress is not None:
+                    b.mul_(1.0 / self.world)                  # the mean's division in fp32, before the cast
+                    w = b.to(self.compress)
+                    log_collective("all_reduce", w)
                     dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
                     b.copy_(w)
+                elif self.native_avg:
+                    log_collective("all_reduce", b)
+                    self._pending.append(dist.all_reduce(b, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
                 else:
                     b.div_(self.world)
+                    log_collective("all_reduce", b)
                     self._pending.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
@@ -150,23 +159,30 @@ class GDTrainer:
         student.train()
         self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=max_grad_norm)
         force = bool(os.environ.get("EVLM_FORCE_REDUCE"))
-        if (grad_compress is None and dtype == torch.bfloat16 and (dist_ready() or force)
-                and not os.environ.get("EVLM_FP32_WIRE")):
-            grad_compress = torch.bfloat16           # bf16 runs: bf16 on the wire too (xGMI rings are per-link bound)
+        if grad_compress is None and dtype == torch.bfloat16 and os.environ.get("EVLM_BF16_WIRE"):
+            grad_compress = torch.bfloat16           # opt-in: bf16 on the wire (default: fp32, as the reference's DDP)
         self.reducer = GradReducer(self.opt.flat_grads, compress=grad_compress, force=force)
         self.world = self.reducer.world
-        self._early, self._late = self.opt.grad_segments()
-        self._early_sent = False
-        self._vit_segments, self._vit_sent = [], 0
-        self._defer_reduce, self._seg, self._seg_pool, self._cap_stream = False, {}, None, None
+        # Gradient exchange overlapped with backward.  `_stages` = slab ranges in the order backward completes them; stage
+        # i < last is sent from a hook the moment it is complete, the last one after backward:
+        #   "vision": text / fusion encoder + heads, complete when backward enters the image encoder (tensor hook on the
+        #             ViT output; the autograd engine runs every text-side node - created later - before any ViT node);
+        #   ("vit", b): ViT layers >= b, hook on the input of layer b (6 layers: {4,5} + post-norm, then {2,3});
+        #   last: layers {0,1} + embeddings.
+        # EVLM_DP_CUTS = all (default) | vit | vision | none drops hook points (their ranges ride with the next stage).
+        # The eager step sends from the hooks; the captured step (hipGraph segments) CUTS its capture at the same points,
+        # so both issue the same collective sequence.
+        self._stages, self._sent, self._cut = [list(self.opt.flat_grads)], 0, None
+        self._seg, self._seg_pool, self._cap_stream = {}, None, None
         if self.reducer.active and hasattr(student, "on_vision_grad"):
-            student.on_vision_grad = self._on_vision_grad      # fires when backward enters the image encoder
+            which = os.environ.get("EVLM_DP_CUTS", "all")
+            early, late = self.opt.grad_segments()
+            points = [("vision", early)]
             enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
-            if enc is not None and hasattr(enc, "grad_hooks") and len(enc.layers) >= 4:
-                # the image-encoder slab goes out in three pieces while its backward is still running: a hook on the input
-                # of layer b fires when layers >= b are done (their queued weight gradients are flushed first)
+            vit_hooks = enc is not None and hasattr(enc, "grad_hooks") and len(enc.layers) >= 4
+            if vit_hooks:
                 n = len(enc.layers)
-                cuts = [n - n // 3, n - 2 * (n // 3)]              # 6 layers: hooks at 4 and 2 -> {4,5}, {2,3}, {0,1}+embeddings
+                cuts = [n - n // 3, n - 2 * (n // 3)]              # 6 layers: hooks at 4 and 2
                 layer_of = lambda nme: int(nme.split("encoder.layers.")[1].split(".")[0]) if "encoder.layers." in nme else None
                 in_vit = lambda nme: nme.startswith("vision_encoder.")
                 hi = n
@@ -174,12 +190,32 @@ class GDTrainer:
                     pred = (lambda lo_, hi_: lambda nme: in_vit(nme) and (
                         (layer_of(nme) is not None and lo_ <= layer_of(nme) < hi_) or
                         (hi_ == n and layer_of(nme) is None and "post_layernorm" in nme)))(b, hi)
-                    self._vit_segments.append(self.opt.grad_ranges(pred))
+                    points.append((("vit", b), self.opt.grad_ranges(pred)))
                     hi = b
                 rest = (lambda hi_: lambda nme: in_vit(nme) and not (
                     (layer_of(nme) is not None and layer_of(nme) >= hi_) or (layer_of(nme) is None and "post_layernorm" in nme)))(hi)
-                self._vit_segments.append(self.opt.grad_ranges(rest))      # sent after backward
-                enc.grad_hooks = {b: (lambda k: lambda: self._on_vit_layers_done(k))(k) for k, b in enumerate(cuts)}
+                points.append((None, self.opt.grad_ranges(rest)))
+            else:
+                points.append((None, late))
+            active = {"all": lambda k: True, "vit": lambda k: k != "vision", "vision": lambda k: k == "vision",
+                      "none": lambda k: False}[which]
+            stages, hooks, carry = [], [], []
+            for key, ranges in points:
+                carry = carry + list(ranges)
+                if key is None or active(key):
+                    stages.append(carry)
+                    hooks.append(key)
+                    carry = []
+            self._stages = stages
+            student.on_vision_grad = None
+            if vit_hooks:
+                enc.grad_hooks = {}
+            for i, key in enumerate(hooks[:-1]):
+                cb = (lambda i_: lambda: self._stage_done(i_))(i)
+                if key == "vision":
+                    student.on_vision_grad = cb
+                else:
+                    enc.grad_hooks[key[1]] = cb
         self.use_graph = use_graph
         self.wgrad_inplace = True
         if not os.environ.get("EVLM_TEACHER_ALL_MAPS"):
@@ -231,38 +267,29 @@ class GDTrainer:
                             S["loss"]["loss_itm"].detach().float(), S["loss"]["loss_mlm"].detach().float(),
                             mix["loss_kd"].detach().float()])
 
-    def _on_vision_grad(self):
-        """tensor hook on the ViT output: text / fusion / head gradients are all enqueued -> reduce them under the ViT
-        backward"""
-        if self._defer_reduce:            # segmented-graph step: no collective inside the captured backward
-            return
-        if not self._early_sent:
-            self._early_sent = True
-            ops.flush_wgrad()                 # the queued text / fusion weight gradients must be in the slabs first
-            self.reducer.reduce_async(self._early)
+    def _stage_done(self, i):
+        """tensor hook: backward has finished with gradient stage i (see __init__) - send it under the rest of backward"""
+        if self._sent == i:
+            self._send(self._stages[i])
+            self._sent = i + 1
 
-    def _on_vit_layers_done(self, k):
-        """tensor hook inside the image encoder: ViT segment k (layers >= its cut) is complete"""
-        if self._defer_reduce:
-            return
-        if self._early_sent and self._vit_sent == k:
-            ops.flush_wgrad()
-            self.reducer.reduce_async(self._vit_segments[k])
-            self._vit_sent = k + 1
+    def _send(self, ranges):
+        ops.flush_wgrad()                 # the queued weight gradients of the stage must be in the slabs first
+        if self._cut is not None:         # capture pass of the segmented step: the graph segment ends here
+            self._cut(ranges)
+        else:
+            self.reducer.reduce_async(ranges)
 
     def _reduce_rest(self):
-        """what backward has not sent from its hooks: the remaining image-encoder segments (or everything)"""
-        if not self._early_sent:
-            self.reducer.reduce_async(self.opt.flat_grads)
-        elif self._vit_segments:
-            for k in range(self._vit_sent, len(self._vit_segments)):
-                self.reducer.reduce_async(self._vit_segments[k])
-        else:
-            self.reducer.reduce_async(self._late)
-        self.reducer.finish()
+        """what backward has not sent from its hooks (the last stage; everything when no hook fired)"""
+        for i in range(self._sent, len(self._stages)):
+            self._send(self._stages[i])
+        self._sent = len(self._stages)
+        if self._cut is None:
+            self.reducer.finish()
 
     def _step_eager(self, batch, teacher_out=None):
-        self._early_sent, self._vit_sent = False, 0
+        self._sent = 0
         out = self._forward_backward(batch, teacher_out)
         if self.reducer.active:
             self._reduce_rest()
@@ -321,6 +348,7 @@ class GDTrainer:
         if self.use_graph and self.reducer.active and not os.environ.get("EVLM_NO_TEACHER_GRAPH"):
             # the frozen teacher's forward holds no collective (skip_task_losses): capturable on multi-GPU runs too
             side.wait_stream(cur)
+            ops.reserve_tables()
             tg = []
             try:
                 for k in (0, 1):
@@ -383,12 +411,7 @@ class GDTrainer:
 
     def _student_eager(self, pipe, k):
         """student forward + backward on (batch k, teacher outputs k), gradient reduction, optimiser step"""
-        self._early_sent, self._vit_sent = False, 0
-        out = self._forward_backward(pipe["B"][k], pipe["T"][k])
-        if self.reducer.active:
-            self._reduce_rest()
-        self.opt.step()
-        return out
+        return self._step_eager(pipe["B"][k], pipe["T"][k])
 
     def _step_pipelined(self, batch, lr_mult):
         """teacher forward of `batch` on the side stream || student step on the batch of the previous call; returns the
@@ -415,6 +438,7 @@ class GDTrainer:
             jg = self._joint.get(key)
             if jg is None:
                 ops.CACHE.invalidate()                             # capture the casts of the trainable weights too
+                ops.reserve_tables()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=self._spool):
                     res = self._joint_body(pipe, p, pp, pk)
@@ -426,20 +450,20 @@ class GDTrainer:
         elif (self.use_graph and self.reducer.active and self._pending is not None
               and not os.environ.get("EVLM_NO_SEGMENT_GRAPHS") and not getattr(self, "_segments_broken", False)):
             # multi-GPU: hipGraph segments around the collectives; the new batch's teacher forward is forked onto the side
-            # stream INSIDE the longest segment (as in the single-GPU joint graph: two separately launched graphs overlap
-            # only when their start times happen to line up - measured 19 vs 24 ms from run to run)
+            # stream INSIDE a segment (as in the single-GPU joint graph), or - EVLM_SEG_TEACHER=graph - replays as its
+            # own graph on the side stream beside the segments
             pp, pk = self._pending
             self.opt.set_schedule(lr_mult)
-            try:
-                out = self._student_segmented(pipe, p, pp, pk)
+            own_graph = os.environ.get("EVLM_SEG_TEACHER", "fork") == "graph" and pipe["tgraphs"] is not None
+            if own_graph:
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    pipe["tgraphs"][p].replay()
+            out = self._student_segmented(None if own_graph else pipe, p, pp, pk)
+            done = out is not None
+            if not done and own_graph:            # (the fallback below must not run the teacher a second time)
+                out = self._student_eager(pp, pk)
                 done = True
-            except RuntimeError as e:             # a capture this stack refuses: same kernels launched one by one from here on
-                import sys
-                print(f"[efficientvlm_amd] hipGraph segments of the multi-GPU student step failed ({e}); "
-                      "the student step stays eager", file=sys.stderr)
-                self._segments_broken = True
-                self._seg.clear()
-                torch.cuda.synchronize()
         if not done:
             side.wait_stream(cur)                 # inputs copied; every earlier reader of this parity's buffers is done
             with torch.cuda.stream(side):
@@ -449,27 +473,33 @@ class GDTrainer:
                     self._teacher_eager(pipe, p)
             if self._pending is not None:
                 pp, pk = self._pending
-                self.opt.set_schedule(lr_mult)
+                if not self.opt._scheduled:       # (a segmented attempt that fell back has staged this step already)
+                    self.opt.set_schedule(lr_mult)
                 out = self._student_eager(pp, pk)
         self._pending = (pipe, p)
         return out
 
     # ---- multi-GPU: the student step as hipGraph SEGMENTS around its collectives --------------------------------------
-    # RCCL collectives cannot be captured on this stack, and an eager step costs the host ~1 100 launches (20+ ms: more than
-    # the GPU needs).  So the step is captured as a chain: [graph: forward up to the ITC feature gather] all_gather (eager)
-    # [graph: rest of the forward, the whole backward, the grouped weight gradients] all-reduce of the gradient slabs (eager,
-    # bf16 on the wire, on the side stream) [graph: clip + AdamW].  The capture is cut INSIDE the model's forward by
-    # efficient_models.xvlm.GATHER_HOOK, which the ITC all-gather calls instead of dist.all_gather.  The gradient exchange
-    # is not overlapped with backward in this form (a capture cannot be cut from an autograd hook): at 240 MB of bf16
-    # gradients over xGMI that is ~1-3 ms per step against ~5 ms of host-bound launch time saved.
+    # RCCL collectives cannot be captured on this stack, and an eager step costs the host ~1 100 launches (more time than
+    # the GPU needs).  So the step is captured as a chain of graphs with the collectives issued eagerly between them:
+    #   [forward up to the ITC feature gather] all_gather [rest of the forward, backward of heads / fusion / text layers]
+    #   all-reduce(stage 0) [ViT layers 5,4 backward] all-reduce(stage 1) [layers 3,2] all-reduce(stage 2) [layers 1,0,
+    #   embeddings, last grouped weight gradients] all-reduce(stage 3) [clip + AdamW]
+    # Every all-reduce runs on the reducer's stream while the NEXT graph segment replays on the main stream: the exchange
+    # is overlapped with backward exactly as in the eager step, and both forms issue the same collective sequence.  The
+    # capture is cut inside the model's forward by efficient_models.xvlm.GATHER_HOOK (which the ITC all-gather calls
+    # instead of dist.all_gather) and inside backward by the gradient-stage hooks (_stage_done -> _send -> _cut): the
+    # capture pass runs autograd single-threaded, so a hook ends / begins captures on the thread that started them.
     def _capture_segments(self, tpipe, tp, pipe, k):
-        """segments of: student step on (pipe, k) with the teacher forward of (tpipe, tp) forked beside its longest part"""
+        """segments of: student step on (pipe, k); with `tpipe` the teacher forward of (tpipe, tp) is forked onto the side
+        stream in the segment behind the ITC gather and joins where that segment ends"""
         from .efficient_models import xvlm as X
         if self._cap_stream is None:
             self._cap_stream, self._seg_pool = torch.cuda.Stream(), torch.cuda.graph_pool_handle()
         cur, cs, side = torch.cuda.current_stream(), self._cap_stream, self._side
+        ops.reserve_tables()
         torch.cuda.synchronize()
-        segs, state = [], {"g": None, "forked": False}
+        segs, state = [], {"g": None, "forked": tpipe is None, "joined": tpipe is None}
 
         def fork_teacher():
             side.wait_stream(cs)
@@ -483,6 +513,9 @@ class GDTrainer:
             state["g"].capture_begin(pool=self._seg_pool, capture_error_mode="thread_local")
 
         def end():
+            if state["forked"] and not state["joined"]:
+                cs.wait_stream(side)                 # the teacher branch joins before its segment ends
+                state["joined"] = True
             state["g"].capture_end()
             segs.append(("graph", state["g"]))
             state["g"] = None
@@ -493,23 +526,28 @@ class GDTrainer:
             end()
             segs.append(("gather", (out_list, src)))
             begin()
-            if not state["forked"]:                  # the segment behind the ITC gather: rest of forward + whole backward
+            if not state["forked"]:
                 fork_teacher()
+
+        def cut(ranges):
+            if not state["forked"]:                  # (no gather cut the forward: single-rank group without the forced gather)
+                fork_teacher()
+            end()
+            segs.append(("reduce", ranges))
+            begin()
 
         ops.CACHE.invalidate()
         cs.wait_stream(cur)
-        self._defer_reduce = True
+        self._cut = cut
         try:
-            with torch.cuda.stream(cs):
+            with torch.cuda.stream(cs), torch.autograd.set_multithreading_enabled(False):
                 X.GATHER_HOOK = gather
                 try:
                     begin()
-                    if not (dist_ready() or os.environ.get("EVLM_FORCE_REDUCE")):
-                        fork_teacher()                   # (no gather will cut the capture: fork at once)
+                    self._sent = 0
                     out = self._forward_backward(pipe["B"][k], pipe["T"][k])
-                    if not state["forked"]:
-                        fork_teacher()
-                    cs.wait_stream(side)                 # the teacher branch joins before its segment ends
+                    self._reduce_rest()                  # the remaining stages: one cut each
+                    self.opt.step()                      # clip + AdamW: the segment behind the last all-reduce
                     end()
                 finally:
                     X.GATHER_HOOK = None
@@ -519,31 +557,55 @@ class GDTrainer:
                         except RuntimeError:
                             pass
                 kd = self.last_kd
-                gopt = torch.cuda.CUDAGraph()
-                gopt.capture_begin(pool=self._seg_pool, capture_error_mode="thread_local")
-                self.opt.step()
-                gopt.capture_end()
         finally:
-            self._defer_reduce = False
+            self._cut = None
         cur.wait_stream(cs)
         torch.cuda.synchronize()
-        return dict(segs=segs, opt=gopt, out=out, kd=kd)
+        last_reduce = [item for kind, item in segs if kind == "reduce"][-1]
+        return dict(segs=segs, out=out, kd=kd, last_reduce=last_reduce)
+
+    def _ranks_agree(self, ok):
+        """did the capture succeed on EVERY rank?  (MIN all-reduce of the local flag: a rank that fell back to the eager
+        step alone would issue a different collective sequence than its peers replaying segments - a hang)"""
+        if not dist_ready():
+            return ok
+        flag = torch.tensor([1.0 if ok else 0.0], device=self.opt.gnorm_sq.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
 
     def _student_segmented(self, tpipe, tp, pipe, k):
+        """replay (capture on first use) the segmented student step; returns None when the capture failed on ANY rank -
+        every rank then runs the eager step from here on"""
         key = (id(tpipe), tp, id(pipe), k)
         sg = self._seg.get(key)
         if sg is None:
             scheduled = self.opt._scheduled
-            sg = self._seg[key] = self._capture_segments(tpipe, tp, pipe, k)
+            err = None
+            try:
+                sg = self._capture_segments(tpipe, tp, pipe, k)
+            except RuntimeError as e:             # a capture this stack refuses
+                err, sg = e, None
+                torch.cuda.synchronize()
             self.opt._scheduled = scheduled              # the captured optimiser step consumed the flag, not the schedule
+            if not self._ranks_agree(sg is not None):
+                import sys
+                print(f"[efficientvlm_amd] hipGraph segments of the multi-GPU student step failed "
+                      f"({err if err is not None else 'on another rank'}); the student step stays eager on every rank",
+                      file=sys.stderr)
+                self._segments_broken = True
+                self._seg.clear()
+                return None
+            self._seg[key] = sg
         for kind, item in sg["segs"]:
             if kind == "graph":
                 item.replay()
-            else:
+            elif kind == "gather":
+                log_collective("all_gather", item[1])
                 dist.all_gather(item[0], item[1])
-        self.reducer.reduce_async(self.opt.flat_grads)
-        self.reducer.finish()
-        sg["opt"].replay()
+            else:
+                self.reducer.reduce_async(item)          # side stream; the next segment replays beside it
+                if item is sg["last_reduce"]:
+                    self.reducer.finish()                # ... except the optimiser segment, which needs every gradient
         self.opt._scheduled = False
         self.last_kd = sg["kd"]
         return sg["out"]
@@ -593,6 +655,7 @@ class GDTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ops.CACHE.invalidate()                             # capture the casts of the trainable weights too
+        ops.reserve_tables()
         self.opt.set_schedule(0.0)                         # (the captured optimiser step reads the staged scalars at replay)
         graph = torch.cuda.CUDAGraph()
         pool = next(iter(self._graphs.values()))[0].pool() if self._graphs else None   # the kinds never run concurrently
@@ -628,6 +691,7 @@ class TeacherPrefetch:
             with torch.cuda.stream(self.side):
                 self.run_teacher(st["B"][0])                   # warm-up: allocator, cached weight casts
             torch.cuda.synchronize()
+            ops.reserve_tables()
             st["graphs"] = []
             for k in (0, 1):
                 g = torch.cuda.CUDAGraph()

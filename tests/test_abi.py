@@ -45,6 +45,19 @@ def test_struct_layout_matches_header():
         assert fields == [f[0] for f in st._fields_], cname
 
 
+def test_integration_doc_struct_matches_the_binding():
+    """the GemmArgs example in INTEGRATION.md (what a maintainer would paste) has the fields of the shipped binding, in
+    order and with the same ctypes: a struct one field short makes the library read past it"""
+    import ctypes as C
+    from efficientvlm_amd import _lib
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"class GemmArgs\(C\.Structure\):.*?_fields_ = \[(.*?)\]\n", doc, flags=re.S).group(1)
+    fields = re.findall(r'\("([a-zA-Z_0-9]+)",\s*C\.([a-z_0-9]+)\)', block)
+    assert [f for f, _ in fields] == [f[0] for f in _lib.GemmArgs._fields_]
+    for (name, ty), (_, want) in zip(fields, _lib.GemmArgs._fields_):
+        assert getattr(C, ty) is want, name
+
+
 def test_ops_refuse_cpu_tensors():
     from efficientvlm_amd import ops
     x = torch.randn(4, 8)

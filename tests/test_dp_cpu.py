@@ -237,37 +237,76 @@ def test_parameter_broadcast_aligns_differently_seeded_replicas():
 
 
 def _segments_case(rank, world):
-    """GDTrainer at world 2 (CPU tensors, gloo): the gradient slabs are cut into the text / fusion / head part (sent when
-    backward enters the image encoder), two image-encoder layer groups (sent from hooks inside its backward) and the rest
-    (sent after backward) - together they must cover every gradient element exactly once"""
+    """GDTrainer at world 2 (CPU tensors, gloo): the gradient slabs are cut into STAGES in the order backward completes
+    them - the text / fusion / head part (sent when backward enters the image encoder), two image-encoder layer groups
+    (sent from hooks inside its backward) and the rest (sent after backward); together they must cover every gradient
+    element exactly once, for every EVLM_DP_CUTS setting (a dropped hook point's ranges ride with the next stage)"""
     from efficientvlm_amd.models.model_pretrain import XVLM
     from efficientvlm_amd.trainer import GDTrainer
     from efficientvlm_amd.workload import GEOMS, model_config
     torch.manual_seed(5 + rank)
     geom = GEOMS["tiny"]
-    student, teacher = XVLM(model_config(geom, "s")), XVLM(model_config(geom, "t"))
-    tr = GDTrainer(student, teacher, dtype=torch.float32, use_graph=False)
-    assert tr.reducer.active and len(tr._vit_segments) == 3
-    enc = student.vision_encoder.encoder
-    assert sorted(enc.grad_hooks) == [2, 4]
-    for g in tr.opt.flat_grads:
-        g.zero_()
-    for seg in [tr._early] + tr._vit_segments:
-        for v in seg:
-            v.add_(1.0)
-    covered_once = all(bool((g == 1.0).all()) for g in tr.opt.flat_grads)
-    # the slabs' padding words (segments are rounded up to 8 elements) are covered too, so == 1 everywhere
-    names = {n: p for n, p in student.named_parameters()}
-    p45 = names["vision_encoder.encoder.layers.5.mlp.fc1.weight"].grad
-    p01 = names["vision_encoder.encoder.layers.0.mlp.fc1.weight"].grad
-    inside = lambda t, seg: any(v.data_ptr() <= t.data_ptr() < v.data_ptr() + v.numel() * 4 for v in seg)
-    order_ok = inside(p45, tr._vit_segments[0]) and inside(p01, tr._vit_segments[2]) and not inside(p01, tr._vit_segments[0])
-    # replicas were built from different seeds: after construction they hold rank 0's parameters
-    flat = torch.cat([g["p"] for g in tr.opt.groups])
-    return covered_once, order_ok, flat.clone()
+    res = {}
+    for which, n_stages, hooks, vision in (("all", 4, [2, 4], True), ("vit", 3, [2, 4], False), ("vision", 2, [], True),
+                                           ("none", 1, [], False)):
+        os.environ["EVLM_DP_CUTS"] = which
+        student, teacher = XVLM(model_config(geom, "s")), XVLM(model_config(geom, "t"))
+        tr = GDTrainer(student, teacher, dtype=torch.float32, use_graph=False)
+        ok = tr.reducer.active and len(tr._stages) == n_stages
+        enc = student.vision_encoder.encoder
+        ok = ok and sorted(enc.grad_hooks or {}) == hooks and (student.on_vision_grad is not None) == vision
+        for g in tr.opt.flat_grads:
+            g.zero_()
+        for seg in tr._stages:
+            for v in seg:
+                v.add_(1.0)
+        # the slabs' padding words (segments are rounded up to 8 elements) are covered too, so == 1 everywhere
+        ok = ok and all(bool((g == 1.0).all()) for g in tr.opt.flat_grads)
+        if which == "all":
+            names = {n: p for n, p in student.named_parameters()}
+            p45 = names["vision_encoder.encoder.layers.5.mlp.fc1.weight"].grad
+            p01 = names["vision_encoder.encoder.layers.0.mlp.fc1.weight"].grad
+            ptx = names["text_encoder.bert.encoder.layer.0.output.dense.weight"].grad
+            inside = lambda t, seg: any(v.data_ptr() <= t.data_ptr() < v.data_ptr() + v.numel() * 4 for v in seg)
+            ok = ok and (inside(ptx, tr._stages[0]) and inside(p45, tr._stages[1]) and inside(p01, tr._stages[3])
+                         and not inside(p01, tr._stages[1]))
+            # replicas were built from different seeds: after construction they hold rank 0's parameters
+            res["flat"] = torch.cat([g["p"] for g in tr.opt.groups]).clone()
+        res[which] = bool(ok)
+    os.environ.pop("EVLM_DP_CUTS", None)
+    return res
 
 
-def test_trainer_gradient_segments_partition_the_slabs_and_replicas_start_equal():
-    (c0, o0, f0), (c1, o1, f1) = run2(_segments_case)
-    assert c0 and c1 and o0 and o1
-    assert torch.equal(f0, f1)
+def test_trainer_gradient_stages_partition_the_slabs_and_replicas_start_equal():
+    r0, r1 = run2(_segments_case)
+    for which in ("all", "vit", "vision", "none"):
+        assert r0[which] and r1[which], which
+    assert torch.equal(r0["flat"], r1["flat"])
+
+
+def _wire_case(rank, world):
+    """the opt-in bf16 wire (GradReducer(compress=torch.bfloat16)) against the default fp32 wire on the same gradients:
+    the mean's division happens in fp32 before the cast, so every rank's contribution carries ONE bf16 rounding and the
+    two-rank sum one more"""
+    from efficientvlm_amd.trainer import GradReducer
+    g = torch.Generator().manual_seed(77)
+    base = torch.randn(20000, generator=g) * torch.logspace(-6, 2, 20000)       # gradients span 8 decades
+    mine = base * (1.0 + 0.37 * rank) + 0.01 * rank
+    a, b = [mine.clone()], [mine.clone()]
+    GradReducer(a, bucket_bytes=1 << 14).reduce()
+    GradReducer(b, bucket_bytes=1 << 14, compress=torch.bfloat16).reduce()
+    exact = (base * 2.37 + 0.01) / 2.0
+    err32 = float((a[0] - exact).abs().max() / exact.abs().max())
+    mag = (base.abs() + (base * 1.37 + 0.01).abs()) / 2.0                       # sum of the |contributions| (no cancellation)
+    rel = (b[0] - a[0]).abs() / mag.clamp_min(1e-30)
+    return err32, float(rel.max()), float((b[0] - a[0]).norm() / a[0].norm())
+
+
+def test_bf16_wire_is_opt_in_and_bounded_against_the_fp32_wire():
+    from efficientvlm_amd.trainer import GradReducer
+    assert GradReducer([torch.zeros(4)]).compress is None            # default wire: fp32, as the reference's DDP
+    for err32, rel_max, rel_l2 in run2(_wire_case):
+        assert err32 < 1e-6
+        # roundings to 8 significant bits (unit roundoff 2^-8; each contribution once, the sum once): <= 2 * 2^-8 of the
+        # summed magnitudes per element, a few 1e-3 in norm
+        assert rel_max < 2 * 2.0 ** -8 * 1.01 and rel_l2 < 4e-3, (rel_max, rel_l2)

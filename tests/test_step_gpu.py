@@ -333,7 +333,7 @@ tr = GDTrainer(student, teacher, lr=1e-3, weight_decay=0.01, lr_mult=2.0, max_gr
 batch = {k: v.cuda() for k, v in synth.make_batch(geom, 4, seed=3).items()}
 ops.dropout_seed(0)        # hard-negative draws (device Philox stream)
 out = [tr.step(batch).tolist() for _ in range(3)]
-assert tr.reducer.active == dp and (tr._early_sent or not dp)
+assert tr.reducer.active == dp and (not dp or (len(tr._stages) == 4 and tr._sent == 4))
 torch.cuda.synchronize()
 if dp:
     dist.destroy_process_group()
@@ -387,7 +387,11 @@ for i in range(6):
         out.append(o.tolist())
 torch.cuda.synchronize()
 if dp:
-    assert tr._seg and all(len([s for s in sg["segs"] if s[0] == "gather"]) == 1 for sg in tr._seg.values()), "no segmented graphs"
+    assert tr._seg and not getattr(tr, "_segments_broken", False), "no segmented graphs"
+    for sg in tr._seg.values():       # forward cut at the ITC gather, backward cut at the three gradient-stage hooks
+        kinds = [s[0] for s in sg["segs"]]
+        assert kinds == ["graph", "gather", "graph", "reduce", "graph", "reduce", "graph", "reduce", "graph", "reduce",
+                         "graph"], kinds
     dist.destroy_process_group()
 else:
     assert tr._joint
@@ -415,6 +419,61 @@ def test_segmented_graph_step_of_the_multi_gpu_path_matches_the_single_gpu_graph
     a, b = run(False), run(True)
     assert a.shape == b.shape and a.shape[0] == 5
     assert np.allclose(a, b, rtol=3e-4, atol=1e-5), (a, b)
+
+
+_DP_SEQ_SCRIPT = r"""
+import os, sys, json, torch
+sys.path.insert(0, os.environ["EVLM_REPO"]); sys.path.insert(0, os.path.join(os.environ["EVLM_REPO"], "tests"))
+import torch.distributed as dist
+from oracle import synth
+from test_step_gpu import build_gd
+from efficientvlm_amd import runtime
+from efficientvlm_amd.trainer import GDTrainer
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+geom = synth.GEOMS["tiny"]
+student, teacher = build_gd(geom, 9)
+tr = GDTrainer(student, teacher, dtype=torch.bfloat16, use_graph=True, pipeline_teacher=True)
+batches = [{k: v.cuda() for k, v in synth.make_batch(geom, 4, seed=3 + i).items()} for i in range(3)]
+seqs = []
+for i in range(7):
+    runtime.COLLECTIVES = []
+    tr.step(batches[i % 3])
+    seqs.append(runtime.COLLECTIVES)
+torch.cuda.synchronize()
+runtime.COLLECTIVES = None
+segmented = bool(tr._seg) and not getattr(tr, "_segments_broken", False)
+slab = sum(g.numel() for g in tr.opt.flat_grads)
+dist.destroy_process_group()
+print("RESULT " + json.dumps({"seqs": seqs, "segmented": segmented, "slab": slab}))
+"""
+
+
+def test_segmented_and_eager_multi_gpu_steps_issue_the_same_collective_sequence():
+    """N > 1 code path on one GPU (RCCL group of one rank): the student step replayed as hipGraph segments and the eager
+    student step (what every rank falls back to when a capture fails anywhere) must issue the SAME collectives in the
+    same order with the same sizes and wire dtype - ranks in different modes would otherwise hang each other - and the
+    all-reduces of one step cover the gradient slabs exactly once"""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(eager):
+        env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", EVLM_FORCE_REDUCE="1")
+        env.pop("EVLM_NO_SEGMENT_GRAPHS", None)
+        if eager:
+            env["EVLM_NO_SEGMENT_GRAPHS"] = "1"
+        r = subprocess.run([sys.executable, "-c", _DP_SEQ_SCRIPT], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+
+    seg, eag = run(False), run(True)
+    assert seg["segmented"] and not eag["segmented"]
+    assert seg["seqs"][0] == eag["seqs"][0] == []                  # the priming call runs the teacher only: no collective
+    for a, b in zip(seg["seqs"][1:], eag["seqs"][1:]):
+        assert a == b and len(a) >= 5, (a, b)
+        assert a[0][0] == "all_gather" and all(k == "all_reduce" for k, _, _ in a[1:])
+        assert all(d == "torch.float32" for _, _, d in a[1:])       # default wire: fp32
+        assert sum(n for _, n, _ in a[1:]) == seg["slab"]
 
 
 def test_deferred_grouped_weight_gradients_match_immediate_ones():

@@ -1,45 +1,108 @@
 #!/usr/bin/env python3
-"""Where the N > 1 code path of the GD step spends its time on ONE GPU (RCCL group of one rank): eager student step vs
-hipGraph segments, gradient exchange on / off.  EVLM_FORCE_REDUCE=1 python tools/dp_path_probe.py"""
-import os, sys, time
+"""Where the N > 1 code path of the GD step spends its time on ONE GPU (RCCL group of one rank, ITC gather forced through
+the collective): hipGraph segments with the backward cut at the gradient-stage hooks (EVLM_DP_CUTS) against the uncut form,
+the teacher forked inside a segment or replayed as its own graph (EVLM_SEG_TEACHER), the eager student step, and the
+single-GPU joint graph.
+
+A one-rank all-reduce moves nothing, so the exchange is SIMULATED for the overlap question: `--wire-gbps G` makes every
+all-reduce additionally hold its stream for bytes / G (a one-thread spin kernel: the timeline of a ring all-reduce at that
+algorithm bandwidth, without its CU / HBM contention).  "exchange hidden" = (segments + simulated wire) - (segments, no
+exchange).
+
+    EVLM_FORCE_REDUCE=1 python tools/dp_path_probe.py [--wire-gbps 170] [--steps 12] [--only tag,tag]"""
+import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("EVLM_FORCE_REDUCE", "1")
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29561")
 import torch, torch.distributed as dist
 import bench
 from efficientvlm_amd.workload import GEOMS, make_batch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--wire-gbps", type=float, default=170.0, help="simulated all-reduce algorithm bandwidth (8-GPU ring "
+                "over 7 xGMI links at ~300 GB/s bus bandwidth: ~170 GB/s)")
+ap.add_argument("--steps", type=int, default=12)
+ap.add_argument("--only", default="")
+ap.add_argument("--reps", type=int, default=2)
+args = ap.parse_args()
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
 geom = GEOMS["full"]; dev = torch.device("cuda", 0)
 batches = [{k: v.to(dev) for k, v in make_batch(geom, 64, seed=42 + 1000 * i).items()} for i in range(4)]
 
-def run(tag, env=None, patch=None, steps=10):
+# spin-kernel calibration (cycles per microsecond of torch.cuda._sleep)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda._sleep(1000); torch.cuda.synchronize()
+e0.record(); torch.cuda._sleep(20_000_000); e1.record(); torch.cuda.synchronize()
+CYC_PER_US = 20_000_000 / (e0.elapsed_time(e1) * 1e3)
+_real_all_reduce = dist.all_reduce
+SIM = {"on": False, "bytes": 0}
+
+
+def all_reduce_sim(t, *a, **kw):
+    h = _real_all_reduce(t, *a, **kw)
+    if SIM["on"]:
+        nb = t.numel() * t.element_size()
+        SIM["bytes"] += nb
+        torch.cuda._sleep(int(nb / (args.wire_gbps * 1e3) * CYC_PER_US))     # bytes / (GB/s) = ns * 1e-... -> us
+    return h
+
+
+dist.all_reduce = all_reduce_sim
+
+
+def run(tag, env=None, patch=None, sim=False):
+    if args.only and tag.split(":")[0] not in args.only.split(","):
+        return
+    saved = {}
     for k, v in (env or {}).items():
-        os.environ[k] = v
+        saved[k] = os.environ.get(k)
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     s, t = bench.build(geom, dev, 1234)
     tr = bench.make_trainer(s, t, torch.bfloat16, True, True)
     if patch: patch(tr)
+    SIM["on"], SIM["bytes"] = sim, 0
     it = 0
-    for _ in range(6):
+    for _ in range(7):
         tr.step(batches[it % 4]); it += 1
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(steps):
+    torch.cuda.synchronize(); SIM["bytes"] = 0; t0 = time.perf_counter()
+    for _ in range(args.steps):
         tr.step(batches[it % 4]); it += 1
     host = time.perf_counter() - t0
     torch.cuda.synchronize(); el = time.perf_counter() - t0
-    print(f"{tag:50s} {el / steps * 1e3:7.2f} ms/step   (host issue {host / steps * 1e3:6.2f} ms)", flush=True)
-    for k in (env or {}):
-        os.environ.pop(k, None)
+    wire = f"  simulated wire {SIM['bytes'] / args.steps / 1e6:6.1f} MB = {SIM['bytes'] / args.steps / (args.wire_gbps * 1e6):5.2f} ms/step" if sim else ""
+    mode = "segments" if (tr._seg and not getattr(tr, "_segments_broken", False)) else ("joint graph" if tr._joint else "eager")
+    print(f"{tag:58s} {el / args.steps * 1e3:7.2f} ms/step   (host issue {host / args.steps * 1e3:6.2f} ms) [{mode}]{wire}", flush=True)
+    SIM["on"] = False
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     del tr, s, t
+
 
 def no_reduce(tr):
     tr.reducer.reduce_async = lambda tensors: None
     tr.reducer.finish = lambda: None
-def fp32_wire(tr):
-    tr.reducer.compress = None
 
-for rep in range(2):
-    run("segments, fp32 wire", patch=fp32_wire)
-    run("segments, bf16 wire")
-    run("segments, no gradient exchange", patch=no_reduce)
+
+print(f"# spin calibration: {CYC_PER_US:.0f} cycles/us; simulated wire {args.wire_gbps:.0f} GB/s; "
+      f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}", flush=True)
+for rep in range(args.reps):
+    run("joint: single-GPU joint graph (no process-group path)", env={"EVLM_FORCE_REDUCE": None})
+    run("cuts_all: segments, cuts=all, teacher forked, fp32 wire", env={"EVLM_DP_CUTS": "all"})
+    run("cuts_all_sim: same + simulated wire", env={"EVLM_DP_CUTS": "all"}, sim=True)
+    run("cuts_all_noex: same, no gradient exchange", env={"EVLM_DP_CUTS": "all"}, patch=no_reduce)
+    run("cuts_vit: segments, cuts=vit (first send after ViT 5,4)", env={"EVLM_DP_CUTS": "vit"})
+    run("cuts_vit_sim: same + simulated wire", env={"EVLM_DP_CUTS": "vit"}, sim=True)
+    run("cuts_none: segments, no cut in backward (round-2 form)", env={"EVLM_DP_CUTS": "none"})
+    run("cuts_none_sim: same + simulated wire", env={"EVLM_DP_CUTS": "none"}, sim=True)
+    run("tgraph: segments, cuts=all, teacher as its own graph", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER": "graph"})
+    run("tgraph_sim: same + simulated wire", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER": "graph"}, sim=True)
+    run("bf16: segments, cuts=all, bf16 wire (opt-in) + simulated wire", env={"EVLM_DP_CUTS": "all", "EVLM_BF16_WIRE": "1"}, sim=True)
+    run("eager: eager student step (fallback), hooks send the stages", env={"EVLM_NO_SEGMENT_GRAPHS": "1"})
 dist.destroy_process_group()
