@@ -23,6 +23,9 @@ class XVLM(XVLMBase):
     # the gathered hard-negative copies.  Row-wise identical arithmetic, 3-4x larger GEMMs, ~1/3 of the launches.
     batched_passes = True
     on_vision_grad = None      # optional callback: fired (tensor hook) when backward has produced d(loss)/d(image_embeds)
+    # optional callback(name) at fixed points of the batched forward - "vision_done" (image encoder finished), "text_done"
+    # (text layers finished, ITC / fusion passes next): a trainer forks side-stream work (the pipelined teacher) there
+    phase_hook = None
     # extension (False = the reference's behaviour): a frozen TEACHER's task losses are never read by the distillation
     # loss (GeneralDistill.py:300-376 uses its hidden states, attention maps and logits only); with this set the batched
     # forward skips ITC / ITM / MLM cross-entropies - and with them the ITC feature all-gather, the teacher forward's only
@@ -105,6 +108,8 @@ class XVLM(XVLMBase):
         if self.on_vision_grad is not None and image_embeds.requires_grad:
             cb = self.on_vision_grad
             image_embeds.register_hook(lambda grad: (cb(), grad)[1])
+        if self.phase_hook is not None:
+            self.phase_hook("vision_done")
         core = self._text_core()
         # text layers 0..F-1 on [text_ids ; text_ids_masked]
         t = core(torch.cat([text_ids, text_ids_masked], 0), attention_mask=torch.cat([text_atts, text_atts], 0),
@@ -117,6 +122,8 @@ class XVLM(XVLMBase):
         else:
             text_embeds, mlm_text = torch.split(t.last_hidden_state, [B, B], 0)
         text_attentions, mlm_text_attentions = halves(t.attentions)
+        if self.phase_hook is not None:
+            self.phase_hook("text_done")
         with torch.no_grad():
             self.temp.clamp_(0.001, 0.5)
         image_feat, text_feat = self.get_features(image_embeds, text_embeds)

@@ -49,6 +49,7 @@ class GradReducer:
         self.active = self.world > 1 or (force and ready)
         # RCCL averages in the collective itself (one pass over the slabs less); gloo has no AVG
         self.native_avg = bool(ready and dist.get_backend(group) == "nccl" and hasattr(dist.ReduceOp, "AVG"))
+        self.coalesce = hasattr(dist, "_coalescing_manager") and not os.environ.get("EVLM_NO_COALESCE")
         self.buckets = self._buckets(self.flat)
         self.stream = torch.cuda.Stream() if (self.flat and self.flat[0].is_cuda) else None
         self._pending = []
@@ -72,20 +73,38 @@ class GradReducer:
             import contextlib
             ctx = contextlib.nullcontext()
         with ctx:
-            for b in self._buckets(tensors):
-                if self.compress is not None:
+            buckets = self._buckets(tensors)
+            wire = buckets
+            if self.compress is not None:
+                wire = []
+                for b in buckets:
                     b.mul_(1.0 / self.world)                  # the mean's division in fp32, before the cast
-                    w = b.to(self.compress)
-                    log_collective("all_reduce", w)
-                    dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
-                    b.copy_(w)
-                elif self.native_avg:
-                    log_collective("all_reduce", b)
-                    self._pending.append(dist.all_reduce(b, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
-                else:
+                    wire.append(b.to(self.compress))
+                op = dist.ReduceOp.SUM
+            elif self.native_avg:
+                op = dist.ReduceOp.AVG
+            else:
+                for b in buckets:
                     b.div_(self.world)
-                    log_collective("all_reduce", b)
-                    self._pending.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                op = dist.ReduceOp.SUM
+            for w in wire:
+                log_collective("all_reduce", w)
+            if self.coalesce and len(wire) > 1:
+                # ONE grouped launch for the ranges of a stage (the bulk of a stage is one range; the no-decay groups'
+                # biases / LayerNorm ranges are latency-bound messages of their own otherwise)
+                with dist._coalescing_manager(self.group, async_ops=True) as cm:
+                    for w in wire:
+                        dist.all_reduce(w, op=op, group=self.group)
+                self._pending.append(cm)
+            else:
+                for w in wire:
+                    self._pending.append(dist.all_reduce(w, op=op, group=self.group, async_op=True))
+            if self.compress is not None:
+                for h in self._pending:                       # (the cast-back reads the reduced wire buffers)
+                    h.wait()
+                self._pending = []
+                for b, w in zip(buckets, wire):
+                    b.copy_(w)
 
     def finish(self):
         if not self.active:
@@ -173,6 +192,7 @@ class GDTrainer:
         # The eager step sends from the hooks; the captured step (hipGraph segments) CUTS its capture at the same points,
         # so both issue the same collective sequence.
         self._stages, self._sent, self._cut = [list(self.opt.flat_grads)], 0, None
+        self._vision_stage, self._join_at_vision = None, None
         self._seg, self._seg_pool, self._cap_stream = {}, None, None
         if self.reducer.active and hasattr(student, "on_vision_grad"):
             which = os.environ.get("EVLM_DP_CUTS", "all")
@@ -183,6 +203,8 @@ class GDTrainer:
             if vit_hooks:
                 n = len(enc.layers)
                 cuts = [n - n // 3, n - 2 * (n // 3)]              # 6 layers: hooks at 4 and 2
+                if os.environ.get("EVLM_DP_VIT_CUTS"):             # e.g. "4,2,1": a smaller last (exposed) stage
+                    cuts = sorted({int(c) for c in os.environ["EVLM_DP_VIT_CUTS"].split(",") if 0 < int(c) < n}, reverse=True)
                 layer_of = lambda nme: int(nme.split("encoder.layers.")[1].split(".")[0]) if "encoder.layers." in nme else None
                 in_vit = lambda nme: nme.startswith("vision_encoder.")
                 hi = n
@@ -207,15 +229,16 @@ class GDTrainer:
                     hooks.append(key)
                     carry = []
             self._stages = stages
-            student.on_vision_grad = None
             if vit_hooks:
                 enc.grad_hooks = {}
             for i, key in enumerate(hooks[:-1]):
                 cb = (lambda i_: lambda: self._stage_done(i_))(i)
                 if key == "vision":
-                    student.on_vision_grad = cb
+                    self._vision_stage = i
                 else:
                     enc.grad_hooks[key[1]] = cb
+        if hasattr(student, "on_vision_grad"):
+            student.on_vision_grad = self._on_vision_grad
         self.use_graph = use_graph
         self.wgrad_inplace = True
         if not os.environ.get("EVLM_TEACHER_ALL_MAPS"):
@@ -266,6 +289,15 @@ class GDTrainer:
         return torch.stack([total.detach().float(), S["loss"]["loss_itc"].detach().float(),
                             S["loss"]["loss_itm"].detach().float(), S["loss"]["loss_mlm"].detach().float(),
                             mix["loss_kd"].detach().float()])
+
+    def _on_vision_grad(self):
+        """tensor hook on the ViT output (backward is about to enter the image encoder): a side-stream teacher forward that
+        was asked to finish here joins, then the text / fusion / head gradient stage goes out"""
+        if self._join_at_vision is not None:
+            self._join_at_vision()
+            self._join_at_vision = None
+        if self._vision_stage is not None:
+            self._stage_done(self._vision_stage)
 
     def _stage_done(self, i):
         """tensor hook: backward has finished with gradient stage i (see __init__) - send it under the rest of backward"""
@@ -611,11 +643,37 @@ class GDTrainer:
         return sg["out"]
 
     def _joint_body(self, pipe, p, pp, pk):
+        """single GPU: student step on (pp, pk) with the teacher forward of (pipe, p) forked onto the side stream.
+        EVLM_TEACHER_FORK = start | vision_done | text_done: where the fork sits in the student's forward;
+        EVLM_TEACHER_JOIN = end | vision: join at the end of the step, or when backward enters the image encoder (the ViT
+        backward - large, chip-filling GEMMs - then runs alone; the teacher shares the chip with the text-side work)."""
         cur, side = torch.cuda.current_stream(), self._side
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            self._teacher_eager(pipe, p)
-        out = self._student_eager(pp, pk)
+        fork_at = os.environ.get("EVLM_TEACHER_FORK", "start")
+        join_at = os.environ.get("EVLM_TEACHER_JOIN", "end")
+        state = {"forked": False}
+
+        def fork():
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self._teacher_eager(pipe, p)
+            state["forked"] = True
+
+        def phase(name):
+            if name == fork_at and not state["forked"]:
+                fork()
+
+        if fork_at == "start":
+            fork()
+        self.student.phase_hook = phase
+        if join_at == "vision":
+            self._join_at_vision = lambda: cur.wait_stream(side) if state["forked"] else None
+        try:
+            out = self._student_eager(pp, pk)
+        finally:
+            self.student.phase_hook = None
+            self._join_at_vision = None
+        if not state["forked"]:
+            fork()
         cur.wait_stream(side)
         return out
 

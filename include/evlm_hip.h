@@ -160,6 +160,12 @@ typedef struct {
   const void* kd_teacher;
   float* kd_loss;
   float kd_weight;
+  /* optional [B, H, Lq] f32: per-row log2-sum-exp of the scaled, masked scores,  lse = m + log2(sum_k 2^(s_k - m))  with
+     s_k = (scale * q.k + mask) * log2(e).  With it the backward RECOMPUTES the probabilities from Q and K in fp32
+     (evlm_attn_bwd_args.lse) and P may be NULL: no [B, H, Lq, Lk] map is written or read back unless a caller wants it
+     (the reference keeps softmax in fp32 under Apex O1; a bf16-stored P costs 13-36 % of the q / k gradients' norm).
+     bf16 MFMA path with Lk <= 224 and no dropout only: evlm_attention_lse_supported(). */
+  float* lse;
 } evlm_attn_fwd_args;
 int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream);
 
@@ -193,8 +199,18 @@ typedef struct {
   const void* kd_teacher;
   const float* kd_gout;         /* device f32 word: dL/d(kd term) */
   float kd_weight;
+  /* recomputing backward (set when the forward call wrote `lse`): P = 2^(s - lse) is rebuilt in fp32 registers from Q, K,
+     the same additive `mask` ([B, Lk] f32 or NULL) and `causal` flag as in the forward call.  P may then be NULL; problems
+     that take the two-kernel path (kv_index, Lq > 224) additionally need `P_ws` ([B, H, Lq, ldpr] of dtype, uninitialised)
+     for the second kernel unless P is given. */
+  const float* lse;
+  const float* mask;
+  int causal;
+  void* P_ws;
 } evlm_attn_bwd_args;
 int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream);
+/* 1 when evlm_attention_fwd / _bwd serve (dtype, dh, Lk, dropout_p) through the lse / recompute form, else 0 */
+int evlm_attention_lse_supported(int dtype, int dh, int Lk, float dropout_p);
 
 /* many device-to-device copies in ONE launch.  table: DEVICE int64 [n_units][4] = {source pointer, destination pointer, bytes,
  * index of the unit's first workgroup}; bytes a multiple of 16, pointers 16-byte aligned, one workgroup per 64 KiB;

@@ -254,7 +254,7 @@ def _segments_case(rank, world):
         tr = GDTrainer(student, teacher, dtype=torch.float32, use_graph=False)
         ok = tr.reducer.active and len(tr._stages) == n_stages
         enc = student.vision_encoder.encoder
-        ok = ok and sorted(enc.grad_hooks or {}) == hooks and (student.on_vision_grad is not None) == vision
+        ok = ok and sorted(enc.grad_hooks or {}) == hooks and (tr._vision_stage is not None) == vision
         for g in tr.opt.flat_grads:
             g.zero_()
         for seg in tr._stages:

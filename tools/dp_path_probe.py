@@ -97,6 +97,12 @@ for rep in range(args.reps):
     run("cuts_all: segments, cuts=all, teacher forked, fp32 wire", env={"EVLM_DP_CUTS": "all"})
     run("cuts_all_sim: same + simulated wire", env={"EVLM_DP_CUTS": "all"}, sim=True)
     run("cuts_all_noex: same, no gradient exchange", env={"EVLM_DP_CUTS": "all"}, patch=no_reduce)
+    run("cuts_421: segments, ViT cuts at 4,2,1", env={"EVLM_DP_VIT_CUTS": "4,2,1"})
+    run("cuts_421_sim: same + simulated wire", env={"EVLM_DP_VIT_CUTS": "4,2,1"}, sim=True)
+    for fk in ("start", "vision_done", "text_done"):
+        for jn in ("end", "vision"):
+            run(f"joint_{fk}_{jn}: joint graph, teacher fork={fk} join={jn}",
+                env={"EVLM_FORCE_REDUCE": None, "EVLM_TEACHER_FORK": fk, "EVLM_TEACHER_JOIN": jn})
     run("cuts_vit: segments, cuts=vit (first send after ViT 5,4)", env={"EVLM_DP_CUTS": "vit"})
     run("cuts_vit_sim: same + simulated wire", env={"EVLM_DP_CUTS": "vit"}, sim=True)
     run("cuts_none: segments, no cut in backward (round-2 form)", env={"EVLM_DP_CUTS": "none"})
