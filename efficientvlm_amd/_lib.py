@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVLM_LIB", os.path.join(_HERE, "libevlm_hip.so"))
 
-ABI_VERSION = 3      # evlm_abi_version() of the library this binding was written against (struct layouts, entry points)
+ABI_VERSION = 4      # evlm_abi_version() of the library this binding was written against (struct layouts, entry points)
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2
 GATE_PRE, GATE_POST = 0, 1
@@ -41,7 +41,7 @@ class AttnFwdArgs(C.Structure):
                 ("Q", _vp), ("K", _vp), ("V", _vp), ("kv_index", _vp), ("mask", _vp), ("head_gate", _vp),
                 ("scale", _f), ("O", _vp), ("P", _vp), ("causal", _i),
                 ("dropout_p", _f), ("rng_state", _vp), ("call_id", C.c_uint32),
-                ("kd_teacher", _vp), ("kd_loss", _vp), ("kd_weight", _f)]
+                ("kd_teacher", _vp), ("kd_loss", _vp), ("kd_weight", _f), ("lse", _vp)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -53,7 +53,8 @@ class AttnBwdArgs(C.Structure):
                 ("kv_index", _vp), ("head_gate", _vp), ("scale", _f),
                 ("dS", _vp), ("dQ", _vp), ("dK", _vp), ("dV", _vp), ("dgate", _vp),
                 ("dropout_p", _f), ("rng_state", _vp), ("call_id", C.c_uint32),
-                ("kd_teacher", _vp), ("kd_gout", _vp), ("kd_weight", _f)]
+                ("kd_teacher", _vp), ("kd_gout", _vp), ("kd_weight", _f),
+                ("lse", _vp), ("mask", _vp), ("causal", _i), ("P_ws", _vp)]
 
 
 class XAttnFusedArgs(C.Structure):
@@ -74,6 +75,7 @@ SIGNATURES = {
     "evlm_layernorm_bwd_add": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "evlm_attention_fwd": [C.POINTER(AttnFwdArgs), _vp],
     "evlm_attention_bwd": [C.POINTER(AttnBwdArgs), _vp],
+    "evlm_attention_lse_supported": [_i, _i, _i, _f],
     "evlm_xattn_fused_fwd": [C.POINTER(XAttnFusedArgs), _vp],
     "evlm_mse_fwd": [_i, _vp, _i, _vp, _i64, _f, _vp, _vp],
     "evlm_mse_bwd": [_i, _vp, _i, _vp, _i64, _f, _vp, _vp, _vp],

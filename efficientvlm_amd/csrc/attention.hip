@@ -334,6 +334,7 @@ extern "C" int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream_) {
     if (int e = evlm_attention_fwd_mfma(a, stream, &handled)) return e;
   }
   if (handled) return 0;
+  EVLM_REQUIRE(!a->lse, "evlm_attention_fwd: the lse form exists on the bf16 MFMA path only (evlm_attention_lse_supported)");
   EVLM_REQUIRE(!a->kd_teacher, "evlm_attention_fwd: the fused map distillation exists on the bf16 MFMA path only "
                "(head dim 64, Lk <= 928, no dropout); use evlm_mse_fwd on the returned map");
   AttnF f;
@@ -358,7 +359,7 @@ extern "C" int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream_) {
 
 extern "C" int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  EVLM_REQUIRE(a && a->Q && a->K && a->V && a->P && a->dO && a->dQ, "evlm_attention_bwd: null operand");
+  EVLM_REQUIRE(a && a->Q && a->K && a->V && (a->P || a->lse) && a->dO && a->dQ, "evlm_attention_bwd: null operand");
   EVLM_REQUIRE(a->dK && a->dV, "evlm_attention_bwd: dK/dV required (f32 accumulators when kv_index is set)");
   if (int e = attn_check(a->dtype, a->p_dtype, a->dh, "evlm_attention_bwd")) return e;
   EVLM_REQUIRE(a->ldpr >= a->Lk && a->ldpr % 8 == 0, "evlm_attention_bwd: ldpr must be a multiple of 8 and >= Lk");
@@ -370,6 +371,8 @@ extern "C" int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream_) {
     if (handled) return 0;
   }
   EVLM_REQUIRE(!a->kd_teacher, "evlm_attention_bwd: the fused map distillation exists on the bf16 MFMA path only");
+  EVLM_REQUIRE(!a->lse && a->P, "evlm_attention_bwd: the recomputing (lse) form exists on the bf16 MFMA path only "
+               "(evlm_attention_lse_supported); this problem needs the stored map P");
   EVLM_REQUIRE(a->dS, "evlm_attention_bwd: this problem needs the dS workspace");
   AttnB g;
   g.drop_p = a->dropout_p; g.rng = a->rng_state; g.call = a->call_id;

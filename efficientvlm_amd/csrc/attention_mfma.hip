@@ -15,6 +15,7 @@ struct MAttnF {
   float scale;
   int causal;
   const bf16* Pt; float* kd; float kd_coef;      // fused map distillation: *kd += kd_coef * sum((P - Pt)^2)
+  float* lse;                                    // [B, H, Lq] log2-sum-exp of the scaled, masked scores (recomputing backward)
 };
 
 #define DH 64
@@ -22,6 +23,14 @@ struct MAttnF {
 // 16-byte chunk swizzles of the two row-major [key][64] bf16 tiles (128-byte rows)
 __device__ __forceinline__ int k_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }          // ds_read_b128 rows
 __device__ __forceinline__ int v_swz(int row, int chunk) { return chunk ^ (((row >> 1) & 3) << 1); }   // tr16 column reads
+// both at once (the recomputing backward reads its K tile by rows for S^T = K Q^T AND by columns for dQ^T = K^T dS^T):
+// the column reads of a half-wave touch rows 8i .. 8i+7, whose (row >> 3) bit is constant - the chunk PAIR slots stay
+// those of v_swz -, and the 16 rows of a b128 row read get 16 distinct (row parity, chunk slot) bank groups
+__device__ __forceinline__ int kv_swz(int row, int chunk) { return chunk ^ ((((row >> 1) & 3) << 1) | ((row >> 3) & 1)); }
+enum { SW_K = 0, SW_V = 1, SW_KV = 2 };
+template <int SW> __device__ __forceinline__ int swz(int row, int chunk) {
+  return SW == SW_K ? k_swz(row, chunk) : (SW == SW_V ? v_swz(row, chunk) : kv_swz(row, chunk));
+}
 
 // Key order inside the LDS tiles.  Keys are PERMUTED within every block of 32: key 32s + 8g + 4h + r sits in LDS row
 // (2s + h)*16 + 4g + r, i.e. MFMA tile 2s + h, row 4g + r.  An accumulator lane (g = lane >> 4) of the tile pair (2s, 2s+1)
@@ -46,12 +55,12 @@ __device__ __forceinline__ int row_key(int row) {
 // fills 8 consecutive 128-byte LDS rows, lane-linear; the key permutation and the chunk swizzle (XOR: its own inverse)
 // are applied to each lane's SOURCE address.  Keys >= L read key L-1: their scores carry the -1e30 of the mask row /
 // their probabilities are zero, so any finite value serves.  The caller waits (stage_wait) before its barrier.
-template <bool VSWZ>
+template <int SW>
 __device__ __forceinline__ void stage_rows(const bf16* base, int ld, int L, int nrows, char* sm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int r0 = wave * 8; r0 < nrows; r0 += nw * 8) {
     const int row = r0 + (lane >> 3), cs = lane & 7;
-    const int c = VSWZ ? v_swz(row, cs) : k_swz(row, cs);
+    const int c = swz<SW>(row, cs);
     const int key = min(row_key(row), L - 1);
     const bf16* src = base + (size_t)key * ld + c * 8;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -61,19 +70,21 @@ __device__ __forceinline__ void stage_rows(const bf16* base, int ld, int L, int 
 __device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // A/B operand fragment (rows = keys, k = head dim) from a k_swz tile: row = 16*t + (lane&15), k = 32*ks + 8*(lane>>4)..+7
+template <int SW = SW_K>
 __device__ __forceinline__ bf16x8 krow_frag(const char* sm, int t, int ks, int lane) {
   const int row = t * 16 + (lane & 15), c = ks * 4 + (lane >> 4);
-  return *reinterpret_cast<const bf16x8*>(sm + row * 128 + k_swz(row, c) * 16);
+  return *reinterpret_cast<const bf16x8*>(sm + row * 128 + swz<SW>(row, c) * 16);
 }
 // A operand = (tile)^T for a sum over KEYS: row index d = 16*dt + (lane&15); k-slots j=0..3 <-> keys 16*t0+4g+j,
 // j=4..7 <-> keys 16*t1+4g+(j-4)   (g = lane>>4).  `sm` is a v_swz tile.
+template <int SW = SW_V>
 __device__ __forceinline__ bf16x8 vcol_frag(const char* sm, int t0, int t1, int dt, int lane) {
   const int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3;
   bf16x8 out;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = (h ? t1 : t0) * 16 + g * 4 + q;
-    const int off = row * 128 + v_swz(row, dt * 2 + (p >> 1)) * 16 + ((p & 1) << 3);
+    const int off = row * 128 + swz<SW>(row, dt * 2 + (p >> 1)) * 16 + ((p & 1) << 3);
     bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(sm + off));
     out[4 * h + 0] = t[0]; out[4 * h + 1] = t[1]; out[4 * h + 2] = t[2]; out[4 * h + 3] = t[3];
   }
@@ -86,7 +97,10 @@ __device__ __forceinline__ bf16x8 vcol_frag(const char* sm, int t0, int t1, int 
 // SEQ (long key sequences: 480x480 images = 901 tokens): K and V do not fit in LDS together, so they take turns in ONE
 // region - K for the scores, then (after the probabilities are in registers) V for P V.  Waves past the last query stay
 // for the barriers.
-template <int NT, int MAXW, bool SEQ>
+// LSE: the per-row log2-sum-exp is written for a backward that recomputes P in fp32 (the map itself is then written only
+// when a caller wants it), and the fused map distillation compares the fp32 probabilities - the ones that backward will
+// rebuild - with the teacher map, before the P V product (while the un-normalised row is still in registers).
+template <int NT, int MAXW, bool SEQ, bool LSE>
 __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;                                       // [NT*16][64] bf16, k_swz
@@ -97,8 +111,8 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   const int bkv = a.kv_index ? a.kv_index[b] : b;
   const bf16* Kb = a.K + (size_t)bkv * a.Lk * a.ldk + h * DH;
   const bf16* Vb = a.V + (size_t)bkv * a.Lk * a.ldv + h * DH;
-  stage_rows<false>(Kb, a.ldk, a.Lk, NT * 16, Ks);
-  if (!SEQ) stage_rows<true>(Vb, a.ldv, a.Lk, NT * 16, Vs);
+  stage_rows<SW_K>(Kb, a.ldk, a.Lk, NT * 16, Ks);
+  if (!SEQ) stage_rows<SW_V>(Vb, a.ldv, a.Lk, NT * 16, Vs);
   for (int k = threadIdx.x; k < NT * 16; k += blockDim.x)
     Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
   float* kdw = Ms + NT * 16;                     // {partial sum, arrived waves} of the fused map distillation
@@ -154,6 +168,24 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
+  if (LSE && qok && g == 0) a.lse[((size_t)b * a.H + h) * a.Lq + q] = m + __log2f(sum);
+  float sq = 0.f;
+  if (LSE && a.Pt && qok) {
+    const bf16* Tr = a.Pt + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr;
+#pragma unroll
+    for (int s = 0; s < NT / 2; ++s) {
+      const int kcol = s * 32 + g * 8;
+      if (kcol < a.ldpr) {
+        const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(Tr + kcol);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d0 = acc[2 * s][r] * inv - (float)t8[r], d1 = acc[2 * s + 1][r] * inv - (float)t8[4 + r];
+          sq = fmaf(d0, d0, sq);
+          sq = fmaf(d1, d1, sq);
+        }
+      }
+    }
+  }
   // P (bf16): 4 consecutive keys per lane per tile -> 8-byte stores; also the PV B operand
   bf16x4 pk[NT];
   bf16* Pr = a.P ? a.P + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr : nullptr;
@@ -174,7 +206,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   }
   if (SEQ) {                                             // the scores are done with K: V takes its place
     __syncthreads();
-    stage_rows<true>(Vb, a.ldv, a.Lk, NT * 16, Vs);
+    stage_rows<SW_V>(Vb, a.ldv, a.Lk, NT * 16, Vs);
     stage_wait();
     __syncthreads();
   }
@@ -204,8 +236,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
     // attention-map distillation while the (bf16-rounded, as stored) probabilities are still in registers
     // (placed after the P V product: fewest live registers): the teacher's map is
     // read once, the student's not at all; one atomic per WORKGROUP (the waves meet in LDS, last arriver publishes)
-    float sq = 0.f;
-    if (qok) {
+    if (!LSE && qok) {
       const bf16* Tr = a.Pt + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr;
 #pragma unroll
       for (int s = 0; s < NT / 2; ++s) {
@@ -237,11 +268,19 @@ static int launch_fwd(const MAttnF& f, hipStream_t stream) {
   constexpr int MAXW = NT <= 14 ? 16 : (NT <= 26 ? 8 : 4);   // register budget: 16 (8) waves/workgroup need <= 128 (256) VGPRs
   constexpr bool SEQ = NT > 38;                        // 2 x NT x 2 KiB of K and V no longer fit in 160 KiB of LDS
   const size_t lds = (size_t)(SEQ ? 1 : 2) * NT * 16 * 128 + (size_t)NT * 16 * sizeof(float) + 16;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT, MAXW, SEQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nw = imin(MAXW, (f.Lq + 15) / 16);         // waves per workgroup (16 queries each)
   dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
-  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT, MAXW, SEQ>), grid, block, lds, stream, f);
+  if constexpr (NT <= 14) {
+    if (f.lse) {
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT, MAXW, SEQ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT, MAXW, SEQ, true>), grid, block, lds, stream, f);
+      return 0;
+    }
+  }
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT, MAXW, SEQ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT, MAXW, SEQ, false>), grid, block, lds, stream, f);
   return 0;
 }
 
@@ -255,61 +294,102 @@ struct MAttnB {
   int B, Bkv, H, Lq, Lk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, ldpr;
   float scale;
   const bf16* Pt; const float* kd_gout; float kd_coef;   // fused map distillation: dP += kd_coef * (*kd_gout) * (P - Pt)
+  // recomputing form (RC kernels): P = 2^(s - lse) rebuilt in fp32 from Q, K, the forward's mask / causal flag; Pw = bf16
+  // copy of it for kernel B of the two-kernel path (NULL in the single-pass kernel)
+  const float* lse; const float* mask; int causal; bf16* Pw;
 };
+
+#define LOG2E 1.44269504088896341f
+// mask row of one (batch): Ms[k] = additive mask of key k (0 without one), -1e30 beyond Lk - as the forward kernel builds it
+__device__ __forceinline__ void stage_mask(const float* mask, int b, int Lk, int n, float* Ms) {
+  for (int k = threadIdx.x; k < n; k += blockDim.x)
+    Ms[k] = (k < Lk) ? (mask ? mask[(size_t)b * Lk + k] : 0.f) : -1e30f;
+}
+// the probabilities of this lane's query for the 8 keys of tile pair s (tiles 2s, 2s+1), recomputed exactly as the forward
+// kernel formed them: S^T = K Q^T (K tile read by rows), scaled + masked in the log2 domain, minus the saved row lse
+template <int SW>
+__device__ __forceinline__ void recompute_p(const char* Ks, const float* Ms, const bf16x8 (&qf)[2], int s, int g, int lane,
+                                            float sc, float lse_q, bool qok, int causal, int q, float (&p)[8]) {
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int t = 2 * s + hh;
+    f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag<SW>(Ks, t, ks, lane), qf[ks], sa, 0, 0, 0);
+    const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + tile_key0(t, g));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float add = mk[r];
+      if (causal && tile_key0(t, g) + r > q) add = fminf(add, -10000.0f);
+      p[hh * 4 + r] = qok ? exp2f(sa[r] * sc + add * LOG2E - lse_q) : 0.f;
+    }
+  }
+}
 
 // kernel A: same shape as the forward (a wave owns 16 queries and ALL keys):
 //   dPo^T = V dO^T ;  dP = gate*dPo + E ;  delta = rowsum(P .* dP) ;  dS = P .* (dP - delta) -> HBM (for kernel B)
 //   dQ^T  = scale * K^T dS^T           (dS^T accumulators reused as the MFMA B operand, K^T through tr16 reads)
-template <int NT, int MAXW>
+template <int NT, int MAXW, bool RC>
 __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;                          // v_swz (column reads)
+  constexpr int KSW = RC ? SW_KV : SW_V;
+  char* Ks = smem;                          // column reads (dQ); RC: also row reads (scores)
   char* Vs = smem + NT * 16 * 128;          // k_swz (row reads)
+  float* Ms = reinterpret_cast<float*>(smem + 2 * NT * 16 * 128);   // RC: mask row
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
   const int bkv = a.kv_index ? a.kv_index[b] : b;
-  stage_rows<true>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
-  stage_rows<false>(a.V + (size_t)bkv * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
+  stage_rows<KSW>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
+  stage_rows<SW_K>(a.V + (size_t)bkv * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
+  if (RC) stage_mask(a.mask, b, a.Lk, NT * 16, Ms);
   stage_wait();
   __syncthreads();
   const int q0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 16;
   if (q0 >= a.Lq) return;
   const int q = q0 + ql;
   const bool qok = q < a.Lq;
-  bf16x8 dof[2];
+  bf16x8 dof[2], qf[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    uint4 v = make_uint4(0, 0, 0, 0);
+    uint4 v = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);
     if (qok) v = *reinterpret_cast<const uint4*>(a.dO + ((size_t)b * a.Lq + q) * a.ldo + h * DH + ks * 32 + g * 8);
+    if (RC && qok) vq = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + ks * 32 + g * 8);
     dof[ks] = *reinterpret_cast<bf16x8*>(&v);
+    qf[ks] = *reinterpret_cast<bf16x8*>(&vq);
   }
   const size_t prow = (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr;
   const float gz = a.gate ? a.gate[h] : 1.0f;
   const float kdc = a.Pt ? a.kd_coef * a.kd_gout[0] : 0.f;
+  const float sc = a.scale * LOG2E;
+  const float lse_q = (RC && qok) ? a.lse[((size_t)b * a.H + h) * a.Lq + q] : 0.f;
   f32x4 acc[NT];
+  f32x4 pf[RC ? NT : 1];
   bf16x4 pv[NT];
   float dsum = 0.f, gsum = 0.f;
 #pragma unroll
   for (int s = 0; s < NT / 2; ++s) {            // tile pair: this lane's 8 consecutive keys 32s + 8g .. + 7
     const int kcol = s * 32 + g * 8;
     const bool ok = qok && kcol < a.ldpr;
-    bf16x8 p8, e8;
+    float pr[8], ex[8];                          // ex: external gradient on the map (dP_ext and / or the fused distillation term)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { p8[r] = (bf16)0.f; e8[r] = (bf16)0.f; }
-    float ex[8];                                 // external gradient on the map: dP_ext and / or the fused distillation term
-#pragma unroll
-    for (int r = 0; r < 8; ++r) ex[r] = 0.f;
+    for (int r = 0; r < 8; ++r) { pr[r] = 0.f; ex[r] = 0.f; }
+    if (RC) recompute_p<KSW>(Ks, Ms, qf, s, g, lane, sc, lse_q, qok, a.causal, q, pr);
     if (ok) {
-      p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
+      if (!RC) {
+        const bf16x8 p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pr[r] = (float)p8[r];
+      }
       if (a.E) {
-        e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
+        const bf16x8 e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
 #pragma unroll
         for (int r = 0; r < 8; ++r) ex[r] = (float)e8[r];
       }
       if (a.Pt) {
         const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(a.Pt + prow + kcol);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) ex[r] += kdc * ((float)p8[r] - (float)t8[r]);
+        for (int r = 0; r < 8; ++r) ex[r] += kdc * (pr[r] - (float)t8[r]);
       }
     }
 #pragma unroll
@@ -321,8 +401,9 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, t, ks, lane), dof[ks], acc[t], 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pv[t][r] = p8[hh * 4 + r];
-        const float p = (float)pv[t][r], dpo = acc[t][r];
+        const float p = pr[hh * 4 + r], dpo = acc[t][r];
+        pv[t][r] = (bf16)p;
+        if (RC) pf[RC ? t : 0][r] = p;
         gsum += p * dpo;
         const float dp = gz * dpo + ex[hh * 4 + r];
         acc[t][r] = dp;
@@ -339,7 +420,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dsk[t][r] = (bf16)((float)pv[t][r] * (acc[t][r] - dsum));
+    for (int r = 0; r < 4; ++r) dsk[t][r] = (bf16)((RC ? pf[RC ? t : 0][r] : (float)pv[t][r]) * (acc[t][r] - dsum));
   }
 #pragma unroll
   for (int s = 0; s < NT / 2; ++s) {
@@ -349,6 +430,12 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { d8[r] = dsk[2 * s][r]; d8[4 + r] = dsk[2 * s + 1][r]; }
       *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
+      if (RC && a.Pw) {                          // kernel B reads the map from here (the forward did not store one)
+        bf16x8 p8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p8[r] = pv[2 * s][r]; p8[4 + r] = pv[2 * s + 1][r]; }
+        *reinterpret_cast<bf16x8*>(a.Pw + prow + kcol) = p8;
+      }
     }
   }
   f32x4 o[4];
@@ -361,7 +448,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
     for (int r = 0; r < 4; ++r) { pb[r] = dsk[2 * s][r]; pb[4 + r] = dsk[2 * s + 1][r]; }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Ks, 2 * s, 2 * s + 1, dt, lane), pb, o[dt], 0, 0, 0);
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag<KSW>(Ks, 2 * s, 2 * s + 1, dt, lane), pb, o[dt], 0, 0, 0);
   }
   if (qok) {
     bf16* dQr = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + h * DH;
@@ -389,7 +476,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
   const int bkv = a.kv_index ? a.kv_index[b] : b;
   const bf16* Kb = a.K + (size_t)bkv * a.Lk * a.ldk + h * DH;
   const bf16* Vb = a.V + (size_t)bkv * a.Lk * a.ldv + h * DH;
-  stage_rows<false>(Vb, a.ldv, a.Lk, NT * 16, smem);
+  stage_rows<SW_K>(Vb, a.ldv, a.Lk, NT * 16, smem);
   stage_wait();
   __syncthreads();
   const int q = (blockIdx.x * (blockDim.x >> 6) + wave) * 16 + ql;
@@ -454,8 +541,8 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
   for (int half = 0; half < 2; ++half) {
     const int key0 = half * HT * 16;
     __syncthreads();                                       // every wave is done with the previous contents
-    stage_rows<false>(Vb + (size_t)key0 * a.ldv, a.ldv, a.Lk - key0, HT * 16, Vs);
-    stage_rows<true>(Kb + (size_t)key0 * a.ldk, a.ldk, a.Lk - key0, HT * 16, Ks);
+    stage_rows<SW_K>(Vb + (size_t)key0 * a.ldv, a.ldv, a.Lk - key0, HT * 16, Vs);
+    stage_rows<SW_V>(Kb + (size_t)key0 * a.ldk, a.ldk, a.Lk - key0, HT * 16, Ks);
     stage_wait();
     __syncthreads();
 #pragma unroll 2
@@ -615,16 +702,18 @@ __device__ __forceinline__ bf16x8 scol_frag(const char* tile, int ct, int lane) 
   return out;
 }
 
-template <int NT, int NW>
+template <int NT, int NW, bool RC>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
   constexpr int G = (NT + NW - 1) / NW, KC = NT / 2, QC = NT / 2;
+  constexpr int KSW = RC ? SW_KV : SW_V;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool EARLY = NT <= 4;           // short sequences: LDS to spare - Q and dO get their own tiles, staged up front
   char* Ss = smem;                          // [QC][KC] tiles of [32 q][32 key]: dS, then P
-  char* Ks = smem + QC * KC * 2048;         // phase 1: K (v_swz);  phases 2-3: Q as [QC] tiles of [32 q][64] (p_swz)
+  char* Ks = smem + QC * KC * 2048;         // phase 1: K (column reads; RC: row reads too);  phases 2-3: Q as [QC] tiles of [32 q][64] (p_swz)
   char* Vs = Ks + NT * 16 * 128;            // phase 1: V (k_swz);  phases 2-3: dO likewise
   char* Qs = EARLY ? Vs + NT * 16 * 128 : Ks;
   char* dOs = EARLY ? Qs + NT * 16 * 128 : Vs;
+  float* Ms = reinterpret_cast<float*>((EARLY ? dOs : Vs) + NT * 16 * 128);      // RC: mask row of this batch
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ql = lane & 15;
   auto stage_q_do = [&]() {                          // Q, dO as [32 q][64] tiles (p_swz), rows >= Lq zero
@@ -640,13 +729,15 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
       *reinterpret_cast<uint4*>(dOs + off) = vo;
     }
   };
-  stage_rows<true>(a.K + (size_t)b * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
-  stage_rows<false>(a.V + (size_t)b * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
+  stage_rows<KSW>(a.K + (size_t)b * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
+  stage_rows<SW_K>(a.V + (size_t)b * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
   if (EARLY) stage_q_do();
+  if (RC) stage_mask(a.mask, b, a.Lk, NT * 16, Ms);
   stage_wait();
   __syncthreads();
   const float gz = a.gate ? a.gate[h] : 1.0f;
   const float kdc = a.Pt ? a.kd_coef * a.kd_gout[0] : 0.f;
+  const float sc = a.scale * LOG2E;
   bf16x4 pvg[G][NT];
   float gsum = 0.f;
 #pragma unroll
@@ -655,26 +746,34 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
     if (qt >= NT) continue;                         // wave-uniform
     const int q = qt * 16 + ql;
     const bool qok = q < a.Lq;
-    bf16x8 dof[2];
+    bf16x8 dof[2], qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      uint4 v = make_uint4(0, 0, 0, 0);
+      uint4 v = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);
       if (qok) v = *reinterpret_cast<const uint4*>(a.dO + ((size_t)b * a.Lq + q) * a.ldo + h * DH + ks * 32 + g * 8);
+      if (RC && qok) vq = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + ks * 32 + g * 8);
       dof[ks] = *reinterpret_cast<bf16x8*>(&v);
+      qf[ks] = *reinterpret_cast<bf16x8*>(&vq);
     }
     const size_t prow = (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr;
+    const float lse_q = (RC && qok) ? a.lse[((size_t)b * a.H + h) * a.Lq + q] : 0.f;
     f32x4 acc[NT];
+    f32x4 pf[RC ? NT : 1];
     float dsum = 0.f;
 #pragma unroll
     for (int s = 0; s < NT / 2; ++s) {
       const int kcol = s * 32 + g * 8;
       const bool ok = qok && kcol < a.ldpr;
-      bf16x8 p8;
-      float ex[8];
+      float pr[8], ex[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) { p8[r] = (bf16)0.f; ex[r] = 0.f; }
+      for (int r = 0; r < 8; ++r) { pr[r] = 0.f; ex[r] = 0.f; }
+      if (RC) recompute_p<KSW>(Ks, Ms, qf, s, g, lane, sc, lse_q, qok, a.causal, q, pr);
       if (ok) {
-        p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
+        if (!RC) {
+          const bf16x8 p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) pr[r] = (float)p8[r];
+        }
         if (a.E) {
           const bf16x8 e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
 #pragma unroll
@@ -683,7 +782,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
         if (a.Pt) {
           const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(a.Pt + prow + kcol);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) ex[r] += kdc * ((float)p8[r] - (float)t8[r]);
+          for (int r = 0; r < 8; ++r) ex[r] += kdc * (pr[r] - (float)t8[r]);
         }
       }
 #pragma unroll
@@ -695,8 +794,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, t, ks, lane), dof[ks], acc[t], 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pvg[gi][t][r] = p8[hh * 4 + r];
-          const float p = (float)p8[hh * 4 + r], dpo = acc[t][r];
+          const float p = pr[hh * 4 + r], dpo = acc[t][r];
+          pvg[gi][t][r] = (bf16)p;
+          if (RC) pf[RC ? t : 0][r] = p;
           gsum += p * dpo;
           const float dp = gz * dpo + ex[hh * 4 + r];
           acc[t][r] = dp;
@@ -715,13 +815,15 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
       bf16x8 d8;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        d8[r] = (bf16)((float)pvg[gi][2 * s][r] * (acc[2 * s][r] - dsum));
-        d8[4 + r] = (bf16)((float)pvg[gi][2 * s + 1][r] * (acc[2 * s + 1][r] - dsum));
+        const float p0 = RC ? pf[RC ? 2 * s : 0][r] : (float)pvg[gi][2 * s][r];
+        const float p1 = RC ? pf[RC ? 2 * s + 1 : 0][r] : (float)pvg[gi][2 * s + 1][r];
+        d8[r] = (bf16)(p0 * (acc[2 * s][r] - dsum));
+        d8[4 + r] = (bf16)(p1 * (acc[2 * s + 1][r] - dsum));
       }
       *reinterpret_cast<bf16x8*>(srow + s * 2048 + s_swz(sr, g) * 16) = d8;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Ks, 2 * s, 2 * s + 1, dt, lane), d8, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag<KSW>(Ks, 2 * s, 2 * s + 1, dt, lane), d8, o[dt], 0, 0, 0);
     }
     if (qok) {
       bf16* dQr = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + h * DH;
@@ -789,27 +891,27 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
   }
 }
 
-template <int NT>
+template <int NT, bool RC>
 static bool launch_bwd_fused(const MAttnB& f, hipStream_t stream) {
   constexpr int NW = NT < 8 ? NT : 8;
   const char* env = getenv("EVLM_ATTN_BWD_SPLIT");          // (debug / A-B switch: force kernels A + B)
   if ((env && atoi(env)) || f.kv_index || f.Lq > NT * 16 || f.Lk > NT * 16) return false;
-  const size_t lds = (size_t)(NT / 2) * (NT / 2) * 2048 + (size_t)(NT <= 4 ? 4 : 2) * NT * 16 * 128;
+  const size_t lds = (size_t)(NT / 2) * (NT / 2) * 2048 + (size_t)(NT <= 4 ? 4 : 2) * NT * 16 * 128 + (RC ? NT * 16 * sizeof(float) : 0);
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_bwd_fused_kernel<NT, NW>), dim3(f.H, f.B), dim3(64 * NW), lds, stream, f);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<NT, NW, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<NT, NW, RC>), dim3(f.H, f.B), dim3(64 * NW), lds, stream, f);
   return true;
 }
 
-template <int NT>
+template <int NT, bool RC>
 static void launch_bwd_dq(const MAttnB& f, hipStream_t stream) {
   constexpr int MAXW = NT <= 14 ? 8 : 4;
-  const size_t lds = (size_t)2 * NT * 16 * 128;
+  const size_t lds = (size_t)2 * NT * 16 * 128 + (RC ? NT * 16 * sizeof(float) : 0);
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<NT, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<NT, MAXW, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nw = imin(MAXW, (f.Lq + 15) / 16);
   dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
-  hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NT, MAXW>), grid, block, lds, stream, f);
+  hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NT, MAXW, RC>), grid, block, lds, stream, f);
 }
 
 template <int NT>
@@ -836,10 +938,20 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
   f.Pt = (const bf16*)a->kd_teacher; f.kd_gout = a->kd_gout;
   f.kd_coef = a->kd_teacher ? 2.0f * a->kd_weight / ((float)a->B * a->H * a->Lq * a->Lk) : 0.f;
   if (a->kd_teacher && !a->kd_gout) return evlm_set_error("evlm_attention_bwd: kd_teacher without kd_gout");
+  f.lse = a->lse; f.mask = a->mask; f.causal = a->causal; f.Pw = nullptr;
+  const bool rc = a->lse != nullptr;
+  if (rc && a->Lk > 224) return evlm_set_error("evlm_attention_bwd: the recomputing form serves Lk <= 224 (got %d)", a->Lk);
+  if (!rc && !a->P) return evlm_set_error("evlm_attention_bwd: neither the probability map nor the row lse was given");
   bool fused = false;                       // whole (batch, head) problems that fit one workgroup: one launch, no dS in HBM
-  if (a->Lk <= 32) fused = launch_bwd_fused<2>(f, stream);
-  else if (a->Lk <= 64) fused = launch_bwd_fused<4>(f, stream);
-  else if (a->Lk <= 224) fused = launch_bwd_fused<14>(f, stream);
+  if (rc) {
+    if (a->Lk <= 32) fused = launch_bwd_fused<2, true>(f, stream);
+    else if (a->Lk <= 64) fused = launch_bwd_fused<4, true>(f, stream);
+    else fused = launch_bwd_fused<14, true>(f, stream);
+  } else {
+    if (a->Lk <= 32) fused = launch_bwd_fused<2, false>(f, stream);
+    else if (a->Lk <= 64) fused = launch_bwd_fused<4, false>(f, stream);
+    else if (a->Lk <= 224) fused = launch_bwd_fused<14, false>(f, stream);
+  }
   if (fused) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return evlm_set_error("evlm_attention_bwd(mfma, fused): %s", hipGetErrorString(e));
@@ -847,10 +959,20 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
     return 0;
   }
   if (!f.dS) return evlm_set_error("evlm_attention_bwd: the two-kernel path needs the dS workspace");
-  if (a->Lk <= 32) launch_bwd_dq<2>(f, stream);
-  else if (a->Lk <= 64) launch_bwd_dq<4>(f, stream);
-  else if (a->Lk <= 224) launch_bwd_dq<14>(f, stream);
-  else if (a->Lk <= 416) launch_bwd_dq<26>(f, stream);
+  if (rc) {
+    // kernel B reads the map kernel A rebuilds (the same bf16 values the single-pass kernel hands its third phase); only
+    // without a workspace does it fall back to the map the forward stored
+    if (a->P_ws) {
+      f.Pw = (bf16*)a->P_ws;
+      f.P = (const bf16*)a->P_ws;
+    } else if (!a->P) return evlm_set_error("evlm_attention_bwd: the two-kernel recomputing path needs P or the P_ws workspace");
+    if (a->Lk <= 32) launch_bwd_dq<2, true>(f, stream);
+    else if (a->Lk <= 64) launch_bwd_dq<4, true>(f, stream);
+    else launch_bwd_dq<14, true>(f, stream);
+  } else if (a->Lk <= 32) launch_bwd_dq<2, false>(f, stream);
+  else if (a->Lk <= 64) launch_bwd_dq<4, false>(f, stream);
+  else if (a->Lk <= 224) launch_bwd_dq<14, false>(f, stream);
+  else if (a->Lk <= 416) launch_bwd_dq<26, false>(f, stream);
   else if (a->Lk <= 640) launch_bwd_dq_long<40>(f, stream);      // long sequences: two passes over the keys, nothing spilled
   else launch_bwd_dq_long<60>(f, stream);
   dim3 gridB((a->Lk + 63) / 64, a->H, f.Bkv), block(256);
@@ -859,6 +981,10 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
   if (e != hipSuccess) return evlm_set_error("evlm_attention_bwd(mfma): %s", hipGetErrorString(e));
   *handled = 1;
   return 0;
+}
+
+extern "C" int evlm_attention_lse_supported(int dtype, int dh, int Lk, float dropout_p) {
+  return dtype == EVLM_BF16 && dh == DH && Lk <= 224 && dropout_p == 0.f;
 }
 
 // returns 0 and sets *handled = 1 when a specialised kernel took the call
@@ -873,6 +999,8 @@ int evlm_attention_fwd_mfma(const evlm_attn_fwd_args* a, hipStream_t stream, int
   f.ldpr = a->ldpr; f.scale = a->scale; f.causal = a->causal;
   f.Pt = (const bf16*)a->kd_teacher; f.kd = a->kd_loss;
   f.kd_coef = a->kd_teacher ? a->kd_weight / ((float)a->B * a->H * a->Lq * a->Lk) : 0.f;
+  f.lse = a->lse;
+  if (a->lse && a->Lk > 224) return evlm_set_error("evlm_attention_fwd: the lse form serves Lk <= 224 (got %d)", a->Lk);
   if (a->kd_teacher && !a->kd_loss) return evlm_set_error("evlm_attention_fwd: kd_teacher without kd_loss");
   if (a->Lk <= 32) launch_fwd<2>(f, stream);
   else if (a->Lk <= 64) launch_fwd<4>(f, stream);

@@ -108,8 +108,11 @@ class CLIPAttention(nn.Module):
         qkv = ops.linear_packed(hidden_states, (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight),
                                 (self.q_proj.bias, self.k_proj.bias, self.v_proj.bias))
         if kd_teacher is not None:
+            # (the map itself is materialised only when the caller wants it: the kernels compare the probabilities with the
+            # teacher's in registers, and the backward rebuilds them from Q and K)
             out, probs, kd = ops.self_attention(qkv, self.num_heads, self.head_dim, self.scale, mask=mask2d, gate=head_z,
-                                                want_probs=True, kd_teacher=kd_teacher,
+                                                want_probs=bool(output_attentions) or not ops.attention_recomputes(qkv, self.head_dim, tgt_len),
+                                                kd_teacher=kd_teacher,
                                                 kd_weight=float(tgt_len) if kd_word is None else ops.KdSlot(kd_word, tgt_len))
             out = ops.linear(out, self.out_proj.weight, self.out_proj.bias, residual=residual)
             return out, (probs if output_attentions else None), kd
@@ -178,6 +181,10 @@ class CLIPEncoder(nn.Module):
         # teacher's outputs of this batch already exist - the pipelined trainer); the per-layer terms land in kd_fused
         self.kd_teacher_maps = None
         self.kd_fused = None
+        # extension (False = the reference's behaviour of returning every map): a layer whose map distillation ran fused in
+        # its attention kernel does not materialise the map (None in its slot) - nobody else reads a student's ViT maps in
+        # the GD recipe (trainer.GDTrainer sets this on the student)
+        self.kd_drop_maps = False
         # extension: {layer index: callback} - a tensor hook on the INPUT of that layer: it fires when backward has finished
         # with layers >= index (their parameter gradients are complete): the data-parallel trainer reduces them right then
         self.grad_hooks = None
@@ -206,7 +213,8 @@ class CLIPEncoder(nn.Module):
         for idx, encoder_layer in enumerate(self.layers):
             if output_hidden_states:
                 encoder_states = encoder_states + (hidden_states,)
-            want_map = bool(output_attentions) and (self.attn_keep is None or idx in self.attn_keep)
+            want_map = (bool(output_attentions) and (self.attn_keep is None or idx in self.attn_keep)
+                        and not (kd_maps is not None and self.kd_drop_maps))
             kw = dict(output_attentions=want_map,
                       head_z=head_z[idx] if head_z is not None else None,
                       head_layer_z=head_layer_z[idx] if head_layer_z is not None else None,

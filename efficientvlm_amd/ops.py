@@ -169,6 +169,7 @@ CACHE = WeightCache()
 GEMM_PROFILE = None
 # set to [0.0] to count the FLOPs of the attention cores that are launched (QK^T + PV forward, 5 products backward)
 ATTN_FLOPS = None
+ATTN_STORE_P = bool(os.environ.get("EVLM_ATTN_STORE_P"))   # A/B switch: attention backward from the stored bf16 map (round-2 form)
 
 
 def _as2d(x):
@@ -759,12 +760,14 @@ class _Attention(torch.autograd.Function):
         O = torch.empty((B, Lq, H * dh), dtype=tdt, device=dev)
         need = any(ctx.needs_input_grad)
         Lkp = _pad8(Lk)          # probability rows are padded to 16 bytes; the kernels zero the padding
-        Pbuf = torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev) if (want_probs or need) else None
-        if p_out is not None and Pbuf is not None:         # caller-owned (persistent) buffer for the map: no copy later
-            if tuple(p_out.shape) != (B, H, Lq, Lkp) or p_out.dtype != tdt or not p_out.is_contiguous():
-                raise RuntimeError("p_out must be a contiguous [B, H, Lq, pad8(Lk)] buffer of the activation dtype")
-            Pbuf = p_out
-        P = (Pbuf[..., :Lk] if Lkp != Lk else Pbuf) if Pbuf is not None else None
+        # Recomputing form (bf16 MFMA kernels, Lk <= 224, no dropout): the forward keeps the per-row log2-sum-exp instead
+        # of the map, the backward rebuilds P from Q and K in fp32 - no [B, H, Lq, Lk] bf16 map is written or read back
+        # unless a caller wants it, and the q / k gradients are formed from fp32 probabilities, as the reference's
+        # autocast softmax does.  EVLM_ATTN_STORE_P=1: the round-2 form (backward from the stored bf16 map).
+        rc = bool(need and not ATTN_STORE_P and not (dropout_p and dropout_p > 0.0)
+                  and _lib().evlm_attention_lse_supported(L.dt(tdt), dh, Lk, 0.0))
+        lse = torch.empty((B, H, Lq), dtype=torch.float32, device=dev) if rc else None
+        Pbuf = torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev) if (want_probs or (need and not rc)) else None
         m32 = mask.detach().to(torch.float32).contiguous() if mask is not None else None
         g32 = gate.detach().reshape(-1).to(torch.float32).contiguous() if gate is not None else None
         es = qbuf.element_size()
@@ -772,12 +775,12 @@ class _Attention(torch.autograd.Function):
                           ldo=H * dh, ldpr=Lkp, Q=C.c_void_p(qbuf.data_ptr() + q_off * es),
                           K=C.c_void_p(kvbuf.data_ptr() + k_off * es), V=C.c_void_p(kvbuf.data_ptr() + v_off * es),
                           kv_index=L.ptr(kv_index), mask=L.ptr(m32), head_gate=L.ptr(g32), scale=scale, O=L.ptr(O),
-                          P=L.ptr(Pbuf), causal=int(bool(causal)))
+                          P=L.ptr(Pbuf), causal=int(bool(causal)), lse=L.ptr(lse))
         kd = kd_base = None
         if kd_teacher is not None:                # fused map distillation: the teacher's (padded) map, read once in-kernel
             kd_base = _padded_base(kd_teacher, Lkp) if kd_teacher.shape[-1] != Lkp else kd_teacher
             if (kd_base is None or not kd_base.is_contiguous() or tuple(kd_base.shape) != (B, H, Lq, Lkp)
-                    or kd_base.dtype != tdt or tdt != torch.bfloat16 or Pbuf is None):
+                    or kd_base.dtype != tdt or tdt != torch.bfloat16 or (Pbuf is None and lse is None)):
                 raise RuntimeError("fused attention-map distillation needs the teacher map as a [B, H, Lq, Lk] view of a "
                                    "row-padded contiguous bf16 buffer (what the attention kernels return)")
             if isinstance(kd_weight, KdSlot):     # caller-provided zeroed f32 word (one fill for all layers of an encoder)
@@ -793,16 +796,17 @@ class _Attention(torch.autograd.Function):
         if ATTN_FLOPS is not None:
             ATTN_FLOPS[0] += 4.0 * B * H * Lq * Lk * dh
         ctx.set_materialize_grads(False)        # an unused probability map must not cost a zero tensor in backward
-        ctx.save_for_backward(qbuf, kvbuf, Pbuf, g32, kv_index, kd_base)
+        ctx.save_for_backward(qbuf, kvbuf, Pbuf, g32, kv_index, kd_base, lse, m32 if rc else None)
         ctx.meta = (H, dh, q_off, k_off, v_off, scale, qbuf is kvbuf or qbuf.data_ptr() == kvbuf.data_ptr(),
                     gate.shape if gate is not None else None)
+        ctx.causal = int(bool(causal))
         ctx.drop = drop
         ctx.kd_weight = float(kd_weight) if kd_teacher is not None else 0.0
         return O, P, kd
 
     @staticmethod
     def backward(ctx, dO, dP, dkd):
-        qbuf, kvbuf, P, g32, kv_index, kd_base = ctx.saved_tensors
+        qbuf, kvbuf, P, g32, kv_index, kd_base, lse, m32 = ctx.saved_tensors
         H, dh, q_off, k_off, v_off, scale, self_attn, gshape = ctx.meta
         B, Lq, ldq = qbuf.shape
         Bkv, Lk, ldk = kvbuf.shape
@@ -811,7 +815,7 @@ class _Attention(torch.autograd.Function):
         if dO is None:
             dO = torch.zeros((B, Lq, H * dh), dtype=tdt, device=dev)
         dOc = dO if dO.is_contiguous() else dO.contiguous()
-        Lkp = P.shape[-1]
+        Lkp = _pad8(Lk)
         dPc = None
         if dP is not None:
             dPc = _padded_base(dP, Lkp)          # the KD loss hands back a view of a padded buffer: no copy
@@ -827,6 +831,8 @@ class _Attention(torch.autograd.Function):
         single_pass = (tdt == torch.bfloat16 and dh == 64 and kv_index is None and Lq <= 224 and Lk <= 224
                        and ctx.drop is None and os.environ.get("EVLM_ATTN_BWD_SPLIT", "0") in ("", "0"))
         dS = None if single_pass else torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev)
+        # (two-kernel recomputing path: the second kernel reads the map the first one rebuilds)
+        P_ws = torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev) if (lse is not None and not single_pass) else None
         dgate = torch.zeros(H, dtype=torch.float32, device=dev) if g32 is not None else None
         a = L.AttnBwdArgs(dtype=L.dt(tdt), p_dtype=L.dt(tdt), B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, Bkv=Bkv, ldq=ldq, ldk=ldk, ldv=ldk,
                           ldo=H * dh, lddq=ldq, lddk=ldk, lddv=ldk, ldpr=Lkp,
@@ -834,7 +840,8 @@ class _Attention(torch.autograd.Function):
                           V=C.c_void_p(kvbuf.data_ptr() + v_off * es), P=L.ptr(P), dO=L.ptr(dOc), dP_ext=L.ptr(dPc),
                           kv_index=L.ptr(kv_index), head_gate=L.ptr(g32), scale=scale, dS=L.ptr(dS),
                           dQ=C.c_void_p(dqbuf.data_ptr() + q_off * es), dK=C.c_void_p(dkvbuf.data_ptr() + k_off * es),
-                          dV=C.c_void_p(dkvbuf.data_ptr() + v_off * es), dgate=L.ptr(dgate))
+                          dV=C.c_void_p(dkvbuf.data_ptr() + v_off * es), dgate=L.ptr(dgate),
+                          lse=L.ptr(lse), mask=L.ptr(m32), causal=ctx.causal if lse is not None else 0, P_ws=L.ptr(P_ws))
         if kd_base is not None and dkd is not None:       # dP of the fused distillation term is formed in-kernel from P_t
             gk = dkd.to(torch.float32).contiguous()
             a.kd_teacher, a.kd_gout, a.kd_weight = L.ptr(kd_base), L.ptr(gk), ctx.kd_weight
@@ -844,7 +851,7 @@ class _Attention(torch.autograd.Function):
                 raise RuntimeError("attention-probability dropout with a shared K/V index: materialise the gather first")
         L.check(_lib().evlm_attention_bwd(C.byref(a), L.stream()), "attention_bwd")
         if ATTN_FLOPS is not None:
-            ATTN_FLOPS[0] += 8.0 * B * H * Lq * Lk * dh          # dP, dV, dQ, dK (P is read back, not recomputed)
+            ATTN_FLOPS[0] += (10.0 if lse is not None else 8.0) * B * H * Lq * Lk * dh     # dP, dV, dQ, dK (+ S when P is recomputed)
         dg = dgate.view(gshape) if dgate is not None else None
         if self_attn:
             return (dqbuf, None, None, dg) + (None,) * 13
@@ -868,6 +875,13 @@ class KdSlot:
 
     def __init__(self, word, weight):
         self.word, self.weight = word, float(weight)
+
+
+def attention_recomputes(x, dh, Lk, dropout_p=0.0):
+    """will the attention backward of this problem rebuild the probabilities from Q and K (bf16 MFMA kernels, lse saved by
+    the forward) instead of reading a stored map?"""
+    return bool(x.is_cuda and not ATTN_STORE_P and not dropout_p
+                and _lib().evlm_attention_lse_supported(L.dt(x.dtype), dh, Lk, 0.0))
 
 
 def attention_kd_fusable(x, H, dh, Lk):

@@ -243,6 +243,16 @@ class GDTrainer:
         self.wgrad_inplace = True
         if not os.environ.get("EVLM_TEACHER_ALL_MAPS"):
             teacher_map_filter(student, teacher, with_cross=False)
+        if not os.environ.get("EVLM_STUDENT_ALL_MAPS"):
+            # maps of the STUDENT that nothing in the GD recipe reads are not materialised (None in their output slots): the
+            # cross-attention maps (GeneralDistill.py:300-366 distils self-attention maps only) and the ViT maps whose
+            # distillation term was formed inside the attention kernel; their backward rebuilds the probabilities
+            enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
+            if enc is not None and hasattr(enc, "kd_drop_maps"):
+                enc.kd_drop_maps = True
+            tenc = getattr(getattr(student.text_encoder, "bert", student.text_encoder), "encoder", None)
+            if tenc is not None and hasattr(tenc, "cross_keep"):
+                tenc.cross_keep = set()
         if hasattr(teacher, "skip_task_losses"):
             teacher.skip_task_losses = True       # nobody reads a frozen teacher's ITC / ITM / MLM losses (nor gathers for them)
         self.defer_wgrad = self.dtype == torch.bfloat16 and not os.environ.get("EVLM_NO_DEFER_WGRAD")
