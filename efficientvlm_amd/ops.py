@@ -768,6 +768,11 @@ class _Attention(torch.autograd.Function):
                   and _lib().evlm_attention_lse_supported(L.dt(tdt), dh, Lk, 0.0))
         lse = torch.empty((B, H, Lq), dtype=torch.float32, device=dev) if rc else None
         Pbuf = torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev) if (want_probs or (need and not rc)) else None
+        if p_out is not None and Pbuf is not None:         # caller-owned (persistent) buffer for the map: no copy later
+            if tuple(p_out.shape) != (B, H, Lq, Lkp) or p_out.dtype != tdt or not p_out.is_contiguous():
+                raise RuntimeError("p_out must be a contiguous [B, H, Lq, pad8(Lk)] buffer of the activation dtype")
+            Pbuf = p_out
+        P = (Pbuf[..., :Lk] if Lkp != Lk else Pbuf) if Pbuf is not None else None
         m32 = mask.detach().to(torch.float32).contiguous() if mask is not None else None
         g32 = gate.detach().reshape(-1).to(torch.float32).contiguous() if gate is not None else None
         es = qbuf.element_size()
