@@ -322,7 +322,7 @@ __device__ __forceinline__ void recompute_p(const char* Ks, const float* Ms, con
     for (int r = 0; r < 4; ++r) {
       float add = mk[r];
       if (causal && tile_key0(t, g) + r > q) add = fminf(add, -10000.0f);
-      p[hh * 4 + r] = qok ? exp2f(sa[r] * sc + add * LOG2E - lse_q) : 0.f;
+      p[hh * 4 + r] = qok ? exp2f(fmaf(sa[r], sc, add * LOG2E) - lse_q) : 0.f;
     }
   }
 }
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
       if (a.Pt) {
         const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(a.Pt + prow + kcol);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) ex[r] += kdc * (pr[r] - (float)t8[r]);
+        for (int r = 0; r < 8; ++r) ex[r] = fmaf(kdc, pr[r] - (float)t8[r], ex[r]);
       }
     }
 #pragma unroll
@@ -404,10 +404,10 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
         const float p = pr[hh * 4 + r], dpo = acc[t][r];
         pv[t][r] = (bf16)p;
         if (RC) pf[RC ? t : 0][r] = p;
-        gsum += p * dpo;
-        const float dp = gz * dpo + ex[hh * 4 + r];
+        gsum = fmaf(p, dpo, gsum);                 // (explicit fma forms: the single-pass kernel and kernels A + B must
+        const float dp = fmaf(gz, dpo, ex[hh * 4 + r]);   //  round identically whatever the compiler would contract)
         acc[t][r] = dp;
-        dsum += p * dp;
+        dsum = fmaf(p, dp, dsum);
       }
     }
   }
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
         if (a.Pt) {
           const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(a.Pt + prow + kcol);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) ex[r] += kdc * (pr[r] - (float)t8[r]);
+          for (int r = 0; r < 8; ++r) ex[r] = fmaf(kdc, pr[r] - (float)t8[r], ex[r]);
         }
       }
 #pragma unroll
@@ -797,10 +797,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
           const float p = pr[hh * 4 + r], dpo = acc[t][r];
           pvg[gi][t][r] = (bf16)p;
           if (RC) pf[RC ? t : 0][r] = p;
-          gsum += p * dpo;
-          const float dp = gz * dpo + ex[hh * 4 + r];
+          gsum = fmaf(p, dpo, gsum);
+          const float dp = fmaf(gz, dpo, ex[hh * 4 + r]);
           acc[t][r] = dp;
-          dsum += p * dp;
+          dsum = fmaf(p, dp, dsum);
         }
       }
     }

@@ -1068,11 +1068,14 @@ def test_recomputing_attention_backward_needs_no_stored_map_and_tightens_the_gra
     Pr = torch.softmax(q @ k.transpose(-1, -2) * scale + add, -1)
     Or = (Pr @ v).transpose(1, 2).reshape(B, Lq, d)
     (Or * gO.float()).sum().backward()
-    e_rc, e_st = rel_err(gx_rc, xr.grad), rel_err(gx_st, xr.grad)
-    assert e_rc < 1.2e-2 and e_rc <= e_st * 1.05, (e_rc, e_st)
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    e_rc, e_st = l2(gx_rc, xr.grad), l2(gx_st, xr.grad)
+    assert rel_err(gx_rc, xr.grad) < 1.2e-2 and e_rc < 6e-3, (e_rc, e_st)
+    if case == "vit197":                                   # long rows: the bf16 map costs the query / key gradient visibly
+        assert e_rc < 0.8 * e_st, (e_rc, e_st)
     if kvr is not None:
-        k_rc, k_st = rel_err(gkv_rc, kvr.grad), rel_err(gkv_st, kvr.grad)
-        assert k_rc < 1.2e-2 and k_rc <= k_st * 1.05, (k_rc, k_st)
+        k_rc, k_st = l2(gkv_rc, kvr.grad), l2(gkv_st, kvr.grad)
+        assert rel_err(gkv_rc, kvr.grad) < 1.2e-2 and k_rc < 6e-3, (k_rc, k_st)
 
 
 def test_attention_lse_form_refuses_what_it_cannot_serve():

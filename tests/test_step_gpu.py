@@ -1032,6 +1032,59 @@ def test_vqa_480_step_full_width_bf16_tracks_the_fp32_oracle():
     assert torch.allclose(got, want, rtol=4e-2, atol=2e-3), (got, want)
 
 
+@pytest.mark.parametrize("keep", [0.25, 0.5, 0.75])
+def test_full_width_pruned_model_matches_the_oracles_masked_dense_forward(keep):
+    """BASELINE configs[4] at FULL width (768 hidden, 12 heads, 3072 FFN units, 224x224, 30 tokens): the physically pruned
+    X-VLM-small (utils/xvlm_utils.py:37-145) run by the HIP kernels - bf16, the dtype the sweep is measured in, and fp32 -
+    against the ORACLE's masked-dense eval forward (efficient_models/model_retrieval.py:76-93 with the 0/1 gates applied as
+    multipliers) in fp32 on the CPU: ITC / ITM losses and the ITM logits.  `keep` of every gate vector survives."""
+    from efficientvlm_amd import pruning
+    from efficientvlm_amd.efficient_models.model_retrieval import EffXVLMforRetrieval
+    from efficientvlm_amd.runtime import compute
+    geom = synth.GEOMS["full"]
+    s_cfg = O.model_cfg(geom, "s")
+    B = 6
+    batch = synth.make_batch(geom, B, seed=13, ragged=True)
+    idx = torch.arange(B)
+    neg = torch.tensor([(i + 1 + (i % 2)) % B for i in range(B)] + [(i + 2) % B for i in range(B)])
+    gen = torch.Generator().manual_seed(int(keep * 1000))
+    sch = schema.xvlm_schema(s_cfg, geom["max_pos"], mlm=False, bbox=False, l0=True)
+    want = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        model = EffXVLMforRetrieval(model_config(geom, "s"))
+        sd = load_det_weights(model, sch, 41, geom["std"])
+        model.to(DEV).eval()
+        if not want:                                   # gates + the oracle's masked-dense answer (once)
+            logas = {k[len("l0_module."):]: v for k, v in sd.items() if k.endswith("_loga")}
+            shapes = {t + "_z": shp for t, shp in O.l0_shapes(logas).items()}
+            zs = {}
+            for k, shp in shapes.items():
+                n = shp[2] if k.endswith("head_z") else shp[-1]
+                nk = max(1, int(round(n * keep)))
+                z = torch.zeros(shp[0], n)
+                for r in range(shp[0]):
+                    z[r, torch.randperm(n, generator=gen)[:nk]] = 1.0
+                zs[k] = z.view(shp)
+            with torch.no_grad():
+                S = O.retrieval_forward(sd, s_cfg, batch, idx, neg, zs)
+            want = {"itc": S["loss"]["loss_itc"], "itm": S["loss"]["loss_itm"], "logits": S["logits_dict"]["itm_head_logits"]}
+        dev_batch = {k: v.to(DEV) for k, v in batch.items()}
+        zd = {k: v.to(DEV) for k, v in zs.items()}
+        with torch.no_grad(), compute(dtype):
+            n_before = sum(p.numel() for p in model.parameters())
+            pruning.update_params(model, zd)
+            pruning.prune_model_with_z(zd, model)
+            assert sum(p.numel() for p in model.parameters()) < n_before * (0.55 + 0.5 * keep)
+            model.injected_neg_idx = neg.clone()
+            itc, itm = pruning.retrieval_eval_losses(model, dev_batch["image"], dev_batch["text_ids"], dev_batch["text_atts"],
+                                                     idx=idx.to(DEV))
+        rtol = 1e-4 if dtype == torch.float32 else 2e-2
+        close(itc, want["itc"], rtol, 1e-6, f"itc keep {keep} {dtype}")
+        close(itm, want["itm"], rtol, 1e-6, f"itm keep {keep} {dtype}")
+        del model
+
+
+
 @pytest.mark.parametrize("keep", [0.75, 0.5, 0.25])
 def test_pruned_inference_equals_masked_dense_at_every_sparsity_of_the_sweep(keep):
     """BASELINE configs[4] (25 / 50 / 75 % retained heads + FFN units): the physically pruned model (utils/xvlm_utils.py:37-145:
