@@ -883,129 +883,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp192_kernel(GemmP g) {
   else pp_epilogue<false, false, 2>(g, accL, accH, ib, jb, lane_e, swin);
 }
 
-// =============================================================================================
-// Register-staged form of the 192 x 256 kernel (gemm_bf16_pp192v_kernel, EVLM_PP192V=1): the operands travel HBM -> VGPRs
-// (global_load_dwordx4, SGPR base + 32-bit VGPR offset) -> LDS (ds_write_b128, lane-linear: the same LDS image and the same
-// source-side swizzle as the LDS-DMA form) instead of by global_load_lds.  In-kernel stamps put an LDS-DMA piece at 100-185
-// issue cycles inside a phase that also carries the fragment reads (MI355X_MICROARCH.md, LDS-DMA piece issue cost) - the
-// memory section of a phase then outlasts the partner wave's 16 MFMAs; a global_load + ds_write pair issues in a fraction.
-// Schedule (K tile t read from stage t & 1; every unit is WRITTEN into the other stage one K tile ahead of its use and
-// LOADED one K tile before that, into the registers its predecessor was just written from):
-//   phase A(t): wait QL(t+1) -> vmcnt(5) ; ds_write QL(t+1) ; load QL(t+2)
-//   phase B(t): wait PL PX(t+1) -> vmcnt(4) ; ds_write PL PX(t+1) ; load PL PX(t+2)
-//   phase C(t): wait QH(t+1) -> vmcnt(5) ; ds_write QH(t+1) ; load QH(t+2)
-// (tail, no further loads: 5 / 2 / 0).  7 x 4 staging registers per lane.  The loads and the LDS writes are inline asm
-// (the counted waits are placed by hand; the compiler must not insert its own, nor copy a register with a load in flight:
-// checked in the ISA by tools/check_pp192v_isa.py).  DIAG 1: no staging in the loop (timing floor of the K loop: wrong
-// results), DIAG 2: loads without the LDS writes (wrong results).
-// =============================================================================================
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-#define PPV_LOAD(dst, base, so, kel)                                                                                \
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(so), "s"((base) + (size_t)(kel)) : "memory")
-#define PPV_STORE(addr, src, imm)                                                                                   \
-  asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(src), "n"(imm) : "memory")
-
-#define PPV_KTILE(BUF, t)                                                                                  \
-  do {                                                                                                     \
-    constexpr int B0 = (BUF) * PPX_STAGE;                                                                  \
-    const unsigned wb = (BUF) ? lw0 : lw1;             /* the OTHER stage */                               \
-    const bool n1 = (t) + 1 < nt, n2 = (t) + 2 < nt;                                                       \
-    /* ---- phase A: i[0..63] x j-lo ; QL(t+1) -> LDS, QL(t+2) -> registers ---- */                        \
-    if (DIAG == 0 && n1) { if (n2) PP_WAIT(5); else PP_WAIT(5);                                            \
-      PPV_STORE(wb, rQL[0], XOFF_QL); PPV_STORE(wb, rQL[1], XOFF_QL + 8192); }                             \
-    if (DIAG != 1 && n2) { PPV_LOAD(rQL[0], Qk, src.ql[0], ((t) + 2) * kq); PPV_LOAD(rQL[1], Qk, src.ql[1], ((t) + 2) * kq); } \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
-      qlo[a][0] = pp_frag<QT>(smem, B0 + XOFF_QL, qlb, a, 0);                                              \
-      qlo[a][1] = pp_frag<QT>(smem, B0 + XOFF_QL, qlb, a, 1); }                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                     \
-    _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                        \
-      pf[b][0] = pp_frag<false>(smem, B0 + XOFF_PL, plb, b, 0);                                            \
-      pf[b][1] = pp_frag<false>(smem, B0 + XOFF_PL, plb, b, 1); }                                          \
-    PP_MFMA_BEGIN(); PP_QUAD(accL, 0, qlo); PP_MFMA_END();                                                 \
-    /* ---- phase B: i[0..63] x j-hi ; PL PX(t+1) -> LDS, PL PX(t+2) -> registers ---- */                  \
-    if (DIAG == 0 && n1) { if (n2) PP_WAIT(4); else PP_WAIT(2);                                            \
-      PPV_STORE(wb, rPL[0], XOFF_PL); PPV_STORE(wb, rPL[1], XOFF_PL + 8192); PPV_STORE(wb, rPX, XOFF_PX); } \
-    if (DIAG != 1 && n2) { PPV_LOAD(rPL[0], Pk, src.pl[0], ((t) + 2) * kp); PPV_LOAD(rPL[1], Pk, src.pl[1], ((t) + 2) * kp); \
-                           PPV_LOAD(rPX, Pk, src.ph[0], ((t) + 2) * kp); }                                 \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
-      qhi[a][0] = pp_frag<QT>(smem, B0 + XOFF_QH, qlb, a, 0);                                              \
-      qhi[a][1] = pp_frag<QT>(smem, B0 + XOFF_QH, qlb, a, 1); }                                            \
-    PP_MFMA_BEGIN(); PP_QUAD(accL, 2, qhi); PP_MFMA_END();                                                 \
-    /* ---- phase C: i[64..95] x (j-lo, j-hi) ; QH(t+1) -> LDS, QH(t+2) -> registers ---- */               \
-    if (DIAG == 0 && n1) { if (n2) PP_WAIT(5); else PP_WAIT(0);                                            \
-      PPV_STORE(wb, rQH[0], XOFF_QH); PPV_STORE(wb, rQH[1], XOFF_QH + 8192); }                             \
-    if (DIAG != 1 && n2) { PPV_LOAD(rQH[0], Qk, src.qh[0], ((t) + 2) * kq); PPV_LOAD(rQH[1], Qk, src.qh[1], ((t) + 2) * kq); } \
-    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                        \
-      px[b][0] = pp_frag<false>(smem, B0 + XOFF_PX, pxb, b, 0);                                            \
-      px[b][1] = pp_frag<false>(smem, B0 + XOFF_PX, pxb, b, 1); }                                          \
-    PP_MFMA_BEGIN();                                                                                       \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                          \
-    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                        \
-      accH[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qlo[a][ks], px[b][ks], accH[a][b], 0, 0, 0);    \
-      accH[2 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qhi[a][ks], px[b][ks], accH[2 + a][b], 0, 0, 0); } \
-    PP_MFMA_END();                                                                                         \
-  } while (0)
-
-template <bool QT, int DIAG>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_pp192v_kernel(GemmP g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x 56 KiB
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int nt = g.K >> 6;
-  int ti, tj;
-  pp_tile_ij(g, blockIdx.x, g.tiles_i * g.tiles_j, ti, tj);
-  const int i0 = ti * 192, j0 = tj * 256;
-  const int kp = 64, kq = QT ? 64 * g.ldq : 64;
-  const bf16* Pk = reinterpret_cast<const bf16*>(g.P);
-  const bf16* Qk = reinterpret_cast<const bf16*>(g.Q);
-  PPSrc src;
-  pp_src_192<QT>(g, i0, j0, tid, wave, src);
-  const int plb = pp_lane_base<false, true>(lane, wr), qlb = pp_lane_base<QT, false>(lane, wc);
-  const int pxb = pp_lane_base<false, false>(lane, wr);
-  // LDS byte address of this lane's 16 bytes inside piece 0 of a unit of stage 0 / 1 (piece 1: + 8 KiB)
-  const unsigned sm0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned lw0 = sm0 + wave * 1024 + lane * 16, lw1 = lw0 + PPX_STAGE;
-  f32x4 accL[4][4], accH[4][4];
-  bf16x8 pf[4][2], px[2][2], qlo[2][2], qhi[2][2];
-  v4u rPL[2], rPX, rQL[2], rQH[2];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { accL[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; accH[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  // prologue: K tile 0 through the registers into stage 0, K tile 1 into the registers (in flight); nt >= 2
-  PPV_LOAD(rQL[0], Qk, src.ql[0], 0); PPV_LOAD(rQL[1], Qk, src.ql[1], 0);
-  PPV_LOAD(rPL[0], Pk, src.pl[0], 0); PPV_LOAD(rPL[1], Pk, src.pl[1], 0); PPV_LOAD(rPX, Pk, src.ph[0], 0);
-  PPV_LOAD(rQH[0], Qk, src.qh[0], 0); PPV_LOAD(rQH[1], Qk, src.qh[1], 0);
-  PP_WAIT(0);
-  PPV_STORE(lw0, rQL[0], XOFF_QL); PPV_STORE(lw0, rQL[1], XOFF_QL + 8192);
-  PPV_STORE(lw0, rPL[0], XOFF_PL); PPV_STORE(lw0, rPL[1], XOFF_PL + 8192); PPV_STORE(lw0, rPX, XOFF_PX);
-  PPV_STORE(lw0, rQH[0], XOFF_QH); PPV_STORE(lw0, rQH[1], XOFF_QH + 8192);
-  PPV_LOAD(rQL[0], Qk, src.ql[0], kq); PPV_LOAD(rQL[1], Qk, src.ql[1], kq);
-  PPV_LOAD(rPL[0], Pk, src.pl[0], kp); PPV_LOAD(rPL[1], Pk, src.pl[1], kp); PPV_LOAD(rPX, Pk, src.ph[0], kp);
-  PPV_LOAD(rQH[0], Qk, src.qh[0], kq); PPV_LOAD(rQH[1], Qk, src.qh[1], kq);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's share of K tile 0 is in LDS
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one barrier behind group 0
-  __builtin_amdgcn_sched_barrier(0);
-  int t = 0;
-  for (; t + 1 < nt; t += 2) {
-    PPV_KTILE(0, t);
-    PPV_KTILE(1, t + 1);
-  }
-  if (t < nt) PPV_KTILE(0, t);
-  if (wr == 0) __builtin_amdgcn_s_barrier();    // re-align the groups: every LDS read of the K loop has retired
-  __builtin_amdgcn_sched_barrier(0);
-  const int ib = i0 + wr * 96, jb = j0 + wc * 64;
-  const bool full = (i0 + 192 <= g.I) && (j0 + 256 <= g.J);
-  int tid_e = tid;
-  asm volatile("" : "+v"(tid_e));
-  const int lane_e = tid_e & 63;
-  char* swin = smem + wave * 4096;              // (stage 0 is dead: one tile per workgroup)
-  if (full) pp_epilogue<true, false, 2>(g, accL, accH, ib, jb, lane_e, swin);
-  else pp_epilogue<false, false, 2>(g, accL, accH, ib, jb, lane_e, swin);
-}
-
 template <bool PT, bool QT, int OUT>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
   pp256_body<PT, QT, OUT, false>(g, nullptr);
@@ -1125,28 +1002,6 @@ int evlm_gemm_pp192_launch(GemmP& g, int qt, hipStream_t stream) {
     }                                                                                                         \
     hipLaunchKernelGGL((gemm_bf16_pp192_kernel<QT_>), grid, block, lds, stream, g);                           \
   } while (0)
-  static const int vmode = getenv("EVLM_PP192V") ? atoi(getenv("EVLM_PP192V")) : 0;     // register-staged form (experimental)
-  static const int vdiag = getenv("EVLM_PP192V_DIAG") ? atoi(getenv("EVLM_PP192V_DIAG")) : 0;
-#define PP_LAUNCH_V(QT_, DIAG_)                                                                               \
-  do {                                                                                                        \
-    static bool attr_set = false;                                                                             \
-    if (!attr_set) {                                                                                          \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp192v_kernel<QT_, DIAG_>),  \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);                    \
-      if (e != hipSuccess) return evlm_set_error("evlm_gemm: cannot reserve 112 KiB LDS: %s", hipGetErrorString(e)); \
-      attr_set = true;                                                                                        \
-    }                                                                                                         \
-    hipLaunchKernelGGL((gemm_bf16_pp192v_kernel<QT_, DIAG_>), grid, block, lds, stream, g);                   \
-  } while (0)
-  if (vmode && !qt) {
-    if (vdiag == 1) PP_LAUNCH_V(false, 1); else if (vdiag == 2) PP_LAUNCH_V(false, 2); else PP_LAUNCH_V(false, 0);
-    return 0;
-  }
-  if (vmode && qt) {
-    if (vdiag == 1) PP_LAUNCH_V(true, 1); else if (vdiag == 2) PP_LAUNCH_V(true, 2); else PP_LAUNCH_V(true, 0);
-    return 0;
-  }
-#undef PP_LAUNCH_V
   if (qt) PP_LAUNCH_X(true); else PP_LAUNCH_X(false);
 #undef PP_LAUNCH_X
   return 0;

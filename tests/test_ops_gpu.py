@@ -1071,8 +1071,9 @@ def test_recomputing_attention_backward_needs_no_stored_map_and_tightens_the_gra
     l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
     e_rc, e_st = l2(gx_rc, xr.grad), l2(gx_st, xr.grad)
     assert rel_err(gx_rc, xr.grad) < 1.2e-2 and e_rc < 6e-3, (e_rc, e_st)
-    if case == "vit197":                                   # long rows: the bf16 map costs the query / key gradient visibly
-        assert e_rc < 0.8 * e_st, (e_rc, e_st)
+    if self_attn:                                          # the query / key part: P .* (dP - delta), where the bf16 map costs
+        qk_rc, qk_st = l2(gx_rc[..., :2 * d], xr.grad[..., :2 * d]), l2(gx_st[..., :2 * d], xr.grad[..., :2 * d])
+        assert qk_rc < 6e-3 and qk_rc <= qk_st * 1.02, (qk_rc, qk_st)
     if kvr is not None:
         k_rc, k_st = l2(gkv_rc, kvr.grad), l2(gkv_st, kvr.grad)
         assert rel_err(gkv_rc, kvr.grad) < 1.2e-2 and k_rc < 6e-3, (k_rc, k_st)
