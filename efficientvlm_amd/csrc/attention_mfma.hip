@@ -19,6 +19,13 @@ struct MAttnF {
 };
 
 #define DH 64
+// 2^x for x <= 0 (softmax numerators, recomputed probabilities): the bare v_exp_f32 (1 ulp; results below 2^-126 flush to
+// zero) instead of exp2f()'s range handling - 8 VALU issue slots per element saved in kernels that are VALU-bound
+#ifdef EVLM_SLOW_EXP2
+#define EXP2(x) exp2f(x)
+#else
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
 
 // 16-byte chunk swizzles of the two row-major [key][64] bf16 tiles (128-byte rows)
 __device__ __forceinline__ int k_swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }          // ds_read_b128 rows
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      acc[t][r] = exp2f(acc[t][r] - m);
+      acc[t][r] = EXP2(acc[t][r] - m);
       sum += acc[t][r];
     }
   sum += __shfl_xor(sum, 16, 64);
@@ -268,7 +275,9 @@ static int launch_fwd(const MAttnF& f, hipStream_t stream) {
   constexpr int MAXW = NT <= 14 ? 16 : (NT <= 26 ? 8 : 4);   // register budget: 16 (8) waves/workgroup need <= 128 (256) VGPRs
   constexpr bool SEQ = NT > 38;                        // 2 x NT x 2 KiB of K and V no longer fit in 160 KiB of LDS
   const size_t lds = (size_t)(SEQ ? 1 : 2) * NT * 16 * 128 + (size_t)NT * 16 * sizeof(float) + 16;
-  const int nw = imin(MAXW, (f.Lq + 15) / 16);         // waves per workgroup (16 queries each)
+  static const int nw_cap = getenv("EVLM_ATTN_FWD_NW") ? atoi(getenv("EVLM_ATTN_FWD_NW")) : 0;     // (tuning aid)
+  int nw = imin(MAXW, (f.Lq + 15) / 16);               // waves per workgroup (16 queries each)
+  if (nw_cap > 0 && !SEQ) nw = imin(nw, nw_cap);
   dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
   if constexpr (NT <= 14) {
     if (f.lse) {
@@ -322,7 +331,7 @@ __device__ __forceinline__ void recompute_p(const char* Ks, const float* Ms, con
     for (int r = 0; r < 4; ++r) {
       float add = mk[r];
       if (causal && tile_key0(t, g) + r > q) add = fminf(add, -10000.0f);
-      p[hh * 4 + r] = qok ? exp2f(fmaf(sa[r], sc, add * LOG2E) - lse_q) : 0.f;
+      p[hh * 4 + r] = qok ? EXP2(fmaf(sa[r], sc, add * LOG2E) - lse_q) : 0.f;
     }
   }
 }
