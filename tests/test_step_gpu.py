@@ -288,7 +288,9 @@ def test_benchmarked_configuration_matches_the_oracle(B):
     import json, os
     if os.environ.get("EVLM_DUMP_GRAD_STATS"):
         with open(os.environ["EVLM_DUMP_GRAD_STATS"], "w") as f:
-            json.dump({"global_cos": num / math.sqrt(da * db), "stats": sorted(stats, reverse=True)}, f)
+            json.dump({"global_cos": num / math.sqrt(da * db), "stats": sorted(stats, reverse=True),
+                       "loss_rel_err": {n: abs(a - b) / abs(b) for n, a, b in zip(("total", "itc", "itm", "mlm", "kd"), got, want)},
+                       "kd_rel_err": {k: abs(v - float(okd[k])) / (abs(float(okd[k])) + 1e-12) for k, v in got_kd.items()}}, f)
     # The whole gradient the optimiser sees, and every tensor individually.  Measured on MI355X (profiles/r02_grad_parity.json):
     # global cosine 0.99988, median relative L2 error 1.6 %; the noisiest tensors are the query / key projections (their
     # gradient is P .* (dP - delta), a cancellation of bf16-stored probabilities: 13-17 %) and the first ViT layer / patch

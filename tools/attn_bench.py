@@ -28,7 +28,7 @@ def timeit(f, n=20):
 
 
 def report(name, us, mb):
-    print(f"{tag:10s} {name:58s} {us:8.1f} us   {mb:7.1f} MB algorithmic = {mb / us * 1e-3 if us else 0:5.2f} TB/s", flush=True)
+    print(f"{tag:10s} {name:58s} {us:8.1f} us   {mb:7.1f} MB algorithmic = {mb / us if us else 0:5.2f} TB/s", flush=True)
 
 
 def self_case(B, L, label):
