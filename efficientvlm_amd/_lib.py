@@ -41,7 +41,7 @@ class AttnFwdArgs(C.Structure):
                 ("Q", _vp), ("K", _vp), ("V", _vp), ("kv_index", _vp), ("mask", _vp), ("head_gate", _vp),
                 ("scale", _f), ("O", _vp), ("P", _vp), ("causal", _i),
                 ("dropout_p", _f), ("rng_state", _vp), ("call_id", C.c_uint32),
-                ("kd_teacher", _vp), ("kd_loss", _vp), ("kd_weight", _f), ("lse", _vp)]
+                ("kd_teacher", _vp), ("kd_loss", _vp), ("kd_weight", _f), ("lse", _vp), ("Bkv", _i)]
 
 
 class AttnBwdArgs(C.Structure):

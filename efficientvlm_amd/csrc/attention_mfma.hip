@@ -19,6 +19,7 @@ struct MAttnF {
 };
 
 #define DH 64
+#define LOG2E 1.44269504088896341f
 // 2^x for x <= 0 (softmax numerators, recomputed probabilities): the bare v_exp_f32 (1 ulp; results below 2^-126 flush to
 // zero) instead of exp2f()'s range handling - 8 VALU issue slots per element saved in kernels that are VALU-bound
 #ifdef EVLM_SLOW_EXP2
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
     for (int r = 0; r < 4; ++r) {
       float add = mk[r];
       if (a.causal && tile_key0(t, g) + r > q) add = fminf(add, -10000.0f);   // decoder: keys after the query
-      acc[t][r] = acc[t][r] * sc + add * 1.44269504088896341f;
+      acc[t][r] = fmaf(acc[t][r], sc, add * LOG2E);     // (explicit fma: the recomputing backward forms the same number)
       m = fmaxf(m, acc[t][r]);
     }
   }
@@ -270,6 +271,144 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   }
 }
 
+// Cross-attention with a shared K/V index (kv_index: the image tokens of the positive / hard-negative / MLM fusion rows):
+// ONE workgroup per (K/V row, head) stages K and V once and serves EVERY query batch that attends to them - found with a
+// ballot over the index, 64 entries at a time; the (query batch, 16-query tile) tasks go round the waves.  The per-batch
+// kernel above stages the same 50 KiB once per text row (4x per image in the GD step) with two waves per workgroup to use
+// them.  Each wave keeps the additive mask row of its current query batch in a private LDS strip.
+template <int NT, int NW, bool LSE>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_kernel(MAttnF a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;                                       // [NT*16][64] bf16, k_swz
+  char* Vs = smem + NT * 16 * 128;                       // [NT*16][64] bf16, v_swz
+  const int bkv = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
+  float* Ms = reinterpret_cast<float*>(smem + 2 * NT * 16 * 128) + wave * NT * 16;     // this wave's mask strip
+  stage_rows<SW_K>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
+  stage_rows<SW_V>(a.V + (size_t)bkv * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
+  stage_wait();
+  __syncthreads();
+  const int qtiles = (a.Lq + 15) >> 4;
+  const float sc = a.scale * 1.44269504088896341f;
+  int task = 0;                                          // running (query batch, tile) counter: wave w takes task % NW == w
+  for (int b0 = 0; b0 < a.B; b0 += 64) {
+    unsigned long long hits = __ballot(b0 + lane < a.B && a.kv_index[min(b0 + lane, a.B - 1)] == bkv);
+    while (hits) {                                       // wave-uniform, identical in every wave
+      const int b = b0 + __builtin_amdgcn_readfirstlane(__ffsll((long long)hits) - 1);
+      hits &= hits - 1;
+      bool mask_ready = false;
+      for (int qt = 0; qt < qtiles; ++qt, ++task) {
+        if (task % NW != wave) continue;
+        if (!mask_ready) {                               // (in-order LDS: the strip is complete before this wave reads it)
+          for (int k = lane; k < NT * 16; k += 64)
+            Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
+          mask_ready = true;
+        }
+        const int q = qt * 16 + ql;
+        const bool qok = q < a.Lq;
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (qok) v = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + ks * 32 + g * 8);
+          qf[ks] = *reinterpret_cast<bf16x8*>(&v);
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Ks, t, ks, lane), qf[ks], acc[t], 0, 0, 0);
+        }
+        float m = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + tile_key0(t, g));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[t][r] = fmaf(acc[t][r], sc, mk[r] * LOG2E);
+            m = fmaxf(m, acc[t][r]);
+          }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[t][r] = EXP2(acc[t][r] - m);
+            sum += acc[t][r];
+          }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        if (LSE && qok && g == 0) a.lse[((size_t)b * a.H + h) * a.Lq + q] = m + __log2f(sum);
+        bf16x4 pk[NT];
+        bf16* Pr = a.P ? a.P + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr : nullptr;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pk[t][r] = (bf16)(acc[t][r] * inv);
+        }
+#pragma unroll
+        for (int s = 0; s < NT / 2; ++s) {
+          const int kcol = s * 32 + g * 8;
+          if (Pr && qok && kcol < a.ldpr) {
+            bf16x8 pp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pp[r] = pk[2 * s][r]; pp[4 + r] = pk[2 * s + 1][r]; }
+            *reinterpret_cast<bf16x8*>(Pr + kcol) = pp;
+          }
+        }
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NT / 2; ++s) {
+          bf16x8 pb;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pb[r] = pk[2 * s][r]; pb[4 + r] = pk[2 * s + 1][r]; }
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Vs, 2 * s, 2 * s + 1, dt, lane), pb, o[dt], 0, 0, 0);
+        }
+        if (qok) {
+          const float gz = a.gate ? a.gate[h] : 1.0f;
+          bf16* Or = a.O + ((size_t)b * a.Lq + q) * a.ldo + h * DH;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            bf16x4 ov = {(bf16)(o[dt][0] * gz), (bf16)(o[dt][1] * gz), (bf16)(o[dt][2] * gz), (bf16)(o[dt][3] * gz)};
+            *reinterpret_cast<bf16x4*>(Or + dt * 16 + g * 4) = ov;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+static bool launch_fwd_grouped(const MAttnF& f, int Bkv, hipStream_t stream) {
+  // the grouped form pays when several query batches share a K/V row and a batch is a few query tiles (text rows on image
+  // tokens); causal masks and the fused map distillation stay on the per-batch kernel
+  const char* env = getenv("EVLM_ATTN_NO_GROUP");         // (A/B switch, read per call: the tests toggle it)
+  if ((env && atoi(env)) || !f.kv_index || Bkv <= 0 || Bkv >= f.B || f.Lq > 64 || f.causal || f.Pt) return false;
+  constexpr int NW = 8;
+  const size_t lds = (size_t)2 * NT * 16 * 128 + (size_t)NW * NT * 16 * sizeof(float);
+  dim3 grid(1, f.H, Bkv), block(64 * NW);
+  if (f.lse) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)attn_fwd_grouped_kernel<NT, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_fwd_grouped_kernel<NT, NW, true>), grid, block, lds, stream, f);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)attn_fwd_grouped_kernel<NT, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_fwd_grouped_kernel<NT, NW, false>), grid, block, lds, stream, f);
+  }
+  return true;
+}
+
 template <int NT>
 static int launch_fwd(const MAttnF& f, hipStream_t stream) {
   constexpr int MAXW = NT <= 14 ? 16 : (NT <= 26 ? 8 : 4);   // register budget: 16 (8) waves/workgroup need <= 128 (256) VGPRs
@@ -308,7 +447,6 @@ struct MAttnB {
   const float* lse; const float* mask; int causal; bf16* Pw;
 };
 
-#define LOG2E 1.44269504088896341f
 // mask row of one (batch): Ms[k] = additive mask of key k (0 without one), -1e30 beyond Lk - as the forward kernel builds it
 __device__ __forceinline__ void stage_mask(const float* mask, int b, int Lk, int n, float* Ms) {
   for (int k = threadIdx.x; k < n; k += blockDim.x)
@@ -1011,7 +1149,8 @@ int evlm_attention_fwd_mfma(const evlm_attn_fwd_args* a, hipStream_t stream, int
   f.lse = a->lse;
   if (a->lse && a->Lk > 224) return evlm_set_error("evlm_attention_fwd: the lse form serves Lk <= 224 (got %d)", a->Lk);
   if (a->kd_teacher && !a->kd_loss) return evlm_set_error("evlm_attention_fwd: kd_teacher without kd_loss");
-  if (a->Lk <= 32) launch_fwd<2>(f, stream);
+  if (a->Lk > 64 && a->Lk <= 224 && launch_fwd_grouped<14>(f, a->Bkv, stream)) {}
+  else if (a->Lk <= 32) launch_fwd<2>(f, stream);
   else if (a->Lk <= 64) launch_fwd<4>(f, stream);
   else if (a->Lk <= 224) launch_fwd<14>(f, stream);
   else if (a->Lk <= 416) launch_fwd<26>(f, stream);

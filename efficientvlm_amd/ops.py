@@ -780,7 +780,7 @@ class _Attention(torch.autograd.Function):
                           ldo=H * dh, ldpr=Lkp, Q=C.c_void_p(qbuf.data_ptr() + q_off * es),
                           K=C.c_void_p(kvbuf.data_ptr() + k_off * es), V=C.c_void_p(kvbuf.data_ptr() + v_off * es),
                           kv_index=L.ptr(kv_index), mask=L.ptr(m32), head_gate=L.ptr(g32), scale=scale, O=L.ptr(O),
-                          P=L.ptr(Pbuf), causal=int(bool(causal)), lse=L.ptr(lse))
+                          P=L.ptr(Pbuf), causal=int(bool(causal)), lse=L.ptr(lse), Bkv=Bkv if kv_index is not None else 0)
         kd = kd_base = None
         if kd_teacher is not None:                # fused map distillation: the teacher's (padded) map, read once in-kernel
             kd_base = _padded_base(kd_teacher, Lkp) if kd_teacher.shape[-1] != Lkp else kd_teacher

@@ -166,6 +166,9 @@ typedef struct {
      (the reference keeps softmax in fp32 under Apex O1; a bf16-stored P costs 13-36 % of the q / k gradients' norm).
      bf16 MFMA path with Lk <= 224 and no dropout only: evlm_attention_lse_supported(). */
   float* lse;
+  int Bkv;                      /* with kv_index: number of K/V batch rows (0 = unknown).  When given, problems in which
+                                   several short query batches share a K/V row run one workgroup per (K/V row, head) that
+                                   stages K and V once for all of them */
 } evlm_attn_fwd_args;
 int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream);
 

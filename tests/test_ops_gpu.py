@@ -1079,6 +1079,46 @@ def test_recomputing_attention_backward_needs_no_stored_map_and_tightens_the_gra
         assert rel_err(gkv_rc, kvr.grad) < 1.2e-2 and k_rc < 6e-3, (k_rc, k_st)
 
 
+@pytest.mark.parametrize("B,Bkv,Lq,Lk,with_mask", [(7, 3, 30, 197, False), (256, 64, 30, 197, True), (9, 2, 17, 100, True),
+                                                   (5, 4, 64, 224, False)])
+def test_grouped_cross_attention_forward_is_bit_identical_to_the_per_batch_kernel(B, Bkv, Lq, Lk, with_mask, monkeypatch):
+    """attn_fwd_grouped_kernel (one workgroup per (K/V row, head) serving every query batch that shares it) against the
+    per-batch kernel: same arithmetic per (batch, head, query) - identical context, map and row lse; a K/V row nobody
+    attends to and uneven sharing included; forward + backward through both"""
+    o = ops()
+    H, dh = 12, 64
+    d = H * dh
+    g = torch.Generator().manual_seed(77 + B)
+    q0 = rnd((B, Lq, d), torch.bfloat16, g)
+    kv0 = rnd((Bkv, Lk, 2 * d), torch.bfloat16, g)
+    idx = torch.randint(0, max(1, Bkv - 1), (B,), generator=g).to(DEV)          # the last K/V row is never used
+    mask = None
+    if with_mask:
+        mask = torch.zeros(B, Lk)
+        mask[::3, Lk - 5:] = -10000.0
+        mask = mask.to(DEV)
+    gO = rnd((B, Lq, d), torch.bfloat16, g)
+
+    def run(no_group, want):
+        monkeypatch.setenv("EVLM_ATTN_NO_GROUP", "1" if no_group else "0")
+        q, kv = q0.clone().requires_grad_(True), kv0.clone().requires_grad_(True)
+        O, P = o.cross_attention(q, kv, H, dh, 0.125, mask=mask, want_probs=want, kv_index=idx)
+        (O.float() * gO.float()).sum().backward()
+        return O.detach(), (P.detach() if P is not None else None), q.grad, kv.grad
+
+    for want in (True, False):
+        a, b = run(False, want), run(True, want)
+        assert torch.equal(a[0], b[0])
+        assert (a[1] is None) == (b[1] is None) and (a[1] is None or torch.equal(a[1], b[1]))
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])       # (same lse -> same recomputed probabilities)
+    with torch.no_grad():
+        monkeypatch.setenv("EVLM_ATTN_NO_GROUP", "0")
+        O1, P1 = o.cross_attention(q0, kv0, H, dh, 0.125, mask=mask, want_probs=True, kv_index=idx)
+        monkeypatch.setenv("EVLM_ATTN_NO_GROUP", "1")
+        O2, P2 = o.cross_attention(q0, kv0, H, dh, 0.125, mask=mask, want_probs=True, kv_index=idx)
+    assert torch.equal(O1, O2) and torch.equal(P1, P2)
+
+
 def test_attention_lse_form_refuses_what_it_cannot_serve():
     """C ABI: the lse / recompute form exists for bf16, head dim 64, Lk <= 224 without dropout; anything else answers with
     an error code - never a fault - and evlm_attention_lse_supported says so beforehand"""

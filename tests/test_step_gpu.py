@@ -234,8 +234,9 @@ def test_benchmarked_configuration_matches_the_oracle(B):
     ahead, deferred grouped weight gradients, the 256 x 256 GEMM routing - held to the fp32 CPU oracle on the same
     weights, batch and hard negatives (GeneralDistill.py:286-376): step-0 losses, every KD term, and the gradients the
     optimiser consumes (read back from its flat slabs after the graph replay).  bf16 storage has 8 significand bits:
-    losses within 1e-2, hidden-state KD terms within 3e-2 (attention-map and logit terms 0.15), the whole gradient at cosine > 0.999 with the oracle's, median
-    per-tensor error < 3 % of the norm (per-tensor bounds in the body)."""
+    losses within 1e-3 (measured 1e-6 ... 2e-5), every KD term within 1e-2 / the logit terms 5e-2 (measured <= 2.4e-4 /
+    1.2e-2: since round 3 the attention backward rebuilds the probabilities in fp32 and the fused map term is formed from
+    them), the whole gradient at cosine > 0.9999 with the oracle's, per-tensor bounds in the body."""
     from efficientvlm_amd import ops
     from efficientvlm_amd.trainer import GDTrainer
     geom = synth.GEOMS["full"]
@@ -266,13 +267,12 @@ def test_benchmarked_configuration_matches_the_oracle(B):
     want = [float(ototal), float(oS["loss"]["loss_itc"]), float(oS["loss"]["loss_itm"]), float(oS["loss"]["loss_mlm"]),
             float(omix["loss_kd"])]
     for name, a, b in zip(("total", "itc", "itm", "mlm", "kd"), got, want):
-        assert abs(a - b) <= 1e-2 * abs(b), f"{name}: {a} vs oracle {b}"
+        assert abs(a - b) <= 1e-3 * abs(b), f"{name}: {a} vs oracle {b}"
     assert set(got_kd) == {k for k, v in okd.items() if torch.is_tensor(v)}
     for k, v in got_kd.items():
-        # attention-map terms: the maps are STORED in bf16 (8 significand bits) and the term is a mean of squared
-        # differences of nearly equal probabilities, so it carries the rounding noise of both maps
-        # (and the logit terms are KL divergences of nearly identical distributions: same reason)
-        rt = 0.15 if (k.endswith("_attn") or k.endswith("_logits")) else 3e-2
+        # (logit terms: KL divergences of nearly identical distributions formed from bf16 logits; the text-side map terms
+        # still read bf16-stored maps, the image-map term is formed in-kernel from fp32 probabilities)
+        rt = 5e-2 if k.endswith("_logits") else 1e-2
         assert abs(v - float(okd[k])) <= rt * abs(float(okd[k])) + 1e-6, f"kd.{k}: {v} vs oracle {float(okd[k])}"
     stats, num, da, db = [], 0.0, 0.0, 0.0
     gmax = max(float(l.grad.norm()) for l in leaves.values() if l.grad is not None)
@@ -291,14 +291,18 @@ def test_benchmarked_configuration_matches_the_oracle(B):
             json.dump({"global_cos": num / math.sqrt(da * db), "stats": sorted(stats, reverse=True),
                        "loss_rel_err": {n: abs(a - b) / abs(b) for n, a, b in zip(("total", "itc", "itm", "mlm", "kd"), got, want)},
                        "kd_rel_err": {k: abs(v - float(okd[k])) / (abs(float(okd[k])) + 1e-12) for k, v in got_kd.items()}}, f)
-    # The whole gradient the optimiser sees, and every tensor individually.  Measured on MI355X (profiles/r02_grad_parity.json):
-    # global cosine 0.99988, median relative L2 error 1.6 %; the noisiest tensors are the query / key projections (their
-    # gradient is P .* (dP - delta), a cancellation of bf16-stored probabilities: 13-17 %) and the first ViT layer / patch
-    # embedding, which sit behind six of those (up to 36 %, cosine 0.934).
+    # The whole gradient the optimiser sees, and every tensor individually.  Measured on MI355X (profiles/r03_grad_parity.json;
+    # r02 in brackets, when the backward read bf16-stored probabilities): global cosine 0.999988 (0.99988), median relative L2
+    # error 0.55 % (1.6 %), 90th percentile 1.1 % (14.8 %), worst tensor 17 % (36 %).  The noisiest tensors are now the two
+    # ITC projection heads (13-17 %: their gradient is (softmax - labels) of logits that amplify the bf16 noise of the CLS
+    # rows by 1 / temp = 14) and what sits behind all six ViT layers (class / position embeddings 11-13 %, layer-0 query /
+    # key projections 8-9 %, every other query / key projection <= 5.3 %).
     rels = sorted(r for r, _, _ in stats)
-    assert num / math.sqrt(da * db) > 0.999, (num / math.sqrt(da * db), worst)
-    assert all(r < 0.45 and c > 0.90 for r, c, _ in stats), worst
-    assert rels[len(rels) // 2] < 0.03 and rels[int(0.9 * len(rels))] < 0.2, (rels[len(rels) // 2], rels[int(0.9 * len(rels))])
+    assert num / math.sqrt(da * db) > 0.9999, (num / math.sqrt(da * db), worst)
+    assert all(r < 0.25 and c > 0.97 for r, c, _ in stats), worst
+    qk = [r for r, _, n in stats if any(t in n for t in ("q_proj", "k_proj", ".query.", ".key."))]
+    assert max(qk) < 0.12 and sorted(qk)[len(qk) // 2] < 0.02, sorted(qk)[-3:]
+    assert rels[len(rels) // 2] < 0.01 and rels[int(0.9 * len(rels))] < 0.03, (rels[len(rels) // 2], rels[int(0.9 * len(rels))])
 
     # the routing this configuration is benchmarked with: the dominant kernels must be the ones that served this step
     ops.GEMM_PROFILE = []
