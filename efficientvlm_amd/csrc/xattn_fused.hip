@@ -89,7 +89,7 @@ __device__ __forceinline__ void xa_attend(const XAttnP& a, const char* Ks, const
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        acc[t][r] = acc[t][r] * sc + mk[r] * 1.44269504088896341f;
+        acc[t][r] = fmaf(acc[t][r], sc, mk[r] * 1.44269504088896341f);   // (the forms of attention_mfma.hip: bit-identical maps)
         m = fmaxf(m, acc[t][r]);
       }
     }
@@ -100,7 +100,7 @@ __device__ __forceinline__ void xa_attend(const XAttnP& a, const char* Ks, const
     for (int t = 0; t < XA_NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        acc[t][r] = exp2f(acc[t][r] - m);
+        acc[t][r] = __builtin_amdgcn_exp2f(acc[t][r] - m);
         sum += acc[t][r];
       }
     sum += __shfl_xor(sum, 16, 64);
