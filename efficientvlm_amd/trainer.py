@@ -137,6 +137,93 @@ def broadcast_parameters(opt, src=0):
             ops.CACHE.refresh_slab(g["p"], g["pb"])
 
 
+def install_grad_stages(owner, opt, student, which="all"):
+    """Gradient exchange overlapped with backward.  Returns (stages, vision stage index | None): `stages` = slab ranges in
+    the order backward completes them; stage i < last is sent from a hook the moment it is complete (owner._stage_done(i)),
+    the last one after backward:
+      "vision": text / fusion encoder + heads, complete when backward enters the image encoder (tensor hook on the ViT
+                output, fired by the model through owner._on_vision_grad; the autograd engine runs every text-side node -
+                created later - before any ViT node);
+      ("vit", b): ViT layers >= b, hook on the input of layer b (6 layers: {4,5} + post-norm, then {2,3});
+      last: layers {0,1} + embeddings.
+    which = all | vit | vision | none drops hook points (their ranges ride with the next stage).  The eager step sends from
+    the hooks; GDTrainer's captured step (hipGraph segments) CUTS its capture at the same points, so both issue the same
+    collective sequence.  EVLM_DP_VIT_CUTS (e.g. "4,2,1") overrides the layer cuts."""
+    # (the L0 gate parameters and multipliers belong to no encoder: every gated layer - the first ViT layer included -
+    # contributes to their gradient, which is therefore complete only when backward is: they travel with the LAST stage)
+    is_l0 = lambda nme: nme.startswith("l0_module.")
+    early = opt.grad_ranges(lambda nme: not nme.startswith("vision_encoder.") and not is_l0(nme))
+    late = opt.grad_ranges(lambda nme: nme.startswith("vision_encoder."))
+    l0_ranges = opt.grad_ranges(is_l0)
+    points = [("vision", early)]
+    enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
+    vit_hooks = enc is not None and hasattr(enc, "grad_hooks") and len(enc.layers) >= 4
+    if vit_hooks:
+        n = len(enc.layers)
+        cuts = [n - n // 3, n - 2 * (n // 3)]              # 6 layers: hooks at 4 and 2
+        if os.environ.get("EVLM_DP_VIT_CUTS"):             # e.g. "4,2,1": a smaller last (exposed) stage
+            cuts = sorted({int(c) for c in os.environ["EVLM_DP_VIT_CUTS"].split(",") if 0 < int(c) < n}, reverse=True)
+        layer_of = lambda nme: int(nme.split("encoder.layers.")[1].split(".")[0]) if "encoder.layers." in nme else None
+        in_vit = lambda nme: nme.startswith("vision_encoder.")
+        hi = n
+        for b in cuts:
+            pred = (lambda lo_, hi_: lambda nme: in_vit(nme) and (
+                (layer_of(nme) is not None and lo_ <= layer_of(nme) < hi_) or
+                (hi_ == n and layer_of(nme) is None and "post_layernorm" in nme)))(b, hi)
+            points.append((("vit", b), opt.grad_ranges(pred)))
+            hi = b
+        rest = (lambda hi_: lambda nme: in_vit(nme) and not (
+            (layer_of(nme) is not None and layer_of(nme) >= hi_) or (layer_of(nme) is None and "post_layernorm" in nme)))(hi)
+        points.append((None, opt.grad_ranges(rest) + l0_ranges))
+    else:
+        points.append((None, late + l0_ranges))
+    active = {"all": lambda k: True, "vit": lambda k: k != "vision", "vision": lambda k: k == "vision",
+              "none": lambda k: False}[which]
+    stages, hooks, carry = [], [], []
+    for key, ranges in points:
+        carry = carry + list(ranges)
+        if key is None or active(key):
+            stages.append(carry)
+            hooks.append(key)
+            carry = []
+    vision_stage = None
+    if vit_hooks:
+        enc.grad_hooks = {}
+    for i, key in enumerate(hooks[:-1]):
+        if key == "vision":
+            vision_stage = i
+        else:
+            enc.grad_hooks[key[1]] = (lambda i_: lambda: owner._stage_done(i_))(i)
+    return stages, vision_stage
+
+
+class _StagedExchange:
+    """the sending side of install_grad_stages (shared by the three trainers); needs self.reducer, self._stages, self._sent and
+    self._cut (None outside a segmented capture)"""
+    _cut = None
+
+    def _stage_done(self, i):
+        """tensor hook: backward has finished with gradient stage i - send it under the rest of backward"""
+        if self._sent == i:
+            self._send(self._stages[i])
+            self._sent = i + 1
+
+    def _send(self, ranges):
+        ops.flush_wgrad()                 # the queued weight gradients of the stage must be in the slabs first
+        if self._cut is not None:         # capture pass of the segmented step: the graph segment ends here
+            self._cut(ranges)
+        else:
+            self.reducer.reduce_async(ranges)
+
+    def _reduce_rest(self):
+        """what backward has not sent from its hooks (the last stage; everything when no hook fired)"""
+        for i in range(self._sent, len(self._stages)):
+            self._send(self._stages[i])
+        self._sent = len(self._stages)
+        if self._cut is None:
+            self.reducer.finish()
+
+
 def teacher_map_filter(student, teacher, with_cross):
     """The KD terms read every k-th attention map of the (deeper) teacher (get_cor_teacher: map i*k + k-1 for student map i;
     GD reads no cross-attention map, the ITR fine-tune does): tell the frozen teacher's encoders to materialise only those.
@@ -160,7 +247,7 @@ def teacher_map_filter(student, teacher, with_cross):
             te.cross_keep = ({l for l in keep if l >= ft} if with_cross else set())
 
 
-class GDTrainer:
+class GDTrainer(_StagedExchange):
     def __init__(self, student, teacher, lr=1e-4, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, temperature=1.0,
                  dtype=torch.bfloat16, use_graph=True, grad_compress=None, pipeline_teacher=False):
         """pipeline_teacher: the frozen teacher's forward for batch i+1 runs (second stream) WHILE the student trains on
@@ -182,61 +269,13 @@ class GDTrainer:
             grad_compress = torch.bfloat16           # opt-in: bf16 on the wire (default: fp32, as the reference's DDP)
         self.reducer = GradReducer(self.opt.flat_grads, compress=grad_compress, force=force)
         self.world = self.reducer.world
-        # Gradient exchange overlapped with backward.  `_stages` = slab ranges in the order backward completes them; stage
-        # i < last is sent from a hook the moment it is complete, the last one after backward:
-        #   "vision": text / fusion encoder + heads, complete when backward enters the image encoder (tensor hook on the
-        #             ViT output; the autograd engine runs every text-side node - created later - before any ViT node);
-        #   ("vit", b): ViT layers >= b, hook on the input of layer b (6 layers: {4,5} + post-norm, then {2,3});
-        #   last: layers {0,1} + embeddings.
-        # EVLM_DP_CUTS = all (default) | vit | vision | none drops hook points (their ranges ride with the next stage).
-        # The eager step sends from the hooks; the captured step (hipGraph segments) CUTS its capture at the same points,
-        # so both issue the same collective sequence.
+        # gradient exchange overlapped with backward: install_grad_stages (stages sent from hooks / capture cut there)
         self._stages, self._sent, self._cut = [list(self.opt.flat_grads)], 0, None
         self._vision_stage, self._join_at_vision = None, None
         self._seg, self._seg_pool, self._cap_stream = {}, None, None
         if self.reducer.active and hasattr(student, "on_vision_grad"):
-            which = os.environ.get("EVLM_DP_CUTS", "all")
-            early, late = self.opt.grad_segments()
-            points = [("vision", early)]
-            enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
-            vit_hooks = enc is not None and hasattr(enc, "grad_hooks") and len(enc.layers) >= 4
-            if vit_hooks:
-                n = len(enc.layers)
-                cuts = [n - n // 3, n - 2 * (n // 3)]              # 6 layers: hooks at 4 and 2
-                if os.environ.get("EVLM_DP_VIT_CUTS"):             # e.g. "4,2,1": a smaller last (exposed) stage
-                    cuts = sorted({int(c) for c in os.environ["EVLM_DP_VIT_CUTS"].split(",") if 0 < int(c) < n}, reverse=True)
-                layer_of = lambda nme: int(nme.split("encoder.layers.")[1].split(".")[0]) if "encoder.layers." in nme else None
-                in_vit = lambda nme: nme.startswith("vision_encoder.")
-                hi = n
-                for b in cuts:
-                    pred = (lambda lo_, hi_: lambda nme: in_vit(nme) and (
-                        (layer_of(nme) is not None and lo_ <= layer_of(nme) < hi_) or
-                        (hi_ == n and layer_of(nme) is None and "post_layernorm" in nme)))(b, hi)
-                    points.append((("vit", b), self.opt.grad_ranges(pred)))
-                    hi = b
-                rest = (lambda hi_: lambda nme: in_vit(nme) and not (
-                    (layer_of(nme) is not None and layer_of(nme) >= hi_) or (layer_of(nme) is None and "post_layernorm" in nme)))(hi)
-                points.append((None, self.opt.grad_ranges(rest)))
-            else:
-                points.append((None, late))
-            active = {"all": lambda k: True, "vit": lambda k: k != "vision", "vision": lambda k: k == "vision",
-                      "none": lambda k: False}[which]
-            stages, hooks, carry = [], [], []
-            for key, ranges in points:
-                carry = carry + list(ranges)
-                if key is None or active(key):
-                    stages.append(carry)
-                    hooks.append(key)
-                    carry = []
-            self._stages = stages
-            if vit_hooks:
-                enc.grad_hooks = {}
-            for i, key in enumerate(hooks[:-1]):
-                cb = (lambda i_: lambda: self._stage_done(i_))(i)
-                if key == "vision":
-                    self._vision_stage = i
-                else:
-                    enc.grad_hooks[key[1]] = cb
+            self._stages, self._vision_stage = install_grad_stages(self, self.opt, student,
+                                                                   os.environ.get("EVLM_DP_CUTS", "all"))
         if hasattr(student, "on_vision_grad"):
             student.on_vision_grad = self._on_vision_grad
         self.use_graph = use_graph
@@ -308,27 +347,6 @@ class GDTrainer:
             self._join_at_vision = None
         if self._vision_stage is not None:
             self._stage_done(self._vision_stage)
-
-    def _stage_done(self, i):
-        """tensor hook: backward has finished with gradient stage i (see __init__) - send it under the rest of backward"""
-        if self._sent == i:
-            self._send(self._stages[i])
-            self._sent = i + 1
-
-    def _send(self, ranges):
-        ops.flush_wgrad()                 # the queued weight gradients of the stage must be in the slabs first
-        if self._cut is not None:         # capture pass of the segmented step: the graph segment ends here
-            self._cut(ranges)
-        else:
-            self.reducer.reduce_async(ranges)
-
-    def _reduce_rest(self):
-        """what backward has not sent from its hooks (the last stage; everything when no hook fired)"""
-        for i in range(self._sent, len(self._stages)):
-            self._send(self._stages[i])
-        self._sent = len(self._stages)
-        if self._cut is None:
-            self.reducer.finish()
 
     def _step_eager(self, batch, teacher_out=None):
         self._sent = 0
@@ -792,7 +810,7 @@ class TeacherPrefetch:
         return None if prev is None else (prev[0]["B"][prev[1]], prev[0]["T"][prev[1]])
 
 
-class ITRTrainer:
+class ITRTrainer(_StagedExchange):
     """Pruning fine-tune step of Eff_Retrieval.py:75-213 (image-text retrieval with hard-concrete L0 gates): student with
     gates forward + backward, teacher forward, ITC + ITM + hidden / attention / cross-attention / logit KD, the Lagrangian
     sparsity term, THREE optimisers (main AdamW over every student parameter - the gate parameters included, as in the
@@ -813,8 +831,12 @@ class ITRTrainer:
         student.train()
         self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=0.0)
         self.reducer = GradReducer(self.opt.flat_grads)
+        self._stages, self._sent = [list(self.opt.flat_grads)], 0
         if self.reducer.active:
             broadcast_parameters(self.opt)      # gates and multipliers included: they are members of the main groups
+            # the exchange overlaps backward as torch DDP's buckets do in the reference (Eff_Retrieval.py:449, Eff_VQA.py:327):
+            # text side + ViT layers {4,5} go out when backward reaches ViT layer 3, {2,3} at layer 1, the rest after backward
+            self._stages, _ = install_grad_stages(self, self.opt, student, os.environ.get("EVLM_DP_CUTS", "vit").replace("all", "vit"))
         self.l0_opt, self.lagrangian_opt = create_L0_optimizer({"reg_learning_rate": reg_learning_rate}, student.l0_module)
         self.defer_wgrad = dtype == torch.bfloat16 and not os.environ.get("EVLM_NO_DEFER_WGRAD")
         self.overlap_teacher = not os.environ.get("EVLM_NO_OVERLAP_TEACHER")
@@ -854,14 +876,16 @@ class ITRTrainer:
             total, mix = distill.itr_loss_mix(S["loss"], kd, lagrangian)
             ops.WGRAD_INPLACE = True
             ops.WGRAD_DEFER = [] if self.defer_wgrad else None
+            self._sent = 0
             try:
-                total.backward()
+                total.backward()                 # (multi-GPU: the gradient stages leave from hooks inside it)
                 ops.flush_wgrad()
             finally:
                 ops.WGRAD_INPLACE = False
                 ops.WGRAD_DEFER = None
                 ops.LN_DEFER.clear()             # (empty after a flush; stale only when backward raised)
-        self.reducer.reduce()
+        if self.reducer.active:
+            self._reduce_rest()
         self.opt.set_schedule(lr_mult)
         self.opt.step()
         self.l0_opt.step()
@@ -873,7 +897,7 @@ class ITRTrainer:
                             lagrangian.detach().float().reshape(())])
 
 
-class VQATrainer:
+class VQATrainer(_StagedExchange):
     """Pruning fine-tune step of Eff_VQA.py:74-200 (visual question answering with hard-concrete L0 gates on the image
     encoder, question encoder AND answer decoder): student forward + backward, teacher forward, the weighted answer LM loss,
     text / fusion / image / decoder hidden + attention KD, logit KD, the Lagrangian, THREE optimisers as in ITRTrainer, no
@@ -891,8 +915,12 @@ class VQATrainer:
         student.train()
         self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=0.0)
         self.reducer = GradReducer(self.opt.flat_grads)
+        self._stages, self._sent = [list(self.opt.flat_grads)], 0
         if self.reducer.active:
             broadcast_parameters(self.opt)      # gates and multipliers included: they are members of the main groups
+            # the exchange overlaps backward as torch DDP's buckets do in the reference (Eff_Retrieval.py:449, Eff_VQA.py:327):
+            # text side + ViT layers {4,5} go out when backward reaches ViT layer 3, {2,3} at layer 1, the rest after backward
+            self._stages, _ = install_grad_stages(self, self.opt, student, os.environ.get("EVLM_DP_CUTS", "vit").replace("all", "vit"))
         self.l0_opt, self.lagrangian_opt = create_L0_optimizer({"reg_learning_rate": reg_learning_rate}, student.l0_module)
         self.defer_wgrad = dtype == torch.bfloat16 and not os.environ.get("EVLM_NO_DEFER_WGRAD")
         self.overlap_teacher = not os.environ.get("EVLM_NO_OVERLAP_TEACHER")
@@ -934,14 +962,16 @@ class VQATrainer:
             total, mix = distill.vqa_loss_mix(S["loss"], kd, lagrangian)
             ops.WGRAD_INPLACE = True
             ops.WGRAD_DEFER = [] if self.defer_wgrad else None
+            self._sent = 0
             try:
-                total.backward()
+                total.backward()                 # (multi-GPU: the gradient stages leave from hooks inside it)
                 ops.flush_wgrad()
             finally:
                 ops.WGRAD_INPLACE = False
                 ops.WGRAD_DEFER = None
                 ops.LN_DEFER.clear()             # (empty after a flush; stale only when backward raised)
-        self.reducer.reduce()
+        if self.reducer.active:
+            self._reduce_rest()
         self.opt.set_schedule(lr_mult)
         self.opt.step()
         self.l0_opt.step()
