@@ -607,135 +607,6 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   }
 }
 
-// kernel A grouped by K/V row (recomputing form, shared K/V index): ONE workgroup per (K/V row, head) stages K and V once
-// and runs kernel A's arithmetic for every (query batch, 16-query tile) that attends to them - the backward counterpart of
-// attn_fwd_grouped_kernel (the per-batch kernel stages the image's 50 KiB once per text row for two waves of work).
-template <int NT, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_grouped_kernel(MAttnB a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;                          // SW_KV: row reads (scores) and column reads (dQ)
-  char* Vs = smem + NT * 16 * 128;          // k_swz (row reads)
-  const int bkv = blockIdx.z, h = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
-  float* Ms = reinterpret_cast<float*>(smem + 2 * NT * 16 * 128) + wave * NT * 16;     // this wave's mask strip
-  stage_rows<SW_KV>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
-  stage_rows<SW_K>(a.V + (size_t)bkv * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
-  stage_wait();
-  __syncthreads();
-  const int qtiles = (a.Lq + 15) >> 4;
-  const float gz = a.gate ? a.gate[h] : 1.0f;
-  const float kdc = a.Pt ? a.kd_coef * a.kd_gout[0] : 0.f;
-  const float sc = a.scale * LOG2E;
-  float gsum = 0.f;
-  int task = 0;
-  for (int b0 = 0; b0 < a.B; b0 += 64) {
-    unsigned long long hits = __ballot(b0 + lane < a.B && a.kv_index[min(b0 + lane, a.B - 1)] == bkv);
-    while (hits) {
-      const int b = b0 + __builtin_amdgcn_readfirstlane(__ffsll((long long)hits) - 1);
-      hits &= hits - 1;
-      bool mask_ready = false;
-      for (int qt = 0; qt < qtiles; ++qt, ++task) {
-        if (task % NW != wave) continue;
-        if (!mask_ready) {
-          for (int k = lane; k < NT * 16; k += 64)
-            Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
-          mask_ready = true;
-        }
-        const int q = qt * 16 + ql;
-        const bool qok = q < a.Lq;
-        bf16x8 dof[2], qf[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          uint4 v = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);
-          if (qok) {
-            v = *reinterpret_cast<const uint4*>(a.dO + ((size_t)b * a.Lq + q) * a.ldo + h * DH + ks * 32 + g * 8);
-            vq = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + ks * 32 + g * 8);
-          }
-          dof[ks] = *reinterpret_cast<bf16x8*>(&v);
-          qf[ks] = *reinterpret_cast<bf16x8*>(&vq);
-        }
-        const size_t prow = (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr;
-        const float lse_q = qok ? a.lse[((size_t)b * a.H + h) * a.Lq + q] : 0.f;
-        f32x4 acc[NT], pf[NT];
-        float dsum = 0.f;
-#pragma unroll
-        for (int s = 0; s < NT / 2; ++s) {
-          const int kcol = s * 32 + g * 8;
-          const bool ok = qok && kcol < a.ldpr;
-          float pr[8], ex[8];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) { pr[r] = 0.f; ex[r] = 0.f; }
-          recompute_p<SW_KV>(Ks, Ms, qf, s, g, lane, sc, lse_q, qok, a.causal, q, pr);
-          if (ok) {
-            if (a.E) {
-              const bf16x8 e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
-#pragma unroll
-              for (int r = 0; r < 8; ++r) ex[r] = (float)e8[r];
-            }
-            if (a.Pt) {
-              const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(a.Pt + prow + kcol);
-#pragma unroll
-              for (int r = 0; r < 8; ++r) ex[r] = fmaf(kdc, pr[r] - (float)t8[r], ex[r]);
-            }
-          }
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            const int t = 2 * s + hh;
-            acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-              acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, t, ks, lane), dof[ks], acc[t], 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float p = pr[hh * 4 + r], dpo = acc[t][r];
-              pf[t][r] = p;
-              gsum = fmaf(p, dpo, gsum);
-              const float dp = fmaf(gz, dpo, ex[hh * 4 + r]);
-              acc[t][r] = dp;
-              dsum = fmaf(p, dp, dsum);
-            }
-          }
-        }
-        dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < NT / 2; ++s) {
-          const int kcol = s * 32 + g * 8;
-          bf16x8 d8, p8;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            d8[r] = (bf16)(pf[2 * s][r] * (acc[2 * s][r] - dsum));
-            d8[4 + r] = (bf16)(pf[2 * s + 1][r] * (acc[2 * s + 1][r] - dsum));
-            p8[r] = (bf16)pf[2 * s][r];
-            p8[4 + r] = (bf16)pf[2 * s + 1][r];
-          }
-          if (qok && kcol < a.ldpr) {
-            *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
-            if (a.Pw) *reinterpret_cast<bf16x8*>(a.Pw + prow + kcol) = p8;
-          }
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt)
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag<SW_KV>(Ks, 2 * s, 2 * s + 1, dt, lane), d8, o[dt], 0, 0, 0);
-        }
-        if (qok) {
-          bf16* dQr = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + h * DH;
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            bf16x4 ov = {(bf16)(o[dt][0] * a.scale), (bf16)(o[dt][1] * a.scale), (bf16)(o[dt][2] * a.scale), (bf16)(o[dt][3] * a.scale)};
-            *reinterpret_cast<bf16x4*>(dQr + dt * 16 + g * 4) = ov;
-          }
-        }
-      }
-    }
-  }
-  if (a.dgate) {
-    const float gs = wave_sum(gsum);
-    if (lane == 0) atomicAdd(a.dgate + h, gs);
-  }
-}
-
 // kernel A for LONG key sequences (608 < Lk <= 960: 480x480 images are 901 tokens).  Holding a whole row of dP / P / dS
 // in registers (kernel A above) needs ~460 VGPRs at this length and spilled ~1 KiB per lane, so this variant makes two
 // passes over the keys and keeps nothing but the running sums:
@@ -1191,18 +1062,6 @@ static void launch_bwd_dq(const MAttnB& f, hipStream_t stream) {
 }
 
 template <int NT>
-static bool launch_bwd_dq_grouped(const MAttnB& f, hipStream_t stream) {
-  const char* env = getenv("EVLM_ATTN_NO_GROUP");         // (A/B switch, read per call)
-  if ((env && atoi(env)) || !f.kv_index || f.Bkv >= f.B || f.Lq > 64 || !f.lse) return false;
-  constexpr int NW = 8;
-  const size_t lds = (size_t)2 * NT * 16 * 128 + (size_t)NW * NT * 16 * sizeof(float);
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_grouped_kernel<NT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_bwd_dq_grouped_kernel<NT, NW>), dim3(1, f.H, f.Bkv), dim3(64 * NW), lds, stream, f);
-  return true;
-}
-
-template <int NT>
 static void launch_bwd_dq_long(const MAttnB& f, hipStream_t stream) {
   constexpr int MAXW = 8;
   const size_t lds = (size_t)NT * 16 * 128;
@@ -1254,8 +1113,10 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
       f.Pw = (bf16*)a->P_ws;
       f.P = (const bf16*)a->P_ws;
     } else if (!a->P) return evlm_set_error("evlm_attention_bwd: the two-kernel recomputing path needs P or the P_ws workspace");
-    if (a->Lk > 64 && launch_bwd_dq_grouped<14>(f, stream)) {}
-    else if (a->Lk <= 32) launch_bwd_dq<2, true>(f, stream);
+    // (a grouped-by-K/V-row form of kernel A - the backward counterpart of attn_fwd_grouped_kernel - was measured 20 %
+    // SLOWER than this per-batch launch on the GD shape, tools/attn_bench.py: a backward task is VALU-bound work of ~20 k
+    // cycles per wave, so the staging it would share is a small part of it, and 256 registers leave one workgroup per CU)
+    if (a->Lk <= 32) launch_bwd_dq<2, true>(f, stream);
     else if (a->Lk <= 64) launch_bwd_dq<4, true>(f, stream);
     else launch_bwd_dq<14, true>(f, stream);
   } else if (a->Lk <= 32) launch_bwd_dq<2, false>(f, stream);
