@@ -31,7 +31,7 @@ class GemmArgs(C.Structure):
 
 class WgradProblem(C.Structure):
     _fields_ = [("P", _vp), ("Q", _vp), ("C", _vp), ("psum", _vp),
-                ("I", _i), ("J", _i), ("ldp", _i), ("ldq", _i), ("ldc", _i)]
+                ("I", _i), ("J", _i), ("ldp", _i), ("ldq", _i), ("ldc", _i), ("assign", _i)]
 
 
 class AttnFwdArgs(C.Structure):

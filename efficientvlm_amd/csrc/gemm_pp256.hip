@@ -337,6 +337,7 @@ struct PPGroup {
   int tile0[PP_MAXG + 1];
   const void* P[PP_MAXG]; const void* Q[PP_MAXG]; void* C[PP_MAXG]; float* psum[PP_MAXG];
   int I[PP_MAXG], J[PP_MAXG], ldp[PP_MAXG], ldq[PP_MAXG], ldc[PP_MAXG];
+  int assign[PP_MAXG];             // 1: C = tile (this step's first contribution: no zero-fill before, no read here)
 };
 
 // select the problem item `vb0` belongs to; returns the tile id inside it.  Item ids are first remapped so that the
@@ -352,6 +353,7 @@ __device__ __forceinline__ int pp_group_select(const PPGroup& grp, int vb0, Gemm
   g.P = grp.P[p]; g.Q = grp.Q[p]; g.C = grp.C[p]; g.psum = grp.psum[p];
   g.I = grp.I[p]; g.J = grp.J[p]; g.ldp = grp.ldp[p]; g.ldq = grp.ldq[p]; g.ldc = grp.ldc[p];
   g.tiles_i = (g.I + 255) >> 8; g.tiles_j = (g.J + 255) >> 8;
+  g.accumulate = grp.assign[p] ? 0 : 1;
   return vb - grp.tile0[p];
 }
 
@@ -605,7 +607,7 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
       else if (full) pp_epilogue<true>(gc, accL, accH, ib, jb, lane_e, swin_e);
       else pp_epilogue<false>(gc, accL, accH, ib, jb, lane_e, swin_e);
     } else {
-      const int mode = GROUPED ? (grp->rmw ? 2 : 1) : ((gc.accumulate || splits > 1) ? 1 : 0);
+      const int mode = GROUPED ? (grp->rmw ? (gc.accumulate ? 2 : 0) : 1) : ((gc.accumulate || splits > 1) ? 1 : 0);
       if (full) { pp_epi_f32_half<true>(gc, accL, ib, jb, lane_e, swin_e, mode); pp_epi_f32_half<true>(gc, accH, ib + 64, jb, lane_e, swin_e, mode); }
       else { pp_epi_f32_half<false>(gc, accL, ib, jb, lane_e, swin_e, mode); pp_epi_f32_half<false>(gc, accH, ib + 64, jb, lane_e, swin_e, mode); }
       if (do_psum) {                              // lanes l, l+16, l+32, l+48 hold the four k quarters of row l
@@ -1080,10 +1082,14 @@ extern "C" int evlm_wgrad_grouped(const evlm_wgrad_problem* pr, int n, int K, vo
       EVLM_REQUIRE((int64_t)K * q.ldp < (1ll << 31) && (int64_t)K * q.ldq < (1ll << 31), "evlm_wgrad_grouped: operand too large");
       grp.P[k] = q.P; grp.Q[k] = q.Q; grp.C[k] = q.C; grp.psum[k] = q.psum;
       grp.I[k] = q.I; grp.J[k] = q.J; grp.ldp[k] = q.ldp; grp.ldq[k] = q.ldq; grp.ldc[k] = q.ldc;
+      grp.assign[k] = q.assign ? 1 : 0;
       grp.tile0[k + 1] = grp.tile0[k] + ceil_div(q.I, 256) * ceil_div(q.J, 256);
       for (int o = 0; o < k; ++o)
         if (grp.C[o] == q.C) grp.rmw = 0;           // two contributions to one C in this launch: fall back to atomics
     }
+    if (!grp.rmw)
+      for (int k = 0; k < m; ++k)
+        EVLM_REQUIRE(!grp.assign[k], "evlm_wgrad_grouped: an assigning problem in a call with two contributions to one C");
     GemmP g;
     memset(&g, 0, sizeof(g));
     g.K = K; g.alpha = 1.0f; g.c_f32 = 1; g.bare_f32 = 1; g.accumulate = 1; g.kt_per_split = K / 64;

@@ -273,6 +273,67 @@ def _flush_ln():
     L.check(_lib().evlm_layernorm_bwd_reduce_grouped(L.ptr(table), len(q), max(r[2] for r in q), L.stream()), "ln_reduce_grouped")
 
 
+# First-touch ASSIGNMENT of weight gradients (set by a trainer together with WGRAD_DEFER): {"skip": {grad data_ptr: grad view}
+# of the Linear weights whose slab ranges the step's zero-fill leaves out, "done": set of data_ptrs initialised this step}.
+# The first grouped product of such a weight WRITES its tile (C = dY^T X: no fill before, no read of C in the kernel -
+# ~370 MB less of each per GD step); any other first contribution zero-fills the range itself, and finish_assign() zeroes
+# what the step never touched (heads a batch kind does not use).
+WGRAD_ASSIGN = None
+
+
+def _assign_prepare(params, will_assign):
+    """before a contribution to `params`' gradients: returns True when it may ASSIGN (every member still untouched and
+    eligible).  Otherwise members that are eligible and untouched are zero-filled here, and a queued-but-unflushed
+    assigning product of a member is demoted to an accumulating one (its range zero-filled now): an assignment launched
+    at the flush would wipe out what this contribution is about to add."""
+    st = WGRAD_ASSIGN
+    if st is None:
+        return False
+    keys = [p.grad.data_ptr() if p.grad is not None else None for p in params]
+    fresh = [k is not None and k in st["skip"] and k not in st["done"] for k in keys]
+    if will_assign and all(fresh):
+        st["done"].update(keys)
+        return True
+    for k, f in zip(keys, fresh):
+        if f:
+            st["skip"][k].zero_()
+            st["done"].add(k)
+        elif k is not None and k in st["pending"]:
+            rec = st["pending"].pop(k)
+            if rec[10]:
+                rec[10] = False
+                for kk in rec[11]:
+                    st["skip"][kk].zero_()
+                    st["pending"].pop(kk, None)
+    return False
+
+
+def assign_settle(ranges):
+    """before gradient ranges leave for a data-parallel exchange in the middle of backward: eligible gradients inside them
+    that nothing has written yet (a head this batch kind does not use) are zero-filled NOW - finish_assign() at the end of
+    backward would race with the exchange"""
+    st = WGRAD_ASSIGN
+    if st is None:
+        return
+    spans = [(r.data_ptr(), r.data_ptr() + r.numel() * r.element_size()) for r in ranges]
+    for k, g in st["skip"].items():
+        if k not in st["done"] and any(lo <= k < hi for lo, hi in spans):
+            g.zero_()
+            st["done"].add(k)
+
+
+def finish_assign():
+    """end of a step's backward: zero the eligible gradients nothing has written (a head this batch kind does not use)"""
+    st = WGRAD_ASSIGN
+    if st is None:
+        return
+    for k, g in st["skip"].items():
+        if k not in st["done"]:
+            g.zero_()
+    st["done"].clear()
+    st["pending"].clear()
+
+
 def flush_wgrad():
     """launch the queued weight-gradient products and LayerNorm column-sum reductions (no-op when nothing is queued)"""
     global WGRAD_DEFER
@@ -281,6 +342,8 @@ def flush_wgrad():
     if not q:
         return
     WGRAD_DEFER = [] if q is not None else None
+    if WGRAD_ASSIGN is not None:
+        WGRAD_ASSIGN["pending"].clear()          # (the queued assignments are launched below, in queue order per K)
     by_k = {}
     for rec in q:
         by_k.setdefault(rec[0], []).append(rec)
@@ -289,12 +352,19 @@ def flush_wgrad():
         # large problems first: the persistent workgroups take items in order
         recs.sort(key=lambda r: -(r[5] * r[6]))
         arr = (L.WgradProblem * len(recs))()
-        for k, (_, d2, p_off, x2, cgrad, I, J, ldd, ldp, ps) in enumerate(recs):
+        ptrs = [rec[4].data_ptr() for rec in recs]
+        for rec in recs:                       # two contributions to one C in ONE launch run on atomics: no assignment then
+            if rec[10] and ptrs.count(rec[4].data_ptr()) > 1:
+                rec[10] = False
+                for kk in rec[11]:
+                    WGRAD_ASSIGN["skip"][kk].zero_()
+        for k, (_, d2, p_off, x2, cgrad, I, J, ldd, ldp, ps, assign, _keys) in enumerate(recs):
             arr[k].P = d2.data_ptr() + p_off * d2.element_size()
             arr[k].Q = x2.data_ptr()
             arr[k].C = cgrad.data_ptr()
             arr[k].psum = ps.data_ptr() if ps is not None else None
             arr[k].I, arr[k].J, arr[k].ldp, arr[k].ldq, arr[k].ldc = I, J, ldd, ldp, J
+            arr[k].assign = int(bool(assign))
         if GEMM_PROFILE is None:
             L.check(lib.evlm_wgrad_grouped(arr, len(recs), K, L.stream()), "wgrad_grouped")
             continue
@@ -335,6 +405,7 @@ def _wgrad(dtype, d2, ldd, x2, ldp, M, K, params, rows, biases=None):
     fast = dtype == L.BF16 and M % 64 == 0
     has_b = biases is not None and len(biases) and biases[0] is not None
     if not (fast and all(_inplace(w) for w in params)):
+        _assign_prepare(params, False)            # (autograd will ADD these into .grad: eligible ranges zero-filled first)
         N = sum(rows)
         dW = torch.empty((N, K), dtype=torch.float32, device=x2.device)
         db = torch.zeros(N, dtype=torch.float32, device=x2.device) if (has_b and fast) else None
@@ -369,8 +440,14 @@ def _wgrad(dtype, d2, ldd, x2, ldp, M, K, params, rows, biases=None):
             ps = res = None
         if (WGRAD_DEFER is not None and res is None and M >= WGRAD_DEFER_MIN_K and r % 8 == 0 and K % 8 == 0
                 and (r0 * d2.element_size()) % 16 == 0 and M * max(ldd, ldp) < (1 << 31)):
-            WGRAD_DEFER.append((M, d2, r0, x2, params[i].grad, r, K, ldd, ldp, ps))
+            assign = _assign_prepare(params[i:j], True)
+            keys = [w.grad.data_ptr() for w in params[i:j]] if assign else []
+            rec = [M, d2, r0, x2, params[i].grad, r, K, ldd, ldp, ps, assign, keys]
+            for kk in keys:
+                WGRAD_ASSIGN["pending"][kk] = rec
+            WGRAD_DEFER.append(rec)
         else:
+            _assign_prepare(params[i:j], False)
             _gemm(dtype, d2, x2, params[i].grad, r, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1, accumulate=1, p_off=r0, psum=ps)
         for k in range(i, j):
             gw.append(None)

@@ -57,6 +57,7 @@ class FlatAdamW:
             groups[gi]["names"].append(n)
         self.groups = [g for g in groups if g["params"]]
         self.step_count = 0
+        self._assign = None
         self._scheduled, self._last_mult = False, 1.0      # has set_schedule() run since the last step()?
         dev = named[0][1].device
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -128,9 +129,41 @@ class FlatAdamW:
                 off += seg
         return [g["g"][lo:hi] for g, (lo, hi) in out]
 
-    def zero_grad(self):
+    def zero_grad(self, skip_assigned=False):
+        """skip_assigned: leave out the ranges of assign_state() - the caller promises that this step's backward runs with
+        ops.WGRAD_ASSIGN = that state (every such range is then written by its first contribution or zero-filled by
+        ops.finish_assign)"""
+        if not skip_assigned or self._assign is None:
+            for g in self.groups:
+                g["g"].zero_()
+            return
+        for view in self._assign["fill"]:
+            view.zero_()
+
+    def assign_state(self, model):
+        """state for ops.WGRAD_ASSIGN: the weights of the model's nn.Linear modules (not tied to an embedding) - the
+        parameters whose gradient is one dY^T X product per step - and the slab ranges a step still has to zero-fill
+        (everything else: biases, LayerNorms, embeddings, scalars, the L0 parameters, padding words)"""
+        if self._assign is not None:
+            return self._assign
+        tied = {id(m.weight) for m in model.modules() if isinstance(m, torch.nn.Embedding)}
+        lin = {id(m.weight) for m in model.modules() if isinstance(m, torch.nn.Linear) and id(m.weight) not in tied}
+        skip, fill = {}, []
         for g in self.groups:
-            g["g"].zero_()
+            off, pos = 0, 0
+            for p in g["params"]:
+                k = p.numel()
+                seg = (k + 7) // 8 * 8
+                if id(p) in lin and p.dim() == 2 and k >= 4096 and k == seg:
+                    if off > pos:
+                        fill.append(g["g"][pos:off])
+                    skip[g["g"].data_ptr() + off * 4] = g["g"][off:off + k]
+                    pos = off + seg
+                off += seg
+            if g["g"].numel() > pos:
+                fill.append(g["g"][pos:])
+        self._assign = {"skip": skip, "done": set(), "pending": {}, "fill": fill}
+        return self._assign
 
     def set_schedule(self, lr_mult=1.0):
         """host-side per-step scalars -> device (call OUTSIDE a captured graph, before replay)"""

@@ -210,6 +210,7 @@ class _StagedExchange:
 
     def _send(self, ranges):
         ops.flush_wgrad()                 # the queued weight gradients of the stage must be in the slabs first
+        ops.assign_settle(ranges)         # (... and what the step never writes must be zero before it travels)
         if self._cut is not None:         # capture pass of the segmented step: the graph segment ends here
             self._cut(ranges)
         else:
@@ -309,7 +310,10 @@ class GDTrainer(_StagedExchange):
 
     # ---- the step body (pure device work) ----------------------------------------------------------
     def _forward_backward(self, batch, teacher_out=None):
-        self.opt.zero_grad()
+        # (first-touch assignment of the Linear weights' gradients: their slab ranges are not zero-filled, ops.WGRAD_ASSIGN)
+        self._assign = (self.opt.assign_state(self.student)
+                        if (self.wgrad_inplace and self.defer_wgrad and not os.environ.get("EVLM_NO_WGRAD_ASSIGN")) else None)
+        self.opt.zero_grad(skip_assigned=self._assign is not None)
         ops.begin_step(batch["image"].device)
         try:
             return self._forward_backward_body(batch, teacher_out)
@@ -326,12 +330,18 @@ class GDTrainer(_StagedExchange):
             self.last_kd = {k: v.detach() for k, v in kd.items() if torch.is_tensor(v)}
             ops.WGRAD_INPLACE = self.wgrad_inplace      # kernels sum parameter gradients straight into the flat slabs
             ops.WGRAD_DEFER = [] if (self.wgrad_inplace and self.defer_wgrad) else None   # ... dW products grouped per K
+            ops.WGRAD_ASSIGN = self._assign
             try:
                 total.backward()
                 ops.flush_wgrad()
+                ops.finish_assign()
             finally:
                 ops.WGRAD_INPLACE = False
                 ops.WGRAD_DEFER = None
+                ops.WGRAD_ASSIGN = None
+                if self._assign is not None:     # (non-empty only when backward raised: the next step starts clean)
+                    self._assign["done"].clear()
+                    self._assign["pending"].clear()
                 ops.LN_DEFER.clear()             # (empty after a flush; stale only when backward raised)
         if ops.DROPOUT_USED:              # p > 0 configurations: next step (next graph replay) draws new masks
             ops.dropout_tick(total.device)

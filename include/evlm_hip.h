@@ -91,6 +91,9 @@ int evlm_gemm(const evlm_gemm_args* args, void* stream);
 typedef struct {
   const void* P; const void* Q; void* C; float* psum;
   int I, J, ldp, ldq, ldc;
+  int assign;               /* 1: C = P^T Q - this step's FIRST contribution to C, which then needs no zero-fill before and
+                               no read in the kernel (ignored - accumulated with atomics - when another problem of the same
+                               call writes the same C);  0: C += P^T Q */
 } evlm_wgrad_problem;
 int evlm_wgrad_grouped(const evlm_wgrad_problem* problems, int n, int K, void* stream);
 

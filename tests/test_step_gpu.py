@@ -482,6 +482,42 @@ def test_segmented_and_eager_multi_gpu_steps_issue_the_same_collective_sequence(
         assert sum(n for _, n, _ in a[1:]) == seg["slab"]
 
 
+@pytest.mark.parametrize("geom_name,B", [("full", 64), ("tiny", 5)])
+def test_first_touch_assignment_of_weight_gradients_equals_zero_fill_plus_accumulate(geom_name, B, monkeypatch):
+    """ops.WGRAD_ASSIGN (the Linear weights' slab ranges are not zero-filled; the first grouped dY^T X product of a weight
+    writes its tile, anything else zero-fills the range first, finish_assign zeroes what the step never touched) against
+    the plain form (one zero-fill of every slab, every product accumulated): IDENTICAL gradient slabs - with the slabs
+    poisoned with NaN beforehand, so nothing stale can survive; B = 5 at the tiny geometry takes the tail path of
+    reduction lengths that are not multiples of 64 (a queued assignment demoted by the tail's immediate product) and
+    products too short to be queued"""
+    from efficientvlm_amd import ops
+    from efficientvlm_amd.trainer import GDTrainer
+    geom = synth.GEOMS[geom_name]
+    batch = {k: v.to(DEV) for k, v in synth.make_batch(geom, B, seed=19).items()}
+    slabs, skipped = [], []
+    for off in ("1", ""):
+        if off:
+            monkeypatch.setenv("EVLM_NO_WGRAD_ASSIGN", off)
+        else:
+            monkeypatch.delenv("EVLM_NO_WGRAD_ASSIGN", raising=False)
+        student, teacher = build_gd(geom, 5)
+        tr = GDTrainer(student, teacher, dtype=torch.bfloat16, use_graph=False)
+        ops.dropout_seed(0)           # hard-negative draws (device Philox stream): the same in both runs
+        for g in tr.opt.flat_grads:
+            g.fill_(float("nan"))
+        if off:
+            tr.opt.zero_grad()        # (the plain form zero-fills in _forward_backward anyway; explicit for the NaN poison)
+        tr._forward_backward(batch)
+        torch.cuda.synchronize()
+        slabs.append([g.clone() for g in tr.opt.flat_grads])
+        skipped.append(0 if tr._assign is None else sum(v.numel() for v in tr._assign["skip"].values()))
+        del tr, student, teacher
+    assert skipped[0] == 0 and skipped[1] > 0.6 * sum(g.numel() for g in slabs[1])       # most of the slabs is never filled
+    for a, b in zip(*slabs):
+        assert bool(torch.isfinite(b).all())
+        assert torch.equal(a, b)
+
+
 def test_deferred_grouped_weight_gradients_match_immediate_ones():
     """GDTrainer (bf16, B = 64, full geometry): gradients with the dW products queued and flushed as grouped launches
     against the same step with every dW launched in place (split-K kernels)"""
