@@ -1,16 +1,19 @@
 """GD training step runtime: student + frozen teacher, KD loss mix, backward, data-parallel gradient reduction,
-global-norm clip + AdamW — the body of GeneralDistill.py:train (reference :286-387) for a general batch.
+global-norm clip + AdamW — the body of GeneralDistill.py:train (reference :286-387) for a general or a region batch; and
+the pruning fine-tune steps of Eff_Retrieval.py / Eff_VQA.py (ITRTrainer, VQATrainer).
 
 MI355X-first execution
   * one process per GPU; the teacher is a plain replica on every rank and never communicates;
   * the whole step is device-resident (no .item() syncs: the reference's 2B multinomial().item() calls and 11 meter
-    reads per step are gone), so it can be captured once into a hipGraph and replayed (~1.2k kernel launches);
+    reads per step are gone), so it is captured into hipGraphs and replayed (~900 kernel launches);
+  * the frozen teacher runs one batch ahead of the student on a second stream inside the same graph (pipeline_teacher);
   * gradients live in the optimiser's flat fp32 slabs, so data parallelism is a few large RCCL all-reduces over
-    contiguous memory on a side stream (xGMI is point-to-point: few, large messages); the text / fusion / head part
-    of the slabs is reduced from a tensor hook while the ViT backward is still running, the ViT part after it.
-    With N > 1 the student step runs eagerly (RCCL collectives are not capturable here); the frozen teacher's forward,
-    which holds no collective, still replays as a hipGraph on the side stream, so the host issues ~700 instead of ~1100
-    launches per step and the step stays GPU-bound (20.7 ms on the DP code path vs 20.3 ms for the full-graph step).
+    contiguous memory on a side stream (xGMI is point-to-point: few, large messages), issued in STAGES as backward
+    completes them (install_grad_stages): text / fusion / heads when backward enters the image encoder, the ViT layer
+    groups from hooks inside its backward, the rest after it;
+  * with N > 1 the step replays as hipGraph SEGMENTS cut at its collectives (RCCL is not capturable on this stack): the
+    ITC gather in the forward, the stage boundaries in the backward - the all-reduce of a stage overlaps the next
+    segment; a capture that fails on any rank switches every rank to the eager step (same collective sequence).
 """
 import os
 
