@@ -377,6 +377,23 @@ class GDTrainer(_StagedExchange):
     # both halves (teacher forked onto the side stream, joined at the end), captured lazily into one memory pool.
     # Multi-GPU: the student step stays eager (RCCL is not capturable here) and only the teacher replays a graph.  Kinds
     # may alternate freely; optimiser updates are applied in arrival order, one call late.
+    MAX_BATCH_KINDS = 6          # batch shapes with live pipeline state (static buffers x2, captured graphs) at a time
+    _tick = 0
+
+    def _evict_pipe(self):
+        """drop the least recently used batch kind (never the one whose batch is still waiting for its student step): its
+        static buffers and every captured graph that names it; the blocks go back to the graphs' shared memory pool"""
+        waiting = self._pending[0] if self._pending is not None else None
+        victims = sorted((p.get("tick", 0), sig) for sig, p in self._pipes.items() if p is not waiting)
+        if not victims:
+            return
+        sig = victims[0][1]
+        pid = id(self._pipes.pop(sig))
+        torch.cuda.synchronize()
+        for cache in (self._joint, self._seg):
+            for key in [k for k in cache if pid in (k[0], k[2])]:
+                del cache[key]
+
     def _pipe_create(self, batch):
         """state of one batch kind: static buffers x2, two eager warm-up steps (lr 0, optimiser state restored), the
         persistent teacher-output buffers x2 (only the tensors the KD terms read; attention maps keep their padded rows),
@@ -492,7 +509,11 @@ class GDTrainer(_StagedExchange):
         sig = tuple(sorted((k, tuple(v.shape)) for k, v in batch.items()))
         pipe = self._pipes.get(sig)
         if pipe is None:
+            if len(self._pipes) >= self.MAX_BATCH_KINDS:       # (a short last batch, odd region sizes ...: bounded state)
+                self._evict_pipe()
             pipe = self._pipes[sig] = self._pipe_create(batch)
+        self._tick += 1
+        pipe["tick"] = self._tick
         cur, side = torch.cuda.current_stream(), self._side
         cur.wait_stream(side)                     # the waiting batch's teacher outputs are complete
         p = pipe["par"] = 1 - pipe["par"]

@@ -501,8 +501,10 @@ def test_first_touch_assignment_of_weight_gradients_equals_zero_fill_plus_accumu
         else:
             monkeypatch.delenv("EVLM_NO_WGRAD_ASSIGN", raising=False)
         student, teacher = build_gd(geom, 5)
+        neg = torch.tensor([(i + 1) % B for i in range(B)] + [(i + 2) % B for i in range(B)])
+        student.injected_neg_idx = teacher.injected_neg_idx = neg        # (the same hard negatives in both runs)
+        student.keep_injected_neg = teacher.keep_injected_neg = True
         tr = GDTrainer(student, teacher, dtype=torch.bfloat16, use_graph=False)
-        ops.dropout_seed(0)           # hard-negative draws (device Philox stream): the same in both runs
         for g in tr.opt.flat_grads:
             g.fill_(float("nan"))
         if off:
@@ -726,6 +728,40 @@ def test_pipelined_teacher_reproduces_the_unpipelined_training_trajectory(use_gr
         del tr, student, teacher
     assert torch.allclose(outs[True], outs[False], rtol=5e-4, atol=1e-5), (outs[True], outs[False])
     assert float((outs[False][0] - outs[False][3]).abs().max()) > 1e-3      # the batches (and the training) do differ
+
+
+def test_pipeline_state_of_batch_kinds_is_bounded_and_evicted_kinds_come_back(monkeypatch):
+    """GDTrainer keeps static buffers and captured graphs per batch SHAPE; the number of live kinds is bounded
+    (MAX_BATCH_KINDS, least recently used evicted - never the kind whose batch is still waiting for its student step).
+    Three batch sizes cycled through a trainer that may keep two kinds must train exactly like one that keeps them all."""
+    from efficientvlm_amd.efficient_models.xvlm import XVLMBase
+    from efficientvlm_amd.trainer import GDTrainer
+
+    def fixed_negatives(self, image_feat, text_feat, idx):
+        bs = image_feat.size(0)
+        ar = torch.arange(bs, device=image_feat.device)
+        return (ar + 1) % bs, (ar + 2) % bs
+    monkeypatch.setattr(XVLMBase, "_sample_negatives", fixed_negatives)
+    geom = synth.GEOMS["tiny"]
+    batches = [{k: v.to(DEV) for k, v in synth.make_batch(geom, 3 + (i % 3), seed=70 + i).items()} for i in range(8)]
+    outs = {}
+    for cap in (6, 2):
+        student, teacher = build_gd(geom, 9)
+        tr = GDTrainer(student, teacher, lr=1e-3, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=torch.float32,
+                       use_graph=True, pipeline_teacher=True)
+        tr.MAX_BATCH_KINDS = cap
+        seq = []
+        for b in batches:
+            o = tr.step(b)
+            if o is not None:
+                seq.append(o.clone())
+            assert len(tr._pipes) <= cap
+        torch.cuda.synchronize()
+        outs[cap] = torch.stack(seq).cpu()
+        if cap == 2:
+            assert len(tr._joint) <= 8
+        del tr, student, teacher
+    assert torch.allclose(outs[2], outs[6], rtol=5e-4, atol=1e-5), (outs[2], outs[6])
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
