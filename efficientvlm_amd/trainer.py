@@ -377,24 +377,21 @@ class GDTrainer(_StagedExchange):
     # both halves (teacher forked onto the side stream, joined at the end), captured lazily into one memory pool.
     # Multi-GPU: the student step stays eager (RCCL is not capturable here) and only the teacher replays a graph.  Kinds
     # may alternate freely; optimiser updates are applied in arrival order, one call late.
-    MAX_BATCH_KINDS = 6          # batch shapes with live pipeline state (static buffers x2, captured graphs) at a time
+    MAX_BATCH_KINDS = 6          # batch shapes whose steps are captured into hipGraphs (first come); further kinds run eagerly
+    MAX_EAGER_KINDS = 4          # ... with at most this many of them keeping their static buffers (least recently used evicted)
     _tick = 0
 
     def _evict_pipe(self):
-        """drop the least recently used batch kind (never the one whose batch is still waiting for its student step): its
-        static buffers and every captured graph that names it; the blocks go back to the graphs' shared memory pool"""
+        """drop the least recently used EAGER batch kind (never the one whose batch is still waiting for its student
+        step).  Kinds with captured graphs are never dropped: destroying graphs that share a memory pool with live ones
+        trips an internal assertion of the caching allocator on this stack."""
         waiting = self._pending[0] if self._pending is not None else None
-        victims = sorted((p.get("tick", 0), sig) for sig, p in self._pipes.items() if p is not waiting)
-        if not victims:
-            return
-        sig = victims[0][1]
-        pid = id(self._pipes.pop(sig))
-        torch.cuda.synchronize()
-        for cache in (self._joint, self._seg):
-            for key in [k for k in cache if pid in (k[0], k[2])]:
-                del cache[key]
+        victims = sorted((p.get("tick", 0), sig) for sig, p in self._pipes.items() if p.get("eager") and p is not waiting)
+        if victims:
+            torch.cuda.synchronize()
+            del self._pipes[victims[0][1]]
 
-    def _pipe_create(self, batch):
+    def _pipe_create(self, batch, eager=False):
         """state of one batch kind: static buffers x2, two eager warm-up steps (lr 0, optimiser state restored), the
         persistent teacher-output buffers x2 (only the tensors the KD terms read; attention maps keep their padded rows),
         the graphs"""
@@ -431,11 +428,11 @@ class GDTrainer(_StagedExchange):
                 else:
                     out[d][key][i] = buf
             return out
-        pipe = dict(B=B, T=[persist(), persist()], slots=slots, par=0, tgraphs=None)
+        pipe = dict(B=B, T=[persist(), persist()], slots=slots, par=0, tgraphs=None, eager=eager)
         self._last_ST = None
         del S, T
         side = self._side
-        if self.use_graph and self.reducer.active and not os.environ.get("EVLM_NO_TEACHER_GRAPH"):
+        if self.use_graph and not eager and self.reducer.active and not os.environ.get("EVLM_NO_TEACHER_GRAPH"):
             # the frozen teacher's forward holds no collective (skip_task_losses): capturable on multi-GPU runs too
             side.wait_stream(cur)
             ops.reserve_tables()
@@ -509,9 +506,12 @@ class GDTrainer(_StagedExchange):
         sig = tuple(sorted((k, tuple(v.shape)) for k, v in batch.items()))
         pipe = self._pipes.get(sig)
         if pipe is None:
-            if len(self._pipes) >= self.MAX_BATCH_KINDS:       # (a short last batch, odd region sizes ...: bounded state)
+            # bounded state (a short last batch, odd region sizes ...): the first MAX_BATCH_KINDS shapes get graphs, later
+            # ones run the same kernels eagerly out of static buffers that are recycled
+            eager = sum(1 for q in self._pipes.values() if not q.get("eager")) >= self.MAX_BATCH_KINDS
+            if eager and sum(1 for q in self._pipes.values() if q.get("eager")) >= self.MAX_EAGER_KINDS:
                 self._evict_pipe()
-            pipe = self._pipes[sig] = self._pipe_create(batch)
+            pipe = self._pipes[sig] = self._pipe_create(batch, eager)
         self._tick += 1
         pipe["tick"] = self._tick
         cur, side = torch.cuda.current_stream(), self._side
@@ -521,7 +521,8 @@ class GDTrainer(_StagedExchange):
             pipe["B"][p][name].copy_(v, non_blocking=True)
         out = None
         done = False                              # both halves of this call issued (joint graph / graph segments)?
-        if self.use_graph and not self.reducer.active and self._pending is not None:
+        graphs_ok = self.use_graph and not pipe.get("eager") and (self._pending is None or not self._pending[0].get("eager"))
+        if graphs_ok and not self.reducer.active and self._pending is not None:
             # single GPU: ONE hipGraph per (waiting batch, new batch) combination holds both halves - the teacher forward
             # of the new batch forked onto the side stream, the student step of the waiting batch on the capture stream,
             # joined at the end.  (Two separately launched graphs - one per stream - ran 1.5 % faster but aborted with a
@@ -541,7 +542,7 @@ class GDTrainer(_StagedExchange):
             jg[0].replay()
             out, self.last_kd = jg[1], jg[2]
             done = True
-        elif (self.use_graph and self.reducer.active and self._pending is not None
+        elif (graphs_ok and self.reducer.active and self._pending is not None
               and not os.environ.get("EVLM_NO_SEGMENT_GRAPHS") and not getattr(self, "_segments_broken", False)):
             # multi-GPU: hipGraph segments around the collectives; the new batch's teacher forward is forked onto the side
             # stream INSIDE a segment (as in the single-GPU joint graph), or - EVLM_SEG_TEACHER=graph - replays as its

@@ -486,6 +486,62 @@ def test_inplace_parameter_gradients_match_autograd(M):
         assert rel_err(c, a) < 3e-4
 
 
+@pytest.mark.parametrize("M,twice", [(2048, False), (1802, False), (256, False), (2048, True), (1802, True)])
+def test_first_touch_assignment_of_weight_gradients(M, twice):
+    """ops.WGRAD_ASSIGN on single layers, gradients poisoned with NaN beforehand: M = 2048 - the queued product ASSIGNS
+    (no zero-fill, no read of C); 1802 = 28 x 64 + 10 - the queued main part is demoted by the tail's immediate product;
+    256 - too short to be queued: zero-filled, then accumulated; `twice` - the same weights used by two products of one
+    flush (atomics, no assignment).  An eligible weight nothing touches is zeroed by finish_assign.  Against autograd."""
+    o = ops()
+    from efficientvlm_amd import _lib as L
+    g = torch.Generator().manual_seed(91)
+    K, N, Fh = 64, 72, 136
+    x = rnd((2, M // 2, K), torch.bfloat16, g)
+
+    def make():
+        gg = torch.Generator().manual_seed(7)
+        mk = lambda *s: torch.nn.Parameter(rnd(s, torch.float32, gg, 0.3))
+        return dict(ws=[mk(N, K) for _ in range(3)], bs=[mk(N) for _ in range(3)], w1=mk(Fh, 3 * N), b1=mk(Fh),
+                    w2=mk(K, Fh), b2=mk(K), unused=mk(N, K))
+
+    def run(P, assign):
+        weights = P["ws"] + [P["w1"], P["w2"], P["unused"]]
+        params = weights + P["bs"] + [P["b1"], P["b2"]]
+        if assign:      # q | k | v gradients back to back, as in the optimiser slabs; weights poisoned, the rest zeroed
+            gw = torch.full((3 * N * K,), float("nan"), device=DEV)
+            for i in range(3):
+                P["ws"][i].grad = gw[i * N * K:(i + 1) * N * K].view(N, K)
+            for p in (P["w1"], P["w2"], P["unused"]):
+                p.grad = torch.full_like(p, float("nan"))
+            for p in P["bs"] + [P["b1"], P["b2"]]:
+                p.grad = torch.zeros_like(p)
+            state = {"skip": {p.grad.data_ptr(): p.grad for p in weights}, "done": set(), "pending": {}}
+        xi = x.clone().requires_grad_(True)
+        h = o.linear_packed(xi, P["ws"], P["bs"])
+        y = o.mlp(h, P["w1"], P["b1"], P["w2"], P["b2"], L.ACT_GELU, gate_pos=L.GATE_POST)
+        loss = y.float().square().mean()
+        if twice:
+            loss = loss + o.linear_packed(xi, P["ws"], P["bs"]).float().mean()
+        if assign:
+            o.WGRAD_INPLACE, o.WGRAD_DEFER, o.WGRAD_ASSIGN = True, [], state
+        try:
+            loss.backward()
+            if assign:
+                o.flush_wgrad()
+                o.finish_assign()
+        finally:
+            o.WGRAD_INPLACE, o.WGRAD_DEFER, o.WGRAD_ASSIGN = False, None, None
+        return [(p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for p in params], xi.grad
+
+    ga, xa = run(make(), False)
+    gb, xb = run(make(), True)
+    assert rel_err(xb.float(), xa.float()) < 1e-6
+    for a, b in zip(ga, gb):
+        assert bool(torch.isfinite(b).all())
+        assert rel_err(b, a) < 3e-4
+    assert float(gb[5].abs().max()) == 0.0                # the weight no product touched
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_cross_attention_shared_kv_index(dtype):
     """several query batches attend to the same K/V row (positive / hard-negative / MLM passes sharing an image):
