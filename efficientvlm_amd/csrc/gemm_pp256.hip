@@ -333,7 +333,7 @@ __device__ __forceinline__ void pp_tile_ij(const GemmP& g, int vb, int ntiles, i
 #define PP_MAXG 40
 struct PPGroup {
   int n;
-  int rmw;                         // 1: C += tile by load/add/store (single owner); 0: atomics (a C appears twice)
+  int dup[PP_MAXG];                // 1: this problem's C is written by another problem of the launch too: f32 atomics
   int tile0[PP_MAXG + 1];
   const void* P[PP_MAXG]; const void* Q[PP_MAXG]; void* C[PP_MAXG]; float* psum[PP_MAXG];
   int I[PP_MAXG], J[PP_MAXG], ldp[PP_MAXG], ldq[PP_MAXG], ldc[PP_MAXG];
@@ -353,7 +353,7 @@ __device__ __forceinline__ int pp_group_select(const PPGroup& grp, int vb0, Gemm
   g.P = grp.P[p]; g.Q = grp.Q[p]; g.C = grp.C[p]; g.psum = grp.psum[p];
   g.I = grp.I[p]; g.J = grp.J[p]; g.ldp = grp.ldp[p]; g.ldq = grp.ldq[p]; g.ldc = grp.ldc[p];
   g.tiles_i = (g.I + 255) >> 8; g.tiles_j = (g.J + 255) >> 8;
-  g.accumulate = grp.assign[p] ? 0 : 1;
+  g.accumulate = grp.dup[p] ? 2 : (grp.assign[p] ? 0 : 1);      // 0: C = tile, 1: C += tile (load / add / store), 2: atomics
   return vb - grp.tile0[p];
 }
 
@@ -607,7 +607,7 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
       else if (full) pp_epilogue<true>(gc, accL, accH, ib, jb, lane_e, swin_e);
       else pp_epilogue<false>(gc, accL, accH, ib, jb, lane_e, swin_e);
     } else {
-      const int mode = GROUPED ? (grp->rmw ? (gc.accumulate ? 2 : 0) : 1) : ((gc.accumulate || splits > 1) ? 1 : 0);
+      const int mode = GROUPED ? (gc.accumulate == 2 ? 1 : (gc.accumulate ? 2 : 0)) : ((gc.accumulate || splits > 1) ? 1 : 0);
       if (full) { pp_epi_f32_half<true>(gc, accL, ib, jb, lane_e, swin_e, mode); pp_epi_f32_half<true>(gc, accH, ib + 64, jb, lane_e, swin_e, mode); }
       else { pp_epi_f32_half<false>(gc, accL, ib, jb, lane_e, swin_e, mode); pp_epi_f32_half<false>(gc, accH, ib + 64, jb, lane_e, swin_e, mode); }
       if (do_psum) {                              // lanes l, l+16, l+32, l+48 hold the four k quarters of row l
@@ -1072,7 +1072,7 @@ extern "C" int evlm_wgrad_grouped(const evlm_wgrad_problem* pr, int n, int K, vo
   for (int base = 0; base < n; base += PP_MAXG) {
     const int m = imin(PP_MAXG, n - base);
     PPGroup grp;
-    grp.n = m; grp.rmw = 1; grp.tile0[0] = 0;
+    grp.n = m; grp.tile0[0] = 0;
     for (int k = 0; k < m; ++k) {
       const evlm_wgrad_problem& q = pr[base + k];
       EVLM_REQUIRE(q.P && q.Q && q.C && q.I > 0 && q.J > 0, "evlm_wgrad_grouped: bad problem %d", base + k);
@@ -1083,13 +1083,14 @@ extern "C" int evlm_wgrad_grouped(const evlm_wgrad_problem* pr, int n, int K, vo
       grp.P[k] = q.P; grp.Q[k] = q.Q; grp.C[k] = q.C; grp.psum[k] = q.psum;
       grp.I[k] = q.I; grp.J[k] = q.J; grp.ldp[k] = q.ldp; grp.ldq[k] = q.ldq; grp.ldc[k] = q.ldc;
       grp.assign[k] = q.assign ? 1 : 0;
+      grp.dup[k] = 0;
       grp.tile0[k + 1] = grp.tile0[k] + ceil_div(q.I, 256) * ceil_div(q.J, 256);
-      for (int o = 0; o < k; ++o)
-        if (grp.C[o] == q.C) grp.rmw = 0;           // two contributions to one C in this launch: fall back to atomics
     }
-    if (!grp.rmw)
-      for (int k = 0; k < m; ++k)
-        EVLM_REQUIRE(!grp.assign[k], "evlm_wgrad_grouped: an assigning problem in a call with two contributions to one C");
+    for (int k = 0; k < m; ++k)                       // two contributions to one C in this launch: both run on atomics
+      for (int o = 0; o < k; ++o)
+        if (grp.C[o] == grp.C[k]) { grp.dup[o] = grp.dup[k] = 1; }
+    for (int k = 0; k < m; ++k)
+      EVLM_REQUIRE(!(grp.dup[k] && grp.assign[k]), "evlm_wgrad_grouped: problem %d assigns a C another problem of the call writes", base + k);
     GemmP g;
     memset(&g, 0, sizeof(g));
     g.K = K; g.alpha = 1.0f; g.c_f32 = 1; g.bare_f32 = 1; g.accumulate = 1; g.kt_per_split = K / 64;
