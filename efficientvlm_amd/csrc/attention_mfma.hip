@@ -19,6 +19,7 @@ struct MAttnF {
 };
 
 #define DH 64
+extern "C" int evlm_attention_lse_supported(int dtype, int dh, int Lk, float dropout_p);
 #define LOG2E 1.44269504088896341f
 // 2^x for x <= 0 (softmax numerators, recomputed probabilities): the bare v_exp_f32 (1 ulp; results below 2^-126 flush to
 // zero) instead of exp2f()'s range handling - 8 VALU issue slots per element saved in kernels that are VALU-bound
@@ -418,7 +419,7 @@ static int launch_fwd(const MAttnF& f, hipStream_t stream) {
   int nw = imin(MAXW, (f.Lq + 15) / 16);               // waves per workgroup (16 queries each)
   if (nw_cap > 0 && !SEQ) nw = imin(nw, nw_cap);
   dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
-  if constexpr (NT <= 14) {
+  if constexpr (NT != 26) {                            // (225..416 keys keep the stored-map backward: no lse form)
     if (f.lse) {
       if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT, MAXW, SEQ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -614,122 +615,129 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
 //   pass 2: per key HALF, V_h and K_h side by side in the same LDS space: dP recomputed (2 MFMAs per tile), dS = P .* (dP -
 //           delta) stored for kernel B and consumed at once by dQ^T += K_h^T dS^T.
 // P and E are read twice (the second time mostly from the last-level cache); ~70 VGPRs, 8 waves = 128 queries per workgroup.
-template <int NT, int MAXW>
+template <int NT, int MAXW, bool RC>
 __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HT = NT / 2;                               // key tiles per half (even: tile pairs stay together)
+  constexpr int KSW = RC ? SW_KV : SW_V;
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
   const int bkv = a.kv_index ? a.kv_index[b] : b;
   const bf16* Kb = a.K + (size_t)bkv * a.Lk * a.ldk + h * DH;
   const bf16* Vb = a.V + (size_t)bkv * a.Lk * a.ldv + h * DH;
-  stage_rows<SW_K>(Vb, a.ldv, a.Lk, NT * 16, smem);
-  stage_wait();
+  char* Vs = smem;                                         // k_swz rows (dP = V dO^T)
+  char* Ks = smem + HT * 16 * 128;                         // columns (dQ^T = K^T dS^T); RC: rows too (scores)
+  float* Ms = reinterpret_cast<float*>(smem + NT * 16 * 128);       // RC: mask row of this batch (all keys)
+  if (!RC) {
+    stage_rows<SW_K>(Vb, a.ldv, a.Lk, NT * 16, smem);      // pass 1 of the stored-map form: V of ALL keys
+    stage_wait();
+  } else {
+    stage_mask(a.mask, b, a.Lk, NT * 16, Ms);
+  }
   __syncthreads();
   const int q = (blockIdx.x * (blockDim.x >> 6) + wave) * 16 + ql;
   const bool qok = q < a.Lq;                               // (waves past the last query stay for the barriers)
-  bf16x8 dof[2];
+  bf16x8 dof[2], qf[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    uint4 v = make_uint4(0, 0, 0, 0);
+    uint4 v = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);
     if (qok) v = *reinterpret_cast<const uint4*>(a.dO + ((size_t)b * a.Lq + q) * a.ldo + h * DH + ks * 32 + g * 8);
+    if (RC && qok) vq = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + ks * 32 + g * 8);
     dof[ks] = *reinterpret_cast<bf16x8*>(&v);
+    qf[ks] = *reinterpret_cast<bf16x8*>(&vq);
   }
   const size_t prow = (((size_t)b * a.H + h) * a.Lq + (qok ? q : 0)) * a.ldpr;
   const float gz = a.gate ? a.gate[h] : 1.0f;
   const float kdc = a.Pt ? a.kd_coef * a.kd_gout[0] : 0.f;
+  const float sc = a.scale * LOG2E;
+  const float lse_q = (RC && qok) ? a.lse[((size_t)b * a.H + h) * a.Lq + q] : 0.f;
   float dsum = 0.f, gsum = 0.f;
-#pragma unroll 2
-  for (int s = 0; s < NT / 2; ++s) {
-    const int kcol = s * 32 + g * 8;
-    bf16x8 p8, e8;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { p8[r] = (bf16)0.f; e8[r] = (bf16)0.f; }
-    float ex[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) ex[r] = 0.f;
-    if (qok && kcol < a.ldpr) {
-      p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
-      if (a.E) {
-        e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) ex[r] = (float)e8[r];
-      }
-      if (a.Pt) {
-        const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(a.Pt + prow + kcol);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) ex[r] += kdc * ((float)p8[r] - (float)t8[r]);
-      }
-    }
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(smem, 2 * s + hh, ks, lane), dof[ks], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = (float)p8[hh * 4 + r];
-        gsum += p * acc[r];
-        dsum += p * (gz * acc[r] + ex[hh * 4 + r]);
-      }
-    }
-  }
-  dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
-  if (a.dgate) {
-    const float gs = wave_sum(gsum);
-    if (lane == 0) atomicAdd(a.dgate + h, gs);
-  }
   f32x4 o[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  char* Vs = smem;                                         // k_swz rows (dP = V dO^T)
-  char* Ks = smem + HT * 16 * 128;                         // v_swz columns (dQ^T = K^T dS^T)
-  for (int half = 0; half < 2; ++half) {
-    const int key0 = half * HT * 16;
-    __syncthreads();                                       // every wave is done with the previous contents
-    stage_rows<SW_K>(Vb + (size_t)key0 * a.ldv, a.ldv, a.Lk - key0, HT * 16, Vs);
-    stage_rows<SW_V>(Kb + (size_t)key0 * a.ldk, a.ldk, a.Lk - key0, HT * 16, Ks);
-    stage_wait();
-    __syncthreads();
+  // stored-map form: pass 0 over all keys out of the one V tile staged above, then pass 1 per key half (V_h | K_h);
+  // recomputing form: BOTH passes per key half (the scores need K_h beside V_h): pass 0 the row sums, pass 1 dS / dQ
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      const int key0 = half * HT * 16;
+      const bool staged_all = !RC && pass == 0;            // (every key's V is in LDS: no restaging, one sweep)
+      if (staged_all && half == 1) break;
+      if (!staged_all) {
+        __syncthreads();                                   // every wave is done with the previous contents
+        stage_rows<SW_K>(Vb + (size_t)key0 * a.ldv, a.ldv, a.Lk - key0, HT * 16, Vs);
+        stage_rows<KSW>(Kb + (size_t)key0 * a.ldk, a.ldk, a.Lk - key0, HT * 16, Ks);
+        stage_wait();
+        __syncthreads();
+      }
+      const int npairs = staged_all ? NT / 2 : HT / 2;
 #pragma unroll 2
-    for (int s = 0; s < HT / 2; ++s) {
-      const int kcol = key0 + s * 32 + g * 8;
-      const bool ok = qok && kcol < a.ldpr;
-      bf16x8 p8, e8;
+      for (int s = 0; s < npairs; ++s) {
+        const int kcol = (staged_all ? 0 : key0) + s * 32 + g * 8;
+        const bool ok = qok && kcol < a.ldpr;
+        float pr[8], ex[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) { p8[r] = (bf16)0.f; e8[r] = (bf16)0.f; }
-      float ex[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) ex[r] = 0.f;
-      if (ok) {
-        p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
-        if (a.E) {
-          e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
-#pragma unroll
-          for (int r = 0; r < 8; ++r) ex[r] = (float)e8[r];
+        for (int r = 0; r < 8; ++r) { pr[r] = 0.f; ex[r] = 0.f; }
+        if (RC) {
+          // (the mask strip covers all keys: tile s of this half is tile HT/2*half + s of the row; recompute_p indexes the
+          // strip by tile through `Ms + key0`)
+          recompute_p<KSW>(Ks, Ms + key0, qf, s, g, lane, sc, lse_q, qok, a.causal, q - key0, pr);
         }
-        if (a.Pt) {
-          const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(a.Pt + prow + kcol);
+        if (ok) {
+          if (!RC) {
+            const bf16x8 p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) ex[r] += kdc * ((float)p8[r] - (float)t8[r]);
+            for (int r = 0; r < 8; ++r) pr[r] = (float)p8[r];
+          }
+          if (a.E) {
+            const bf16x8 e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) ex[r] = (float)e8[r];
+          }
+          if (a.Pt) {
+            const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(a.Pt + prow + kcol);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) ex[r] = fmaf(kdc, pr[r] - (float)t8[r], ex[r]);
+          }
+        }
+        bf16x8 d8, p8o;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, 2 * s + hh, ks, lane), dof[ks], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = pr[hh * 4 + r];
+            const float dp = fmaf(gz, acc[r], ex[hh * 4 + r]);
+            if (pass == 0) {
+              gsum = fmaf(p, acc[r], gsum);
+              dsum = fmaf(p, dp, dsum);
+            } else {
+              d8[hh * 4 + r] = (bf16)(p * (dp - dsum));
+              p8o[hh * 4 + r] = (bf16)p;
+            }
+          }
+        }
+        if (pass == 1) {
+          if (ok) {
+            *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
+            if (RC && a.Pw) *reinterpret_cast<bf16x8*>(a.Pw + prow + kcol) = p8o;
+          }
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag<KSW>(Ks, 2 * s, 2 * s + 1, dt, lane), d8, o[dt], 0, 0, 0);
         }
       }
-      bf16x8 d8;
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, 2 * s + hh, ks, lane), dof[ks], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          d8[hh * 4 + r] = (bf16)((float)p8[hh * 4 + r] * (gz * acc[r] + ex[hh * 4 + r] - dsum));
+    }
+    if (pass == 0) {
+      dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
+      if (a.dgate) {
+        const float gs = wave_sum(gsum);
+        if (lane == 0) atomicAdd(a.dgate + h, gs);
       }
-      if (ok) *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Ks, 2 * s, 2 * s + 1, dt, lane), d8, o[dt], 0, 0, 0);
     }
   }
   if (qok) {
@@ -1061,14 +1069,14 @@ static void launch_bwd_dq(const MAttnB& f, hipStream_t stream) {
   hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NT, MAXW, RC>), grid, block, lds, stream, f);
 }
 
-template <int NT>
+template <int NT, bool RC>
 static void launch_bwd_dq_long(const MAttnB& f, hipStream_t stream) {
   constexpr int MAXW = 8;
-  const size_t lds = (size_t)NT * 16 * 128;
-  (void)hipFuncSetAttribute((const void*)attn_bwd_dq_long_kernel<NT, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t lds = (size_t)NT * 16 * 128 + (RC ? NT * 16 * sizeof(float) : 0);
+  (void)hipFuncSetAttribute((const void*)attn_bwd_dq_long_kernel<NT, MAXW, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nw = imin(MAXW, (f.Lq + 15) / 16);
   dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
-  hipLaunchKernelGGL((attn_bwd_dq_long_kernel<NT, MAXW>), grid, block, lds, stream, f);
+  hipLaunchKernelGGL((attn_bwd_dq_long_kernel<NT, MAXW, RC>), grid, block, lds, stream, f);
 }
 
 int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int* handled) {
@@ -1087,13 +1095,14 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
   if (a->kd_teacher && !a->kd_gout) return evlm_set_error("evlm_attention_bwd: kd_teacher without kd_gout");
   f.lse = a->lse; f.mask = a->mask; f.causal = a->causal; f.Pw = nullptr;
   const bool rc = a->lse != nullptr;
-  if (rc && a->Lk > 224) return evlm_set_error("evlm_attention_bwd: the recomputing form serves Lk <= 224 (got %d)", a->Lk);
+  if (rc && !evlm_attention_lse_supported(a->dtype, a->dh, a->Lk, 0.f))
+    return evlm_set_error("evlm_attention_bwd: the recomputing form serves Lk <= 224 and 417..928 (got %d)", a->Lk);
   if (!rc && !a->P) return evlm_set_error("evlm_attention_bwd: neither the probability map nor the row lse was given");
   bool fused = false;                       // whole (batch, head) problems that fit one workgroup: one launch, no dS in HBM
   if (rc) {
     if (a->Lk <= 32) fused = launch_bwd_fused<2, true>(f, stream);
     else if (a->Lk <= 64) fused = launch_bwd_fused<4, true>(f, stream);
-    else fused = launch_bwd_fused<14, true>(f, stream);
+    else if (a->Lk <= 224) fused = launch_bwd_fused<14, true>(f, stream);
   } else {
     if (a->Lk <= 32) fused = launch_bwd_fused<2, false>(f, stream);
     else if (a->Lk <= 64) fused = launch_bwd_fused<4, false>(f, stream);
@@ -1118,13 +1127,15 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
     // cycles per wave, so the staging it would share is a small part of it, and 256 registers leave one workgroup per CU)
     if (a->Lk <= 32) launch_bwd_dq<2, true>(f, stream);
     else if (a->Lk <= 64) launch_bwd_dq<4, true>(f, stream);
-    else launch_bwd_dq<14, true>(f, stream);
+    else if (a->Lk <= 224) launch_bwd_dq<14, true>(f, stream);
+    else if (a->Lk <= 640) launch_bwd_dq_long<40, true>(f, stream);
+    else launch_bwd_dq_long<60, true>(f, stream);
   } else if (a->Lk <= 32) launch_bwd_dq<2, false>(f, stream);
   else if (a->Lk <= 64) launch_bwd_dq<4, false>(f, stream);
   else if (a->Lk <= 224) launch_bwd_dq<14, false>(f, stream);
   else if (a->Lk <= 416) launch_bwd_dq<26, false>(f, stream);
-  else if (a->Lk <= 640) launch_bwd_dq_long<40>(f, stream);      // long sequences: two passes over the keys, nothing spilled
-  else launch_bwd_dq_long<60>(f, stream);
+  else if (a->Lk <= 640) launch_bwd_dq_long<40, false>(f, stream);      // long sequences: two passes over the keys, nothing spilled
+  else launch_bwd_dq_long<60, false>(f, stream);
   dim3 gridB((a->Lk + 63) / 64, a->H, f.Bkv), block(256);
   hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, gridB, block, 0, stream, f);
   hipError_t e = hipGetLastError();
@@ -1134,7 +1145,9 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
 }
 
 extern "C" int evlm_attention_lse_supported(int dtype, int dh, int Lk, float dropout_p) {
-  return dtype == EVLM_BF16 && dh == DH && Lk <= 224 && dropout_p == 0.f;
+  // (225..416 keys: the one-pass kernel A of that bucket holds a whole row in registers and has no room for the
+  // recomputed probabilities; 417..928 keys run the two-pass kernel, which recomputes per key half)
+  return dtype == EVLM_BF16 && dh == DH && (Lk <= 224 || (Lk > 416 && Lk <= 928)) && dropout_p == 0.f;
 }
 
 // returns 0 and sets *handled = 1 when a specialised kernel took the call
@@ -1150,7 +1163,8 @@ int evlm_attention_fwd_mfma(const evlm_attn_fwd_args* a, hipStream_t stream, int
   f.Pt = (const bf16*)a->kd_teacher; f.kd = a->kd_loss;
   f.kd_coef = a->kd_teacher ? a->kd_weight / ((float)a->B * a->H * a->Lq * a->Lk) : 0.f;
   f.lse = a->lse;
-  if (a->lse && a->Lk > 224) return evlm_set_error("evlm_attention_fwd: the lse form serves Lk <= 224 (got %d)", a->Lk);
+  if (a->lse && !evlm_attention_lse_supported(a->dtype, a->dh, a->Lk, 0.f))
+    return evlm_set_error("evlm_attention_fwd: the lse form serves Lk <= 224 and 417..928 (got %d)", a->Lk);
   if (a->kd_teacher && !a->kd_loss) return evlm_set_error("evlm_attention_fwd: kd_teacher without kd_loss");
   if (a->Lk > 64 && a->Lk <= 224 && launch_fwd_grouped<14>(f, a->Bkv, stream)) {}
   else if (a->Lk <= 32) launch_fwd<2>(f, stream);

@@ -114,7 +114,7 @@ def itr_loss_mix(loss, kd, lagrangian):
                                                            loss_cross_kd=loss_cross_kd, loss_kd=loss_kd)
 
 
-def vqa_kd_terms(S, T, temperature=1.0):
+def vqa_kd_terms(S, T, temperature=1.0, fused=None):
     """Eff_VQA.py:113-163.  The split of the question encoder's lists at state 4 / map 3 is hard-coded there for the
     (3 text + 3 fusion)-layer student; the decoder-hidden term passes is_img=True (skip of list index 6: a no-op on the
     student's 4 decoder states)."""
@@ -128,7 +128,8 @@ def vqa_kd_terms(S, T, temperature=1.0):
         "cross_hidden": get_kd_loss(s_h[4:], t_h[4:]), "cross_self_attn": get_kd_loss(s_a[3:], t_a[3:], is_attn=True),
         "cross_attn": get_kd_loss(sc["cross_attentions"], cor(tc, sc, "cross_attentions", True), is_attn=True),
         "image_hidden": get_kd_loss(sh["image_hidden_states"], cor(th, sh, "image_hidden_states", False), is_img=True),
-        "image_attn": get_kd_loss(sa["image_attentions"], cor(ta, sa, "image_attentions", True), is_attn=True),
+        "image_attn": (fused["image_attn"] if fused and "image_attn" in fused else
+                       get_kd_loss(sa["image_attentions"], cor(ta, sa, "image_attentions", True), is_attn=True)),
         "decoder_hidden": get_kd_loss(sh["decoder_hidden_states"], cor(th, sh, "decoder_hidden_states", False), is_img=True),
         "decoder_attn": get_kd_loss(sa["decoder_attentions"], cor(ta, sa, "decoder_attentions", True), is_attn=True),
         "decoder_cross": get_kd_loss(sc["decoder_cross_attentions"], cor(tc, sc, "decoder_cross_attentions", True), is_attn=True),
@@ -248,6 +249,19 @@ def collect_fused_kd(enc):
     if not terms or any(t is None for t in terms) or len(terms) != len(enc.layers):
         raise RuntimeError("fused attention-map distillation: a ViT layer did not report its term")
     return {"image_attn": torch.stack(terms).sum()}
+
+
+def student_forward_fused_kd(student, call, teacher_out, batch):
+    """student forward (`call()`) with the image-map distillation fused into its attention kernels when the teacher's
+    outputs of this batch exist already (pipelined trainers); returns (student outputs, {'image_attn': term} or {})"""
+    enc = fuse_image_map_kd(student, teacher_out, batch) if teacher_out is not None else None
+    try:
+        S = call()
+    except BaseException:
+        if enc is not None:                    # disarm the encoder; the forward's own exception is the one to report
+            enc.kd_teacher_maps = enc.kd_fused = None
+        raise
+    return S, (collect_fused_kd(enc) if enc is not None else {})
 
 
 def gd_forward(student, teacher, batch, temperature=1.0, overlap_teacher=False, teacher_out=None):

@@ -879,6 +879,9 @@ class ITRTrainer(_StagedExchange):
             teacher_map_filter(student, teacher, with_cross=True)
         self.global_step = 0
         self.prefetch = TeacherPrefetch(self._teacher_forward, use_graph) if pipeline_teacher else None
+        enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
+        if enc is not None and hasattr(enc, "kd_drop_maps") and not os.environ.get("EVLM_STUDENT_ALL_MAPS"):
+            enc.kd_drop_maps = True        # a ViT map whose distillation term was formed in-kernel is not materialised
 
     def _teacher_forward(self, b):
         with torch.no_grad(), compute(self.dtype):
@@ -899,14 +902,18 @@ class ITRTrainer(_StagedExchange):
         l0 = self.student.l0_module
         with compute(self.dtype):
             kw = dict(idx=idx, output_attentions=True, output_hidden_states=True)
-            if T_ready is not None:
-                S, T = self.student(batch["image"], batch["text_ids"], batch["text_atts"], **kw), T_ready
+            fused = {}
+            if T_ready is not None:      # the teacher's maps exist: the image-map term is formed inside the attention kernels
+                S, fused = distill.student_forward_fused_kd(
+                    self.student, lambda: self.student(batch["image"], batch["text_ids"], batch["text_atts"], **kw),
+                    T_ready, batch)
+                T = T_ready
             else:
                 S, T = distill.student_and_teacher(
                     lambda: self.student(batch["image"], batch["text_ids"], batch["text_atts"], **kw),
                     lambda: self.teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw),
                     batch["image"], self.overlap_teacher)
-            kd = distill.kd_terms(S, T, self.temperature, with_cross_attn=True)
+            kd = distill.kd_terms(S, T, self.temperature, with_cross_attn=True, fused=fused)
             lagrangian, _, _ = l0.lagrangian_regularization(self.global_step)
             total, mix = distill.itr_loss_mix(S["loss"], kd, lagrangian)
             ops.WGRAD_INPLACE = True
@@ -961,6 +968,9 @@ class VQATrainer(_StagedExchange):
         self.overlap_teacher = not os.environ.get("EVLM_NO_OVERLAP_TEACHER")
         self.global_step = 0
         self.prefetch = TeacherPrefetch(self._teacher_forward, use_graph) if pipeline_teacher else None
+        enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
+        if enc is not None and hasattr(enc, "kd_drop_maps") and not os.environ.get("EVLM_STUDENT_ALL_MAPS"):
+            enc.kd_drop_maps = True        # a ViT map whose distillation term was formed in-kernel is not materialised
 
     def _teacher_forward(self, b):
         from types import SimpleNamespace as NS
@@ -986,13 +996,17 @@ class VQATrainer(_StagedExchange):
         answer = NS(input_ids=batch["answer_ids"], attention_mask=batch["answer_atts"])
         kw = dict(train=True, k=batch["k"], weights=batch["weights"], output_attentions=True, output_hidden_states=True)
         with compute(self.dtype):
+            fused = {}
             if T_ready is not None:
-                S, T = self.student(batch["image"], question, answer, stop_prune=stop_prune, **kw), T_ready
+                S, fused = distill.student_forward_fused_kd(
+                    self.student, lambda: self.student(batch["image"], question, answer, stop_prune=stop_prune, **kw),
+                    T_ready, batch)
+                T = T_ready
             else:
                 S, T = distill.student_and_teacher(
                     lambda: self.student(batch["image"], question, answer, stop_prune=stop_prune, **kw),
                     lambda: self.teacher(batch["image"], question, answer, **kw), batch["image"], self.overlap_teacher)
-            kd = distill.vqa_kd_terms(S, T, self.temperature)
+            kd = distill.vqa_kd_terms(S, T, self.temperature, fused=fused)
             lagrangian, _, _ = l0.lagrangian_regularization(self.global_step)
             total, mix = distill.vqa_loss_mix(S["loss"], kd, lagrangian)
             ops.WGRAD_INPLACE = True

@@ -1076,9 +1076,10 @@ def _attn_problem(B, Bkv, H, Lq, Lk, seed, self_attn):
     return x, kv, mask.to(DEV), idx, gO, dh, d
 
 
-@pytest.mark.parametrize("case", ["vit197", "text30", "cross197", "cross_shared", "causal40"])
+@pytest.mark.parametrize("case", ["vit197", "text30", "cross197", "cross_shared", "causal40", "vit577", "vit901", "cross577"])
 def test_recomputing_attention_backward_needs_no_stored_map_and_tightens_the_gradients(case, monkeypatch):
-    """The recomputing form (default for bf16, head dim 64, Lk <= 224, no dropout): with want_probs=False NO [B, H, Lq, Lk]
+    """The recomputing form (default for bf16, head dim 64, Lk <= 224 or 417..928 - the two-pass long-sequence kernel
+    recomputes per key half -, no dropout): with want_probs=False NO [B, H, Lq, Lk]
     map exists in HBM (the forward returns None, the backward rebuilds P from Q, K and the saved row lse in fp32) and the
     gradients sit closer to the fp32 reference than those formed from the stored bf16 map (the round-2 form,
     ATTN_STORE_P) - the query / key gradient is the cancellation P .* (dP - delta)."""
@@ -1086,7 +1087,9 @@ def test_recomputing_attention_backward_needs_no_stored_map_and_tightens_the_gra
     B, Bkv, H, Lq, Lk, self_attn, causal = {"vit197": (3, 3, 12, 197, 197, True, False), "text30": (4, 4, 12, 30, 30, True, False),
                                             "cross197": (3, 3, 12, 30, 197, False, False),
                                             "cross_shared": (7, 3, 12, 30, 197, False, False),
-                                            "causal40": (2, 2, 12, 40, 40, True, True)}[case]
+                                            "causal40": (2, 2, 12, 40, 40, True, True),
+                                            "vit577": (2, 2, 12, 577, 577, True, False), "vit901": (1, 1, 4, 901, 901, True, False),
+                                            "cross577": (5, 2, 12, 30, 577, False, False)}[case]
     x0, kv0, mask, idx, gO, dh, d = _attn_problem(B, Bkv, H, Lq, Lk, 900 + Lq + Lk, self_attn)
     scale = dh ** -0.5
 

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round profile bundle (run on the GPU box from the repo root): default bench line, rocprofv3 kernel stats of the bench
 # command, and the PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) summarised per kernel.  Only small summaries are kept.
-#   EVLM_COMMIT=<sha> OUT=gpurun_out/r02p tools/profile_round.sh
+#   EVLM_COMMIT=<sha> OUT=gpurun_out/r03p tools/profile_round.sh
 set -u
-OUT=${OUT:-gpurun_out/r02p}
+OUT=${OUT:-gpurun_out/r03p}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 bench.py > $OUT/bench_default.log 2>&1
