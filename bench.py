@@ -62,16 +62,20 @@ def make_trainer(student, teacher, dtype, use_graph, pipelined):
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU legs (child processes that never touch the GPU): the reported CPU baseline and the oracle side of the loss check
 # ---------------------------------------------------------------------------------------------------------------------
+def _cpu_allowed():
+    """cores this process may run on"""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)
+
+
 def _cpu_threads():
-    """threads the CPU legs use: every core this process is allowed on (all host cores; EVLM_CPU_THREADS
-    overrides, e.g. on a quota-limited container whose affinity mask is wider than its CPU quota)"""
+    """threads of the oracle-check CPU leg (not a timed leg): EVLM_CPU_THREADS, else every allowed core up to 64 (past one
+    socket the fp32 oracle at these batch sizes only gets slower, see cpu_baseline_child)"""
     if os.environ.get("EVLM_CPU_THREADS"):
         return max(1, int(os.environ["EVLM_CPU_THREADS"]))
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, n)
+    return min(_cpu_allowed(), 64)
 
 
 def _cpu_model():
@@ -108,8 +112,6 @@ def cpu_baseline_child(budget_s=60.0):
     string says how many were timed).  Prints one JSON object."""
     from oracle import synth
     from oracle import xvlm_oracle as O
-    nthreads = _cpu_threads()
-    torch.set_num_threads(nthreads)
     geom, s_cfg, t_cfg, s_sd, t_sd = _oracle_state(1, 2)
     s_sd, t_sd = _tie(s_sd), _tie(t_sd)
     leaves = {}
@@ -133,12 +135,33 @@ def cpu_baseline_child(budget_s=60.0):
                 break
         return times
 
+    # Thread count: BASELINE.md asks for every host core.  The GPU boxes report 256 logical CPUs (2 x 64 cores, SMT) and the
+    # fp32 oracle at batch 4 does not finish a step in tens of seconds on 256 threads (memory-bound small GEMMs, two NUMA
+    # nodes), so the count is PROBED: one warm + one timed batch-4 step per candidate, ascending, stopping when more threads
+    # stop helping; the protocol below then runs on the fastest.  EVLM_CPU_THREADS pins it.
+    allowed = _cpu_allowed()
+    if os.environ.get("EVLM_CPU_THREADS"):
+        cands = [max(1, int(os.environ["EVLM_CPU_THREADS"]))]
+    else:
+        cands = sorted({min(allowed, c) for c in (32, 64, 128, allowed)})
+    probe, best = {}, None
+    for c in cands:
+        torch.set_num_threads(c)
+        t = run(4, 1, 1, time.time() + 60.0)
+        probe[c] = round(t[0], 2)
+        if best is not None and t[0] > probe[best] * 0.97:
+            break                                  # no gain from more threads
+        best = c
+    nthreads = best
+    torch.set_num_threads(nthreads)
     t_start = time.time()
     t4 = run(4, 3, 5, t_start + budget_s)
     med4 = sorted(t4)[len(t4) // 2]
-    res = {"value": round(4 / med4, 3), "unit": "pairs/s", "cores": nthreads, "kind": "port", "cpu": _cpu_model(),
+    res = {"value": round(4 / med4, 3), "unit": "pairs/s", "cores": nthreads, "cores_allowed": allowed,
+           "thread_probe_s_per_step": probe, "kind": "port", "cpu": _cpu_model(),
            "sample": f"BASELINE configs[0]: GD step of batch 4 (224x224, 30 tokens), fp32, oracle/xvlm_oracle.py on "
-                     f"{nthreads} host threads, 3 warm-up + {len(t4)} timed steps, median {med4:.2f} s"}
+                     f"{nthreads} host threads (fastest of a probe over {list(probe)} of {allowed} allowed), 3 warm-up + "
+                     f"{len(t4)} timed steps, median {med4:.2f} s"}
     if time.time() - t_start < budget_s * 0.6:
         t16 = run(16, 3, 5, t_start + budget_s)
         med16 = sorted(t16)[len(t16) // 2]
