@@ -1146,8 +1146,13 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
 
 extern "C" int evlm_attention_lse_supported(int dtype, int dh, int Lk, float dropout_p) {
   // (225..416 keys: the one-pass kernel A of that bucket holds a whole row in registers and has no room for the
-  // recomputed probabilities; 417..928 keys run the two-pass kernel, which recomputes per key half)
-  return dtype == EVLM_BF16 && dh == DH && (Lk <= 224 || (Lk > 416 && Lk <= 928)) && dropout_p == 0.f;
+  // recomputed probabilities; 417..928 keys run the two-pass kernel, which recomputes per key half - EVLM_ATTN_RC_LONG=0/1
+  // switches that bucket, read per call)
+  if (dtype != EVLM_BF16 || dh != DH || dropout_p != 0.f) return 0;
+  if (Lk <= 224) return 1;
+  const char* env = getenv("EVLM_ATTN_RC_LONG");
+  const bool rc_long = env ? atoi(env) != 0 : true;
+  return rc_long && Lk > 416 && Lk <= 928;
 }
 
 // returns 0 and sets *handled = 1 when a specialised kernel took the call

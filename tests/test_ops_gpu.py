@@ -1185,22 +1185,24 @@ def test_attention_lse_form_refuses_what_it_cannot_serve():
     from efficientvlm_amd import _lib as L
     lib = L.load()
     assert lib.evlm_attention_lse_supported(L.BF16, 64, 197, 0.0) == 1
-    assert lib.evlm_attention_lse_supported(L.BF16, 64, 577, 0.0) == 0
+    assert lib.evlm_attention_lse_supported(L.BF16, 64, 577, 0.0) == 1        # the two-pass long-sequence kernel
+    assert lib.evlm_attention_lse_supported(L.BF16, 64, 300, 0.0) == 0        # 225..416 keys: stored-map form only
+    assert lib.evlm_attention_lse_supported(L.BF16, 64, 1000, 0.0) == 0
     assert lib.evlm_attention_lse_supported(L.F32, 64, 30, 0.0) == 0
     assert lib.evlm_attention_lse_supported(L.BF16, 32, 30, 0.0) == 0
     assert lib.evlm_attention_lse_supported(L.BF16, 64, 30, 0.1) == 0
-    B, H, Lq, Lk, dh = 1, 2, 16, 577, 64
+    B, H, Lq, Lk, dh = 1, 2, 16, 300, 64
     d = H * dh
     q = torch.zeros(B, Lq, d, dtype=torch.bfloat16, device=DEV)
     kv = torch.zeros(B, Lk, 2 * d, dtype=torch.bfloat16, device=DEV)
     O = torch.empty_like(q)
     lse = torch.empty(B, H, Lq, dtype=torch.float32, device=DEV)
-    a = L.AttnFwdArgs(dtype=L.BF16, p_dtype=L.BF16, B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, ldpr=584,
+    a = L.AttnFwdArgs(dtype=L.BF16, p_dtype=L.BF16, B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d, ldpr=304,
                       Q=L.ptr(q), K=L.ptr(kv), V=C.c_void_p(kv.data_ptr() + d * 2), scale=0.125, O=L.ptr(O), lse=L.ptr(lse))
     assert lib.evlm_attention_fwd(C.byref(a), L.stream()) != 0 and b"lse" in lib.evlm_last_error()
     dq, dkv = torch.empty_like(q), torch.empty_like(kv)
     b = L.AttnBwdArgs(dtype=L.BF16, p_dtype=L.BF16, B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, Bkv=B, ldq=d, ldk=2 * d, ldv=2 * d, ldo=d,
-                      lddq=d, lddk=2 * d, lddv=2 * d, ldpr=584, Q=L.ptr(q), K=L.ptr(kv), V=C.c_void_p(kv.data_ptr() + d * 2),
+                      lddq=d, lddk=2 * d, lddv=2 * d, ldpr=304, Q=L.ptr(q), K=L.ptr(kv), V=C.c_void_p(kv.data_ptr() + d * 2),
                       dO=L.ptr(O), scale=0.125, dQ=L.ptr(dq), dK=L.ptr(dkv), dV=C.c_void_p(dkv.data_ptr() + d * 2), lse=L.ptr(lse))
     assert lib.evlm_attention_bwd(C.byref(b), L.stream()) != 0
     b.lse = None                                          # neither P nor lse
