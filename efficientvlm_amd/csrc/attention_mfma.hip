@@ -750,138 +750,6 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
   }
 }
 
-// Recomputing long-sequence kernel A with the probabilities CACHED between its two passes (NT <= 40: 577 keys at 384 x 384):
-// pass 0 rebuilds p = 2^(s - lse) in fp32 for the row sums (delta, the gate gradient) and keeps a bf16 copy of it in
-// registers (NT x 2 VGPRs per lane); pass 1 forms dS = p (dP - delta) from that copy instead of running the score MFMAs
-// and the exponentials a second time.  The cancellation that made a bf16 map costly sits in delta (a sum over the whole
-// row) - formed from the fp32 values; a bf16 p as the outer factor of dS is a plain 0.4 % rounding.
-template <int NT, int MAXW>
-__global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_pc_kernel(MAttnB a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int HT = NT / 2, HP = HT / 2;                  // key tiles / tile pairs per half
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
-  const int bkv = a.kv_index ? a.kv_index[b] : b;
-  const bf16* Kb = a.K + (size_t)bkv * a.Lk * a.ldk + h * DH;
-  const bf16* Vb = a.V + (size_t)bkv * a.Lk * a.ldv + h * DH;
-  char* Vs = smem;                                         // k_swz rows (dP = V dO^T)
-  char* Ks = smem + HT * 16 * 128;                         // SW_KV: rows (scores) and columns (dQ^T = K^T dS^T)
-  float* Ms = reinterpret_cast<float*>(smem + NT * 16 * 128);
-  stage_mask(a.mask, b, a.Lk, NT * 16, Ms);
-  const int q = (blockIdx.x * (blockDim.x >> 6) + wave) * 16 + ql;
-  const bool qok = q < a.Lq;                               // (waves past the last query stay for the barriers)
-  bf16x8 dof[2], qf[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    uint4 v = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0);
-    if (qok) {
-      v = *reinterpret_cast<const uint4*>(a.dO + ((size_t)b * a.Lq + q) * a.ldo + h * DH + ks * 32 + g * 8);
-      vq = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + ks * 32 + g * 8);
-    }
-    dof[ks] = *reinterpret_cast<bf16x8*>(&v);
-    qf[ks] = *reinterpret_cast<bf16x8*>(&vq);
-  }
-  const size_t prow = (((size_t)b * a.H + h) * a.Lq + (qok ? q : 0)) * a.ldpr;
-  const float gz = a.gate ? a.gate[h] : 1.0f;
-  const float kdc = a.Pt ? a.kd_coef * a.kd_gout[0] : 0.f;
-  const float sc = a.scale * LOG2E;
-  const float lse_q = qok ? a.lse[((size_t)b * a.H + h) * a.Lq + q] : 0.f;
-  float dsum = 0.f, gsum = 0.f;
-  bf16x8 pc[2 * HP];                                       // the row's probabilities, 8 keys per entry
-  f32x4 o[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int key0 = half * HT * 16;
-      __syncthreads();                                     // every wave is done with the previous contents (and the mask is in)
-      stage_rows<SW_K>(Vb + (size_t)key0 * a.ldv, a.ldv, a.Lk - key0, HT * 16, Vs);
-      stage_rows<SW_KV>(Kb + (size_t)key0 * a.ldk, a.ldk, a.Lk - key0, HT * 16, Ks);
-      stage_wait();
-      __syncthreads();
-#pragma unroll
-      for (int s = 0; s < HP; ++s) {
-        // (the loops are unrolled for the register-resident cache; without a fence per pair the scheduler hoists the
-        // global loads of all twenty pairs to the top: 269 spilled registers)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        const int kcol = key0 + s * 32 + g * 8;
-        const bool ok = qok && kcol < a.ldpr;
-        float pr[8], ex[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { pr[r] = 0.f; ex[r] = 0.f; }
-        if (pass == 0) {
-          recompute_p<SW_KV>(Ks, Ms + key0, qf, s, g, lane, sc, lse_q, qok, a.causal, q - key0, pr);
-          bf16x8 c;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) c[r] = (bf16)pr[r];
-          pc[half * HP + s] = c;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) pr[r] = (float)pc[half * HP + s][r];
-        }
-        if (ok) {
-          if (a.E) {
-            const bf16x8 e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) ex[r] = (float)e8[r];
-          }
-          if (a.Pt) {
-            const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(a.Pt + prow + kcol);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) ex[r] = fmaf(kdc, pr[r] - (float)t8[r], ex[r]);
-          }
-        }
-        bf16x8 d8;
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, 2 * s + hh, ks, lane), dof[ks], acc, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = pr[hh * 4 + r];
-            const float dp = fmaf(gz, acc[r], ex[hh * 4 + r]);
-            if (pass == 0) {
-              gsum = fmaf(p, acc[r], gsum);
-              dsum = fmaf(p, dp, dsum);
-            } else {
-              d8[hh * 4 + r] = (bf16)(p * (dp - dsum));
-            }
-          }
-        }
-        if (pass == 1) {
-          if (ok) {
-            *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
-            if (a.Pw) *reinterpret_cast<bf16x8*>(a.Pw + prow + kcol) = pc[half * HP + s];
-          }
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt)
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag<SW_KV>(Ks, 2 * s, 2 * s + 1, dt, lane), d8, o[dt], 0, 0, 0);
-        }
-      }
-    }
-    if (pass == 0) {
-      dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
-      if (a.dgate) {
-        const float gs = wave_sum(gsum);
-        if (lane == 0) atomicAdd(a.dgate + h, gs);
-      }
-    }
-  }
-  if (qok) {
-    bf16* dQr = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + h * DH;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      bf16x4 ov = {(bf16)(o[dt][0] * a.scale), (bf16)(o[dt][1] * a.scale), (bf16)(o[dt][2] * a.scale), (bf16)(o[dt][3] * a.scale)};
-      *reinterpret_cast<bf16x4*>(dQr + dt * 16 + g * 4) = ov;
-    }
-  }
-}
-
 // kernel B: one workgroup = 64 keys of one (batch, head); wave w owns key tile w.  Sums over the queries in chunks of 32:
 //   dK^T[d][key] = scale * sum_q Q[q][d] dS[q][key] ;  dV^T[d][key] = gate * sum_q dO[q][d] P[q][key]
 // All four operands are [32 q][64] bf16 LDS tiles read by COLUMNS (ds_read_b64_tr_b16): the reduction index (q) is
@@ -1201,16 +1069,6 @@ static void launch_bwd_dq(const MAttnB& f, hipStream_t stream) {
   hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NT, MAXW, RC>), grid, block, lds, stream, f);
 }
 
-template <int NT>
-static void launch_bwd_dq_long_pc(const MAttnB& f, hipStream_t stream) {
-  constexpr int MAXW = 8;
-  const size_t lds = (size_t)NT * 16 * 128 + NT * 16 * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)attn_bwd_dq_long_pc_kernel<NT, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int nw = imin(MAXW, (f.Lq + 15) / 16);
-  dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
-  hipLaunchKernelGGL((attn_bwd_dq_long_pc_kernel<NT, MAXW>), grid, block, lds, stream, f);
-}
-
 template <int NT, bool RC>
 static void launch_bwd_dq_long(const MAttnB& f, hipStream_t stream) {
   constexpr int MAXW = 8;
@@ -1270,7 +1128,7 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
     if (a->Lk <= 32) launch_bwd_dq<2, true>(f, stream);
     else if (a->Lk <= 64) launch_bwd_dq<4, true>(f, stream);
     else if (a->Lk <= 224) launch_bwd_dq<14, true>(f, stream);
-    else if (a->Lk <= 640) { if (getenv("EVLM_ATTN_NO_PCACHE")) launch_bwd_dq_long<40, true>(f, stream); else launch_bwd_dq_long_pc<40>(f, stream); }
+    else if (a->Lk <= 640) launch_bwd_dq_long<40, true>(f, stream);
     else launch_bwd_dq_long<60, true>(f, stream);
   } else if (a->Lk <= 32) launch_bwd_dq<2, false>(f, stream);
   else if (a->Lk <= 64) launch_bwd_dq<4, false>(f, stream);
@@ -1287,14 +1145,15 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
 }
 
 extern "C" int evlm_attention_lse_supported(int dtype, int dh, int Lk, float dropout_p) {
-  // (225..416 keys: the one-pass kernel A of that bucket holds a whole row in registers and has no room for the
-  // recomputed probabilities; 417..928 keys run the two-pass kernel, which recomputes per key half - EVLM_ATTN_RC_LONG=0/1
-  // switches that bucket, read per call)
+  // Lk <= 224: the default.  417..928 keys (384 x 384 / 480 x 480 images): the two-pass kernel can recompute per key half too,
+  // but that is OPT-IN (EVLM_ATTN_RC_LONG=1, read per call): measured on the ITR-384 step it costs 4.6 % of the step (the
+  // kernel is VALU-bound: a second score product + exponentials per pass) and changes nothing in the gradient parity there
+  // (tools/itr_grad_parity.py: cosine 0.99998, query / key median 1.3 % either way).  225..416 keys: stored-map form only
+  // (the one-pass kernel A of that bucket holds a whole row in registers).
   if (dtype != EVLM_BF16 || dh != DH || dropout_p != 0.f) return 0;
   if (Lk <= 224) return 1;
   const char* env = getenv("EVLM_ATTN_RC_LONG");
-  const bool rc_long = env ? atoi(env) != 0 : true;
-  return rc_long && Lk > 416 && Lk <= 928;
+  return env && atoi(env) != 0 && Lk > 416 && Lk <= 928;
 }
 
 // returns 0 and sets *handled = 1 when a specialised kernel took the call

@@ -4,6 +4,8 @@ Eff_VQA.py:165-176,
 with the same names and argument meaning.  MSE and the dual-softmax KL run as HIP reductions (evlm_mse_*, evlm_kl_*);
 each term is a device scalar, so a whole step issues no host synchronisation.
 """
+import os
+
 import torch
 
 from . import ops
@@ -225,6 +227,8 @@ def fuse_image_map_kd(student, teacher_out, batch):
     from .runtime import compute_dtype
     enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
     if enc is None or not hasattr(enc, "kd_teacher_maps") or teacher_out is None or "idx_to_group_img" in batch:
+        return None
+    if os.environ.get("EVLM_NO_FUSED_KD"):          # (A/B switch)
         return None
     if compute_dtype() != torch.bfloat16:
         return None
