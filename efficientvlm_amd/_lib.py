@@ -72,7 +72,7 @@ SIGNATURES = {
     "evlm_wgrad_grouped": [C.POINTER(WgradProblem), _i, _i, _vp],
     "evlm_layernorm_bwd_blocks": [_i],
     "evlm_layernorm_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "evlm_layernorm_bwd_add": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "evlm_layernorm_bwd_add": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "evlm_attention_fwd": [C.POINTER(AttnFwdArgs), _vp],
     "evlm_attention_bwd": [C.POINTER(AttnBwdArgs), _vp],
     "evlm_attention_lse_supported": [_i, _i, _i, _f],

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const T* __restrict__ x
 // owns; the 4 waves are reduced through LDS, then ONE f32 atomic per column per block.
 template <typename T, int DCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ addend,
+                                                     const T* __restrict__ addend2,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, int rows, int d, T* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -173,6 +174,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
           if (addend) {               // the gradient that reaches x past this LayerNorm (residual branch): summed here
             float ad[8];
             load8<T>(addend + (size_t)(row0 + r) * d + c * 8, ad);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += ad[e];
+          }
+          if (addend2) {              // ... and a second one: the distillation term that reads x itself (the "tap")
+            float ad[8];
+            load8<T>(addend2 + (size_t)(row0 + r) * d + c * 8, ad);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] += ad[e];
           }
@@ -275,7 +282,7 @@ static int ln_bwd_blocks(int rows) { return imin(ceil_div(rows, 8), 768); }   //
 
 extern "C" int evlm_layernorm_bwd_blocks(int rows) { return ln_bwd_blocks(rows); }
 
-static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const void* addend, const float* gamma, const float* mean,
+static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const void* addend, const void* addend2, const float* gamma, const float* mean,
                                   const float* rstd, int rows, int d, void* dx, float* dgamma, float* dbeta,
                                   float* partials, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -287,7 +294,7 @@ static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const vo
   const int nblk = ln_bwd_blocks(rows);                // row pairs per wave
   dim3 grid(nblk), block(256);
   const size_t lds = 8 * (size_t)d * sizeof(float);
-#define LN_BWD(DCH_) hipLaunchKernelGGL((ln_bwd_kernel<T, DCH_>), grid, block, lds, stream, (const T*)dy, (const T*)x, (const T*)addend, gamma, mean, rstd, rows, d, (T*)dx, dgamma, dbeta, partials)
+#define LN_BWD(DCH_) hipLaunchKernelGGL((ln_bwd_kernel<T, DCH_>), grid, block, lds, stream, (const T*)dy, (const T*)x, (const T*)addend, (const T*)addend2, gamma, mean, rstd, rows, d, (T*)dx, dgamma, dbeta, partials)
   EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_bwd",
     if (d <= 512) LN_BWD(1); else if (d <= 1024) LN_BWD(2); else if (d <= 1536) LN_BWD(3); else LN_BWD(4);)
 #undef LN_BWD
@@ -301,13 +308,13 @@ static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const vo
 extern "C" int evlm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
                                   const float* rstd, int rows, int d, void* dx, float* dgamma, float* dbeta,
                                   float* partials, void* stream) {
-  return layernorm_bwd_impl(dtype, dy, x, nullptr, gamma, mean, rstd, rows, d, dx, dgamma, dbeta, partials, stream);
+  return layernorm_bwd_impl(dtype, dy, x, nullptr, nullptr, gamma, mean, rstd, rows, d, dx, dgamma, dbeta, partials, stream);
 }
 // dx = LayerNorm backward + addend: the gradient that reaches x along the residual branch past this LayerNorm (pre-LN
 // blocks: h = x + f(LN(x))) is summed inside the kernel instead of by a separate element-wise add over [rows, d]
-extern "C" int evlm_layernorm_bwd_add(int dtype, const void* dy, const void* x, const void* addend, const float* gamma,
-                                      const float* mean, const float* rstd, int rows, int d, void* dx, float* dgamma,
-                                      float* dbeta, float* partials, void* stream) {
+extern "C" int evlm_layernorm_bwd_add(int dtype, const void* dy, const void* x, const void* addend, const void* addend2,
+                                      const float* gamma, const float* mean, const float* rstd, int rows, int d, void* dx,
+                                      float* dgamma, float* dbeta, float* partials, void* stream) {
   EVLM_REQUIRE(addend, "evlm_layernorm_bwd_add: null addend");
-  return layernorm_bwd_impl(dtype, dy, x, addend, gamma, mean, rstd, rows, d, dx, dgamma, dbeta, partials, stream);
+  return layernorm_bwd_impl(dtype, dy, x, addend, addend2, gamma, mean, rstd, rows, d, dx, dgamma, dbeta, partials, stream);
 }

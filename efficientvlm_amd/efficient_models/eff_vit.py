@@ -139,6 +139,7 @@ class CLIPMLP(nn.Module):
 
 class CLIPEncoderLayer(nn.Module):
     """eff_vit.py:223-273"""
+    input_tap = None       # (set by forward: alias of the block input for the hidden-state distillation, see there)
 
     def __init__(self, hidden_size, hidden_act, num_attention_heads, attention_dropout, intermediate_size):
         super().__init__()
@@ -151,7 +152,10 @@ class CLIPEncoderLayer(nn.Module):
                 head_layer_z=None, mlp_z=None, kd_teacher=None, kd_word=None, p_out=None):
         # (layer_norm_fork: the residual branch gets an ALIAS of the block input, so that the LayerNorm backward kernel sums
         # the two gradients of the input itself - evlm_layernorm_bwd_add - instead of autograd adding them element-wise)
-        h, residual = ops.layer_norm_fork(hidden_states, self.layer_norm1.weight, self.layer_norm1.bias, self.layer_norm1.eps)
+        # (`tap`: a third alias of the block input, for the hidden-state distillation that reads it - CLIPEncoder reports it
+        # in `encoder_states`, so that the input's two extra gradients reach the LayerNorm backward kernel as addends)
+        h, residual, self.input_tap = ops.layer_norm_fork(hidden_states, self.layer_norm1.weight, self.layer_norm1.bias,
+                                                          self.layer_norm1.eps, tap=True)
         attn_out = self.self_attn(hidden_states=h, attention_mask=attention_mask,
                                   causal_attention_mask=None, output_attentions=output_attentions,
                                   head_z=head_z, head_layer_z=head_layer_z, residual=residual, kd_teacher=kd_teacher,
@@ -211,6 +215,7 @@ class CLIPEncoder(nn.Module):
         self.kd_fused = [] if kd_maps is not None else None
         kd_words = torch.zeros(len(self.layers), dtype=torch.float32, device=inputs_embeds.device) if kd_maps is not None else None
         for idx, encoder_layer in enumerate(self.layers):
+            states_slot = len(encoder_states) if output_hidden_states else None
             if output_hidden_states:
                 encoder_states = encoder_states + (hidden_states,)
             want_map = (bool(output_attentions) and (self.attn_keep is None or idx in self.attn_keep)
@@ -230,9 +235,15 @@ class CLIPEncoder(nn.Module):
                     do_gather = False
                     hidden_states_bs = torch.index_select(hidden_states, 0, idx_to_group_img.view(-1))
                     hidden_states = torch.cat([hidden_states_bs, hidden_states], dim=0)
+                gathered = hidden_states is not (encoder_states[states_slot] if states_slot is not None else hidden_states)
                 layer_outputs = encoder_layer(hidden_states, attention_mask=image_atts_blk, **kw, **kdkw)
             else:
+                gathered = False
                 layer_outputs = encoder_layer(hidden_states, attention_mask=None, **kw, **kdkw)
+            if states_slot is not None and not gathered and encoder_layer.input_tap is not None:
+                # (same values: the alias the layer's first LayerNorm handed out - see CLIPEncoderLayer.forward)
+                encoder_states = encoder_states[:states_slot] + (encoder_layer.input_tap,) + encoder_states[states_slot + 1:]
+            encoder_layer.input_tap = None
             if kd_maps is not None:
                 self.kd_fused.append(encoder_layer.kd_term)
             hidden_states = layer_outputs[0]

@@ -769,20 +769,23 @@ class _LayerNorm(torch.autograd.Function):
 
 
 class _LayerNormFork(torch.autograd.Function):
-    """(LayerNorm(x), x) - the second output is an alias of x for the residual branch that bypasses the norm (pre-LN blocks:
-    h = x + f(LN(x))).  Autograd then sees ONE use of x, and the backward kernel sums both incoming gradients itself
-    (evlm_layernorm_bwd_add) instead of autograd issuing an element-wise add over [rows, d] per block."""
+    """(LayerNorm(x), x [, x]) - the extra outputs are aliases of x: one for the residual branch that bypasses the norm
+    (pre-LN blocks: h = x + f(LN(x))) and, with `tap`, one for a distillation term that reads x itself (the hidden-state KD).
+    Autograd then sees ONE use of x, and the backward kernel sums the incoming gradients itself (evlm_layernorm_bwd_add, up
+    to two addends) instead of autograd issuing an element-wise add over [rows, d] per extra use."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, tap=False):
         y = _LayerNorm.forward(ctx, x, gamma, beta, eps)
-        return y, x.view_as(x)
+        return (y, x.view_as(x), x.view_as(x)) if tap else (y, x.view_as(x))
 
     @staticmethod
-    def backward(ctx, dy, dres):
+    def backward(ctx, dy, dres, dtap=None):
         xc, gamma, mean, rstd = ctx.saved_tensors
+        adds = [g for g in (dres, dtap) if g is not None]
         if dy is None:
-            return dres, None, None, None
+            out = None if not adds else (adds[0] if len(adds) == 1 else adds[0] + adds[1])
+            return out, None, None, None, None
         d = xc.shape[-1]
         rows = xc.numel() // d
         dyc = dy if dy.is_contiguous() else dy.contiguous()
@@ -797,26 +800,28 @@ class _LayerNormFork(torch.autograd.Function):
         if defer:
             LN_DEFER.append((ws, nblk, d, dg, db))
         pdg, pdb = (None, None) if defer else (L.ptr(dg), L.ptr(db))
-        if dres is not None:
-            rc = dres if (dres.is_contiguous() and dres.dtype == xc.dtype) else dres.to(xc.dtype).contiguous()
-            L.check(_lib().evlm_layernorm_bwd_add(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(rc), L.ptr(gamma.detach()), L.ptr(mean),
+        if adds:
+            rcs = [g if (g.is_contiguous() and g.dtype == xc.dtype) else g.to(xc.dtype).contiguous() for g in adds]
+            L.check(_lib().evlm_layernorm_bwd_add(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(rcs[0]),
+                                                  L.ptr(rcs[1]) if len(rcs) > 1 else None, L.ptr(gamma.detach()), L.ptr(mean),
                                                   L.ptr(rstd), rows, d, L.ptr(dx), pdg, pdb, L.ptr(ws), L.stream()),
                     "layernorm_bwd_add")
         else:
             L.check(_lib().evlm_layernorm_bwd(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd),
                                               rows, d, L.ptr(dx), pdg, pdb, L.ptr(ws), L.stream()), "layernorm_bwd")
-        return (dx.view(ctx.xshape), None, None, None) if inplace else (dx.view(ctx.xshape), dg, db, None)
+        return (dx.view(ctx.xshape), None, None, None, None) if inplace else (dx.view(ctx.xshape), dg, db, None, None)
 
 
 def layer_norm(x, gamma, beta, eps):
     return _LayerNorm.apply(x, gamma, beta, eps)
 
 
-def layer_norm_fork(x, gamma, beta, eps):
-    """(LayerNorm(x), alias of x for the residual branch): see _LayerNormFork"""
+def layer_norm_fork(x, gamma, beta, eps, tap=False):
+    """(LayerNorm(x), alias of x for the residual branch [, alias of x for a distillation term]): see _LayerNormFork"""
     if not (torch.is_grad_enabled() and x.requires_grad) or _NO_FORK:
-        return _LayerNorm.apply(x, gamma, beta, eps), x
-    return _LayerNormFork.apply(x, gamma, beta, eps)
+        y = _LayerNorm.apply(x, gamma, beta, eps)
+        return (y, x, x) if tap else (y, x)
+    return _LayerNormFork.apply(x, gamma, beta, eps, tap)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -119,10 +119,11 @@ int evlm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* ga
                        void* stream);
 /* the same with  dx += addend  ([rows, d], dtype): the gradient arriving at x along the residual branch that bypasses this
  * LayerNorm (CLIPEncoderLayer: hidden = residual + f(layer_norm(residual)), eff_vit.py:250-266) is summed in the kernel,
- * replacing the element-wise add autograd would issue for the two uses of x. */
-int evlm_layernorm_bwd_add(int dtype, const void* dy, const void* x, const void* addend, const float* gamma,
-                           const float* mean, const float* rstd, int rows, int d, void* dx, float* dgamma,
-                           float* dbeta, float* partials, void* stream);
+ * replacing the element-wise add autograd would issue for the two uses of x.  addend2 (or NULL): a second such gradient -
+ * of a distillation term that reads x itself (the hidden-state KD "tap", GeneralDistill.py:60-82). */
+int evlm_layernorm_bwd_add(int dtype, const void* dy, const void* x, const void* addend, const void* addend2,
+                           const float* gamma, const float* mean, const float* rstd, int rows, int d, void* dx,
+                           float* dgamma, float* dbeta, float* partials, void* stream);
 /* dgamma == dbeta == NULL (workspace given): the per-block column sums stay in `partials`; reduce the workspaces of many
  * LayerNorms at once with  table: device int64 [n][5] = {partials, blocks (evlm_layernorm_bwd_blocks(rows)), d, dgamma,
  * dbeta}  (accumulated), d_max = largest d in the table. */
