@@ -90,18 +90,39 @@ def kd_terms(S, T, temperature=1.0, with_cross_attn=False, fused=None):
     return out
 
 
+_MIX = {}
+
+
+def _mix_weights(names, rows, device):
+    """[len(rows), len(names)] coefficient matrix of a loss mix (cached per device): row r = weights of output r"""
+    key = (tuple(names), tuple(tuple(sorted(r.items())) for r in rows), str(device))
+    M = _MIX.get(key)
+    if M is None:
+        M = torch.tensor([[r.get(n, 0.0) for n in names] for r in rows], dtype=torch.float32, device=device)
+        _MIX[key] = M
+    return M
+
+
 def gd_loss_mix(loss, kd):
-    """GeneralDistill.py:369-376 (general step) / :252-260 (region step: + bbox + giou in the task term)"""
-    loss_small = loss["loss_itc"] + loss["loss_itm"] + loss["loss_mlm"]
-    if "loss_bbox" in loss:
-        loss_small = loss_small + loss["loss_bbox"] + loss["loss_giou"]
-    loss_text_kd = kd["text_attn"] + kd["text_hidden"]
-    loss_img_kd = kd["image_attn"] + 0.1 * kd["image_hidden"]
-    loss_cross_kd = (kd["itm_neg_attn"] + kd["itm_neg_hidden"] + kd["itm_pos_attn"] + kd["itm_pos_hidden"]
-                     + kd["mlm_attn"] + kd["mlm_hidden"])
-    loss_kd = kd["itm_logits"] + kd["mlm_logits"] + loss_text_kd + loss_img_kd + loss_cross_kd
-    return loss_small * 0.6 + loss_kd * 0.4, dict(loss_small=loss_small, loss_text_kd=loss_text_kd,
-                                                  loss_img_kd=loss_img_kd, loss_cross_kd=loss_cross_kd, loss_kd=loss_kd)
+    """GeneralDistill.py:369-376 (general step) / :252-260 (region step: + bbox + giou in the task term).  The ~17 device
+    scalars are stacked once and every output is one weighted sum of them (5 small launches instead of ~20 scalar adds /
+    multiplies on the step's critical path; the same linear combination, summed in one pass)."""
+    task = ["loss_itc", "loss_itm", "loss_mlm"] + (["loss_bbox", "loss_giou"] if "loss_bbox" in loss else [])
+    text, img = {"text_attn": 1.0, "text_hidden": 1.0}, {"image_attn": 1.0, "image_hidden": 0.1}
+    cross = {k: 1.0 for k in ("itm_neg_attn", "itm_neg_hidden", "itm_pos_attn", "itm_pos_hidden", "mlm_attn", "mlm_hidden")}
+    logit = {"itm_logits": 1.0, "mlm_logits": 1.0}
+    names = task + list(logit) + list(text) + list(img) + list(cross)
+    vals = [loss[n] if n in loss else kd[n] for n in names]
+    dev = next(t.device for t in vals if torch.is_tensor(t))
+    v = torch.stack([t.float().reshape(()) if torch.is_tensor(t) else torch.full((), float(t), device=dev) for t in vals])
+    small = {n: 1.0 for n in task}
+    kd_all = {**logit, **text, **img, **cross}
+    total_w = {**{n: 0.6 for n in task}, **{n: 0.4 * w for n, w in kd_all.items()}}
+    M = _mix_weights(names, [total_w, small, text, img, cross, kd_all], v.device)
+    total = (v * M[0]).sum()
+    with torch.no_grad():
+        rep = (M[1:] * v.detach()).sum(1)
+    return total, dict(loss_small=rep[0], loss_text_kd=rep[1], loss_img_kd=rep[2], loss_cross_kd=rep[3], loss_kd=rep[4])
 
 
 def itr_loss_mix(loss, kd, lagrangian):
