@@ -26,6 +26,7 @@ class XVLM(XVLMBase):
     # optional callback(name) at fixed points of the batched forward - "vision_done" (image encoder finished), "text_done"
     # (text layers finished, ITC / fusion passes next): a trainer forks side-stream work (the pipelined teacher) there
     phase_hook = None
+    text_stream = None         # optional torch.cuda.Stream: see _forward_batched
     # extension (False = the reference's behaviour): a frozen TEACHER's task losses are never read by the distillation
     # loss (GeneralDistill.py:300-376 uses its hidden states, attention maps and logits only); with this set the batched
     # forward skips ITC / ITM / MLM cross-entropies - and with them the ITC feature all-gather, the teacher forward's only
@@ -92,6 +93,21 @@ class XVLM(XVLMBase):
         fusion rows that cross-attends to the full-attention embeddings through the same batch index."""
         B = text_ids.shape[0]
         dev = image.device
+        core = self._text_core()
+
+        def text_pass():      # text layers 0..F-1 on [text_ids ; text_ids_masked]
+            return core(torch.cat([text_ids, text_ids_masked], 0), attention_mask=torch.cat([text_atts, text_atts], 0),
+                        return_dict=True, mode="text", output_attentions=True, output_hidden_states=True)
+        # extension: the text pass is independent of the image encoder until the ITC features - with `text_stream` set
+        # (single-GPU trainers) it is issued on that stream BESIDE the image encoder: its ~25 small launches (and, since
+        # autograd runs a node on its forward's stream, their backward) share the chip with the ViT's large products
+        side = self.text_stream if (self.text_stream is not None and image.is_cuda) else None
+        t = None
+        if side is not None:
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                t = text_pass()
         if region is None:
             image_embeds, image_atts, image_hidden_states, image_attentions = self.get_vision_embeds(
                 image, output_attentions=True, output_hidden_states=True)
@@ -110,10 +126,13 @@ class XVLM(XVLMBase):
             image_embeds.register_hook(lambda grad: (cb(), grad)[1])
         if self.phase_hook is not None:
             self.phase_hook("vision_done")
-        core = self._text_core()
-        # text layers 0..F-1 on [text_ids ; text_ids_masked]
-        t = core(torch.cat([text_ids, text_ids_masked], 0), attention_mask=torch.cat([text_atts, text_atts], 0),
-                 return_dict=True, mode="text", output_attentions=True, output_hidden_states=True)
+        if side is not None:
+            cur.wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():
+                for x in list(t.hidden_states) + [a for a in t.attentions if a is not None] + [t.last_hidden_state]:
+                    x.record_stream(cur)          # allocated on the side stream, consumed on this one
+        else:
+            t = text_pass()
         # torch.split, not slices: its backward is ONE concatenation per tensor (a slice's is zero-fill + copy + add)
         halves = lambda tup: tuple(zip(*[torch.split(x, [B, B], 0) if x is not None else (None, None) for x in tup]))
         text_hidden_states, mlm_text_hidden = halves(t.hidden_states)

@@ -282,6 +282,11 @@ class GDTrainer(_StagedExchange):
                                                                    os.environ.get("EVLM_DP_CUTS", "all"))
         if hasattr(student, "on_vision_grad"):
             student.on_vision_grad = self._on_vision_grad
+        # single GPU: the student's text pass beside its image encoder (multi-GPU keeps them in sequence: the "vision"
+        # gradient stage relies on every text-side gradient being issued before backward enters the image encoder)
+        if (hasattr(student, "text_stream") and not self.reducer.active and os.environ.get("EVLM_TEXT_STREAM")
+                and next(student.parameters()).is_cuda):
+            student.text_stream = torch.cuda.Stream()
         self.use_graph = use_graph
         self.wgrad_inplace = True
         if not os.environ.get("EVLM_TEACHER_ALL_MAPS"):
