@@ -284,7 +284,7 @@ class GDTrainer(_StagedExchange):
             student.on_vision_grad = self._on_vision_grad
         # single GPU: the student's text pass beside its image encoder (multi-GPU keeps them in sequence: the "vision"
         # gradient stage relies on every text-side gradient being issued before backward enters the image encoder)
-        if (hasattr(student, "text_stream") and not self.reducer.active and os.environ.get("EVLM_TEXT_STREAM")
+        if (hasattr(student, "text_stream") and not self.reducer.active and not os.environ.get("EVLM_NO_TEXT_STREAM")
                 and next(student.parameters()).is_cuda):
             student.text_stream = torch.cuda.Stream()
         self.use_graph = use_graph
