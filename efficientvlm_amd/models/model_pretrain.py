@@ -1,5 +1,7 @@
 """GD / pre-training model — drop-in for models/model_pretrain.py:XVLM (reference :5-82), the object
 GeneralDistill.py builds for both student and teacher."""
+import os
+
 import torch
 
 from .xvlm import XVLMBase
@@ -27,6 +29,7 @@ class XVLM(XVLMBase):
     # (text layers finished, ITC / fusion passes next): a trainer forks side-stream work (the pipelined teacher) there
     phase_hook = None
     text_stream = None         # optional torch.cuda.Stream: see _forward_batched
+    kd_fork = None             # set by _forward_batched (with text_stream): event behind the fusion pass
     # extension (False = the reference's behaviour): a frozen TEACHER's task losses are never read by the distillation
     # loss (GeneralDistill.py:300-376 uses its hidden states, attention maps and logits only); with this set the batched
     # forward skips ITC / ITM / MLM cross-entropies - and with them the ITC feature all-gather, the teacher forward's only
@@ -165,6 +168,12 @@ class XVLM(XVLMBase):
                  encoder_attention_mask=torch.index_select(enc_atts, 0, img_index),
                  encoder_batch_index=img_index.to(torch.int32),      # (cast once here, not in every cross-attention)
                  return_dict=True, mode="fusion", output_attentions=True, output_hidden_states=True)
+        # (the hidden-state / attention-map distillation terms depend on nothing past this point: a trainer that runs them
+        # on the side stream - distill.kd_terms - forks from HERE, beside the task heads below)
+        self.kd_fork = None
+        if side is not None and not os.environ.get("EVLM_NO_KD_STREAM"):
+            self.kd_fork = torch.cuda.Event()
+            self.kd_fork.record(torch.cuda.current_stream())
         thirds = lambda tup: tuple(zip(*[torch.split(x, sizes, 0) if x is not None else (None,) * len(sizes)
                                          for x in tup]))                                       # pos | neg | mlm [| bbox]
         f_hid, f_att, f_cross = thirds(f.hidden_states), thirds(f.attentions), thirds(f.cross_attentions)
