@@ -45,14 +45,7 @@ class WeightCache:
         self.epoch += 1
 
     # ---- transposed bf16 copies of slab-backed weights (W^T for dX = dY W) --------------------------------------------
-    _t_stale = False           # set by an optimiser step that left the refresh to the next step's start (trainer)
-
     def get_t(self, params):
-        if self._t_stale:      # (a backward outside the trainer's step: never hand out a copy of the old weights)
-            self.refresh_transposed()
-        return self._get_t(params)
-
-    def _get_t(self, params):
         """[K, sum N_i] bf16 = transpose of the packed bf16 weight of `params`, or None when they are not adjacent members
         of an optimiser slab.  Created (and filled) on first use, afterwards kept current by refresh_transposed(), which
         the optimiser calls after every parameter update."""
@@ -84,7 +77,6 @@ class WeightCache:
 
     def refresh_transposed(self):
         """re-derive every W^T copy from the bf16 mirror: ONE grouped launch (capturable: the table is a device tensor)"""
-        self._t_stale = False
         if not self._t_units:
             return
         if any(u[2]() is None for u in self._t_units.values()):           # models that are gone

@@ -178,10 +178,8 @@ class FlatAdamW:
             host = host.pin_memory()
         self.hyper.copy_(host, non_blocking=True)
 
-    def step(self, defer_transposed=False):
-        """clip by global norm + AdamW; pure device work (capturable).  defer_transposed: the W^T copies the input-gradient
-        products read are NOT re-derived here - the caller does it (ops.CACHE.refresh_transposed) before the next backward,
-        off the critical path; ops.CACHE refreshes by itself if anything asks for a copy first.  Gradients must live in the flat slabs.
+    def step(self):
+        """clip by global norm + AdamW; pure device work (capturable).  Gradients must live in the flat slabs.
         A reference-style loop (optimizer.step() with no scheduler call, optim.py:67 + GeneralDistill.py:386) never calls
         set_schedule(): the step then advances the count itself with the last lr multiplier, so Adam's bias corrections
         are never silently left at 1.  Under hipGraph capture the scalars cannot be staged from here: that is an error."""
@@ -210,10 +208,7 @@ class FlatAdamW:
                                         g["lr"], b1, b2, self.eps, g["weight_decay"], 1.0, 1.0, L.ptr(self.gnorm_sq),
                                         float(self.max_grad_norm or 0.0), L.ptr(g["pb"]), L.ptr(self.hyper), L.stream()), "adamw")
         ops.CACHE.invalidate()
-        if defer_transposed:
-            ops.CACHE._t_stale = True
-        else:
-            ops.CACHE.refresh_transposed()  # W^T copies of the bf16 mirror (one grouped launch; no-op in fp32 runs)
+        ops.CACHE.refresh_transposed()      # W^T copies of the bf16 mirror (one grouped launch; no-op in fp32 runs)
 
     def grad_norm(self):
         return self.gnorm_sq.sqrt()

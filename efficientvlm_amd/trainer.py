@@ -252,7 +252,6 @@ def teacher_map_filter(student, teacher, with_cross):
 
 
 class GDTrainer(_StagedExchange):
-    _prelude_stream = None
     def __init__(self, student, teacher, lr=1e-4, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, temperature=1.0,
                  dtype=torch.bfloat16, use_graph=True, grad_compress=None, pipeline_teacher=False):
         """pipeline_teacher: the frozen teacher's forward for batch i+1 runs (second stream) WHILE the student trains on
@@ -322,21 +321,7 @@ class GDTrainer(_StagedExchange):
         # (first-touch assignment of the Linear weights' gradients: their slab ranges are not zero-filled, ops.WGRAD_ASSIGN)
         self._assign = (self.opt.assign_state(self.student)
                         if (self.wgrad_inplace and self.defer_wgrad and not os.environ.get("EVLM_NO_WGRAD_ASSIGN")) else None)
-        ts = getattr(self.student, "text_stream", None)
-        if ts is not None and not os.environ.get("EVLM_NO_PRELUDE_STREAM"):
-            # single GPU: the step's prelude - zero-fill of the gradient ranges that are accumulated into, W^T copies of
-            # the weights the previous step updated (needed by the backward only) - runs on the side stream that carries
-            # the student's text pass next, under the image encoder's forward; joined before backward (below)
-            cur = torch.cuda.current_stream()
-            ts.wait_stream(cur)
-            with torch.cuda.stream(ts):
-                self.opt.zero_grad(skip_assigned=self._assign is not None)
-                if ops.CACHE._t_stale:
-                    ops.CACHE.refresh_transposed()
-        else:
-            ts = None
-            self.opt.zero_grad(skip_assigned=self._assign is not None)
-        self._prelude_stream = ts
+        self.opt.zero_grad(skip_assigned=self._assign is not None)
         ops.begin_step(batch["image"].device)
         try:
             return self._forward_backward_body(batch, teacher_out)
@@ -351,8 +336,6 @@ class GDTrainer(_StagedExchange):
                 self._last_ST = (S, T)
             # the individual KD terms of this step (device scalars; under capture: static tensors of that graph)
             self.last_kd = {k: v.detach() for k, v in kd.items() if torch.is_tensor(v)}
-            if self._prelude_stream is not None:     # (the batched forward has joined it already; any other forward has not)
-                torch.cuda.current_stream().wait_stream(self._prelude_stream)
             ops.WGRAD_INPLACE = self.wgrad_inplace      # kernels sum parameter gradients straight into the flat slabs
             ops.WGRAD_DEFER = [] if (self.wgrad_inplace and self.defer_wgrad) else None   # ... dW products grouped per K
             ops.WGRAD_ASSIGN = self._assign
@@ -388,8 +371,7 @@ class GDTrainer(_StagedExchange):
         out = self._forward_backward(batch, teacher_out)
         if self.reducer.active:
             self._reduce_rest()
-        # (with the prelude stream the W^T copies are re-derived at the start of the NEXT step, beside its forward)
-        self.opt.step(defer_transposed=self._prelude_stream is not None)
+        self.opt.step()
         return out
 
     # ---- teacher pipelining ------------------------------------------------------------------------
