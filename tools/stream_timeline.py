@@ -40,3 +40,7 @@ for q, lst in sorted(byq.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1]
     small = [g for g in gaps if 0 < g < 20000]
     print(f"queue {q}: {len(lst)} dispatches, busy {b/1e6:.2f} ms ({b/span*100:.1f} %), "
           f"sum of gaps < 20 us: {sum(small)/1e6:.2f} ms ({len(small)} gaps, median {sorted(small)[len(small)//2]/1e3 if small else 0:.2f} us)")
+    hist = collections.Counter(min(int(g // 1000), 20) for g in gaps if g > 0)
+    print("   gap histogram (us: count): " + " ".join(f"{k}:{hist[k]}" for k in sorted(hist)))
+    neg = [g for g in gaps if g <= 0]
+    print(f"   back-to-back overlapped (gap <= 0): {len(neg)}")
