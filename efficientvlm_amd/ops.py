@@ -334,54 +334,10 @@ def finish_assign():
     st["pending"].clear()
 
 
-# Weight gradients BESIDE the input-gradient chain (single GPU, set by a trainer together with WGRAD_DEFER): {"stream": side
-# stream, "tiles": launch threshold, "queued": tiles waiting, "producers": streams that queued them, "keep": launched
-# records (dY / X stay alive until wgrad_join), "ptrs": gradient addresses the side stream writes this step}.  The queued
-# products leave for the side stream whenever `tiles` output tiles have gathered; their workgroups fill the CUs the chain's
-# part-filled launches leave idle (the chain's products depend on each other, the weight gradients on nothing downstream).
-WGRAD_SIDE = None
-
-
-def _side_guard(*tensors):
-    """a contribution launched on the CURRENT stream to gradients the side stream may still be writing waits for it"""
-    st = WGRAD_SIDE
-    if st is not None and st["ptrs"] and any(t is not None and t.data_ptr() in st["ptrs"] for t in tensors):
-        torch.cuda.current_stream().wait_stream(st["stream"])
-        st["ptrs"].clear()
-
-
-def wgrad_join():
-    """end of backward: the side stream's weight gradients are complete before anything reads the slabs"""
-    st = WGRAD_SIDE
-    if st is None:
-        return
-    torch.cuda.current_stream().wait_stream(st["stream"])
-    st["keep"].clear(); st["ptrs"].clear(); st["producers"].clear()
-    st["queued"] = 0
-
-
-def flush_wgrad(ln=True):
-    """launch the queued weight-gradient products and (ln) LayerNorm column-sum reductions (no-op when nothing is queued)"""
-    if ln:
-        _flush_ln()
-    st = WGRAD_SIDE
-    if st is None or not WGRAD_DEFER:
-        return _flush_wgrad_here()
-    for ps in st["producers"]:                     # dY / X of the queued products come from these streams
-        st["stream"].wait_stream(ps)
-    st["producers"].clear()
-    st["queued"] = 0
-    for rec in WGRAD_DEFER:
-        st["ptrs"].add(rec[4].data_ptr())
-        if rec[9] is not None:
-            st["ptrs"].add(rec[9].data_ptr())
-    st["keep"].append(WGRAD_DEFER)
-    with torch.cuda.stream(st["stream"]):
-        _flush_wgrad_here()
-
-
-def _flush_wgrad_here():
+def flush_wgrad():
+    """launch the queued weight-gradient products and LayerNorm column-sum reductions (no-op when nothing is queued)"""
     global WGRAD_DEFER
+    _flush_ln()
     q = WGRAD_DEFER
     if not q:
         return
@@ -490,14 +446,8 @@ def _wgrad(dtype, d2, ldd, x2, ldp, M, K, params, rows, biases=None):
             for kk in keys:
                 WGRAD_ASSIGN["pending"][kk] = rec
             WGRAD_DEFER.append(rec)
-            if WGRAD_SIDE is not None:
-                WGRAD_SIDE["producers"].add(torch.cuda.current_stream())
-                WGRAD_SIDE["queued"] += ((r + 255) // 256) * ((K + 255) // 256)
-                if WGRAD_SIDE["queued"] >= WGRAD_SIDE["tiles"]:
-                    flush_wgrad(ln=False)
         else:
             _assign_prepare(params[i:j], False)
-            _side_guard(params[i].grad, ps)
             _gemm(dtype, d2, x2, params[i].grad, r, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1, accumulate=1, p_off=r0, psum=ps)
         for k in range(i, j):
             gw.append(None)

@@ -287,12 +287,6 @@ class GDTrainer(_StagedExchange):
         if (hasattr(student, "text_stream") and not self.reducer.active and not os.environ.get("EVLM_NO_TEXT_STREAM")
                 and next(student.parameters()).is_cuda):
             student.text_stream = torch.cuda.Stream()
-        # single GPU: the weight-gradient products leave for a side stream while backward goes on (ops.WGRAD_SIDE); multi-GPU
-        # keeps them on the backward's stream - a gradient stage must be complete in the slabs when its exchange starts
-        self._wgrad_side = None
-        if (not self.reducer.active and next(student.parameters()).is_cuda and not os.environ.get("EVLM_NO_WGRAD_SIDE")):
-            self._wgrad_side = dict(stream=torch.cuda.Stream(), tiles=int(os.environ.get("EVLM_WGRAD_SIDE_TILES", "200")),
-                                    queued=0, producers=set(), keep=[], ptrs=set())
         self.use_graph = use_graph
         self.wgrad_inplace = True
         if not os.environ.get("EVLM_TEACHER_ALL_MAPS"):
@@ -345,19 +339,14 @@ class GDTrainer(_StagedExchange):
             ops.WGRAD_INPLACE = self.wgrad_inplace      # kernels sum parameter gradients straight into the flat slabs
             ops.WGRAD_DEFER = [] if (self.wgrad_inplace and self.defer_wgrad) else None   # ... dW products grouped per K
             ops.WGRAD_ASSIGN = self._assign
-            ops.WGRAD_SIDE = self._wgrad_side if ops.WGRAD_DEFER is not None else None
             try:
                 total.backward()
                 ops.flush_wgrad()
-                ops.wgrad_join()
                 ops.finish_assign()
             finally:
                 ops.WGRAD_INPLACE = False
                 ops.WGRAD_DEFER = None
                 ops.WGRAD_ASSIGN = None
-                if ops.WGRAD_SIDE is not None:   # (no-op after a clean backward: joined above)
-                    ops.wgrad_join()
-                    ops.WGRAD_SIDE = None
                 if self._assign is not None:     # (non-empty only when backward raised: the next step starts clean)
                     self._assign["done"].clear()
                     self._assign["pending"].clear()
