@@ -38,5 +38,11 @@ class Mode(TorchDispatchMode):
 with Mode():
     tr.step(batch)
 torch.cuda.synchronize()
-for (name, where, shp), n in sorted(agg.items(), key=lambda kv: -kv[1])[:120]:
+# metadata-only ops launch nothing: listed only with --all
+NOLAUNCH = ("view", "detach", "slice", "select", "empty", "as_strided", "split", "record_stream", "t.", "transpose", "unsqueeze",
+            "squeeze", "expand", "permute", "alias", "_unsafe_view", "reshape", "unbind", "unflatten", "is_", "size", "stride",
+            "_local_scalar", "chunk", "narrow", "new_empty", "lift_fresh", "resize_", "set_", "_reshape_alias", "unfold")
+rows = [(k, n) for k, n in agg.items() if "--all" in sys.argv or not k[0].startswith(NOLAUNCH)]
+print(f"# {sum(n for _, n in rows)} launching ATen calls in one eager step")
+for (name, where, shp), n in sorted(rows, key=lambda kv: -kv[1])[:200]:
     print(f"{n:5d}  {name:22s} {where:60s} {shp}")

@@ -13,6 +13,7 @@ from efficientvlm_amd.workload import GEOMS, make_batch
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--only", default="", help="J, S or T: that run alone (for a kernel trace)")
 args = ap.parse_args()
 torch.cuda.set_device(0)
 geom = GEOMS["full"]; dev = torch.device("cuda", 0)
@@ -44,6 +45,9 @@ def no_student(tr):
     tr._student_eager = lambda pipe, k: z
 
 
+if args.only:
+    run(*{"J": ("J: joint graph",), "S": ("S: student step alone", no_teacher), "T": ("T: teacher forward alone", no_student)}[args.only])
+    sys.exit(0)
 for rep in range(args.reps):
     j = run("J: joint graph (student step || teacher forward)")
     s = run("S: student step alone (teacher branch empty)", no_teacher)
