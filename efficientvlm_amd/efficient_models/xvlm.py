@@ -510,7 +510,7 @@ class _MatmulNT(torch.autograd.Function):
         m, k = ac.shape
         n = bc.shape[0]
         ldc = (n + 7) // 8 * 8
-        cbuf = torch.zeros((m, ldc), dtype=ac.dtype, device=a.device)
+        cbuf = torch.empty((m, ldc), dtype=ac.dtype, device=a.device) if ldc == n else ops.zeros_small((m, ldc), ac.dtype, a.device)
         ops._gemm(dt(ac), ac, bc, cbuf, m, n, k, k, k, ldc)
         ctx.save_for_backward(ac, bc)
         return cbuf[:, :n]
@@ -522,8 +522,11 @@ class _MatmulNT(torch.autograd.Function):
         m, k = ac.shape
         n = bc.shape[0]
         ldd = (n + 7) // 8 * 8
-        d = torch.zeros((m, ldd), dtype=ac.dtype, device=ac.device)
-        d[:, :n].copy_(dc)
+        if ldd == n and dc.is_contiguous() and dc.dtype == ac.dtype:
+            d = dc
+        else:
+            d = ops.zeros_small((m, ldd), ac.dtype, ac.device)
+            d[:, :n].copy_(dc)
         da = torch.empty_like(ac)
         db = torch.empty_like(bc)
         ops._gemm(dt(ac), d, bc, da, m, k, n, ldd, k, k, p_trans=0, q_trans=1)       # dA = dC B

@@ -236,7 +236,7 @@ def _gemm(dtype, P, Q, Cm, I, J, K, ldp, ldq, ldc, p_trans=0, q_trans=0, bias=No
 def _colsum(x2d, I, J, ld, out=None, x_off=0):
     """out[j] += sum_i x[i, x_off + j]; a fresh zero vector when `out` is None"""
     if out is None:
-        out = torch.zeros(J, dtype=torch.float32, device=x2d.device)
+        out = zeros_small(J, torch.float32, x2d.device)
     xp = L.ptr(x2d) if not x_off else C.c_void_p(x2d.data_ptr() + x_off * x2d.element_size())
     L.check(_lib().evlm_colsum(L.dt(x2d), xp, I, J, ld, L.ptr(out), L.stream()), "colsum")
     return out
@@ -408,7 +408,7 @@ def _wgrad(dtype, d2, ldd, x2, ldp, M, K, params, rows, biases=None):
         _assign_prepare(params, False)            # (autograd will ADD these into .grad: eligible ranges zero-filled first)
         N = sum(rows)
         dW = torch.empty((N, K), dtype=torch.float32, device=x2.device)
-        db = torch.zeros(N, dtype=torch.float32, device=x2.device) if (has_b and fast) else None
+        db = zeros_small(N, torch.float32, x2.device) if (has_b and fast) else None
         _gemm(dtype, d2, x2, dW, N, K, M, ldd, ldp, K, p_trans=1, q_trans=1, c_f32=1, psum=db)
         for i, r in enumerate(rows):
             gw.append(dW[r0:r0 + r])
@@ -435,7 +435,7 @@ def _wgrad(dtype, d2, ldd, x2, ldp, M, K, params, rows, biases=None):
         if b is not None and _inplace(b):
             ps, res = b.grad, None
         elif b is not None:
-            ps = res = torch.zeros(r, dtype=torch.float32, device=x2.device)
+            ps = res = zeros_small(r, torch.float32, x2.device)
         else:
             ps = res = None
         if (WGRAD_DEFER is not None and res is None and M >= WGRAD_DEFER_MIN_K and r % 8 == 0 and K % 8 == 0
@@ -478,16 +478,23 @@ def _pad8(n):
 # Loss kernels accumulate into f32 device words that must start at zero.  A trainer calls begin_step() once per step: ONE
 # fill of a small block, the ~30 loss scalars of a step are then views of it (instead of ~30 one-element fill launches).
 _ZERO_BLOCK = [None, 0]
+_ZERO_ARENA = [None, 0]        # bytes: the small zero-initialised work buffers of a step (zeros_small)
+ZERO_ARENA_BYTES = 2 << 20
+ZERO_SMALL_MAX = 256 << 10
 
 
 def begin_step(device):
-    """fresh zeroed block of loss accumulators for this step (capturable: a plain allocation + fill)"""
-    _ZERO_BLOCK[0] = torch.zeros(256, dtype=torch.float32, device=device)
+    """fresh zeroed block of loss accumulators for this step (capturable: a plain allocation + fill) and the arena the
+    step's small zero-initialised buffers are carved from - ONE fill launch instead of one per buffer"""
+    arena = torch.zeros(1024 + ZERO_ARENA_BYTES, dtype=torch.uint8, device=device)
+    _ZERO_BLOCK[0] = arena[:1024].view(torch.float32)
     _ZERO_BLOCK[1] = 0
+    _ZERO_ARENA[0], _ZERO_ARENA[1] = arena, 1024
 
 
 def end_step():
     _ZERO_BLOCK[0] = None
+    _ZERO_ARENA[0] = None
 
 
 def zero_scalar(device):
@@ -496,6 +503,22 @@ def zero_scalar(device):
         return torch.zeros((), dtype=torch.float32, device=device)
     _ZERO_BLOCK[1] = used + 1
     return blk[used]
+
+
+def zeros_small(shape, dtype, device):
+    """torch.zeros(shape) for a buffer a kernel is about to write into / accumulate into: inside a trainer's step small ones
+    are views of the step's pre-zeroed arena (no launch); anything else is a plain torch.zeros"""
+    arena, used = _ZERO_ARENA
+    shape = (shape,) if isinstance(shape, int) else tuple(shape)
+    n = 1
+    for k in shape:
+        n *= k
+    nb = n * torch.empty((), dtype=dtype).element_size()
+    if (arena is None or nb == 0 or nb > ZERO_SMALL_MAX or arena.device != torch.device(device)
+            or used + nb > arena.numel()):
+        return torch.zeros(shape, dtype=dtype, device=device)
+    _ZERO_ARENA[1] = (used + nb + 255) // 256 * 256
+    return arena[used:used + nb].view(dtype).view(shape)
 
 
 _SCRATCH = {}
@@ -528,8 +551,7 @@ class _Linear(torch.autograd.Function):
         N = W.shape[0]
         ydt = torch.float32 if out_f32 else x2.dtype
         ldc = _pad8(N)
-        ybuf = torch.empty((M, ldc), dtype=ydt, device=x.device) if ldc == N else \
-            torch.zeros((M, ldc), dtype=ydt, device=x.device)
+        ybuf = torch.empty((M, ldc), dtype=ydt, device=x.device) if ldc == N else zeros_small((M, ldc), ydt, x.device)
         need_grad = any(ctx.needs_input_grad)
         preact = None
         if act != L.ACT_NONE and need_grad:
@@ -565,7 +587,7 @@ def _linear_backward(ctx, dy, dx_add):
         if d2.dtype != x2.dtype:          # f32-output heads only: bring the gradient to the compute dtype
             d2 = cast(d2.contiguous(), x2.dtype)
         if d2.stride(1) != 1 or d2.stride(0) % 8 != 0 or d2.stride(0) < _pad8(N):
-            buf = torch.zeros((M, _pad8(N)), dtype=x2.dtype, device=x2.device)
+            buf = zeros_small((M, _pad8(N)), x2.dtype, x2.device)
             buf[:, :N].copy_(d2)
             d2 = buf
         ldd = d2.stride(0)
@@ -1459,7 +1481,7 @@ class _CE(torch.autograd.Function):
         lab = labels.reshape(-1).to(torch.int64).contiguous()
         out = zero_scalar(logits.device)
         lse = torch.empty(2 * R, dtype=torch.float32, device=logits.device)
-        valid = torch.zeros(1, dtype=torch.int32, device=logits.device)
+        valid = torch.empty(1, dtype=torch.int32, device=logits.device)      # (written by the finish kernel)
         L.check(_lib().evlm_ce_fwd(L.dt(x2), L.ptr(x2), R, Cn, ld, L.ptr(lab), ignore_index, 1.0, L.ptr(lse), L.ptr(valid),
                                    L.ptr(out), L.stream()), "ce_fwd")
         ctx.save_for_backward(x2, lab, lse, valid)
@@ -1472,8 +1494,7 @@ class _CE(torch.autograd.Function):
         R, Cn, ld, ignore_index, shape = ctx.meta
         gc = g.to(torch.float32).contiguous()
         ldd = _pad8(Cn)
-        dl = torch.empty((R, ldd), dtype=x2.dtype, device=x2.device) if ldd == Cn else \
-            torch.zeros((R, ldd), dtype=x2.dtype, device=x2.device)
+        dl = torch.empty((R, ldd), dtype=x2.dtype, device=x2.device)      # (padding columns: zeroed by the kernel)
         L.check(_lib().evlm_ce_bwd(L.dt(x2), L.ptr(x2), R, Cn, ld, L.ptr(lab), ignore_index, 1.0, L.ptr(lse), L.ptr(valid),
                                    L.ptr(gc), L.ptr(dl), ldd, L.stream()), "ce_bwd")
         d = dl[:, :Cn] if ldd != Cn else dl
@@ -1498,7 +1519,7 @@ class _CEWeighted(torch.autograd.Function):
         assert lab.numel() == R and rw.numel() == R
         out = zero_scalar(logits.device)
         lse = torch.empty(2 * R, dtype=torch.float32, device=logits.device)
-        valid = torch.zeros(1, dtype=torch.int32, device=logits.device)
+        valid = torch.empty(1, dtype=torch.int32, device=logits.device)      # (written by the finish kernel)
         L.check(_lib().evlm_ce_weighted_fwd(L.dt(x2), L.ptr(x2), R, Cn, ld, L.ptr(lab), ignore_index, 1.0, L.ptr(rw),
                                             L.ptr(lse), L.ptr(valid), L.ptr(out), L.stream()), "ce_weighted_fwd")
         ctx.save_for_backward(x2, lab, lse, rw)
@@ -1511,8 +1532,7 @@ class _CEWeighted(torch.autograd.Function):
         R, Cn, ld, ignore_index, shape = ctx.meta
         gc = g.to(torch.float32).contiguous()
         ldd = _pad8(Cn)
-        dl = torch.empty((R, ldd), dtype=x2.dtype, device=x2.device) if ldd == Cn else \
-            torch.zeros((R, ldd), dtype=x2.dtype, device=x2.device)
+        dl = torch.empty((R, ldd), dtype=x2.dtype, device=x2.device)      # (padding columns: zeroed by the kernel)
         L.check(_lib().evlm_ce_weighted_bwd(L.dt(x2), L.ptr(x2), R, Cn, ld, L.ptr(lab), ignore_index, 1.0, L.ptr(rw),
                                             L.ptr(lse), L.ptr(gc), L.ptr(dl), ldd, L.stream()), "ce_weighted_bwd")
         d = dl[:, :Cn] if ldd != Cn else dl
@@ -1550,8 +1570,7 @@ class _KL(torch.autograd.Function):
         R, Cn, lds, ldt, inv_t, shape = ctx.meta
         gc = g.to(torch.float32).contiguous()
         ldd = _pad8(Cn)
-        ds = torch.empty((R, ldd), dtype=s2.dtype, device=s2.device) if ldd == Cn else \
-            torch.zeros((R, ldd), dtype=s2.dtype, device=s2.device)
+        ds = torch.empty((R, ldd), dtype=s2.dtype, device=s2.device)      # (padding columns: zeroed by the kernel)
         L.check(_lib().evlm_kl_bwd(L.dt(s2), L.ptr(s2), lds, L.dt(t2), L.ptr(t2), ldt, R, Cn, inv_t, 1.0, L.ptr(ls), L.ptr(lt),
                                    L.ptr(gc), L.ptr(ds), ldd, L.stream()), "kl_bwd")
         d = ds[:, :Cn] if ldd != Cn else ds
@@ -1619,7 +1638,7 @@ class _BertEmbed(torch.autograd.Function):
         word, typ = ctx.params
         wi, ti = _inplace(word), _inplace(typ)
         dword = word.grad if wi else torch.zeros(wshape, dtype=torch.float32, device=de.device)   # 94 MB at full size
-        dpos = torch.zeros(pshape, dtype=torch.float32, device=de.device)
+        dpos = zeros_small(pshape, torch.float32, de.device)
         dtyp = typ.grad if ti else torch.zeros(tshape, dtype=torch.float32, device=de.device)
         L.check(_lib().evlm_bert_embed_bwd(L.dt(dec), L.ptr(idc), B, Ln, d, L.ptr(dec), pad_id, L.ptr(dword), L.ptr(dpos),
                                            L.ptr(dtyp), L.stream()), "bert_embed_bwd")

@@ -288,7 +288,8 @@ int evlm_mse_grouped(int dtype, int backward, const int64_t* table, int n_units,
 /* hard-label cross entropy, mean over rows with label != ignore_index (F.cross_entropy: MLM loss
  * eff_bert.py:1697-1699, ITM xvlm.py:484, ITC :399-400).  logits [R,C] (ld), labels int64.
  * lse [2R] f32 workspace (lse, then per-row losses) saved for backward; *loss += weight * mean;
- * valid_count: device int32 word (written). */
+ * valid_count: device int32 word (written).  The backward kernels write every column 0 .. ldd-1 of a gradient row (the
+ * padding columns C .. ldd-1 as zeros): dlogits needs no initialisation. */
 int evlm_ce_fwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
                 float weight, float* lse, int32_t* valid_count, float* loss, void* stream);
 int evlm_ce_bwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
@@ -304,7 +305,8 @@ int evlm_ce_weighted_bwd(int dtype, const void* logits, int R, int C, int ld, co
                          void* dlogits, int ldd, void* stream);
 
 /* soft_cross_entropy (GeneralDistill.py:84-89): KLDiv(log_softmax(s*inv_t), softmax(t*inv_t), batchmean)
- * over R rows of C classes.  lse_s/lse_t [R] f32 saved for backward.  d s = (p_s - p_t) * inv_t / R. */
+ * over R rows of C classes.  lse_s/lse_t [R] f32 saved for backward.  d s = (p_s - p_t) * inv_t / R; columns C .. ldds-1
+ * of ds are written as zeros (no initialisation needed). */
 int evlm_kl_fwd(int dtype_s, const void* s, int lds, int dtype_t, const void* t, int ldt, int R, int C,
                 float inv_t, float weight, float* lse_s, float* lse_t, float* loss, void* stream);
 int evlm_kl_bwd(int dtype_s, const void* s, int lds, int dtype_t, const void* t, int ldt, int R, int C,
