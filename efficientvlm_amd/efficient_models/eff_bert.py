@@ -529,7 +529,9 @@ class BertModel(BertPreTrainedModel):
             if type(encoder_attention_mask) == list:
                 encoder_extended_attention_mask = [self.invert_attention_mask(m) for m in encoder_attention_mask]
             elif encoder_attention_mask is None:
-                encoder_extended_attention_mask = self.invert_attention_mask(torch.ones(enc_shape, device=device))
+                # (the reference builds an all-ones mask here: an additive bias of 0.0 on every key - the attention kernels'
+                # no-mask form adds the same 0.0, so nothing is built)
+                encoder_extended_attention_mask = None
             else:
                 encoder_extended_attention_mask = self.invert_attention_mask(encoder_attention_mask)
         else:

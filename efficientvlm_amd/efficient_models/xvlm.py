@@ -351,7 +351,7 @@ class XVLMBase(nn.Module):
         logits_t = _matmul_nt(text_feat_all, image_feat_all).float() / self.temp
         bsz = image_feat_all.shape[0]
         if idx is None:
-            labels = torch.arange(bsz, device=image_feat.device)
+            labels = ops.const_tensor("arange", bsz, image_feat.device)
             loss_i2t = ops.cross_entropy(logits, labels)
             loss_t2i = ops.cross_entropy(logits_t, labels)
         else:

@@ -89,6 +89,29 @@ class XVLM(XVLMBase):
                 "cross_attention_dict": cross_attention_dict, "logits_dict": logits_dict}
 
     def _forward_batched(self, image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids, region=None):
+        """the batched forward run to completion, `phase_hook` called at its phase points"""
+        gen = self._forward_batched_gen(image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids, region)
+        try:
+            while True:
+                name = next(gen)
+                if self.phase_hook is not None:
+                    self.phase_hook(name)
+        except StopIteration as done:
+            return done.value
+
+    def forward_phases(self, image, text_ids, text_atts, text_ids_masked=None, masked_pos=None, masked_ids=None,
+                       image_atts=None, idx_to_group_img=None, target_bbox=None, is_image=None, ret_bbox_loss=False,
+                       output_attentions=True, output_hidden_states=True):
+        """extension: forward() as a GENERATOR over the phases of the batched forward - it yields "vision_done" (image
+        encoder finished) and "text_done" (text layers finished) and returns forward()'s dict (StopIteration.value).  A
+        trainer resumes it where it wants the rest issued: the pipelined teacher's image encoder in one hipGraph segment of
+        the multi-GPU step, its text / fusion passes in the next.  Each resume runs under the CALLER's grad mode, autocast
+        state and current stream."""
+        assert self.batched_passes and output_attentions and output_hidden_states
+        region = (image_atts, idx_to_group_img, target_bbox, is_image) if ret_bbox_loss else None
+        return self._forward_batched_gen(image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids, region)
+
+    def _forward_batched_gen(self, image, text_ids, text_atts, text_ids_masked, masked_pos, masked_ids, region=None):
         """same outputs as the pass-by-pass forward above (reference model_pretrain.py:11-82), batched as described at
         `batched_passes`.  region = (image_atts [R, N], idx_to_group_img [R], target_bbox [R, 4], is_image [R] | None)
         for a REGION batch: the image encoder yields R region-masked embeddings + the full-attention embeddings of the
@@ -127,8 +150,7 @@ class XVLM(XVLMBase):
         if self.on_vision_grad is not None and image_embeds.requires_grad:
             cb = self.on_vision_grad
             image_embeds.register_hook(lambda grad: (cb(), grad)[1])
-        if self.phase_hook is not None:
-            self.phase_hook("vision_done")
+        yield "vision_done"
         if side is not None:
             cur.wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():
@@ -144,8 +166,7 @@ class XVLM(XVLMBase):
         else:
             text_embeds, mlm_text = torch.split(t.last_hidden_state, [B, B], 0)
         text_attentions, mlm_text_attentions = halves(t.attentions)
-        if self.phase_hook is not None:
-            self.phase_hook("text_done")
+        yield "text_done"
         with torch.no_grad():
             self.temp.clamp_(0.001, 0.5)
         image_feat, text_feat = self.get_features(image_embeds, text_embeds)
@@ -154,7 +175,7 @@ class XVLM(XVLMBase):
         img_neg, txt_neg = self._sample_negatives(image_feat, text_feat, None)
         self.last_neg_idx = torch.cat([img_neg, txt_neg])
         # fusion layers on [pos (B) ; neg (2B: text|text_neg x img_neg|img) ; mlm (B)]
-        ar = torch.arange(B, device=dev)
+        ar = ops.const_tensor("arange", B, dev)
         txt_all = torch.cat([text_embeds, text_embeds, torch.index_select(text_embeds, 0, txt_neg), mlm_text], 0)
         atts_all = torch.cat([text_atts, text_atts, torch.index_select(text_atts, 0, txt_neg), text_atts], 0)
         img_index = torch.cat([ar, img_neg, ar, ar], 0)
@@ -165,7 +186,8 @@ class XVLM(XVLMBase):
             img_index = torch.cat([img_index, B + idx_to_group_img.view(-1)], 0)
             sizes.append(B)
         f = core(encoder_embeds=txt_all, attention_mask=atts_all, encoder_hidden_states=enc_states,
-                 encoder_attention_mask=torch.index_select(enc_atts, 0, img_index),
+                 # (a general batch attends to every image token - get_vision_embeds' all-ones mask: no mask is built)
+                 encoder_attention_mask=None if region is None else torch.index_select(enc_atts, 0, img_index),
                  encoder_batch_index=img_index.to(torch.int32),      # (cast once here, not in every cross-attention)
                  return_dict=True, mode="fusion", output_attentions=True, output_hidden_states=True)
         # (the hidden-state / attention-map distillation terms depend on nothing past this point: a trainer that runs them
@@ -179,7 +201,7 @@ class XVLM(XVLMBase):
         f_hid, f_att, f_cross = thirds(f.hidden_states), thirds(f.attentions), thirds(f.cross_attentions)
         last = f.last_hidden_state
         itm_logits = mlp_head_forward(self.itm_head, last[:3 * B, 0, :])
-        itm_labels = torch.cat([torch.ones(B, dtype=torch.long, device=dev), torch.zeros(2 * B, dtype=torch.long, device=dev)])
+        itm_labels = ops.const_tensor("itm_labels", B, dev)
         loss_itm = None if skip else ops.cross_entropy(itm_logits, itm_labels)
         # MLM head on the masked positions of the last quarter
         enc = self.text_encoder

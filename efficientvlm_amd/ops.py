@@ -521,6 +521,28 @@ def zeros_small(shape, dtype, device):
     return arena[used:used + nb].view(dtype).view(shape)
 
 
+_CONST = {}
+
+
+def const_tensor(kind, n, device):
+    """small index / label tensors that depend on a batch size only - built once per (kind, n, device) instead of two or three
+    launches per forward: "arange" = 0..n-1 (int64), "itm_labels" = n ones then 2n zeros (int64: positives, hard negatives).
+    Read-only by contract.  (Not cached when first asked for inside a hipGraph capture: the tensor would live in that
+    graph's pool.)"""
+    key = (kind, int(n), str(device))
+    t = _CONST.get(key)
+    if t is None:
+        if kind == "arange":
+            t = torch.arange(n, device=device)
+        elif kind == "itm_labels":
+            t = torch.cat([torch.ones(n, dtype=torch.long, device=device), torch.zeros(2 * n, dtype=torch.long, device=device)])
+        else:
+            raise ValueError(kind)
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _CONST[key] = t
+    return t
+
+
 _SCRATCH = {}
 
 

@@ -467,6 +467,12 @@ class GDTrainer(_StagedExchange):
         """teacher forward on batch buffer k -> persistent outputs k (current stream).  The image encoder's attention maps
         (most of the bytes: 60 MB per kept layer) are WRITTEN into the persistent buffers by the attention kernels
         themselves; everything else is parked by ONE grouped copy launch."""
+        self._teacher_finish(self._teacher_begin(pipe, k), pipe, k)
+
+    def _teacher_begin(self, pipe, k):
+        """first half of _teacher_eager: the teacher's IMAGE ENCODER on batch buffer k (current stream).  Returns the state
+        _teacher_finish resumes - possibly on another stream state / in another hipGraph segment: the forward is suspended
+        at its "vision_done" phase (models/model_pretrain.py:forward_phases)."""
         b = pipe["B"][k]
         enc = getattr(getattr(self.teacher, "vision_encoder", None), "encoder", None)
         region = "idx_to_group_img" in b
@@ -474,12 +480,31 @@ class GDTrainer(_StagedExchange):
             maps = pipe["T"][k]["attention_dict"].get("image_attentions", [])
             enc.attn_out = {i: ops._padded_base(m) if ops._padded_base(m) is not None else m
                             for i, m in enumerate(maps) if torch.is_tensor(m) and m.numel() > 0}
+        st = {"enc": enc, "gen": None, "T": None}
         try:
             with torch.no_grad(), compute(self.dtype):
-                T = self.teacher(b["image"], b["text_ids"], b["text_atts"], **distill.model_kwargs(b))
+                if hasattr(self.teacher, "forward_phases") and getattr(self.teacher, "batched_passes", False):
+                    st["gen"] = self.teacher.forward_phases(b["image"], b["text_ids"], b["text_atts"], **distill.model_kwargs(b))
+                    while next(st["gen"]) != "vision_done":
+                        pass
+                else:                                  # a teacher without phases: everything here
+                    st["T"] = self.teacher(b["image"], b["text_ids"], b["text_atts"], **distill.model_kwargs(b))
         finally:
             if enc is not None and hasattr(enc, "attn_out"):
                 enc.attn_out = None
+        return st
+
+    def _teacher_finish(self, st, pipe, k):
+        """second half: the teacher's text / fusion passes, then its outputs parked in the persistent buffers k"""
+        T = st["T"]
+        if T is None:
+            with torch.no_grad(), compute(self.dtype):
+                try:
+                    while True:
+                        next(st["gen"])
+                except StopIteration as done:
+                    T = done.value
+        st["gen"] = None
         pairs = []
         for d, key, i in pipe["slots"]:
             src = T[d][key] if i is None else T[d][key][i]
@@ -599,13 +624,28 @@ class GDTrainer(_StagedExchange):
         cur, cs, side = torch.cuda.current_stream(), self._cap_stream, self._side
         ops.reserve_tables()
         torch.cuda.synchronize()
-        segs, state = [], {"g": None, "forked": tpipe is None, "joined": tpipe is None}
+        segs, state = [], {"g": None, "forked": tpipe is None, "joined": tpipe is None, "half": None}
+        # the teacher in two halves (default): its image encoder beside the student's forward in the FIRST segment, its text /
+        # fusion passes in the segment behind the ITC gather - each half about as long as the student work it shares the
+        # chip with (one fork behind the gather leaves the first segment without a partner and the teacher outlasts the
+        # second).  EVLM_SEG_TEACHER_SPLIT=0: the whole forward behind the gather.
+        split = tpipe is not None and os.environ.get("EVLM_SEG_TEACHER_SPLIT", "1") not in ("", "0")
 
         def fork_teacher():
             side.wait_stream(cs)
             with torch.cuda.stream(side):
-                self._teacher_eager(tpipe, tp)
+                if state["half"] is not None:
+                    self._teacher_finish(state["half"], tpipe, tp)
+                    state["half"] = None
+                else:
+                    self._teacher_eager(tpipe, tp)
             state["forked"] = True
+
+        def fork_teacher_vision():
+            side.wait_stream(cs)
+            with torch.cuda.stream(side):
+                state["half"] = self._teacher_begin(tpipe, tp)
+            state["vision_open"] = True              # (joins where this segment ends: end())
 
         def begin():
             state["g"] = torch.cuda.CUDAGraph()
@@ -613,6 +653,9 @@ class GDTrainer(_StagedExchange):
             state["g"].capture_begin(pool=self._seg_pool, capture_error_mode="thread_local")
 
         def end():
+            if state.get("vision_open"):
+                cs.wait_stream(side)                 # the teacher's first half joins before its segment ends
+                state["vision_open"] = False
             if state["forked"] and not state["joined"]:
                 cs.wait_stream(side)                 # the teacher branch joins before its segment ends
                 state["joined"] = True
@@ -645,6 +688,8 @@ class GDTrainer(_StagedExchange):
                 try:
                     begin()
                     self._sent = 0
+                    if split:
+                        fork_teacher_vision()
                     out = self._forward_backward(pipe["B"][k], pipe["T"][k])
                     self._reduce_rest()                  # the remaining stages: one cut each
                     self.opt.step()                      # clip + AdamW: the segment behind the last all-reduce

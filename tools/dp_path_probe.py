@@ -94,8 +94,10 @@ print(f"# spin calibration: {CYC_PER_US:.0f} cycles/us; simulated wire {args.wir
       f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}", flush=True)
 for rep in range(args.reps):
     run("joint: single-GPU joint graph (no process-group path)", env={"EVLM_FORCE_REDUCE": None})
-    run("cuts_all: segments, cuts=all, teacher forked, fp32 wire", env={"EVLM_DP_CUTS": "all"})
+    run("cuts_all: segments, cuts=all, teacher forked in two halves, fp32 wire", env={"EVLM_DP_CUTS": "all"})
     run("cuts_all_sim: same + simulated wire", env={"EVLM_DP_CUTS": "all"}, sim=True)
+    run("nosplit: segments, cuts=all, whole teacher forward behind the gather", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER_SPLIT": "0"})
+    run("nosplit_sim: same + simulated wire", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER_SPLIT": "0"}, sim=True)
     run("cuts_all_noex: same, no gradient exchange", env={"EVLM_DP_CUTS": "all"}, patch=no_reduce)
     run("cuts_421: segments, ViT cuts at 4,2,1", env={"EVLM_DP_VIT_CUTS": "4,2,1"})
     run("cuts_421_sim: same + simulated wire", env={"EVLM_DP_VIT_CUTS": "4,2,1"}, sim=True)
