@@ -487,7 +487,7 @@ def begin_step(device):
     """fresh zeroed block of loss accumulators for this step (capturable: a plain allocation + fill) and the arena the
     step's small zero-initialised buffers are carved from - ONE fill launch instead of one per buffer"""
     arena = torch.zeros(1024 + ZERO_ARENA_BYTES, dtype=torch.uint8, device=device)
-    _ZERO_BLOCK[0] = arena[:1024].view(torch.float32)
+    _ZERO_BLOCK[0] = _alias(arena, 0, (256,), torch.float32)
     _ZERO_BLOCK[1] = 0
     _ZERO_ARENA[0], _ZERO_ARENA[1] = arena, 1024
 
@@ -505,6 +505,13 @@ def zero_scalar(device):
     return blk[used]
 
 
+def _alias(arena, byte_off, shape, dtype):
+    """a tensor OVER a byte range of `arena`'s storage that autograd does not know as a view of it (own version counter, no
+    base): kernels and in-place ATen ops on one such tensor say nothing about the others"""
+    t = torch.empty(0, dtype=dtype, device=arena.device)
+    return t.set_(arena.untyped_storage(), byte_off // t.element_size(), tuple(shape))
+
+
 def zeros_small(shape, dtype, device):
     """torch.zeros(shape) for a buffer a kernel is about to write into / accumulate into: inside a trainer's step small ones
     are views of the step's pre-zeroed arena (no launch); anything else is a plain torch.zeros"""
@@ -518,7 +525,7 @@ def zeros_small(shape, dtype, device):
             or used + nb > arena.numel()):
         return torch.zeros(shape, dtype=dtype, device=device)
     _ZERO_ARENA[1] = (used + nb + 255) // 256 * 256
-    return arena[used:used + nb].view(dtype).view(shape)
+    return _alias(arena, used, shape, dtype)
 
 
 _CONST = {}
