@@ -329,7 +329,11 @@ def gd_forward(student, teacher, batch, temperature=1.0, overlap_teacher=False, 
     else:
         S, T = student_and_teacher(lambda: call(student), lambda: call(teacher), batch["image"], overlap_teacher)
     fork = getattr(student, "kd_fork", None)
-    side = (student.text_stream, fork) if (fork is not None and getattr(student, "text_stream", None) is not None) else None
+    # (the side stream starts at the student's fork event - it sees NOTHING issued after it: only teacher tensors that were
+    # complete before this step began may be read there, i.e. the pipelined trainer's; a teacher forward of this step joins
+    # the main stream after that event)
+    side = (student.text_stream, fork) if (teacher_out is not None and fork is not None
+                                           and getattr(student, "text_stream", None) is not None) else None
     kd = kd_terms(S, T, temperature, fused=fused, side=side)
     student.kd_fork = None
     total, mix = gd_loss_mix(S["loss"], kd)
