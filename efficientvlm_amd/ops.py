@@ -1040,34 +1040,65 @@ def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True, 
     return _Attention.apply(q, kv, mask, gate, H, dh, 0, 0, d, scale, want_probs, kv_index, False, dropout_p)[:2]
 
 
-_PIN_CHUNKS, _PIN_USED = [], 0            # pinned int64 chunks (every one stays alive: captured memcpy nodes read them)
+_PIN_CHUNKS, _PIN_USED = [], 0            # pinned int64 chunks (every one stays alive: pending uploads read them)
 _PIN_CHUNK_WORDS = 1 << 17                # 1 MiB each: ~700 tables of 45 copies
+_DEV_CHUNKS = {}                          # device index -> [int64 device chunk (outside any graph pool), words used]
+_PENDING_UPLOADS = []                     # (device slice, pinned slice) of tables built during a capture
 
 
 def reserve_tables(min_words=1 << 14):
-    """make sure the pinned table pool has `min_words` free int64 words - call OUTSIDE a hipGraph capture, before one
-    starts (pinning memory is not capturable; a capture consumes a few KiB of tables and the words are never reclaimed,
-    because the graph's memcpy nodes keep reading them).  Grows the pool by another chunk when the current one is short."""
+    """make sure the table pools (pinned host words + a device arena on the current device) have `min_words` free int64
+    words - call OUTSIDE a hipGraph capture, before one starts (neither pinning nor a persistent allocation is capturable; a
+    capture consumes a few KiB of tables and the words are never reclaimed: the captured launches keep reading them).  Grows
+    a pool by another chunk when the current one is short.  Also sends up tables an earlier capture left pending."""
     global _PIN_USED
     if torch.cuda.is_current_stream_capturing():
         raise RuntimeError("reserve_tables() inside a hipGraph capture")
+    flush_table_uploads()
     if not _PIN_CHUNKS or _PIN_USED + min_words > _PIN_CHUNKS[-1].numel():
         _PIN_CHUNKS.append(torch.empty(max(_PIN_CHUNK_WORDS, min_words), dtype=torch.int64).pin_memory())
         _PIN_USED = 0
+    d = torch.cuda.current_device()
+    ent = _DEV_CHUNKS.get(d)
+    if ent is None or ent[1] + min_words > ent[0].numel():
+        ent = _DEV_CHUNKS.setdefault(d, [None, 0])
+        ent[0] = torch.empty(max(_PIN_CHUNK_WORDS, min_words), dtype=torch.int64, device=torch.device("cuda", d))
+        ent[1] = 0            # (the chunk it replaces stays alive through the slices handed out of it)
+
+
+def flush_table_uploads():
+    """send up the tables built during a hipGraph capture - ONCE, eagerly, after the capture has ended and before the graph
+    is first replayed (every trainer does so right behind its captures; reserve_tables() and the next eager table do it
+    too).  A captured launch reads its table out of the persistent device arena: there is no memcpy node per table in the
+    graph (the GD step's graphs held ~55 of them, each a 6 us copy kernel on some launch's critical path)."""
+    global _PENDING_UPLOADS
+    if not _PENDING_UPLOADS or torch.cuda.is_current_stream_capturing():
+        return
+    q, _PENDING_UPLOADS = _PENDING_UPLOADS, []
+    devs = set()
+    for dst, src in q:
+        dst.copy_(src, non_blocking=True)
+        devs.add(dst.device)
+    for d in devs:
+        torch.cuda.synchronize(d)         # (the graph may be replayed on any stream)
 
 
 def _upload_table(rows, dev):
-    """flat list of int64 -> device tensor.  Inside a hipGraph capture the table goes up as a memcpy node out of a PINNED
-    block that is never rewritten (a slice of a pool chunk allocated outside any capture, see reserve_tables)."""
+    """flat list of int64 -> device tensor.  Inside a hipGraph capture the table is a slice of the persistent device arena
+    (reserve_tables), filled once after the capture (flush_table_uploads) out of a pinned slice that is never rewritten:
+    its contents - addresses inside the graph's pool, sizes - are the same at every replay."""
     global _PIN_USED
     if torch.cuda.is_current_stream_capturing():
-        if not _PIN_CHUNKS or _PIN_USED + len(rows) > _PIN_CHUNKS[-1].numel():
-            raise RuntimeError("pinned table pool missing / exhausted (ops.reserve_tables() before the capture starts)")
+        ent = _DEV_CHUNKS.get(torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device())
+        if (not _PIN_CHUNKS or _PIN_USED + len(rows) > _PIN_CHUNKS[-1].numel() or ent is None
+                or ent[1] + len(rows) > ent[0].numel()):
+            raise RuntimeError("table pools missing / exhausted (ops.reserve_tables() before the capture starts)")
         host = _PIN_CHUNKS[-1][_PIN_USED:_PIN_USED + len(rows)]
         _PIN_USED += len(rows)
         host.copy_(torch.tensor(rows, dtype=torch.int64))
-        table = torch.empty(len(rows), dtype=torch.int64, device=dev)
-        table.copy_(host, non_blocking=True)
+        table = ent[0][ent[1]:ent[1] + len(rows)]
+        ent[1] += len(rows)
+        _PENDING_UPLOADS.append((table, host))
         return table
     reserve_tables()
     return torch.tensor(rows, dtype=torch.int64).to(dev)

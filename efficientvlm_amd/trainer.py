@@ -448,6 +448,7 @@ class GDTrainer(_StagedExchange):
                     # (thread_local: on multi-GPU runs the RCCL watchdog thread may query events while this captures)
                     with torch.cuda.graph(g, pool=self._tpool, stream=side, capture_error_mode="thread_local"):
                         self._teacher_eager(pipe, k)
+                    ops.flush_table_uploads()
                     tg.append(g)
                     self._tpool = g.pool()
                 pipe["tgraphs"] = tg
@@ -567,6 +568,7 @@ class GDTrainer(_StagedExchange):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=self._spool):
                     res = self._joint_body(pipe, p, pp, pk)
+                ops.flush_table_uploads()
                 self._spool = g.pool()
                 jg = self._joint[key] = (g, res, self.last_kd)
             jg[0].replay()
@@ -706,6 +708,7 @@ class GDTrainer(_StagedExchange):
             self._cut = None
         cur.wait_stream(cs)
         torch.cuda.synchronize()
+        ops.flush_table_uploads()
         last_reduce = [item for kind, item in segs if kind == "reduce"][-1]
         return dict(segs=segs, out=out, kd=kd, last_reduce=last_reduce)
 
@@ -832,6 +835,7 @@ class GDTrainer(_StagedExchange):
         pool = next(iter(self._graphs.values()))[0].pool() if self._graphs else None   # the kinds never run concurrently
         with torch.cuda.graph(graph, pool=pool):
             out = self._step_eager(static)
+        ops.flush_table_uploads()
         # the warm-up advanced Adam's step count and moments: restore them so replay k is optimiser step k
         for g, (m, v) in zip(self.opt.groups, state[0]):
             g["m"].copy_(m)
@@ -870,6 +874,7 @@ class TeacherPrefetch:
                     st["T"][k] = self.run_teacher(st["B"][k])
                 st["graphs"].append(g)
             torch.cuda.synchronize()
+            ops.flush_table_uploads()
         return st
 
     def submit(self, batch):

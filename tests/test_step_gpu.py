@@ -320,6 +320,34 @@ def test_benchmarked_configuration_matches_the_oracle(B):
     assert served.get("gemm_bf16_pp256_grouped_kernel", 0) >= 2, served
 
 
+@pytest.mark.gpu
+def test_forward_phases_generator_equals_forward():
+    """XVLM.forward_phases (the batched forward as a generator over its phases - what lets a trainer issue the pipelined
+    teacher's image encoder and its text / fusion passes in two different hipGraph segments) yields "vision_done" then
+    "text_done" and returns forward()'s dict, tensor for tensor"""
+    from efficientvlm_amd import distill
+    from efficientvlm_amd.runtime import compute
+    geom = synth.GEOMS["tiny"]
+    _, teacher = build_gd(geom, 5)
+    batch = {k: v.to(DEV) for k, v in synth.make_batch(geom, 4, seed=17).items()}
+    teacher.injected_neg_idx = torch.tensor([1, 2, 3, 0, 2, 3, 0, 1])
+    teacher.keep_injected_neg = True
+    with torch.no_grad(), compute(torch.float32):
+        ref = teacher(batch["image"], batch["text_ids"], batch["text_atts"], **distill.model_kwargs(batch))
+        gen = teacher.forward_phases(batch["image"], batch["text_ids"], batch["text_atts"], **distill.model_kwargs(batch))
+        names = []
+        try:
+            while True:
+                names.append(next(gen))
+        except StopIteration as done:
+            out = done.value
+    assert names == ["vision_done", "text_done"]
+    a, b = list(distill._tensors(ref)), list(distill._tensors(out))
+    assert len(a) == len(b) and len(a) > 20
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and torch.equal(x, y)
+
+
 _DP_SCRIPT = r"""
 import os, sys, json, torch
 sys.path.insert(0, os.environ["EVLM_REPO"]); sys.path.insert(0, os.path.join(os.environ["EVLM_REPO"], "tests"))
@@ -405,15 +433,18 @@ print("RESULT " + json.dumps(out))
 """
 
 
-def test_segmented_graph_step_of_the_multi_gpu_path_matches_the_single_gpu_graph():
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_segmented_graph_step_of_the_multi_gpu_path_matches_the_single_gpu_graph(split):
     """N > 1 code path with world_size 1 (RCCL group of one rank, the ITC all-gather forced through the collective): the
     student step replayed as hipGraph segments around the gather and the gradient all-reduce (trainer._student_segmented)
-    must train exactly like the single-GPU joint graph - same losses over five optimiser steps on rotating batches"""
+    must train exactly like the single-GPU joint graph - same losses over five optimiser steps on rotating batches.
+    split: the pipelined teacher forward in two halves (image encoder in the first segment, text / fusion passes in the
+    second: the forward suspended at its "vision_done" phase between two captures) or whole behind the gather"""
     import json, os, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
     def run(dp):
-        env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", EVLM_SEG_TEACHER_SPLIT=split)
         env.pop("EVLM_FORCE_REDUCE", None)
         if dp:
             env["EVLM_FORCE_REDUCE"] = "1"

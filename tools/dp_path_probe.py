@@ -99,6 +99,9 @@ for rep in range(args.reps):
     run("nosplit: segments, cuts=all, whole teacher forward behind the gather", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER_SPLIT": "0"})
     run("nosplit_sim: same + simulated wire", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER_SPLIT": "0"}, sim=True)
     run("cuts_all_noex: same, no gradient exchange", env={"EVLM_DP_CUTS": "all"}, patch=no_reduce)
+    for vc in ("4", "3", "2"):
+        run(f"cuts_v{vc}: segments, ONE ViT cut at layer {vc}", env={"EVLM_DP_VIT_CUTS": vc})
+        run(f"cuts_v{vc}_sim: same + simulated wire", env={"EVLM_DP_VIT_CUTS": vc}, sim=True)
     run("cuts_421: segments, ViT cuts at 4,2,1", env={"EVLM_DP_VIT_CUTS": "4,2,1"})
     run("cuts_421_sim: same + simulated wire", env={"EVLM_DP_VIT_CUTS": "4,2,1"}, sim=True)
     for fk in ("start", "vision_done", "text_done"):

@@ -20,6 +20,7 @@ def bench(f, reps=30):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for _ in range(reps): f()
+    ops.flush_table_uploads()
     g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
