@@ -1096,6 +1096,10 @@ def _upload_table(rows, dev):
         host = _PIN_CHUNKS[-1][_PIN_USED:_PIN_USED + len(rows)]
         _PIN_USED += len(rows)
         host.copy_(torch.tensor(rows, dtype=torch.int64))
+        if os.environ.get("EVLM_TABLE_MEMCPY_NODES"):        # A/B switch: the round-2 form, one captured memcpy per table
+            table = torch.empty(len(rows), dtype=torch.int64, device=dev)
+            table.copy_(host, non_blocking=True)
+            return table
         table = ent[0][ent[1]:ent[1] + len(rows)]
         ent[1] += len(rows)
         _PENDING_UPLOADS.append((table, host))
