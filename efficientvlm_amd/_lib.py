@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVLM_LIB", os.path.join(_HERE, "libevlm_hip.so"))
 
-ABI_VERSION = 4      # evlm_abi_version() of the library this binding was written against (struct layouts, entry points)
+ABI_VERSION = 5      # evlm_abi_version() of the library this binding was written against (struct layouts, entry points)
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2
 GATE_PRE, GATE_POST = 0, 1
@@ -109,7 +109,7 @@ SIGNATURES = {
     "evlm_layernorm_bwd_reduce_grouped": [_vp, _i, _i, _vp],
     "evlm_mse_grouped": [_i, _i, _vp, _i, _i, _vp],
     "evlm_sample_negatives": [_vp, _i, _i, _vp, _vp, _vp, C.c_uint32, _vp, _vp],
-    "evlm_sumsq": [_vp, _i64, _vp, _vp],
+    "evlm_sumsq": [_vp, _i64, _vp, _vp, _vp],
     "evlm_adamw_step": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _vp, _vp, _vp],
 }
 

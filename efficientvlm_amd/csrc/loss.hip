@@ -441,8 +441,14 @@ extern "C" int evlm_log_softmax_bwd(int dtype, const void* y, const void* dy, in
 // ---------------------------------------------------------------------------------------------
 // optimiser-side helpers
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+// DETERMINISTIC with a workspace (ws[0]: arrival counter, kept zero between launches; ws[2 + b]: partial sum of block b):
+// the last block to arrive sums the partials in a fixed order and adds the result to *out - the same bits on every rank of
+// a data-parallel run, whose replicas stay bit-identical only if their clip factors are (f32 atomics in arrival order
+// differ in the last bits from launch to launch).  ws == NULL: one f32 atomic per block (order-dependent rounding).
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out,
+                                                    float* __restrict__ ws) {
   __shared__ float red[16];
+  __shared__ int last;
   float s = 0.f;
   const int64_t nv = n >> 2;
   for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nv; c += (int64_t)gridDim.x * blockDim.x) {
@@ -452,14 +458,32 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   }
   if (blockIdx.x == 0) for (int64_t i = (nv << 2) + threadIdx.x; i < n; i += blockDim.x) s += x[i] * x[i];
   s = block_sum(s, red);
-  if (threadIdx.x == 0) atomicAdd(out, s);
+  if (!ws) {
+    if (threadIdx.x == 0) atomicAdd(out, s);
+    return;
+  }
+  if (threadIdx.x == 0) {
+    atomicExch(ws + 2 + blockIdx.x, s);                       // (device-scope: visible to whichever block arrives last)
+    __threadfence();
+    last = atomicAdd(reinterpret_cast<unsigned int*>(ws), 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float t = 0.f;
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) t += atomicAdd(ws + 2 + b, 0.f);   // coherent read
+  t = block_sum(t, red);
+  if (threadIdx.x == 0) {
+    *out += t;                                                // single writer; launches of a stream run in order
+    atomicExch(reinterpret_cast<unsigned int*>(ws), 0u);
+  }
 }
-extern "C" int evlm_sumsq(const float* x, int64_t n, float* out, void* stream_) {
+extern "C" int evlm_sumsq(const float* x, int64_t n, float* out, float* workspace, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(x && out && n > 0, "evlm_sumsq: bad args");
   EVLM_REQUIRE(((uintptr_t)x) % 16 == 0, "evlm_sumsq: x must be 16-byte aligned");
-  const int grid = imin(2048, (n / 4 + 255) / 256 + 1);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, stream, x, n, out);
+  const int grid = imin(EVLM_SUMSQ_WORKSPACE_FLOATS - 2, (n / 4 + 255) / 256 + 1);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, stream, x, n, out, workspace);
   EVLM_LAUNCH_CHECK("evlm_sumsq");
   return 0;
 }

@@ -61,6 +61,8 @@ class FlatAdamW:
         self._scheduled, self._last_mult = False, 1.0      # has set_schedule() run since the last step()?
         dev = named[0][1].device
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        # fixed-order sum of squares (include/evlm_hip.h: evlm_sumsq): data-parallel replicas clip by bit-identical factors
+        self.sumsq_ws = torch.zeros(2050, dtype=torch.float32, device=dev) if torch.device(dev).type == "cuda" else None
         self.hyper = torch.ones(3, dtype=torch.float32, device=dev)       # {lr multiplier, bias_c1, bias_c2}
         lowp = dev.type == "cuda"
         for g in self.groups:
@@ -201,7 +203,7 @@ class FlatAdamW:
                 off += (k + 7) // 8 * 8
         self.gnorm_sq.zero_()
         for g in self.groups:
-            L.check(lib.evlm_sumsq(L.ptr(g["g"]), g["g"].numel(), L.ptr(self.gnorm_sq), L.stream()), "sumsq")
+            L.check(lib.evlm_sumsq(L.ptr(g["g"]), g["g"].numel(), L.ptr(self.gnorm_sq), L.ptr(self.sumsq_ws), L.stream()), "sumsq")
         b1, b2 = self.betas
         for g in self.groups:
             L.check(lib.evlm_adamw_step(L.ptr(g["p"]), L.ptr(g["g"]), L.ptr(g["m"]), L.ptr(g["v"]), g["p"].numel(),

@@ -52,7 +52,10 @@ class GradReducer:
         self.active = self.world > 1 or (force and ready)
         # RCCL averages in the collective itself (one pass over the slabs less); gloo has no AVG
         self.native_avg = bool(ready and dist.get_backend(group) == "nccl" and hasattr(dist.ReduceOp, "AVG"))
-        self.coalesce = hasattr(dist, "_coalescing_manager") and not os.environ.get("EVLM_NO_COALESCE")
+        # (gloo coalesces host tensors only: device slabs over gloo - the two-ranks-on-one-GPU test - go one by one)
+        on_gpu = bool(self.flat and self.flat[0].is_cuda)
+        self.coalesce = (hasattr(dist, "_coalescing_manager") and not os.environ.get("EVLM_NO_COALESCE")
+                         and (self.native_avg or not on_gpu))
         self.buckets = self._buckets(self.flat)
         self.stream = torch.cuda.Stream() if (self.flat and self.flat[0].is_cuda) else None
         self._pending = []

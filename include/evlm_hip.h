@@ -384,8 +384,13 @@ int evlm_sample_negatives(const float* sim, int B, int ld, const float* temp, co
 /* ------------------------------------------------------------------------------------------------
  * Optimiser-side helpers (next-tier row §8f-1; kept minimal here)
  * ---------------------------------------------------------------------------------------------- */
-/* *out += sum(x^2) over n f32 values (global grad norm, apex_ddp_accelerator.py:99-102) */
-int evlm_sumsq(const float* x, int64_t n, float* out, void* stream);
+/* *out += sum(x^2) over n f32 values (global grad norm, apex_ddp_accelerator.py:99-102).  workspace (ABI 5):
+ * EVLM_SUMSQ_WORKSPACE_FLOATS f32 words of device memory, zero before the first use (the kernel leaves word 0 zero), not
+ * shared by launches that may overlap - the sum is then formed in a FIXED order: bit-identical from launch to launch and
+ * from rank to rank, which data-parallel replicas need to stay bit-identical (their clip factors derive from it).  NULL:
+ * one f32 atomic per block, order-dependent in the last bits. */
+#define EVLM_SUMSQ_WORKSPACE_FLOATS 2050
+int evlm_sumsq(const float* x, int64_t n, float* out, float* workspace, void* stream);
 /* HF-AdamW step (optim.py:67, transformers AdamW: Adam update then p -= lr*wd*p), with the gradient
  * pre-scaled by min(1, max_norm/ (sqrt(*gnorm_sq)+1e-6)) (clip_grad_norm_, apex_ddp_accelerator.py:99-102); optionally
  * refreshes a bf16 copy.  hyper (device f32[3] or NULL) = {lr multiplier, bias_c1, bias_c2}: when given it overrides the

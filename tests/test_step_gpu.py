@@ -458,6 +458,83 @@ def test_segmented_graph_step_of_the_multi_gpu_path_matches_the_single_gpu_graph
     assert np.allclose(a, b, rtol=3e-4, atol=1e-5), (a, b)
 
 
+_DP2_SCRIPT = r"""
+import os, sys, json, hashlib, torch
+sys.path.insert(0, os.environ["EVLM_REPO"]); sys.path.insert(0, os.path.join(os.environ["EVLM_REPO"], "tests"))
+import torch.distributed as dist
+from oracle import synth
+from test_step_gpu import build_gd
+from efficientvlm_amd.trainer import GDTrainer
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)                         # both ranks share the one GPU of the box: gloo moves the bytes
+dist.init_process_group("gloo", rank=rank, world_size=2)
+geom = synth.GEOMS["tiny"]
+student, teacher = build_gd(geom, 9 + 100 * rank)           # DIFFERENT initial students: the constructor's broadcast must level them
+neg = torch.tensor([1, 2, 3, 0, 2, 3, 0, 1])
+student.injected_neg_idx = teacher.injected_neg_idx = neg
+student.keep_injected_neg = teacher.keep_injected_neg = True
+tr = GDTrainer(student, teacher, lr=1e-3, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=torch.float32,
+               use_graph=True, pipeline_teacher=True)
+assert tr.world == 2 and tr.reducer.active
+batches = [{k: v.cuda() for k, v in synth.make_batch(geom, 4, seed=3 + i + 50 * rank).items()} for i in range(3)]
+out = []
+for i in range(6):
+    o = tr.step(batches[i % 3])
+    if o is not None:
+        out.append(o.tolist())
+torch.cuda.synchronize()
+segmented = bool(tr._seg) and not getattr(tr, "_segments_broken", False)
+flat = torch.cat([g["p"].detach().reshape(-1).float().cpu() for g in tr.opt.groups])
+digest = hashlib.sha256(flat.numpy().tobytes()).hexdigest()
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps({"rank": rank, "out": out, "segmented": segmented, "digest": digest, "pnorm": float(flat.norm())}))
+"""
+
+
+def test_two_ranks_train_in_lockstep_through_the_segmented_multi_gpu_step():
+    """TWO ranks (two processes on the one GPU of the box, gloo carrying the collectives - RCCL refuses two ranks on one
+    device) through the shipping N > 1 path: parameter broadcast from rank 0 at construction (the students are built from
+    different seeds), the step as hipGraph segments around a REAL two-rank ITC gather and staged gradient all-reduces, the
+    pipelined teacher in two halves, rank agreement on the capture.  After five optimiser steps on rank-specific batches
+    the parameter slabs of the two ranks are bit-identical (every rank applied the same averaged gradients to the same
+    parameters), and each rank's loss trajectory equals the one it gets from the eager fallback path
+    (EVLM_NO_SEGMENT_GRAPHS=1: hooks send the stages) - the two forms that must stay interchangeable rank by rank"""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(port, eager):
+        procs = []
+        for rank in (0, 1):
+            env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2")
+            env.pop("EVLM_FORCE_REDUCE", None)
+            if eager:
+                env["EVLM_NO_SEGMENT_GRAPHS"] = "1"
+            procs.append(subprocess.Popen([sys.executable, "-c", _DP2_SCRIPT], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE, text=True))
+        res = []
+        for p in procs:
+            try:
+                so, se = p.communicate(timeout=900)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise AssertionError("a rank hung (collective sequences of the two ranks differ?)")
+            assert p.returncode == 0, se[-3000:]
+            res.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]))
+        return sorted(res, key=lambda r: r["rank"])
+
+    seg = run(29571, eager=False)
+    assert all(r["segmented"] for r in seg), "the segmented form was not used"
+    assert seg[0]["digest"] == seg[1]["digest"], (seg[0]["pnorm"], seg[1]["pnorm"])
+    assert len(seg[0]["out"]) == 5 and np.isfinite(np.array(seg[0]["out"])).all()
+    eag = run(29573, eager=True)
+    assert not any(r["segmented"] for r in eag)
+    assert eag[0]["digest"] == eag[1]["digest"]
+    for a, b in zip(seg, eag):
+        assert np.allclose(np.array(a["out"]), np.array(b["out"]), rtol=3e-4, atol=1e-5), (a["out"], b["out"])
+
+
 _DP_SEQ_SCRIPT = r"""
 import os, sys, json, torch
 sys.path.insert(0, os.environ["EVLM_REPO"]); sys.path.insert(0, os.path.join(os.environ["EVLM_REPO"], "tests"))
