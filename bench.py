@@ -342,8 +342,13 @@ def main():
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        backend = "nccl"                                               # "nccl" IS RCCL on ROCm
+        if os.environ.get("EVLM_BENCH_SHARE_GPU"):
+            # dry run of the N > 1 flow on a ONE-GPU box: every rank on device 0, gloo carrying the collectives (RCCL refuses
+            # two ranks on one device).  Checks the launch contract, not a throughput - the line says so in config.launch.
+            local_rank, backend = 0, "gloo"
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     dev = torch.device("cuda", local_rank)
 
@@ -401,7 +406,8 @@ def main():
                           "image": "224x224", "text_len": geom["L"], "masked": geom["M"], "batch_per_gpu": B,
                           "global_batch": B * world, "parallelism": f"dp{world}",
                           "launch": "eager" if (args.no_graph or force_dp) else
-                                    ("hipGraph segments around the collectives" if world > 1 else "hipGraph replay"),
+                                    ("hipGraph segments around the collectives" if world > 1 else "hipGraph replay")
+                                    + (" [DRY RUN: ranks share one GPU, gloo]" if os.environ.get("EVLM_BENCH_SHARE_GPU") else ""),
                           "teacher_pipelined": pipelined, "distinct_batches": 4,
                           "init": "random (reference init), no checkpoints"},
                "last_losses": {"total": losses[0], "itc": losses[1], "itm": losses[2], "mlm": losses[3], "kd": losses[4]}}
