@@ -535,6 +535,88 @@ def test_two_ranks_train_in_lockstep_through_the_segmented_multi_gpu_step():
         assert np.allclose(np.array(a["out"]), np.array(b["out"]), rtol=3e-4, atol=1e-5), (a["out"], b["out"])
 
 
+_DP2_ITR_SCRIPT = r"""
+import os, sys, json, hashlib, torch
+sys.path.insert(0, os.environ["EVLM_REPO"]); sys.path.insert(0, os.path.join(os.environ["EVLM_REPO"], "tests"))
+import torch.distributed as dist
+from oracle import synth, schema
+from oracle import xvlm_oracle as O
+from helpers import load_det_weights, model_config
+from efficientvlm_amd.efficient_models.model_retrieval import EffXVLMforRetrieval
+from efficientvlm_amd.efficient_models.xvlm import XVLMBase
+from efficientvlm_amd.models.model_retrieval import XVLM as TeacherITR
+from efficientvlm_amd.trainer import ITRTrainer
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=2)
+def fixed_negatives(self, image_feat, text_feat, idx):
+    bs = image_feat.size(0)
+    ar = torch.arange(bs, device=image_feat.device)
+    return (ar + 1) % bs, (ar + 2) % bs
+XVLMBase._sample_negatives = fixed_negatives
+geom = synth.GEOMS["tiny"]
+s_cfg, t_cfg = O.model_cfg(geom, "s"), O.model_cfg(geom, "t")
+B = 4
+student, teacher = EffXVLMforRetrieval(model_config(geom, "s")), TeacherITR(model_config(geom, "t"))
+load_det_weights(student, schema.xvlm_schema(s_cfg, geom["max_pos"], mlm=False, bbox=False, l0=True), 51 + 7 * rank, geom["std"])
+load_det_weights(teacher, schema.xvlm_schema(t_cfg, geom["max_pos"], mlm=False, bbox=False), 52, geom["std"])
+gen = torch.Generator().manual_seed(8 + rank)                # rank-specific gate parameters too: the broadcast levels them
+with torch.no_grad():
+    for n, p in student.l0_module.named_parameters():
+        p.copy_(torch.full_like(p, 0.3) if "lambda" in n else torch.randn(p.shape, generator=gen) + 0.5)
+student.l0_module.set_lagrangian_warmup_steps(10)
+student.cuda(); teacher.cuda()
+tr = ITRTrainer(student, teacher, lr=1e-3, reg_learning_rate=0.05, dtype=torch.float32, pipeline_teacher=True, use_graph=True)
+assert tr.reducer.active and tr.reducer.world == 2
+batches = [{k: v.cuda() for k, v in synth.make_batch(geom, B, seed=30 + i + 40 * rank, ragged=True).items()
+            if k in ("image", "text_ids", "text_atts")} for i in range(3)]
+idx = torch.arange(B).cuda() + B * rank
+out = []
+for c in range(5):
+    # (each rank draws its own gate noise, as each reference process does)
+    student.l0_module.injected_eps = {t: torch.rand(getattr(student.l0_module, O.L0_PARAM[t]).shape, generator=gen).clamp(1e-6, 1 - 1e-6)
+                                      for t in O.L0_TYPES}
+    o = tr.step(batches[c % 3], idx=idx)
+    if o is not None:
+        out.append(o.tolist())
+torch.cuda.synchronize()
+h = hashlib.sha256()
+for k, v in sorted(student.state_dict().items()):
+    h.update(v.detach().float().cpu().numpy().tobytes())
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps({"rank": rank, "out": out, "digest": h.hexdigest()}))
+"""
+
+
+def test_two_ranks_of_the_itr_pruning_step_stay_bit_identical():
+    """the ITR pruning fine-tune (ITRTrainer: three optimisers, L0 gate parameters and Lagrange multipliers travelling in the
+    LAST gradient stage, teacher prefetched through hipGraphs) on TWO ranks - two processes on the one GPU, gloo: students
+    and gate parameters built differently per rank are levelled by the constructor's broadcast, every rank draws its own
+    gate noise and batches; after four optimiser steps every student tensor (gates and multipliers included) is
+    bit-identical on the two ranks"""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK=str(rank), WORLD_SIZE="2")
+        env.pop("EVLM_FORCE_REDUCE", None)
+        procs.append(subprocess.Popen([sys.executable, "-c", _DP2_ITR_SCRIPT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    res = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung (collective sequences of the two ranks differ?)")
+        assert p.returncode == 0, se[-3000:]
+        res.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    assert len(res[0]["out"]) == 4 and np.isfinite(np.array(res[0]["out"])).all()
+    assert res[0]["digest"] == res[1]["digest"]
+
+
 _DP_SEQ_SCRIPT = r"""
 import os, sys, json, torch
 sys.path.insert(0, os.environ["EVLM_REPO"]); sys.path.insert(0, os.path.join(os.environ["EVLM_REPO"], "tests"))
