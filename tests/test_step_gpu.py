@@ -535,6 +535,102 @@ def test_two_ranks_train_in_lockstep_through_the_segmented_multi_gpu_step():
         assert np.allclose(np.array(a["out"]), np.array(b["out"]), rtol=3e-4, atol=1e-5), (a["out"], b["out"])
 
 
+_DP2_ORACLE_SCRIPT = r"""
+import os, sys, json, torch
+sys.path.insert(0, os.environ["EVLM_REPO"]); sys.path.insert(0, os.path.join(os.environ["EVLM_REPO"], "tests"))
+import torch.distributed as dist
+from oracle import synth, schema
+from oracle import xvlm_oracle as O
+from helpers import load_det_weights, model_config
+from test_dp_cpu import _gd_problem, _B_HALF
+from efficientvlm_amd.models.model_pretrain import XVLM
+from efficientvlm_amd.trainer import GDTrainer
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=2)
+geom = synth.GEOMS["tiny"]
+_, s_cfg, t_cfg, s_sd, t_sd, batch, neg_local = _gd_problem()
+student, teacher = XVLM(model_config(geom, "s")), XVLM(model_config(geom, "t"))
+load_det_weights(student, schema.xvlm_schema(s_cfg, geom["max_pos"]), 31, geom["std"])
+load_det_weights(teacher, schema.xvlm_schema(t_cfg, geom["max_pos"]), 32, geom["std"])
+student.cuda().train(); teacher.cuda().eval()
+student.injected_neg_idx = teacher.injected_neg_idx = neg_local[rank]
+student.keep_injected_neg = teacher.keep_injected_neg = True
+use_graph = bool(int(os.environ["EVLM_TEST_GRAPH"]))
+tr = GDTrainer(student, teacher, lr=0.0, weight_decay=0.0, max_grad_norm=0.0, dtype=torch.float32, use_graph=use_graph,
+               pipeline_teacher=use_graph)
+lo, hi = rank * _B_HALF, (rank + 1) * _B_HALF
+half = {k: v[lo:hi].cuda() for k, v in batch.items()}
+out = tr.step(half)
+if out is None:                                   # pipelined: the first call primed the teacher, the second trains on `half`
+    out = tr.step(half)
+torch.cuda.synchronize()
+grads = {k: p.grad.detach().float().cpu() for k, p in student.named_parameters() if p.grad is not None}
+torch.save({"grads": grads, "losses": out.tolist(),
+            "segmented": bool(getattr(tr, "_seg", None)) and not getattr(tr, "_segments_broken", False)},
+           os.environ["EVLM_TEST_OUT"] + f".{rank}")
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_rank_hip_gradients_equal_the_oracles_global_batch_gradient(use_graph, tmp_path):
+    """The data-parallel semantics of tests/test_dp_cpu.py (there: oracle forward + the product's gather and reducer) with
+    the PRODUCT doing all of it on the GPU: two ranks (two processes on the one GPU, gloo), each running GDTrainer's N > 1
+    step (eager with hook-driven stages / hipGraph segments with the pipelined teacher) on its half of a global batch -
+    the rank-averaged gradient left in the slabs must equal the CPU oracle's single-process gradient on the WHOLE batch,
+    with the reference's ITC term reaching the encoders scaled by 1 / world (its slice-only gather backward,
+    efficient_models/xvlm.py:54-74); every rank reports the global ITC loss"""
+    import os, subprocess, sys
+    from test_dp_cpu import _gd_problem, _tied, _B_HALF
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outp = str(tmp_path / "dp2")
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29581" if use_graph else "29583",
+                   RANK=str(rank), WORLD_SIZE="2", EVLM_TEST_OUT=outp, EVLM_TEST_GRAPH=str(int(use_graph)))
+        env.pop("EVLM_FORCE_REDUCE", None)
+        procs.append(subprocess.Popen([sys.executable, "-c", _DP2_ORACLE_SCRIPT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung")
+        assert p.returncode == 0, se[-3000:]
+    res = [torch.load(outp + f".{r}") for r in (0, 1)]
+    assert all(r["segmented"] == use_graph for r in res)
+    # the oracle on the whole batch, ITC gradient into the features scaled by 1 / world (as in test_dp_cpu.py)
+    Oo, s_cfg, t_cfg, s_sd, t_sd, batch, neg_local = _gd_problem()
+    names = sorted(s_sd)
+    leaves = {k: s_sd[k].clone().requires_grad_(True) for k in names}
+    B = _B_HALF
+    neg = torch.cat([neg_local[0][:B], neg_local[1][:B] + B, neg_local[0][B:], neg_local[1][B:] + B])
+    S = Oo.pretrain_forward(_tied(leaves), s_cfg, batch, neg)
+    with torch.no_grad():
+        T = Oo.pretrain_forward(_tied(t_sd), t_cfg, batch, neg)
+    loss = dict(S["loss"])
+    i_feat, t_feat = S["features"]
+    half_grad = lambda x: x * 0.5 + x.detach() * 0.5
+    loss["loss_itc"] = Oo.contrastive_loss(half_grad(i_feat), half_grad(t_feat), leaves["temp"].clamp(0.001, 0.5))
+    total, _ = Oo.gd_loss_mix(loss, Oo.kd_terms(S, T))
+    total.backward()
+    common = [k for k in names if k in res[0]["grads"] and leaves[k].grad is not None]
+    covered = sum(leaves[k].numel() for k in common) / sum(leaves[k].numel() for k in names if leaves[k].grad is not None)
+    assert covered > 0.99, covered
+    ref = torch.cat([leaves[k].grad.reshape(-1) for k in common])
+    for r in res:
+        g = torch.cat([r["grads"][k].reshape(-1) for k in common])
+        err = float((g - ref).norm() / ref.norm())
+        assert err < 1e-4, err
+        itc = float(S["loss"]["loss_itc"].detach())
+        assert abs(r["losses"][1] - itc) < 1e-5 * max(1.0, abs(itc))
+    assert all(torch.equal(res[0]["grads"][k], res[1]["grads"][k]) for k in common), "ranks disagree after the exchange"
+
+
 _DP2_ITR_SCRIPT = r"""
 import os, sys, json, hashlib, torch
 sys.path.insert(0, os.environ["EVLM_REPO"]); sys.path.insert(0, os.path.join(os.environ["EVLM_REPO"], "tests"))
