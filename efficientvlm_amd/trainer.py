@@ -16,6 +16,8 @@ MI355X-first execution
     segment; a capture that fails on any rank switches every rank to the eager step (same collective sequence).
 """
 import os
+import contextlib
+import gc
 
 import torch
 import torch.distributed as dist
@@ -27,6 +29,24 @@ from .runtime import compute, log_collective
 
 def dist_ready():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+@contextlib.contextmanager
+def no_gc_during_capture():
+    """around a hipGraph capture: the cyclic garbage collector must not run inside it.  A collection that fires during a
+    capture (any allocation can trigger one) may finalise objects of EARLIER work that were only reachable through cycles -
+    a trainer and its hooks, its captured graphs, pinned staging blocks - and their destructors (hipGraphExecDestroy,
+    hipHostFree, frees into another graph's pool) are not permitted while a stream captures: the process aborts
+    (seen once in ~5 runs of the GPU suite, inside TeacherPrefetch's capture after many trainers had come and gone).
+    Everything collectable is collected before the capture starts."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class GradReducer:
@@ -449,7 +469,8 @@ class GDTrainer(_StagedExchange):
                 for k in (0, 1):
                     g = torch.cuda.CUDAGraph()
                     # (thread_local: on multi-GPU runs the RCCL watchdog thread may query events while this captures)
-                    with torch.cuda.graph(g, pool=self._tpool, stream=side, capture_error_mode="thread_local"):
+                    with no_gc_during_capture(), torch.cuda.graph(g, pool=self._tpool, stream=side,
+                                                                  capture_error_mode="thread_local"):
                         self._teacher_eager(pipe, k)
                     ops.flush_table_uploads()
                     tg.append(g)
@@ -569,7 +590,7 @@ class GDTrainer(_StagedExchange):
                 ops.CACHE.invalidate()                             # capture the casts of the trainable weights too
                 ops.reserve_tables()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self._spool):
+                with no_gc_during_capture(), torch.cuda.graph(g, pool=self._spool):
                     res = self._joint_body(pipe, p, pp, pk)
                 ops.flush_table_uploads()
                 self._spool = g.pool()
@@ -688,7 +709,7 @@ class GDTrainer(_StagedExchange):
         cs.wait_stream(cur)
         self._cut = cut
         try:
-            with torch.cuda.stream(cs), torch.autograd.set_multithreading_enabled(False):
+            with no_gc_during_capture(), torch.cuda.stream(cs), torch.autograd.set_multithreading_enabled(False):
                 X.GATHER_HOOK = gather
                 try:
                     begin()
@@ -836,7 +857,7 @@ class GDTrainer(_StagedExchange):
         self.opt.set_schedule(0.0)                         # (the captured optimiser step reads the staged scalars at replay)
         graph = torch.cuda.CUDAGraph()
         pool = next(iter(self._graphs.values()))[0].pool() if self._graphs else None   # the kinds never run concurrently
-        with torch.cuda.graph(graph, pool=pool):
+        with no_gc_during_capture(), torch.cuda.graph(graph, pool=pool):
             out = self._step_eager(static)
         ops.flush_table_uploads()
         # the warm-up advanced Adam's step count and moments: restore them so replay k is optimiser step k
@@ -873,7 +894,7 @@ class TeacherPrefetch:
             st["graphs"] = []
             for k in (0, 1):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.side, capture_error_mode="thread_local"):    # (no shared pool: see the class docstring)
+                with no_gc_during_capture(), torch.cuda.graph(g, stream=self.side, capture_error_mode="thread_local"):    # (no shared pool: see the class docstring)
                     st["T"][k] = self.run_teacher(st["B"][k])
                 st["graphs"].append(g)
             torch.cuda.synchronize()
