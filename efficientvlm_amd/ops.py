@@ -37,7 +37,7 @@ class WeightCache:
         self._store = {}
         self._slab = {}         # id(param) -> [fp32 slab, bf16 slab, offset, numel, version, weakref]
         self._t_units = {}      # (bf16 view pointer, rows, cols) -> (bf16 slab view [N, K], transposed copy [K, N])
-        self._t_table = None    # (device descriptor table, tiles, units) of the grouped transpose launch
+        self._t_tables = {}     # owner (slab pointers | None) -> (device table, tiles, units, unit keys) of a grouped transpose
         self._t_keep = []
         self.epoch = 0          # bump to force a re-cast of trainable weights (e.g. before graph capture)
 
@@ -62,7 +62,6 @@ class WeightCache:
             import weakref
             dst = torch.empty((src.shape[1], src.shape[0]), dtype=torch.bfloat16, device=src.device)
             u = self._t_units[key] = (src, dst, weakref.ref(params[0]))
-            self._t_table = None
             self._t_keep.append(self._transpose([u])[0])
         return u[1]
 
@@ -71,25 +70,38 @@ class WeightCache:
         for src, dst, _ in units:
             rows += [src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], tiles]
             tiles += ((src.shape[0] + 63) // 64) * ((src.shape[1] + 63) // 64)
-        table = torch.tensor(rows, dtype=torch.int64).to(units[0][0].device)
+        table = _upload_table(rows, units[0][0].device)       # (capture-safe: a table may have to be rebuilt inside one)
         L.check(_lib().evlm_transpose_grouped(L.ptr(table), len(units), tiles, L.stream()), "transpose_grouped")
         return table, tiles
 
-    def refresh_transposed(self):
-        """re-derive every W^T copy from the bf16 mirror: ONE grouped launch (capturable: the table is a device tensor)"""
+    def refresh_transposed(self, slabs=None):
+        """re-derive the W^T copies from the bf16 mirror: ONE grouped launch (capturable: the table is a device tensor).
+        slabs (the bf16 parameter slabs of ONE optimiser): only the copies of weights inside them - what a trainer's captured
+        step may bake into its graph.  (One table over every model alive in the process would leave a graph transposing
+        the weights of OTHER models into their copies - freed memory once those models are gone.)"""
         if not self._t_units:
             return
-        if any(u[2]() is None for u in self._t_units.values()):           # models that are gone
-            self._t_units = {k: u for k, u in self._t_units.items() if u[2]() is not None}
-            self._t_table = None
-            if not self._t_units:
-                return
-        if self._t_table is None:
-            units = list(self._t_units.values())
-            self._t_table = self._transpose(units) + (len(units),)
-            self._t_keep.append(self._t_table[0])     # a captured graph may hold an older table: tables are never freed
+        dead = [k for k, u in self._t_units.items() if u[2]() is None]           # models that are gone
+        if dead:
+            for k in dead:
+                del self._t_units[k]
+            self._t_tables = {o: e for o, e in self._t_tables.items() if not (set(e[3]) & set(dead))}
+        units = list(self._t_units.items())
+        okey = None
+        if slabs is not None:
+            spans = [(s.data_ptr(), s.data_ptr() + s.numel() * s.element_size()) for s in slabs if s is not None]
+            units = [(k, u) for k, u in units if any(lo <= u[0].data_ptr() < hi for lo, hi in spans)]
+            okey = tuple(sorted(lo for lo, _ in spans))
+        if not units:
             return
-        table, tiles, n = self._t_table
+        ukeys = tuple(k for k, _ in units)
+        ent = self._t_tables.get(okey)
+        if ent is None or ent[3] != ukeys:
+            table, tiles = self._transpose([u for _, u in units])
+            self._t_tables[okey] = (table, tiles, len(units), ukeys)
+            self._t_keep.append(table)                # a captured graph may hold an older table: tables are never freed
+            return
+        table, tiles, n, _ = ent
         L.check(_lib().evlm_transpose_grouped(L.ptr(table), n, tiles, L.stream()), "transpose_grouped")
 
     # ---- optimiser-owned parameter slabs (optim.FlatAdamW): the bf16 mirror is kept current by the AdamW kernel ----
@@ -100,7 +112,7 @@ class WeightCache:
     def refresh_slab(self, slab32, slab16):
         """re-cast a whole slab (construction; or a parameter was modified outside the optimiser)"""
         L.check(_lib().evlm_cast(L.F32, L.ptr(slab32), L.BF16, L.ptr(slab16), slab32.numel(), L.stream()), "cast")
-        self.refresh_transposed()
+        self.refresh_transposed([slab16])
         for ent in self._slab.values():
             if ent[0] is slab32:
                 pr = ent[5]()

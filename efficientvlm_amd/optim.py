@@ -210,7 +210,8 @@ class FlatAdamW:
                                         g["lr"], b1, b2, self.eps, g["weight_decay"], 1.0, 1.0, L.ptr(self.gnorm_sq),
                                         float(self.max_grad_norm or 0.0), L.ptr(g["pb"]), L.ptr(self.hyper), L.stream()), "adamw")
         ops.CACHE.invalidate()
-        ops.CACHE.refresh_transposed()      # W^T copies of the bf16 mirror (one grouped launch; no-op in fp32 runs)
+        # W^T copies of THIS optimiser's bf16 mirror (one grouped launch; no-op in fp32 runs)
+        ops.CACHE.refresh_transposed([g["pb"] for g in self.groups if g.get("pb") is not None])
 
     def grad_norm(self):
         return self.gnorm_sq.sqrt()
