@@ -506,7 +506,7 @@ def test_two_ranks_train_in_lockstep_through_the_segmented_multi_gpu_step():
     def run(port, eager):
         procs = []
         for rank in (0, 1):
-            env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2")
+            env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", GLOO_SOCKET_IFNAME="lo")
             env.pop("EVLM_FORCE_REDUCE", None)
             if eager:
                 env["EVLM_NO_SEGMENT_GRAPHS"] = "1"
@@ -589,7 +589,7 @@ def test_two_rank_hip_gradients_equal_the_oracles_global_batch_gradient(use_grap
     procs = []
     for rank in (0, 1):
         env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29581" if use_graph else "29583",
-                   RANK=str(rank), WORLD_SIZE="2", EVLM_TEST_OUT=outp, EVLM_TEST_GRAPH=str(int(use_graph)))
+                   RANK=str(rank), WORLD_SIZE="2", GLOO_SOCKET_IFNAME="lo", EVLM_TEST_OUT=outp, EVLM_TEST_GRAPH=str(int(use_graph)))
         env.pop("EVLM_FORCE_REDUCE", None)
         procs.append(subprocess.Popen([sys.executable, "-c", _DP2_ORACLE_SCRIPT], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
@@ -695,7 +695,7 @@ def test_two_ranks_of_the_itr_pruning_step_stay_bit_identical():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     procs = []
     for rank in (0, 1):
-        env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK=str(rank), WORLD_SIZE="2")
+        env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK=str(rank), WORLD_SIZE="2", GLOO_SOCKET_IFNAME="lo")
         env.pop("EVLM_FORCE_REDUCE", None)
         procs.append(subprocess.Popen([sys.executable, "-c", _DP2_ITR_SCRIPT], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
