@@ -406,11 +406,12 @@ def _wgrad(dtype, d2, ldd, x2, ldp, M, K, params, rows, biases=None):
         M0 = M - M % 64
         gw, gb = _wgrad(dtype, d2, ldd, x2, ldp, M0, K, params, rows, biases)
         N = sum(rows)
-        td = torch.zeros((64, N), dtype=d2.dtype, device=d2.device)
-        tx = torch.zeros((64, K), dtype=x2.dtype, device=x2.device)
+        # (leading dimensions padded to 16 bytes: N may be ragged - the 30 522-wide vocabulary head of the VQA decoder)
+        td = torch.zeros((64, _pad8(N)), dtype=d2.dtype, device=d2.device)
+        tx = torch.zeros((64, _pad8(K)), dtype=x2.dtype, device=x2.device)
         tail = lambda t, ld, w: torch.as_strided(t, (M - M0, w), (ld, 1), t.storage_offset() + M0 * ld)
-        td[:M - M0].copy_(tail(d2, ldd, N))
-        tx[:M - M0].copy_(tail(x2, ldp, K))
+        td[:M - M0, :N].copy_(tail(d2, ldd, N))
+        tx[:M - M0, :K].copy_(tail(x2, ldp, K))
         _, gb_t = _wgrad(dtype, td, td.stride(0), tx, tx.stride(0), 64, K, params, rows, biases)
         gb = [a if b is None else (b if a is None else a + b) for a, b in zip(gb, gb_t)]
         return gw, gb

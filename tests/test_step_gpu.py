@@ -1323,8 +1323,8 @@ def test_itr_trainer_with_pipelined_teacher_reproduces_the_unpipelined_trajector
 # ---------------------------------------------------------------------------------------------------------------------
 # full-width steps of BASELINE configs[2] / [3] / [4] (per-GPU shards, long image sequences) against the oracle
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("pipelined", [False, True])
-def test_itr_384_step_full_width_bf16_tracks_the_fp32_oracle(pipelined):
+@pytest.mark.parametrize("pipelined,B", [(False, 8), (True, 8), (True, 64)])
+def test_itr_384_step_full_width_bf16_tracks_the_fp32_oracle(pipelined, B):
     """BASELINE configs[2] on one GPU at full width (`pipelined`: the teacher prefetched one call ahead, the image-map
     distillation then fused into the student's attention kernels and its maps never written): EffXVLMforRetrieval student + base teacher, 384 x 384 images = 577
     image tokens (MFMA attention with 26-tile / long-sequence kernels, ragged weight-gradient reductions 8 x 577), L0 gates
@@ -1334,7 +1334,8 @@ def test_itr_384_step_full_width_bf16_tracks_the_fp32_oracle(pipelined):
     from efficientvlm_amd.models.model_retrieval import XVLM as TeacherITR
     from efficientvlm_amd.trainer import ITRTrainer
     geom = dict(synth.GEOMS["full"], image_res=384)
-    B = 8
+    # (B = 64: the per-GPU batch configs[2] is quoted on - 36 928 image-token rows, multi-round GEMM launches, 768 attention
+    # workgroups per layer; the oracle forward of that batch takes the host about a minute)
     s_cfg, t_cfg = O.model_cfg(geom, "s"), O.model_cfg(geom, "t")
     s_sch = schema.xvlm_schema(s_cfg, geom["max_pos"], mlm=False, bbox=False, l0=True)
     t_sch = schema.xvlm_schema(t_cfg, geom["max_pos"], mlm=False, bbox=False)
@@ -1380,10 +1381,11 @@ def test_itr_384_step_full_width_bf16_tracks_the_fp32_oracle(pipelined):
     assert torch.allclose(got, want, rtol=3e-2, atol=2e-3), (got, want)
 
 
-def test_vqa_480_step_full_width_bf16_tracks_the_fp32_oracle():
+@pytest.mark.parametrize("B", [3, 32])
+def test_vqa_480_step_full_width_bf16_tracks_the_fp32_oracle(B):
     """BASELINE configs[3] on one GPU at full width: 480 x 480 images = 901 image tokens (the two-pass long-sequence dQ
     kernel, K / V taking turns in LDS), causal answer decoder, VQAL0Module gates; VQATrainer step in bf16 against the fp32
-    CPU oracle (reference: Eff_VQA.py:74-200)"""
+    CPU oracle (reference: Eff_VQA.py:74-200).  B = 32: the per-GPU batch configs[3] is quoted on."""
     from efficientvlm_amd.trainer import VQATrainer
     geom = dict(synth.GEOMS["full"], image_res=480)
     student, teacher, s_sd, t_sd, s_cfg, t_cfg = _vqa_models(geom, 51, 52)
@@ -1394,8 +1396,8 @@ def test_vqa_480_step_full_width_bf16_tracks_the_fp32_oracle():
             s_sd["l0_module." + n] = p.detach().clone()
     student.l0_module.set_lagrangian_warmup_steps(10)
     student.to(DEV); teacher.to(DEV)
-    batch = synth.make_vqa_batch(geom, 3, seed=23)
-    batch["image"] = torch.randn(3, 3, 480, 480, generator=gen)
+    batch = synth.make_vqa_batch(geom, B, seed=23)
+    batch["image"] = torch.randn(B, 3, 480, 480, generator=gen)
     tr = VQATrainer(student, teacher, lr=5e-5, reg_learning_rate=0.05, dtype=torch.bfloat16)
     eps = {t: torch.rand(s_sd["l0_module." + O.L0_PARAM[t]].shape, generator=gen).clamp(1e-6, 1 - 1e-6) for t in O.L0_TYPES_VQA}
     student.l0_module.injected_eps = {t: e.clone() for t, e in eps.items()}
