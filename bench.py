@@ -405,8 +405,11 @@ def main():
                                       "teacher fwd, ITC+ITM+MLM + hidden/attention/logit KD, grad all-reduce, clip 1.0, AdamW",
                           "image": "224x224", "text_len": geom["L"], "masked": geom["M"], "batch_per_gpu": B,
                           "global_batch": B * world, "parallelism": f"dp{world}",
-                          "launch": "eager" if (args.no_graph or force_dp) else
-                                    ("hipGraph segments around the collectives" if world > 1 else "hipGraph replay")
+                          # (what the trainer actually replayed: a failed segment capture falls back to the eager step)
+                          "launch": ("hipGraph segments around the collectives"
+                                     if (getattr(trainer, "_seg", None) and not getattr(trainer, "_segments_broken", False))
+                                     else "hipGraph replay" if (getattr(trainer, "_joint", None) or getattr(trainer, "_graphs", None))
+                                     else "eager")
                                     + (" [DRY RUN: ranks share one GPU, gloo]" if os.environ.get("EVLM_BENCH_SHARE_GPU") else ""),
                           "teacher_pipelined": pipelined, "distinct_batches": 4,
                           "init": "random (reference init), no checkpoints"},
