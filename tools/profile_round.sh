@@ -20,4 +20,7 @@ rm -rf $OUT/pf $OUT/pw
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pm -o pm -- $P > $OUT/pm.log 2>&1
 python3 tools/pmc_mfma.py $OUT/pm/pm_results.db $OUT/pmc_mfma.json > $OUT/pmc_mfma.txt 2>&1
 rm -rf $OUT/pm
+python3 tools/xattn_bench.py 2>&1 | grep composite_us > $OUT/xattn_bench.jsonl
+python3 tools/gemm_bench.py --lib 2>&1 | grep -v amdgpu.ids > $OUT/gemm_vs_library.txt
+python3 tools/find_small_ops.py 2>&1 | grep -v amdgpu.ids > $OUT/aten_launching_calls.txt
 ls -la $OUT
