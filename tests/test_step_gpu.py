@@ -713,6 +713,69 @@ def test_two_ranks_of_the_itr_pruning_step_stay_bit_identical():
     assert res[0]["digest"] == res[1]["digest"]
 
 
+_DP2_VQA_SCRIPT = r"""
+import os, sys, json, hashlib, torch
+sys.path.insert(0, os.environ["EVLM_REPO"]); sys.path.insert(0, os.path.join(os.environ["EVLM_REPO"], "tests"))
+import torch.distributed as dist
+from oracle import synth
+from oracle import xvlm_oracle as O
+from test_step_gpu import _vqa_models
+from efficientvlm_amd.trainer import VQATrainer
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=2)
+geom = synth.GEOMS["tiny"]
+student, teacher, *_ = _vqa_models(geom, 51 + 9 * rank, 52)
+gen = torch.Generator().manual_seed(4 + rank)
+with torch.no_grad():
+    for n, p in student.l0_module.named_parameters():
+        p.copy_(torch.full_like(p, 0.3) if "lambda" in n else torch.randn(p.shape, generator=gen) + 0.5)
+student.l0_module.set_lagrangian_warmup_steps(10)
+student.cuda(); teacher.cuda()
+tr = VQATrainer(student, teacher, lr=1e-3, reg_learning_rate=0.05, dtype=torch.float32)
+assert tr.reducer.active and tr.reducer.world == 2
+out = []
+for c in range(4):
+    batch = {k: v.cuda() for k, v in synth.make_vqa_batch(geom, 4, seed=21 + c + 30 * rank).items()}
+    student.l0_module.injected_eps = {t: torch.rand(getattr(student.l0_module, O.L0_PARAM[t]).shape, generator=gen).clamp(1e-6, 1 - 1e-6)
+                                      for t in O.L0_TYPES_VQA}
+    out.append(tr.step(batch).tolist())
+torch.cuda.synchronize()
+h = hashlib.sha256()
+for k, v in sorted(student.state_dict().items()):
+    h.update(v.detach().float().cpu().numpy().tobytes())
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps({"rank": rank, "out": out, "digest": h.hexdigest()}))
+"""
+
+
+def test_two_ranks_of_the_vqa_pruning_step_stay_bit_identical():
+    """the VQA pruning fine-tune (VQATrainer: causal answer decoder, VQAL0Module gates, three optimisers) on TWO ranks - two
+    processes on the one GPU, gloo; differently built students levelled by the broadcast, rank-specific batches and gate
+    noise: after four optimiser steps every student tensor is bit-identical on the two ranks"""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29579", RANK=str(rank), WORLD_SIZE="2", GLOO_SOCKET_IFNAME="lo")
+        env.pop("EVLM_FORCE_REDUCE", None)
+        procs.append(subprocess.Popen([sys.executable, "-c", _DP2_VQA_SCRIPT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    res = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung (collective sequences of the two ranks differ?)")
+        assert p.returncode == 0, se[-3000:]
+        res.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    assert len(res[0]["out"]) == 4 and np.isfinite(np.array(res[0]["out"])).all()
+    assert res[0]["digest"] == res[1]["digest"]
+
+
 _DP_SEQ_SCRIPT = r"""
 import os, sys, json, torch
 sys.path.insert(0, os.environ["EVLM_REPO"]); sys.path.insert(0, os.path.join(os.environ["EVLM_REPO"], "tests"))
