@@ -463,15 +463,18 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     return;
   }
   if (threadIdx.x == 0) {
-    atomicExch(ws + 2 + blockIdx.x, s);                       // (device-scope: visible to whichever block arrives last)
-    __threadfence();
-    last = atomicAdd(reinterpret_cast<unsigned int*>(ws), 1u) == gridDim.x - 1;
+    // no fence (a device-scope release writes the L2 back: ~25 us over a thousand blocks): the partial goes out as a
+    // RETURNING device-scope atomic - performed at the coherence point before its value comes back - and only then the
+    // arrival count moves; the last arriver reads the partials with device-scope loads
+    const float old = __hip_atomic_exchange(ws + 2 + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" :: "v"(old) : "memory");
+    last = __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(ws), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;
-  __threadfence();
   float t = 0.f;
-  for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) t += atomicAdd(ws + 2 + b, 0.f);   // coherent read
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x)      // device-scope loads (past this CU's caches), all in flight
+    t += __hip_atomic_load(ws + 2 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   t = block_sum(t, red);
   if (threadIdx.x == 0) {
     *out += t;                                                // single writer; launches of a stream run in order
@@ -482,7 +485,8 @@ extern "C" int evlm_sumsq(const float* x, int64_t n, float* out, float* workspac
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(x && out && n > 0, "evlm_sumsq: bad args");
   EVLM_REQUIRE(((uintptr_t)x) % 16 == 0, "evlm_sumsq: x must be 16-byte aligned");
-  const int grid = imin(EVLM_SUMSQ_WORKSPACE_FLOATS - 2, (n / 4 + 255) / 256 + 1);
+  static const int cap = getenv("EVLM_SUMSQ_BLOCKS") ? atoi(getenv("EVLM_SUMSQ_BLOCKS")) : 1024;    // (tuning aid)
+  const int grid = imin(imin(cap, EVLM_SUMSQ_WORKSPACE_FLOATS - 2), (n / 4 + 255) / 256 + 1);
   hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, stream, x, n, out, workspace);
   EVLM_LAUNCH_CHECK("evlm_sumsq");
   return 0;

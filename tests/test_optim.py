@@ -120,6 +120,30 @@ def test_flat_adamw_kernels_match_the_oracle():
 
 
 @pytest.mark.gpu
+def test_sum_of_squares_with_a_workspace_is_bit_reproducible():
+    """evlm_sumsq with its workspace (ABI 5): block partials summed in a fixed order by the last block to arrive - the same
+    bits on every launch (data-parallel replicas clip by bit-identical factors), equal to the fp64 sum to fp32 accuracy;
+    2 000 launches over slabs of several sizes (multi-block, one block, ragged tail), any lost or stale partial would show"""
+    from efficientvlm_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    ws = torch.zeros(2050, dtype=torch.float32, device="cuda")
+    for n in (23_835_648, 741_888, 1_000_003, 515):
+        x = (torch.randn(n, generator=g) * 0.3).cuda()
+        out = torch.zeros(1, device="cuda")
+        vals = torch.empty(500, device="cuda")
+        for i in range(500):
+            out.zero_()
+            L.check(lib.evlm_sumsq(L.ptr(x), n, L.ptr(out), L.ptr(ws), L.stream()), "sumsq")
+            vals[i:i + 1].copy_(out)
+        torch.cuda.synchronize()
+        assert bool((vals == vals[0]).all()), (n, vals.unique())
+        ref = float((x.double() ** 2).sum())
+        assert abs(float(vals[0]) - ref) < 2e-6 * ref, (n, float(vals[0]), ref)
+        assert float(ws[0]) == 0.0                      # the arrival counter is back to zero
+
+
+@pytest.mark.gpu
 def test_flat_adamw_reference_style_loop_without_scheduler_calls():
     """optimizer.step() with no set_schedule() in between (the reference's loop shape, GeneralDistill.py:385-387 with a
     constant factor): the step count and Adam's bias corrections still advance - three steps against the oracle - and a

@@ -14,8 +14,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--only", default="", help="J, S or T: that run alone (for a kernel trace)")
+ap.add_argument("--dp", action="store_true", help="the N > 1 code path (hipGraph segments, one-rank RCCL group) instead of the joint graph")
 args = ap.parse_args()
 torch.cuda.set_device(0)
+if args.dp:
+    import torch.distributed as dist
+    os.environ["EVLM_FORCE_REDUCE"] = "1"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29563")
+    dist.init_process_group("nccl", rank=0, world_size=1)
 geom = GEOMS["full"]; dev = torch.device("cuda", 0)
 batches = [{k: v.to(dev) for k, v in make_batch(geom, 64, seed=42 + 1000 * i).items()} for i in range(4)]
 
@@ -38,6 +44,8 @@ def run(tag, patch=None):
 
 def no_teacher(tr):
     tr._teacher_eager = lambda pipe, k: None
+    tr._teacher_begin = lambda pipe, k: None
+    tr._teacher_finish = lambda st, pipe, k: None
 
 
 def no_student(tr):
