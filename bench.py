@@ -410,6 +410,13 @@ def main():
                                      if (getattr(trainer, "_seg", None) and not getattr(trainer, "_segments_broken", False))
                                      else "hipGraph replay" if (getattr(trainer, "_joint", None) or getattr(trainer, "_graphs", None))
                                      else "eager")
+                                    # (which branch of the gradient exchange ran: GradReducer probes the grouped launch at
+                                    # construction and the ranks agree on it)
+                                    + (f"; gradient exchange: SUM all-reduce of loss-prescaled fp32 slabs, "
+                                       f"{trainer.reducer.launch} launch per stage, "
+                                       f"{'bf16' if trainer.reducer.compress is not None else 'fp32'} wire, "
+                                       f"{len(trainer._stages)} stages overlapped with backward"
+                                       if trainer.reducer.active else "")
                                     + (" [DRY RUN: ranks share one GPU, gloo]" if os.environ.get("EVLM_BENCH_SHARE_GPU") else ""),
                           "teacher_pipelined": pipelined, "distinct_batches": 4,
                           "init": "random (reference init), no checkpoints"},

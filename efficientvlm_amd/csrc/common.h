@@ -196,6 +196,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int imin(int64_t a, int64_t b) { return (int)(a < b ? a : b); }
+static inline int imax(int64_t a, int64_t b) { return (int)(a > b ? a : b); }
 
 // run `body<T>` for the runtime dtype
 #define EVLM_DISPATCH_DTYPE(dt, NAME, ...)                        \

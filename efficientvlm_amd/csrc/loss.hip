@@ -485,7 +485,7 @@ extern "C" int evlm_sumsq(const float* x, int64_t n, float* out, float* workspac
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(x && out && n > 0, "evlm_sumsq: bad args");
   EVLM_REQUIRE(((uintptr_t)x) % 16 == 0, "evlm_sumsq: x must be 16-byte aligned");
-  static const int cap = getenv("EVLM_SUMSQ_BLOCKS") ? atoi(getenv("EVLM_SUMSQ_BLOCKS")) : 1024;    // (tuning aid)
+  static const int cap = getenv("EVLM_SUMSQ_BLOCKS") ? imax(1, atoi(getenv("EVLM_SUMSQ_BLOCKS"))) : 1024;    // (tuning aid)
   const int grid = imin(imin(cap, EVLM_SUMSQ_WORKSPACE_FLOATS - 2), (n / 4 + 255) / 256 + 1);
   hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, stream, x, n, out, workspace);
   EVLM_LAUNCH_CHECK("evlm_sumsq");

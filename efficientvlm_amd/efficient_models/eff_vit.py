@@ -111,7 +111,11 @@ class CLIPAttention(nn.Module):
             # (the map itself is materialised only when the caller wants it: the kernels compare the probabilities with the
             # teacher's in registers, and the backward rebuilds them from Q and K)
             out, probs, kd = ops.self_attention(qkv, self.num_heads, self.head_dim, self.scale, mask=mask2d, gate=head_z,
-                                                want_probs=bool(output_attentions) or not ops.attention_recomputes(qkv, self.head_dim, tgt_len),
+                                                # (no lse exists without a backward: a no_grad forward with a teacher map -
+                                                # a validation-loss pass - takes the stored-map form of the term)
+                                                want_probs=bool(output_attentions) or not (
+                                                    torch.is_grad_enabled() and qkv.requires_grad
+                                                    and ops.attention_recomputes(qkv, self.head_dim, tgt_len)),
                                                 kd_teacher=kd_teacher,
                                                 kd_weight=float(tgt_len) if kd_word is None else ops.KdSlot(kd_word, tgt_len))
             out = ops.linear(out, self.out_proj.weight, self.out_proj.bias, residual=residual)

@@ -125,8 +125,11 @@ class XVLM(XVLMBase):
             return core(torch.cat([text_ids, text_ids_masked], 0), attention_mask=torch.cat([text_atts, text_atts], 0),
                         return_dict=True, mode="text", output_attentions=True, output_hidden_states=True)
         # extension: the text pass is independent of the image encoder until the ITC features - with `text_stream` set
-        # (single-GPU trainers) it is issued on that stream BESIDE the image encoder: its ~25 small launches (and, since
-        # autograd runs a node on its forward's stream, their backward) share the chip with the ViT's large products
+        # (single-GPU trainers) it is issued on that stream BESIDE the image encoder: its ~25 small FORWARD launches share
+        # the chip with the ViT's large products.  (Autograd runs a node on its forward's stream, so the backward of the
+        # text pass is issued on that stream too - but its nodes were created before the ViT's and the engine runs later
+        # nodes first, so they reach the device behind the whole ViT backward: no overlap there.  The trainer joins the
+        # stream explicitly before it reads the gradients: GDTrainer._join_text_stream.)
         side = self.text_stream if (self.text_stream is not None and image.is_cuda) else None
         t = None
         if side is not None:

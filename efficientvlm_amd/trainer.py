@@ -52,17 +52,25 @@ def no_gc_during_capture():
 class GradReducer:
     """mean all-reduce of flat gradient slabs in <= bucket_bytes pieces on a dedicated stream.
 
-    Works on any backend (RCCL on GPU, gloo in the CPU tests).  The wire carries fp32 by default - what the reference's
-    DDP wrappers reduce (apex_ddp_accelerator.py:87, Eff_Retrieval.py:449).  `compress` = torch.bfloat16 is an OPT-IN that
-    halves the wire bytes (the slabs stay fp32: divide by world in fp32 -> cast -> sum all-reduce -> cast back); its error
-    against the fp32 wire is bounded in tests/test_dp_cpu.py.
+    ONE arithmetic on every backend (RCCL on GPU, gloo in the CPU / two-ranks-on-one-GPU tests): the collective is always
+    a SUM.  The mean's 1 / world is applied
+      * by the CALLER at the source when `prescaled` (the trainers: `scale_loss(total).backward()` - backward then produces
+        gradient / world, no pass over the slabs at all; world sizes are powers of two, so the scaling is exact), or
+      * by one in-place multiply of the ranges before they travel otherwise (the generic `reduce()` of the tests).
+    No ReduceOp.AVG: RCCL's averaging collective was a branch only a real multi-GPU run could reach.
+    The wire carries fp32 by default - what the reference's DDP wrappers reduce (apex_ddp_accelerator.py:87,
+    Eff_Retrieval.py:449).  `compress` = torch.bfloat16 is an OPT-IN that halves the wire bytes (the slabs stay fp32:
+    cast -> sum all-reduce -> cast back); its error against the fp32 wire is bounded in tests/test_dp_cpu.py.
 
     Overlap with backward: the slab ranges of a layer group are handed to `reduce_async` the moment backward has
     finished with the group (GDTrainer: tensor hooks in the eager step, cuts between hipGraph segments in the captured
     one); the collectives run on the side stream under the rest of backward, `finish()` joins them before the optimiser.
-    Few, large messages: xGMI is point-to-point, rings are per-link bound."""
+    Few, large messages: xGMI is point-to-point, rings are per-link bound.  The ranges of one stage go out as ONE grouped
+    launch where the backend can coalesce device tensors (`launch` = "coalesced"); that private torch API is PROBED once at
+    construction and the ranks agree on the outcome (MIN), so a refusal anywhere puts every rank on plain per-range async
+    all-reduces (`launch` = "per-range") - never a mixed collective sequence."""
 
-    def __init__(self, flat_grads, bucket_bytes=64 << 20, compress=None, group=None, force=False):
+    def __init__(self, flat_grads, bucket_bytes=64 << 20, compress=None, group=None, force=False, prescaled=False):
         self.flat = list(flat_grads)
         self.group = group
         self.compress = compress
@@ -70,15 +78,42 @@ class GradReducer:
         ready = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if ready else 1
         self.active = self.world > 1 or (force and ready)
-        # RCCL averages in the collective itself (one pass over the slabs less); gloo has no AVG
-        self.native_avg = bool(ready and dist.get_backend(group) == "nccl" and hasattr(dist.ReduceOp, "AVG"))
-        # (gloo coalesces host tensors only: device slabs over gloo - the two-ranks-on-one-GPU test - go one by one)
-        on_gpu = bool(self.flat and self.flat[0].is_cuda)
-        self.coalesce = (hasattr(dist, "_coalescing_manager") and not os.environ.get("EVLM_NO_COALESCE")
-                         and (self.native_avg or not on_gpu))
+        self.prescaled = prescaled
         self.buckets = self._buckets(self.flat)
         self.stream = torch.cuda.Stream() if (self.flat and self.flat[0].is_cuda) else None
         self._pending = []
+        self.coalesce = self.active and self._probe_coalescing()
+        self.launch = "coalesced" if self.coalesce else "per-range"
+
+    def scale_loss(self, total):
+        """the mean's 1 / world at the source: backward of the returned scalar leaves gradient / world in the slabs"""
+        if not (self.active and self.prescaled) or self.world == 1:
+            return total
+        return total * (1.0 / self.world)
+
+    def _probe_coalescing(self):
+        """can this process group coalesce all-reduces of device (or host) tensors?  Tried once on two one-element tensors;
+        every rank then takes the MINIMUM of the outcomes (a plain all-reduce - the collective every backend has)."""
+        ok = hasattr(dist, "_coalescing_manager") and not os.environ.get("EVLM_NO_COALESCE")
+        dev = self.flat[0].device if self.flat else torch.device("cpu")
+        if ok:
+            try:
+                # (gloo coalesces host tensors only: device slabs over gloo - the two-ranks-on-one-GPU tests - go one by one)
+                if dev.type == "cuda" and dist.get_backend(self.group) != "nccl":
+                    raise RuntimeError("backend cannot coalesce device tensors")
+                a, b = torch.ones(1, device=dev), torch.ones(1, device=dev)
+                with dist._coalescing_manager(self.group, async_ops=True) as cm:
+                    dist.all_reduce(a, op=dist.ReduceOp.SUM, group=self.group)
+                    dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+                cm.wait()
+                if dev.type == "cuda":
+                    torch.cuda.synchronize()
+                ok = bool(a.item() == self.world and b.item() == self.world)
+            except Exception:                      # any refusal: AttributeError / NotImplementedError / RuntimeError ...
+                ok = False
+        flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item() > 0.5)
 
     def _buckets(self, tensors):
         out = []
@@ -96,23 +131,14 @@ class GradReducer:
             self.stream.wait_stream(torch.cuda.current_stream())
             ctx = torch.cuda.stream(self.stream)
         else:
-            import contextlib
             ctx = contextlib.nullcontext()
         with ctx:
             buckets = self._buckets(tensors)
-            wire = buckets
-            if self.compress is not None:
-                wire = []
+            if not self.prescaled and self.world > 1:
                 for b in buckets:
-                    b.mul_(1.0 / self.world)                  # the mean's division in fp32, before the cast
-                    wire.append(b.to(self.compress))
-                op = dist.ReduceOp.SUM
-            elif self.native_avg:
-                op = dist.ReduceOp.AVG
-            else:
-                for b in buckets:
-                    b.div_(self.world)
-                op = dist.ReduceOp.SUM
+                    b.mul_(1.0 / self.world)                  # the mean's division, in fp32, before anything travels
+            wire = buckets if self.compress is None else [b.to(self.compress) for b in buckets]
+            op = dist.ReduceOp.SUM
             for w in wire:
                 log_collective("all_reduce", w)
             if self.coalesce and len(wire) > 1:
@@ -294,7 +320,7 @@ class GDTrainer(_StagedExchange):
         force = bool(os.environ.get("EVLM_FORCE_REDUCE"))
         if grad_compress is None and dtype == torch.bfloat16 and os.environ.get("EVLM_BF16_WIRE"):
             grad_compress = torch.bfloat16           # opt-in: bf16 on the wire (default: fp32, as the reference's DDP)
-        self.reducer = GradReducer(self.opt.flat_grads, compress=grad_compress, force=force)
+        self.reducer = GradReducer(self.opt.flat_grads, compress=grad_compress, force=force, prescaled=True)
         self.world = self.reducer.world
         # gradient exchange overlapped with backward: install_grad_stages (stages sent from hooks / capture cut there)
         self._stages, self._sent, self._cut = [list(self.opt.flat_grads)], 0, None
@@ -363,7 +389,9 @@ class GDTrainer(_StagedExchange):
             ops.WGRAD_DEFER = [] if (self.wgrad_inplace and self.defer_wgrad) else None   # ... dW products grouped per K
             ops.WGRAD_ASSIGN = self._assign
             try:
-                total.backward()
+                # (multi-GPU: the mean's 1 / world enters here, the all-reduces are plain sums)
+                self.reducer.scale_loss(total).backward()
+                self._join_text_stream()
                 ops.flush_wgrad()
                 ops.finish_assign()
             finally:
@@ -379,6 +407,16 @@ class GDTrainer(_StagedExchange):
         return torch.stack([total.detach().float(), S["loss"]["loss_itc"].detach().float(),
                             S["loss"]["loss_itm"].detach().float(), S["loss"]["loss_mlm"].detach().float(),
                             mix["loss_kd"].detach().float()])
+
+    def _join_text_stream(self):
+        """single GPU: the student's text pass ran on student.text_stream, so autograd ran its backward there too (the
+        in-place word-embedding gradient, the queued dY / X of the deferred weight gradients, the MSE backward).  Join that
+        stream explicitly before anything reads the slabs - not left to autograd's AccumulateGrad / end-of-backward stream
+        syncs, which only order it as long as some gradient of that pass is accumulated out of place.  Valid inside a
+        hipGraph capture (an event wait between two streams of the capture)."""
+        ts = getattr(self.student, "text_stream", None)
+        if ts is not None:
+            torch.cuda.current_stream().wait_stream(ts)
 
     def _on_vision_grad(self):
         """tensor hook on the ViT output (backward is about to enter the image encoder): a side-stream teacher forward that
@@ -755,11 +793,17 @@ class GDTrainer(_StagedExchange):
             err = None
             try:
                 sg = self._capture_segments(tpipe, tp, pipe, k)
-            except RuntimeError as e:             # a capture this stack refuses
-                err, sg = e, None
-                torch.cuda.synchronize()
+            except Exception as e:                # a capture this stack refuses (RuntimeError) - or ANY other failure of
+                err, sg = e, None                 # the capture pass: every rank must still reach the agreement round
+                try:                              # below, or its peers wait in that all-reduce until the RCCL timeout
+                    torch.cuda.synchronize()
+                except RuntimeError:
+                    pass
             self.opt._scheduled = scheduled              # the captured optimiser step consumed the flag, not the schedule
-            if not self._ranks_agree(sg is not None):
+            agreed = self._ranks_agree(sg is not None)
+            if err is not None and not isinstance(err, RuntimeError):
+                raise err                         # a bug, not a refusal: surfaced - after the peers have been told
+            if not agreed:
                 import sys
                 print(f"[efficientvlm_amd] hipGraph segments of the multi-GPU student step failed "
                       f"({err if err is not None else 'on another rank'}); the student step stays eager on every rank",
@@ -944,7 +988,7 @@ class ITRTrainer(_StagedExchange):
         teacher.eval()
         student.train()
         self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=0.0)
-        self.reducer = GradReducer(self.opt.flat_grads)
+        self.reducer = GradReducer(self.opt.flat_grads, prescaled=True)
         self._stages, self._sent = [list(self.opt.flat_grads)], 0
         if self.reducer.active:
             broadcast_parameters(self.opt)      # gates and multipliers included: they are members of the main groups
@@ -999,7 +1043,7 @@ class ITRTrainer(_StagedExchange):
             ops.WGRAD_DEFER = [] if self.defer_wgrad else None
             self._sent = 0
             try:
-                total.backward()                 # (multi-GPU: the gradient stages leave from hooks inside it)
+                self.reducer.scale_loss(total).backward()   # (multi-GPU: the gradient stages leave from hooks inside it)
                 ops.flush_wgrad()
             finally:
                 ops.WGRAD_INPLACE = False
@@ -1035,7 +1079,7 @@ class VQATrainer(_StagedExchange):
         teacher.eval()
         student.train()
         self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=0.0)
-        self.reducer = GradReducer(self.opt.flat_grads)
+        self.reducer = GradReducer(self.opt.flat_grads, prescaled=True)
         self._stages, self._sent = [list(self.opt.flat_grads)], 0
         if self.reducer.active:
             broadcast_parameters(self.opt)      # gates and multipliers included: they are members of the main groups
@@ -1092,7 +1136,7 @@ class VQATrainer(_StagedExchange):
             ops.WGRAD_DEFER = [] if self.defer_wgrad else None
             self._sent = 0
             try:
-                total.backward()                 # (multi-GPU: the gradient stages leave from hooks inside it)
+                self.reducer.scale_loss(total).backward()   # (multi-GPU: the gradient stages leave from hooks inside it)
                 ops.flush_wgrad()
             finally:
                 ops.WGRAD_INPLACE = False

@@ -129,17 +129,22 @@ def test_sum_of_squares_with_a_workspace_is_bit_reproducible():
     g = torch.Generator().manual_seed(3)
     ws = torch.zeros(2050, dtype=torch.float32, device="cuda")
     for n in (23_835_648, 741_888, 1_000_003, 515):
-        x = (torch.randn(n, generator=g) * 0.3).cuda()
+        # launches ALTERNATE between two slabs with different partial sums: a partial left over from the previous launch
+        # (a stale read by the last block to arrive - the hazard of the fence-free hand-off) would change the odd or the
+        # even results; with one slab it would carry the same value and go unseen
+        xs = [(torch.randn(n, generator=g) * 0.3).cuda(), (torch.randn(n, generator=g) * 0.7).cuda()]
         out = torch.zeros(1, device="cuda")
         vals = torch.empty(500, device="cuda")
         for i in range(500):
             out.zero_()
-            L.check(lib.evlm_sumsq(L.ptr(x), n, L.ptr(out), L.ptr(ws), L.stream()), "sumsq")
+            L.check(lib.evlm_sumsq(L.ptr(xs[i & 1]), n, L.ptr(out), L.ptr(ws), L.stream()), "sumsq")
             vals[i:i + 1].copy_(out)
         torch.cuda.synchronize()
-        assert bool((vals == vals[0]).all()), (n, vals.unique())
-        ref = float((x.double() ** 2).sum())
-        assert abs(float(vals[0]) - ref) < 2e-6 * ref, (n, float(vals[0]), ref)
+        for par in (0, 1):
+            v = vals[par::2]
+            assert bool((v == v[0]).all()), (n, par, v.unique())
+            ref = float((xs[par].double() ** 2).sum())
+            assert abs(float(v[0]) - ref) < 2e-6 * ref, (n, par, float(v[0]), ref)
         assert float(ws[0]) == 0.0                      # the arrival counter is back to zero
 
 

@@ -834,6 +834,63 @@ def test_segmented_and_eager_multi_gpu_steps_issue_the_same_collective_sequence(
         assert sum(n for _, n, _ in a[1:]) == seg["slab"]
 
 
+_DP_BRANCH_SCRIPT = r"""
+import os, sys, json, torch
+sys.path.insert(0, os.environ["EVLM_REPO"]); sys.path.insert(0, os.path.join(os.environ["EVLM_REPO"], "tests"))
+import torch.distributed as dist
+from oracle import synth
+from test_step_gpu import build_gd
+from efficientvlm_amd import ops, runtime
+from efficientvlm_amd.trainer import GDTrainer
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+geom = synth.GEOMS["tiny"]
+res = {}
+for name, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+    student, teacher = build_gd(geom, 11)
+    neg = torch.tensor([1, 2, 3, 0, 2, 3, 0, 1])
+    student.injected_neg_idx = teacher.injected_neg_idx = neg
+    student.keep_injected_neg = teacher.keep_injected_neg = True
+    tr = GDTrainer(student, teacher, dtype=dtype, use_graph=False)
+    batch = {k: v.cuda() for k, v in synth.make_batch(geom, 4, seed=3).items()}
+    slabs = []
+    for world in (1, 2):
+        tr.reducer.world = world          # what a two-rank group would make of the loss scale (the collective stays real)
+        tr.opt.set_schedule(0.0)
+        runtime.COLLECTIVES = []
+        tr.step(batch)
+        torch.cuda.synchronize()
+        slabs.append(torch.cat([g.clone() for g in tr.opt.flat_grads]))
+    res[name] = {"launch": tr.reducer.launch, "prescaled": tr.reducer.prescaled,
+                 "ops": sorted({k for k, _, _ in runtime.COLLECTIVES}),
+                 "half_err": float((slabs[1] * 2 - slabs[0]).norm() / slabs[0].norm()),
+                 "nonzero": float(slabs[0].abs().sum()) > 0}
+runtime.COLLECTIVES = None
+dist.destroy_process_group()
+print("RESULT " + json.dumps(res))
+"""
+
+
+def test_rccl_branch_of_the_gradient_exchange_on_a_one_rank_group():
+    """The shipping N > 1 branch of GradReducer, selected on a REAL RCCL group (one rank - all a one-GPU box offers): the
+    grouped (coalesced) launch is probed at construction and used, the collective is a plain SUM (no ReduceOp.AVG, no
+    division pass), and the mean's 1 / world is applied at the source: with the reducer told the world is 2, one eager
+    step leaves HALF the gradient in the slabs (fp32 and bf16 compute; every backward kernel - the fused map-distillation
+    terms inside the attention kernels, the deferred grouped weight gradients, the in-place embedding / LayerNorm / bias
+    sums - is linear in the upstream scale, and a power-of-two scale is exact: what is left between the two runs is the
+    order of the f32 atomics of the in-place sums, 1e-6)"""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551", EVLM_FORCE_REDUCE="1")
+    r = subprocess.run([sys.executable, "-c", _DP_BRANCH_SCRIPT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    for name in ("f32", "bf16"):
+        assert res[name]["launch"] == "coalesced" and res[name]["prescaled"], res
+        assert res[name]["ops"] == ["all_gather", "all_reduce"], res
+        assert res[name]["half_err"] < 2e-6 and res[name]["nonzero"], res
+
+
 @pytest.mark.parametrize("geom_name,B", [("full", 64), ("tiny", 5)])
 def test_first_touch_assignment_of_weight_gradients_equals_zero_fill_plus_accumulate(geom_name, B, monkeypatch):
     """ops.WGRAD_ASSIGN (the Linear weights' slab ranges are not zero-filled; the first grouped dY^T X product of a weight
