@@ -16,6 +16,7 @@ struct MAttnF {
   int causal;
   const bf16* Pt; float* kd; float kd_coef;      // fused map distillation: *kd += kd_coef * sum((P - Pt)^2)
   float* lse;                                    // [B, H, Lq] log2-sum-exp of the scaled, masked scores (recomputing backward)
+  float* rkd;                                    // [B, H, Lq] sum_k P (P - Pt) of the fused distillation (one-pass long backward)
 };
 
 #define DH 64
@@ -181,18 +182,27 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   float sq = 0.f;
   if (LSE && a.Pt && qok) {
     const bf16* Tr = a.Pt + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr;
-#pragma unroll
+    float rk = 0.f;                                       // sum_k p (p - pt): the distillation term's share of the
+#pragma unroll                                            // backward's row sum delta (one-pass long-sequence backward)
     for (int s = 0; s < NT / 2; ++s) {
       const int kcol = s * 32 + g * 8;
       if (kcol < a.ldpr) {
         const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(Tr + kcol);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float d0 = acc[2 * s][r] * inv - (float)t8[r], d1 = acc[2 * s + 1][r] * inv - (float)t8[4 + r];
+          const float p0 = acc[2 * s][r] * inv, p1 = acc[2 * s + 1][r] * inv;
+          const float d0 = p0 - (float)t8[r], d1 = p1 - (float)t8[4 + r];
           sq = fmaf(d0, d0, sq);
           sq = fmaf(d1, d1, sq);
+          rk = fmaf(p0, d0, rk);
+          rk = fmaf(p1, d1, rk);
         }
       }
+    }
+    if (a.rkd) {
+      rk += __shfl_xor(rk, 16, 64);
+      rk += __shfl_xor(rk, 32, 64);
+      if (g == 0) a.rkd[((size_t)b * a.H + h) * a.Lq + q] = rk;
     }
   }
   // P (bf16): 4 consecutive keys per lane per tile -> 8-byte stores; also the PV B operand
@@ -446,6 +456,9 @@ struct MAttnB {
   // recomputing form (RC kernels): P = 2^(s - lse) rebuilt in fp32 from Q, K, the forward's mask / causal flag; Pw = bf16
   // copy of it for kernel B of the two-kernel path (NULL in the single-pass kernel)
   const float* lse; const float* mask; int causal; bf16* Pw;
+  // one-pass form of the long-sequence kernel: delta = rowsum(P .* dP) = dO . O + kd_coef * g * rkd (O: the forward's
+  // output, gate included; rkd: the forward's sum_k P (P - Pt)), so no first pass over the keys is needed for it
+  const bf16* O; const float* rkd;
 };
 
 // mask row of one (batch): Ms[k] = additive mask of key k (0 without one), -1e30 beyond Lk - as the forward kernel builds it
@@ -655,10 +668,30 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
   f32x4 o[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // ONE-PASS form (recomputing, no external dP, the forward's O - and its rkd with a fused distillation term - at hand):
+  //   delta = sum_k p (gz dpo + kdc (p - pt)) = dO . O + kdc * rkd      (O = gz * sum_k p V_k, as stored by the forward)
+  // so pass 0 - a second score product, exponentials and a dP product per key just for this row sum - is not run; the gate
+  // gradient's sum_k p dpo is collected in the one pass that remains.  (Wave-uniform: kernel arguments only.)
+  const bool one_pass = RC && a.O != nullptr && a.E == nullptr && (a.Pt == nullptr || a.rkd != nullptr);
+  if (one_pass) {
+    float d = 0.f;
+    if (qok) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const uint4 v = *reinterpret_cast<const uint4*>(a.O + ((size_t)b * a.Lq + q) * a.ldo + h * DH + ks * 32 + g * 8);
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(&v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf((float)of[e], (float)dof[ks][e], d);
+      }
+    }
+    d += __shfl_xor(d, 16, 64); d += __shfl_xor(d, 32, 64);
+    dsum = d;
+    if (a.Pt && qok) dsum = fmaf(kdc, a.rkd[((size_t)b * a.H + h) * a.Lq + q], dsum);
+  }
   // stored-map form: pass 0 over all keys out of the one V tile staged above, then pass 1 per key half (V_h | K_h);
   // recomputing form: BOTH passes per key half (the scores need K_h beside V_h): pass 0 the row sums, pass 1 dS / dQ
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = one_pass ? 1 : 0; pass < 2; ++pass) {
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
       const int key0 = half * HT * 16;
@@ -716,6 +749,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
               gsum = fmaf(p, acc[r], gsum);
               dsum = fmaf(p, dp, dsum);
             } else {
+              if (one_pass) gsum = fmaf(p, acc[r], gsum);
               d8[hh * 4 + r] = (bf16)(p * (dp - dsum));
               p8o[hh * 4 + r] = (bf16)p;
             }
@@ -732,12 +766,10 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
         }
       }
     }
-    if (pass == 0) {
-      dsum += __shfl_xor(dsum, 16, 64); dsum += __shfl_xor(dsum, 32, 64);
-      if (a.dgate) {
-        const float gs = wave_sum(gsum);
-        if (lane == 0) atomicAdd(a.dgate + h, gs);
-      }
+    if (pass == 0) dsum += __shfl_xor(dsum, 16, 64), dsum += __shfl_xor(dsum, 32, 64);
+    if (pass == (one_pass ? 1 : 0) && a.dgate) {
+      const float gs = wave_sum(gsum);
+      if (lane == 0) atomicAdd(a.dgate + h, gs);
     }
   }
   if (qok) {
@@ -1094,6 +1126,7 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
   f.kd_coef = a->kd_teacher ? 2.0f * a->kd_weight / ((float)a->B * a->H * a->Lq * a->Lk) : 0.f;
   if (a->kd_teacher && !a->kd_gout) return evlm_set_error("evlm_attention_bwd: kd_teacher without kd_gout");
   f.lse = a->lse; f.mask = a->mask; f.causal = a->causal; f.Pw = nullptr;
+  f.O = (const bf16*)a->O; f.rkd = a->kd_rowdot;
   const bool rc = a->lse != nullptr;
   if (rc && !evlm_attention_lse_supported(a->dtype, a->dh, a->Lk, 0.f))
     return evlm_set_error("evlm_attention_bwd: the recomputing form serves Lk <= 224 and 417..928 (got %d)", a->Lk);
@@ -1145,15 +1178,14 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
 }
 
 extern "C" int evlm_attention_lse_supported(int dtype, int dh, int Lk, float dropout_p) {
-  // Lk <= 224: the default.  417..928 keys (384 x 384 / 480 x 480 images): the two-pass kernel can recompute per key half too,
-  // but that is OPT-IN (EVLM_ATTN_RC_LONG=1, read per call): measured on the ITR-384 step it costs 4.6 % of the step (the
-  // kernel is VALU-bound: a second score product + exponentials per pass) and changes nothing in the gradient parity there
-  // (tools/itr_grad_parity.py: cosine 0.99998, query / key median 1.3 % either way).  225..416 keys: stored-map form only
-  // (the one-pass kernel A of that bucket holds a whole row in registers).
+  // Lk <= 224: one workgroup per (batch, head) holds a whole row in registers.  417..928 keys (384 x 384 / 480 x 480 images):
+  // the long-sequence kernel recomputes per key half; given the forward's O (and kd_rowdot with a fused distillation term)
+  // and no external dP it needs ONE pass over the keys (round 4; the two-pass recomputing form of round 3 cost 4.6 % of the
+  // ITR-384 step and stays for calls with a dP_ext).  Whether to ask for the lse form is the caller's choice per call
+  // (ops._Attention: when nobody wants the map).  225..416 keys: stored-map form only (the one-pass kernel A of that bucket
+  // holds a whole row in registers).
   if (dtype != EVLM_BF16 || dh != DH || dropout_p != 0.f) return 0;
-  if (Lk <= 224) return 1;
-  const char* env = getenv("EVLM_ATTN_RC_LONG");
-  return env && atoi(env) != 0 && Lk > 416 && Lk <= 928;
+  return Lk <= 224 || (Lk > 416 && Lk <= 928);
 }
 
 // returns 0 and sets *handled = 1 when a specialised kernel took the call
@@ -1168,7 +1200,9 @@ int evlm_attention_fwd_mfma(const evlm_attn_fwd_args* a, hipStream_t stream, int
   f.ldpr = a->ldpr; f.scale = a->scale; f.causal = a->causal;
   f.Pt = (const bf16*)a->kd_teacher; f.kd = a->kd_loss;
   f.kd_coef = a->kd_teacher ? a->kd_weight / ((float)a->B * a->H * a->Lq * a->Lk) : 0.f;
-  f.lse = a->lse;
+  f.lse = a->lse; f.rkd = a->kd_rowdot;
+  if (a->kd_rowdot && !(a->lse && a->kd_teacher))
+    return evlm_set_error("evlm_attention_fwd: kd_rowdot needs lse and kd_teacher");
   if (a->lse && !evlm_attention_lse_supported(a->dtype, a->dh, a->Lk, 0.f))
     return evlm_set_error("evlm_attention_fwd: the lse form serves Lk <= 224 and 417..928 (got %d)", a->Lk);
   if (a->kd_teacher && !a->kd_loss) return evlm_set_error("evlm_attention_fwd: kd_teacher without kd_loss");

@@ -430,7 +430,7 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
   f32x4 accL[4][4], accH[4][4];     // [j fragment][i fragment]; L: i rows 0..63 of the wave's block, H: 64..127
   bf16x8 pf[4][2], qf[2][2];
   bf16x8 ql[2][2], qh[2][2];        // PP_KTILE_HOLD only
-  float ps[8];                      // OUT 1: per-lane partial row sums of P (bias gradient), i fragments 0..7
+  float ps[2];                      // OUT 1: per-lane partial row sums of P (bias gradient), i fragments 2 wc, 2 wc + 1
 
   // prologue (host guarantees >= 2 K tiles per item): six units in flight, in the steady-state issue order of the schedule
   constexpr bool HOLD = OUT == 1;                 // weight gradients: PP_KTILE_HOLD (see there)
@@ -465,14 +465,13 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
 #ifdef PP_STAMP
     const bool do_psum = false;
 #else
-    const bool do_psum = OUT == 1 && g.psum != nullptr && tj == 0 && wc == 0;
+    const bool do_psum = OUT == 1 && g.psum != nullptr && tj == 0;
 #endif
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) { accL[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; accH[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int b = 0; b < 8; ++b) ps[b] = 0.f;
+    ps[0] = ps[1] = 0.f;
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one barrier behind group 0
     __builtin_amdgcn_sched_barrier(0);
@@ -612,11 +611,11 @@ __device__ __forceinline__ void pp256_body(GemmP& g, const PPGroup* grp) {
       else { pp_epi_f32_half<false>(gc, accL, ib, jb, lane_e, swin_e, mode); pp_epi_f32_half<false>(gc, accH, ib + 64, jb, lane_e, swin_e, mode); }
       if (do_psum) {                              // lanes l, l+16, l+32, l+48 hold the four k quarters of row l
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < 2; ++b) {             // (this wave's share: i fragments 2 wc + b, see PP_PSUM)
           float v = ps[b];
           v += __shfl_xor(v, 16, 64);
           v += __shfl_xor(v, 32, 64);
-          const int i = ib + b * 16 + lane_e;
+          const int i = ib + (2 * wc + b) * 16 + lane_e;
           if (lane_e < 16 && i < gc.I) atomicAdd(gc.psum + i, v);
         }
       }

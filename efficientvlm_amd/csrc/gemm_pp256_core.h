@@ -75,17 +75,32 @@ __device__ __forceinline__ void pp_src(const GemmP& g, int i0, int j0, int tid, 
 //   K-contiguous unit : row (lane & 15) of fragment f, chunk (ks*4 + (lane >> 4)) ^ swizzle   -> (lb ^ ks*64) + f*2048
 //   reduction-major   : two transposing reads (h = 0, 1) of k rows ks*32 + (lane >> 4)*8 + h*4 + q; the swizzled chunk
 //                       differs from the lane's base chunk only in the bits (f >> 1, f & 1, h)  -> lb ^ (those bits << 4)
+//
+// The transposing read is INLINE ASM, not __builtin_amdgcn_ds_read_tr16_b64 (round 4).  hipcc (ROCm 7.2) models an LDS-DMA
+// as a pending LDS write and the builtin as an LDS read it cannot disambiguate from it, so it put `s_waitcnt vmcnt(0)` in
+// front of the first transposed read of EVERY phase (7-8 per two K tiles in the .s of every PT / QT kernel of this family;
+// the ds_read_b128 form - a plain pointer load - gets none): each phase then drained the whole staging pipeline, i.e. every
+// unit had to land within the one phase after its issue instead of the 3-6 phases the counted vmcnt schedule gives it -
+// the weight-gradient kernel (both operands reduction-major) ran at 0.30 of the MFMA peak on a 197-K-tile reduction where
+// the K-contiguous loop of the same family holds 0.45-0.49.  An asm statement is invisible to that pass (and to its
+// lgkmcnt bookkeeping: PP_MFMA_BEGIN carries the `s_waitcnt lgkmcnt(0)` the MFMAs need, behind a sched_barrier as rule 18
+// of the guide asks); the RAW / WAR ordering of staged units against these reads is the counted-vmcnt + barrier
+// argument of the file header, exactly as for the ds_read_b128 reads.  The immediates are compile-time after inlining
+// (16-bit offset field; bit 16 of the unit offset - the second staging buffer - goes into the address register).
 template <bool TR>
 __device__ __forceinline__ bf16x8 pp_frag(const char* smem, int uo, int lb, int f, int ks) {
   if (!TR) {
     return *reinterpret_cast<const bf16x8*>(smem + (lb ^ (ks << 6)) + (uo + f * 2048));
   } else {
     bf16x8 out;
+    const uint32_t sb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int cz = ((f >> 1) << 6) | ((f & 1) << 5) | (h << 4);
-      bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-          (bf16x4 __attribute__((address_space(3)))*)(smem + (lb ^ cz) + (uo + ks * 8192 + h * 1024)));
+      const int off = uo + ks * 8192 + h * 1024;
+      const uint32_t a = sb + (uint32_t)(lb ^ cz) + (uint32_t)(off & ~0xFFFF);
+      bf16x4 t;
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t) : "v"(a), "n"(off & 0xFFFF));
       out[4 * h + 0] = t[0]; out[4 * h + 1] = t[1]; out[4 * h + 2] = t[2]; out[4 * h + 3] = t[3];
     }
     return out;
@@ -105,10 +120,12 @@ __device__ __forceinline__ int pp_lane_base(int lane, int wsel) {
 }
 
 // [memory work] | barrier | MFMAs | barrier : the sched_barriers keep hipcc from moving MFMAs (pure register ops) across
-#define PP_MFMA_BEGIN()                 \
-  __builtin_amdgcn_sched_barrier(0);    \
-  __builtin_amdgcn_s_barrier();         \
-  __builtin_amdgcn_sched_barrier(0);    \
+// (the explicit lgkmcnt(0): the asm transposing reads of pp_frag<true> are not in the compiler's own count)
+#define PP_MFMA_BEGIN()                                       \
+  __builtin_amdgcn_sched_barrier(0);                          \
+  __builtin_amdgcn_s_barrier();                               \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
+  __builtin_amdgcn_sched_barrier(0);                          \
   __builtin_amdgcn_s_setprio(1)
 #define PP_MFMA_END()                   \
   __builtin_amdgcn_s_setprio(0);        \
@@ -125,12 +142,22 @@ __device__ __forceinline__ int pp_lane_base(int lane, int wsel) {
   _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                           \
       ACC[AO + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(QF[a][ks], pf[b][ks], ACC[AO + a][b], 0, 0, 0)
 
-// bias gradient: per-lane partial row sums of the P fragments in registers (lane holds k = 8*(lane>>4)..+7 of row lane&15)
+// bias gradient: per-lane partial row sums of the P fragments in registers (lane holds k = 8*(lane>>4)..+7 of row lane&15).
+// All four wave columns of a wave row hold the same eight P fragments, so the sums are SHARED OUT: wave column c sums i
+// fragments 2c, 2c + 1 (columns 0, 1 in the phase that holds fragments 0..3, columns 2, 3 in the one that holds 4..7).
+// Left to wave column 0 alone (rounds 1-3) the 128 conversions + adds per K tile sat inside ONE wave's MFMA sections and
+// every barrier of the workgroup waited for it: a tile with a bias gradient (a third of the ViT's) ran at that wave's pace.
 #define PP_PSUM(PS, BO)                                                                                    \
-  if (OUT == 1 && do_psum) {                                                                               \
-    _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                          \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) PS[(BO) + b] += (float)pf[b][ks][e];                     \
+  if (OUT == 1 && do_psum && (wc >> 1) == ((BO) >> 2)) {                                                   \
+    if (wc & 1) {                                                                                          \
+      _Pragma("unroll") for (int b = 2; b < 4; ++b)                                                        \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) PS[b - 2] += (float)pf[b][ks][e];                      \
+    } else {                                                                                               \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                        \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) PS[b] += (float)pf[b][ks][e];                          \
+    }                                                                                                      \
   }
 
 // one K tile out of buffer BUF (compile-time LDS offsets); K tile index t of nt, operands at Pk / Qk.

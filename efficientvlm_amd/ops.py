@@ -182,6 +182,8 @@ GEMM_PROFILE = None
 # set to [0.0] to count the FLOPs of the attention cores that are launched (QK^T + PV forward, 5 products backward)
 ATTN_FLOPS = None
 ATTN_STORE_P = bool(os.environ.get("EVLM_ATTN_STORE_P"))   # A/B switch: attention backward from the stored bf16 map (round-2 form)
+# long key sequences (417..928) recompute too when nobody wants the map (round 4: one pass); "0": stored map (round 3)
+ATTN_RC_LONG = os.environ.get("EVLM_ATTN_RC_LONG", "1") not in ("", "0")
 
 
 def _as2d(x):
@@ -910,8 +912,13 @@ class _Attention(torch.autograd.Function):
         # of the map, the backward rebuilds P from Q and K in fp32 - no [B, H, Lq, Lk] bf16 map is written or read back
         # unless a caller wants it, and the q / k gradients are formed from fp32 probabilities, as the reference's
         # autocast softmax does.  EVLM_ATTN_STORE_P=1: the round-2 form (backward from the stored bf16 map).
+        # Long key sequences (417..928: 384 x 384 / 480 x 480 images) take that form when NOBODY wants the map (so no dP can
+        # come back for it): the backward then needs one pass over the keys - delta from dO . O (+ the fused distillation
+        # term's row sums, kd_rowdot) - and the student's 518 MB-per-layer maps of the ITR / VQA steps are never written.
+        # A caller that asks for the map keeps the stored-map form there.  EVLM_ATTN_RC_LONG=0: the round-3 behaviour.
         rc = bool(need and not ATTN_STORE_P and not (dropout_p and dropout_p > 0.0)
-                  and _lib().evlm_attention_lse_supported(L.dt(tdt), dh, Lk, 0.0))
+                  and _lib().evlm_attention_lse_supported(L.dt(tdt), dh, Lk, 0.0)
+                  and (Lk <= 224 or (not want_probs and ATTN_RC_LONG)))
         lse = torch.empty((B, H, Lq), dtype=torch.float32, device=dev) if rc else None
         Pbuf = torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev) if (want_probs or (need and not rc)) else None
         if p_out is not None and Pbuf is not None:         # caller-owned (persistent) buffer for the map: no copy later
@@ -927,7 +934,7 @@ class _Attention(torch.autograd.Function):
                           K=C.c_void_p(kvbuf.data_ptr() + k_off * es), V=C.c_void_p(kvbuf.data_ptr() + v_off * es),
                           kv_index=L.ptr(kv_index), mask=L.ptr(m32), head_gate=L.ptr(g32), scale=scale, O=L.ptr(O),
                           P=L.ptr(Pbuf), causal=int(bool(causal)), lse=L.ptr(lse), Bkv=Bkv if kv_index is not None else 0)
-        kd = kd_base = None
+        kd = kd_base = rkd = None
         if kd_teacher is not None:                # fused map distillation: the teacher's (padded) map, read once in-kernel
             kd_base = _padded_base(kd_teacher, Lkp) if kd_teacher.shape[-1] != Lkp else kd_teacher
             if (kd_base is None or not kd_base.is_contiguous() or tuple(kd_base.shape) != (B, H, Lq, Lkp)
@@ -939,6 +946,9 @@ class _Attention(torch.autograd.Function):
             else:
                 kd = zero_scalar(dev)
             a.kd_teacher, a.kd_loss, a.kd_weight = L.ptr(kd_base), L.ptr(kd), float(kd_weight)
+            if rc and Lk > 224:                   # the distillation term's share of the backward's row sums
+                rkd = torch.empty((B, H, Lq), dtype=torch.float32, device=dev)
+                a.kd_rowdot = L.ptr(rkd)
         drop = None
         if dropout_p and dropout_p > 0.0:
             drop = (float(dropout_p), dropout_state(dev), _next_drop_call("attention_probs", (B, H, Lq, Lk), dropout_p))
@@ -947,7 +957,8 @@ class _Attention(torch.autograd.Function):
         if ATTN_FLOPS is not None:
             ATTN_FLOPS[0] += 4.0 * B * H * Lq * Lk * dh
         ctx.set_materialize_grads(False)        # an unused probability map must not cost a zero tensor in backward
-        ctx.save_for_backward(qbuf, kvbuf, Pbuf, g32, kv_index, kd_base, lse, m32 if rc else None)
+        ctx.save_for_backward(qbuf, kvbuf, Pbuf, g32, kv_index, kd_base, lse, m32 if rc else None,
+                              O if (rc and Lk > 224) else None, rkd)
         ctx.meta = (H, dh, q_off, k_off, v_off, scale, qbuf is kvbuf or qbuf.data_ptr() == kvbuf.data_ptr(),
                     gate.shape if gate is not None else None)
         ctx.causal = int(bool(causal))
@@ -957,7 +968,7 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dO, dP, dkd):
-        qbuf, kvbuf, P, g32, kv_index, kd_base, lse, m32 = ctx.saved_tensors
+        qbuf, kvbuf, P, g32, kv_index, kd_base, lse, m32, O_fwd, rkd = ctx.saved_tensors
         H, dh, q_off, k_off, v_off, scale, self_attn, gshape = ctx.meta
         B, Lq, ldq = qbuf.shape
         Bkv, Lk, ldk = kvbuf.shape
@@ -992,7 +1003,8 @@ class _Attention(torch.autograd.Function):
                           kv_index=L.ptr(kv_index), head_gate=L.ptr(g32), scale=scale, dS=L.ptr(dS),
                           dQ=C.c_void_p(dqbuf.data_ptr() + q_off * es), dK=C.c_void_p(dkvbuf.data_ptr() + k_off * es),
                           dV=C.c_void_p(dkvbuf.data_ptr() + v_off * es), dgate=L.ptr(dgate),
-                          lse=L.ptr(lse), mask=L.ptr(m32), causal=ctx.causal if lse is not None else 0, P_ws=L.ptr(P_ws))
+                          lse=L.ptr(lse), mask=L.ptr(m32), causal=ctx.causal if lse is not None else 0, P_ws=L.ptr(P_ws),
+                          O=L.ptr(O_fwd), kd_rowdot=L.ptr(rkd))
         if kd_base is not None and dkd is not None:       # dP of the fused distillation term is formed in-kernel from P_t
             gk = dkd.to(torch.float32).contiguous()
             a.kd_teacher, a.kd_gout, a.kd_weight = L.ptr(kd_base), L.ptr(gk), ctx.kd_weight
@@ -1030,8 +1042,8 @@ class KdSlot:
 
 def attention_recomputes(x, dh, Lk, dropout_p=0.0):
     """will the attention backward of this problem rebuild the probabilities from Q and K (bf16 MFMA kernels, lse saved by
-    the forward) instead of reading a stored map?"""
-    return bool(x.is_cuda and not ATTN_STORE_P and not dropout_p
+    the forward) instead of reading a stored map - provided, on long key sequences, that the caller does not ask for the map?"""
+    return bool(x.is_cuda and not ATTN_STORE_P and not dropout_p and (Lk <= 224 or ATTN_RC_LONG)
                 and _lib().evlm_attention_lse_supported(L.dt(x.dtype), dh, Lk, 0.0))
 
 

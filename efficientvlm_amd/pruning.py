@@ -136,16 +136,22 @@ def prune_model_with_z(zs, model, cross_layers=3, pad_to=64, verbose=False):
     return model, zs
 
 
-def retrieval_eval_losses(model, image, text_ids, text_atts, idx=None, zs=None):
+def retrieval_eval_losses(model, image, text_ids, text_atts, idx=None, zs=None, with_logits=False):
     """(loss_itc, loss_itm) of the eval branch of efficient_models/model_retrieval.py:76-93: without `zs` for a (pruned,
     gate-free) model; with `zs` (a dict of 0/1 gate tensors as l0_module.forward(training=False) returns) the masked-dense
-    form the pruned model must reproduce"""
+    form the pruned model must reproduce.  with_logits: additionally the ITM head's [3B, 2] logits (logits_dict[
+    "itm_head_logits"] of the training branch, :60-74)"""
     z = zs or {}
     image_embeds, image_atts = model.get_vision_embeds(image, head_z=z.get("vision_head_z"),
                                                        mlp_z=z.get("vision_intermediate_z"))[:2]
     text_embeds = model.get_text_embeds(text_ids, text_atts, head_z=z.get("text_head_z"), mlp_z=z.get("text_intermediate_z"))
     image_feat, text_feat = model.get_features(image_embeds, text_embeds)
     loss_itc = model.get_contrastive_loss(image_feat, text_feat, idx=idx)
+    if with_logits:
+        itm = model.get_matching_loss(image_embeds, image_atts, image_feat, text_embeds, text_atts, text_feat, idx=idx,
+                                      output_attentions=False, output_hidden_states=True,
+                                      head_z=z.get("cross_head_z"), mlp_z=z.get("cross_intermediate_z"))
+        return loss_itc, itm["loss"], itm["logits"]
     loss_itm = model.get_matching_loss(image_embeds, image_atts, image_feat, text_embeds, text_atts, text_feat, idx=idx,
                                        head_z=z.get("cross_head_z"), mlp_z=z.get("cross_intermediate_z"))
     return loss_itc, loss_itm

@@ -415,7 +415,7 @@ class GDTrainer(_StagedExchange):
         syncs, which only order it as long as some gradient of that pass is accumulated out of place.  Valid inside a
         hipGraph capture (an event wait between two streams of the capture)."""
         ts = getattr(self.student, "text_stream", None)
-        if ts is not None:
+        if ts is not None and not os.environ.get("EVLM_NO_TEXT_JOIN"):
             torch.cuda.current_stream().wait_stream(ts)
 
     def _on_vision_grad(self):

@@ -168,11 +168,14 @@ typedef struct {
      s_k = (scale * q.k + mask) * log2(e).  With it the backward RECOMPUTES the probabilities from Q and K in fp32
      (evlm_attn_bwd_args.lse) and P may be NULL: no [B, H, Lq, Lk] map is written or read back unless a caller wants it
      (the reference keeps softmax in fp32 under Apex O1; a bf16-stored P costs 13-36 % of the q / k gradients' norm).
-     bf16 MFMA path with Lk <= 224 and no dropout only: evlm_attention_lse_supported(). */
+     bf16 MFMA path, Lk <= 224 or 417 <= Lk <= 928, no dropout: evlm_attention_lse_supported(). */
   float* lse;
   int Bkv;                      /* with kv_index: number of K/V batch rows (0 = unknown).  When given, problems in which
                                    several short query batches share a K/V row run one workgroup per (K/V row, head) that
                                    stages K and V once for all of them */
+  /* optional [B, H, Lq] f32, with lse AND kd_teacher: kd_rowdot[row] = sum_k P (P - P_t), the distillation term's share of
+     the backward's row sum  delta = sum_k P dP  (evlm_attn_bwd_args.kd_rowdot: one-pass long-sequence backward) */
+  float* kd_rowdot;
 } evlm_attn_fwd_args;
 int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream);
 
@@ -214,6 +217,12 @@ typedef struct {
   const float* mask;
   int causal;
   void* P_ws;
+  /* optional, recomputing form on 417 <= Lk <= 928 keys (384 x 384 / 480 x 480 images): O = the forward call's output
+     ([B, Lq, H*dh], ldo) and - with kd_teacher - kd_rowdot = the forward call's kd_rowdot.  Without a dP_ext the row sums
+     delta = sum_k P dP = dO . O + kd_weight' * kd_rowdot  are then taken from them and the kernel makes ONE pass over the
+     keys instead of two (the flash-attention identity, extended by the fused distillation term).  Ignored elsewhere. */
+  const void* O;
+  const float* kd_rowdot;
 } evlm_attn_bwd_args;
 int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream);
 /* 1 when evlm_attention_fwd / _bwd serve (dtype, dh, Lk, dropout_p) through the lse / recompute form, else 0 */

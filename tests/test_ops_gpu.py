@@ -1079,13 +1079,12 @@ def _attn_problem(B, Bkv, H, Lq, Lk, seed, self_attn):
 
 @pytest.mark.parametrize("case", ["vit197", "text30", "cross197", "cross_shared", "causal40", "vit577", "vit901", "cross577"])
 def test_recomputing_attention_backward_needs_no_stored_map_and_tightens_the_gradients(case, monkeypatch):
-    """The recomputing form (default for bf16, head dim 64, Lk <= 224, no dropout; on request - EVLM_ATTN_RC_LONG=1 - for
-    417..928 keys, where the two-pass long-sequence kernel recomputes per key half): with want_probs=False NO [B, H, Lq, Lk]
+    """The recomputing form (bf16, head dim 64, no dropout: Lk <= 224 always; 417..928 keys - the long-sequence kernel, ONE
+    pass per key half with the row sums taken from dO . O - when the caller does not take the map): with want_probs=False NO [B, H, Lq, Lk]
     map exists in HBM (the forward returns None, the backward rebuilds P from Q, K and the saved row lse in fp32) and the
     gradients sit closer to the fp32 reference than those formed from the stored bf16 map (the round-2 form,
     ATTN_STORE_P) - the query / key gradient is the cancellation P .* (dP - delta)."""
     o = ops()
-    monkeypatch.setenv("EVLM_ATTN_RC_LONG", "1")            # (the 417..928-key bucket recomputes on request only)
     B, Bkv, H, Lq, Lk, self_attn, causal = {"vit197": (3, 3, 12, 197, 197, True, False), "text30": (4, 4, 12, 30, 30, True, False),
                                             "cross197": (3, 3, 12, 30, 197, False, False),
                                             "cross_shared": (7, 3, 12, 30, 197, False, False),
@@ -1108,9 +1107,13 @@ def test_recomputing_attention_backward_needs_no_stored_map_and_tightens_the_gra
 
     O_rc, P_rc, gx_rc, gkv_rc = run(False, False)
     assert P_rc is None                                   # nothing materialised
-    O_rcp, P_rcp, gx_rcp, gkv_rcp = run(False, True)      # the map on request: same context, same gradients
-    assert P_rcp is not None and torch.equal(O_rc, O_rcp) and torch.equal(gx_rc, gx_rcp)
+    O_rcp, P_rcp, gx_rcp, gkv_rcp = run(False, True)      # the map on request: same context ...
     O_st, P_st, gx_st, gkv_st = run(True, True)
+    assert P_rcp is not None and torch.equal(O_rc, O_rcp)
+    if Lk <= 224:                                         # ... and the same (recomputed) gradients;
+        assert torch.equal(gx_rc, gx_rcp)
+    else:                                                 # on long key sequences a caller who takes the map keeps the stored-map
+        assert torch.equal(gx_rcp, gx_st)                 # backward (an external dP may come back for it: two passes either way)
     assert torch.equal(O_rc, O_st) and torch.equal(P_rcp, P_st)
     # fp32 reference
     xr = x0.float().requires_grad_(True)
@@ -1138,6 +1141,56 @@ def test_recomputing_attention_backward_needs_no_stored_map_and_tightens_the_gra
     if kvr is not None:
         k_rc, k_st = l2(gkv_rc, kvr.grad), l2(gkv_st, kvr.grad)
         assert rel_err(gkv_rc, kvr.grad) < 1.2e-2 and k_rc < 6e-3, (k_rc, k_st)
+
+
+@pytest.mark.parametrize("B,H,L,with_kd", [(2, 12, 577, True), (1, 4, 901, True), (2, 4, 577, False), (2, 3, 450, True)])
+def test_one_pass_long_sequence_backward_with_fused_distillation_and_gates(B, H, L, with_kd):
+    """attn_bwd_dq_long_kernel in its ONE-PASS form (384 x 384 / 480 x 480 images: 577 / 901 keys; nobody takes the map):
+    probabilities rebuilt from Q, K and the row lse in fp32, the row sums delta = sum_k P dP taken from dO . O (+ the
+    distillation term's share, which the forward kernel leaves as kd_rowdot), the map-distillation dP formed in fp32 from
+    the teacher map, head gates and their gradient collected in the same pass - against plain fp32 autograd of
+    softmax / P V / gate / MSELoss(P, P_t) * L (eff_vit.py:144-195, GeneralDistill.py:63-69), with a key-padding mask"""
+    o = ops()
+    g = torch.Generator().manual_seed(300 + L)
+    dh, d = 64, H * 64
+    qkv0 = rnd((B, L, 3 * d), torch.bfloat16, g, 0.7)
+    mask = torch.zeros(B, L)
+    mask[0, L - 9:] = -10000.0
+    mask = mask.to(DEV)
+    gate0 = (torch.rand(H, generator=g) + 0.5)
+    gate0[0] = 0.0                                        # a closed head: its context and dQ / dK / dV vanish, its gate gradient does not
+    gate0 = gate0.to(DEV)
+    with torch.no_grad():
+        _, Pt = o.self_attention(rnd((B, L, 3 * d), torch.bfloat16, g, 0.7), H, dh, 0.125, mask=mask)     # a "teacher" map
+    gO = rnd((B, L, d), torch.bfloat16, g)
+    coef = 0.3
+    x = qkv0.clone().requires_grad_(True)
+    gate = gate0.clone().requires_grad_(True)
+    if with_kd:
+        O, P, kd = o.self_attention(x, H, dh, 0.125, mask=mask, gate=gate, want_probs=False, kd_teacher=Pt, kd_weight=float(L))
+        ((O.float() * gO.float()).sum() + coef * kd).backward()
+    else:
+        O, P = o.self_attention(x, H, dh, 0.125, mask=mask, gate=gate, want_probs=False)
+        (O.float() * gO.float()).sum().backward()
+    assert P is None
+    xr = qkv0.float().requires_grad_(True)
+    gr = gate0.clone().requires_grad_(True)
+    sp = lambda t: t.reshape(B, L, H, dh).transpose(1, 2)
+    Pr = torch.softmax(sp(xr[..., :d]) @ sp(xr[..., d:2 * d]).transpose(-1, -2) * 0.125 + mask[:, None, None, :], -1)
+    Or = ((Pr @ sp(xr[..., 2 * d:])) * gr[None, :, None, None]).transpose(1, 2).reshape(B, L, d)
+    loss = (Or * gO.float()).sum()
+    if with_kd:
+        kdr = torch.nn.functional.mse_loss(Pr, Pt.float()) * L
+        loss = loss + coef * kdr
+        assert rel_err(kd, kdr) < 1e-4
+    loss.backward()
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    assert rel_err(O.float(), Or) < 2 * tol(torch.bfloat16)
+    assert l2(x.grad.float(), xr.grad) < 8e-3, l2(x.grad.float(), xr.grad)
+    assert l2(x.grad.float()[..., :2 * d], xr.grad[..., :2 * d]) < 1e-2            # query / key part
+    if not with_kd:                                                                 # the closed head (with the distillation
+        assert float(x.grad.float()[..., :64].abs().max()) == 0.0                   # term its map still has a gradient)
+    assert l2(gate.grad, gr.grad) < 5e-3, (gate.grad, gr.grad)
 
 
 @pytest.mark.parametrize("B,Bkv,Lq,Lk,with_mask", [(7, 3, 30, 197, False), (256, 64, 30, 197, True), (9, 2, 17, 100, True),
@@ -1187,7 +1240,7 @@ def test_attention_lse_form_refuses_what_it_cannot_serve():
     from efficientvlm_amd import _lib as L
     lib = L.load()
     assert lib.evlm_attention_lse_supported(L.BF16, 64, 197, 0.0) == 1
-    assert lib.evlm_attention_lse_supported(L.BF16, 64, 577, 0.0) == int(os.environ.get("EVLM_ATTN_RC_LONG", "0") not in ("", "0"))
+    assert lib.evlm_attention_lse_supported(L.BF16, 64, 577, 0.0) == 1 and lib.evlm_attention_lse_supported(L.BF16, 64, 901, 0.0) == 1
     assert lib.evlm_attention_lse_supported(L.BF16, 64, 300, 0.0) == 0        # 225..416 keys: stored-map form only
     assert lib.evlm_attention_lse_supported(L.BF16, 64, 1000, 0.0) == 0
     assert lib.evlm_attention_lse_supported(L.F32, 64, 30, 0.0) == 0

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import batch_from_fixture, close, load_det_weights, load_fixture, model_config
+from helpers import grad_parity_stats, batch_from_fixture, close, load_det_weights, load_fixture, model_config
 from oracle import schema, synth
 from oracle import xvlm_oracle as O
 
@@ -851,12 +851,11 @@ for name, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
     neg = torch.tensor([1, 2, 3, 0, 2, 3, 0, 1])
     student.injected_neg_idx = teacher.injected_neg_idx = neg
     student.keep_injected_neg = teacher.keep_injected_neg = True
-    tr = GDTrainer(student, teacher, dtype=dtype, use_graph=False)
+    tr = GDTrainer(student, teacher, lr=0.0, dtype=dtype, use_graph=False)       # (lr 0: both steps see the same parameters)
     batch = {k: v.cuda() for k, v in synth.make_batch(geom, 4, seed=3).items()}
     slabs = []
     for world in (1, 2):
         tr.reducer.world = world          # what a two-rank group would make of the loss scale (the collective stays real)
-        tr.opt.set_schedule(0.0)
         runtime.COLLECTIVES = []
         tr.step(batch)
         torch.cuda.synchronize()
@@ -1446,8 +1445,32 @@ def test_itr_trainer_with_pipelined_teacher_reproduces_the_unpipelined_trajector
 # ---------------------------------------------------------------------------------------------------------------------
 # full-width steps of BASELINE configs[2] / [3] / [4] (per-GPU shards, long image sequences) against the oracle
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("pipelined,B", [(False, 8), (True, 8), (True, 64)])
-def test_itr_384_step_full_width_bf16_tracks_the_fp32_oracle(pipelined, B):
+# worst single tensor of the ITR-384 / VQA-480 gradient checks (relative L2 against the oracle): the tensors that sit behind
+# the ITC logits' 1 / temp = 14 (vision_proj, text_proj) and behind all six ViT layers (class / position embeddings) at
+# batch 8 / 3, where nothing averages the bf16 noise of the residual stream
+ITR_WORST_TENSOR = 0.25
+VQA_WORST_TENSOR = 0.25
+
+
+def tint_images(image, seed):
+    """white-noise images + a per-image colour offset and brightness ramp.  With pure N(0, 1) pixels every image of a batch
+    has the same statistics, so at random init the CLS features of all images are nearly identical (the 576 noise patches
+    average out); the contrastive loss depends ONLY on the differences between the samples' features, which bf16 activations
+    then resolve to ~20 % - any bf16 pipeline would.  Images that differ in colour / brightness, as real ones do, give the
+    samples distinct features."""
+    g = torch.Generator().manual_seed(seed)
+    Bn, _, Hh, Ww = image.shape
+    off = 1.5 * torch.randn(Bn, 3, 1, 1, generator=g)
+    ramp = torch.linspace(-1.0, 1.0, Ww).view(1, 1, 1, Ww) * torch.randn(Bn, 3, 1, 1, generator=g)
+    return image + off + ramp
+
+
+# the tensors whose gradient comes through the ITC logits alone or sits behind all six ViT layers of the CLS row
+ITC_PATH = ("vision_proj.", "text_proj.", "vision_encoder.class_embedding", "vision_encoder.pos_embed.")
+
+
+@pytest.mark.parametrize("pipelined,B,scene", [(False, 8, "noise"), (True, 8, "noise"), (True, 8, "tinted"), (True, 64, "noise")])
+def test_itr_384_step_full_width_bf16_tracks_the_fp32_oracle(pipelined, B, scene):
     """BASELINE configs[2] on one GPU at full width (`pipelined`: the teacher prefetched one call ahead, the image-map
     distillation then fused into the student's attention kernels and its maps never written): EffXVLMforRetrieval student + base teacher, 384 x 384 images = 577
     image tokens (MFMA attention with 26-tile / long-sequence kernels, ragged weight-gradient reductions 8 x 577), L0 gates
@@ -1474,9 +1497,13 @@ def test_itr_384_step_full_width_bf16_tracks_the_fp32_oracle(pipelined, B):
     student.l0_module.set_lagrangian_warmup_steps(10)
     student.to(DEV); teacher.to(DEV)
     batch = synth.make_batch(geom, B, seed=19, ragged=True, image_res=384)
+    if scene == "tinted":
+        batch["image"] = tint_images(batch["image"], 77)
     idx = torch.arange(B)
     idx[2] = idx[1]
-    tr = ITRTrainer(student, teacher, lr=3e-5, reg_learning_rate=0.05, dtype=torch.bfloat16, pipeline_teacher=pipelined)
+    with_grads = B == 8                           # gradient-level parity at the small batch (lr 0: the step leaves the
+    tr = ITRTrainer(student, teacher, lr=0.0 if with_grads else 3e-5, reg_learning_rate=0.0 if with_grads else 0.05,
+                    dtype=torch.bfloat16, pipeline_teacher=pipelined)          # parameters where the oracle has them)
     eps = {t: torch.rand(s_sd["l0_module." + O.L0_PARAM[t]].shape, generator=gen).clamp(1e-6, 1 - 1e-6) for t in O.L0_TYPES}
     s_neg = torch.tensor([(i + 3) % B for i in range(2 * B)])
     t_neg = torch.tensor([(i + 5) % B for i in range(2 * B)])
@@ -1489,23 +1516,49 @@ def test_itr_384_step_full_width_bf16_tracks_the_fp32_oracle(pipelined, B):
         assert got is None                         # is formed inside the student's attention kernels (577 keys)
         got = tr.step(dev_batch, idx=idx.to(DEV))
     got = got.cpu()
-    with torch.no_grad():
-        logas = {k[len("l0_module."):]: v for k, v in s_sd.items() if k.endswith("_loga")}
-        S = O.retrieval_forward(s_sd, s_cfg, batch, idx, s_neg, O.l0_forward(logas, True, eps))
-        T = O.retrieval_forward(t_sd, t_cfg, batch, idx, t_neg)
+    torch.cuda.synchronize()
+    hip_grads = {n: p.grad.detach().float().cpu().clone() for n, p in student.named_parameters() if p.grad is not None}
+    leaves = {k: (v.clone().float().requires_grad_(True) if (with_grads and torch.is_floating_point(v)) else v)
+              for k, v in s_sd.items()}
+    with torch.set_grad_enabled(with_grads):
+        logas = {k[len("l0_module."):]: v for k, v in leaves.items() if k.endswith("_loga")}
+        S = O.retrieval_forward(leaves, s_cfg, batch, idx, s_neg, O.l0_forward(logas, True, eps))
+        with torch.no_grad():
+            T = O.retrieval_forward(t_sd, t_cfg, batch, idx, t_neg)
         kd = O.kd_terms(S, T, with_cross_attn=True)
         consts = O.l0_constants(geom["hidden"], geom["ffn"], geom["heads"], s_cfg["vit_layers"], s_cfg["fusion_layer"],
                                 s_cfg["text_layers"] - s_cfg["fusion_layer"])
-        lagr, _, _ = O.l0_lagrangian(logas, s_sd["l0_module.lambda_1"], s_sd["l0_module.lambda_2"], consts, 0,
+        lagr, _, _ = O.l0_lagrangian(logas, leaves["l0_module.lambda_1"], leaves["l0_module.lambda_2"], consts, 0,
                                      target_sparsity=0.25, lagrangian_warmup=10)
         total, mix = O.itr_loss_mix(S["loss"], kd, lagr)
-    want = torch.stack([total, S["loss"]["loss_itc"], S["loss"]["loss_itm"], mix["loss_kd"], lagr.reshape(())])
+    want = torch.stack([total, S["loss"]["loss_itc"], S["loss"]["loss_itm"], mix["loss_kd"], lagr.reshape(())]).detach()
     assert torch.isfinite(got).all()
     assert torch.allclose(got, want, rtol=3e-2, atol=2e-3), (got, want)
+    if with_grads:
+        # the gradient the three optimisers consume, per tensor, against the oracle's (fp32 autograd on the CPU) - the bounds of
+        # the GD test (test_benchmarked_configuration_matches_the_oracle).  Round 3 measured this configuration with a tool
+        # only (worst tensor 29 %); the attention backward now rebuilds the probabilities of the 577-key rows in fp32 too.
+        total.backward()
+        st = grad_parity_stats(hip_grads, {k: v for k, v in leaves.items() if torch.is_tensor(v) and v.requires_grad})
+        print("ITR-384 gradient parity:", scene, {k: v for k, v in st.items() if k != "stats"}, st["stats"][:8])
+        assert st["global_cos"] > 0.9999 and st["median"] < 1e-2 and st["p90"] < 4e-2 and st["qk_median"] < 2e-2, st
+        assert all(c > 0.95 for _, c, _ in st["stats"]), st["stats"][:8]
+        if scene == "tinted":            # samples with distinct features: the bounds of the GD test hold for EVERY tensor
+            # (measured: worst tensor 9.7 % - class embedding -, query / key projections <= 3.4 %; the scalar `temp`, whose
+            # gradient is one cancelling sum over the ITC logits, 18 %)
+            assert st["qk_max"] < 0.12 and st["max"] < ITR_WORST_TENSOR, st["stats"][:8]
+            assert max(r for r, _, n in st["stats"] if n != "temp") < 0.12, st["stats"][:8]
+        else:
+            # white-noise images (eight near-identical samples): the tensors behind the ITC logits carry the bf16 noise of the
+            # feature DIFFERENCES (see tint_images) - measured 20-29 %, the same with the stored-map and the recomputing
+            # attention backward; everything else stays within the GD bounds
+            itc = [r for r, _, n in st["stats"] if n.startswith(ITC_PATH)]
+            rest = [r for r, _, n in st["stats"] if not n.startswith(ITC_PATH)]
+            assert max(itc) < 0.32 and max(rest) < 0.15, st["stats"][:8]
 
 
-@pytest.mark.parametrize("B", [3, 32])
-def test_vqa_480_step_full_width_bf16_tracks_the_fp32_oracle(B):
+@pytest.mark.parametrize("pipelined,B", [(False, 3), (True, 3), (True, 32)])
+def test_vqa_480_step_full_width_bf16_tracks_the_fp32_oracle(pipelined, B):
     """BASELINE configs[3] on one GPU at full width: 480 x 480 images = 901 image tokens (the two-pass long-sequence dQ
     kernel, K / V taking turns in LDS), causal answer decoder, VQAL0Module gates; VQATrainer step in bf16 against the fp32
     CPU oracle (reference: Eff_VQA.py:74-200).  B = 32: the per-GPU batch configs[3] is quoted on."""
@@ -1521,25 +1574,46 @@ def test_vqa_480_step_full_width_bf16_tracks_the_fp32_oracle(B):
     student.to(DEV); teacher.to(DEV)
     batch = synth.make_vqa_batch(geom, B, seed=23)
     batch["image"] = torch.randn(B, 3, 480, 480, generator=gen)
-    tr = VQATrainer(student, teacher, lr=5e-5, reg_learning_rate=0.05, dtype=torch.bfloat16)
+    with_grads = B == 3                           # gradient-level parity at the small batch (lr 0: parameters stay put)
+    tr = VQATrainer(student, teacher, lr=0.0 if with_grads else 5e-5, reg_learning_rate=0.0 if with_grads else 0.05,
+                    dtype=torch.bfloat16, pipeline_teacher=pipelined)
     eps = {t: torch.rand(s_sd["l0_module." + O.L0_PARAM[t]].shape, generator=gen).clamp(1e-6, 1 - 1e-6) for t in O.L0_TYPES_VQA}
     student.l0_module.injected_eps = {t: e.clone() for t, e in eps.items()}
-    got = tr.step({k: v.to(DEV) for k, v in batch.items()}).cpu()
+    dev_batch = {k: v.to(DEV) for k, v in batch.items()}
+    got = tr.step(dev_batch)
+    if pipelined:                                 # the first call only starts the teacher; the image-map term of the second
+        assert got is None                        # is formed inside the student's attention kernels (901 keys, no map in HBM)
+        got = tr.step(dev_batch)
+    got = got.cpu()
+    torch.cuda.synchronize()
+    hip_grads = {n: p.grad.detach().float().cpu().clone() for n, p in student.named_parameters() if p.grad is not None}
     tie = lambda sd: {**sd, "text_decoder.cls.predictions.decoder.weight": sd["text_decoder.bert.embeddings.word_embeddings.weight"],
                       "text_decoder.cls.predictions.decoder.bias": sd["text_decoder.cls.predictions.bias"]}
-    with torch.no_grad():
-        logas = {k[len("l0_module."):]: v for k, v in s_sd.items() if k.endswith("_loga")}
-        S = O.vqa_forward(tie(s_sd), s_cfg, batch, O.l0_forward(logas, True, eps))
-        T = O.vqa_forward(tie(t_sd), t_cfg, batch)
+    leaves = {k: (v.clone().float().requires_grad_(True) if (with_grads and torch.is_floating_point(v)) else v)
+              for k, v in s_sd.items()}
+    with torch.set_grad_enabled(with_grads):
+        logas = {k[len("l0_module."):]: v for k, v in leaves.items() if k.endswith("_loga")}
+        S = O.vqa_forward(tie(leaves), s_cfg, batch, O.l0_forward(logas, True, eps))
+        with torch.no_grad():
+            T = O.vqa_forward(tie(t_sd), t_cfg, batch)
         kd = O.vqa_kd_terms(S, T)
         nd = s_cfg["text_layers"] - s_cfg["fusion_layer"]
         consts = O.l0_constants(geom["hidden"], geom["ffn"], geom["heads"], s_cfg["vit_layers"], s_cfg["fusion_layer"], nd, nd)
-        lagr, _, _ = O.l0_lagrangian(logas, s_sd["l0_module.lambda_1"], s_sd["l0_module.lambda_2"], consts, 0,
+        lagr, _, _ = O.l0_lagrangian(logas, leaves["l0_module.lambda_1"], leaves["l0_module.lambda_2"], consts, 0,
                                      target_sparsity=0.25, lagrangian_warmup=10)
         total, mix = O.vqa_loss_mix(S["loss"], kd, lagr)
-    want = torch.stack([total, S["loss"], mix["loss_kd"], lagr.reshape(())])
+    want = torch.stack([total, S["loss"], mix["loss_kd"], lagr.reshape(())]).detach()
     assert torch.isfinite(got).all()
     assert torch.allclose(got, want, rtol=4e-2, atol=2e-3), (got, want)
+    if with_grads:
+        # per-tensor gradient parity against the oracle's fp32 autograd (bounds of the GD test; 901-key attention rows rebuilt
+        # in fp32 by the one-pass long-sequence backward when the teacher is prefetched, stored bf16 maps otherwise)
+        total.backward()
+        st = grad_parity_stats(hip_grads, {k: v for k, v in leaves.items() if torch.is_tensor(v) and v.requires_grad})
+        print("VQA-480 gradient parity:", {k: v for k, v in st.items() if k != "stats"}, st["stats"][:8])
+        assert st["global_cos"] > 0.9999 and st["median"] < 1e-2 and st["p90"] < 3e-2, st
+        assert st["qk_max"] < 0.12 and st["qk_median"] < 2e-2, st
+        assert st["max"] < VQA_WORST_TENSOR and all(c > 0.95 for _, c, _ in st["stats"]), st["stats"][:8]
 
 
 @pytest.mark.parametrize("keep", [0.25, 0.5, 0.75])
@@ -1586,11 +1660,13 @@ def test_full_width_pruned_model_matches_the_oracles_masked_dense_forward(keep):
             pruning.prune_model_with_z(zd, model)
             assert sum(p.numel() for p in model.parameters()) < n_before * (0.55 + 0.5 * keep)
             model.injected_neg_idx = neg.clone()
-            itc, itm = pruning.retrieval_eval_losses(model, dev_batch["image"], dev_batch["text_ids"], dev_batch["text_atts"],
-                                                     idx=idx.to(DEV))
+            itc, itm, logits = pruning.retrieval_eval_losses(model, dev_batch["image"], dev_batch["text_ids"],
+                                                             dev_batch["text_atts"], idx=idx.to(DEV), with_logits=True)
         rtol = 1e-4 if dtype == torch.float32 else 2e-2
         close(itc, want["itc"], rtol, 1e-6, f"itc keep {keep} {dtype}")
         close(itm, want["itm"], rtol, 1e-6, f"itm keep {keep} {dtype}")
+        # ([3B, 2] logits of magnitude ~0.4 at random init, max-norm criterion of helpers.close: bf16 measured 2.6-2.9 %)
+        close(logits.float(), want["logits"], rtol if dtype == torch.float32 else 4e-2, 1e-6, f"itm logits keep {keep} {dtype}")
         del model
 
 
