@@ -49,7 +49,7 @@ class WeightCache:
         """[K, sum N_i] bf16 = transpose of the packed bf16 weight of `params`, or None when they are not adjacent members
         of an optimiser slab.  Created (and filled) on first use, afterwards kept current by refresh_transposed(), which
         the optimiser calls after every parameter update."""
-        if not self._slab or not params[0].is_cuda:
+        if not self._slab or not params[0].is_cuda or NO_WT:
             return None
         src = self._from_slab(params, torch.bfloat16)
         if src is None or src.dim() != 2 or src.shape[0] % 8 or src.shape[1] % 8:
@@ -181,6 +181,9 @@ CACHE = WeightCache()
 GEMM_PROFILE = None
 # set to [0.0] to count the FLOPs of the attention cores that are launched (QK^T + PV forward, 5 products backward)
 ATTN_FLOPS = None
+# A/B switch: no bf16 W^T copies - dX = dY W reads W reduction-major through the transposing LDS reads (round 4: those reads
+# no longer drain the staging pipeline, see gemm_pp256_core.h)
+NO_WT = bool(os.environ.get("EVLM_NO_WT"))
 ATTN_STORE_P = bool(os.environ.get("EVLM_ATTN_STORE_P"))   # A/B switch: attention backward from the stored bf16 map (round-2 form)
 # long key sequences (417..928) recompute too when nobody wants the map (round 4: one pass); "0": stored map (round 3)
 ATTN_RC_LONG = os.environ.get("EVLM_ATTN_RC_LONG", "1") not in ("", "0")
