@@ -24,6 +24,8 @@ int evlm_gemm_pp256_launch(GemmP& g, int pt, int qt, hipStream_t stream);
 int evlm_gemm_pp256_splits(const GemmP& g);
 bool evlm_gemm_pp256_eligible(const GemmP& g, int pt, int qt);
 bool evlm_gemm_pp256_streamk(const GemmP& g, int pt);
+bool evlm_gemm_w4_eligible(const GemmP& g, int pt, int qt);
+int evlm_gemm_w4_launch(GemmP& g, int qt, hipStream_t stream);
 bool evlm_gemm_pp128_eligible(const GemmP& g, int pt, int qt);
 int evlm_gemm_pp128_launch(GemmP& g, int qt, hipStream_t stream);
 bool evlm_gemm_pp192_eligible(const GemmP& g, int pt, int qt);
@@ -838,6 +840,12 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
     // 55 % (tools/gemm_pp256.py), but the step keeps two streams busy (student + pipelined teacher), so CUs a launch
     // leaves free are taken by the other stream's kernels and the per-tile efficiency decides (measured: +1.3 % step)
     static const int pp_pct = getenv("EVLM_PP256_PCT") ? atoi(getenv("EVLM_PP256_PCT")) : 30;   // tuning aid; > 100 disables
+    if (evlm_gemm_w4_eligible(g, pt, qt)) {            // one-wave-per-SIMD 256 x 256 kernel (gemm_w4.hip; opt-in: EVLM_W4=1)
+      if (evlm_gemm_w4_launch(g, qt, stream)) return -1;
+      g_last_kernel = qt ? "gemm_bf16_w4_kernel<true>" : "gemm_bf16_w4_kernel<false>";
+      EVLM_LAUNCH_CHECK("evlm_gemm");
+      return 0;
+    }
     if (evlm_gemm_pp128_eligible(g, pt, qt) && !evlm_gemm_pp256_streamk(g, pt)) {   // 128 x 256 tiles: thinly filled launches
       if (evlm_gemm_pp128_launch(g, qt, stream)) return -1;
       g_last_kernel = qt ? "gemm_bf16_pp128_kernel<true>" : "gemm_bf16_pp128_kernel<false>";

@@ -161,13 +161,16 @@ __device__ __forceinline__ int pp_lane_base(int lane, int wsel) {
   }
 
 // one K tile out of buffer BUF (compile-time LDS offsets); K tile index t of nt, operands at Pk / Qk.
+// N1 / N2 = "K tile t+1 / t+2 exists": LITERAL true in the steady-state loops (round 4) - as run-time flags every staging
+// piece and every counted wait sat behind a scalar compare-and-branch inside the memory sections (on the one-wave-per-SIMD
+// kernel of gemm_w4.hip, where nothing hides them, those branches alone cost 8 % of the K loop).
 // The j-lo Q fragments are read TWICE (phases 0 and 3) instead of being carried through phases 1-2: 16 registers less at
 // the peak, which is what keeps the kernel's long-lived values (next-tile offsets, epilogue pointers) out of scratch, and
 // phase 3 gets LDS reads of its own (it had none), evening out the memory sections the partner wave's MFMAs have to cover.
-#define PP_KTILE(BUF, t)                                                                                   \
+#define PP_KTILE(BUF, t, N1, N2)                                                                                 \
   do {                                                                                                     \
     constexpr int B0 = (BUF) * PPB, B1 = ((BUF) ^ 1) * PPB;                                                \
-    const bool n1 = (t) + 1 < nt, n2 = (t) + 2 < nt;                                                       \
+    const bool n1 = (N1), n2 = (N2);                                                                              \
     /* ---- phase 0: i-lo x j-lo ; stage PH(t+1) ---- */                                                   \
     _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
       qf[a][0] = pp_frag<QT>(smem, B0 + OFF_QL, qlb, a, 0);                                                \
@@ -205,10 +208,10 @@ __device__ __forceinline__ int pp_lane_base(int lane, int wsel) {
 // unit keeps a lead of five phases, which the weight-gradient kernels need - there BOTH operands are activations streamed
 // from HBM, and the three-phase lead the re-read schedule leaves QL is too short for them (measured: +3.5 % on the grouped
 // launch).  Their epilogue is small enough that the extra 16 registers do not spill.
-#define PP_KTILE_HOLD(BUF, t)                                                                                   \
+#define PP_KTILE_HOLD(BUF, t, N1, N2)                                                                                 \
   do {                                                                                                     \
     constexpr int B0 = (BUF) * PPB, B1 = ((BUF) ^ 1) * PPB;                                                \
-    const bool n1 = (t) + 1 < nt, n2 = (t) + 2 < nt;                                                       \
+    const bool n1 = (N1), n2 = (N2);                                                                              \
     /* ---- phase 0: i-lo x j-lo ---- */                                                                   \
     _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                        \
       ql[a][0] = pp_frag<QT>(smem, B0 + OFF_QL, qlb, a, 0);                                     \

@@ -202,10 +202,10 @@ __global__ __launch_bounds__(512, 1) void xattn_fused_kernel(XAttnP a) {
   __builtin_amdgcn_sched_barrier(0);
   int t = 0;
   for (; t + 1 < nt; t += 2) {
-    PP_KTILE(0, t);
-    PP_KTILE(1, t + 1);
+    PP_KTILE(0, t, (t) + 1 < nt, (t) + 2 < nt);
+    PP_KTILE(1, t + 1, (t) + 2 < nt, (t) + 3 < nt);
   }
-  if (t < nt) PP_KTILE(0, t);
+  if (t < nt) PP_KTILE(0, t, (t) + 1 < nt, (t) + 2 < nt);
   if (wr == 0) __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   PP_WAIT(0);
