@@ -841,8 +841,10 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
     // leaves free are taken by the other stream's kernels and the per-tile efficiency decides (measured: +1.3 % step)
     static const int pp_pct = getenv("EVLM_PP256_PCT") ? atoi(getenv("EVLM_PP256_PCT")) : 30;   // tuning aid; > 100 disables
     if (evlm_gemm_w4_eligible(g, pt, qt)) {            // one-wave-per-SIMD 256 x 256 kernel (gemm_w4.hip; opt-in: EVLM_W4=1)
-      if (evlm_gemm_w4_launch(g, qt, stream)) return -1;
-      g_last_kernel = qt ? "gemm_bf16_w4_kernel<true>" : "gemm_bf16_w4_kernel<false>";
+      const int w4rows = evlm_gemm_w4_launch(g, qt, stream);
+      if (w4rows < 0) return -1;
+      g_last_kernel = w4rows == 192 ? (qt ? "gemm_bf16_w4_kernel<true,6>" : "gemm_bf16_w4_kernel<false,6>")
+                                    : (qt ? "gemm_bf16_w4_kernel<true,8>" : "gemm_bf16_w4_kernel<false,8>");
       EVLM_LAUNCH_CHECK("evlm_gemm");
       return 0;
     }

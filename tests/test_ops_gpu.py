@@ -1307,3 +1307,16 @@ def test_grouped_mse_terms_equal_the_per_pair_reductions(dtype):
             else:
                 assert rel_err(xa.grad.float(), xb.grad.float()) < t
     assert rel_err(pa.grad.float(), pb.grad.float()) < t and float(pa.grad[..., 30:].abs().max()) == 0.0
+
+
+def test_one_wave_per_simd_gemm_kernel_passes_the_race_screen():
+    """gemm_w4.hip (opt-in EVLM_W4=1: 4 waves x 128 x 128 or 96 x 128 of C, accumulators pinned in AGPRs, fragment reads and
+    LDS-DMA inside the MFMA stream, persistent): forward and dX products (K-contiguous and reduction-major Q, edge tiles,
+    short reductions) against fp32 torch products of the same bf16 inputs, repeated - a separate process, the switch is
+    read once per process"""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EVLM_W4="1")
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "gemm_pp256_race_screen.py"), "2"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "race screen: CLEAN" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
