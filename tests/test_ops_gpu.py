@@ -1309,6 +1309,27 @@ def test_grouped_mse_terms_equal_the_per_pair_reductions(dtype):
     assert rel_err(pa.grad.float(), pb.grad.float()) < t and float(pa.grad[..., 30:].abs().max()) == 0.0
 
 
+def test_fused_map_distillation_term_of_a_forward_without_a_backward():
+    """eff_vit.CLIPAttention with a teacher map and nothing to differentiate (a validation-loss pass under no_grad, or frozen
+    inputs): no row lse exists without a backward, so the layer takes the stored-map form of the term instead of refusing
+    the call - same term, same context as the training forward"""
+    from efficientvlm_amd.efficient_models.eff_vit import CLIPAttention
+    from efficientvlm_amd.runtime import compute
+    torch.manual_seed(5)
+    attn = CLIPAttention(768, 12, 0.0).to(DEV)
+    x = (torch.randn(2, 197, 768, device=DEV) * 0.5)
+    with torch.no_grad(), compute(torch.bfloat16):
+        _, Pt = attn(x * 0.9, output_attentions=True)
+    with compute(torch.bfloat16):
+        xg = x.clone().requires_grad_(True)
+        out_g, _, kd_g = attn(xg, kd_teacher=Pt)
+        with torch.no_grad():
+            out_n, p_n, kd_n = attn(x, kd_teacher=Pt)
+    assert p_n is None and torch.isfinite(kd_n).all()
+    assert rel_err(out_n.float(), out_g.float()) < 1e-6
+    assert rel_err(kd_n, kd_g.detach()) < 2e-2            # (stored-map form: the term of the bf16-rounded probabilities)
+
+
 def test_one_wave_per_simd_gemm_kernel_passes_the_race_screen():
     """gemm_w4.hip (opt-in EVLM_W4=1: 4 waves x 128 x 128 or 96 x 128 of C, accumulators pinned in AGPRs, fragment reads and
     LDS-DMA inside the MFMA stream, persistent): forward and dX products (K-contiguous and reduction-major Q, edge tiles,
