@@ -17,6 +17,7 @@ struct MAttnF {
   const bf16* Pt; float* kd; float kd_coef;      // fused map distillation: *kd += kd_coef * sum((P - Pt)^2)
   float* lse;                                    // [B, H, Lq] log2-sum-exp of the scaled, masked scores (recomputing backward)
   float* rkd;                                    // [B, H, Lq] sum_k P (P - Pt) of the fused distillation (one-pass long backward)
+  int skip_dead;                                 // heads with a gate of exactly 0: zero context, nothing staged (A/B switch)
 };
 
 #define DH 64
@@ -118,6 +119,19 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   float* Ms = reinterpret_cast<float*>(smem + (SEQ ? 1 : 2) * NT * 16 * 128);   // [NT*16] additive mask (+ -1e30 beyond Lk)
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
+  // A head whose L0 gate is exactly 0 (masked-dense evaluation of a pruned-but-not-compacted model, BASELINE configs[4]:
+  // "kernel skips masked heads") contributes a zero context: when nothing else is asked of the launch - no map, no row
+  // lse for a backward, no distillation term - the workgroup writes the zeros and leaves before staging anything.
+  // (Workgroup-uniform: ahead of every barrier.)
+  if (!LSE && a.skip_dead && a.gate && !a.P && !a.Pt && a.gate[h] == 0.f) {
+    const int q = (blockIdx.x * (blockDim.x >> 6) + wave) * 16 + ql;
+    if (q < a.Lq) {
+      bf16* Or = a.O + ((size_t)b * a.Lq + q) * a.ldo + h * DH + g * 16;
+      *reinterpret_cast<uint4*>(Or) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(Or + 8) = make_uint4(0, 0, 0, 0);
+    }
+    return;
+  }
   const int bkv = a.kv_index ? a.kv_index[b] : b;
   const bf16* Kb = a.K + (size_t)bkv * a.Lk * a.ldk + h * DH;
   const bf16* Vb = a.V + (size_t)bkv * a.Lk * a.ldv + h * DH;
@@ -295,9 +309,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_kernel(MAttnF a) {
   const int bkv = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
   float* Ms = reinterpret_cast<float*>(smem + 2 * NT * 16 * 128) + wave * NT * 16;     // this wave's mask strip
-  stage_rows<SW_K>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
-  stage_rows<SW_V>(a.V + (size_t)bkv * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
-  stage_wait();
+  const bool dead = !LSE && a.skip_dead && a.gate && !a.P && a.gate[h] == 0.f;      // closed head, nothing but a zero context to deliver
+  if (!dead) {
+    stage_rows<SW_K>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, Ks);
+    stage_rows<SW_V>(a.V + (size_t)bkv * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, Vs);
+    stage_wait();
+  }
   __syncthreads();
   const int qtiles = (a.Lq + 15) >> 4;
   const float sc = a.scale * 1.44269504088896341f;
@@ -310,6 +327,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_kernel(MAttnF a) {
       bool mask_ready = false;
       for (int qt = 0; qt < qtiles; ++qt, ++task) {
         if (task % NW != wave) continue;
+        if (dead) {                                      // (wave-uniform)
+          const int q = qt * 16 + ql;
+          if (q < a.Lq) {
+            bf16* Or = a.O + ((size_t)b * a.Lq + q) * a.ldo + h * DH + g * 16;
+            *reinterpret_cast<uint4*>(Or) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(Or + 8) = make_uint4(0, 0, 0, 0);
+          }
+          continue;
+        }
         if (!mask_ready) {                               // (in-order LDS: the strip is complete before this wave reads it)
           for (int k = lane; k < NT * 16; k += 64)
             Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
@@ -1201,6 +1227,8 @@ int evlm_attention_fwd_mfma(const evlm_attn_fwd_args* a, hipStream_t stream, int
   f.Pt = (const bf16*)a->kd_teacher; f.kd = a->kd_loss;
   f.kd_coef = a->kd_teacher ? a->kd_weight / ((float)a->B * a->H * a->Lq * a->Lk) : 0.f;
   f.lse = a->lse; f.rkd = a->kd_rowdot;
+  static const bool no_head_skip = getenv("EVLM_ATTN_NO_HEAD_SKIP") != nullptr;      // (A/B switch)
+  f.skip_dead = no_head_skip ? 0 : 1;
   if (a->kd_rowdot && !(a->lse && a->kd_teacher))
     return evlm_set_error("evlm_attention_fwd: kd_rowdot needs lse and kd_teacher");
   if (a->lse && !evlm_attention_lse_supported(a->dtype, a->dh, a->Lk, 0.f))

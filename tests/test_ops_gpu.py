@@ -1309,6 +1309,44 @@ def test_grouped_mse_terms_equal_the_per_pair_reductions(dtype):
     assert rel_err(pa.grad.float(), pb.grad.float()) < t and float(pa.grad[..., 30:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("kind", ["self197", "cross_shared", "self577"])
+def test_closed_heads_are_skipped_in_a_no_grad_forward(kind):
+    """BASELINE configs[4] "kernel skips masked heads": in a no-grad forward that wants no map, a head whose L0 gate is
+    exactly 0 gets its zero context written without staging K / V or computing anything (attn_fwd_mfma_kernel,
+    attn_fwd_grouped_kernel); open heads are untouched - bit-identical to the launch with those gates at 1 on the open heads
+    and to plain fp32 math overall"""
+    o = ops()
+    g = torch.Generator().manual_seed(23)
+    H, dh = 12, 64
+    d = H * dh
+    gate = torch.ones(H)
+    gate[[1, 4, 5, 11]] = 0.0
+    gate[2] = 0.5
+    gate = gate.to(DEV)
+    with torch.no_grad():
+        if kind == "cross_shared":
+            B, Bkv, Lq, Lk = 12, 3, 30, 197
+            q = rnd((B, Lq, d), torch.bfloat16, g); kv = rnd((Bkv, Lk, 2 * d), torch.bfloat16, g)
+            idx = (torch.arange(B) % Bkv).to(DEV)
+            O, P = o.cross_attention(q, kv, H, dh, 0.125, gate=gate, want_probs=False, kv_index=idx)
+            Oref, _ = o.cross_attention(q, kv, H, dh, 0.125, gate=torch.ones(H, device=DEV), want_probs=False, kv_index=idx)
+        else:
+            L = 197 if kind == "self197" else 577
+            B = 3 if kind == "self197" else 2
+            x = rnd((B, L, 3 * d), torch.bfloat16, g)
+            O, P = o.self_attention(x, H, dh, 0.125, gate=gate, want_probs=False)
+            Oref, _ = o.self_attention(x, H, dh, 0.125, gate=torch.ones(H, device=DEV), want_probs=False)
+    assert P is None
+    Oh, Rh = O.float().unflatten(-1, (H, dh)), Oref.float().unflatten(-1, (H, dh))
+    for h in range(H):
+        if float(gate[h]) == 0.0:
+            assert float(Oh[..., h, :].abs().max()) == 0.0
+        elif float(gate[h]) == 1.0:
+            assert torch.equal(Oh[..., h, :], Rh[..., h, :])
+        else:
+            assert rel_err(Oh[..., h, :], Rh[..., h, :] * float(gate[h])) < 1e-2
+
+
 def test_fused_map_distillation_term_of_a_forward_without_a_backward():
     """eff_vit.CLIPAttention with a teacher map and nothing to differentiate (a validation-loss pass under no_grad, or frozen
     inputs): no row lse exists without a backward, so the layer takes the stored-map form of the term instead of refusing
@@ -1317,7 +1355,7 @@ def test_fused_map_distillation_term_of_a_forward_without_a_backward():
     from efficientvlm_amd.runtime import compute
     torch.manual_seed(5)
     attn = CLIPAttention(768, 12, 0.0).to(DEV)
-    x = (torch.randn(2, 197, 768, device=DEV) * 0.5)
+    x = (torch.randn(2, 197, 768, device=DEV) * 0.5).to(torch.bfloat16)      # (activations carry the compute dtype)
     with torch.no_grad(), compute(torch.bfloat16):
         _, Pt = attn(x * 0.9, output_attentions=True)
     with compute(torch.bfloat16):
