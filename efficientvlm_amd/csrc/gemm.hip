@@ -806,6 +806,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int I, int J, i
 static thread_local const char* g_last_kernel = "";
 extern "C" const char* evlm_gemm_last_kernel(void) { return g_last_kernel; }
 
+// Zero fill of a split reduction's f32 output: a KERNEL, not hipMemsetAsync.  A memset node captured into a hipGraph wrote
+// a 16-byte pattern whose first word was stale (0x..25be80: the low half of a host address) from its SECOND launch on, on
+// ROCm 7.2 - the VQA step's vocabulary-head dX came back as 1e13..inf in every fourth column (round 4,
+// profiles/r04_graph_memset.md).
+__global__ void zero_f32_kernel(float* __restrict__ c, int64_t n) {
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+  if (((uintptr_t)c & 15) == 0) {
+    float4* c4 = reinterpret_cast<float4*>(c);
+    for (int64_t i = i0; i < n / 4; i += step) c4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (n / 4) * 4 + i0; i < n; i += step) c[i] = 0.f;
+  } else {
+    for (int64_t i = i0; i < n; i += step) c[i] = 0.f;
+  }
+}
+static inline int zero_f32(float* c, int64_t n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  const int blocks = imin(ceil_div(ceil_div(n, 4), 256), 2048);
+  hipLaunchKernelGGL(zero_f32_kernel, dim3(blocks), dim3(256), 0, stream, c, n);
+  return hipGetLastError() == hipSuccess ? 0 : evlm_set_error("evlm_gemm: zero fill launch failed");
+}
+
 extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(a && a->P && a->Q && a->C, "evlm_gemm: null operand");
@@ -864,8 +885,7 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
       const int items = ceil_div(g.I, 256) * ceil_div(g.J, 256) * evlm_gemm_pp256_splits(g);
       if (items * 100 >= pp_pct * ceil_div(items, 256) * 256 || evlm_gemm_pp256_streamk(g, pt)) {
         if (g.c_f32 && evlm_gemm_pp256_splits(g) > 1 && !g.accumulate) {
-          hipError_t me = hipMemsetAsync(g.C, 0, (size_t)g.I * g.ldc * sizeof(float), stream);
-          if (me != hipSuccess) return evlm_set_error("evlm_gemm: memset failed: %s", hipGetErrorString(me));
+          if (zero_f32((float*)g.C, (int64_t)g.I * g.ldc, stream)) return -1;
         }
         if (evlm_gemm_pp256_launch(g, pt, qt, stream)) return -1;
         g_last_kernel = g.sk ? (qt ? "gemm_bf16_pp256_sk_kernel<true>" : "gemm_bf16_pp256_sk_kernel<false>")
@@ -909,8 +929,7 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
       g.kt_per_split = ceil_div(nt, splits);
       splits = ceil_div(nt, g.kt_per_split);
       if (splits > 1 && !g.accumulate) {
-        hipError_t me = hipMemsetAsync(g.C, 0, (size_t)g.I * g.ldc * sizeof(float), stream);
-        if (me != hipSuccess) return evlm_set_error("evlm_gemm: memset failed: %s", hipGetErrorString(me));
+        if (zero_f32((float*)g.C, (int64_t)g.I * g.ldc, stream)) return -1;
       }
       dim3 grid(tiles, splits);
       const size_t lds = (size_t)4 * bt * BK * 2;

@@ -150,6 +150,9 @@ class XVLML0Module(Module):
         return n
 
     def get_target_sparsity(self, pruned_steps):
+        if torch.is_tensor(pruned_steps):      # extension: a DEVICE step counter (a captured training step replays with a new one)
+            ramp = torch.clamp(pruned_steps.to(torch.float32) / self.lagrangian_warmup, max=1.0)
+            return (self.target_sparsity - self.start_sparsity) * ramp + self.start_sparsity
         return (self.target_sparsity - self.start_sparsity) * min(1, pruned_steps / self.lagrangian_warmup) + self.start_sparsity
 
     def lagrangian_regularization(self, pruned_steps):
@@ -166,7 +169,17 @@ class XVLML0Module(Module):
         """uniform draws on the CPU generator, like the reference (xvlm_l0_module.py:239-244)"""
         return torch.empty(size).uniform_(epsilon, 1 - epsilon)
 
+    # extension (captured training steps, trainer.ITRTrainer / VQATrainer): `static_eps` = {type: persistent device buffer} the
+    # gate noise is READ from - the trainer refills the buffers before every replay with the draws this method would have
+    # made (same generator, same order: `eps_trace` records (type, shape) of one eager forward);  None = draw here
+    static_eps = None
+    eps_trace = None
+
     def _sample_z(self, loga, type=None):
+        if self.static_eps is not None and type in self.static_eps:
+            return ops.l0_sample(loga, self.static_eps[type], self.temperature)
+        if self.eps_trace is not None:
+            self.eps_trace.append((type, tuple(loga.shape)))
         if self.injected_eps is not None and type in self.injected_eps:
             eps = self.injected_eps[type]
         else:

@@ -654,7 +654,7 @@ def _linear_backward(ctx, dy, dx_add):
                 # of 64 (dY's padding columns are zero already) so the split-K f32 path applies, then cast once
                 Wp = _scratch(("wpad", n64, K), (n64, K), x2.dtype, x2.device, zero=True)
                 Wp[:N].copy_(W)
-                d32 = torch.zeros((M, K), dtype=torch.float32, device=x2.device)
+                d32 = torch.empty((M, K), dtype=torch.float32, device=x2.device)      # (a split reduction zero-fills its output itself)
                 _gemm(dtype, d2, Wp, d32, M, K, n64, ldd, K, K, p_trans=0, q_trans=1, c_f32=1)
                 dxb = cast(d32, x2.dtype)
             else:

@@ -231,17 +231,36 @@ class TensorAdamW:
         self.state = [dict(m=torch.zeros_like(p, dtype=torch.float32), v=torch.zeros_like(p, dtype=torch.float32))
                       for p in self.params]
         self.step_count = 0
+        self.hyper, self._scheduled = None, False
 
     def zero_grad(self):
         for p in self.params:
             if p.grad is not None:
                 p.grad.zero_()
 
-    def step(self):
-        lib = L.load()
+    def set_schedule(self):
+        """stage this step's bias corrections on the DEVICE (call outside a captured graph, before its replay): a captured
+        step() then reads them from there instead of baking the host values of its capture pass into the graph"""
         self.step_count += 1
         b1, b2 = self.betas
+        host = torch.tensor([1.0, 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count], dtype=torch.float32)
+        if self.hyper is None:
+            self.hyper = torch.ones(3, dtype=torch.float32, device=self.params[0].device)
+        if self.hyper.is_cuda:
+            host = host.pin_memory()               # (a fresh pinned block per step: FlatAdamW.set_schedule)
+        self.hyper.copy_(host, non_blocking=True)
+        self._scheduled = True
+
+    def step(self):
+        lib = L.load()
+        b1, b2 = self.betas
         g = self.param_groups[0]
+        staged = self._scheduled
+        if not staged:
+            if self.params and self.params[0].is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("TensorAdamW.step() captured into a hipGraph without set_schedule()")
+            self.step_count += 1
+        self._scheduled = False
         c1, c2 = 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
         for p, st in zip(self.params, self.state):
             if p.grad is None:
@@ -250,7 +269,7 @@ class TensorAdamW:
                 raise RuntimeError("TensorAdamW: parameters must be contiguous fp32 CUDA tensors (no CPU fallback)")
             L.check(lib.evlm_adamw_step(L.ptr(p.data), L.ptr(p.grad), L.ptr(st["m"]), L.ptr(st["v"]), p.numel(),
                                         float(g["lr"]), b1, b2, self.eps, float(g["weight_decay"]), c1, c2, None, 0.0,
-                                        None, None, L.stream()), "adamw")
+                                        None, L.ptr(self.hyper) if staged else None, L.stream()), "adamw")
 
 
 def create_L0_optimizer(args, l0_module):

@@ -924,7 +924,7 @@ class TeacherPrefetch:
         self.run_teacher = run_teacher          # fn(batch dict) -> teacher outputs (any nest of tensors)
         self.use_graph = use_graph
         self.side = torch.cuda.Stream()
-        self.states, self.pending = {}, None
+        self.states, self.pending, self.last_key = {}, None, None
 
     def _create(self, batch):
         cur = torch.cuda.current_stream()
@@ -965,10 +965,98 @@ class TeacherPrefetch:
                 for t in distill._tensors(st["T"][p]):     # allocated on the side stream, consumed on the main one
                     t.record_stream(cur)
         prev, self.pending = self.pending, (st, p)
+        # (identity of the static buffers the returned pair lives in - a captured student step is keyed by it - or None when
+        # the teacher ran eagerly into fresh tensors)
+        self.last_key = None if (prev is None or prev[0]["graphs"] is None) else (id(prev[0]), prev[1])
         return None if prev is None else (prev[0]["B"][prev[1]], prev[0]["T"][prev[1]])
 
 
-class ITRTrainer(_StagedExchange):
+class _CapturedStep:
+    """The pruning fine-tune step as ONE hipGraph per static (batch, teacher outputs) pair of the teacher prefetch
+    (`capture_step=True`; single GPU, prefetched teacher with graphs).  What made the step host-dependent enters through
+    device memory that is refilled before every replay: the Lagrangian warm-up counter (`_pruned_dev`; the reference ramps the
+    target sparsity with a Python step count, Eff_Retrieval.py:113), the gate noise (`l0.static_eps`: drawn on the HOST
+    generator in the order and shapes one eager forward draws them - the same stream of numbers as the eager trainer, and as
+    the reference's CPU draws) and the three optimisers' schedules (FlatAdamW / TensorAdamW `.set_schedule`).  The first step
+    on a pair runs eagerly (it records the gate-noise plan and warms allocator and weight caches), the second is captured,
+    later ones replay."""
+    capture_step = False
+
+    def _cap_init(self):
+        dev = next(self.student.parameters()).device
+        self._sgraphs, self._seen, self._eps_plan, self._eps_static = {}, set(), None, None
+        self._pruned_dev = torch.zeros((), dtype=torch.float32, device=dev)
+        self._cap_stream = None
+        self.last_launch = "eager"
+
+    def _stage_eps(self):
+        l0 = self.student.l0_module
+        for typ, shape in self._eps_plan:
+            inj = l0.injected_eps
+            src = inj[typ] if (inj is not None and typ in inj) else l0.get_eps(shape)
+            src = src.to(torch.float32)
+            if not src.is_cuda:
+                src = src.contiguous().pin_memory()
+            self._eps_static[typ].copy_(src, non_blocking=True)
+
+    def _run_step(self, key, body, lr_mult):
+        """body(pruned_steps, staged) -> device loss stack"""
+        l0 = self.student.l0_module
+        if not self.capture_step or key is None or self.reducer.active:
+            self.last_launch = "eager"
+            return body(self.global_step, False)
+        # Every step of a capturing trainer - the eager ones too - runs on ONE dedicated stream: autograd remembers the stream
+        # an AccumulateGrad node was created on and synchronises a later backward with it, which inside a capture would pull
+        # a non-capturing stream into the graph (hipGraphInstantiate then faults on this stack)
+        cur = torch.cuda.current_stream()
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream()
+        cs = self._cap_stream
+        if key not in self._seen:                     # first step on this pair: eager, recording the gate-noise plan
+            self._seen.add(key)
+            l0.eps_trace = []
+            cs.wait_stream(cur)
+            try:
+                with torch.cuda.stream(cs):
+                    out = body(self.global_step, False)
+            finally:
+                plan, l0.eps_trace = l0.eps_trace, None
+            cur.wait_stream(cs)
+            if self._eps_plan is None:
+                dev = self._pruned_dev.device
+                self._eps_plan = plan
+                self._eps_static = {t: torch.empty(shape, dtype=torch.float32, device=dev) for t, shape in plan}
+            elif plan != self._eps_plan:
+                raise RuntimeError("captured pruning step: the gate-noise draws of this batch kind differ from the recorded plan")
+            self.last_launch = "eager"
+            return out
+        self._pruned_dev.fill_(float(self.global_step))
+        self._stage_eps()
+        self.opt.set_schedule(lr_mult)
+        self.l0_opt.set_schedule()
+        self.lagrangian_opt.set_schedule()
+        ent = self._sgraphs.get(key)
+        if ent is None:
+            ops.CACHE.invalidate()                    # capture the casts of the trainable weights too
+            ops.reserve_tables()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            l0.static_eps = self._eps_static
+            try:
+                with no_gc_during_capture(), torch.cuda.graph(g, stream=cs, capture_error_mode="thread_local"):
+                    out = body(self._pruned_dev, True)
+            finally:
+                l0.static_eps = None
+            ops.flush_table_uploads()
+            ent = self._sgraphs[key] = (g, out)
+            # (the capture pass consumed the optimisers' "staged" flags, not the staged values: the replay reads them)
+        ent[0].replay()
+        self.opt._scheduled = self.l0_opt._scheduled = self.lagrangian_opt._scheduled = False
+        self.last_launch = "hipGraph replay"
+        return ent[1]
+
+
+class ITRTrainer(_StagedExchange, _CapturedStep):
     """Pruning fine-tune step of Eff_Retrieval.py:75-213 (image-text retrieval with hard-concrete L0 gates): student with
     gates forward + backward, teacher forward, ITC + ITM + hidden / attention / cross-attention / logit KD, the Lagrangian
     sparsity term, THREE optimisers (main AdamW over every student parameter - the gate parameters included, as in the
@@ -977,9 +1065,11 @@ class ITRTrainer(_StagedExchange):
     Lagrangian warm-up makes the step depend on a host-side counter."""
 
     def __init__(self, student, teacher, lr=3e-5, weight_decay=0.01, lr_mult=2.0, reg_learning_rate=0.1,
-                 dtype=torch.float32, temperature=1.0, pipeline_teacher=False, use_graph=True):
+                 dtype=torch.float32, temperature=1.0, pipeline_teacher=False, use_graph=True, capture_step=False):
         """pipeline_teacher: as in GDTrainer - the frozen teacher runs one batch ahead (TeacherPrefetch: hipGraph on a side
-        stream) and step() returns the losses of the batch of the PREVIOUS call (None on the first)."""
+        stream) and step() returns the losses of the batch of the PREVIOUS call (None on the first).
+        capture_step: with pipeline_teacher and use_graph on one GPU, the student step replays as a hipGraph too
+        (_CapturedStep)."""
         from .optim import create_L0_optimizer
         self.student, self.teacher = student, teacher
         self.dtype, self.temperature = dtype, temperature
@@ -1002,6 +1092,8 @@ class ITRTrainer(_StagedExchange):
             teacher_map_filter(student, teacher, with_cross=True)
         self.global_step = 0
         self.prefetch = TeacherPrefetch(self._teacher_forward, use_graph) if pipeline_teacher else None
+        self.capture_step = bool(capture_step and pipeline_teacher and use_graph and next(student.parameters()).is_cuda)
+        self._cap_init()
         enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
         if enc is not None and hasattr(enc, "kd_drop_maps") and not os.environ.get("EVLM_STUDENT_ALL_MAPS"):
             enc.kd_drop_maps = True        # a ViT map whose distillation term was formed in-kernel is not materialised
@@ -1014,13 +1106,20 @@ class ITRTrainer(_StagedExchange):
     def step(self, batch, idx=None, lr_mult=1.0):
         """batch: dict(image, text_ids, text_atts); idx: image ids for the soft ITC labels.  Returns a device tensor
         [total, itc, itm, kd, lagrangian]."""
-        T_ready = None
+        T_ready, key = None, None
         if self.prefetch is not None:
             prev = self.prefetch.submit(dict(batch, idx=idx) if idx is not None else dict(batch))
             if prev is None:
                 return None
             batch, T_ready = prev
             idx = batch.get("idx")
+            key = self.prefetch.last_key
+        out = self._run_step(key, lambda pruned, staged: self._body(batch, idx, T_ready, pruned, lr_mult, staged), lr_mult)
+        self.global_step += 1
+        return out
+
+    def _body(self, batch, idx, T_ready, pruned_steps, lr_mult, staged):
+        """the device work of one step (capturable when T_ready / batch are static and `staged`: schedules set outside)"""
         self.opt.zero_grad()
         l0 = self.student.l0_module
         with compute(self.dtype):
@@ -1037,7 +1136,7 @@ class ITRTrainer(_StagedExchange):
                     lambda: self.teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw),
                     batch["image"], self.overlap_teacher)
             kd = distill.kd_terms(S, T, self.temperature, with_cross_attn=True, fused=fused)
-            lagrangian, _, _ = l0.lagrangian_regularization(self.global_step)
+            lagrangian, _, _ = l0.lagrangian_regularization(pruned_steps)
             total, mix = distill.itr_loss_mix(S["loss"], kd, lagrangian)
             ops.WGRAD_INPLACE = True
             ops.WGRAD_DEFER = [] if self.defer_wgrad else None
@@ -1049,28 +1148,31 @@ class ITRTrainer(_StagedExchange):
                 ops.WGRAD_INPLACE = False
                 ops.WGRAD_DEFER = None
                 ops.LN_DEFER.clear()             # (empty after a flush; stale only when backward raised)
+        if ops.DROPOUT_USED:              # hard-negative draws (device Philox stream): a new step word per step / replay
+            ops.dropout_tick(total.device)
         if self.reducer.active:
             self._reduce_rest()
-        self.opt.set_schedule(lr_mult)
+        if not staged:
+            self.opt.set_schedule(lr_mult)
         self.opt.step()
         self.l0_opt.step()
         self.lagrangian_opt.step()
         l0.constrain_parameters()
-        self.global_step += 1
         return torch.stack([total.detach().float(), S["loss"]["loss_itc"].detach().float(),
                             S["loss"]["loss_itm"].detach().float(), mix["loss_kd"].detach().float(),
                             lagrangian.detach().float().reshape(())])
 
 
-class VQATrainer(_StagedExchange):
+class VQATrainer(_StagedExchange, _CapturedStep):
     """Pruning fine-tune step of Eff_VQA.py:74-200 (visual question answering with hard-concrete L0 gates on the image
     encoder, question encoder AND answer decoder): student forward + backward, teacher forward, the weighted answer LM loss,
     text / fusion / image / decoder hidden + attention KD, logit KD, the Lagrangian, THREE optimisers as in ITRTrainer, no
-    gradient clipping, constrain_parameters().  Eager launch (host-side Lagrangian warm-up counter; the number of answer
-    rows varies from batch to batch)."""
+    gradient clipping, constrain_parameters().  Eager launch by default; capture_step=True replays the student step as a
+    hipGraph per (batch shape, teacher-prefetch parity, stop_prune) - _CapturedStep; a new number of answer rows is a new
+    batch kind and starts with an eager step."""
 
     def __init__(self, student, teacher, lr=5e-5, weight_decay=0.01, lr_mult=2.0, reg_learning_rate=0.1,
-                 dtype=torch.float32, temperature=1.0, pipeline_teacher=False, use_graph=True):
+                 dtype=torch.float32, temperature=1.0, pipeline_teacher=False, use_graph=True, capture_step=False):
         from .optim import create_L0_optimizer
         self.student, self.teacher = student, teacher
         self.dtype, self.temperature = dtype, temperature
@@ -1091,6 +1193,8 @@ class VQATrainer(_StagedExchange):
         self.overlap_teacher = not os.environ.get("EVLM_NO_OVERLAP_TEACHER")
         self.global_step = 0
         self.prefetch = TeacherPrefetch(self._teacher_forward, use_graph) if pipeline_teacher else None
+        self.capture_step = bool(capture_step and pipeline_teacher and use_graph and next(student.parameters()).is_cuda)
+        self._cap_init()
         enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
         if enc is not None and hasattr(enc, "kd_drop_maps") and not os.environ.get("EVLM_STUDENT_ALL_MAPS"):
             enc.kd_drop_maps = True        # a ViT map whose distillation term was formed in-kernel is not materialised
@@ -1105,14 +1209,21 @@ class VQATrainer(_StagedExchange):
     def step(self, batch, lr_mult=1.0, stop_prune=False):
         """batch: dict(image [B], question_ids / question_atts [B, Lq], answer_ids / answer_atts [sum k, La], k [B] (tensor
         or list), weights [sum k]).  Returns a device tensor [total, answer loss, kd, lagrangian]."""
-        from types import SimpleNamespace as NS
-        T_ready = None
+        T_ready, key = None, None
         if self.prefetch is not None:
             batch = dict(batch, k=torch.as_tensor(batch["k"], device=batch["image"].device))
             prev = self.prefetch.submit(batch)
             if prev is None:
                 return None
             batch, T_ready = prev
+            key = None if self.prefetch.last_key is None else self.prefetch.last_key + (bool(stop_prune),)
+        out = self._run_step(key, lambda pruned, staged: self._body(batch, T_ready, pruned, lr_mult, stop_prune, staged), lr_mult)
+        self.global_step += 1
+        return out
+
+    def _body(self, batch, T_ready, pruned_steps, lr_mult, stop_prune, staged):
+        """the device work of one step (capturable when T_ready / batch are static and `staged`: schedules set outside)"""
+        from types import SimpleNamespace as NS
         self.opt.zero_grad()
         l0 = self.student.l0_module
         question = NS(input_ids=batch["question_ids"], attention_mask=batch["question_atts"])
@@ -1130,7 +1241,7 @@ class VQATrainer(_StagedExchange):
                     lambda: self.student(batch["image"], question, answer, stop_prune=stop_prune, **kw),
                     lambda: self.teacher(batch["image"], question, answer, **kw), batch["image"], self.overlap_teacher)
             kd = distill.vqa_kd_terms(S, T, self.temperature, fused=fused)
-            lagrangian, _, _ = l0.lagrangian_regularization(self.global_step)
+            lagrangian, _, _ = l0.lagrangian_regularization(pruned_steps)
             total, mix = distill.vqa_loss_mix(S["loss"], kd, lagrangian)
             ops.WGRAD_INPLACE = True
             ops.WGRAD_DEFER = [] if self.defer_wgrad else None
@@ -1142,13 +1253,15 @@ class VQATrainer(_StagedExchange):
                 ops.WGRAD_INPLACE = False
                 ops.WGRAD_DEFER = None
                 ops.LN_DEFER.clear()             # (empty after a flush; stale only when backward raised)
+        if ops.DROPOUT_USED:              # hard-negative draws (device Philox stream): a new step word per step / replay
+            ops.dropout_tick(total.device)
         if self.reducer.active:
             self._reduce_rest()
-        self.opt.set_schedule(lr_mult)
+        if not staged:
+            self.opt.set_schedule(lr_mult)
         self.opt.step()
         self.l0_opt.step()
         self.lagrangian_opt.step()
         l0.constrain_parameters()
-        self.global_step += 1
         return torch.stack([total.detach().float(), S["loss"].detach().float(), mix["loss_kd"].detach().float(),
                             lagrangian.detach().float().reshape(())])

@@ -1390,7 +1390,48 @@ def test_vqa_training_steps_bf16_track_the_fp32_oracle():
     assert float((la - loga0.to(DEV)).abs().max()) > 0 and float(la.min()) >= math.log(1e-2) - 1e-6 and float(la.max()) <= math.log(1e2) + 1e-6
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
+def test_vqa_captured_student_step_reproduces_the_eager_trajectory():
+    """VQATrainer(pipeline_teacher=True, capture_step=True): the student step replays as a hipGraph per teacher-prefetch
+    parity (first step per parity eager, second captured, then replays) - seven steps on three rotating batches must give
+    the loss trajectory and the final gate parameters of the eager trainer: the Lagrangian ramp comes from the device-side
+    step counter, the gate noise from the per-step draws staged into the static buffers, the three optimisers' bias
+    corrections from their device-side schedules"""
+    from efficientvlm_amd.trainer import VQATrainer
+    geom = synth.GEOMS["tiny"]
+    # (one batch kind: the number of answer rows is part of a batch's shape signature, and a new kind starts eagerly)
+    b0 = {k: v.to(DEV) for k, v in synth.make_vqa_batch(geom, 4, seed=60).items()}
+    batches = [b0, {**b0, "image": b0["image"] * 0.5}, {**b0, "image": b0["image"] + 0.25}]
+    outs, logas = {}, {}
+    for cap in (False, True):
+        student, teacher, s_sd, t_sd, s_cfg, t_cfg = _vqa_models(geom, 41, 42)
+        gen = torch.Generator().manual_seed(6)
+        with torch.no_grad():
+            for n, p in student.l0_module.named_parameters():
+                p.copy_(torch.full_like(p, 0.3) if "lambda" in n else torch.randn(p.shape, generator=gen) + 0.5)
+        student.l0_module.set_lagrangian_warmup_steps(5)
+        student.to(DEV); teacher.to(DEV)
+        eps = [{t: torch.rand(getattr(student.l0_module, O.L0_PARAM[t]).shape, generator=gen).clamp(1e-6, 1 - 1e-6)
+                for t in O.L0_TYPES_VQA} for _ in range(7)]
+        tr = VQATrainer(student, teacher, lr=1e-3, reg_learning_rate=0.05, dtype=torch.float32, pipeline_teacher=True,
+                        capture_step=cap)
+        seq = []
+        for c in range(8):
+            if c >= 1:
+                student.l0_module.injected_eps = {t: e.clone() for t, e in eps[c - 1].items()}
+            o = tr.step(batches[c % 3])
+            if o is not None:
+                seq.append(o.clone())
+        torch.cuda.synchronize()
+        assert len(seq) == 7
+        if cap:
+            assert tr.last_launch == "hipGraph replay" and len(tr._sgraphs) >= 2
+        outs[cap] = torch.stack(seq).cpu()
+        logas[cap] = student.l0_module.decoder_int_loga.detach().cpu().clone()
+    assert torch.allclose(outs[True], outs[False], rtol=5e-4, atol=1e-5), (outs[True], outs[False])
+    assert torch.allclose(logas[True], logas[False], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("use_graph", [False, True, "step"])
 def test_itr_trainer_with_pipelined_teacher_reproduces_the_unpipelined_trajectory(use_graph, monkeypatch):
     """ITRTrainer(pipeline_teacher=True): the frozen teacher runs one batch ahead on a side stream (TeacherPrefetch; a
     hipGraph per parity whose outputs are consumed in place).  Same gate noise and (deterministic) hard negatives on both
@@ -1424,10 +1465,17 @@ def test_itr_trainer_with_pipelined_teacher_reproduces_the_unpipelined_trajector
         student.to(DEV); teacher.to(DEV)
         eps = [{t: torch.rand(getattr(student.l0_module, O.L0_PARAM[t]).shape, generator=gen).clamp(1e-6, 1 - 1e-6)
                 for t in O.L0_TYPES} for _ in range(3)]
+        # "step": the student step itself replays as a hipGraph too (capture_step: first step per teacher parity eager, then
+        # captured) - seven steps, so that both parities are captured AND replayed; the gate noise still comes from the
+        # per-step injected draws, the Lagrangian ramp from the device-side step counter
         tr = ITRTrainer(student, teacher, lr=1e-3, reg_learning_rate=0.05, dtype=torch.float32, pipeline_teacher=pipe,
-                        use_graph=use_graph)
+                        use_graph=bool(use_graph), capture_step=(use_graph == "step"))
         seq = []
-        calls = batches + ([batches[0]] if pipe else [])
+        nsteps = 7 if use_graph == "step" else 3
+        while len(eps) < nsteps:
+            eps.append({t: torch.rand(getattr(student.l0_module, O.L0_PARAM[t]).shape, generator=gen).clamp(1e-6, 1 - 1e-6)
+                        for t in O.L0_TYPES})
+        calls = [batches[i % 3] for i in range(nsteps)] + ([batches[0]] if pipe else [])
         for c, b in enumerate(calls):
             i = c - 1 if pipe else c                        # index of the batch whose student step runs in this call
             if i >= 0:
@@ -1438,6 +1486,8 @@ def test_itr_trainer_with_pipelined_teacher_reproduces_the_unpipelined_trajector
                 seq.append(o.clone())
         torch.cuda.synchronize()
         outs[pipe] = torch.stack(seq).cpu()
+        if pipe and use_graph == "step":
+            assert tr.last_launch == "hipGraph replay" and len(tr._sgraphs) == 2
     assert torch.allclose(outs[True], outs[False], rtol=5e-4, atol=1e-5), (outs[True], outs[False])
     assert float((outs[False][0] - outs[False][2]).abs().max()) > 1e-3
 
