@@ -20,6 +20,7 @@ take the fully fused p = 0 path.  The reference's CUDA RNG stream is not reprodu
 the SAME masks to the oracle (ops.dropout_mask).
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -38,6 +39,8 @@ __all__ = ["BertConfig", "BertModel", "BertForMaskedLM", "BertEmbeddings", "Bert
 # the no-grad cross-attention forward through the fused kernel (evlm_xattn_fused_fwd); False = always the two-launch form
 # (packed K/V GEMM + attention kernel).  Set from the measured comparison in profiles/r02_xattn_fused.md.
 FUSED_CROSS_ATTENTION = False
+# one K/V projection of the image tokens for ALL fusion layers of an encoder (round 4); EVLM_NO_MERGED_KV=1: one per layer
+MERGED_CROSS_KV = not os.environ.get("EVLM_NO_MERGED_KV")
 
 
 def _p(config, name):
@@ -98,7 +101,7 @@ class BertSelfAttention(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_value=None, output_attentions=False, head_z=None,
-                encoder_batch_index=None):
+                encoder_batch_index=None, encoder_kv=None):
         """returns (context [B,L,all_head], probs | None).  masks are additive [B,1,1,Lk] (key masks).
 
         encoder_batch_index (extension): LongTensor [B] mapping each text batch row to its row of encoder_hidden_states,
@@ -120,9 +123,14 @@ class BertSelfAttention(nn.Module):
                                                        mask=_key_mask(encoder_attention_mask), gate=head_z,
                                                        want_probs=bool(output_attentions), kv_index=encoder_batch_index)
                 return ((ctx, probs) if output_attentions else (ctx,)) + (None,)
-            kv = ops.linear_packed(encoder_hidden_states, (self.key.weight, self.value.weight), (self.key.bias, self.value.bias))
+            if encoder_kv is not None and drop == 0.0:          # (BertEncoder projected K/V of every fusion layer at once)
+                kv, col, slot = encoder_kv
+            else:
+                kv, col, slot = ops.linear_packed(encoder_hidden_states, (self.key.weight, self.value.weight),
+                                                  (self.key.bias, self.value.bias)), None, None
             ctx, probs = ops.cross_attention(q, kv, H, dh, scale, mask=_key_mask(encoder_attention_mask), gate=head_z,
-                                             want_probs=bool(output_attentions), kv_index=encoder_batch_index, dropout_p=drop)
+                                             want_probs=bool(output_attentions), kv_index=encoder_batch_index, dropout_p=drop,
+                                             kv_col=col, kv_grad=slot)
         else:
             qkv, self.input_alias = ops.linear_fork(hidden_states, (self.query.weight, self.key.weight, self.value.weight),
                                                     (self.query.bias, self.key.bias, self.value.bias))
@@ -200,9 +208,10 @@ class BertAttention(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_value=None, output_attentions=False, head_z=None, head_layer_z=None,
-                encoder_batch_index=None):
+                encoder_batch_index=None, encoder_kv=None):
         self_outputs = self.self(hidden_states, attention_mask, head_mask, encoder_hidden_states, encoder_attention_mask,
-                                 past_key_value, output_attentions, head_z=head_z, encoder_batch_index=encoder_batch_index)
+                                 past_key_value, output_attentions, head_z=head_z, encoder_batch_index=encoder_batch_index,
+                                 **({} if encoder_kv is None else {"encoder_kv": encoder_kv}))
         residual, self.self.input_alias = self.self.input_alias, None
         attention_output = self.output(self_outputs[0], residual if residual is not None else hidden_states,
                                        head_layer_z=head_layer_z)
@@ -256,7 +265,8 @@ class BertLayer(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_value=None, output_attentions=False, head_z=None,
-                head_layer_z=None, mlp_z=None, encoder_batch_index=None, keep_self_map=True, keep_cross_map=True):
+                head_layer_z=None, mlp_z=None, encoder_batch_index=None, keep_self_map=True, keep_cross_map=True,
+                encoder_kv=None):
         """keep_self_map / keep_cross_map (extension, default = reference behaviour): with output_attentions set, a map
         that is not kept is not materialised and its slot in the returned tuple holds None"""
         if self.has_cross_attention and head_z is not None:
@@ -279,7 +289,8 @@ class BertLayer(nn.Module):
             want_cross = bool(output_attentions) and keep_cross_map
             cross_attention_outputs = self.crossattention(attention_output, attention_mask, head_mask, enc, enc_mask,
                                                           output_attentions=want_cross, head_z=cross_head_z,
-                                                          encoder_batch_index=encoder_batch_index)
+                                                          encoder_batch_index=encoder_batch_index,
+                                                          encoder_kv=None if type(encoder_hidden_states) == list else encoder_kv)
             attention_output = cross_attention_outputs[0]
             outputs = outputs + (cross_attention_outputs[1:-1] if want_cross else ((None,) if output_attentions else ()))
         self.mlp_z = mlp_z
@@ -311,6 +322,27 @@ class BertEncoder(nn.Module):
         self.attn_keep = None
         self.cross_keep = None
 
+    def _merged_cross_kv(self, layers, enc, enc_index):
+        """{layer index: (merged K/V buffer, first column, gradient slot)} - the cross-attention K / V of every fusion layer
+        in `layers` from ONE product over the image tokens (N = n * 2 * all_head_size instead of n products of N = 2 *
+        all_head_size: eff_bert.py:284-296 per layer).  Empty when the layers cannot share a buffer (fp32 parity path,
+        physically pruned projections of different widths, dropout on the probabilities, a list of encoder states)."""
+        xl = [i for i in layers if self.layer[i].has_cross_attention]
+        if (not MERGED_CROSS_KV or len(xl) < 2 or enc is None or type(enc) == list or not enc.is_cuda
+                or enc.dtype != torch.bfloat16 or enc.dim() != 3 or enc.shape[1] > 928):
+            return {}
+        sas = [self.layer[i].crossattention.self for i in xl]
+        d = sas[0].all_head_size
+        if any(sa.all_head_size != d or sa.attention_head_size != 64 or sa.key.bias is None or sa.value.bias is None
+               or (self.training and sa.attention_probs_dropout_prob > 0.0) for sa in sas) or d % 8 != 0:
+            return {}
+        if enc_index is None and FUSED_CROSS_ATTENTION:
+            return {}
+        ws = [w for sa in sas for w in (sa.key.weight, sa.value.weight)]
+        bs = [b for sa in sas for b in (sa.key.bias, sa.value.bias)]
+        kv, slot = ops.merged_kv(enc, ws, bs, len(xl))
+        return {i: (kv, 2 * d * n, slot) for n, i in enumerate(xl)}
+
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_values=None, use_cache=None, output_attentions=False,
                 output_hidden_states=False, return_dict=True, mode="multi_modal", head_z=None, head_layer_z=None, mlp_z=None,
@@ -326,6 +358,7 @@ class BertEncoder(nn.Module):
             start_layer, output_layer = 0, self.config.num_hidden_layers
         else:
             raise ValueError(f"mode {mode} is not supported")
+        merged = self._merged_cross_kv(range(start_layer, output_layer), encoder_hidden_states, encoder_batch_index)
         for i in range(start_layer, output_layer):
             layer_module = self.layer[i]
             if output_hidden_states:
@@ -345,7 +378,8 @@ class BertEncoder(nn.Module):
                                          mlp_z=cur_mlp_z if mlp_z is not None else None,
                                          encoder_batch_index=encoder_batch_index,
                                          keep_self_map=self.attn_keep is None or i in self.attn_keep,
-                                         keep_cross_map=self.cross_keep is None or i in self.cross_keep)
+                                         keep_cross_map=self.cross_keep is None or i in self.cross_keep,
+                                         encoder_kv=merged.get(i))
             hidden_states = layer_outputs[0]
             if output_attentions:
                 all_self_attentions = all_self_attentions + (layer_outputs[1],)

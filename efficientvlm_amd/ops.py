@@ -902,7 +902,7 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qbuf, kvbuf, mask, gate, H, dh, q_off, k_off, v_off, scale, want_probs, kv_index=None, causal=False,
-                dropout_p=0.0, kd_teacher=None, kd_weight=1.0, p_out=None):
+                dropout_p=0.0, kd_teacher=None, kd_weight=1.0, p_out=None, kv_grad=None):
         L.require_cuda(qbuf, kvbuf)
         assert qbuf.is_contiguous() and kvbuf.is_contiguous()
         B, Lq, ldq = qbuf.shape
@@ -967,6 +967,7 @@ class _Attention(torch.autograd.Function):
         ctx.causal = int(bool(causal))
         ctx.drop = drop
         ctx.kd_weight = float(kd_weight) if kd_teacher is not None else 0.0
+        ctx.kv_grad = kv_grad
         return O, P, kd
 
     @staticmethod
@@ -988,9 +989,21 @@ class _Attention(torch.autograd.Function):
                 dPc = torch.zeros((B, H, Lq, Lkp), dtype=tdt, device=dev)
                 dPc[..., :Lk].copy_(dP)
         d = H * dh
-        assert ldq == (3 * d if self_attn else d) and ldk == (3 * d if self_attn else 2 * d), "packed buffers must be exact"
+        slot = ctx.kv_grad
+        assert ldq == (3 * d if self_attn else d) and (ldk == (3 * d if self_attn else 2 * d) or slot is not None), \
+            "packed buffers must be exact"
         dqbuf = torch.empty_like(qbuf)                       # the kernels write every element of the packed grads
-        dkvbuf = dqbuf if self_attn else torch.empty_like(kvbuf)
+        if slot is not None:
+            # K/V columns of a projection merged over several layers (KVGradSlot): every consumer writes its own columns of
+            # ONE gradient buffer; the first to run hands the buffer to autograd, the others hand back nothing - no
+            # [Bkv, Lk, n * 2d] additions, no zero fill
+            first = slot.buf is None
+            if first:
+                slot.buf = torch.empty_like(kvbuf)
+            dkvbuf = slot.buf
+            slot.count += 1
+        else:
+            dkvbuf = dqbuf if self_attn else torch.empty_like(kvbuf)
         # dS workspace of the two-kernel path; the single-pass kernel (self-attention problems that fit one workgroup,
         # attention_mfma.hip) keeps dS in LDS and takes none
         single_pass = (tdt == torch.bfloat16 and dh == 64 and kv_index is None and Lq <= 224 and Lk <= 224
@@ -1020,8 +1033,10 @@ class _Attention(torch.autograd.Function):
             ATTN_FLOPS[0] += (10.0 if lse is not None else 8.0) * B * H * Lq * Lk * dh     # dP, dV, dQ, dK (+ S when P is recomputed)
         dg = dgate.view(gshape) if dgate is not None else None
         if self_attn:
-            return (dqbuf, None, None, dg) + (None,) * 13
-        return (dqbuf, dkvbuf, None, dg) + (None,) * 13
+            return (dqbuf, None, None, dg) + (None,) * 14
+        if slot is not None and not first:
+            return (dqbuf, None, None, dg) + (None,) * 14
+        return (dqbuf, dkvbuf, None, dg) + (None,) * 14
 
 
 def self_attention(qkv, H, dh, scale, mask=None, gate=None, want_probs=True, causal=False, dropout_p=0.0,
@@ -1055,17 +1070,63 @@ def attention_kd_fusable(x, H, dh, Lk):
     return x.is_cuda and x.dtype == torch.bfloat16 and dh == 64 and Lk <= 928
 
 
-def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True, kv_index=None, dropout_p=0.0):
+class KVGradSlot:
+    """gradient buffer shared by the `n` attention calls that read their K / V out of ONE merged projection (see
+    merged_kv): allocated by the first backward that runs, complete when all `n` have written their columns"""
+
+    def __init__(self, n):
+        self.buf, self.expected, self.count = None, int(n), 0
+
+
+class _KVJoin(torch.autograd.Function):
+    """identity between a merged K/V projection and its consumers: checks, when the gradient passes, that every consumer
+    has written its columns of the shared buffer (a fusion layer whose output went unused would leave its columns
+    uninitialised)"""
+
+    @staticmethod
+    def forward(ctx, kv, slot):
+        ctx.slot = slot
+        return kv.view_as(kv)
+
+    @staticmethod
+    def backward(ctx, g):
+        slot = ctx.slot
+        buf, count = slot.buf, slot.count
+        slot.buf, slot.count = None, 0
+        if g is not None and (buf is None or g.data_ptr() != buf.data_ptr() or count != slot.expected):
+            raise RuntimeError(f"merged K/V projection: {count} of {slot.expected} consumers produced a gradient "
+                               "(every layer reading the merged buffer must take part in backward)")
+        return g, None
+
+
+def merged_kv(x, weights, biases, n):
+    """K/V of `n` cross-attention layers that read the same tokens in ONE product: x [Bkv, Lk, K] -> ([Bkv, Lk, n * 2d]
+    holding k_0 | v_0 | k_1 | v_1 ..., KVGradSlot | None).  eff_bert.py:284-296 issues one Linear pair per layer; the
+    arithmetic per output column is the same."""
+    kv = linear_packed(x, tuple(weights), tuple(biases))
+    if not (torch.is_grad_enabled() and kv.requires_grad):
+        return kv, None
+    slot = KVGradSlot(n)
+    return _KVJoin.apply(kv, slot), slot
+
+
+def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True, kv_index=None, dropout_p=0.0,
+                    kv_col=None, kv_grad=None):
     """q: [B, Lq, H*dh]; kv: [Bkv, Lk, 2*H*dh] packed (k | v).  kv_index (int32 [B]) maps each query batch to its K/V
-    row, so image tokens shared by several text batches are projected (and their gradient reduced) once."""
+    row, so image tokens shared by several text batches are projected (and their gradient reduced) once.
+    kv_col / kv_grad: kv is a merged buffer (merged_kv) and this call's k | v start at column kv_col."""
     d = H * dh
+    k_off = 0 if kv_col is None else int(kv_col)
     if kv_index is not None:
         if q.dtype == torch.bfloat16 and dh == 64 and kv.shape[1] <= 928 and not dropout_p:
             kv_index = kv_index.to(torch.int32).contiguous()
         else:                                   # exact-fp32 / generic path: materialise the gather (autograd scatters back)
+            if kv_col is not None:
+                raise RuntimeError("merged K/V buffers need the in-kernel K/V index (bf16, dh = 64, no dropout)")
             kv = torch.index_select(kv, 0, kv_index.long())
             kv_index = None
-    return _Attention.apply(q, kv, mask, gate, H, dh, 0, 0, d, scale, want_probs, kv_index, False, dropout_p)[:2]
+    return _Attention.apply(q, kv, mask, gate, H, dh, 0, k_off, k_off + d, scale, want_probs, kv_index, False, dropout_p,
+                            None, 1.0, None, kv_grad)[:2]
 
 
 _PIN_CHUNKS, _PIN_USED = [], 0            # pinned int64 chunks (every one stays alive: pending uploads read them)

@@ -23,20 +23,30 @@ _QKV_RANK = {"q_proj": 0, "k_proj": 1, "v_proj": 2, "query": 0, "key": 1, "value
 
 
 def _pack_order(named):
-    """forward (registration) order, except that the q / k / v projections of one attention module are placed in the
-    order the fused QKV / KV GEMMs pack them (CLIP registers k, v, q), so that the packed operand is ONE contiguous
-    slab range and needs no gather copy."""
+    """forward (registration) order, except that (1) the q / k / v projections of one attention module are placed in the
+    order the fused QKV / KV GEMMs pack them (CLIP registers k, v, q) and (2) the cross-attention key / value projections of
+    ALL fusion layers of one encoder follow each other (k_i, v_i, k_i+1, v_i+1, ...: BertEncoder projects the image tokens
+    for every fusion layer in one product), so that each packed operand is ONE contiguous slab range and needs no gather
+    copy."""
     first = {}
-    for idx, (n, _) in enumerate(named):
+    def slot(n):
         parts = n.split(".")
         if len(parts) >= 2 and parts[-2] in _QKV_RANK:
-            first.setdefault((".".join(parts[:-2]), parts[-1]), idx)
+            if (len(parts) >= 6 and parts[-4:-2] == ["crossattention", "self"] and parts[-6] == "layer"
+                    and parts[-5].isdigit() and parts[-2] in ("key", "value")):
+                return (".".join(parts[:-5]) + ".crossattention.kv", parts[-1]), (int(parts[-5]), _QKV_RANK[parts[-2]])
+            return (".".join(parts[:-2]), parts[-1]), (0, _QKV_RANK[parts[-2]])
+        return None, None
+    for idx, (n, _) in enumerate(named):
+        k, _r = slot(n)
+        if k is not None:
+            first.setdefault(k, idx)
     def key(item):
         idx, (n, _) = item
-        parts = n.split(".")
-        if len(parts) >= 2 and parts[-2] in _QKV_RANK:
-            return (first[(".".join(parts[:-2]), parts[-1])], _QKV_RANK[parts[-2]])
-        return (idx, 0)
+        k, r = slot(n)
+        if k is not None:
+            return (first[k],) + r
+        return (idx, 0, 0)
     return [it for _, it in sorted(enumerate(named), key=key)]
 
 

@@ -52,12 +52,33 @@ def case(Bimg, rows_per_img, Lq=30, N=197, H=12, probs=False):
         kvonly = bench(lambda: ops.linear_packed(x, (Wk, Wv), (bk, bv)))
         kv0 = ops.linear_packed(x, (Wk, Wv), (bk, bv))
         attn_only = bench(lambda: ops.cross_attention(q, kv0, H, dh, scale, want_probs=probs, kv_index=idx))
+        # the training path (round 4): ONE K/V projection for the n fusion layers of the encoder (n = 3 student, 6 teacher),
+        # each layer's attention reading its columns of the merged buffer - per layer: merged GEMM / n + attention
+        mer = {}
+        for n in (3, 6):
+            Ws = [torch.nn.Parameter(torch.randn(d, d, device=dev) * 0.03, requires_grad=False) for _ in range(2 * n)]
+            bs = [torch.nn.Parameter(torch.randn(d, device=dev) * 0.1, requires_grad=False) for _ in range(2 * n)]
+            kvm, _ = ops.merged_kv(x, Ws, bs, n)
+            tg = bench(lambda: ops.merged_kv(x, Ws, bs, n), reps=10)
+            ta = bench(lambda: ops.cross_attention(q, kvm, H, dh, scale, want_probs=probs, kv_index=idx, kv_col=2 * d))
+            def layers():
+                kv_, _ = ops.merged_kv(x, Ws, bs, n)
+                for i in range(n):
+                    ops.cross_attention(q, kv_, H, dh, scale, want_probs=probs, kv_index=idx, kv_col=2 * d * i)
+            tl = bench(layers, reps=6) / n
+            mer[n] = (tg / n, ta, tl)
+            del Ws, bs, kvm
     fl = 2.0 * Bimg * N * d * 2 * d + 4.0 * Bq * H * Lq * N * dh
     rec = dict(Bimg=Bimg, Bq=Bq, Lq=Lq, N=N, probs=probs, gflop=round(fl / 1e9, 2), composite_us=round(tc, 1),
                composite_kv_gemm_us=round(kvonly, 1), composite_attention_us=round(attn_only, 1), fused_us=round(tf, 1),
                composite_tflops=round(fl / tc / 1e6, 1), fused_tflops=round(fl / tf / 1e6, 1),
                composite_mfma_frac=round(fl / tc / 1e6 / PEAK, 4), fused_mfma_frac=round(fl / tf / 1e6 / PEAK, 4),
                max_rel_err_O=err, max_abs_err_P=perr)
+    for n, (tg, ta, tl) in mer.items():
+        rec[f"merged{n}_kv_gemm_us_per_layer"] = round(tg, 1)
+        rec[f"merged{n}_attention_us"] = round(ta, 1)
+        rec[f"merged{n}_composite_us_per_layer"] = round(tl, 1)
+        rec[f"merged{n}_mfma_frac"] = round(fl / tl / 1e6 / PEAK, 4)
     print(json.dumps(rec), flush=True)
 
 case(64, 4)                  # the batched fusion pass of a GD step: [pos ; neg ; neg ; mlm] text rows over 64 images
