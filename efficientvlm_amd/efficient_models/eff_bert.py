@@ -516,12 +516,12 @@ class BertModel(BertPreTrainedModel):
             if is_decoder:                      # causal AND padding: see CausalMask
                 if attention_mask.shape[1] != input_shape[1]:
                     raise NotImplementedError("prefix (past_key_values) masks are off the training path")
-                return CausalMask((1.0 - attention_mask[:, None, None, :].to(dtype=torch.float32)) * -10000.0)
+                return CausalMask(ops.additive_mask(attention_mask[:, None, None, :]))
             ext = attention_mask[:, None, None, :]
         else:
             raise ValueError("Wrong shape for input_ids (shape {}) or attention_mask (shape {})".format(
                 input_shape, attention_mask.shape))
-        return (1.0 - ext.to(dtype=torch.float32)) * -10000.0
+        return ops.additive_mask(ext)
 
     def invert_attention_mask(self, encoder_attention_mask):
         """transformers 4.12.5 ModuleUtilsMixin.invert_attention_mask: (1 - m) * -10000 (fp32)"""
@@ -529,7 +529,7 @@ class BertModel(BertPreTrainedModel):
             ext = encoder_attention_mask[:, None, :, :]
         else:
             ext = encoder_attention_mask[:, None, None, :]
-        return (1.0 - ext.to(dtype=torch.float32)) * -10000.0
+        return ops.additive_mask(ext)
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
                 inputs_embeds=None, encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,

@@ -551,7 +551,7 @@ _CONST = {}
 
 def const_tensor(kind, n, device):
     """small index / label tensors that depend on a batch size only - built once per (kind, n, device) instead of two or three
-    launches per forward: "arange" = 0..n-1 (int64), "itm_labels" = n ones then 2n zeros (int64: positives, hard negatives).
+    launches per forward: "arange" = 0..n-1 (int64), "itm_labels" = n ones then 2n zeros (int64: positives, hard negatives), "mask_table" = (-10000, -0) for additive_mask.
     Read-only by contract.  (Not cached when first asked for inside a hipGraph capture: the tensor would live in that
     graph's pool.)"""
     key = (kind, int(n), str(device))
@@ -559,6 +559,8 @@ def const_tensor(kind, n, device):
     if t is None:
         if kind == "arange":
             t = torch.arange(n, device=device)
+        elif kind == "mask_table":        # additive_mask: (1 - m) * -10000 for m = 0, 1 (-0.0 for m = 1, as the product gives)
+            t = torch.tensor([-10000.0, -0.0], dtype=torch.float32, device=device)
         elif kind == "itm_labels":
             t = torch.cat([torch.ones(n, dtype=torch.long, device=device), torch.zeros(2 * n, dtype=torch.long, device=device)])
         else:
@@ -566,6 +568,14 @@ def const_tensor(kind, n, device):
         if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
             _CONST[key] = t
     return t
+
+
+def additive_mask(mask):
+    """(1.0 - mask.float()) * -10000.0 (eff_bert.py:953-1013, transformers' invert_attention_mask): ONE gather launch for a
+    0/1 integer mask on the GPU instead of cast + rsub + mul; the same bits (-0.0 where the mask is 1)"""
+    if mask.is_cuda and mask.dtype in (torch.int64, torch.int32, torch.uint8, torch.bool):
+        return const_tensor("mask_table", 2, mask.device)[mask.long()]
+    return (1.0 - mask.to(dtype=torch.float32)) * -10000.0
 
 
 _SCRATCH = {}
@@ -652,8 +662,15 @@ def _linear_backward(ctx, dy, dx_add):
             if dtype == L.BF16 and N % 64 != 0 and N >= 4096 and M <= 2048 and ldd >= n64 and act == L.ACT_NONE:
                 # skinny product with a vocabulary-sized ragged reduction (MLM decoder): zero-pad W's rows to a multiple
                 # of 64 (dY's padding columns are zero already) so the split-K f32 path applies, then cast once
-                Wp = _scratch(("wpad", n64, K), (n64, K), x2.dtype, x2.device, zero=True)
-                Wp[:N].copy_(W)
+                # The rows past N only ever meet dY's zero padding columns, so any FINITE words serve: when W is a view into
+                # the optimiser's bf16 slab with n64 - N more rows of slab behind it (other parameters, or the slab's zero
+                # padding), the product reads the slab in place - no 47 MB copy of the vocabulary matrix per step
+                Wp = None
+                if W.is_contiguous() and W.storage_offset() + n64 * K <= W.untyped_storage().nbytes() // W.element_size():
+                    Wp = torch.as_strided(W, (n64, K), (K, 1))
+                if Wp is None:
+                    Wp = _scratch(("wpad", n64, K), (n64, K), x2.dtype, x2.device, zero=True)
+                    Wp[:N].copy_(W)
                 d32 = torch.empty((M, K), dtype=torch.float32, device=x2.device)      # (a split reduction zero-fills its output itself)
                 _gemm(dtype, d2, Wp, d32, M, K, n64, ldd, K, K, p_trans=0, q_trans=1, c_f32=1)
                 dxb = cast(d32, x2.dtype)
