@@ -1233,6 +1233,68 @@ def test_grouped_cross_attention_forward_is_bit_identical_to_the_per_batch_kerne
     assert torch.equal(O1, O2) and torch.equal(P1, P2)
 
 
+@pytest.mark.parametrize("n,Bimg,rows,Lq,Lk,H", [(3, 5, 4, 30, 197, 12), (6, 3, 1, 17, 100, 4), (2, 4, 3, 30, 197, 12)])
+def test_merged_kv_projection_equals_one_projection_per_layer(n, Bimg, rows, Lq, Lk, H):
+    """ops.merged_kv (ONE K/V product of the image tokens for the n fusion layers of an encoder, every layer's attention
+    reading / differentiating its columns of the merged buffers) against n separate packed projections
+    (eff_bert.py:284-296 per layer): the forward is bit-identical (an output column's reduction does not depend on how many
+    columns the product has), the weight / bias gradients agree to f32 rounding (dY^T X per column block); the gradient of the image
+    tokens is ONE product over n * 2d columns instead of n products added in bf16 - compared at bf16 resolution.  A consumer
+    that stays out of backward is an error, not a silently uninitialised column block."""
+    o = ops()
+    from efficientvlm_amd.runtime import compute
+    dh, d, K = 64, H * 64, 768
+    g = torch.Generator().manual_seed(500 + n)
+    x0 = rnd((Bimg, Lk, K), torch.bfloat16, g)
+    Ws = [torch.nn.Parameter((torch.randn(d, K, generator=g) * 0.03).to(DEV)) for _ in range(2 * n)]
+    bs = [torch.nn.Parameter((torch.randn(d, generator=g) * 0.1).to(DEV)) for _ in range(2 * n)]
+    qs = [rnd((Bimg * rows, Lq, d), torch.bfloat16, g) for _ in range(n)]
+    gOs = [rnd((Bimg * rows, Lq, d), torch.bfloat16, g) for _ in range(n)]
+    idx = (torch.arange(Bimg).repeat(rows)[torch.randperm(Bimg * rows, generator=g)]).to(DEV) if rows > 1 else None
+
+    def run(merged, skip_last=False):
+        for p_ in Ws + bs:
+            p_.grad = None
+        x = x0.clone().requires_grad_(True)
+        ql = [q.clone().requires_grad_(True) for q in qs]
+        with compute(torch.bfloat16):
+            if merged:
+                kv, slot = o.merged_kv(x, Ws, bs, n)
+                assert slot is not None and kv.shape[-1] == 2 * d * n
+                outs = [o.cross_attention(ql[i], kv, H, dh, 0.125, want_probs=False, kv_index=idx, kv_col=2 * d * i, kv_grad=slot)[0]
+                        for i in range(n)]
+            else:
+                outs = [o.cross_attention(ql[i], o.linear_packed(x, (Ws[2 * i], Ws[2 * i + 1]), (bs[2 * i], bs[2 * i + 1])), H, dh,
+                                          0.125, want_probs=False, kv_index=idx)[0] for i in range(n)]
+            use = outs[:-1] if skip_last else outs
+            sum((O.float() * gO.float()).sum() for O, gO in zip(use, gOs)).backward()
+        return ([O.detach() for O in outs], x.grad, [q.grad for q in ql[:len(use)]], [p_.grad.clone() for p_ in Ws + bs])
+
+    a, b = run(True), run(False)
+    for Oa, Ob in zip(a[0], b[0]):
+        assert torch.equal(Oa, Ob)
+    for qa, qb in zip(a[2], b[2]):
+        assert torch.equal(qa, qb)
+    for ga, gb in zip(a[3], b[3]):          # (f32 split reductions: the number of splits follows the tile count)
+        assert rel_err(ga, gb) < 1e-5
+    assert rel_err(a[1], b[1]) < 2e-2       # one product over n * 2d columns against n products added in bf16
+    with pytest.raises(RuntimeError, match="merged K/V projection"):
+        run(True, skip_last=True)
+
+
+def test_additive_mask_is_one_gather_with_the_reference_bits():
+    """(1 - m) * -10000 (eff_bert.py:953-1013) from a two-entry table: the same bits, -0.0 where the mask is 1"""
+    o = ops()
+    m = (torch.rand(7, 30) > 0.3).long().to(DEV)
+    for view in (m[:, None, None, :], m[:, None, :, None].expand(7, 1, 30, 30), m.bool()[:, None, None, :], m.int()):
+        got = o.additive_mask(view)
+        want = (1.0 - view.to(torch.float32)) * -10000.0
+        assert got.dtype == torch.float32 and got.shape == want.shape
+        assert torch.equal(got.view(torch.int32), want.contiguous().view(torch.int32))
+    f = torch.rand(3, 5, device=DEV)
+    assert torch.equal(o.additive_mask(f), (1.0 - f) * -10000.0)
+
+
 def test_attention_lse_form_refuses_what_it_cannot_serve():
     """C ABI: the lse / recompute form exists for bf16, head dim 64, Lk <= 224 without dropout; anything else answers with
     an error code - never a fault - and evlm_attention_lse_supported says so beforehand"""

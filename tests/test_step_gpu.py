@@ -299,7 +299,7 @@ def test_benchmarked_configuration_matches_the_oracle(B):
     # key projections 8-9 %, every other query / key projection <= 5.3 %).
     rels = sorted(r for r, _, _ in stats)
     assert num / math.sqrt(da * db) > 0.9999, (num / math.sqrt(da * db), worst)
-    assert all(r < 0.25 and c > 0.97 for r, c, _ in stats), worst
+    assert all(r < 0.20 and c > 0.97 for r, c, _ in stats), worst      # (measured worst 17 %: a regression shows)
     qk = [r for r, _, n in stats if any(t in n for t in ("q_proj", "k_proj", ".query.", ".key."))]
     assert max(qk) < 0.12 and sorted(qk)[len(qk) // 2] < 0.02, sorted(qk)[-3:]
     assert rels[len(rels) // 2] < 0.01 and rels[int(0.9 * len(rels))] < 0.03, (rels[len(rels) // 2], rels[int(0.9 * len(rels))])
