@@ -26,7 +26,7 @@ batch = {k: v.to(dev) for k, v in synth.make_batch(geom, B, seed=5).items()}
 idx = torch.arange(B, device=dev)
 for _ in range(6): out = tr.step(batch, idx=idx)      # (prime, one eager step per parity, one capture per parity)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-K = 10
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 for _ in range(K): out = tr.step(batch, idx=idx)
 host = (time.perf_counter() - t0) / K      # host time per step (before the device has caught up)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K

@@ -34,7 +34,7 @@ for key in ("answer_ids", "answer_atts", "weights"):
 batch = {k: v.to(dev) for k, v in batch.items()}
 for _ in range(6): out = tr.step(batch)      # (prime, one eager step per parity, one capture per parity)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-K = 8
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 for _ in range(K): out = tr.step(batch)
 host = (time.perf_counter() - t0) / K      # host time per step (before the device has caught up)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
