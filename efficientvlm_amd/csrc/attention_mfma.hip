@@ -425,6 +425,226 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_kernel(MAttnF a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Long key sequences (225..928 keys: the ViT at 384 x 384 / 480 x 480, cross-attention onto those image tokens) when
+// nobody takes the map: a STREAMING forward.  The whole-row kernel above keeps all 38 / 58 score tiles of a query tile in
+// registers (256 VGPRs + 197 AGPRs: one wave per SIMD) and K and V of a (batch, head) whole in LDS (152 KiB: one 4-wave
+// workgroup per CU, every 64 queries stage the full 148 KiB again - 1.1 GB of staging per ViT layer at 577 tokens, 488 us
+// for 65 GFLOP, 1 086 us with the fused distillation term).  Here K and V pass through LDS in BLOCKS of 128 keys,
+// double-buffered (64 KiB; the next block's LDS-DMA is in flight under the current block's arithmetic, one barrier per
+// block), and a wave keeps only the current block's 8 score tiles plus the running row maximum m, row sum l and the
+// un-normalised context (online softmax): ~110 VGPRs, 16 waves = 256 queries per workgroup, so K / V of a (batch, head)
+// are streamed 3 times at 577 queries instead of 10.  The row's lse = m + log2 l is what the recomputing backward wants.
+// Fused map distillation in the same pass: sum_k (p - pt)^2 with p = e / l is  (sum e^2) / l^2 - 2 (sum e pt) / l + sum pt^2
+// - three running sums over the un-normalised e, rescaled with the maximum like l; the backward's row term
+// sum_k p (p - pt) = (sum e^2) / l^2 - (sum e pt) / l comes out of the same sums.
+// Workgroups of one (batch, head) are mapped to ONE XCD (consecutive logical ids share an L2).
+template <int SW>
+__device__ __forceinline__ void stage_block(const bf16* base, int ld, int L, int key0, int nrows, int nw, char* sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r0 = wave * 8; r0 < nrows; r0 += nw * 8) {
+    const int row = r0 + (lane >> 3), cs = lane & 7;
+    const int c = swz<SW>(row, cs);
+    const int key = min(key0 + row_key(row), L - 1);
+    const bf16* src = base + (size_t)key * ld + c * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(sm + r0 * 128), 16, 0, 0);
+  }
+}
+
+template <int NW, bool LSE>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
+  constexpr int KBT = 8, KB = KBT * 16;                  // 128 keys per block
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nblk = (a.Lk + KB - 1) / KB;
+  float* Ms = reinterpret_cast<float*>(smem + 4 * KB * 128);     // [nblk * KB] additive mask (+ -1e30 beyond Lk)
+  float* kdw = Ms + nblk * KB;
+  // XCD-aware map: hardware workgroup id i runs on XCD i % 8; logical ids (i % 8) * (n / 8) + i / 8 are then consecutive
+  // per XCD, and the gridDim.x query blocks of one (batch, head) - consecutive logical ids - share an L2
+  const int gx = gridDim.x, nwg = gx * gridDim.y * gridDim.z;
+  int lid = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int qblk = lid % gx, h = (lid / gx) % a.H, b = lid / (gx * a.H);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
+  const int q0 = (qblk * NW + wave) * 16;
+  const int q = q0 + ql;
+  const bool active = q0 < a.Lq, qok = q < a.Lq;         // (waves past the last query still stage and meet the barriers)
+  if (!LSE && a.skip_dead && a.gate && !a.Pt && a.gate[h] == 0.f) {        // closed head, zero context (workgroup-uniform)
+    if (qok) {
+      bf16* Or = a.O + ((size_t)b * a.Lq + q) * a.ldo + h * DH + g * 16;
+      *reinterpret_cast<uint4*>(Or) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(Or + 8) = make_uint4(0, 0, 0, 0);
+    }
+    return;
+  }
+  const int bkv = a.kv_index ? a.kv_index[b] : b;
+  const bf16* Kb = a.K + (size_t)bkv * a.Lk * a.ldk + h * DH;
+  const bf16* Vb = a.V + (size_t)bkv * a.Lk * a.ldv + h * DH;
+  for (int k = threadIdx.x; k < nblk * KB; k += blockDim.x)
+    Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
+  if (threadIdx.x < 2) kdw[threadIdx.x] = 0.f;
+  bf16x8 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (qok) v = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + ks * 32 + g * 8);
+    qf[ks] = *reinterpret_cast<bf16x8*>(&v);
+  }
+  stage_block<SW_K>(Kb, a.ldk, a.Lk, 0, KB, NW, smem);
+  stage_block<SW_V>(Vb, a.ldv, a.Lk, 0, KB, NW, smem + KB * 128);
+  const float sc = a.scale * 1.44269504088896341f;
+  const bool kd_on = LSE && a.Pt != nullptr && qok;
+  const bf16* Tr = kd_on ? a.Pt + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr : nullptr;
+  float m = -3.0e38f, l = 0.f, se2 = 0.f, sep = 0.f, spt = 0.f;
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int blk = 0; blk < nblk; ++blk) {
+    stage_wait();
+    __syncthreads();                                     // block blk has landed; everyone is done with the other buffer
+    // the teacher map's piece for this block is requested BEFORE the next block's DMA: vmcnt counts in order, a wait for
+    // a load issued behind the DMA would drain the DMA with it
+    bf16x8 t8[KBT / 2];
+    if (kd_on) {
+#pragma unroll
+      for (int s2 = 0; s2 < KBT / 2; ++s2) {
+        const int kcol = blk * KB + s2 * 32 + g * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (kcol < a.ldpr) v = *reinterpret_cast<const uint4*>(Tr + kcol);
+        t8[s2] = *reinterpret_cast<bf16x8*>(&v);
+      }
+    }
+    if (blk + 1 < nblk) {
+      char* nb = smem + ((blk + 1) & 1) * 2 * KB * 128;
+      stage_block<SW_K>(Kb, a.ldk, a.Lk, (blk + 1) * KB, KB, NW, nb);
+      stage_block<SW_V>(Vb, a.ldv, a.Lk, (blk + 1) * KB, KB, NW, nb + KB * 128);
+    }
+    if (!active) continue;                               // (wave-uniform)
+    const char* Ks = smem + (blk & 1) * 2 * KB * 128;
+    const char* Vs = Ks + KB * 128;
+    f32x4 acc[KBT];
+#pragma unroll
+    for (int t = 0; t < KBT; ++t) {
+      acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Ks, t, ks, lane), qf[ks], acc[t], 0, 0, 0);
+    }
+    float bm = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < KBT; ++t) {
+      const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + blk * KB + tile_key0(t, g));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[t][r] = fmaf(acc[t][r], sc, mk[r] * LOG2E);   // (the recomputing backward forms the same number)
+        bm = fmaxf(bm, acc[t][r]);
+      }
+    }
+    bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    const float mn = fmaxf(m, bm);
+    const float alpha = EXP2(m - mn);                    // (first block: 2^(-3e38) = 0 on l = 0, o = 0)
+    m = mn;
+    l *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+#pragma unroll
+    for (int t = 0; t < KBT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[t][r] = EXP2(acc[t][r] - mn);
+        l += acc[t][r];                                  // (this lane's keys; the lane groups meet after the last block)
+      }
+    if (kd_on) {
+      se2 *= alpha * alpha;
+      sep *= alpha;
+#pragma unroll
+      for (int s2 = 0; s2 < KBT / 2; ++s2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e0 = acc[2 * s2][r], e1 = acc[2 * s2 + 1][r];
+          const float p0 = (float)t8[s2][r], p1 = (float)t8[s2][4 + r];
+          se2 = fmaf(e0, e0, se2); se2 = fmaf(e1, e1, se2);
+          sep = fmaf(e0, p0, sep); sep = fmaf(e1, p1, sep);
+          spt = fmaf(p0, p0, spt); spt = fmaf(p1, p1, spt);
+        }
+    }
+    // O^T += V^T E^T with the un-normalised e (<= 1) as bf16: the row's 1 / l is applied once, to the context
+#pragma unroll
+    for (int s2 = 0; s2 < KBT / 2; ++s2) {
+      bf16x8 pb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pb[r] = (bf16)acc[2 * s2][r]; pb[4 + r] = (bf16)acc[2 * s2 + 1][r]; }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Vs, 2 * s2, 2 * s2 + 1, dt, lane), pb, o[dt], 0, 0, 0);
+    }
+  }
+  float sq = 0.f;
+  if (active) {
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (LSE && qok && g == 0) a.lse[((size_t)b * a.H + h) * a.Lq + q] = m + __log2f(l);
+    if (qok) {
+      const float gz = (a.gate ? a.gate[h] : 1.0f) * inv;
+      bf16* Or = a.O + ((size_t)b * a.Lq + q) * a.ldo + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 ov = {(bf16)(o[dt][0] * gz), (bf16)(o[dt][1] * gz), (bf16)(o[dt][2] * gz), (bf16)(o[dt][3] * gz)};
+        *reinterpret_cast<bf16x4*>(Or + dt * 16 + g * 4) = ov;
+      }
+    }
+    if (LSE && a.Pt) {
+      if (kd_on) sq = fmaf(se2 * inv, inv, fmaf(-2.f * sep, inv, spt));
+      if (a.rkd) {
+        float rk = kd_on ? fmaf(se2 * inv, inv, -sep * inv) : 0.f;
+        rk += __shfl_xor(rk, 16, 64);
+        rk += __shfl_xor(rk, 32, 64);
+        if (qok && g == 0) a.rkd[((size_t)b * a.H + h) * a.Lq + q] = rk;
+      }
+    }
+  }
+  if (LSE && a.Pt) {                                     // one atomic per workgroup (the waves meet in LDS, last one publishes)
+    sq = wave_sum(sq);
+    if (lane == 0) {
+      atomicAdd(&kdw[0], sq);
+      const float before = atomicAdd(&kdw[1], 1.0f);
+      if ((int)before == NW - 1) atomicAdd(a.kd, atomicAdd(&kdw[0], 0.f) * a.kd_coef);
+    }
+  }
+}
+
+static bool launch_fwd_stream(const MAttnF& f, hipStream_t stream) {
+  // (A/B switch, read per call: the tests toggle it)  EVLM_ATTN_NO_STREAM=1: the whole-row kernels for every length
+  const char* env = getenv("EVLM_ATTN_NO_STREAM");
+  if ((env && atoi(env)) || f.Lk <= 224 || f.Lk > 1024 || f.P || f.causal || (f.Pt && !f.lse)) return false;
+  constexpr int KB = 128;
+  const int nblk = (f.Lk + KB - 1) / KB, qtiles = (f.Lq + 15) / 16;
+  const size_t lds = (size_t)4 * KB * 128 + (size_t)nblk * KB * sizeof(float) + 16;
+#define STREAM_LAUNCH(NW_, LSE_)                                                                                         \
+  do {                                                                                                                   \
+    (void)hipFuncSetAttribute((const void*)attn_fwd_stream_kernel<NW_, LSE_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                                 \
+    dim3 grid((qtiles + NW_ - 1) / NW_, f.H, f.B), block(64 * NW_);                                                     \
+    hipLaunchKernelGGL((attn_fwd_stream_kernel<NW_, LSE_>), grid, block, lds, stream, f);                                \
+  } while (0)
+  // 8 waves = 128 queries per workgroup: measured (tools/attn_long_bench.py) level with or ahead of 16 waves on the ViT's
+  // 577 / 901 tokens (the last query block is fuller, two workgroups share a CU), and a few text queries on those image
+  // tokens want the 8 waves for the K / V streaming itself (61 us against 82 us with one wave per query tile)
+  static const int nw_env = getenv("EVLM_ATTN_STREAM_NW") ? atoi(getenv("EVLM_ATTN_STREAM_NW")) : 0;     // (tuning aid)
+  const int nw = nw_env == 16 ? 16 : 8;
+  if (f.lse) {
+    if (nw == 8) STREAM_LAUNCH(8, true); else STREAM_LAUNCH(16, true);
+  } else {
+    if (nw == 8) STREAM_LAUNCH(8, false); else STREAM_LAUNCH(16, false);
+  }
+#undef STREAM_LAUNCH
+  return true;
+}
+
 template <int NT>
 static bool launch_fwd_grouped(const MAttnF& f, int Bkv, hipStream_t stream) {
   // the grouped form pays when several query batches share a K/V row and a batch is a few query tiles (text rows on image
@@ -1235,6 +1455,7 @@ int evlm_attention_fwd_mfma(const evlm_attn_fwd_args* a, hipStream_t stream, int
     return evlm_set_error("evlm_attention_fwd: the lse form serves Lk <= 224 and 417..928 (got %d)", a->Lk);
   if (a->kd_teacher && !a->kd_loss) return evlm_set_error("evlm_attention_fwd: kd_teacher without kd_loss");
   if (a->Lk > 64 && a->Lk <= 224 && launch_fwd_grouped<14>(f, a->Bkv, stream)) {}
+  else if (launch_fwd_stream(f, stream)) {}
   else if (a->Lk <= 32) launch_fwd<2>(f, stream);
   else if (a->Lk <= 64) launch_fwd<4>(f, stream);
   else if (a->Lk <= 224) launch_fwd<14>(f, stream);

@@ -1109,12 +1109,17 @@ def test_recomputing_attention_backward_needs_no_stored_map_and_tightens_the_gra
     assert P_rc is None                                   # nothing materialised
     O_rcp, P_rcp, gx_rcp, gkv_rcp = run(False, True)      # the map on request: same context ...
     O_st, P_st, gx_st, gkv_st = run(True, True)
-    assert P_rcp is not None and torch.equal(O_rc, O_rcp)
+    assert P_rcp is not None
     if Lk <= 224:                                         # ... and the same (recomputed) gradients;
+        assert torch.equal(O_rc, O_rcp) and torch.equal(O_rc, O_st)
         assert torch.equal(gx_rc, gx_rcp)
     else:                                                 # on long key sequences a caller who takes the map keeps the stored-map
         assert torch.equal(gx_rcp, gx_st)                 # backward (an external dP may come back for it: two passes either way)
-    assert torch.equal(O_rc, O_st) and torch.equal(P_rcp, P_st)
+        # and the whole-row forward kernel that writes it; without the map the STREAMING kernel runs (online softmax over
+        # 128-key blocks, 1 / l applied to the context): the same context at bf16 resolution, not the same bits
+        assert torch.equal(O_rcp, O_st)
+        assert rel_err(O_rc.float(), O_st.float()) < 1e-2
+    assert torch.equal(P_rcp, P_st)
     # fp32 reference
     xr = x0.float().requires_grad_(True)
     sp = lambda t, Ln: t.reshape(t.shape[0], Ln, H, dh).transpose(1, 2)

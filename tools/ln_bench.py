@@ -30,3 +30,20 @@ for rows in (12608, 7680, 3840):
         t = timeit(lambda: ops.layer_norm(x, w, b, 1e-5))
     mb = rows * 768 * 2 * 2 / 1e6
     print(f"ln_fwd rows={rows} three_pass={old}: {t:.2f} us  ({mb / t:.2f} TB/s of r+w, cache-resident input)")
+
+# backward (dx + the deferred column sums of dgamma / dbeta as the training step runs them): forward + backward replayed
+# from one graph, the forward's time subtracted
+for rows in (12608, 7680, 3840):
+    x = torch.randn(rows, 768, device="cuda", dtype=torch.bfloat16).requires_grad_()
+    w = torch.nn.Parameter(torch.randn(768, device="cuda")); b = torch.nn.Parameter(torch.randn(768, device="cuda"))
+    gy = torch.randn(rows, 768, device="cuda", dtype=torch.bfloat16)
+    def fb():
+        y = ops.layer_norm(x, w, b, 1e-5)
+        torch.autograd.grad(y, (x, w, b), gy)
+    def f():
+        with torch.no_grad():
+            ops.layer_norm(x, w, b, 1e-5)
+    os.environ["EVLM_LN_FWD_3PASS"] = "0"
+    tf, tfb = timeit(f, 50), timeit(fb, 50)
+    mb = rows * 768 * 2 * 3 / 1e6
+    print(f"ln_bwd rows={rows}: ~{tfb - tf:.2f} us (fwd+bwd {tfb:.2f}, fwd {tf:.2f})  ({mb / (tfb - tf):.2f} TB/s of dy + x read, dx written)")
