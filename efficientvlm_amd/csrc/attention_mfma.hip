@@ -617,10 +617,176 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
   }
 }
 
+// The same streaming scheme when the probability map IS an output (the teacher's kept layers, cross-attention maps of the
+// pruning steps, the stored-map training form): TWO passes over the keys.  Pass 1 streams K alone and forms the row
+// maximum m and sum l online; pass 2 streams K and V, recomputes the scores, writes p = 2^(s - m) / l as bf16 - 16-byte
+// pieces, rows of `ldpr` - and multiplies the SAME rounded probabilities into V (what a reader of the map would
+// recompute), with the distillation term formed from them (stored-map form) or from the fp32 values (lse form).
+template <int NW, bool LSE>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_stream_map_kernel(MAttnF a) {
+  constexpr int KBT = 8, KB = KBT * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nblk = (a.Lk + KB - 1) / KB;
+  float* Ms = reinterpret_cast<float*>(smem + 4 * KB * 128);
+  float* kdw = Ms + nblk * KB;
+  const int gx = gridDim.x, nwg = gx * gridDim.y * gridDim.z;
+  int lid = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int qblk = lid % gx, h = (lid / gx) % a.H, b = lid / (gx * a.H);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
+  const int q0 = (qblk * NW + wave) * 16;
+  const int q = q0 + ql;
+  const bool active = q0 < a.Lq, qok = q < a.Lq;
+  const int bkv = a.kv_index ? a.kv_index[b] : b;
+  const bf16* Kb = a.K + (size_t)bkv * a.Lk * a.ldk + h * DH;
+  const bf16* Vb = a.V + (size_t)bkv * a.Lk * a.ldv + h * DH;
+  for (int k = threadIdx.x; k < nblk * KB; k += blockDim.x)
+    Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
+  if (threadIdx.x < 2) kdw[threadIdx.x] = 0.f;
+  bf16x8 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (qok) v = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + ks * 32 + g * 8);
+    qf[ks] = *reinterpret_cast<bf16x8*>(&v);
+  }
+  const float sc = a.scale * 1.44269504088896341f;
+  // ---- pass 1: m, l ----
+  stage_block<SW_K>(Kb, a.ldk, a.Lk, 0, KB, NW, smem);
+  float m = -3.0e38f, l = 0.f;
+  for (int blk = 0; blk < nblk; ++blk) {
+    stage_wait();
+    __syncthreads();
+    if (blk + 1 < nblk) stage_block<SW_K>(Kb, a.ldk, a.Lk, (blk + 1) * KB, KB, NW, smem + ((blk + 1) & 1) * 2 * KB * 128);
+    if (!active) continue;
+    const char* Ks = smem + (blk & 1) * 2 * KB * 128;
+    f32x4 acc[KBT];
+#pragma unroll
+    for (int t = 0; t < KBT; ++t) {
+      acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Ks, t, ks, lane), qf[ks], acc[t], 0, 0, 0);
+    }
+    float bm = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < KBT; ++t) {
+      const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + blk * KB + tile_key0(t, g));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[t][r] = fmaf(acc[t][r], sc, mk[r] * LOG2E);
+        bm = fmaxf(bm, acc[t][r]);
+      }
+    }
+    bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    const float mn = fmaxf(m, bm);
+    l *= EXP2(m - mn);
+    m = mn;
+#pragma unroll
+    for (int t = 0; t < KBT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) l += EXP2(acc[t][r] - mn);
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = active ? 1.0f / l : 0.f;
+  if (LSE && active && qok && g == 0) a.lse[((size_t)b * a.H + h) * a.Lq + q] = m + __log2f(l);
+  __syncthreads();                                       // every wave is done with both buffers
+  // ---- pass 2: p, P V ----
+  stage_block<SW_K>(Kb, a.ldk, a.Lk, 0, KB, NW, smem);
+  stage_block<SW_V>(Vb, a.ldv, a.Lk, 0, KB, NW, smem + KB * 128);
+  const bool kd_on = a.Pt != nullptr && qok;
+  const bf16* Tr = kd_on ? a.Pt + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr : nullptr;
+  bf16* Pr = (a.P && qok) ? a.P + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr : nullptr;
+  float sq = 0.f, rk = 0.f;
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int blk = 0; blk < nblk; ++blk) {
+    stage_wait();
+    __syncthreads();
+    bf16x8 t8[KBT / 2];
+    if (kd_on) {                                         // (before the next block's DMA: see attn_fwd_stream_kernel)
+#pragma unroll
+      for (int s2 = 0; s2 < KBT / 2; ++s2) {
+        const int kcol = blk * KB + s2 * 32 + g * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (kcol < a.ldpr) v = *reinterpret_cast<const uint4*>(Tr + kcol);
+        t8[s2] = *reinterpret_cast<bf16x8*>(&v);
+      }
+    }
+    if (blk + 1 < nblk) {
+      char* nb = smem + ((blk + 1) & 1) * 2 * KB * 128;
+      stage_block<SW_K>(Kb, a.ldk, a.Lk, (blk + 1) * KB, KB, NW, nb);
+      stage_block<SW_V>(Vb, a.ldv, a.Lk, (blk + 1) * KB, KB, NW, nb + KB * 128);
+    }
+    if (!active) continue;
+    const char* Ks = smem + (blk & 1) * 2 * KB * 128;
+    const char* Vs = Ks + KB * 128;
+    f32x4 acc[KBT];
+#pragma unroll
+    for (int t = 0; t < KBT; ++t) {
+      acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Ks, t, ks, lane), qf[ks], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < KBT; ++t) {
+      const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + blk * KB + tile_key0(t, g));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = EXP2(fmaf(acc[t][r], sc, mk[r] * LOG2E) - m) * inv;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < KBT / 2; ++s2) {
+      bf16x8 pb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pb[r] = (bf16)acc[2 * s2][r]; pb[4 + r] = (bf16)acc[2 * s2 + 1][r]; }
+      const int kcol = blk * KB + s2 * 32 + g * 8;
+      if (Pr && kcol < a.ldpr) *reinterpret_cast<bf16x8*>(Pr + kcol) = pb;
+      if (kd_on) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p0 = LSE ? acc[2 * s2][r] : (float)pb[r], p1 = LSE ? acc[2 * s2 + 1][r] : (float)pb[4 + r];
+          const float d0 = p0 - (float)t8[s2][r], d1 = p1 - (float)t8[s2][4 + r];
+          sq = fmaf(d0, d0, sq); sq = fmaf(d1, d1, sq);
+          rk = fmaf(p0, d0, rk); rk = fmaf(p1, d1, rk);
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Vs, 2 * s2, 2 * s2 + 1, dt, lane), pb, o[dt], 0, 0, 0);
+    }
+  }
+  if (active && qok) {
+    const float gz = a.gate ? a.gate[h] : 1.0f;
+    bf16* Or = a.O + ((size_t)b * a.Lq + q) * a.ldo + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 ov = {(bf16)(o[dt][0] * gz), (bf16)(o[dt][1] * gz), (bf16)(o[dt][2] * gz), (bf16)(o[dt][3] * gz)};
+      *reinterpret_cast<bf16x4*>(Or + dt * 16 + g * 4) = ov;
+    }
+  }
+  if (a.Pt) {
+    if (LSE && a.rkd && active) {
+      rk += __shfl_xor(rk, 16, 64);
+      rk += __shfl_xor(rk, 32, 64);
+      if (qok && g == 0) a.rkd[((size_t)b * a.H + h) * a.Lq + q] = rk;
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) {
+      atomicAdd(&kdw[0], sq);
+      const float before = atomicAdd(&kdw[1], 1.0f);
+      if ((int)before == NW - 1) atomicAdd(a.kd, atomicAdd(&kdw[0], 0.f) * a.kd_coef);
+    }
+  }
+}
+
 static bool launch_fwd_stream(const MAttnF& f, hipStream_t stream) {
   // (A/B switch, read per call: the tests toggle it)  EVLM_ATTN_NO_STREAM=1: the whole-row kernels for every length
   const char* env = getenv("EVLM_ATTN_NO_STREAM");
-  if ((env && atoi(env)) || f.Lk <= 224 || f.Lk > 1024 || f.P || f.causal || (f.Pt && !f.lse)) return false;
+  if ((env && atoi(env)) || f.Lk <= 224 || f.Lk > 1024 || f.causal) return false;
   constexpr int KB = 128;
   const int nblk = (f.Lk + KB - 1) / KB, qtiles = (f.Lq + 15) / 16;
   const size_t lds = (size_t)4 * KB * 128 + (size_t)nblk * KB * sizeof(float) + 16;
@@ -636,6 +802,18 @@ static bool launch_fwd_stream(const MAttnF& f, hipStream_t stream) {
   // tokens want the 8 waves for the K / V streaming itself (61 us against 82 us with one wave per query tile)
   static const int nw_env = getenv("EVLM_ATTN_STREAM_NW") ? atoi(getenv("EVLM_ATTN_STREAM_NW")) : 0;     // (tuning aid)
   const int nw = nw_env == 16 ? 16 : 8;
+  if (f.P || (f.Pt && !f.lse)) {                         // the map is an output (or the stored-map distillation form): two passes
+#define STREAM_MAP_LAUNCH(LSE_)                                                                                          \
+  do {                                                                                                                   \
+    (void)hipFuncSetAttribute((const void*)attn_fwd_stream_map_kernel<8, LSE_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                                 \
+    dim3 grid((qtiles + 7) / 8, f.H, f.B), block(512);                                                                  \
+    hipLaunchKernelGGL((attn_fwd_stream_map_kernel<8, LSE_>), grid, block, lds, stream, f);                              \
+  } while (0)
+    if (f.lse) STREAM_MAP_LAUNCH(true); else STREAM_MAP_LAUNCH(false);
+#undef STREAM_MAP_LAUNCH
+    return true;
+  }
   if (f.lse) {
     if (nw == 8) STREAM_LAUNCH(8, true); else STREAM_LAUNCH(16, true);
   } else {

@@ -34,7 +34,10 @@ for B, L in ((64, 577), (32, 901)):
         x = qkv.clone().requires_grad_(True)
         t1 = bench(lambda: ops.self_attention(x, H, dh, 0.125, want_probs=False))
         t2 = bench(lambda: ops.self_attention(x, H, dh, 0.125, want_probs=False, kd_teacher=Pt, kd_weight=1.0))
-        out[tag] = dict(no_grad_us=round(t0, 1), lse_us=round(t1, 1), lse_kd_us=round(t2, 1), no_grad_tflops=round(fl / t0 / 1e6, 1))
+        with torch.no_grad():
+            t3 = bench(lambda: ops.self_attention(qkv, H, dh, 0.125, want_probs=True))
+        out[tag] = dict(no_grad_us=round(t0, 1), lse_us=round(t1, 1), lse_kd_us=round(t2, 1), map_written_us=round(t3, 1),
+                        no_grad_tflops=round(fl / t0 / 1e6, 1))
     print(json.dumps(out), flush=True)
     del Pt
 for Bimg, rows, L in ((64, 3, 577), (32, 4, 901)):
@@ -46,5 +49,6 @@ for Bimg, rows, L in ((64, 3, 577), (32, 4, 901)):
     for tag, env in (("stream", "0"), ("whole_row", "1")):
         os.environ["EVLM_ATTN_NO_STREAM"] = env
         with torch.no_grad():
-            out[tag] = round(bench(lambda: ops.cross_attention(q, kv, H, dh, 0.125, want_probs=False, kv_index=idx)), 1)
+            out[tag] = dict(no_map_us=round(bench(lambda: ops.cross_attention(q, kv, H, dh, 0.125, want_probs=False, kv_index=idx)), 1),
+                            map_written_us=round(bench(lambda: ops.cross_attention(q, kv, H, dh, 0.125, want_probs=True, kv_index=idx)), 1))
     print(json.dumps(out), flush=True)
