@@ -1206,6 +1206,138 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
   }
 }
 
+// The ONE-PASS recomputing form of the kernel above with the keys STREAMED (the backward counterpart of
+// attn_fwd_stream_kernel): K and V pass through LDS in double-buffered blocks of 128 keys (64 KiB instead of the 80 KiB
+// key half staged behind two barriers with nothing in flight), the teacher map's piece of a block is requested before the
+// next block's DMA, workgroups of one (batch, head) share an XCD.  Arithmetic per tile pair as above.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
+  constexpr int KBT = 8, KB = KBT * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nblk = (a.Lk + KB - 1) / KB;
+  float* Ms = reinterpret_cast<float*>(smem + 4 * KB * 128);
+  const int gx = gridDim.x, nwg = gx * gridDim.y * gridDim.z;
+  int lid = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int qblk = lid % gx, h = (lid / gx) % a.H, b = lid / (gx * a.H);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
+  const int q0 = (qblk * NW + wave) * 16;
+  const int q = q0 + ql;
+  const bool active = q0 < a.Lq, qok = q < a.Lq;
+  const int bkv = a.kv_index ? a.kv_index[b] : b;
+  const bf16* Kb = a.K + (size_t)bkv * a.Lk * a.ldk + h * DH;
+  const bf16* Vb = a.V + (size_t)bkv * a.Lk * a.ldv + h * DH;
+  stage_mask(a.mask, b, a.Lk, nblk * KB, Ms);
+  bf16x8 dof[2], qf[2];
+  float d = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0), vq = make_uint4(0, 0, 0, 0), vo = make_uint4(0, 0, 0, 0);
+    if (qok) {
+      v = *reinterpret_cast<const uint4*>(a.dO + ((size_t)b * a.Lq + q) * a.ldo + h * DH + ks * 32 + g * 8);
+      vq = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + ks * 32 + g * 8);
+      vo = *reinterpret_cast<const uint4*>(a.O + ((size_t)b * a.Lq + q) * a.ldo + h * DH + ks * 32 + g * 8);
+    }
+    dof[ks] = *reinterpret_cast<bf16x8*>(&v);
+    qf[ks] = *reinterpret_cast<bf16x8*>(&vq);
+    const bf16x8 of = *reinterpret_cast<const bf16x8*>(&vo);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d = fmaf((float)of[e], (float)dof[ks][e], d);
+  }
+  d += __shfl_xor(d, 16, 64); d += __shfl_xor(d, 32, 64);
+  const size_t prow = (((size_t)b * a.H + h) * a.Lq + (qok ? q : 0)) * a.ldpr;
+  const float gz = a.gate ? a.gate[h] : 1.0f;
+  const float kdc = a.Pt ? a.kd_coef * a.kd_gout[0] : 0.f;
+  const float sc = a.scale * LOG2E;
+  const float lse_q = qok ? a.lse[((size_t)b * a.H + h) * a.Lq + q] : 0.f;
+  // delta = sum_k p (gz dpo + kdc (p - pt)) = dO . O + kdc * rkd   (see attn_bwd_dq_long_kernel)
+  const float dsum = (a.Pt && qok) ? fmaf(kdc, a.rkd[((size_t)b * a.H + h) * a.Lq + q], d) : d;
+  const bool kd_on = a.Pt != nullptr && qok;
+  float gsum = 0.f;
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  stage_block<SW_K>(Vb, a.ldv, a.Lk, 0, KB, NW, smem);
+  stage_block<SW_KV>(Kb, a.ldk, a.Lk, 0, KB, NW, smem + KB * 128);
+  for (int blk = 0; blk < nblk; ++blk) {
+    stage_wait();
+    __syncthreads();
+    bf16x8 t8[KBT / 2];
+    if (kd_on) {
+#pragma unroll
+      for (int s2 = 0; s2 < KBT / 2; ++s2) {
+        const int kcol = blk * KB + s2 * 32 + g * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (kcol < a.ldpr) v = *reinterpret_cast<const uint4*>(a.Pt + prow + kcol);
+        t8[s2] = *reinterpret_cast<bf16x8*>(&v);
+      }
+    }
+    if (blk + 1 < nblk) {
+      char* nb = smem + ((blk + 1) & 1) * 2 * KB * 128;
+      stage_block<SW_K>(Vb, a.ldv, a.Lk, (blk + 1) * KB, KB, NW, nb);
+      stage_block<SW_KV>(Kb, a.ldk, a.Lk, (blk + 1) * KB, KB, NW, nb + KB * 128);
+    }
+    if (!active) continue;
+    const char* Vs = smem + (blk & 1) * 2 * KB * 128;
+    const char* Ks = Vs + KB * 128;
+#pragma unroll
+    for (int s2 = 0; s2 < KBT / 2; ++s2) {
+      const int kcol = blk * KB + s2 * 32 + g * 8;
+      const bool ok = qok && kcol < a.ldpr;
+      float pr[8];
+      recompute_p<SW_KV>(Ks, Ms + blk * KB, qf, s2, g, lane, sc, lse_q, qok, 0, 0, pr);
+      bf16x8 d8, p8o;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, 2 * s2 + hh, ks, lane), dof[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pp = pr[hh * 4 + r];
+          const float ex = (kd_on && ok) ? kdc * (pp - (float)t8[s2][hh * 4 + r]) : 0.f;
+          const float dp = fmaf(gz, acc[r], ex);
+          gsum = fmaf(pp, acc[r], gsum);
+          d8[hh * 4 + r] = (bf16)(pp * (dp - dsum));
+          p8o[hh * 4 + r] = (bf16)pp;
+        }
+      }
+      if (ok) {
+        *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
+        if (a.Pw) *reinterpret_cast<bf16x8*>(a.Pw + prow + kcol) = p8o;
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag<SW_KV>(Ks, 2 * s2, 2 * s2 + 1, dt, lane), d8, o[dt], 0, 0, 0);
+    }
+  }
+  if (a.dgate) {
+    const float gs = wave_sum(gsum);
+    if (lane == 0) atomicAdd(a.dgate + h, gs);
+  }
+  if (qok) {
+    bf16* dQr = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 ov = {(bf16)(o[dt][0] * a.scale), (bf16)(o[dt][1] * a.scale), (bf16)(o[dt][2] * a.scale), (bf16)(o[dt][3] * a.scale)};
+      *reinterpret_cast<bf16x4*>(dQr + dt * 16 + g * 4) = ov;
+    }
+  }
+}
+
+static bool launch_bwd_dq_stream(const MAttnB& f, hipStream_t stream) {
+  const char* env = getenv("EVLM_ATTN_NO_STREAM");         // (A/B switch, read per call)
+  if ((env && atoi(env)) || f.Lk <= 224 || f.Lk > 1024 || f.causal || !f.lse || !f.O || f.E || (f.Pt && !f.rkd)) return false;
+  constexpr int KB = 128, NW = 8;
+  const int nblk = (f.Lk + KB - 1) / KB, qtiles = (f.Lq + 15) / 16;
+  const size_t lds = (size_t)4 * KB * 128 + (size_t)nblk * KB * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)attn_bwd_dq_stream_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dim3 grid((qtiles + NW - 1) / NW, f.H, f.B), block(64 * NW);
+  hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<NW>), grid, block, lds, stream, f);
+  return true;
+}
+
 // kernel B: one workgroup = 64 keys of one (batch, head); wave w owns key tile w.  Sums over the queries in chunks of 32:
 //   dK^T[d][key] = scale * sum_q Q[q][d] dS[q][key] ;  dV^T[d][key] = gate * sum_q dO[q][d] P[q][key]
 // All four operands are [32 q][64] bf16 LDS tiles read by COLUMNS (ds_read_b64_tr_b16): the reduction index (q) is
@@ -1585,6 +1717,7 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
     if (a->Lk <= 32) launch_bwd_dq<2, true>(f, stream);
     else if (a->Lk <= 64) launch_bwd_dq<4, true>(f, stream);
     else if (a->Lk <= 224) launch_bwd_dq<14, true>(f, stream);
+    else if (launch_bwd_dq_stream(f, stream)) {}
     else if (a->Lk <= 640) launch_bwd_dq_long<40, true>(f, stream);
     else launch_bwd_dq_long<60, true>(f, stream);
   } else if (a->Lk <= 32) launch_bwd_dq<2, false>(f, stream);

@@ -34,9 +34,18 @@ for B, L in ((64, 577), (32, 901)):
         x = qkv.clone().requires_grad_(True)
         t1 = bench(lambda: ops.self_attention(x, H, dh, 0.125, want_probs=False))
         t2 = bench(lambda: ops.self_attention(x, H, dh, 0.125, want_probs=False, kd_teacher=Pt, kd_weight=1.0))
+        gO = torch.randn(B, L, d, device=dev).bfloat16()
+        def fb(kd):
+            if kd:
+                O, _, k = ops.self_attention(x, H, dh, 0.125, want_probs=False, kd_teacher=Pt, kd_weight=1.0)
+                torch.autograd.grad((O.float() * gO.float()).sum() + k, x)
+            else:
+                O, _ = ops.self_attention(x, H, dh, 0.125, want_probs=False)
+                torch.autograd.grad(O, x, gO)
+        tb1, tb2 = bench(lambda: fb(False), 6), bench(lambda: fb(True), 6)
         with torch.no_grad():
             t3 = bench(lambda: ops.self_attention(qkv, H, dh, 0.125, want_probs=True))
-        out[tag] = dict(no_grad_us=round(t0, 1), lse_us=round(t1, 1), lse_kd_us=round(t2, 1), map_written_us=round(t3, 1),
+        out[tag] = dict(no_grad_us=round(t0, 1), lse_us=round(t1, 1), lse_kd_us=round(t2, 1), map_written_us=round(t3, 1), fwd_bwd_us=round(tb1, 1), fwd_bwd_kd_us=round(tb2, 1),
                         no_grad_tflops=round(fl / t0 / 1e6, 1))
     print(json.dumps(out), flush=True)
     del Pt
