@@ -1326,9 +1326,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
   }
 }
 
-static bool launch_bwd_dq_stream(const MAttnB& f, hipStream_t stream) {
+static bool launch_bwd_dq_stream(MAttnB& f, hipStream_t stream) {
   const char* env = getenv("EVLM_ATTN_NO_STREAM");         // (A/B switch, read per call)
   if ((env && atoi(env)) || f.Lk <= 224 || f.Lk > 1024 || f.causal || !f.lse || !f.O || f.E || (f.Pt && !f.rkd)) return false;
+  const char* keep = getenv("EVLM_ATTN_STREAM_PWS");       // (A/B switch) 1: kernel B reads the map from the workspace
+  if (!(keep && atoi(keep))) { f.P = nullptr; f.Pw = nullptr; }
   constexpr int KB = 128, NW = 8;
   const int nblk = (f.Lk + KB - 1) / KB, qtiles = (f.Lq + 15) / 16;
   const size_t lds = (size_t)4 * KB * 128 + (size_t)nblk * KB * sizeof(float);
@@ -1371,7 +1373,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
   __shared__ __attribute__((aligned(16))) char sm[4 * 32 * 128];
   char* Qs = sm; char* dOs = sm + 4096; char* Ps = sm + 8192; char* Ss = sm + 12288;
   const int bkv = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
+  // No stored map and a row lse: the probabilities are REBUILT here (K Q^T again: 4 MFMAs and 8 exponentials per lane per
+  // 32-query chunk) instead of read from a [B, H, Lq, Lk] workspace that kernel A would have to write - the streaming
+  // kernel A of long sequences then moves 517 MB less per ViT layer at 577 tokens, and this kernel reads 517 MB less
+  const bool rcp = a.P == nullptr && a.lse != nullptr;
+  bf16x8 kf[2];
+  float mk[4] = {0.f, 0.f, 0.f, 0.f};
+  const float sc = a.scale * LOG2E;
+  if (rcp) {
+    const int krow = min(k0 + wave * 16 + ql, a.Lk - 1);             // A operand: row = key, k-slots = 8 head-dim values
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 v = *reinterpret_cast<const uint4*>(a.K + ((size_t)bkv * a.Lk + krow) * a.ldk + h * DH + ks * 32 + g * 8);
+      kf[ks] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+  }
   f32x4 dk[4], dv[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -1388,13 +1405,46 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
     const bf16* Qb = a.Q + (size_t)b * a.Lq * a.ldq + h * DH;
     const bf16* dOb = a.dO + (size_t)b * a.Lq * a.ldo + h * DH;
     const size_t pbase = ((size_t)b * a.H + h) * a.Lq * a.ldpr;
+    if (rcp) {                                           // additive mask of this query batch for the lane's 4 keys (log2 domain)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + wave * 16 + 4 * g + r;
+        mk[r] = (key < a.Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -1e30f) * LOG2E;
+      }
+    }
     for (int q0 = 0; q0 < a.Lq; q0 += 32) {
+      float lq[2] = {0.f, 0.f};
+      if (rcp) {                                         // (requested with the tiles: one latency for all of a chunk's loads)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (q0 + 16 * j + ql < a.Lq) lq[j] = a.lse[((size_t)b * a.H + h) * a.Lq + q0 + 16 * j + ql];
+      }
       __syncthreads();
       stage_qtile(Qb, a.ldq, q0, a.Lq, 0, DH, Qs);
       stage_qtile(dOb, a.ldo, q0, a.Lq, 0, DH, dOs);
-      stage_qtile(a.P + pbase, a.ldpr, q0, a.Lq, k0, a.ldpr, Ps);
+      if (!rcp) stage_qtile(a.P + pbase, a.ldpr, q0, a.Lq, k0, a.ldpr, Ps);
       stage_qtile(a.dS + pbase, a.ldpr, q0, a.Lq, k0, a.ldpr, Ss);
       __syncthreads();
+      if (rcp) {
+        // P of this wave's 16 keys x the chunk's 32 queries, rebuilt as kernel A built it (same operands in the same
+        // k-slots, same fma, same lse: the same bf16 values it multiplied into dS) and written into the wave's OWN 16
+        // columns of the [32 q][64 key] tile - which only this wave reads back (column tile `wave`): no barrier
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const int row = 16 * j + ql;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(Qs + row * 128 + p_swz(row, ks * 4 + g) * 16);
+            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qfr, sa, 0, 0, 0);
+          }
+          const bool qv = q0 + row < a.Lq;
+          bf16x4 p4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p4[r] = (bf16)(qv ? EXP2(fmaf(sa[r], sc, mk[r]) - lq[j]) : 0.f);
+          *reinterpret_cast<bf16x4*>(Ps + row * 128 + p_swz(row, 2 * wave + (g >> 1)) * 16 + (g & 1) * 8) = p4;
+        }
+      }
       const bf16x8 bS = qcol_frag(Ss, wave, lane), bP = qcol_frag(Ps, wave, lane);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -1717,7 +1767,7 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
     if (a->Lk <= 32) launch_bwd_dq<2, true>(f, stream);
     else if (a->Lk <= 64) launch_bwd_dq<4, true>(f, stream);
     else if (a->Lk <= 224) launch_bwd_dq<14, true>(f, stream);
-    else if (launch_bwd_dq_stream(f, stream)) {}
+    else if (launch_bwd_dq_stream(f, stream)) {}      // (kernel B rebuilds the map itself: f.P / f.Pw were cleared)
     else if (a->Lk <= 640) launch_bwd_dq_long<40, true>(f, stream);
     else launch_bwd_dq_long<60, true>(f, stream);
   } else if (a->Lk <= 32) launch_bwd_dq<2, false>(f, stream);
