@@ -1300,6 +1300,72 @@ def test_additive_mask_is_one_gather_with_the_reference_bits():
     assert torch.equal(o.additive_mask(f), (1.0 - f) * -10000.0)
 
 
+@pytest.mark.parametrize("case", ["vit577_kd", "vit901", "vit450_map", "cross577_shared", "cross901_map"])
+def test_streaming_long_sequence_kernels_agree_with_the_whole_row_kernels(case, monkeypatch):
+    """attn_fwd_stream_kernel / attn_fwd_stream_map_kernel / attn_bwd_dq_stream_kernel (+ kernel B rebuilding the map)
+    against the whole-row kernels they replace on 225..928 keys (EVLM_ATTN_NO_STREAM=1): the same context, row lse,
+    distillation term, map and gradients at bf16 resolution - online softmax over 128-key blocks with 1 / l applied to the
+    context is a different rounding sequence, not different arithmetic (eff_vit.py:134-199, eff_bert.py:277-364).  Key
+    padding masks, a closed head gate, shared K/V rows and a sequence that ends inside a block included."""
+    o = ops()
+    B, Bkv, H, Lq, Lk, self_attn, want, kd = {"vit577_kd": (2, 2, 12, 577, 577, True, False, True),
+                                              "vit901": (1, 1, 4, 901, 901, True, False, False),
+                                              "vit450_map": (2, 2, 3, 450, 450, True, True, False),
+                                              "cross577_shared": (7, 3, 12, 30, 577, False, False, False),
+                                              "cross901_map": (3, 3, 4, 30, 901, False, True, False)}[case]
+    dh, d = 64, H * 64
+    g = torch.Generator().manual_seed(4000 + Lq + Lk)
+    x0 = rnd((B, Lq, 3 * d if self_attn else d), torch.bfloat16, g, 0.7)
+    kv0 = None if self_attn else rnd((Bkv, Lk, 2 * d), torch.bfloat16, g, 0.7)
+    idx = None if (self_attn or Bkv == B) else torch.randint(0, Bkv, (B,), generator=g).to(DEV)
+    mask = torch.zeros(B, Lk)
+    mask[0, Lk - 11:] = -10000.0
+    mask = mask.to(DEV)
+    gate0 = torch.rand(H, generator=g) + 0.5
+    gate0[0] = 0.0
+    gate0 = gate0.to(DEV)
+    gO = rnd((B, Lq, d), torch.bfloat16, g)
+    Pt = None
+    if kd:
+        with torch.no_grad():
+            Pt = o.self_attention(rnd((B, Lq, 3 * d), torch.bfloat16, g, 0.7), H, dh, 0.125, mask=mask)[1]
+
+    def run(no_stream):
+        monkeypatch.setenv("EVLM_ATTN_NO_STREAM", "1" if no_stream else "0")
+        x = x0.clone().requires_grad_(True)
+        kv = kv0.clone().requires_grad_(True) if kv0 is not None else None
+        gate = gate0.clone().requires_grad_(True)
+        k_term = None
+        if self_attn and kd:
+            O, P, k_term = o.self_attention(x, H, dh, 0.125, mask=mask, gate=gate, want_probs=want, kd_teacher=Pt, kd_weight=float(Lk))
+        elif self_attn:
+            O, P = o.self_attention(x, H, dh, 0.125, mask=mask, gate=gate, want_probs=want)
+        else:
+            O, P = o.cross_attention(x, kv, H, dh, 0.125, mask=mask, gate=gate, want_probs=want, kv_index=idx)
+        loss = (O.float() * gO.float()).sum()
+        if k_term is not None:
+            loss = loss + 0.3 * k_term
+        if P is not None:
+            loss = loss + (P.float() * 0.5).pow(2).sum()          # a gradient through the map too (stored-map backward)
+        loss.backward()
+        return (O.detach(), P.detach() if P is not None else None, k_term.detach() if k_term is not None else None,
+                x.grad.float(), kv.grad.float() if kv is not None else None, gate.grad.clone())
+
+    a, b = run(False), run(True)
+    l2 = lambda u, v: float((u.double() - v.double()).norm() / (v.double().norm() + 1e-30))
+    assert rel_err(a[0].float(), b[0].float()) < 1e-2 and l2(a[0].float(), b[0].float()) < 4e-3
+    assert (a[1] is None) == (b[1] is None) == (not want)
+    if want:
+        assert rel_err(a[1].float(), b[1].float()) < 1e-2
+        assert float(a[1][..., Lk:].float().abs().max() if a[1].shape[-1] > Lk else 0.0) == 0.0
+    if kd:
+        assert abs(float(a[2]) - float(b[2])) < 1e-4 * abs(float(b[2]))
+    assert l2(a[3], b[3]) < 6e-3, l2(a[3], b[3])
+    if a[4] is not None:
+        assert l2(a[4], b[4]) < 6e-3, l2(a[4], b[4])
+    assert l2(a[5], b[5]) < 6e-3, (a[5], b[5])
+
+
 def test_attention_lse_form_refuses_what_it_cannot_serve():
     """C ABI: the lse / recompute form exists for bf16, head dim 64, Lk <= 224 without dropout; anything else answers with
     an error code - never a fault - and evlm_attention_lse_supported says so beforehand"""
