@@ -1134,6 +1134,13 @@ class ITRTrainer(_StagedExchange, _CapturedStep):
 
     def _body(self, batch, idx, T_ready, pruned_steps, lr_mult, staged):
         """the device work of one step (capturable when T_ready / batch are static and `staged`: schedules set outside)"""
+        ops.begin_step(batch["image"].device)    # ONE fill for the step's loss words and small zeroed buffers (as the GD step)
+        try:
+            return self._body_in_arena(batch, idx, T_ready, pruned_steps, lr_mult, staged)
+        finally:
+            ops.end_step()
+
+    def _body_in_arena(self, batch, idx, T_ready, pruned_steps, lr_mult, staged):
         self.opt.zero_grad()
         l0 = self.student.l0_module
         with compute(self.dtype):
@@ -1237,6 +1244,13 @@ class VQATrainer(_StagedExchange, _CapturedStep):
 
     def _body(self, batch, T_ready, pruned_steps, lr_mult, stop_prune, staged):
         """the device work of one step (capturable when T_ready / batch are static and `staged`: schedules set outside)"""
+        ops.begin_step(batch["image"].device)
+        try:
+            return self._body_in_arena(batch, T_ready, pruned_steps, lr_mult, stop_prune, staged)
+        finally:
+            ops.end_step()
+
+    def _body_in_arena(self, batch, T_ready, pruned_steps, lr_mult, stop_prune, staged):
         from types import SimpleNamespace as NS
         self.opt.zero_grad()
         l0 = self.student.l0_module
