@@ -298,6 +298,15 @@ def teacher_map_filter(student, teacher, with_cross):
             keep = {i * k1 + k1 - 1 for i in range(fs)} | {ft + i * k2 + k2 - 1 for i in range(ls - fs)}
             te.attn_keep = keep
             te.cross_keep = ({l for l in keep if l >= ft} if with_cross else set())
+    # the answer decoder of the VQA models (every layer cross-attends to the question states: Eff_VQA.py:150-160 reads the
+    # decoder's self- and cross-attention maps through get_cor_teacher too)
+    sd, td = getattr(student, "text_decoder", None), getattr(teacher, "text_decoder", None)
+    if sd is not None and td is not None and hasattr(td.bert.encoder, "attn_keep"):
+        ls, lt = len(sd.bert.encoder.layer), len(td.bert.encoder.layer)
+        if lt % ls == 0:
+            k = lt // ls
+            td.bert.encoder.attn_keep = {i * k + k - 1 for i in range(ls)}
+            td.bert.encoder.cross_keep = set(td.bert.encoder.attn_keep) if with_cross else set()
 
 
 class GDTrainer(_StagedExchange):
@@ -1212,6 +1221,8 @@ class VQATrainer(_StagedExchange, _CapturedStep):
         self.l0_opt, self.lagrangian_opt = create_L0_optimizer({"reg_learning_rate": reg_learning_rate}, student.l0_module)
         self.defer_wgrad = dtype == torch.bfloat16 and not os.environ.get("EVLM_NO_DEFER_WGRAD")
         self.overlap_teacher = not os.environ.get("EVLM_NO_OVERLAP_TEACHER")
+        if not os.environ.get("EVLM_TEACHER_ALL_MAPS"):     # (as the ITR trainer: only the maps Eff_VQA.py:113-163 reads)
+            teacher_map_filter(student, teacher, with_cross=True)
         self.global_step = 0
         self.prefetch = TeacherPrefetch(self._teacher_forward, use_graph) if pipeline_teacher else None
         self.capture_step = bool(capture_step and pipeline_teacher and use_graph and next(student.parameters()).is_cuda)
