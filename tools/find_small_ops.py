@@ -10,10 +10,37 @@ from oracle import synth
 from efficientvlm_amd.trainer import GDTrainer
 import bench
 geom = synth.GEOMS["full"]; dev = torch.device("cuda")
-s, t = bench.build(geom, dev, 1234)
-tr = GDTrainer(s, t, dtype=torch.bfloat16, use_graph=False)
-batch = {k: v.to(dev) for k, v in synth.make_batch(geom, 64, seed=42).items()}
-for _ in range(2): tr.step(batch)
+KIND = next((a for a in sys.argv[1:] if a in ("gd", "itr", "vqa")), "gd")       # which step: GD (default), ITR-384, VQA-480
+if KIND == "gd":
+    s, t = bench.build(geom, dev, 1234)
+    tr = GDTrainer(s, t, dtype=torch.bfloat16, use_graph=False)
+    batch = {k: v.to(dev) for k, v in synth.make_batch(geom, 64, seed=42).items()}
+    step = lambda: tr.step(batch)
+else:
+    from helpers import model_config
+    from efficientvlm_amd.trainer import ITRTrainer, VQATrainer
+    res = 384 if KIND == "itr" else 480
+    geom = dict(geom); geom["image_res"] = res
+    torch.manual_seed(0)
+    if KIND == "itr":
+        from efficientvlm_amd.efficient_models.model_retrieval import EffXVLMforRetrieval
+        from efficientvlm_amd.models.model_retrieval import XVLM as TeacherITR
+        s = EffXVLMforRetrieval(model_config(geom, "s", image_res=res)).to(dev)
+        t = TeacherITR(model_config(geom, "t", image_res=res)).to(dev)
+        tr = ITRTrainer(s, t, lr=3e-5, weight_decay=0.01, lr_mult=2, reg_learning_rate=0.1, dtype=torch.bfloat16)
+        batch = {k: v.to(dev) for k, v in synth.make_batch(geom, 16, seed=5).items()}
+        idx = torch.arange(16, device=dev)
+        step = lambda: tr.step(batch, idx=idx)
+    else:
+        from efficientvlm_amd.efficient_models.model_generation import EffXVLMForVQA
+        from efficientvlm_amd.models.model_generation import XVLMForVQA
+        cfg = lambda role, nd: dict(model_config(geom, role, image_res=res), pad_token_id=0, num_dec_layers=nd)
+        s = EffXVLMForVQA(cfg("s", 3)).to(dev); t = XVLMForVQA(cfg("t", 6)).to(dev)
+        tr = VQATrainer(s, t, lr=5e-5, weight_decay=0.01, lr_mult=2, reg_learning_rate=0.1, dtype=torch.bfloat16)
+        batch = {k: v.to(dev) for k, v in synth.make_vqa_batch(geom, 8, seed=5, La=8).items()}
+        step = lambda: tr.step(batch)
+    s.l0_module.set_lagrangian_warmup_steps(100)
+for _ in range(2): step()
 torch.cuda.synchronize()
 agg = collections.Counter()
 WANT = None
@@ -36,7 +63,7 @@ class Mode(TorchDispatchMode):
             agg[(name, where or "?", shp)] += 1
         return func(*args, **(kwargs or {}))
 with Mode():
-    tr.step(batch)
+    step()
 torch.cuda.synchronize()
 # metadata-only ops launch nothing: listed only with --all
 NOLAUNCH = ("view", "detach", "slice", "select", "empty", "as_strided", "split", "record_stream", "t.", "transpose", "unsqueeze",
