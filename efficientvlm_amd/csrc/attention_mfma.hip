@@ -786,7 +786,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_map_kernel(MAttnF a) 
 static bool launch_fwd_stream(const MAttnF& f, hipStream_t stream) {
   // (A/B switch, read per call: the tests toggle it)  EVLM_ATTN_NO_STREAM=1: the whole-row kernels for every length
   const char* env = getenv("EVLM_ATTN_NO_STREAM");
-  if ((env && atoi(env)) || f.Lk <= 224 || f.Lk > 1024 || f.causal) return false;
+  static const int min_keys = getenv("EVLM_ATTN_STREAM_MIN") ? atoi(getenv("EVLM_ATTN_STREAM_MIN")) : 225;   // (tuning aid)
+  if ((env && atoi(env)) || f.Lk < min_keys || f.Lk > 1024 || f.causal) return false;
   constexpr int KB = 128;
   const int nblk = (f.Lk + KB - 1) / KB, qtiles = (f.Lq + 15) / 16;
   const size_t lds = (size_t)4 * KB * 128 + (size_t)nblk * KB * sizeof(float) + 16;

@@ -1431,6 +1431,61 @@ def test_vqa_captured_student_step_reproduces_the_eager_trajectory():
     assert torch.allclose(logas[True], logas[False], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("kind", ["itr384", "vqa480"])
+def test_full_width_bf16_captured_pruning_steps_follow_the_eager_trajectory(kind):
+    """The captured student step at FULL width in bf16 on the long image sequences (577 / 901 tokens: streaming attention
+    kernels, ragged-tail weight gradients, the padded vocabulary head of the VQA decoder - none of which the tiny fp32
+    capture tests reach): ten training steps through hipGraph replays against the same steps launched eagerly.  bf16
+    atomics make the two runs differ in the last bits, so the trajectories are compared at 2 %; a replayed graph that reads
+    or zero-fills the wrong memory (the round-4 graph memset defect showed up as a 2.4 % gap at step 5 and 9 % at step 9
+    of exactly this comparison) does not pass, nor does a non-finite gradient."""
+    from efficientvlm_amd.trainer import ITRTrainer, VQATrainer
+    res = 384 if kind == "itr384" else 480
+    geom = dict(synth.GEOMS["full"]); geom["image_res"] = res
+    seqs, norms = {}, {}
+    for cap in (False, True):
+        torch.manual_seed(0)
+        if kind == "itr384":
+            from efficientvlm_amd.efficient_models.model_retrieval import EffXVLMforRetrieval
+            from efficientvlm_amd.models.model_retrieval import XVLM as TeacherITR
+            student = EffXVLMforRetrieval(model_config(geom, "s", image_res=res)).to(DEV)
+            teacher = TeacherITR(model_config(geom, "t", image_res=res)).to(DEV)
+            tr = ITRTrainer(student, teacher, lr=3e-5, weight_decay=0.01, lr_mult=2, reg_learning_rate=0.1, dtype=torch.bfloat16,
+                            pipeline_teacher=True, capture_step=cap)
+            batch = {k: v.to(DEV) for k, v in synth.make_batch(geom, 4, seed=5).items()}
+            idx = torch.arange(4, device=DEV)
+            step = lambda: tr.step(batch, idx=idx)
+        else:
+            from efficientvlm_amd.efficient_models.model_generation import EffXVLMForVQA
+            from efficientvlm_amd.models.model_generation import XVLMForVQA
+            cfg = lambda role, nd: dict(model_config(geom, role, image_res=res), pad_token_id=0, num_dec_layers=nd)
+            student = EffXVLMForVQA(cfg("s", 3)).to(DEV)
+            teacher = XVLMForVQA(cfg("t", 6)).to(DEV)
+            tr = VQATrainer(student, teacher, lr=5e-5, weight_decay=0.01, lr_mult=2, reg_learning_rate=0.1, dtype=torch.bfloat16,
+                            pipeline_teacher=True, capture_step=cap)
+            batch = {k: v.to(DEV) for k, v in synth.make_vqa_batch(geom, 3, seed=5, La=8).items()}
+            step = lambda: tr.step(batch)
+        student.l0_module.set_lagrangian_warmup_steps(100)
+        torch.manual_seed(1)                                  # the gate noise: the same host draws in both runs
+        seq = []
+        for _ in range(11):
+            o = step()
+            if o is not None:
+                seq.append(o.clone())
+        torch.cuda.synchronize()
+        if cap:
+            assert tr.last_launch == "hipGraph replay" and len(tr._sgraphs) == 2
+        seqs[cap] = torch.stack(seq).float().cpu()
+        norms[cap] = [float(g.float().norm()) for g in tr.opt.flat_grads]
+        del tr, student, teacher
+    assert len(seqs[True]) == 10 and torch.isfinite(seqs[True]).all() and all(math.isfinite(n) for n in norms[True])
+    assert float(seqs[False][-1, 0]) < float(seqs[False][0, 0])                       # (the steps train)
+    assert torch.allclose(seqs[True][:, 0], seqs[False][:, 0], rtol=2e-2), (seqs[True][:, 0], seqs[False][:, 0])
+    assert torch.allclose(seqs[True], seqs[False], rtol=4e-2, atol=2e-3), (seqs[True], seqs[False])
+    for a, b in zip(norms[True], norms[False]):
+        assert abs(a - b) <= 0.25 * b + 1e-6, (norms[True], norms[False])
+
+
 @pytest.mark.parametrize("use_graph", [False, True, "step"])
 def test_itr_trainer_with_pipelined_teacher_reproduces_the_unpipelined_trajectory(use_graph, monkeypatch):
     """ITRTrainer(pipeline_teacher=True): the frozen teacher runs one batch ahead on a side stream (TeacherPrefetch; a
