@@ -452,7 +452,7 @@ __device__ __forceinline__ void stage_block(const bf16* base, int ld, int L, int
   }
 }
 
-template <int NW, bool LSE>
+template <int NW, bool LSE, int TQ>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
   constexpr int KBT = 8, KB = KBT * 16;                  // 128 keys per block
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -466,15 +466,22 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
   if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
   const int qblk = lid % gx, h = (lid / gx) % a.H, b = lid / (gx * a.H);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
-  const int q0 = (qblk * NW + wave) * 16;
-  const int q = q0 + ql;
-  const bool active = q0 < a.Lq, qok = q < a.Lq;         // (waves past the last query still stage and meet the barriers)
+  // TQ query tiles per wave (consecutive): every K / V fragment read out of LDS feeds TQ MFMAs, and the TQ independent
+  // softmax chains interleave in the wave's instruction stream
+  const int q0 = (qblk * NW + wave) * 16 * TQ;
+  int q[TQ];
+  bool qok[TQ];
+#pragma unroll
+  for (int j = 0; j < TQ; ++j) { q[j] = q0 + 16 * j + ql; qok[j] = q[j] < a.Lq; }
+  const bool active = q0 < a.Lq;                         // (waves past the last query still stage and meet the barriers)
   if (!LSE && a.skip_dead && a.gate && !a.Pt && a.gate[h] == 0.f) {        // closed head, zero context (workgroup-uniform)
-    if (qok) {
-      bf16* Or = a.O + ((size_t)b * a.Lq + q) * a.ldo + h * DH + g * 16;
-      *reinterpret_cast<uint4*>(Or) = make_uint4(0, 0, 0, 0);
-      *reinterpret_cast<uint4*>(Or + 8) = make_uint4(0, 0, 0, 0);
-    }
+#pragma unroll
+    for (int j = 0; j < TQ; ++j)
+      if (qok[j]) {
+        bf16* Or = a.O + ((size_t)b * a.Lq + q[j]) * a.ldo + h * DH + g * 16;
+        *reinterpret_cast<uint4*>(Or) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(Or + 8) = make_uint4(0, 0, 0, 0);
+      }
     return;
   }
   const int bkv = a.kv_index ? a.kv_index[b] : b;
@@ -483,36 +490,43 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
   for (int k = threadIdx.x; k < nblk * KB; k += blockDim.x)
     Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
   if (threadIdx.x < 2) kdw[threadIdx.x] = 0.f;
-  bf16x8 qf[2];
+  bf16x8 qf[TQ][2];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (qok) v = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + ks * 32 + g * 8);
-    qf[ks] = *reinterpret_cast<bf16x8*>(&v);
-  }
+  for (int j = 0; j < TQ; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qok[j]) v = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q[j]) * a.ldq + h * DH + ks * 32 + g * 8);
+      qf[j][ks] = *reinterpret_cast<bf16x8*>(&v);
+    }
   stage_block<SW_K>(Kb, a.ldk, a.Lk, 0, KB, NW, smem);
   stage_block<SW_V>(Vb, a.ldv, a.Lk, 0, KB, NW, smem + KB * 128);
   const float sc = a.scale * 1.44269504088896341f;
-  const bool kd_on = LSE && a.Pt != nullptr && qok;
-  const bf16* Tr = kd_on ? a.Pt + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr : nullptr;
-  float m = -3.0e38f, l = 0.f, se2 = 0.f, sep = 0.f, spt = 0.f;
-  f32x4 o[4];
+  const bool kd_any = LSE && a.Pt != nullptr;
+  float m[TQ], l[TQ], se2[TQ], sep[TQ], spt[TQ];
+  f32x4 o[TQ][4];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < TQ; ++j) {
+    m[j] = -3.0e38f; l[j] = 0.f; se2[j] = 0.f; sep[j] = 0.f; spt[j] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[j][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   for (int blk = 0; blk < nblk; ++blk) {
     stage_wait();
     __syncthreads();                                     // block blk has landed; everyone is done with the other buffer
     // the teacher map's piece for this block is requested BEFORE the next block's DMA: vmcnt counts in order, a wait for
     // a load issued behind the DMA would drain the DMA with it
-    bf16x8 t8[KBT / 2];
-    if (kd_on) {
+    bf16x8 t8[TQ][KBT / 2];
+    if (kd_any) {
 #pragma unroll
-      for (int s2 = 0; s2 < KBT / 2; ++s2) {
-        const int kcol = blk * KB + s2 * 32 + g * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (kcol < a.ldpr) v = *reinterpret_cast<const uint4*>(Tr + kcol);
-        t8[s2] = *reinterpret_cast<bf16x8*>(&v);
-      }
+      for (int j = 0; j < TQ; ++j)
+#pragma unroll
+        for (int s2 = 0; s2 < KBT / 2; ++s2) {
+          const int kcol = blk * KB + s2 * 32 + g * 8;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (qok[j] && kcol < a.ldpr) v = *reinterpret_cast<const uint4*>(a.Pt + (((size_t)b * a.H + h) * a.Lq + q[j]) * a.ldpr + kcol);
+          t8[j][s2] = *reinterpret_cast<bf16x8*>(&v);
+        }
     }
     if (blk + 1 < nblk) {
       char* nb = smem + ((blk + 1) & 1) * 2 * KB * 128;
@@ -522,92 +536,116 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
     if (!active) continue;                               // (wave-uniform)
     const char* Ks = smem + (blk & 1) * 2 * KB * 128;
     const char* Vs = Ks + KB * 128;
-    f32x4 acc[KBT];
+    f32x4 acc[TQ][KBT];
 #pragma unroll
     for (int t = 0; t < KBT; ++t) {
-      acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Ks, t, ks, lane), qf[ks], acc[t], 0, 0, 0);
+      for (int j = 0; j < TQ; ++j) acc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kf = krow_frag(Ks, t, ks, lane);
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[j][ks], acc[j][t], 0, 0, 0);
+      }
     }
-    float bm = -3.0e38f;
+    float bm[TQ];
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) bm[j] = -3.0e38f;
 #pragma unroll
     for (int t = 0; t < KBT; ++t) {
       const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + blk * KB + tile_key0(t, g));
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        acc[t][r] = fmaf(acc[t][r], sc, mk[r] * LOG2E);   // (the recomputing backward forms the same number)
-        bm = fmaxf(bm, acc[t][r]);
+        const float ml = mk[r] * LOG2E;
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+          acc[j][t][r] = fmaf(acc[j][t][r], sc, ml);     // (the recomputing backward forms the same number)
+          bm[j] = fmaxf(bm[j], acc[j][t][r]);
+        }
       }
     }
-    bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-    const float mn = fmaxf(m, bm);
-    const float alpha = EXP2(m - mn);                    // (first block: 2^(-3e38) = 0 on l = 0, o = 0)
-    m = mn;
-    l *= alpha;
+    float alpha[TQ];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int j = 0; j < TQ; ++j) {
+      bm[j] = fmaxf(bm[j], __shfl_xor(bm[j], 16, 64));
+      bm[j] = fmaxf(bm[j], __shfl_xor(bm[j], 32, 64));
+      const float mn = fmaxf(m[j], bm[j]);
+      alpha[j] = EXP2(m[j] - mn);                        // (first block: 2^(-3e38) = 0 on l = 0, o = 0)
+      m[j] = mn;
+      l[j] *= alpha[j];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+      for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-    for (int t = 0; t < KBT; ++t)
+        for (int r = 0; r < 4; ++r) o[j][dt][r] *= alpha[j];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        acc[t][r] = EXP2(acc[t][r] - mn);
-        l += acc[t][r];                                  // (this lane's keys; the lane groups meet after the last block)
-      }
-    if (kd_on) {
-      se2 *= alpha * alpha;
-      sep *= alpha;
-#pragma unroll
-      for (int s2 = 0; s2 < KBT / 2; ++s2)
+      for (int t = 0; t < KBT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e0 = acc[2 * s2][r], e1 = acc[2 * s2 + 1][r];
-          const float p0 = (float)t8[s2][r], p1 = (float)t8[s2][4 + r];
-          se2 = fmaf(e0, e0, se2); se2 = fmaf(e1, e1, se2);
-          sep = fmaf(e0, p0, sep); sep = fmaf(e1, p1, sep);
-          spt = fmaf(p0, p0, spt); spt = fmaf(p1, p1, spt);
+          acc[j][t][r] = EXP2(acc[j][t][r] - mn);
+          l[j] += acc[j][t][r];                          // (this lane's keys; the lane groups meet after the last block)
         }
+      if (kd_any && qok[j]) {
+        se2[j] *= alpha[j] * alpha[j];
+        sep[j] *= alpha[j];
+#pragma unroll
+        for (int s2 = 0; s2 < KBT / 2; ++s2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e0 = acc[j][2 * s2][r], e1 = acc[j][2 * s2 + 1][r];
+            const float p0 = (float)t8[j][s2][r], p1 = (float)t8[j][s2][4 + r];
+            se2[j] = fmaf(e0, e0, se2[j]); se2[j] = fmaf(e1, e1, se2[j]);
+            sep[j] = fmaf(e0, p0, sep[j]); sep[j] = fmaf(e1, p1, sep[j]);
+            spt[j] = fmaf(p0, p0, spt[j]); spt[j] = fmaf(p1, p1, spt[j]);
+          }
+      }
     }
     // O^T += V^T E^T with the un-normalised e (<= 1) as bf16: the row's 1 / l is applied once, to the context
 #pragma unroll
     for (int s2 = 0; s2 < KBT / 2; ++s2) {
-      bf16x8 pb;
+      bf16x8 pb[TQ];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { pb[r] = (bf16)acc[2 * s2][r]; pb[4 + r] = (bf16)acc[2 * s2 + 1][r]; }
+      for (int j = 0; j < TQ; ++j)
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Vs, 2 * s2, 2 * s2 + 1, dt, lane), pb, o[dt], 0, 0, 0);
+        for (int r = 0; r < 4; ++r) { pb[j][r] = (bf16)acc[j][2 * s2][r]; pb[j][4 + r] = (bf16)acc[j][2 * s2 + 1][r]; }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 vf = vcol_frag(Vs, 2 * s2, 2 * s2 + 1, dt, lane);
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) o[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[j], o[j][dt], 0, 0, 0);
+      }
     }
   }
   float sq = 0.f;
   if (active) {
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
-    if (LSE && qok && g == 0) a.lse[((size_t)b * a.H + h) * a.Lq + q] = m + __log2f(l);
-    if (qok) {
-      const float gz = (a.gate ? a.gate[h] : 1.0f) * inv;
-      bf16* Or = a.O + ((size_t)b * a.Lq + q) * a.ldo + h * DH;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        bf16x4 ov = {(bf16)(o[dt][0] * gz), (bf16)(o[dt][1] * gz), (bf16)(o[dt][2] * gz), (bf16)(o[dt][3] * gz)};
-        *reinterpret_cast<bf16x4*>(Or + dt * 16 + g * 4) = ov;
+    for (int j = 0; j < TQ; ++j) {
+      float lj = l[j];
+      lj += __shfl_xor(lj, 16, 64);
+      lj += __shfl_xor(lj, 32, 64);
+      const float inv = 1.0f / lj;
+      if (LSE && qok[j] && g == 0) a.lse[((size_t)b * a.H + h) * a.Lq + q[j]] = m[j] + __log2f(lj);
+      if (qok[j]) {
+        const float gz = (a.gate ? a.gate[h] : 1.0f) * inv;
+        bf16* Or = a.O + ((size_t)b * a.Lq + q[j]) * a.ldo + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          bf16x4 ov = {(bf16)(o[j][dt][0] * gz), (bf16)(o[j][dt][1] * gz), (bf16)(o[j][dt][2] * gz), (bf16)(o[j][dt][3] * gz)};
+          *reinterpret_cast<bf16x4*>(Or + dt * 16 + g * 4) = ov;
+        }
       }
-    }
-    if (LSE && a.Pt) {
-      if (kd_on) sq = fmaf(se2 * inv, inv, fmaf(-2.f * sep, inv, spt));
-      if (a.rkd) {
-        float rk = kd_on ? fmaf(se2 * inv, inv, -sep * inv) : 0.f;
-        rk += __shfl_xor(rk, 16, 64);
-        rk += __shfl_xor(rk, 32, 64);
-        if (qok && g == 0) a.rkd[((size_t)b * a.H + h) * a.Lq + q] = rk;
+      if (kd_any) {
+        const bool on = qok[j];
+        if (on) sq += fmaf(se2[j] * inv, inv, fmaf(-2.f * sep[j], inv, spt[j]));
+        if (a.rkd) {
+          float rk = on ? fmaf(se2[j] * inv, inv, -sep[j] * inv) : 0.f;
+          rk += __shfl_xor(rk, 16, 64);
+          rk += __shfl_xor(rk, 32, 64);
+          if (on && g == 0) a.rkd[((size_t)b * a.H + h) * a.Lq + q[j]] = rk;
+        }
       }
     }
   }
-  if (LSE && a.Pt) {                                     // one atomic per workgroup (the waves meet in LDS, last one publishes)
+  if (kd_any) {                                          // one atomic per workgroup (the waves meet in LDS, last one publishes)
     sq = wave_sum(sq);
     if (lane == 0) {
       atomicAdd(&kdw[0], sq);
@@ -791,12 +829,12 @@ static bool launch_fwd_stream(const MAttnF& f, hipStream_t stream) {
   constexpr int KB = 128;
   const int nblk = (f.Lk + KB - 1) / KB, qtiles = (f.Lq + 15) / 16;
   const size_t lds = (size_t)4 * KB * 128 + (size_t)nblk * KB * sizeof(float) + 16;
-#define STREAM_LAUNCH(NW_, LSE_)                                                                                         \
+#define STREAM_LAUNCH(NW_, LSE_, TQ_)                                                                                    \
   do {                                                                                                                   \
-    (void)hipFuncSetAttribute((const void*)attn_fwd_stream_kernel<NW_, LSE_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    (void)hipFuncSetAttribute((const void*)attn_fwd_stream_kernel<NW_, LSE_, TQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                                                 \
-    dim3 grid((qtiles + NW_ - 1) / NW_, f.H, f.B), block(64 * NW_);                                                     \
-    hipLaunchKernelGGL((attn_fwd_stream_kernel<NW_, LSE_>), grid, block, lds, stream, f);                                \
+    dim3 grid((qtiles + NW_ * TQ_ - 1) / (NW_ * TQ_), f.H, f.B), block(64 * NW_);                                       \
+    hipLaunchKernelGGL((attn_fwd_stream_kernel<NW_, LSE_, TQ_>), grid, block, lds, stream, f);                           \
   } while (0)
   // 8 waves = 128 queries per workgroup: measured (tools/attn_long_bench.py) level with or ahead of 16 waves on the ViT's
   // 577 / 901 tokens (the last query block is fuller, two workgroups share a CU), and a few text queries on those image
@@ -815,10 +853,15 @@ static bool launch_fwd_stream(const MAttnF& f, hipStream_t stream) {
 #undef STREAM_MAP_LAUNCH
     return true;
   }
+  // two query tiles per wave once a (batch, head) has more than one workgroup's worth of single tiles (EVLM_ATTN_STREAM_TQ)
+  static const int tq_env = getenv("EVLM_ATTN_STREAM_TQ") ? atoi(getenv("EVLM_ATTN_STREAM_TQ")) : 0;     // (tuning aid)
+  // measured (tools/attn_long_bench.py, TQ = 1 -> 2): with lse 190 -> 158 us (577 keys) / 227 -> 162 (901), with lse + fused
+  // distillation 289 -> 264 / 359 -> 289, no-grad 155 -> 166 / 177 -> 158; two text query tiles on image tokens 62 -> 111
+  const int tq = tq_env == 1 || tq_env == 2 ? tq_env : ((qtiles > 8 && (f.lse || qtiles > 40)) ? 2 : 1);
   if (f.lse) {
-    if (nw == 8) STREAM_LAUNCH(8, true); else STREAM_LAUNCH(16, true);
+    if (nw == 16) STREAM_LAUNCH(16, true, 1); else if (tq == 2) STREAM_LAUNCH(8, true, 2); else STREAM_LAUNCH(8, true, 1);
   } else {
-    if (nw == 8) STREAM_LAUNCH(8, false); else STREAM_LAUNCH(16, false);
+    if (nw == 16) STREAM_LAUNCH(16, false, 1); else if (tq == 2) STREAM_LAUNCH(8, false, 2); else STREAM_LAUNCH(8, false, 1);
   }
 #undef STREAM_LAUNCH
   return true;
