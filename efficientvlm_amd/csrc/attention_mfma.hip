@@ -1456,19 +1456,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
         mk[r] = (key < a.Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -1e30f) * LOG2E;
       }
     }
-    for (int q0 = 0; q0 < a.Lq; q0 += 32) {
-      float lq[2] = {0.f, 0.f};
-      if (rcp) {                                         // (requested with the tiles: one latency for all of a chunk's loads)
+    // software pipeline over the 32-query chunks: chunk i+1's global loads (Q, dO, dS [, P] pieces and the row lse) are in
+    // flight in registers while chunk i is multiplied - before, every chunk was a bare round trip to memory between two
+    // barriers
+    const int srow = threadIdx.x >> 3, scol = threadIdx.x & 7;          // this thread's 16-byte piece of a [32][64] tile
+    uint4 nq, ndo, np, ns;
+    float nlq[2];
+    auto fetch = [&](int q0) {
+      const bool rv = q0 + srow < a.Lq;
+      nq = ndo = np = ns = make_uint4(0, 0, 0, 0);
+      nlq[0] = nlq[1] = 0.f;
+      if (rv) {
+        nq = *reinterpret_cast<const uint4*>(Qb + (size_t)(q0 + srow) * a.ldq + scol * 8);
+        ndo = *reinterpret_cast<const uint4*>(dOb + (size_t)(q0 + srow) * a.ldo + scol * 8);
+        if (k0 + scol * 8 < a.ldpr) {
+          ns = *reinterpret_cast<const uint4*>(a.dS + pbase + (size_t)(q0 + srow) * a.ldpr + k0 + scol * 8);
+          if (!rcp) np = *reinterpret_cast<const uint4*>(a.P + pbase + (size_t)(q0 + srow) * a.ldpr + k0 + scol * 8);
+        }
+      }
+      if (rcp) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          if (q0 + 16 * j + ql < a.Lq) lq[j] = a.lse[((size_t)b * a.H + h) * a.Lq + q0 + 16 * j + ql];
+          if (q0 + 16 * j + ql < a.Lq) nlq[j] = a.lse[((size_t)b * a.H + h) * a.Lq + q0 + 16 * j + ql];
       }
+    };
+    fetch(0);
+    for (int q0 = 0; q0 < a.Lq; q0 += 32) {
+      __syncthreads();                                   // every wave is done with the previous chunk's tiles
+      const int so = srow * 128 + p_swz(srow, scol) * 16;
+      *reinterpret_cast<uint4*>(Qs + so) = nq;
+      *reinterpret_cast<uint4*>(dOs + so) = ndo;
+      if (!rcp) *reinterpret_cast<uint4*>(Ps + so) = np;
+      *reinterpret_cast<uint4*>(Ss + so) = ns;
+      const float lq[2] = {nlq[0], nlq[1]};
       __syncthreads();
-      stage_qtile(Qb, a.ldq, q0, a.Lq, 0, DH, Qs);
-      stage_qtile(dOb, a.ldo, q0, a.Lq, 0, DH, dOs);
-      if (!rcp) stage_qtile(a.P + pbase, a.ldpr, q0, a.Lq, k0, a.ldpr, Ps);
-      stage_qtile(a.dS + pbase, a.ldpr, q0, a.Lq, k0, a.ldpr, Ss);
-      __syncthreads();
+      if (q0 + 32 < a.Lq) fetch(q0 + 32);
       if (rcp) {
         // P of this wave's 16 keys x the chunk's 32 queries, rebuilt as kernel A built it (same operands in the same
         // k-slots, same fma, same lse: the same bf16 values it multiplied into dS) and written into the wave's OWN 16
