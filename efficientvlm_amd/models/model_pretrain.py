@@ -193,6 +193,7 @@ class XVLM(XVLMBase):
                  encoder_attention_mask=None if region is None else torch.index_select(enc_atts, 0, img_index),
                  encoder_batch_index=img_index.to(torch.int32),      # (cast once here, not in every cross-attention)
                  return_dict=True, mode="fusion", output_attentions=True, output_hidden_states=True)
+        yield "fusion_done"
         # (the hidden-state / attention-map distillation terms depend on nothing past this point: a trainer that runs them
         # on the side stream - distill.kd_terms - forks from HERE, beside the task heads below)
         self.kd_fork = None

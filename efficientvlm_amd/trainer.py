@@ -399,6 +399,9 @@ class GDTrainer(_StagedExchange):
             ops.WGRAD_ASSIGN = self._assign
             try:
                 # (multi-GPU: the mean's 1 / world enters here, the all-reduces are plain sums)
+                hook = getattr(self.student, "phase_hook", None)
+                if hook is not None:
+                    hook("forward_done")
                 self.reducer.scale_loss(total).backward()
                 self._join_text_stream()
                 ops.flush_wgrad()
@@ -837,11 +840,15 @@ class GDTrainer(_StagedExchange):
 
     def _joint_body(self, pipe, p, pp, pk):
         """single GPU: student step on (pp, pk) with the teacher forward of (pipe, p) forked onto the side stream.
-        EVLM_TEACHER_FORK = start | vision_done | text_done: where the fork sits in the student's forward;
+        EVLM_TEACHER_FORK = start | vision_done | text_done (default) | fusion_done | forward_done: where the fork sits in the
+        student's forward;
         EVLM_TEACHER_JOIN = end | vision: join at the end of the step, or when backward enters the image encoder (the ViT
         backward - large, chip-filling GEMMs - then runs alone; the teacher shares the chip with the text-side work)."""
         cur, side = torch.cuda.current_stream(), self._side
-        fork_at = os.environ.get("EVLM_TEACHER_FORK", "start")
+        # (round 4, 40-step A/Bs on one box: fork at "start" 14.79 / 14.80 / 14.78 ms, at "text_done" - the student's image and
+        # text encoders are through, its small fusion / head kernels begin - 14.65 / 14.67 / 14.66, "vision_done" 16.6,
+        # "fusion_done" 15.4, "forward_done" 15.5)
+        fork_at = os.environ.get("EVLM_TEACHER_FORK", "text_done")
         join_at = os.environ.get("EVLM_TEACHER_JOIN", "end")
         state = {"forked": False}
 
