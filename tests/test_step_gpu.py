@@ -323,8 +323,9 @@ def test_benchmarked_configuration_matches_the_oracle(B):
 @pytest.mark.gpu
 def test_forward_phases_generator_equals_forward():
     """XVLM.forward_phases (the batched forward as a generator over its phases - what lets a trainer issue the pipelined
-    teacher's image encoder and its text / fusion passes in two different hipGraph segments) yields "vision_done" then
-    "text_done" and returns forward()'s dict, tensor for tensor"""
+    teacher's image encoder and its text / fusion passes in two different hipGraph segments, and a trainer fork the teacher's
+    branch at a phase of the student's forward) yields "vision_done", "text_done", "fusion_done" and returns forward()'s
+    dict, tensor for tensor"""
     from efficientvlm_amd import distill
     from efficientvlm_amd.runtime import compute
     geom = synth.GEOMS["tiny"]
@@ -341,7 +342,7 @@ def test_forward_phases_generator_equals_forward():
                 names.append(next(gen))
         except StopIteration as done:
             out = done.value
-    assert names == ["vision_done", "text_done"]
+    assert names == ["vision_done", "text_done", "fusion_done"]
     a, b = list(distill._tensors(ref)), list(distill._tensors(out))
     assert len(a) == len(b) and len(a) > 20
     for x, y in zip(a, b):
