@@ -3,9 +3,10 @@
 X-VLM-base teacher forward under no_grad, every KD loss, gradient reduction, global-norm clip + AdamW) on synthetic
 224x224 images + 30-token captions, batch 64 per GPU, bf16 compute (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N --steps K --warmup W]             # N=1 directly
+    python bench.py [--gpus N --steps K --warmup W]             # N=1 directly; N>1: starts its own N ranks (child
+                                                                # launcher, one rank per GPU over RCCL) and relays the line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W                  # N>1: one rank per GPU over RCCL
+        bench.py --gpus N --steps K --warmup W                  # N>1 under an existing launcher: this process is a rank
 
 The frozen teacher is pipelined one batch ahead of the student (GDTrainer(pipeline_teacher=True)): every
 timed step runs one teacher forward (on the next batch), one student forward + backward and one optimiser step; four
@@ -308,6 +309,53 @@ def roofline_leg(trainer, batch):
     return roof, all_fl + attn_flops
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# launch: `python bench.py --gpus N` starts its own ranks (as the reference's run.py:42-66,190-197 shells out to
+# torch.distributed.launch); under an existing launcher (WORLD_SIZE set) the process IS a rank
+# ---------------------------------------------------------------------------------------------------------------------
+def launch_plan(gpus, env):
+    """'rank' - this process runs the step (N = 1, or a launcher has set WORLD_SIZE); 'spawn' - N > 1 asked for with no
+    launcher around: this process starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD,
+    relays rank 0's JSON line and exits with the child's return code.  Decided before any GPU call: the parent never
+    touches the GPU (and nothing is ever exec'ed over a process that has)."""
+    if gpus <= 1 or "WORLD_SIZE" in env:
+        return "rank"
+    return "spawn"
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(gpus, argv, run=subprocess.run):
+    """parent of an N > 1 run started without a launcher: one child (the launcher module), N grandchildren (the ranks)"""
+    have = torch.cuda.device_count()             # (counting devices does not initialise the GPU)
+    if have < gpus and not os.environ.get("EVLM_BENCH_SHARE_GPU"):
+        print(f"bench.py: --gpus {gpus} but this node shows {have} GPU(s)  (EVLM_BENCH_SHARE_GPU=1: a dry run of the launch "
+              f"contract with every rank on device 0 over gloo)", file=sys.stderr)
+        return 2
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__), *argv]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, _cpu_allowed() // max(1, gpus))))
+    r = run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in (r.stdout or "").splitlines() if l.startswith('{"metric"')]
+    for l in (r.stdout or "").splitlines():
+        if not l.startswith('{"metric"'):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif r.returncode == 0:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
+        return 1
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -330,6 +378,10 @@ def main():
         oracle_check_child(args.oracle_check_child)
         return
 
+    plan = launch_plan(args.gpus, os.environ)
+    if plan == "spawn":
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     # stdout carries exactly ONE line (the JSON result): anything libraries write to fd 1 meanwhile - RCCL prints a
     # version / hostname block there when its first communicator is created - is sent to stderr instead
     sys.stdout.flush()
@@ -349,7 +401,8 @@ def main():
             local_rank, backend = 0, "gloo"
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}")
     dev = torch.device("cuda", local_rank)
 
     from efficientvlm_amd.workload import GEOMS, make_batch

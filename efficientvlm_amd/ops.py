@@ -105,9 +105,18 @@ class WeightCache:
         L.check(_lib().evlm_transpose_grouped(L.ptr(table), n, tiles, L.stream()), "transpose_grouped")
 
     # ---- optimiser-owned parameter slabs (optim.FlatAdamW): the bf16 mirror is kept current by the AdamW kernel ----
-    def register_slab(self, p, slab32, slab16, off):
+    def register_slab(self, p, slab32, slab16, off, seg=None):
+        """seg: slab words reserved for the parameter (>= numel; what lies between is ZERO and stays zero: optim._seg)"""
         import weakref
-        self._slab[id(p)] = [slab32, slab16, off, p.numel(), p._version, weakref.ref(p)]
+        self._slab[id(p)] = [slab32, slab16, off, p.numel(), p._version, weakref.ref(p), seg or p.numel()]
+
+    def zero_padded_rows(self, W, rows):
+        """may a [rows, K] operand be read in place at W (a [N, K] bf16 view, rows > N)?  Only when W is the mirror of a
+        slab-backed parameter whose segment reserves - and keeps at zero - the words behind the matrix"""
+        for e in self._slab.values():
+            if e[1] is not None and W.data_ptr() == e[1].data_ptr() + e[2] * 2 and e[5]() is not None:
+                return W.dim() == 2 and W.is_contiguous() and W.numel() == e[3] and rows * W.shape[1] <= e[6]
+        return False
 
     def refresh_slab(self, slab32, slab16):
         """re-cast a whole slab (construction; or a parameter was modified outside the optimiser)"""
@@ -672,11 +681,12 @@ def _linear_backward(ctx, dy, dx_add):
             if dtype == L.BF16 and N % 64 != 0 and N >= 4096 and M <= 2048 and ldd >= n64 and act == L.ACT_NONE:
                 # skinny product with a vocabulary-sized ragged reduction (MLM decoder): zero-pad W's rows to a multiple
                 # of 64 (dY's padding columns are zero already) so the split-K f32 path applies, then cast once
-                # The rows past N only ever meet dY's zero padding columns, so any FINITE words serve: when W is a view into
-                # the optimiser's bf16 slab with n64 - N more rows of slab behind it (other parameters, or the slab's zero
-                # padding), the product reads the slab in place - no 47 MB copy of the vocabulary matrix per step
+                # When W is the bf16 mirror of a slab-backed parameter the slab layout keeps n64 - N ZERO rows behind the
+                # matrix (optim._seg: zero gradient and moments, so AdamW leaves them at zero) and the product reads the slab
+                # in place - no 47 MB copy of the vocabulary matrix per step.  Anything else (a weight outside a slab) is
+                # copied into a zero-padded scratch: the rows meet dY's zero columns, but 0 x non-finite is NaN
                 Wp = None
-                if W.is_contiguous() and W.storage_offset() + n64 * K <= W.untyped_storage().nbytes() // W.element_size():
+                if CACHE.zero_padded_rows(W, n64):
                     Wp = torch.as_strided(W, (n64, K), (K, 1))
                 if Wp is None:
                     Wp = _scratch(("wpad", n64, K), (n64, K), x2.dtype, x2.device, zero=True)
@@ -1037,7 +1047,15 @@ class _Attention(torch.autograd.Function):
                        and ctx.drop is None and os.environ.get("EVLM_ATTN_BWD_SPLIT", "0") in ("", "0"))
         dS = None if single_pass else torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev)
         # (two-kernel recomputing path: the second kernel reads the map the first one rebuilds)
-        P_ws = torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev) if (lse is not None and not single_pass) else None
+        # ... except on the streaming one-pass path (attention_mfma.hip:launch_bwd_dq_stream - the same conditions): there
+        # kernel B rebuilds the probabilities itself and a [B, H, Lq, Lkp] workspace (518 MB per layer at ITR-384, reserved
+        # for the life of a captured step's pool) would never be touched
+        env_on = lambda n: os.environ.get(n, "0") not in ("", "0")
+        streams = (lse is not None and Lk > 224 and Lk <= 928 and not ctx.causal and O_fwd is not None and dPc is None
+                   and (kd_base is None or dkd is None or rkd is not None) and tdt == torch.bfloat16 and dh == 64
+                   and not env_on("EVLM_ATTN_NO_STREAM") and not env_on("EVLM_ATTN_STREAM_PWS"))
+        P_ws = (torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev)
+                if (lse is not None and not single_pass and not streams) else None)
         dgate = torch.zeros(H, dtype=torch.float32, device=dev) if g32 is not None else None
         a = L.AttnBwdArgs(dtype=L.dt(tdt), p_dtype=L.dt(tdt), B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, Bkv=Bkv, ldq=ldq, ldk=ldk, ldv=ldk,
                           ldo=H * dh, lddq=ldq, lddk=ldk, lddv=ldk, ldpr=Lkp,

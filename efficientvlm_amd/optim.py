@@ -50,6 +50,18 @@ def _pack_order(named):
     return [it for _, it in sorted(enumerate(named), key=key)]
 
 
+def _seg(p):
+    """slab words a parameter occupies: its elements rounded up to 8 (32-byte fp32 / 16-byte bf16 alignment).  A tall matrix
+    whose row count is not a multiple of 64 (the 30 522-row vocabulary matrix) is followed by ZERO rows up to the next
+    multiple: the vocabulary head's dX = dY W reads W out of the bf16 mirror in place as a [ceil64(rows), K] operand
+    (ops._Linear.backward) - the rows behind the matrix meet dY's zero padding columns, and 0 x (a neighbouring parameter
+    gone non-finite) would be NaN in every row of dX.  Zero gradient, zero moments: AdamW leaves the pad at zero."""
+    k = p.numel()
+    if p.dim() == 2 and p.shape[0] >= 4096 and p.shape[0] % 64:
+        k = (p.shape[0] + 63) // 64 * 64 * p.shape[1]
+    return (k + 7) // 8 * 8
+
+
 class FlatAdamW:
     def __init__(self, model, lr=1e-4, weight_decay=0.01, lr_mult=1.0, betas=(0.9, 0.98), eps=1e-8, max_grad_norm=1.0,
                  late_prefix="vision_encoder."):
@@ -76,7 +88,7 @@ class FlatAdamW:
         self.hyper = torch.ones(3, dtype=torch.float32, device=dev)       # {lr multiplier, bias_c1, bias_c2}
         lowp = dev.type == "cuda"
         for g in self.groups:
-            n = sum((p.numel() + 7) // 8 * 8 for p in g["params"])          # 32-byte (fp32) / 16-byte (bf16) aligned segments
+            n = sum(_seg(p) for p in g["params"])          # 32-byte (fp32) / 16-byte (bf16) aligned segments
             g["p"] = torch.zeros(n, dtype=torch.float32, device=dev)
             g["g"] = torch.zeros(n, dtype=torch.float32, device=dev)
             g["m"] = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -88,7 +100,7 @@ class FlatAdamW:
             late = []                  # [lo, hi) slab ranges of the parameters whose gradients arrive LAST in backward
             for p, nme in zip(g["params"], g["names"]):
                 k = p.numel()
-                seg = (k + 7) // 8 * 8
+                seg = _seg(p)
                 if nme.startswith(late_prefix):
                     if late and late[-1][1] == off:
                         late[-1][1] = off + seg
@@ -98,7 +110,7 @@ class FlatAdamW:
                 p.data = g["p"][off:off + k].view(p.shape)
                 p.grad = g["g"][off:off + k].view(p.shape)
                 if lowp:
-                    ops.CACHE.register_slab(p, g["p"], g["pb"], off)
+                    ops.CACHE.register_slab(p, g["p"], g["pb"], off, seg)
                 off += seg
             g["late"] = late
             if lowp:
@@ -131,7 +143,7 @@ class FlatAdamW:
         for g in self.groups:
             off, cur = 0, None
             for p, nme in zip(g["params"], g["names"]):
-                seg = (p.numel() + 7) // 8 * 8
+                seg = _seg(p)
                 if pred(nme):
                     if cur is not None and cur[1] == off:
                         cur[1] = off + seg
@@ -165,7 +177,7 @@ class FlatAdamW:
             off, pos = 0, 0
             for p in g["params"]:
                 k = p.numel()
-                seg = (k + 7) // 8 * 8
+                seg = _seg(p)
                 if id(p) in lin and p.dim() == 2 and k >= 4096 and k == seg:
                     if off > pos:
                         fill.append(g["g"][pos:off])
@@ -210,7 +222,7 @@ class FlatAdamW:
                 if p.grad is not None and p.grad.data_ptr() != g["g"].data_ptr() + off * 4:
                     g["g"][off:off + k].copy_(p.grad.reshape(-1))
                     p.grad = g["g"][off:off + k].view(p.shape)
-                off += (k + 7) // 8 * 8
+                off += _seg(p)
         self.gnorm_sq.zero_()
         for g in self.groups:
             L.check(lib.evlm_sumsq(L.ptr(g["g"]), g["g"].numel(), L.ptr(self.gnorm_sq), L.ptr(self.sumsq_ws), L.stream()), "sumsq")

@@ -276,6 +276,77 @@ class _StagedExchange:
         if self._cut is None:
             self.reducer.finish()
 
+    def _replay_segments(self, segs, last_reduce):
+        """a step captured as hipGraph segments around its collectives: graphs replay on the current stream, the ITC gather
+        is issued between two of them, every gradient stage's all-reduce goes to the reducer's stream beside the NEXT
+        segment - except the last one, which the optimiser segment waits for"""
+        for kind, item in segs:
+            if kind == "graph":
+                item.replay()
+            elif kind == "gather":
+                log_collective("all_gather", item[1])
+                dist.all_gather(item[0], item[1])
+            else:
+                self.reducer.reduce_async(item)
+                if item is last_reduce:
+                    self.reducer.finish()
+
+    # ---- lifetime --------------------------------------------------------------------------------------------------
+    # A trainer owns hipGraphs (hipGraphExec objects, their private memory pools), pinned staging blocks and side streams,
+    # and sits in reference cycles (model hooks point back at it), so without close() all of that dies whenever Python's
+    # cyclic collector happens to run - possibly while ANOTHER trainer captures or replays, which this stack answers with
+    # a fault inside hipGraphLaunch / an abort inside the capture (DESIGN.md "runtime landmines").  close() releases them at
+    # a moment of the caller's choosing, with the device idle.
+    _closed = False
+    _GRAPH_ATTRS = ("_joint", "_seg", "_graphs", "_pipes", "_sgraphs", "_seen", "_eps")
+
+    def close(self):
+        """destroy this trainer's hipGraphs, static buffers and pinned blocks with the device idle, and cut the hooks that
+        tie the models to it.  Idempotent; the trainer must not step afterwards."""
+        if self._closed:
+            return
+        self._closed = True
+        cuda = torch.cuda.is_available()
+        if cuda:
+            torch.cuda.synchronize()
+        for model in (getattr(self, "student", None),):
+            if model is None:
+                continue
+            if getattr(model, "on_vision_grad", None) is not None:
+                model.on_vision_grad = None
+            if hasattr(model, "phase_hook"):
+                model.phase_hook = None
+            enc = getattr(getattr(model, "vision_encoder", None), "encoder", None)
+            if enc is not None and getattr(enc, "grad_hooks", None):
+                enc.grad_hooks = {}
+        pre = getattr(self, "prefetch", None)
+        if pre is not None:
+            pre.close()
+        for name in self._GRAPH_ATTRS:
+            v = getattr(self, name, None)
+            if isinstance(v, (dict, set)):
+                v.clear()
+        for name in ("graph", "static", "out", "_pending", "_last_ST", "_tpool", "_spool", "_seg_pool", "_step_pool"):
+            if hasattr(self, name):
+                setattr(self, name, None)
+        self.last_kd = {}
+        gc.collect()                       # the graphs die HERE (device idle), not at a later collection
+        if cuda:
+            torch.cuda.synchronize()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):                     # last resort only (a trainer dropped without close()): never raise from here
+        try:
+            if not self._closed and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                self.close()
+        except Exception:
+            pass
+
 
 def teacher_map_filter(student, teacher, with_cross):
     """The KD terms read every k-th attention map of the (deeper) teacher (get_cor_teacher: map i*k + k-1 for student map i;
@@ -824,16 +895,7 @@ class GDTrainer(_StagedExchange):
                 self._seg.clear()
                 return None
             self._seg[key] = sg
-        for kind, item in sg["segs"]:
-            if kind == "graph":
-                item.replay()
-            elif kind == "gather":
-                log_collective("all_gather", item[1])
-                dist.all_gather(item[0], item[1])
-            else:
-                self.reducer.reduce_async(item)          # side stream; the next segment replays beside it
-                if item is sg["last_reduce"]:
-                    self.reducer.finish()                # ... except the optimiser segment, which needs every gradient
+        self._replay_segments(sg["segs"], sg["last_reduce"])
         self.opt._scheduled = False
         self.last_kd = sg["kd"]
         return sg["out"]
@@ -936,16 +998,33 @@ class TeacherPrefetch:
     tensors then stay valid until that same graph is replayed two submits later - exactly as long as they are needed -
     so nothing is copied."""
 
+    MAX_GRAPH_KINDS = 6         # batch shapes whose teacher forward is captured (first come: each holds two private pools)
+    MAX_EAGER_KINDS = 4         # ... further shapes run the same kernels eagerly; least recently used static buffers evicted
+
     def __init__(self, run_teacher, use_graph=True):
         self.run_teacher = run_teacher          # fn(batch dict) -> teacher outputs (any nest of tensors)
         self.use_graph = use_graph
         self.side = torch.cuda.Stream()
         self.states, self.pending, self.last_key = {}, None, None
+        self._tick = 0
+
+    def close(self):
+        """drop the graphs / static buffers (caller: trainer.close(), device idle)"""
+        self.states.clear()
+        self.pending = None
 
     def _create(self, batch):
         cur = torch.cuda.current_stream()
         st = dict(B=[{k: v.clone() for k, v in batch.items()} for _ in range(2)], T=[None, None], graphs=None, par=0)
-        if self.use_graph:
+        graphed = sum(1 for q in self.states.values() if q["graphs"] is not None)
+        if self.use_graph and graphed >= self.MAX_GRAPH_KINDS:
+            # bounded state: real VQA batches differ in their number of answer rows from batch to batch
+            eager = sorted((q.get("tick", 0), sig) for sig, q in self.states.items()
+                           if q["graphs"] is None and (self.pending is None or q is not self.pending[0]))
+            if len(eager) >= self.MAX_EAGER_KINDS:
+                torch.cuda.synchronize()
+                del self.states[eager[0][1]]
+        elif self.use_graph:
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
                 self.run_teacher(st["B"][0])                   # warm-up: allocator, cached weight casts
@@ -967,6 +1046,8 @@ class TeacherPrefetch:
         st = self.states.get(sig)
         if st is None:
             st = self.states[sig] = self._create(batch)
+        self._tick += 1
+        st["tick"] = self._tick
         cur, side = torch.cuda.current_stream(), self.side
         cur.wait_stream(side)                     # the waiting batch's teacher outputs are complete
         p = st["par"] = 1 - st["par"]
@@ -988,37 +1069,117 @@ class TeacherPrefetch:
 
 
 class _CapturedStep:
-    """The pruning fine-tune step as ONE hipGraph per static (batch, teacher outputs) pair of the teacher prefetch
-    (`capture_step=True`; single GPU, prefetched teacher with graphs).  What made the step host-dependent enters through
-    device memory that is refilled before every replay: the Lagrangian warm-up counter (`_pruned_dev`; the reference ramps the
-    target sparsity with a Python step count, Eff_Retrieval.py:113), the gate noise (`l0.static_eps`: drawn on the HOST
-    generator in the order and shapes one eager forward draws them - the same stream of numbers as the eager trainer, and as
-    the reference's CPU draws) and the three optimisers' schedules (FlatAdamW / TensorAdamW `.set_schedule`).  The first step
-    on a pair runs eagerly (it records the gate-noise plan and warms allocator and weight caches), the second is captured,
-    later ones replay."""
+    """The pruning fine-tune step replayed from hipGraphs, one (chain) per static (batch, teacher outputs) pair of the teacher
+    prefetch (`capture_step=True`, the default; needs the prefetched teacher with graphs).  What made the step host-dependent
+    enters through device memory that is refilled before every replay: the Lagrangian warm-up counter (`_pruned_dev`; the
+    reference ramps the target sparsity with a Python step count, Eff_Retrieval.py:113), the gate noise (`l0.static_eps`:
+    drawn on the HOST generator in the order and shapes one eager forward draws them - the same stream of numbers as the
+    eager trainer, and as the reference's CPU draws) and the three optimisers' schedules (FlatAdamW / TensorAdamW
+    `.set_schedule`).  The first step on a pair runs eagerly (it records the gate-noise plan of its KIND - for the VQA
+    trainer `stop_prune` is part of the kind: a stop_prune step evaluates the deterministic gates and draws nothing - and
+    warms allocator and weight caches), the second is captured, later ones replay.
+
+    One GPU: ONE graph per pair.  N > 1 (a live reducer): a chain of graph SEGMENTS cut at the step's collectives, exactly
+    as GDTrainer._capture_segments does - the ITC feature (and image-id) gathers of the retrieval forward through
+    xvlm.GATHER_HOOK, the gradient stages through _StagedExchange._cut from the hooks inside backward, [three optimisers +
+    constrain_parameters] behind the last all-reduce - with the collectives issued eagerly between the replays
+    (torch DDP's bucketed all-reduce under backward: Eff_Retrieval.py:449, Eff_VQA.py:327).  The eager step and the chain
+    issue the SAME collective sequence (tests/test_step_gpu.py), so a rank whose capture fails simply keeps stepping
+    eagerly: no agreement round is held here - VQA batch kinds (answer rows) differ from rank to rank, so ranks reach
+    their captures at different steps and a collective at that moment would pair with a peer's gradient all-reduce."""
     capture_step = False
+    MAX_STEP_GRAPHS = 8         # static pairs whose step is captured (first come); pairs beyond that step eagerly
 
     def _cap_init(self):
         dev = next(self.student.parameters()).device
-        self._sgraphs, self._seen, self._eps_plan, self._eps_static = {}, set(), None, None
+        self._sgraphs, self._seen, self._eps = {}, set(), {}
         self._pruned_dev = torch.zeros((), dtype=torch.float32, device=dev)
-        self._cap_stream = None
+        self._cap_stream, self._step_pool = None, None
+        self._capture_failed = None
         self.last_launch = "eager"
 
-    def _stage_eps(self):
+    def _stage_eps(self, kind):
+        """this step's gate noise -> the static device buffers of its kind; an injected draw (tests) is consumed by ONE step,
+        as XVLML0Module.forward(training=True) consumes it; a kind without draws (stop_prune) touches no generator"""
+        plan, static = self._eps[kind]
+        if not plan:
+            return
         l0 = self.student.l0_module
-        for typ, shape in self._eps_plan:
-            inj = l0.injected_eps
+        inj = l0.injected_eps
+        for typ, shape in plan:
             src = inj[typ] if (inj is not None and typ in inj) else l0.get_eps(shape)
             src = src.to(torch.float32)
             if not src.is_cuda:
                 src = src.contiguous().pin_memory()
-            self._eps_static[typ].copy_(src, non_blocking=True)
+            static[typ].copy_(src, non_blocking=True)
+        l0.injected_eps = None
+
+    def _set_scheduled(self, flag):
+        self.opt._scheduled = self.l0_opt._scheduled = self.lagrangian_opt._scheduled = flag
+
+    def _capture_one(self, body, cs):
+        """single GPU: the whole step as one graph"""
+        g = torch.cuda.CUDAGraph()
+        with no_gc_during_capture(), torch.cuda.graph(g, pool=self._step_pool, stream=cs, capture_error_mode="thread_local"):
+            out = body(self._pruned_dev, True)
+        self._step_pool = g.pool()
+        return dict(segs=[("graph", g)], out=out, last_reduce=None)
+
+    def _capture_chain(self, body, cs):
+        """N > 1: the step as graph segments around its collectives (no collective is issued during the capture pass)"""
+        from .efficient_models import xvlm as X
+        if self._step_pool is None:
+            self._step_pool = torch.cuda.graph_pool_handle()
+        cur = torch.cuda.current_stream()
+        segs, state = [], {"g": None}
+
+        def begin():
+            state["g"] = torch.cuda.CUDAGraph()
+            # (thread_local: the process group's watchdog thread queries events while this thread captures)
+            state["g"].capture_begin(pool=self._step_pool, capture_error_mode="thread_local")
+
+        def end():
+            state["g"].capture_end()
+            segs.append(("graph", state["g"]))
+            state["g"] = None
+
+        def gather(out_list, src):
+            end()
+            segs.append(("gather", (out_list, src)))
+            begin()
+
+        def cut(ranges):
+            end()
+            segs.append(("reduce", ranges))
+            begin()
+
+        cs.wait_stream(cur)
+        self._cut = cut
+        try:
+            # (autograd single-threaded: the gradient-stage hooks end / begin captures on the thread that started them)
+            with no_gc_during_capture(), torch.cuda.stream(cs), torch.autograd.set_multithreading_enabled(False):
+                X.GATHER_HOOK = gather
+                try:
+                    begin()
+                    out = body(self._pruned_dev, True)       # (its _reduce_rest() cuts once per remaining stage)
+                    end()
+                finally:
+                    X.GATHER_HOOK = None
+                    if state["g"] is not None:               # an exception inside a capture: close it before re-raising
+                        try:
+                            state["g"].capture_end()
+                        except RuntimeError:
+                            pass
+        finally:
+            self._cut = None
+        cur.wait_stream(cs)
+        torch.cuda.synchronize()
+        return dict(segs=segs, out=out, last_reduce=[item for kind, item in segs if kind == "reduce"][-1])
 
     def _run_step(self, key, body, lr_mult):
         """body(pruned_steps, staged) -> device loss stack"""
         l0 = self.student.l0_module
-        if not self.capture_step or key is None or self.reducer.active:
+        if not self.capture_step or key is None:
             self.last_launch = "eager"
             return body(self.global_step, False)
         # Every step of a capturing trainer - the eager ones too - runs on ONE dedicated stream: autograd remembers the stream
@@ -1028,7 +1189,13 @@ class _CapturedStep:
         if self._cap_stream is None:
             self._cap_stream = torch.cuda.Stream()
         cs = self._cap_stream
-        if key not in self._seen:                     # first step on this pair: eager, recording the gate-noise plan
+        kind = tuple(key[2:])
+        ent = self._sgraphs.get(key)
+        first = key not in self._seen
+        if first or (ent is None and (len(self._sgraphs) >= self.MAX_STEP_GRAPHS or self._capture_failed)):
+            # first step on this pair: eager, recording the gate-noise plan of its kind; also every step of a pair beyond the
+            # bound on captured pairs (real VQA batches vary in their answer rows: each shape would hold a step's
+            # activations in its graph's pool for good) and of a trainer whose capture this stack refused
             self._seen.add(key)
             l0.eps_trace = []
             cs.wait_stream(cur)
@@ -1038,52 +1205,75 @@ class _CapturedStep:
             finally:
                 plan, l0.eps_trace = l0.eps_trace, None
             cur.wait_stream(cs)
-            if self._eps_plan is None:
+            if kind not in self._eps:
                 dev = self._pruned_dev.device
-                self._eps_plan = plan
-                self._eps_static = {t: torch.empty(shape, dtype=torch.float32, device=dev) for t, shape in plan}
-            elif plan != self._eps_plan:
+                self._eps[kind] = (plan, {t: torch.empty(shape, dtype=torch.float32, device=dev) for t, shape in plan})
+            elif plan != self._eps[kind][0]:
                 raise RuntimeError("captured pruning step: the gate-noise draws of this batch kind differ from the recorded plan")
             self.last_launch = "eager"
             return out
         self._pruned_dev.fill_(float(self.global_step))
-        self._stage_eps()
+        self._stage_eps(kind)
         self.opt.set_schedule(lr_mult)
         self.l0_opt.set_schedule()
         self.lagrangian_opt.set_schedule()
-        ent = self._sgraphs.get(key)
+        static = self._eps[kind][1]
         if ent is None:
             ops.CACHE.invalidate()                    # capture the casts of the trainable weights too
             ops.reserve_tables()
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            l0.static_eps = self._eps_static
+            l0.static_eps = static
+            err = None
             try:
-                with no_gc_during_capture(), torch.cuda.graph(g, stream=cs, capture_error_mode="thread_local"):
-                    out = body(self._pruned_dev, True)
+                ent = self._capture_chain(body, cs) if self.reducer.active else self._capture_one(body, cs)
+            except RuntimeError as e:                 # a capture this stack refuses
+                if not self.reducer.active:
+                    raise
+                err = e
+                try:
+                    torch.cuda.synchronize()
+                except RuntimeError:
+                    pass
             finally:
                 l0.static_eps = None
-            ops.flush_table_uploads()
-            ent = self._sgraphs[key] = (g, out)
             # (the capture pass consumed the optimisers' "staged" flags, not the staged values: the replay reads them)
+            if err is not None:
+                import sys
+                print(f"[efficientvlm_amd] hipGraph segments of the multi-GPU pruning step failed ({err}); this rank keeps "
+                      "stepping eagerly (same collective sequence)", file=sys.stderr)
+                self._capture_failed = str(err)
+                # this step: the captured body executed eagerly (schedules and noise are staged already)
+                self._set_scheduled(True)
+                l0.static_eps = static
+                cs.wait_stream(cur)
+                try:
+                    with torch.cuda.stream(cs):
+                        out = body(self._pruned_dev, True)
+                finally:
+                    l0.static_eps = None
+                cur.wait_stream(cs)
+                self.last_launch = "eager"
+                return out
+            ops.flush_table_uploads()
+            self._sgraphs[key] = ent
         # EVLM_REPLAY_PRIORITY=1: the graph replays on a HIGH-priority stream (its kernels are the step's critical path, the
         # teacher's graph of the next batch runs on the prefetch's side stream): 44.7 -> 44.3 ms on the ITR step, two A/B
         # pairs.  Opt-in: queue priority on this stack is close to strict - the GD step as two graphs with the student on
         # a high-priority stream SERIALISED the teacher behind it (22.1 ms against 16.0 without priority and 14.8 for the
-        # joint graph); a priority on the joint graph's capture stream changes nothing (DESIGN.md section 5).
-        if not os.environ.get("EVLM_REPLAY_PRIORITY"):
-            ent[0].replay()
+        # joint graph); a priority on the joint graph's capture stream changes nothing (DESIGN.md).
+        if not os.environ.get("EVLM_REPLAY_PRIORITY") or self.reducer.active:
+            self._replay_segments(ent["segs"], ent["last_reduce"])
         else:
             if getattr(self, "_hp_stream", None) is None:
                 self._hp_stream = torch.cuda.Stream(priority=-1)
             hp = self._hp_stream
             hp.wait_stream(cur)
             with torch.cuda.stream(hp):
-                ent[0].replay()
+                self._replay_segments(ent["segs"], ent["last_reduce"])
             cur.wait_stream(hp)
-        self.opt._scheduled = self.l0_opt._scheduled = self.lagrangian_opt._scheduled = False
-        self.last_launch = "hipGraph replay"
-        return ent[1]
+        self._set_scheduled(False)
+        self.last_launch = "hipGraph segments" if self.reducer.active else "hipGraph replay"
+        return ent["out"]
 
 
 class ITRTrainer(_StagedExchange, _CapturedStep):
@@ -1091,15 +1281,16 @@ class ITRTrainer(_StagedExchange, _CapturedStep):
     gates forward + backward, teacher forward, ITC + ITM + hidden / attention / cross-attention / logit KD, the Lagrangian
     sparsity term, THREE optimisers (main AdamW over every student parameter - the gate parameters included, as in the
     reference -, +reg_lr on the gate log-alphas, -reg_lr = ascent on lambda_1 / lambda_2; optim.py:4-69), no gradient
-    clipping (the reference calls optimizer.step() directly here), then constrain_parameters().  Eager launch: the
-    Lagrangian warm-up makes the step depend on a host-side counter."""
+    clipping (the reference calls optimizer.step() directly here), then constrain_parameters().  With the teacher prefetched the step
+    replays from hipGraphs (_CapturedStep: one graph on one GPU, segments around the collectives with N > 1)."""
 
     def __init__(self, student, teacher, lr=3e-5, weight_decay=0.01, lr_mult=2.0, reg_learning_rate=0.1,
-                 dtype=torch.float32, temperature=1.0, pipeline_teacher=False, use_graph=True, capture_step=False):
+                 dtype=torch.float32, temperature=1.0, pipeline_teacher=False, use_graph=True, capture_step=True):
         """pipeline_teacher: as in GDTrainer - the frozen teacher runs one batch ahead (TeacherPrefetch: hipGraph on a side
         stream) and step() returns the losses of the batch of the PREVIOUS call (None on the first).
-        capture_step: with pipeline_teacher and use_graph on one GPU, the student step replays as a hipGraph too
-        (_CapturedStep)."""
+        capture_step (default on; effective with pipeline_teacher and use_graph): the student step replays from hipGraphs
+        too - one graph on one GPU, a chain of segments around the collectives with N > 1 (_CapturedStep);
+        EVLM_NO_STEP_GRAPH=1 turns it off."""
         from .optim import create_L0_optimizer
         self.student, self.teacher = student, teacher
         self.dtype, self.temperature = dtype, temperature
@@ -1108,7 +1299,8 @@ class ITRTrainer(_StagedExchange, _CapturedStep):
         teacher.eval()
         student.train()
         self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=0.0)
-        self.reducer = GradReducer(self.opt.flat_grads, prescaled=True)
+        # (EVLM_FORCE_REDUCE=1: the N > 1 code path - collectives, gradient stages, graph segments - on a one-rank group)
+        self.reducer = GradReducer(self.opt.flat_grads, prescaled=True, force=bool(os.environ.get("EVLM_FORCE_REDUCE")))
         self._stages, self._sent = [list(self.opt.flat_grads)], 0
         if self.reducer.active:
             broadcast_parameters(self.opt)      # gates and multipliers included: they are members of the main groups
@@ -1122,7 +1314,8 @@ class ITRTrainer(_StagedExchange, _CapturedStep):
             teacher_map_filter(student, teacher, with_cross=True)
         self.global_step = 0
         self.prefetch = TeacherPrefetch(self._teacher_forward, use_graph) if pipeline_teacher else None
-        self.capture_step = bool(capture_step and pipeline_teacher and use_graph and next(student.parameters()).is_cuda)
+        self.capture_step = bool(capture_step and pipeline_teacher and use_graph and next(student.parameters()).is_cuda
+                                 and not os.environ.get("EVLM_NO_STEP_GRAPH"))
         self._cap_init()
         enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
         if enc is not None and hasattr(enc, "kd_drop_maps") and not os.environ.get("EVLM_STUDENT_ALL_MAPS"):
@@ -1204,12 +1397,12 @@ class VQATrainer(_StagedExchange, _CapturedStep):
     """Pruning fine-tune step of Eff_VQA.py:74-200 (visual question answering with hard-concrete L0 gates on the image
     encoder, question encoder AND answer decoder): student forward + backward, teacher forward, the weighted answer LM loss,
     text / fusion / image / decoder hidden + attention KD, logit KD, the Lagrangian, THREE optimisers as in ITRTrainer, no
-    gradient clipping, constrain_parameters().  Eager launch by default; capture_step=True replays the student step as a
-    hipGraph per (batch shape, teacher-prefetch parity, stop_prune) - _CapturedStep; a new number of answer rows is a new
-    batch kind and starts with an eager step."""
+    gradient clipping, constrain_parameters().  With the teacher prefetched the student step replays from hipGraphs per
+    (batch shape, teacher-prefetch parity, stop_prune) - _CapturedStep; a new number of answer rows is a new batch kind and
+    starts with an eager step (bounded: MAX_STEP_GRAPHS pairs are captured, later kinds step eagerly)."""
 
     def __init__(self, student, teacher, lr=5e-5, weight_decay=0.01, lr_mult=2.0, reg_learning_rate=0.1,
-                 dtype=torch.float32, temperature=1.0, pipeline_teacher=False, use_graph=True, capture_step=False):
+                 dtype=torch.float32, temperature=1.0, pipeline_teacher=False, use_graph=True, capture_step=True):
         from .optim import create_L0_optimizer
         self.student, self.teacher = student, teacher
         self.dtype, self.temperature = dtype, temperature
@@ -1218,7 +1411,8 @@ class VQATrainer(_StagedExchange, _CapturedStep):
         teacher.eval()
         student.train()
         self.opt = FlatAdamW(student, lr=lr, weight_decay=weight_decay, lr_mult=lr_mult, max_grad_norm=0.0)
-        self.reducer = GradReducer(self.opt.flat_grads, prescaled=True)
+        # (EVLM_FORCE_REDUCE=1: the N > 1 code path - collectives, gradient stages, graph segments - on a one-rank group)
+        self.reducer = GradReducer(self.opt.flat_grads, prescaled=True, force=bool(os.environ.get("EVLM_FORCE_REDUCE")))
         self._stages, self._sent = [list(self.opt.flat_grads)], 0
         if self.reducer.active:
             broadcast_parameters(self.opt)      # gates and multipliers included: they are members of the main groups
@@ -1232,7 +1426,8 @@ class VQATrainer(_StagedExchange, _CapturedStep):
             teacher_map_filter(student, teacher, with_cross=True)
         self.global_step = 0
         self.prefetch = TeacherPrefetch(self._teacher_forward, use_graph) if pipeline_teacher else None
-        self.capture_step = bool(capture_step and pipeline_teacher and use_graph and next(student.parameters()).is_cuda)
+        self.capture_step = bool(capture_step and pipeline_teacher and use_graph and next(student.parameters()).is_cuda
+                                 and not os.environ.get("EVLM_NO_STEP_GRAPH"))
         self._cap_init()
         enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
         if enc is not None and hasattr(enc, "kd_drop_maps") and not os.environ.get("EVLM_STUDENT_ALL_MAPS"):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[2] on one GPU: the ITR pruning fine-tune step (Eff_Retrieval.py:train body = trainer.ITRTrainer:
 X-VLM-small student with L0 gates fwd+bwd, X-VLM-base teacher fwd, ITC + ITM + KD incl. cross-attention maps, Lagrangian,
-three optimisers), B = 64, 384x384 images (577 tokens), 30 text tokens, bf16, synthetic data, random init, eager launch."""
+three optimisers), B = 64, 384x384 images (577 tokens), 30 text tokens, bf16, synthetic data, random init, hipGraph replay of the student step (EVLM_NO_STEP_GRAPH=1: eager; EVLM_FORCE_REDUCE=1: the N > 1 path as graph segments on a one-rank RCCL group)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,6 +15,11 @@ res = int(sys.argv[1]) if len(sys.argv) > 1 else 384
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 geom = dict(synth.GEOMS["full"]); geom["image_res"] = res
 dev = torch.device("cuda")
+if os.environ.get("EVLM_FORCE_REDUCE"):       # the N > 1 code path (collectives, gradient stages, graph segments) on a one-rank RCCL group
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29561")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
 torch.manual_seed(0)
 student = EffXVLMforRetrieval(model_config(geom, "s", image_res=res)).to(dev)
 teacher = TeacherITR(model_config(geom, "t", image_res=res)).to(dev)

@@ -2,7 +2,7 @@
 """BASELINE.json configs[3] on one GPU: the VQA pruning fine-tune step (Eff_VQA.py:74-200 = trainer.VQATrainer: X-VLM-small
 student with VQAL0Module gates fwd+bwd, X-VLM-base teacher fwd, weighted answer LM loss + hidden / attention / logit KD,
 Lagrangian, three optimisers), per-GPU batch 32 (256 over 8 GPUs), 480x480 images (901 tokens), 30-token questions, about
-4 candidate answers of <= 8 tokens per question, bf16, synthetic data, random init, eager launch.
+4 candidate answers of <= 8 tokens per question, bf16, synthetic data, random init, hipGraph replay of the student step (EVLM_NO_STEP_GRAPH=1: eager; EVLM_FORCE_REDUCE=1: the N > 1 path as graph segments on a one-rank RCCL group).
 usage: vqa_bench.py [image_res] [batch]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,6 +17,11 @@ res = int(sys.argv[1]) if len(sys.argv) > 1 else 480
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 geom = dict(synth.GEOMS["full"]); geom["image_res"] = res
 dev = torch.device("cuda")
+if os.environ.get("EVLM_FORCE_REDUCE"):       # the N > 1 code path (collectives, gradient stages, graph segments) on a one-rank RCCL group
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29561")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
 torch.manual_seed(0)
 cfg = lambda role, nd: dict(model_config(geom, role, image_res=res), pad_token_id=0, num_dec_layers=nd)
 student = EffXVLMForVQA(cfg("s", 3)).to(dev)
