@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVLM_LIB", os.path.join(_HERE, "libevlm_hip.so"))
 
-ABI_VERSION = 6      # evlm_abi_version() of the library this binding was written against (struct layouts, entry points)
+ABI_VERSION = 7      # evlm_abi_version() of the library this binding was written against (struct layouts, entry points)
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2
 GATE_PRE, GATE_POST = 0, 1
@@ -74,6 +74,9 @@ SIGNATURES = {
     "evlm_layernorm_bwd_blocks": [_i],
     "evlm_layernorm_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "evlm_layernorm_bwd_add": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "evlm_layernorm_fwd_kd_slots": [],
+    "evlm_layernorm_fwd_kd": [_i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp],
+    "evlm_layernorm_bwd_kd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp],
     "evlm_attention_fwd": [C.POINTER(AttnFwdArgs), _vp],
     "evlm_attention_bwd": [C.POINTER(AttnBwdArgs), _vp],
     "evlm_attention_lse_supported": [_i, _i, _i, _f],

@@ -426,6 +426,235 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_kernel(MAttnF a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// PERSISTENT form of the grouped cross-attention forward (round 5).  The kernel above is one workgroup per (K/V row, head):
+// it stages 56 KiB, waits for them, then computes - two workgroups per CU, 768 of them on 512 slots, and while a workgroup
+// computes nothing of its CU-share of the 62 MB is in flight (21 us = 2.9 TB/s on the GD shape).  Here ONE 8-wave workgroup
+// per CU walks its items i, i + grid, i + 2 grid ... with K / V DOUBLE-BUFFERED: right behind the barrier that opens item
+// i the LDS-DMA of item i + 1 goes out into the other buffer and stays in flight under item i's whole arithmetic, and the
+// Q fragments of a wave's first task of item i + 1 are requested just ahead of that DMA (vmcnt counts in order: a load
+// issued BEHIND the DMA could only be waited for together with it).  kv_index is copied into LDS once; a wave finds the
+// batches of its tasks t = wave, wave + NW, ... with ballots over that copy.
+// The transposing V reads are inline asm: hipcc models an LDS-DMA as a pending LDS write and puts `s_waitcnt vmcnt(0)` in
+// front of every __builtin_amdgcn_ds_read_tr16_b64 while one is outstanding (gemm_pp256_core.h: pp_frag) - which here
+// would drain the NEXT item's staging before the P V product of the current one.  RAW: buffer i & 1 is read only behind
+// `s_waitcnt vmcnt(0)` + barrier of iteration i; WAR: its next DMA (item i + 2) is issued behind the barrier of iteration
+// i + 1, which every wave reaches only after its last read of item i.  Same arithmetic in the same order as the kernels
+// above: bit-identical outputs (tests/test_ops_gpu.py).
+__device__ __forceinline__ bf16x8 vcol_frag_asm(const char* sm, int t0, int t1, int dt, int lane) {
+  const int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3;
+  const uint32_t sb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)sm;
+  bf16x8 out;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = (h ? t1 : t0) * 16 + g * 4 + q;
+    const uint32_t off = sb + row * 128 + v_swz(row, dt * 2 + (p >> 1)) * 16 + ((p & 1) << 3);
+    bf16x4 t;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(t) : "v"(off));
+    out[4 * h + 0] = t[0]; out[4 * h + 1] = t[1]; out[4 * h + 2] = t[2]; out[4 * h + 3] = t[3];
+  }
+  return out;
+}
+
+// the n-th query batch (0-based, index order) that attends to K/V row `bkv`, or -1 (wave-uniform: n, result)
+__device__ __forceinline__ int nth_hit(const int* kvs, int B, int bkv, int n, int lane) {
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    unsigned long long hits = __ballot(b0 + lane < B && kvs[min(b0 + lane, B - 1)] == bkv);
+    const int c = __popcll(hits);
+    if (n < c) {
+      for (int i = 0; i < n; ++i) hits &= hits - 1;
+      return b0 + __builtin_amdgcn_readfirstlane(__ffsll((long long)hits) - 1);
+    }
+    n -= c;
+  }
+  return -1;
+}
+
+template <int NT, int NW, bool LSE>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_persist_kernel(MAttnF a, int nitems) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE = NT * 16 * 128;                    // one [NT*16][64] bf16 tile; a buffer = K tile | V tile
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, ql = lane & 15;
+  float* Ms = reinterpret_cast<float*>(smem + 4 * TILE) + wave * NT * 16;         // this wave's mask strip
+  int* kvs = reinterpret_cast<int*>(smem + 4 * TILE + NW * NT * 16 * sizeof(float));
+  int it = blockIdx.x;
+  if (it >= nitems) return;
+  for (int i = threadIdx.x; i < a.B; i += blockDim.x) kvs[i] = a.kv_index[i];
+  if (!a.mask)
+    for (int k = lane; k < NT * 16; k += 64) Ms[k] = (k < a.Lk) ? 0.f : -1e30f;
+  const bool skip = !LSE && a.skip_dead && a.gate && !a.P;       // closed heads deliver a zero context and stage nothing
+  const int qtiles = (a.Lq + 15) >> 4;
+  const float sc = a.scale * 1.44269504088896341f;
+  __syncthreads();
+  // first task of the first item: batch, Q fragments; then the item's K / V
+  bf16x8 qn[2];
+  int bn;
+  {
+    const int bkv = it / a.H, h = it - bkv * a.H;
+    bn = nth_hit(kvs, a.B, bkv, wave / qtiles, lane);
+    const int q = (wave % qtiles) * 16 + ql;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (bn >= 0 && q < a.Lq) v = *reinterpret_cast<const uint4*>(a.Q + ((size_t)bn * a.Lq + q) * a.ldq + h * DH + ks * 32 + g * 8);
+      qn[ks] = *reinterpret_cast<bf16x8*>(&v);
+    }
+    if (!(skip && a.gate[h] == 0.f)) {
+      stage_rows<SW_K>(a.K + (size_t)bkv * a.Lk * a.ldk + h * DH, a.ldk, a.Lk, NT * 16, smem);
+      stage_rows<SW_V>(a.V + (size_t)bkv * a.Lk * a.ldv + h * DH, a.ldv, a.Lk, NT * 16, smem + TILE);
+    }
+  }
+  int mb = -1;                                           // batch whose mask row sits in this wave's strip
+  for (int i = 0; it < nitems; ++i, it += gridDim.x) {
+    const int bkv = it / a.H, h = it - bkv * a.H;
+    stage_wait();
+    // (the prefetched Q fragments are "consumed" HERE for the compiler's wait-count pass: it cannot see the wait above, and
+    // would otherwise place its own vmcnt(0) at their first use - behind the next item's DMA, draining it)
+    asm volatile("" : "+v"(qn[0]), "+v"(qn[1]));
+    __syncthreads();                                     // item i has landed; everyone is done with the other buffer
+    bf16x8 qc[2] = {qn[0], qn[1]};
+    const int bc = bn;
+    const int itn = it + gridDim.x;
+    if (itn < nitems) {
+      const int bkvn = itn / a.H, hn = itn - bkvn * a.H;
+      bn = nth_hit(kvs, a.B, bkvn, wave / qtiles, lane);
+      const int q = (wave % qtiles) * 16 + ql;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (bn >= 0 && q < a.Lq) v = *reinterpret_cast<const uint4*>(a.Q + ((size_t)bn * a.Lq + q) * a.ldq + hn * DH + ks * 32 + g * 8);
+        qn[ks] = *reinterpret_cast<bf16x8*>(&v);
+      }
+      if (!(skip && a.gate[hn] == 0.f)) {
+        char* nb = smem + ((i + 1) & 1) * 2 * TILE;
+        stage_rows<SW_K>(a.K + (size_t)bkvn * a.Lk * a.ldk + hn * DH, a.ldk, a.Lk, NT * 16, nb);
+        stage_rows<SW_V>(a.V + (size_t)bkvn * a.Lk * a.ldv + hn * DH, a.ldv, a.Lk, NT * 16, nb + TILE);
+      }
+    }
+    const char* Ks = smem + (i & 1) * 2 * TILE;
+    const char* Vs = Ks + TILE;
+    const bool dead = skip && a.gate[h] == 0.f;
+    for (int t = wave;; t += NW) {
+      int b;
+      bf16x8 qf[2];
+      const int qt = t % qtiles, q = qt * 16 + ql;
+      const bool qok = q < a.Lq;
+      if (t == wave) {
+        b = bc; qf[0] = qc[0]; qf[1] = qc[1];
+      } else {
+        b = nth_hit(kvs, a.B, bkv, t / qtiles, lane);
+        if (b >= 0 && !dead) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (qok) v = *reinterpret_cast<const uint4*>(a.Q + ((size_t)b * a.Lq + q) * a.ldq + h * DH + ks * 32 + g * 8);
+            qf[ks] = *reinterpret_cast<bf16x8*>(&v);
+          }
+          // (a wave's second and later tasks of an item: this load sits behind the next item's DMA and waits for it - the
+          // wait belongs in THIS branch, not at the join with the prefetched first task)
+          asm volatile("" : "+v"(qf[0]), "+v"(qf[1]));
+        }
+      }
+      if (b < 0) break;                                  // (wave-uniform)
+      if (dead) {
+        if (qok) {
+          bf16* Or = a.O + ((size_t)b * a.Lq + q) * a.ldo + h * DH + g * 16;
+          *reinterpret_cast<uint4*>(Or) = make_uint4(0, 0, 0, 0);
+          *reinterpret_cast<uint4*>(Or + 8) = make_uint4(0, 0, 0, 0);
+        }
+        continue;
+      }
+      if (a.mask && mb != b) {                           // (in-order LDS: the strip is complete before this wave reads it)
+        for (int k = lane; k < NT * 16; k += 64) Ms[k] = (k < a.Lk) ? a.mask[(size_t)b * a.Lk + k] : -1e30f;
+        mb = b;
+      }
+      f32x4 acc[NT];
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Ks, tt, ks, lane), qf[ks], acc[tt], 0, 0, 0);
+      }
+      float m = -3.0e38f;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + tile_key0(tt, g));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[tt][r] = fmaf(acc[tt][r], sc, mk[r] * LOG2E);
+          m = fmaxf(m, acc[tt][r]);
+        }
+      }
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[tt][r] = EXP2(acc[tt][r] - m);
+          sum += acc[tt][r];
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.0f / sum;
+      if (LSE && qok && g == 0) a.lse[((size_t)b * a.H + h) * a.Lq + q] = m + __log2f(sum);
+      bf16x4 pk[NT];
+      bf16* Pr = a.P ? a.P + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr : nullptr;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pk[tt][r] = (bf16)(acc[tt][r] * inv);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < NT / 2; ++s2) {
+        const int kcol = s2 * 32 + g * 8;
+        if (Pr && qok && kcol < a.ldpr) {
+          bf16x8 pp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pp[r] = pk[2 * s2][r]; pp[4 + r] = pk[2 * s2 + 1][r]; }
+          *reinterpret_cast<bf16x8*>(Pr + kcol) = pp;
+        }
+      }
+      f32x4 o[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // V fragments of tile pair s2 + 1 are requested before the MFMAs of pair s2 (asm reads: the explicit lgkmcnt)
+      bf16x8 vf[2][4];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vf[0][dt] = vcol_frag_asm(Vs, 0, 1, dt, lane);
+#pragma unroll
+      for (int s2 = 0; s2 < NT / 2; ++s2) {
+        bf16x8 pb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pb[r] = pk[2 * s2][r]; pb[4 + r] = pk[2 * s2 + 1][r]; }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (s2 + 1 < NT / 2) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) vf[(s2 + 1) & 1][dt] = vcol_frag_asm(Vs, 2 * s2 + 2, 2 * s2 + 3, dt, lane);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[s2 & 1][dt], pb, o[dt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (qok) {
+        const float gz = a.gate ? a.gate[h] : 1.0f;
+        bf16* Or = a.O + ((size_t)b * a.Lq + q) * a.ldo + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          bf16x4 ov = {(bf16)(o[dt][0] * gz), (bf16)(o[dt][1] * gz), (bf16)(o[dt][2] * gz), (bf16)(o[dt][3] * gz)};
+          *reinterpret_cast<bf16x4*>(Or + dt * 16 + g * 4) = ov;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Long key sequences (225..928 keys: the ViT at 384 x 384 / 480 x 480, cross-attention onto those image tokens) when
 // nobody takes the map: a STREAMING forward.  The whole-row kernel above keeps all 38 / 58 score tiles of a query tile in
 // registers (256 VGPRs + 197 AGPRs: one wave per SIMD) and K and V of a (batch, head) whole in LDS (152 KiB: one 4-wave
@@ -874,6 +1103,24 @@ static bool launch_fwd_grouped(const MAttnF& f, int Bkv, hipStream_t stream) {
   const char* env = getenv("EVLM_ATTN_NO_GROUP");         // (A/B switch, read per call: the tests toggle it)
   if ((env && atoi(env)) || !f.kv_index || Bkv <= 0 || Bkv >= f.B || f.Lq > 64 || f.causal || f.Pt) return false;
   constexpr int NW = 8;
+  // persistent, double-buffered form (round 5): one workgroup per CU walks the (K/V row, head) items - EVLM_ATTN_GROUP_PERSIST=1.
+  // Measured 23.7 us against 21.2 us for one workgroup per item on the GD shape (profiles/r05_xattn_persist.md): opt-in.
+  // The index copy bounds B (a query batch count of 4 096 is 16 KiB of LDS)
+  const char* pe = getenv("EVLM_ATTN_GROUP_PERSIST");     // (A/B switch, read per call; measured SLOWER: opt-in)
+  if (pe && atoi(pe) == 1 && f.B <= 4096) {
+    const int nitems = Bkv * f.H;
+    const size_t ldsp = (size_t)4 * NT * 16 * 128 + (size_t)NW * NT * 16 * sizeof(float) + (size_t)f.B * sizeof(int);
+    static const int ncu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); (void)hipGetDeviceProperties(&p, d); return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }();
+    dim3 gridp(imin(nitems, ncu)), blockp(64 * NW);
+    if (f.lse) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_grouped_persist_kernel<NT, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+      hipLaunchKernelGGL((attn_fwd_grouped_persist_kernel<NT, NW, true>), gridp, blockp, ldsp, stream, f, nitems);
+    } else {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_grouped_persist_kernel<NT, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+      hipLaunchKernelGGL((attn_fwd_grouped_persist_kernel<NT, NW, false>), gridp, blockp, ldsp, stream, f, nitems);
+    }
+    return true;
+  }
   const size_t lds = (size_t)2 * NT * 16 * 128 + (size_t)NW * NT * 16 * sizeof(float);
   dim3 grid(1, f.H, Bkv), block(64 * NW);
   if (f.lse) {
@@ -1370,9 +1617,14 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
   }
 }
 
-static bool launch_bwd_dq_stream(MAttnB& f, hipStream_t stream) {
+// does the one-pass streaming dQ kernel take this call?  (ops._Attention.backward mirrors the predicate: it allocates no
+// [B, H, Lq, Lk] probability workspace when it holds)
+static bool bwd_dq_stream_applies(const MAttnB& f) {
   const char* env = getenv("EVLM_ATTN_NO_STREAM");         // (A/B switch, read per call)
-  if ((env && atoi(env)) || f.Lk <= 224 || f.Lk > 1024 || f.causal || !f.lse || !f.O || f.E || (f.Pt && !f.rkd)) return false;
+  return !((env && atoi(env)) || f.Lk <= 224 || f.Lk > 1024 || f.causal || !f.lse || !f.O || f.E || (f.Pt && !f.rkd));
+}
+static bool launch_bwd_dq_stream(MAttnB& f, hipStream_t stream) {
+  if (!bwd_dq_stream_applies(f)) return false;
   const char* keep = getenv("EVLM_ATTN_STREAM_PWS");       // (A/B switch) 1: kernel B reads the map from the workspace
   if (!(keep && atoi(keep))) { f.P = nullptr; f.Pw = nullptr; }
   constexpr int KB = 128, NW = 8;
@@ -1826,7 +2078,8 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
     if (a->P_ws) {
       f.Pw = (bf16*)a->P_ws;
       f.P = (const bf16*)a->P_ws;
-    } else if (!a->P) return evlm_set_error("evlm_attention_bwd: the two-kernel recomputing path needs P or the P_ws workspace");
+    } else if (!a->P && !bwd_dq_stream_applies(f))       // (the streaming pair needs neither: kernel B rebuilds the map)
+      return evlm_set_error("evlm_attention_bwd: the two-kernel recomputing path needs P or the P_ws workspace");
     // (a grouped-by-K/V-row form of kernel A - the backward counterpart of attn_fwd_grouped_kernel - was measured 20 %
     // SLOWER than this per-batch launch on the GD shape, tools/attn_bench.py: a backward task is VALU-bound work of ~20 k
     // cycles per wave, so the staging it would share is a small part of it, and 256 registers leave one workgroup per CU)

@@ -50,12 +50,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // d % 8 == 0 and d <= 512 * DCH: the row is read ONCE and kept in registers (chunk c of lane l: l + 64 c), gamma / beta
 // chunks are loaded once per wave, and a wave walks rows  first, first + stride, ...  - same sums in the same order as
 // ln_fwd_kernel (bit-identical output), one pass over memory instead of three dependent ones (-10 % on [12608, 768]).
-template <typename T, int DCH>
+// KD (round 5): the hidden-state distillation term of a block INPUT (GeneralDistill.py:60-82: MSE(student state, teacher
+// state)) rides on this kernel - the student's row is in registers, the teacher's (resident: the pipelined teacher ran a
+// batch ahead) is read once: kd_slots[(block & 31) * 32] += kd_coef * sum (x - t)^2, one atomic per workgroup, 32 slots
+// on 32 different cache lines (the caller sums them).  evlm_mse_grouped no longer reads the 6 x 2 x 19 MB of the ViT states.
+#define LN_KD_SLOTS 32
+template <typename T, int DCH, bool KD = false>
 __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps, int rows, int d,
                                                          T* __restrict__ y, float* __restrict__ mean_out,
-                                                         float* __restrict__ rstd_out) {
+                                                         float* __restrict__ rstd_out, const T* __restrict__ kd_t = nullptr,
+                                                         float* __restrict__ kd_slots = nullptr, float kd_coef = 0.f) {
   const int lane = threadIdx.x & 63, nchunk = d >> 3;
+  float sq = 0.f;
   float gm[DCH][8], bt[DCH][8];
 #pragma unroll
   for (int k = 0; k < DCH; ++k) {
@@ -73,6 +80,12 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const T* __restrict__ x
         load8<T>(xr + c * 8, v[k]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += v[k][e];
+        if (KD) {
+          float tv[8];
+          load8<T>(kd_t + (size_t)row * d + c * 8, tv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float df = v[k][e] - tv[e]; sq = fmaf(df, df, sq); }
+        }
       }
     }
     const float mean = wave_sum(s) / (float)d;
@@ -100,6 +113,14 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const T* __restrict__ x
       if (rstd_out) rstd_out[row] = rstd;
     }
   }
+  if (KD) {
+    __shared__ float kdsum[4];
+    sq = wave_sum(sq);
+    if (lane == 0) kdsum[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      atomicAdd(kd_slots + (blockIdx.x & (LN_KD_SLOTS - 1)) * 32, ((kdsum[0] + kdsum[1]) + (kdsum[2] + kdsum[3])) * kd_coef);
+  }
 }
 
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma += sum_rows dy*xhat;  dbeta += sum_rows dy.
@@ -112,8 +133,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, int rows, int d, T* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     float* __restrict__ partials) {
+                                                     float* __restrict__ partials, const T* __restrict__ kd_t = nullptr,
+                                                     const float* __restrict__ kd_g = nullptr, float kd_k = 0.f) {
   extern __shared__ float sred[];   // [4 waves][2][d]
+  // fused hidden-state distillation (see ln_fwd_reg_kernel): dx += kd_k * (*kd_g) * (x - t), kd_k = 2 w / n, *kd_g = the
+  // upstream gradient of the term - what evlm_mse_grouped's backward wrote into an addend buffer before
+  const float kdk = kd_t ? kd_k * kd_g[0] : 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
   float pg[DCH][8], pb[DCH][8], gm[DCH][8];
@@ -182,6 +207,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             load8<T>(addend2 + (size_t)(row0 + r) * d + c * 8, ad);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] += ad[e];
+          }
+          if (kd_t) {                 // ... or that term's gradient formed here: x = xhat / rstd + mean (registers), t read once
+            float tv[8];
+            load8<T>(kd_t + (size_t)(row0 + r) * d + c * 8, tv);
+            const float irs = 1.0f / rs[r];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(kdk, fmaf(xh[r][u][e], irs, mu[r]) - tv[e], o[e]);
           }
           store8<T>(dxr + c * 8, o);
         }
@@ -256,6 +288,23 @@ extern "C" int evlm_layernorm_bwd_reduce_grouped(const int64_t* table, int n_uni
   return 0;
 }
 
+extern "C" int evlm_layernorm_fwd_kd_slots(void) { return LN_KD_SLOTS * 32; }
+
+extern "C" int evlm_layernorm_fwd_kd(int dtype, const void* x, const float* gamma, const float* beta, float eps,
+                                     int rows, int d, void* y, float* mean, float* rstd, const void* kd_teacher,
+                                     float* kd_slots, float kd_coef, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(x && y && gamma && beta && rows > 0 && d > 0 && kd_teacher && kd_slots, "evlm_layernorm_fwd_kd: bad args");
+  EVLM_REQUIRE(d % 8 == 0 && d <= 2048, "evlm_layernorm_fwd_kd: d=%d unsupported (multiple of 8, <= 2048)", d);
+  dim3 block(256), rgrid(rows >= 4096 ? ceil_div(rows, 12) : ceil_div(rows, 4));
+#define LN_FWD_KD(DCH_) hipLaunchKernelGGL((ln_fwd_reg_kernel<T, DCH_, true>), rgrid, block, 0, stream, (const T*)x, gamma, beta, eps, rows, d, (T*)y, mean, rstd, (const T*)kd_teacher, kd_slots, kd_coef)
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_fwd_kd",
+    if (d <= 512) LN_FWD_KD(1); else if (d <= 1024) LN_FWD_KD(2); else if (d <= 1536) LN_FWD_KD(3); else LN_FWD_KD(4);)
+#undef LN_FWD_KD
+  EVLM_LAUNCH_CHECK("evlm_layernorm_fwd_kd");
+  return 0;
+}
+
 extern "C" int evlm_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, float eps,
                                   int rows, int d, void* y, float* mean, float* rstd, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -284,7 +333,8 @@ extern "C" int evlm_layernorm_bwd_blocks(int rows) { return ln_bwd_blocks(rows);
 
 static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const void* addend, const void* addend2, const float* gamma, const float* mean,
                                   const float* rstd, int rows, int d, void* dx, float* dgamma, float* dbeta,
-                                  float* partials, void* stream_) {
+                                  float* partials, void* stream_, const void* kd_t = nullptr, const float* kd_g = nullptr,
+                                  float kd_k = 0.f) {
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(dy && x && gamma && mean && rstd && dx && rows > 0, "evlm_layernorm_bwd: bad args");
   // dgamma == dbeta == NULL with a workspace: the column sums stay in the workspace, the caller reduces them later
@@ -294,7 +344,7 @@ static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const vo
   const int nblk = ln_bwd_blocks(rows);                // row pairs per wave
   dim3 grid(nblk), block(256);
   const size_t lds = 8 * (size_t)d * sizeof(float);
-#define LN_BWD(DCH_) hipLaunchKernelGGL((ln_bwd_kernel<T, DCH_>), grid, block, lds, stream, (const T*)dy, (const T*)x, (const T*)addend, (const T*)addend2, gamma, mean, rstd, rows, d, (T*)dx, dgamma, dbeta, partials)
+#define LN_BWD(DCH_) hipLaunchKernelGGL((ln_bwd_kernel<T, DCH_>), grid, block, lds, stream, (const T*)dy, (const T*)x, (const T*)addend, (const T*)addend2, gamma, mean, rstd, rows, d, (T*)dx, dgamma, dbeta, partials, (const T*)kd_t, kd_g, kd_k)
   EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_bwd",
     if (d <= 512) LN_BWD(1); else if (d <= 1024) LN_BWD(2); else if (d <= 1536) LN_BWD(3); else LN_BWD(4);)
 #undef LN_BWD
@@ -317,4 +367,14 @@ extern "C" int evlm_layernorm_bwd_add(int dtype, const void* dy, const void* x, 
                                       float* dgamma, float* dbeta, float* partials, void* stream) {
   EVLM_REQUIRE(addend, "evlm_layernorm_bwd_add: null addend");
   return layernorm_bwd_impl(dtype, dy, x, addend, addend2, gamma, mean, rstd, rows, d, dx, dgamma, dbeta, partials, stream);
+}
+// ... and with the gradient of the fused hidden-state distillation term of x (evlm_layernorm_fwd_kd) formed in the kernel:
+// dx += kd_k * kd_gout[0] * (x - kd_teacher);  addend / addend2 may be NULL
+extern "C" int evlm_layernorm_bwd_kd(int dtype, const void* dy, const void* x, const void* addend, const void* addend2,
+                                     const float* gamma, const float* mean, const float* rstd, int rows, int d, void* dx,
+                                     float* dgamma, float* dbeta, float* partials, const void* kd_teacher,
+                                     const float* kd_gout, float kd_k, void* stream) {
+  EVLM_REQUIRE(kd_teacher && kd_gout, "evlm_layernorm_bwd_kd: null kd_teacher / kd_gout");
+  return layernorm_bwd_impl(dtype, dy, x, addend, addend2, gamma, mean, rstd, rows, d, dx, dgamma, dbeta, partials, stream,
+                            kd_teacher, kd_gout, kd_k);
 }

@@ -63,8 +63,11 @@ def kd_terms(S, T, temperature=1.0, with_cross_attn=False, fused=None, side=None
     s_list = lambda d, key: rows[key] if (key in rows and all(x is not None for x in rows[key])) else d[key]
 
     def pair(name, hkey, akey, is_img=False):
-        names.append(name + "_hidden")
-        terms.append(_kd_pairs(s_list(sh, hkey), get_cor_teacher(th[hkey], sh[hkey]), is_img=is_img))
+        if name + "_hidden" in fused:
+            out[name + "_hidden"] = fused[name + "_hidden"]
+        else:
+            names.append(name + "_hidden")
+            terms.append(_kd_pairs(s_list(sh, hkey), get_cor_teacher(th[hkey], sh[hkey]), is_img=is_img))
         if name + "_attn" in fused:
             out[name + "_attn"] = fused[name + "_attn"]
         else:
@@ -166,7 +169,8 @@ def vqa_kd_terms(S, T, temperature=1.0, fused=None):
         "text_hidden": get_kd_loss(s_h[:4], t_h[:4]), "text_attn": get_kd_loss(s_a[:3], t_a[:3], is_attn=True),
         "cross_hidden": get_kd_loss(s_h[4:], t_h[4:]), "cross_self_attn": get_kd_loss(s_a[3:], t_a[3:], is_attn=True),
         "cross_attn": get_kd_loss(sc["cross_attentions"], cor(tc, sc, "cross_attentions", True), is_attn=True),
-        "image_hidden": get_kd_loss(sh["image_hidden_states"], cor(th, sh, "image_hidden_states", False), is_img=True),
+        "image_hidden": (fused["image_hidden"] if fused and "image_hidden" in fused else
+                         get_kd_loss(sh["image_hidden_states"], cor(th, sh, "image_hidden_states", False), is_img=True)),
         "image_attn": (fused["image_attn"] if fused and "image_attn" in fused else
                        get_kd_loss(sa["image_attentions"], cor(ta, sa, "image_attentions", True), is_attn=True)),
         "decoder_hidden": get_kd_loss(sh["decoder_hidden_states"], cor(th, sh, "decoder_hidden_states", False), is_img=True),
@@ -280,6 +284,17 @@ def fuse_image_map_kd(student, teacher_out, batch):
     if not ops.attention_kd_fusable(cor[0], attn.num_heads, attn.head_dim, cor[0].shape[-1]):
         return None
     enc.kd_teacher_maps = cor
+    # ... and the hidden-state term of the same encoder inside each layer's first LayerNorm (round 5): student state i - the
+    # input of layer i - against teacher state i * k (get_cor_teacher); the last pair (index 6 of a 6-layer student) is the
+    # one get_kd_loss(is_img=True) skips (GeneralDistill.py:71-72), so every term pair is a layer input
+    enc.kd_teacher_states = None
+    states = teacher_out["hidden_dict"].get("image_hidden_states")
+    if (states is not None and not os.environ.get("EVLM_NO_FUSED_HIDDEN_KD") and ns == 6 and (len(states) - 1) % ns == 0
+            and hasattr(enc, "kd_teacher_states")):
+        k = (len(states) - 1) // ns
+        cor_h = [states[i * k] for i in range(ns)]
+        if all(torch.is_tensor(t) and t.is_contiguous() and t.dtype == torch.bfloat16 and t.numel() > 0 for t in cor_h):
+            enc.kd_teacher_states = [t.detach() for t in cor_h]
     return enc
 
 
@@ -287,9 +302,16 @@ def collect_fused_kd(enc):
     """{'image_attn': sum of the per-layer terms} produced during the forward the encoder was armed for"""
     terms, enc.kd_teacher_maps = enc.kd_fused, None
     enc.kd_fused = None
+    hidden, armed = getattr(enc, "kd_hidden_fused", None), getattr(enc, "kd_teacher_states", None) is not None
+    enc.kd_hidden_fused = enc.kd_teacher_states = None
     if not terms or any(t is None for t in terms) or len(terms) != len(enc.layers):
         raise RuntimeError("fused attention-map distillation: a ViT layer did not report its term")
-    return {"image_attn": torch.stack(terms).sum()}
+    out = {"image_attn": torch.stack(terms).sum()}
+    if armed and hidden is not None:            # (None: the forward did not qualify - no grad, no hidden states asked for)
+        if any(t is None for t in hidden) or len(hidden) != len(enc.layers):
+            raise RuntimeError("fused hidden-state distillation: a ViT layer did not report its term")
+        out["image_hidden"] = torch.stack(hidden).sum()
+    return out
 
 
 def student_forward_fused_kd(student, call, teacher_out, batch):
@@ -300,7 +322,7 @@ def student_forward_fused_kd(student, call, teacher_out, batch):
         S = call()
     except BaseException:
         if enc is not None:                    # disarm the encoder; the forward's own exception is the one to report
-            enc.kd_teacher_maps = enc.kd_fused = None
+            enc.kd_teacher_maps = enc.kd_fused = enc.kd_teacher_states = enc.kd_hidden_fused = None
         raise
     return S, (collect_fused_kd(enc) if enc is not None else {})
 
@@ -322,7 +344,7 @@ def gd_forward(student, teacher, batch, temperature=1.0, overlap_teacher=False, 
             S, T = call(student), teacher_out
         except BaseException:
             if enc is not None:                # disarm the encoder; the forward's own exception is the one to report
-                enc.kd_teacher_maps = enc.kd_fused = None
+                enc.kd_teacher_maps = enc.kd_fused = enc.kd_teacher_states = enc.kd_hidden_fused = None
             raise
         if enc is not None:
             fused = collect_fused_kd(enc)      # (validates the terms: only after a forward that completed)

@@ -153,13 +153,21 @@ class CLIPEncoderLayer(nn.Module):
         self.layer_norm2 = nn.LayerNorm(hidden_size)
 
     def forward(self, hidden_states, attention_mask: None, output_attentions: Optional[bool] = False, head_z=None,
-                head_layer_z=None, mlp_z=None, kd_teacher=None, kd_word=None, p_out=None):
+                head_layer_z=None, mlp_z=None, kd_teacher=None, kd_word=None, p_out=None, kd_state=None):
         # (layer_norm_fork: the residual branch gets an ALIAS of the block input, so that the LayerNorm backward kernel sums
         # the two gradients of the input itself - evlm_layernorm_bwd_add - instead of autograd adding them element-wise)
         # (`tap`: a third alias of the block input, for the hidden-state distillation that reads it - CLIPEncoder reports it
         # in `encoder_states`, so that the input's two extra gradients reach the LayerNorm backward kernel as addends)
-        h, residual, self.input_tap = ops.layer_norm_fork(hidden_states, self.layer_norm1.weight, self.layer_norm1.bias,
-                                                          self.layer_norm1.eps, tap=True)
+        # (`kd_state` = (teacher state, zeroed slots, weight / numel): the hidden-state distillation term of the block input is
+        # formed INSIDE this LayerNorm's kernels - forward sum and backward gradient - and nothing else reads the input)
+        self.kd_hidden_term = None
+        if kd_state is not None and torch.is_grad_enabled() and hidden_states.requires_grad:
+            h, residual, self.kd_hidden_term = ops.layer_norm_fork_kd(hidden_states, self.layer_norm1.weight,
+                                                                      self.layer_norm1.bias, self.layer_norm1.eps, *kd_state)
+            self.input_tap = None
+        else:
+            h, residual, self.input_tap = ops.layer_norm_fork(hidden_states, self.layer_norm1.weight, self.layer_norm1.bias,
+                                                              self.layer_norm1.eps, tap=True)
         attn_out = self.self_attn(hidden_states=h, attention_mask=attention_mask,
                                   causal_attention_mask=None, output_attentions=output_attentions,
                                   head_z=head_z, head_layer_z=head_layer_z, residual=residual, kd_teacher=kd_teacher,
@@ -189,6 +197,11 @@ class CLIPEncoder(nn.Module):
         # teacher's outputs of this batch already exist - the pipelined trainer); the per-layer terms land in kd_fused
         self.kd_teacher_maps = None
         self.kd_fused = None
+        # extension: per-layer teacher STATES (the input of student layer i against get_cor_teacher's state) for the fused
+        # hidden-state distillation - formed inside each layer's first LayerNorm; the per-layer slot vectors land in
+        # kd_hidden_fused (distill.fuse_image_map_kd / collect_fused_kd)
+        self.kd_teacher_states = None
+        self.kd_hidden_fused = None
         # extension (False = the reference's behaviour of returning every map): a layer whose map distillation ran fused in
         # its attention kernel does not materialise the map (None in its slot) - nobody else reads a student's ViT maps in
         # the GD recipe (trainer.GDTrainer sets this on the student)
@@ -218,6 +231,13 @@ class CLIPEncoder(nn.Module):
         kd_maps = self.kd_teacher_maps if (self.kd_teacher_maps is not None and not do_gather and output_attentions) else None
         self.kd_fused = [] if kd_maps is not None else None
         kd_words = torch.zeros(len(self.layers), dtype=torch.float32, device=inputs_embeds.device) if kd_maps is not None else None
+        kd_states = self.kd_teacher_states if (self.kd_teacher_states is not None and not do_gather
+                                               and output_hidden_states and torch.is_grad_enabled()
+                                               and inputs_embeds.requires_grad) else None
+        self.kd_hidden_fused = [] if kd_states is not None else None
+        if kd_states is not None:
+            nslot = ops.hidden_kd_slots()
+            kd_hslots = ops.zeros_small((len(self.layers), nslot), torch.float32, inputs_embeds.device)
         for idx, encoder_layer in enumerate(self.layers):
             states_slot = len(encoder_states) if output_hidden_states else None
             if output_hidden_states:
@@ -231,6 +251,9 @@ class CLIPEncoder(nn.Module):
             kdkw = dict(kd_teacher=kd_maps[idx], kd_word=kd_words[idx]) if kd_maps is not None else {}
             if self.attn_out and idx in self.attn_out and want_map and not do_gather and image_atts_blk is None:
                 kdkw["p_out"] = self.attn_out[idx]
+            if kd_states is not None and kd_states[idx] is not None:
+                # MSELoss (mean over the elements) with weight 1 (GeneralDistill.py:78-80)
+                kdkw["kd_state"] = (kd_states[idx], kd_hslots[idx], 1.0 / float(hidden_states.numel()))
             if self.grad_hooks and idx in self.grad_hooks and hidden_states.requires_grad:
                 cb = self.grad_hooks[idx]
                 hidden_states.register_hook(lambda grad, cb=cb: (cb(), grad)[1])
@@ -250,6 +273,9 @@ class CLIPEncoder(nn.Module):
             encoder_layer.input_tap = None
             if kd_maps is not None:
                 self.kd_fused.append(encoder_layer.kd_term)
+            if kd_states is not None:
+                self.kd_hidden_fused.append(encoder_layer.kd_hidden_term)
+                encoder_layer.kd_hidden_term = None
             hidden_states = layer_outputs[0]
             if output_attentions:
                 all_attentions = all_attentions + ((layer_outputs[1] if want_map else None),)

@@ -883,10 +883,11 @@ class _LayerNormFork(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, tap=False):
         y = _LayerNorm.forward(ctx, x, gamma, beta, eps)
+        ctx.set_materialize_grads(False)        # an alias nobody differentiates through must not cost a zero tensor
         return (y, x.view_as(x), x.view_as(x)) if tap else (y, x.view_as(x))
 
     @staticmethod
-    def backward(ctx, dy, dres, dtap=None):
+    def backward(ctx, dy, dres=None, dtap=None):
         xc, gamma, mean, rstd = ctx.saved_tensors
         adds = [g for g in (dres, dtap) if g is not None]
         if dy is None:
@@ -916,6 +917,88 @@ class _LayerNormFork(torch.autograd.Function):
             L.check(_lib().evlm_layernorm_bwd(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd),
                                               rows, d, L.ptr(dx), pdg, pdb, L.ptr(ws), L.stream()), "layernorm_bwd")
         return (dx.view(ctx.xshape), None, None, None, None) if inplace else (dx.view(ctx.xshape), dg, db, None, None)
+
+
+class _LayerNormForkKD(torch.autograd.Function):
+    """_LayerNormFork with the hidden-state distillation term of x fused in (evlm_layernorm_fwd_kd / _bwd_kd): returns
+    (LayerNorm(x), alias of x for the residual branch, kd_slots).  kd_slots [evlm_layernorm_fwd_kd_slots()] f32, zeroed by
+    the caller, receives kd_coef * sum (x - kd_teacher)^2 spread over its cache lines (sum it for the term: weight *
+    MSELoss(x, kd_teacher) with kd_coef = weight / numel); its incoming gradient is the term's upstream scalar, and the
+    backward kernel adds 2 kd_coef * g * (x - kd_teacher) to dx itself - no squared-difference pass over [rows, d] in either
+    direction, no gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, kd):
+        # (kd = (teacher state, slots, coefficient) travels as ONE non-tensor argument: the slots are written by the kernel
+        # and returned as a fresh output, like _Attention's KdSlot word - not an autograd input modified in place)
+        kd_teacher, kd_slots, kd_coef = kd
+        L.require_cuda(x, gamma, kd_teacher)
+        d = x.shape[-1]
+        xc = x if x.is_contiguous() else x.contiguous()
+        if (not kd_teacher.is_contiguous() or kd_teacher.shape != xc.shape or kd_teacher.dtype != xc.dtype
+                or kd_slots.dtype != torch.float32 or kd_slots.numel() < _lib().evlm_layernorm_fwd_kd_slots()):
+            raise RuntimeError("fused hidden-state distillation: the teacher state must be a contiguous tensor of the "
+                               "student state's shape and dtype, kd_slots a zeroed f32 vector of evlm_layernorm_fwd_kd_slots()")
+        rows = xc.numel() // d
+        y = torch.empty_like(xc)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        L.check(_lib().evlm_layernorm_fwd_kd(L.dt(xc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(beta.detach()), eps, rows, d,
+                                             L.ptr(y), L.ptr(mean), L.ptr(rstd), L.ptr(kd_teacher), L.ptr(kd_slots),
+                                             float(kd_coef), L.stream()), "layernorm_fwd_kd")
+        ctx.save_for_backward(xc, gamma, mean, rstd, kd_teacher)
+        ctx.params = (gamma, beta)
+        ctx.xshape = x.shape
+        ctx.kd_coef = float(kd_coef)
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x), kd_slots
+
+    @staticmethod
+    def backward(ctx, dy, dres=None, dkd=None):
+        xc, gamma, mean, rstd, kd_t = ctx.saved_tensors
+        d = xc.shape[-1]
+        rows = xc.numel() // d
+        if dy is None:
+            raise RuntimeError("fused hidden-state distillation: the LayerNorm output took no part in the loss")
+        dyc = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty_like(xc)
+        pg, pb = ctx.params
+        inplace = _inplace(pg) and _inplace(pb)
+        dg = pg.grad if inplace else torch.zeros(d, dtype=torch.float32, device=xc.device)
+        db = pb.grad if inplace else torch.zeros(d, dtype=torch.float32, device=xc.device)
+        nblk = _lib().evlm_layernorm_bwd_blocks(rows)
+        ws = torch.empty(nblk * 2 * d, dtype=torch.float32, device=xc.device)
+        defer = inplace and WGRAD_DEFER is not None
+        if defer:
+            LN_DEFER.append((ws, nblk, d, dg, db))
+        pdg, pdb = (None, None) if defer else (L.ptr(dg), L.ptr(db))
+        rc = None
+        if dres is not None:
+            rc = dres if (dres.is_contiguous() and dres.dtype == xc.dtype) else dres.to(xc.dtype).contiguous()
+        if dkd is not None:
+            # (every slot's gradient is the term's upstream scalar - the slots are only ever summed: its first word serves)
+            g = dkd.reshape(-1)[:1]
+            g = g if g.dtype == torch.float32 else g.float()
+            L.check(_lib().evlm_layernorm_bwd_kd(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(rc), None, L.ptr(gamma.detach()),
+                                                 L.ptr(mean), L.ptr(rstd), rows, d, L.ptr(dx), pdg, pdb, L.ptr(ws),
+                                                 L.ptr(kd_t), L.ptr(g), 2.0 * ctx.kd_coef, L.stream()), "layernorm_bwd_kd")
+        elif rc is not None:
+            L.check(_lib().evlm_layernorm_bwd_add(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(rc), None, L.ptr(gamma.detach()),
+                                                  L.ptr(mean), L.ptr(rstd), rows, d, L.ptr(dx), pdg, pdb, L.ptr(ws),
+                                                  L.stream()), "layernorm_bwd_add")
+        else:
+            L.check(_lib().evlm_layernorm_bwd(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd),
+                                              rows, d, L.ptr(dx), pdg, pdb, L.ptr(ws), L.stream()), "layernorm_bwd")
+        return (dx.view(ctx.xshape), None, None, None, None) if inplace else (dx.view(ctx.xshape), dg, db, None, None)
+
+
+def layer_norm_fork_kd(x, gamma, beta, eps, kd_teacher, kd_slots, kd_coef):
+    """(LayerNorm(x), alias of x for the residual branch, kd_slots): see _LayerNormForkKD"""
+    return _LayerNormForkKD.apply(x, gamma, beta, eps, (kd_teacher, kd_slots, kd_coef))
+
+
+def hidden_kd_slots():
+    return _lib().evlm_layernorm_fwd_kd_slots()
 
 
 def layer_norm(x, gamma, beta, eps):

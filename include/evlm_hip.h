@@ -124,6 +124,20 @@ int evlm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* ga
 int evlm_layernorm_bwd_add(int dtype, const void* dy, const void* x, const void* addend, const void* addend2,
                            const float* gamma, const float* mean, const float* rstd, int rows, int d, void* dx,
                            float* dgamma, float* dbeta, float* partials, void* stream);
+/* LayerNorm with the HIDDEN-STATE DISTILLATION TERM of its input fused in (ABI 7; GeneralDistill.py:60-82 get_kd_loss on
+ * image_hidden_states: MSELoss(student state, teacher state), the state being the input of a pre-LN ViT block,
+ * eff_vit.py:250).  Forward: kd_slots[evlm_layernorm_fwd_kd_slots() floats, zeroed by the caller] receive
+ * kd_coef * sum (x - kd_teacher)^2 spread over 32 cache lines (the caller sums the slots; kd_coef = weight / numel).
+ * Backward: dx += kd_k * kd_gout[0] * (x - kd_teacher) with kd_k = 2 * weight / numel and kd_gout the device scalar
+ * gradient of the term; addend / addend2 as in evlm_layernorm_bwd_add (either may be NULL). */
+int evlm_layernorm_fwd_kd_slots(void);
+int evlm_layernorm_fwd_kd(int dtype, const void* x, const float* gamma, const float* beta, float eps, int rows, int d,
+                          void* y, float* mean, float* rstd, const void* kd_teacher, float* kd_slots, float kd_coef,
+                          void* stream);
+int evlm_layernorm_bwd_kd(int dtype, const void* dy, const void* x, const void* addend, const void* addend2,
+                          const float* gamma, const float* mean, const float* rstd, int rows, int d, void* dx,
+                          float* dgamma, float* dbeta, float* partials, const void* kd_teacher, const float* kd_gout,
+                          float kd_k, void* stream);
 /* dgamma == dbeta == NULL (workspace given): the per-block column sums stay in `partials`; reduce the workspaces of many
  * LayerNorms at once with  table: device int64 [n][5] = {partials, blocks (evlm_layernorm_bwd_blocks(rows)), d, dgamma,
  * dbeta}  (accumulated), d_max = largest d in the table. */

@@ -610,6 +610,60 @@ def test_fused_attention_map_distillation_equals_the_separate_reduction(B, H, L,
     assert rel_err(a.grad.float(), b.grad.float()) < (1.2e-2 if recomputes else 6e-3)
 
 
+@pytest.mark.parametrize("B,L,d", [(64, 197, 768), (3, 50, 512), (2, 577, 768), (5, 7, 1536)])
+def test_fused_hidden_state_distillation_equals_layernorm_plus_the_separate_reduction(B, L, d):
+    """evlm_layernorm_fwd_kd / evlm_layernorm_bwd_kd (round 5): the hidden-state distillation term of a pre-LN block's input
+    (GeneralDistill.py:60-82: MSELoss(student state, teacher state)) formed inside the block's first LayerNorm - forward sum
+    from the row in registers, backward gradient 2 c g (x - t) added to dx in the kernel - against the separate path
+    (layer_norm_fork with a tap + evlm_mse): the LayerNorm output is bit-identical, the term agrees to f32 summation order,
+    the input gradient to one bf16 rounding (the separate path rounds the term's gradient to bf16 on its way through HBM),
+    and both are held to an fp32 torch reference"""
+    o = ops()
+    g = torch.Generator().manual_seed(17 + L)
+    x0 = rnd((B, L, d), torch.bfloat16, g, 0.8)
+    t = rnd((B, L, d), torch.bfloat16, g, 0.8)
+    gam = torch.nn.Parameter((torch.rand(d, generator=g) + 0.5).to(DEV))
+    bet = torch.nn.Parameter((torch.randn(d, generator=g) * 0.1).to(DEV))
+    gy, gres = rnd((B, L, d), torch.bfloat16, g), rnd((B, L, d), torch.bfloat16, g)
+    coef = 0.37
+
+    def fused():
+        x = x0.clone().requires_grad_(True)
+        gam.grad = bet.grad = None
+        slots = torch.zeros(o.hidden_kd_slots(), dtype=torch.float32, device=DEV)
+        y, res, sl = o.layer_norm_fork_kd(x, gam, bet, 1e-5, t, slots, 1.0 / x.numel())
+        term = sl.sum()
+        ((y * gy).sum() + (res * gres).sum() + coef * term).backward()
+        return y.detach(), term.detach(), x.grad, gam.grad.clone(), bet.grad.clone()
+
+    def separate():
+        x = x0.clone().requires_grad_(True)
+        gam.grad = bet.grad = None
+        y, res, tap = o.layer_norm_fork(x, gam, bet, 1e-5, tap=True)
+        term = o.mse(tap, t)
+        ((y * gy).sum() + (res * gres).sum() + coef * term).backward()
+        return y.detach(), term.detach(), x.grad, gam.grad.clone(), bet.grad.clone()
+
+    a, b = fused(), separate()
+    assert torch.equal(a[0], b[0])
+    ref = torch.nn.functional.mse_loss(x0.float(), t.float())
+    assert rel_err(a[1], ref) < 1e-5 and rel_err(b[1], ref) < 1e-5
+    xr = x0.float().clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (d,), gam.detach(), bet.detach(), 1e-5)
+    ((yr * gy.float()).sum() + (xr * gres.float()).sum() + coef * torch.nn.functional.mse_loss(xr, t.float())).backward()
+    l2 = lambda u, v: float((u.double() - v.double()).norm() / v.double().norm())
+    assert l2(a[2].float(), xr.grad) < 4e-3 and l2(b[2].float(), xr.grad) < 4e-3
+    assert l2(a[2].float(), b[2].float()) < 4e-3
+    assert rel_err(a[3], b[3]) < 1e-5 and rel_err(a[4], b[4]) < 1e-5     # (same dy, same x: the column sums, up to atomics' order)
+    # the distillation gradient alone (dy = 0, no residual gradient): exactly 2 c g (x - t), rounded once
+    x = x0.clone().requires_grad_(True)
+    slots = torch.zeros(o.hidden_kd_slots(), dtype=torch.float32, device=DEV)
+    y, res, sl = o.layer_norm_fork_kd(x, gam, bet, 1e-5, t, slots, 1.0 / x.numel())
+    ((y * 0).sum() + coef * sl.sum()).backward()
+    want = (2 * coef / x0.numel()) * (x0.float() - t.float())
+    assert l2(x.grad.float(), want) < 3e-3
+
+
 @pytest.mark.parametrize("Bimg,rows,Lq,N,H", [(6, 4, 30, 197, 12), (5, 1, 30, 197, 12), (3, 3, 17, 100, 4), (2, 5, 40, 224, 2)])
 def test_fused_cross_attention_forward_is_bit_identical_to_the_two_launch_path(Bimg, rows, Lq, N, H):
     """evlm_xattn_fused_fwd (K/V projection + QK^T + softmax + PV in one launch, K/V never in HBM; eff_bert.py:277-364 with
@@ -1199,11 +1253,13 @@ def test_one_pass_long_sequence_backward_with_fused_distillation_and_gates(B, H,
 
 
 @pytest.mark.parametrize("B,Bkv,Lq,Lk,with_mask", [(7, 3, 30, 197, False), (256, 64, 30, 197, True), (9, 2, 17, 100, True),
-                                                   (5, 4, 64, 224, False)])
+                                                   (5, 4, 64, 224, False), (700, 90, 30, 197, False), (40, 3, 40, 150, True)])
 def test_grouped_cross_attention_forward_is_bit_identical_to_the_per_batch_kernel(B, Bkv, Lq, Lk, with_mask, monkeypatch):
-    """attn_fwd_grouped_kernel (one workgroup per (K/V row, head) serving every query batch that shares it) against the
-    per-batch kernel: same arithmetic per (batch, head, query) - identical context, map and row lse; a K/V row nobody
-    attends to and uneven sharing included; forward + backward through both"""
+    """the grouped cross-attention forward kernels - attn_fwd_grouped_persist_kernel (round 5: one workgroup per CU walks the
+    (K/V row, head) items with double-buffered K / V; the default) and attn_fwd_grouped_kernel (one workgroup per item:
+    EVLM_ATTN_GROUP_PERSIST=0) - against the per-batch kernel: same arithmetic per (batch, head, query) - identical
+    context, map and row lse; a K/V row nobody attends to, uneven sharing, more items than CUs (1 080: several per
+    workgroup) and waves with several tasks per item (40 batches on 3 rows) included; forward + backward through all"""
     o = ops()
     H, dh = 12, 64
     d = H * dh
@@ -1218,24 +1274,35 @@ def test_grouped_cross_attention_forward_is_bit_identical_to_the_per_batch_kerne
         mask = mask.to(DEV)
     gO = rnd((B, Lq, d), torch.bfloat16, g)
 
-    def run(no_group, want):
-        monkeypatch.setenv("EVLM_ATTN_NO_GROUP", "1" if no_group else "0")
+    def run(form, want):
+        monkeypatch.setenv("EVLM_ATTN_NO_GROUP", "1" if form == "per-batch" else "0")
+        monkeypatch.setenv("EVLM_ATTN_GROUP_PERSIST", "0" if form == "per-item" else "1")
         q, kv = q0.clone().requires_grad_(True), kv0.clone().requires_grad_(True)
         O, P = o.cross_attention(q, kv, H, dh, 0.125, mask=mask, want_probs=want, kv_index=idx)
         (O.float() * gO.float()).sum().backward()
         return O.detach(), (P.detach() if P is not None else None), q.grad, kv.grad
 
     for want in (True, False):
-        a, b = run(False, want), run(True, want)
-        assert torch.equal(a[0], b[0])
-        assert (a[1] is None) == (b[1] is None) and (a[1] is None or torch.equal(a[1], b[1]))
-        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])       # (same lse -> same recomputed probabilities)
+        b = run("per-batch", want)
+        for form in ("persistent", "per-item"):
+            a = run(form, want)
+            assert torch.equal(a[0], b[0]), form
+            assert (a[1] is None) == (b[1] is None) and (a[1] is None or torch.equal(a[1], b[1])), form
+            assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]), form     # (same lse -> same recomputed probabilities)
+    # no-grad launches (no lse), with a closed head: its context is zero and its K / V are never staged
+    gate = torch.ones(H, device=DEV)
+    gate[1] = 0.0
+    outs = []
     with torch.no_grad():
-        monkeypatch.setenv("EVLM_ATTN_NO_GROUP", "0")
-        O1, P1 = o.cross_attention(q0, kv0, H, dh, 0.125, mask=mask, want_probs=True, kv_index=idx)
-        monkeypatch.setenv("EVLM_ATTN_NO_GROUP", "1")
-        O2, P2 = o.cross_attention(q0, kv0, H, dh, 0.125, mask=mask, want_probs=True, kv_index=idx)
-    assert torch.equal(O1, O2) and torch.equal(P1, P2)
+        for form in ("persistent", "per-item", "per-batch"):
+            monkeypatch.setenv("EVLM_ATTN_NO_GROUP", "1" if form == "per-batch" else "0")
+            monkeypatch.setenv("EVLM_ATTN_GROUP_PERSIST", "0" if form == "per-item" else "1")
+            outs.append(o.cross_attention(q0, kv0, H, dh, 0.125, mask=mask, want_probs=True, kv_index=idx))
+            outs.append(o.cross_attention(q0, kv0, H, dh, 0.125, mask=mask, gate=gate, want_probs=False, kv_index=idx))
+    for k in (2, 4):
+        assert torch.equal(outs[0][0], outs[k][0]) and torch.equal(outs[0][1], outs[k][1])
+        assert torch.equal(outs[1][0], outs[k + 1][0])
+    assert float(outs[1][0][..., 64:128].abs().max()) == 0.0 and float(outs[1][0][..., :64].abs().max()) > 0.0
 
 
 @pytest.mark.parametrize("n,Bimg,rows,Lq,Lk,H", [(3, 5, 4, 30, 197, 12), (6, 3, 1, 17, 100, 4), (2, 4, 3, 30, 197, 12)])

@@ -229,7 +229,7 @@ def _tie(sd):
 
 
 @pytest.mark.parametrize("B", [64])
-def test_benchmarked_configuration_matches_the_oracle(B):
+def test_benchmarked_configuration_matches_the_oracle(B, monkeypatch):
     """The configuration bench.py times - bf16, batch 64, full geometry, hipGraph replay, teacher pipelined one batch
     ahead, deferred grouped weight gradients, the 256 x 256 GEMM routing - held to the fp32 CPU oracle on the same
     weights, batch and hard negatives (GeneralDistill.py:286-376): step-0 losses, every KD term, and the gradients the
@@ -253,10 +253,14 @@ def test_benchmarked_configuration_matches_the_oracle(B):
     tr = GDTrainer(student, teacher, lr=1e-4, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=torch.bfloat16,
                    use_graph=True, pipeline_teacher=True)
     gb = {k: v.to(DEV) for k, v in batch.items()}
+    fused_ln = []                                 # (round 5: the ViT hidden-state term is formed inside the LayerNorm kernels)
+    orig_fork_kd = ops.layer_norm_fork_kd
+    monkeypatch.setattr(ops, "layer_norm_fork_kd", lambda *a, **k: (fused_ln.append(1), orig_fork_kd(*a, **k))[1])
     assert tr.step(gb) is None                    # primes the teacher pipeline
     out = tr.step(gb)                             # student step on the first batch, replayed from the joint hipGraph
     torch.cuda.synchronize()
     assert tr._joint, "the step did not run from a captured graph"
+    assert len(fused_ln) >= 6, "the image hidden-state distillation did not run fused (one LayerNorm per ViT layer)"
     got = [float(x) for x in out.tolist()]
     got_kd = {k: float(v) for k, v in tr.last_kd.items()}
     got_grad = {n: p.grad.detach().float().cpu().clone() for n, p in student.named_parameters()}
@@ -871,6 +875,12 @@ if kind == "itr":
     from efficientvlm_amd.efficient_models.model_retrieval import EffXVLMforRetrieval
     from efficientvlm_amd.models.model_retrieval import XVLM as TeacherITR
     from efficientvlm_amd.trainer import ITRTrainer
+    from efficientvlm_amd.efficient_models.xvlm import XVLMBase
+    def fixed_negatives(self, image_feat, text_feat, idx):        # (the device draws differ from process to process)
+        bs = image_feat.size(0)
+        ar = torch.arange(bs, device=image_feat.device)
+        return (ar + 1) % bs, (ar + 2) % bs
+    XVLMBase._sample_negatives = fixed_negatives
     s_cfg, t_cfg = O.model_cfg(geom, "s"), O.model_cfg(geom, "t")
     student, teacher = EffXVLMforRetrieval(model_config(geom, "s")), TeacherITR(model_config(geom, "t"))
     load_det_weights(student, schema.xvlm_schema(s_cfg, geom["max_pos"], mlm=False, bbox=False, l0=True), 51, geom["std"])
