@@ -102,6 +102,41 @@ __device__ __forceinline__ bf16x8 vcol_frag(const char* sm, int t0, int t1, int 
   return out;
 }
 
+// The same fragment through INLINE-ASM transposing reads (round 5), for kernels that keep an LDS-DMA in flight while they
+// read another buffer: hipcc models an LDS-DMA as a pending LDS write and puts `s_waitcnt vmcnt(0)` in front of every
+// __builtin_amdgcn_ds_read_tr16_b64 while one is outstanding (found on the GEMM side in round 4, gemm_pp256_core.h:
+// pp_frag) - the streaming attention kernels' "next block under the current block's arithmetic" ended at the first V / K^T
+// fragment read of the block.  The asm reads are invisible to that pass AND to the compiler's lgkmcnt bookkeeping: the
+// caller issues TR_WAIT() (s_waitcnt lgkmcnt(0) between two sched_barriers) before the MFMAs that consume them.  Counted
+// waits the compiler emits for its own LDS reads stay correct: LDS operations complete in order, so extra operations in
+// the queue can only make such a wait longer, never shorter.
+template <int SW = SW_V>
+__device__ __forceinline__ bf16x8 vcol_frag_a(const char* sm, int t0, int t1, int dt, int lane) {
+  const int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3;
+  const uint32_t sb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)sm;
+  bf16x8 out;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = (h ? t1 : t0) * 16 + g * 4 + q;
+    const uint32_t off = sb + row * 128 + swz<SW>(row, dt * 2 + (p >> 1)) * 16 + ((p & 1) << 3);
+    bf16x4 t;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(t) : "v"(off));
+    out[4 * h + 0] = t[0]; out[4 * h + 1] = t[1]; out[4 * h + 2] = t[2]; out[4 * h + 3] = t[3];
+  }
+  return out;
+}
+// (Measured and NOT kept, round 5: the teacher-map pieces of the streaming kernels as inline-asm global loads with counted
+// waits - hipcc answers a wait for a tracked load that is older than an LDS-DMA with vmcnt(0) whatever it knows about the
+// DMA count, draining the next block's staging at the piece's first use.  The asm form ran 2 % SLOWER on the forward with
+// fused distillation (266 against 261 us at 577 keys) and level on forward + backward, and an asm load's destination must
+// not be copied before its wait - a loop-carried set of pieces produced exactly that copy, and a memory fault.)
+#define TR_WAIT()                                          \
+  do {                                                     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+  } while (0)
+
 // NT = number of 16-key tiles (even).  One workgroup = up to 16 waves x 16 queries of one (batch, head): with Lq <= 256
 // (the ViT's 197 tokens) a single workgroup covers every query, so K and V are staged into LDS exactly once per
 // (batch, head) instead of once per 64-query block on four different XCDs.
@@ -668,10 +703,16 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_persist_kernel(MAttn
 // - three running sums over the un-normalised e, rescaled with the maximum like l; the backward's row term
 // sum_k p (p - pt) = (sum e^2) / l^2 - (sum e pt) / l comes out of the same sums.
 // Workgroups of one (batch, head) are mapped to ONE XCD (consecutive logical ids share an L2).
+// (round 5: every caller passes compile-time nrows / nw with nrows % (8 nw) == 0, so the trip count nrows / (8 nw) is the
+// SAME for every wave and known to the compiler - written `r0 = wave * 8; r0 < nrows` it looked wave-dependent, the loop
+// stayed a loop, and the wait-count pass, unable to count the DMA instructions in flight, answered every wait for an older
+// load - the teacher map's pieces requested just before the DMA - with vmcnt(0): draining the next block's staging)
 template <int SW>
 __device__ __forceinline__ void stage_block(const bf16* base, int ld, int L, int key0, int nrows, int nw, char* sm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int r0 = wave * 8; r0 < nrows; r0 += nw * 8) {
+#pragma unroll
+  for (int k = 0; k < nrows / (nw * 8); ++k) {
+    const int r0 = wave * 8 + k * nw * 8;
     const int row = r0 + (lane >> 3), cs = lane & 7;
     const int c = swz<SW>(row, cs);
     const int key = min(key0 + row_key(row), L - 1);
@@ -829,6 +870,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
       }
     }
     // O^T += V^T E^T with the un-normalised e (<= 1) as bf16: the row's 1 / l is applied once, to the context
+    // (asm fragment reads, one tile pair ahead of the MFMAs that consume them: the next block's DMA stays in flight)
+    // (16 waves per workgroup run at 128 VGPRs: no room for the second fragment set - read, wait, multiply there)
+    constexpr bool AHEAD = NW <= 8;
+    bf16x8 vfr[AHEAD ? 2 : 1][4];
+    __builtin_amdgcn_sched_barrier(0);
+    if (AHEAD) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vfr[0][dt] = vcol_frag_a<SW_V>(Vs, 0, 1, dt, lane);
+    }
 #pragma unroll
     for (int s2 = 0; s2 < KBT / 2; ++s2) {
       bf16x8 pb[TQ];
@@ -836,13 +886,24 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
       for (int j = 0; j < TQ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pb[j][r] = (bf16)acc[j][2 * s2][r]; pb[j][4 + r] = (bf16)acc[j][2 * s2 + 1][r]; }
+      if (!AHEAD) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vfr[0][dt] = vcol_frag_a<SW_V>(Vs, 2 * s2, 2 * s2 + 1, dt, lane);
+      }
+      TR_WAIT();
+      if (AHEAD && s2 + 1 < KBT / 2) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vfr[(s2 + 1) & 1][dt] = vcol_frag_a<SW_V>(Vs, 2 * s2 + 2, 2 * s2 + 3, dt, lane);
+      }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 vf = vcol_frag(Vs, 2 * s2, 2 * s2 + 1, dt, lane);
 #pragma unroll
-        for (int j = 0; j < TQ; ++j) o[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[j], o[j][dt], 0, 0, 0);
+        for (int j = 0; j < TQ; ++j)
+          o[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[AHEAD ? (s2 & 1) : 0][dt], pb[j], o[j][dt], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   float sq = 0.f;
   if (active) {
@@ -1021,9 +1082,14 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_map_kernel(MAttnF a) 
           rk = fmaf(p0, d0, rk); rk = fmaf(p1, d1, rk);
         }
       }
+      bf16x8 vfr[4];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vfr[dt] = vcol_frag_a<SW_V>(Vs, 2 * s2, 2 * s2 + 1, dt, lane);
+      TR_WAIT();
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Vs, 2 * s2, 2 * s2 + 1, dt, lane), pb, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[dt], pb, o[dt], 0, 0, 0);
     }
   }
   if (active && qok) {
@@ -1179,13 +1245,19 @@ struct MAttnB {
 // mask row of one (batch): Ms[k] = additive mask of key k (0 without one), -1e30 beyond Lk - as the forward kernel builds it
 __device__ __forceinline__ void stage_mask(const float* mask, int b, int Lk, int n, float* Ms) {
   for (int k = threadIdx.x; k < n; k += blockDim.x)
-    Ms[k] = (k < Lk) ? (mask ? mask[(size_t)b * Lk + k] : 0.f) : -1e30f;
+    Ms[k] = ((k < Lk) ? (mask ? mask[(size_t)b * Lk + k] : 0.f) : -1e30f) * LOG2E;      // (log2 domain: see recompute_p)
 }
 // the probabilities of this lane's query for the 8 keys of tile pair s (tiles 2s, 2s+1), recomputed exactly as the forward
 // kernel formed them: S^T = K Q^T (K tile read by rows), scaled + masked in the log2 domain, minus the saved row lse
-template <int SW>
+// (round 5: the backward kernels are VALU-bound on exactly this chain, so it is kept to mul-free form - the mask strip is
+// staged already multiplied by log2 e: the forward's `mk * LOG2E`, the same fp32 product, formed once per key instead of
+// once per (query, key); the causal clamp moves with it (min commutes with a multiplication by a positive constant, bit
+// for bit); rows beyond Lq get lse = +3e38, i.e. p = 2^(-inf) = 0, instead of a select per element; NOCAUSAL drops the
+// clamp's compare / min / select at compile time for the encoders, which never set the flag)
+template <int SW, bool NOCAUSAL = false>
 __device__ __forceinline__ void recompute_p(const char* Ks, const float* Ms, const bf16x8 (&qf)[2], int s, int g, int lane,
                                             float sc, float lse_q, bool qok, int causal, int q, float (&p)[8]) {
+  const float lq = qok ? lse_q : 3.0e38f;
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
     const int t = 2 * s + hh;
@@ -1197,8 +1269,8 @@ __device__ __forceinline__ void recompute_p(const char* Ks, const float* Ms, con
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float add = mk[r];
-      if (causal && tile_key0(t, g) + r > q) add = fminf(add, -10000.0f);
-      p[hh * 4 + r] = qok ? EXP2(fmaf(sa[r], sc, add * LOG2E) - lse_q) : 0.f;
+      if (!NOCAUSAL && causal && tile_key0(t, g) + r > q) add = fminf(add, -10000.0f * LOG2E);
+      p[hh * 4 + r] = EXP2(fmaf(sa[r], sc, add) - lq);
     }
   }
 }
@@ -1568,6 +1640,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
       stage_block<SW_K>(Vb, a.ldv, a.Lk, (blk + 1) * KB, KB, NW, nb);
       stage_block<SW_KV>(Kb, a.ldk, a.Lk, (blk + 1) * KB, KB, NW, nb + KB * 128);
     }
+
     if (!active) continue;
     const char* Vs = smem + (blk & 1) * 2 * KB * 128;
     const char* Ks = Vs + KB * 128;
@@ -1575,6 +1648,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
     for (int s2 = 0; s2 < KBT / 2; ++s2) {
       const int kcol = blk * KB + s2 * 32 + g * 8;
       const bool ok = qok && kcol < a.ldpr;
+      // (K^T fragments of this tile pair through asm reads, requested here and consumed behind the softmax-backward
+      // arithmetic below: the next block's DMA stays in flight through the whole block)
+      bf16x8 kfr[4];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) kfr[dt] = vcol_frag_a<SW_KV>(Ks, 2 * s2, 2 * s2 + 1, dt, lane);
+      __builtin_amdgcn_sched_barrier(0);
       float pr[8];
       recompute_p<SW_KV>(Ks, Ms + blk * KB, qf, s2, g, lane, sc, lse_q, qok, 0, 0, pr);
       bf16x8 d8, p8o;
@@ -1598,9 +1678,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
         *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
         if (a.Pw) *reinterpret_cast<bf16x8*>(a.Pw + prow + kcol) = p8o;
       }
+      TR_WAIT();
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag<SW_KV>(Ks, 2 * s2, 2 * s2 + 1, dt, lane), d8, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[dt], d8, o[dt], 0, 0, 0);
     }
   }
   if (a.dgate) {
@@ -1813,7 +1894,7 @@ __device__ __forceinline__ bf16x8 scol_frag(const char* tile, int ct, int lane) 
   return out;
 }
 
-template <int NT, int NW, bool RC>
+template <int NT, int NW, bool RC, bool NOCAUSAL = false>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
   constexpr int G = (NT + NW - 1) / NW, KC = NT / 2, QC = NT / 2;
   constexpr int KSW = RC ? SW_KV : SW_V;
@@ -1871,14 +1952,26 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
     f32x4 acc[NT];
     f32x4 pf[RC ? NT : 1];
     float dsum = 0.f;
+    // The 16-byte pieces of the teacher map / the external dP of tile pair s + 1 are requested BEFORE pair s is worked on
+    // (round 5): read where they are used, every pair was a bare round trip to memory inside a wave that shares its SIMD
+    // with one other wave - 7 pairs x 2 query tiles of exposed latency per workgroup.
+    auto piece = [&](const bf16* base, int s_) -> uint4 {
+      const int kc = s_ * 32 + g * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (base && qok && kc < a.ldpr) v = *reinterpret_cast<const uint4*>(base + prow + kc);
+      return v;
+    };
+    uint4 t_nx = piece(a.Pt, 0), e_nx = piece(a.E, 0);
 #pragma unroll
     for (int s = 0; s < NT / 2; ++s) {
       const int kcol = s * 32 + g * 8;
       const bool ok = qok && kcol < a.ldpr;
+      const uint4 t_cu = t_nx, e_cu = e_nx;
+      if (s + 1 < NT / 2) { t_nx = piece(a.Pt, s + 1); e_nx = piece(a.E, s + 1); }
       float pr[8], ex[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) { pr[r] = 0.f; ex[r] = 0.f; }
-      if (RC) recompute_p<KSW>(Ks, Ms, qf, s, g, lane, sc, lse_q, qok, a.causal, q, pr);
+      if (RC) recompute_p<KSW, NOCAUSAL>(Ks, Ms, qf, s, g, lane, sc, lse_q, qok, a.causal, q, pr);
       if (ok) {
         if (!RC) {
           const bf16x8 p8 = *reinterpret_cast<const bf16x8*>(a.P + prow + kcol);
@@ -1886,12 +1979,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
           for (int r = 0; r < 8; ++r) pr[r] = (float)p8[r];
         }
         if (a.E) {
-          const bf16x8 e8 = *reinterpret_cast<const bf16x8*>(a.E + prow + kcol);
+          const bf16x8 e8 = *reinterpret_cast<const bf16x8*>(&e_cu);
 #pragma unroll
           for (int r = 0; r < 8; ++r) ex[r] = (float)e8[r];
         }
         if (a.Pt) {
-          const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(a.Pt + prow + kcol);
+          const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(&t_cu);
 #pragma unroll
           for (int r = 0; r < 8; ++r) ex[r] = fmaf(kdc, pr[r] - (float)t8[r], ex[r]);
         }
@@ -2008,6 +2101,12 @@ static bool launch_bwd_fused(const MAttnB& f, hipStream_t stream) {
   const char* env = getenv("EVLM_ATTN_BWD_SPLIT");          // (debug / A-B switch: force kernels A + B)
   if ((env && atoi(env)) || f.kv_index || f.Lq > NT * 16 || f.Lk > NT * 16) return false;
   const size_t lds = (size_t)(NT / 2) * (NT / 2) * 2048 + (size_t)(NT <= 4 ? 4 : 2) * NT * 16 * 128 + (RC ? NT * 16 * sizeof(float) : 0);
+  if (RC && !f.causal) {                    // (the encoders: no causal clamp in the recomputation)
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<NT, NW, RC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<NT, NW, RC, true>), dim3(f.H, f.B), dim3(64 * NW), lds, stream, f);
+    return true;
+  }
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<NT, NW, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((attn_bwd_fused_kernel<NT, NW, RC>), dim3(f.H, f.B), dim3(64 * NW), lds, stream, f);
