@@ -108,6 +108,8 @@ SIGNATURES = {
     "evlm_l0_sample_fwd": [_vp, _vp, _i64, _f, _vp, _vp],
     "evlm_l0_sample_bwd": [_vp, _vp, _vp, _i64, _f, _vp, _vp],
     "evlm_l0_deterministic": [_vp, _i, _i, _f, _f, _vp, _vp],
+    "evlm_l0_lagrangian_fwd": [_vp, _i, _f, _f, _f, _f, _f, _f, _vp, _f, _vp, _vp, _vp, _vp],
+    "evlm_l0_lagrangian_bwd": [_vp, _vp, _i, _i64, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "evlm_dropout": [_i, _vp, _vp, _i64, _f, _vp, C.c_uint32, _vp, _vp],
     "evlm_dropout_mask": [_i64, _f, _vp, C.c_uint32, _vp, _vp],
     "evlm_layernorm_bwd_reduce_grouped": [_vp, _i, _i, _vp],

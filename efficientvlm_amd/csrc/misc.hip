@@ -407,6 +407,102 @@ extern "C" int evlm_l0_sample_bwd(const float* loga, const float* eps, const flo
   return 0;
 }
 
+// ---- the Lagrangian sparsity term in ONE launch each way (round 5) --------------------------------------------------------
+// xvlm_l0_module.py:get_num_parameters_and_constraint + lagrangian_regularization: per gate type t
+//   S_t = sum_i (1 - clamp(sigmoid(c - loga_t[i]), eps, 1 - eps)),  n = sum_t S_t * w_t  (type order),
+//   es = 1 - n / prunable,  ts = target sparsity (ramped by the step counter),  lag = l1 (es - ts) + l2 (es - ts)^2
+// As tensor expressions this is ~40 launches of a few microseconds forward and ~50 backward on the critical path of every
+// pruning step (six to eight gate tensors of 36 .. 18 432 elements).  table: int64 [ntypes][3] = {loga, n, f32 bits of w_t}.
+__global__ __launch_bounds__(1024) void l0_lagrangian_fwd_kernel(const int64_t* __restrict__ table, int ntypes, float c, float eps,
+                                                                 float prunable, float target_sp, float start_sp, float warmup,
+                                                                 const float* __restrict__ steps_dev, float steps_host,
+                                                                 const float* __restrict__ l1, const float* __restrict__ l2,
+                                                                 float* __restrict__ out) {
+  __shared__ float red[16];
+  __shared__ float S[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = 0; t < ntypes; ++t) {
+    const float* la = reinterpret_cast<const float*>(table[3 * t]);
+    const int64_t n = table[3 * t + 1];
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+      float s = 1.0f / (1.0f + expf(-(c - la[i])));
+      s = fminf(fmaxf(s, eps), 1.0f - eps);
+      acc += 1.0f - s;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float v = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += red[w];
+      S[t] = v;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float n = 0.f;
+    for (int t = 0; t < ntypes; ++t) {
+      const int32_t wb = (int32_t)table[3 * t + 2];
+      n = n + S[t] * __int_as_float(wb);
+    }
+    const float es = 1.0f - n / prunable;
+    float ts = target_sp;
+    if (warmup > 0.f) {
+      const float st = steps_dev ? steps_dev[0] : steps_host;
+      ts = (target_sp - start_sp) * fminf(st / warmup, 1.0f) + start_sp;
+    }
+    const float d = es - ts;
+    out[0] = l1[0] * d + l2[0] * (d * d);
+    out[1] = es;
+    out[2] = ts;
+  }
+}
+// dloga_t[i] += g (l1 + 2 l2 d) (-1 / prunable) w_t [eps <= s <= 1 - eps] s (1 - s);  dl1 += g d;  dl2 += g d^2
+// gtable: int64 [ntypes] = gradient buffers (accumulated)
+__global__ __launch_bounds__(256) void l0_lagrangian_bwd_kernel(const int64_t* __restrict__ table, const int64_t* __restrict__ gtable,
+                                                                float c, float eps, float prunable, const float* __restrict__ out_fwd,
+                                                                const float* __restrict__ l1, const float* __restrict__ l2,
+                                                                const float* __restrict__ gout, float* __restrict__ dl1,
+                                                                float* __restrict__ dl2) {
+  const int t = blockIdx.y;
+  const float* la = reinterpret_cast<const float*>(table[3 * t]);
+  float* dla = reinterpret_cast<float*>(gtable[t]);
+  const int64_t n = table[3 * t + 1];
+  const float w = __int_as_float((int32_t)table[3 * t + 2]);
+  const float g = gout[0], d = out_fwd[1] - out_fwd[2];
+  const float k = g * (l1[0] + 2.0f * l2[0] * d) * (-1.0f / prunable) * w;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float s = 1.0f / (1.0f + expf(-(c - la[i])));
+    if (s >= eps && s <= 1.0f - eps) dla[i] += k * (s * (1.0f - s));
+  }
+  if (t == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (dl1) dl1[0] += g * d;
+    if (dl2) dl2[0] += g * (d * d);
+  }
+}
+extern "C" int evlm_l0_lagrangian_fwd(const int64_t* table, int ntypes, float logit_c, float eps, float prunable, float target_sp,
+                                      float start_sp, float warmup, const float* steps_dev, float steps_host,
+                                      const float* lambda1, const float* lambda2, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(table && ntypes > 0 && ntypes <= 16 && lambda1 && lambda2 && out && prunable > 0.f, "evlm_l0_lagrangian_fwd: bad args");
+  hipLaunchKernelGGL(l0_lagrangian_fwd_kernel, dim3(1), dim3(1024), 0, stream, table, ntypes, logit_c, eps, prunable, target_sp,
+                     start_sp, warmup, steps_dev, steps_host, lambda1, lambda2, out);
+  EVLM_LAUNCH_CHECK("evlm_l0_lagrangian_fwd");
+  return 0;
+}
+extern "C" int evlm_l0_lagrangian_bwd(const int64_t* table, const int64_t* gtable, int ntypes, int64_t n_max, float logit_c, float eps,
+                                      float prunable, const float* out_fwd, const float* lambda1, const float* lambda2,
+                                      const float* gout, float* dlambda1, float* dlambda2, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(table && gtable && ntypes > 0 && ntypes <= 16 && n_max > 0 && out_fwd && lambda1 && lambda2 && gout,
+               "evlm_l0_lagrangian_bwd: bad args");
+  hipLaunchKernelGGL(l0_lagrangian_bwd_kernel, dim3(imin(64, (int)((n_max + 255) / 256)), ntypes), dim3(256), 0, stream, table, gtable,
+                     logit_c, eps, prunable, out_fwd, lambda1, lambda2, gout, dlambda1, dlambda2);
+  EVLM_LAUNCH_CHECK("evlm_l0_lagrangian_bwd");
+  return 0;
+}
+
 // eval masks: one block per layer row.  k = round_half_even(size - sum(1 - cdf_qz(0)));  the k smallest
 // sigmoid(loga/T*magic) by ascending (value, index) become 0, everything else 1.
 __global__ __launch_bounds__(256) void l0_det_kernel(const float* __restrict__ loga, int size, float temperature,

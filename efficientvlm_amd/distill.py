@@ -87,7 +87,7 @@ def kd_terms(S, T, temperature=1.0, with_cross_attn=False, fused=None, side=None
         for nm in ("itm_pos", "itm_neg"):
             k = nm + "_cross_attentions"
             names.append(nm + "_cross")
-            terms.append(_kd_pairs(sc[k], get_cor_teacher(tc[k], sc[k], True), is_attn=True))
+            terms.append(_kd_pairs(s_list(sc, k), get_cor_teacher(tc[k], sc[k], True), is_attn=True))
     if side is not None:
         # side = (stream, event recorded behind the student's fusion pass): the grouped MSE forward - and, since autograd
         # runs a node on its forward's stream, its backward - runs beside the task heads (MLM decoder product, the CEs)

@@ -359,6 +359,8 @@ class BertEncoder(nn.Module):
         else:
             raise ValueError(f"mode {mode} is not supported")
         merged = self._merged_cross_kv(range(start_layer, output_layer), encoder_hidden_states, encoder_batch_index)
+        # (the L0 gates as per-layer rows that carry their gradient slot: ops.GateGradSlot; indexing below is unchanged)
+        head_z, mlp_z = ops.gate_rows(head_z), ops.gate_rows(mlp_z)
         for i in range(start_layer, output_layer):
             layer_module = self.layer[i]
             if output_hidden_states:

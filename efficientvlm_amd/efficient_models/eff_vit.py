@@ -217,6 +217,8 @@ class CLIPEncoder(nn.Module):
 
     def forward(self, inputs_embeds, idx_to_group_img=None, image_atts=None, output_attentions=None,
                 output_hidden_states=None, head_z=None, head_layer_z=None, mlp_z=None):
+        # (the L0 gates as per-layer rows that carry their gradient slot: ops.GateGradSlot)
+        head_z, mlp_z = ops.gate_rows(head_z), ops.gate_rows(mlp_z)
         do_gather = idx_to_group_img is not None
         if do_gather and (image_atts is not None):                                     # :325-333
             full_atts = torch.ones(inputs_embeds.shape[:2], dtype=torch.float32, device=inputs_embeds.device)

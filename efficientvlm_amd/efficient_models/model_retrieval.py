@@ -36,8 +36,11 @@ class EffXVLMforRetrieval(XVLMBase):
             cross_attention_dict["itm_pos_cross_attentions"] = itm["pos_cross_attentions"]
             cross_attention_dict["itm_neg_cross_attentions"] = itm["neg_cross_attentions"]
             logits_dict["itm_head_logits"] = itm["logits"]
-            return {"loss": loss, "hidden_dict": hidden_dict, "attention_dict": attention_dict,
-                    "cross_attention_dict": cross_attention_dict, "logits_dict": logits_dict}
+            out = {"loss": loss, "hidden_dict": hidden_dict, "attention_dict": attention_dict,
+                   "cross_attention_dict": cross_attention_dict, "logits_dict": logits_dict}
+            if "batched" in itm:       # (extension: row ranges of the batched ITM pass for the distillation losses, xvlm.py)
+                out["batched"] = itm["batched"]
+            return out
         zs = self.l0_module.forward(training=False)
         image_embeds, image_atts = self.get_vision_embeds(image, head_z=zs["vision_head_z"], mlp_z=zs["vision_intermediate_z"])
         text_embeds = self.get_text_embeds(text_ids, text_atts, head_z=zs["text_head_z"], mlp_z=zs["text_intermediate_z"])

@@ -440,9 +440,17 @@ class XVLMBase(nn.Module):
             two(f.cross_attentions)
         output = mlp_head_forward(self.itm_head, f.last_hidden_state[:, 0, :])
         itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)])
+        # extension: the same lists as row ranges of the UN-split pass outputs (ops.RowSlice) - the distillation losses take
+        # these, so each batched tensor receives ONE gradient buffer instead of autograd concatenating a positive and a
+        # negative piece (the cross-attention maps of a 384 x 384 step are 80 MB each: six 54-us cats per step)
+        rs = lambda tup, r0, r1: [ops.RowSlice(x, r0, r1) if x is not None else None for x in tup]
+        batched = {"itm_pos_hidden_states": rs(f.hidden_states, 0, bs), "itm_neg_hidden_states": rs(f.hidden_states, bs, 3 * bs),
+                   "itm_pos_attentions": rs(f.attentions, 0, bs), "itm_neg_attentions": rs(f.attentions, bs, 3 * bs),
+                   "itm_pos_cross_attentions": rs(f.cross_attentions, 0, bs),
+                   "itm_neg_cross_attentions": rs(f.cross_attentions, bs, 3 * bs)}
         return {"loss": ops.cross_entropy(output, itm_labels), "pos_hidden_states": pos_hs, "neg_hidden_states": neg_hs,
                 "pos_attentions": pos_att, "neg_attentions": neg_att, "pos_cross_attentions": pos_catt,
-                "neg_cross_attentions": neg_catt, "logits": output}
+                "neg_cross_attentions": neg_catt, "logits": output, "batched": batched}
 
     def get_mlm_loss(self, text_ids_masked, text_atts, image_embeds, image_atts, masked_pos, masked_ids,
                      output_attentions=None, output_hidden_states=None, head_z=None, head_layer_z=None, mlp_z=None):

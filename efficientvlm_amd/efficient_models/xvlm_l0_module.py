@@ -155,7 +155,25 @@ class XVLML0Module(Module):
             return (self.target_sparsity - self.start_sparsity) * ramp + self.start_sparsity
         return (self.target_sparsity - self.start_sparsity) * min(1, pruned_steps / self.lagrangian_warmup) + self.start_sparsity
 
+    # extension: on the GPU the whole term - expected size over every gate type, ramped target, the two multiplier products -
+    # is ONE kernel launch each way (ops.l0_lagrangian) instead of ~90 launches of a few microseconds; the tensor expressions
+    # below remain for tensors that are not on the device.  EVLM_NO_FUSED_LAGRANGIAN=1: the expressions everywhere.
+    fused_lagrangian = True
+
+    def _lagrangian_types(self):
+        return ("vision_head", "text_head", "cross_head", "vision_intermediate", "text_intermediate", "cross_intermediate") \
+            + (("decoder_head", "decoder_intermediate") if self.with_decoder else ())
+
     def lagrangian_regularization(self, pruned_steps):
+        import os
+        if (self.fused_lagrangian and self.lambda_1.is_cuda and not os.environ.get("EVLM_NO_FUSED_LAGRANGIAN")
+                and all(t in self.z_logas for t in self._lagrangian_types())):
+            types = self._lagrangian_types()
+            xn = (0 - limit_a) / (limit_b - limit_a)
+            logit_c = (math.log(xn) - math.log(1 - xn)) * self.temperature
+            return ops.l0_lagrangian([self.z_logas[t] for t in types], [self.parameters_per_dim[t] for t in types], logit_c,
+                                     epsilon, self.prunable_model_size, self.target_sparsity, self.start_sparsity,
+                                     self.lagrangian_warmup, pruned_steps, self.lambda_1, self.lambda_2)
         target_sparsity = self.target_sparsity
         expected_size = self.get_num_parameters_and_constraint()
         expected_sparsity = 1 - expected_size / self.prunable_model_size

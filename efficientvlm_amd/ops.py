@@ -781,6 +781,7 @@ class _MLP(torch.autograd.Function):
         ctx.res_is_x = residual is x and N == K and not _NO_FORK
         ctx.meta = (M, K, Fh, N, ldp, act, gate_pos, x.shape, gate.shape if gate is not None else None,
                     residual is not None)
+        ctx.gate_slot = getattr(gate, "_evlm_gate_slot", None) if gate is not None else None
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -807,10 +808,11 @@ class _MLP(torch.autograd.Function):
         else:
             da = torch.empty((M, Fh), dtype=x2.dtype, device=dev)
             _gemm(dtype, d2, Q2, da, M, Fh, N, N, ld2, Fh, **q2)
-            dg = torch.zeros(Fh, dtype=torch.float32, device=dev)
+            gslot = ctx.gate_slot if (ctx.gate_slot is not None and ctx.gate_slot[0].row(ctx.gate_slot[1]).numel() == Fh) else None
+            dg = gslot[0].row(gslot[1]) if gslot is not None else torch.zeros(Fh, dtype=torch.float32, device=dev)
             L.check(lib.evlm_gated_act_bwd(dtype, L.ptr(da), L.ptr(h), L.ptr(g32), M, Fh, Fh, act, gate_pos, L.ptr(dh),
                                            L.ptr(dg), L.stream()), "gated_act_bwd")
-            dgate = dg.view(gshape)
+            dgate = gslot[0].take(gslot[1], gshape) if gslot is not None else dg.view(gshape)
         w1, b1, w2, b2 = ctx.params
         (dW2,), (db2,) = _wgrad(dtype, d2, N, a, Fh, M, Fh, (w2,), (N,), (b2,))
         dx = None
@@ -1085,6 +1087,7 @@ class _Attention(torch.autograd.Function):
         ctx.meta = (H, dh, q_off, k_off, v_off, scale, qbuf is kvbuf or qbuf.data_ptr() == kvbuf.data_ptr(),
                     gate.shape if gate is not None else None)
         ctx.causal = int(bool(causal))
+        ctx.gate_slot = getattr(gate, "_evlm_gate_slot", None) if gate is not None else None
         ctx.drop = drop
         ctx.kd_weight = float(kd_weight) if kd_teacher is not None else 0.0
         ctx.kv_grad = kv_grad
@@ -1139,7 +1142,10 @@ class _Attention(torch.autograd.Function):
                    and not env_on("EVLM_ATTN_NO_STREAM") and not env_on("EVLM_ATTN_STREAM_PWS"))
         P_ws = (torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev)
                 if (lse is not None and not single_pass and not streams) else None)
-        dgate = torch.zeros(H, dtype=torch.float32, device=dev) if g32 is not None else None
+        gslot = ctx.gate_slot if (g32 is not None and ctx.gate_slot is not None
+                                  and ctx.gate_slot[0].row(ctx.gate_slot[1]).numel() == H) else None
+        dgate = (gslot[0].row(gslot[1]) if gslot is not None
+                 else (torch.zeros(H, dtype=torch.float32, device=dev) if g32 is not None else None))
         a = L.AttnBwdArgs(dtype=L.dt(tdt), p_dtype=L.dt(tdt), B=B, H=H, Lq=Lq, Lk=Lk, dh=dh, Bkv=Bkv, ldq=ldq, ldk=ldk, ldv=ldk,
                           ldo=H * dh, lddq=ldq, lddk=ldk, lddv=ldk, ldpr=Lkp,
                           Q=C.c_void_p(qbuf.data_ptr() + q_off * es), K=C.c_void_p(kvbuf.data_ptr() + k_off * es),
@@ -1159,7 +1165,7 @@ class _Attention(torch.autograd.Function):
         L.check(_lib().evlm_attention_bwd(C.byref(a), L.stream()), "attention_bwd")
         if ATTN_FLOPS is not None:
             ATTN_FLOPS[0] += (10.0 if lse is not None else 8.0) * B * H * Lq * Lk * dh     # dP, dV, dQ, dK (+ S when P is recomputed)
-        dg = dgate.view(gshape) if dgate is not None else None
+        dg = (gslot[0].take(gslot[1], gshape) if gslot is not None else (dgate.view(gshape) if dgate is not None else None))
         if self_attn:
             return (dqbuf, None, None, dg) + (None,) * 14
         if slot is not None and not first:
@@ -1196,6 +1202,62 @@ def attention_recomputes(x, dh, Lk, dropout_p=0.0):
 def attention_kd_fusable(x, H, dh, Lk):
     """can the attention-map distillation of this problem run inside the attention kernels (bf16 MFMA path)?"""
     return x.is_cuda and x.dtype == torch.bfloat16 and dh == 64 and Lk <= 928
+
+
+class GateGradSlot:
+    """gradient buffer of ONE L0 gate tensor z [n, ...] (a row per gated layer: xvlm_l0_module.py zs['*_z']): zeroed, f32,
+    a slice of the step's zero arena.  Every consumer of row i - an attention or an FFN backward kernel - ACCUMULATES its
+    gate gradient into row i itself; the first consumer of a row hands the row to autograd, later ones hand back nothing
+    (the KVGradSlot protocol), and _GateFanout.backward returns the whole buffer.  Before: one zero-filled vector per
+    consumer, one zero-filled [n, ...] tensor + one add per row in autograd's SelectBackward - ~70 launches of a few
+    microseconds each on the critical path of a pruning step."""
+
+    def __init__(self, z):
+        self.buf = zeros_small(tuple(z.shape), torch.float32, z.device)
+        self.handed = set()
+
+    def row(self, i):
+        return self.buf[i].reshape(-1)
+
+    def take(self, i, shape):
+        if i in self.handed:
+            return None
+        self.handed.add(i)
+        return self.buf[i].view(shape)
+
+
+class _GateFanout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, slot):
+        ctx.slot = slot
+        return tuple(z[i] for i in range(z.shape[0]))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        slot = ctx.slot
+        buf = slot.buf
+        for i, g in enumerate(grads):          # a row whose consumer did not go through the slot (an op that knows nothing
+            if g is not None and g.data_ptr() != buf[i].data_ptr():      # of it): its gradient is added the ordinary way
+                buf[i].add_(g.reshape(buf[i].shape).to(buf.dtype))
+        slot.handed = set()
+        return buf, None
+
+
+def gate_rows(z):
+    """the rows of an L0 gate tensor z [n, ...] as a tuple the encoders index per layer (head_z[i], mlp_z[i]): each row
+    carries its GateGradSlot, so the kernels that consume it accumulate its gradient in place (see GateGradSlot).
+    Anything else - no gradient wanted, not a float32 CUDA tensor, EVLM_NO_GATE_SLOTS=1 - is returned unchanged."""
+    if (not torch.is_tensor(z) or not z.is_cuda or z.dtype != torch.float32 or z.dim() < 1
+            or not (torch.is_grad_enabled() and z.requires_grad) or _NO_GATE_SLOTS):
+        return z
+    slot = GateGradSlot(z)
+    rows = _GateFanout.apply(z, slot)
+    for i, r in enumerate(rows):
+        r._evlm_gate_slot = (slot, i)
+    return rows
+
+
+_NO_GATE_SLOTS = bool(os.environ.get("EVLM_NO_GATE_SLOTS"))
 
 
 class KVGradSlot:
@@ -2116,6 +2178,82 @@ class _L0Sample(torch.autograd.Function):
 
 def l0_sample(loga, eps, temperature):
     return _L0Sample.apply(loga, eps, float(temperature))
+
+
+_L0_TABLES = {}
+
+
+class _L0Lagrangian(torch.autograd.Function):
+    """(lagrangian, expected sparsity, target sparsity) of xvlm_l0_module.py:lagrangian_regularization in ONE launch
+    (evlm_l0_lagrangian_fwd) - and one more for every gradient (gate log-alphas, lambda_1, lambda_2), accumulated in place
+    where the parameters' gradients live in the optimiser's slabs."""
+
+    @staticmethod
+    def forward(ctx, cfg, lambda_1, lambda_2, steps, *logas):
+        weights, logit_c, eps, prunable, target_sp, start_sp, warmup = cfg
+        L.require_cuda(lambda_1, *logas)
+        dev = logas[0].device
+        if any(la.dtype != torch.float32 or not la.is_contiguous() for la in logas):
+            raise RuntimeError("l0_lagrangian: the gate log-alphas must be contiguous float32 tensors")
+        key = ("fwd",) + tuple((la.data_ptr(), la.numel(), float(w)) for la, w in zip(logas, weights))
+        table = _L0_TABLES.get(key)
+        if table is None:
+            rows = []
+            for la, w in zip(logas, weights):
+                rows += [la.data_ptr(), la.numel(), _f32_bits(w)]
+            if torch.cuda.is_current_stream_capturing():
+                table = _upload_table(rows, dev)              # (lives in the capture's table arena; not cached)
+            else:
+                table = _L0_TABLES[key] = torch.tensor(rows, dtype=torch.int64).to(dev)
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        steps_dev, steps_host = (steps.to(torch.float32).reshape(-1), 0.0) if torch.is_tensor(steps) else (None, float(steps))
+        L.check(_lib().evlm_l0_lagrangian_fwd(L.ptr(table), len(logas), float(logit_c), float(eps), float(prunable),
+                                              float(target_sp), float(start_sp), float(warmup), L.ptr(steps_dev), steps_host,
+                                              L.ptr(lambda_1.detach()), L.ptr(lambda_2.detach()), L.ptr(out), L.stream()),
+                "l0_lagrangian_fwd")
+        ctx.save_for_backward(out, table)
+        ctx.params = (lambda_1, lambda_2) + tuple(logas)
+        ctx.cfg = (float(logit_c), float(eps), float(prunable))
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g, _ges=None, _gts=None):
+        out, table = ctx.saved_tensors
+        lambda_1, lambda_2 = ctx.params[:2]
+        logas = ctx.params[2:]
+        n = len(logas) + 4
+        if g is None:
+            return (None,) * n
+        dev = out.device
+        gs = g.to(torch.float32).reshape(-1)
+        inplace = all(_inplace(p) for p in ctx.params)
+        if inplace:
+            grads = [p.grad for p in ctx.params]
+        else:
+            grads = [torch.zeros_like(p, dtype=torch.float32) for p in ctx.params]
+        key = ("bwd",) + tuple(t.data_ptr() for t in grads[2:])
+        gtable = _L0_TABLES.get(key) if inplace else None
+        if gtable is None:
+            rows = [t.data_ptr() for t in grads[2:]]
+            if torch.cuda.is_current_stream_capturing():
+                gtable = _upload_table(rows, dev)
+            else:
+                gtable = torch.tensor(rows, dtype=torch.int64).to(dev)
+                if inplace:
+                    _L0_TABLES[key] = gtable
+        logit_c, eps, prunable = ctx.cfg
+        L.check(_lib().evlm_l0_lagrangian_bwd(L.ptr(table), L.ptr(gtable), len(logas), max(la.numel() for la in logas), logit_c,
+                                              eps, prunable, L.ptr(out), L.ptr(lambda_1.detach()), L.ptr(lambda_2.detach()),
+                                              L.ptr(gs), L.ptr(grads[0]), L.ptr(grads[1]), L.stream()), "l0_lagrangian_bwd")
+        if inplace:
+            return (None,) * n
+        return (None, grads[0], grads[1], None) + tuple(grads[2:])
+
+
+def l0_lagrangian(logas, weights, logit_c, eps, prunable, target_sp, start_sp, warmup, steps, lambda_1, lambda_2):
+    cfg = (tuple(float(w) for w in weights), logit_c, eps, prunable, target_sp, start_sp, warmup)
+    return _L0Lagrangian.apply(cfg, lambda_1, lambda_2, steps, *logas)
 
 
 def l0_deterministic(loga, temperature, magical_number):

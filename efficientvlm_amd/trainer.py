@@ -1117,6 +1117,31 @@ class _CapturedStep:
     def _set_scheduled(self, flag):
         self.opt._scheduled = self.l0_opt._scheduled = self.lagrangian_opt._scheduled = flag
 
+    # The Lagrangian sparsity term depends on nothing but the gate parameters, so it could run on a side stream beside the
+    # student forward (EVLM_L0_STREAM=1; one GPU only: a branch may not straddle a segment cut).  MEASURED SLOWER and off: as
+    # ~90 small launches on a third stream of the captured step it cost +2.0 ms per ITR-384 step and +2.4 ms per VQA-480 step
+    # (profiles/r05_pruning_residue.md) - the graph's cross-stream hand-overs outweigh what the branch hides.  The term is
+    # now one kernel launch each way instead (ops.l0_lagrangian).
+    def _lagrangian_begin(self, pruned_steps):
+        l0 = self.student.l0_module
+        if self.reducer.active or not os.environ.get("EVLM_L0_STREAM") or not self._pruned_dev.is_cuda:
+            return None
+        if getattr(self, "_l0_stream", None) is None:
+            self._l0_stream = torch.cuda.Stream()
+        cur, ls = torch.cuda.current_stream(), self._l0_stream
+        ls.wait_stream(cur)
+        with torch.cuda.stream(ls):
+            lag = l0.lagrangian_regularization(pruned_steps)[0]
+        if not torch.cuda.is_current_stream_capturing():
+            lag.record_stream(cur)
+        return lag
+
+    def _lagrangian_end(self, lag, pruned_steps):
+        if lag is None:
+            return self.student.l0_module.lagrangian_regularization(pruned_steps)[0]
+        torch.cuda.current_stream().wait_stream(self._l0_stream)
+        return lag
+
     def _capture_one(self, body, cs):
         """single GPU: the whole step as one graph"""
         g = torch.cuda.CUDAGraph()
@@ -1353,6 +1378,7 @@ class ITRTrainer(_StagedExchange, _CapturedStep):
         self.opt.zero_grad()
         l0 = self.student.l0_module
         with compute(self.dtype):
+            lag = self._lagrangian_begin(pruned_steps)
             kw = dict(idx=idx, output_attentions=True, output_hidden_states=True)
             fused = {}
             if T_ready is not None:      # the teacher's maps exist: the image-map term is formed inside the attention kernels
@@ -1366,7 +1392,7 @@ class ITRTrainer(_StagedExchange, _CapturedStep):
                     lambda: self.teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw),
                     batch["image"], self.overlap_teacher)
             kd = distill.kd_terms(S, T, self.temperature, with_cross_attn=True, fused=fused)
-            lagrangian, _, _ = l0.lagrangian_regularization(pruned_steps)
+            lagrangian = self._lagrangian_end(lag, pruned_steps)
             total, mix = distill.itr_loss_mix(S["loss"], kd, lagrangian)
             ops.WGRAD_INPLACE = True
             ops.WGRAD_DEFER = [] if self.defer_wgrad else None
@@ -1471,6 +1497,7 @@ class VQATrainer(_StagedExchange, _CapturedStep):
         answer = NS(input_ids=batch["answer_ids"], attention_mask=batch["answer_atts"])
         kw = dict(train=True, k=batch["k"], weights=batch["weights"], output_attentions=True, output_hidden_states=True)
         with compute(self.dtype):
+            lag = self._lagrangian_begin(pruned_steps)
             fused = {}
             if T_ready is not None:
                 S, fused = distill.student_forward_fused_kd(
@@ -1482,7 +1509,7 @@ class VQATrainer(_StagedExchange, _CapturedStep):
                     lambda: self.student(batch["image"], question, answer, stop_prune=stop_prune, **kw),
                     lambda: self.teacher(batch["image"], question, answer, **kw), batch["image"], self.overlap_teacher)
             kd = distill.vqa_kd_terms(S, T, self.temperature, fused=fused)
-            lagrangian, _, _ = l0.lagrangian_regularization(pruned_steps)
+            lagrangian = self._lagrangian_end(lag, pruned_steps)
             total, mix = distill.vqa_loss_mix(S["loss"], kd, lagrangian)
             ops.WGRAD_INPLACE = True
             ops.WGRAD_DEFER = [] if self.defer_wgrad else None

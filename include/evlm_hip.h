@@ -389,6 +389,20 @@ int evlm_gated_act_bwd(int dtype, const void* da, const void* h, const float* ga
 int evlm_l0_sample_fwd(const float* loga, const float* eps, int64_t n, float temperature, float* z, void* stream);
 int evlm_l0_sample_bwd(const float* loga, const float* eps, const float* dz, int64_t n, float temperature,
                        float* dloga, void* stream);
+/* The Lagrangian sparsity term in one launch each way (ABI 7; xvlm_l0_module.py get_num_parameters_and_constraint :196-213 +
+ * lagrangian_regularization :215-235; Eff_Retrieval.py:160-163, Eff_VQA.py:160-163 add it to the loss):
+ *   expected size n = sum_t w_t * sum_i (1 - clamp(sigmoid(logit_c - loga_t[i]), eps, 1 - eps)),  es = 1 - n / prunable,
+ *   ts = warmup > 0 ? (target_sp - start_sp) * min(1, steps / warmup) + start_sp : target_sp   (steps = *steps_dev if given),
+ *   out[0] = lambda1 (es - ts) + lambda2 (es - ts)^2,  out[1] = es,  out[2] = ts.
+ * table: device int64 [ntypes][3] = {loga pointer, element count, bit pattern of the f32 weight w_t (parameters_per_dim)}.
+ * Backward ACCUMULATES into gtable[t] (device int64 [ntypes] of f32 gradient buffers) and dlambda1 / dlambda2 (may be NULL);
+ * gout = device scalar gradient of out[0]; n_max = largest element count in the table. */
+int evlm_l0_lagrangian_fwd(const int64_t* table, int ntypes, float logit_c, float eps, float prunable, float target_sp,
+                           float start_sp, float warmup, const float* steps_dev, float steps_host, const float* lambda1,
+                           const float* lambda2, float* out, void* stream);
+int evlm_l0_lagrangian_bwd(const int64_t* table, const int64_t* gtable, int ntypes, int64_t n_max, float logit_c, float eps,
+                           float prunable, const float* out_fwd, const float* lambda1, const float* lambda2, const float* gout,
+                           float* dlambda1, float* dlambda2, void* stream);
 /* eval masks (:253-271): per row of `size` gates, k = round(size - sum(1-cdf_qz(0))) smallest
  * sigmoid(loga/T*magic) are set to 0, the rest 1.  Selection order = ascending (value, index). */
 int evlm_l0_deterministic(const float* loga, int rows, int size, float temperature, float magical_number,

@@ -420,6 +420,62 @@ def test_l0_gates_match_reference_fixture(golden_dir):
         assert np.array_equal(ze.cpu().numpy(), refe), f"eval mask of {t} differs from the reference"
 
 
+def test_fused_lagrangian_term_matches_the_reference_vectors_and_the_oracles_gradient(golden_dir):
+    """evlm_l0_lagrangian_fwd / _bwd (round 5: the Lagrangian sparsity term of xvlm_l0_module.py in one launch each way)
+    against tests/golden/l0_full.npz - (lagrangian, expected sparsity, target sparsity) captured from the REFERENCE's module
+    at five points of the warm-up ramp, and its lambda gradients - and against the oracle's autograd for the gate
+    log-alphas; with the step counter as a host number and as a device scalar (the captured pruning steps), and with
+    gradients returned (plain tensors) as well as accumulated in place (parameters whose .grad is pre-allocated)"""
+    import os
+    from oracle import xvlm_oracle as Oo
+    o = ops()
+    fx = dict(np.load(os.path.join(golden_dir, "l0_full.npz")))
+    names = ["vision_head_loga", "text_head_loga", "cross_head_loga", "vision_int_loga", "text_int_loga", "cross_int_loga"]
+    consts = Oo.l0_constants(768, 3072, 12, 6, 3, 3)
+    weights = [consts["params_per_head"]] * 3 + [consts["params_per_int"]] * 3
+    xn = (0 - (-0.1)) / (1.1 - (-0.1))
+    logit_c = (math.log(xn) - math.log(1 - xn)) * (2.0 / 3.0)
+    mk = lambda: ([torch.from_numpy(fx["in." + n]).to(DEV).requires_grad_(True) for n in names],
+                  torch.from_numpy(fx["in.lambda_1"]).to(DEV).requires_grad_(True),
+                  torch.from_numpy(fx["in.lambda_2"]).to(DEV).requires_grad_(True))
+    logas, l1, l2 = mk()
+    for step, trip in zip(fx["lagrangian.steps"], fx["lagrangian.triples"]):
+        for st in (int(step), torch.tensor(float(step), device=DEV)):
+            lag, es, ts = o.l0_lagrangian(logas, weights, logit_c, 1e-6, consts["prunable"], 0.6, 0.0, 200, st, l1, l2)
+            np.testing.assert_allclose([float(lag), float(es), float(ts)], trip, rtol=1e-5, atol=1e-7)
+    # gradients at step 37: oracle autograd on the CPU (the same restatement the fixture pins)
+    cl = {n: torch.from_numpy(fx["in." + n]).clone().requires_grad_(True) for n in names}
+    c1 = torch.from_numpy(fx["in.lambda_1"]).clone().requires_grad_(True)
+    c2 = torch.from_numpy(fx["in.lambda_2"]).clone().requires_grad_(True)
+    lo, _, _ = Oo.l0_lagrangian(cl, c1, c2, consts, 37, target_sparsity=0.6, lagrangian_warmup=200)
+    (lo * 1.7).backward()
+    close_ = lambda a, b, what: np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=2e-5, atol=1e-9, err_msg=what)
+    # (a) gradients returned
+    logas, l1, l2 = mk()
+    lag, _, _ = o.l0_lagrangian(logas, weights, logit_c, 1e-6, consts["prunable"], 0.6, 0.0, 200, 37, l1, l2)
+    (lag * 1.7).backward()
+    for p, n in zip(logas, names):
+        close_(p.grad, cl[n].grad, n)
+    close_(l1.grad, c1.grad, "lambda_1"); close_(l2.grad, c2.grad, "lambda_2")
+    np.testing.assert_allclose(float(l1.grad) / 1.7, float(fx["grad.lambda_1"]), rtol=1e-5)
+    np.testing.assert_allclose(float(l2.grad) / 1.7, float(fx["grad.lambda_2"]), rtol=1e-5)
+    # (b) accumulated in place on top of what is already there (the trainers' flat gradient slabs)
+    logas, l1, l2 = mk()
+    for p in logas + [l1, l2]:
+        p.grad = torch.zeros_like(p)
+    o.WGRAD_INPLACE = True
+    try:
+        for _ in range(2):                       # two backward passes into the same buffers: twice the gradient
+            lag, _, _ = o.l0_lagrangian(logas, weights, logit_c, 1e-6, consts["prunable"], 0.6, 0.0, 200,
+                                        torch.tensor(37.0, device=DEV), l1, l2)
+            (lag * 1.7).backward()
+    finally:
+        o.WGRAD_INPLACE = False
+    for p, n in zip(logas, names):
+        close_(p.grad * 0.5, cl[n].grad, n + " (in place)")
+    close_(l1.grad * 0.5, c1.grad, "lambda_1 (in place)"); close_(l2.grad * 0.5, c2.grad, "lambda_2 (in place)")
+
+
 @pytest.mark.parametrize("pt,qt", [(0, 0), (0, 1), (1, 1)])
 def test_gemm_large_tiles_and_split_k(pt, qt):
     """shapes that select the 128x128 tile (>= 384 tiles), edge tiles in both dimensions, and the split-K weight-gradient

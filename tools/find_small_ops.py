@@ -13,7 +13,8 @@ geom = synth.GEOMS["full"]; dev = torch.device("cuda")
 KIND = next((a for a in sys.argv[1:] if a in ("gd", "itr", "vqa")), "gd")       # which step: GD (default), ITR-384, VQA-480
 if KIND == "gd":
     s, t = bench.build(geom, dev, 1234)
-    tr = GDTrainer(s, t, dtype=torch.bfloat16, use_graph=False)
+    # (teacher pipelined one batch ahead, as bench.py runs it: the fused distillation paths are armed; launched eagerly)
+    tr = GDTrainer(s, t, dtype=torch.bfloat16, use_graph=False, pipeline_teacher=True)
     batch = {k: v.to(dev) for k, v in synth.make_batch(geom, 64, seed=42).items()}
     step = lambda: tr.step(batch)
 else:
@@ -27,7 +28,8 @@ else:
         from efficientvlm_amd.models.model_retrieval import XVLM as TeacherITR
         s = EffXVLMforRetrieval(model_config(geom, "s", image_res=res)).to(dev)
         t = TeacherITR(model_config(geom, "t", image_res=res)).to(dev)
-        tr = ITRTrainer(s, t, lr=3e-5, weight_decay=0.01, lr_mult=2, reg_learning_rate=0.1, dtype=torch.bfloat16)
+        tr = ITRTrainer(s, t, lr=3e-5, weight_decay=0.01, lr_mult=2, reg_learning_rate=0.1, dtype=torch.bfloat16,
+                        pipeline_teacher=True, capture_step=False)
         batch = {k: v.to(dev) for k, v in synth.make_batch(geom, 16, seed=5).items()}
         idx = torch.arange(16, device=dev)
         step = lambda: tr.step(batch, idx=idx)
@@ -36,11 +38,12 @@ else:
         from efficientvlm_amd.models.model_generation import XVLMForVQA
         cfg = lambda role, nd: dict(model_config(geom, role, image_res=res), pad_token_id=0, num_dec_layers=nd)
         s = EffXVLMForVQA(cfg("s", 3)).to(dev); t = XVLMForVQA(cfg("t", 6)).to(dev)
-        tr = VQATrainer(s, t, lr=5e-5, weight_decay=0.01, lr_mult=2, reg_learning_rate=0.1, dtype=torch.bfloat16)
+        tr = VQATrainer(s, t, lr=5e-5, weight_decay=0.01, lr_mult=2, reg_learning_rate=0.1, dtype=torch.bfloat16,
+                        pipeline_teacher=True, capture_step=False)
         batch = {k: v.to(dev) for k, v in synth.make_vqa_batch(geom, 8, seed=5, La=8).items()}
         step = lambda: tr.step(batch)
     s.l0_module.set_lagrangian_warmup_steps(100)
-for _ in range(2): step()
+for _ in range(3): step()
 torch.cuda.synchronize()
 agg = collections.Counter()
 WANT = None
