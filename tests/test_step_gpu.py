@@ -1656,8 +1656,14 @@ def test_full_width_bf16_captured_pruning_steps_follow_the_eager_trajectory(kind
             teacher = TeacherITR(model_config(geom, "t", image_res=res)).to(DEV)
             tr = ITRTrainer(student, teacher, lr=3e-5, weight_decay=0.01, lr_mult=2, reg_learning_rate=0.1, dtype=torch.bfloat16,
                             pipeline_teacher=True, capture_step=cap)
-            batch = {k: v.to(DEV) for k, v in synth.make_batch(geom, 4, seed=5).items()}
+            batch = synth.make_batch(geom, 4, seed=5)
+            batch["image"] = tint_images(batch["image"], 77)      # (samples with distinct features: see tint_images)
+            batch = {k: v.to(DEV) for k, v in batch.items()}
             idx = torch.arange(4, device=DEV)
+            # (the same hard negatives in both runs - every forward, captured ones included: the device draw's position in
+            # its random stream differs between an eager and a replayed run, which left the ITM term comparable at 20 % only)
+            student.injected_neg_idx = teacher.injected_neg_idx = torch.tensor([1, 2, 3, 0, 2, 3, 0, 1])
+            student.keep_injected_neg = teacher.keep_injected_neg = True
             step = lambda: tr.step(batch, idx=idx)
         else:
             from efficientvlm_amd.efficient_models.model_generation import EffXVLMForVQA
@@ -1685,16 +1691,12 @@ def test_full_width_bf16_captured_pruning_steps_follow_the_eager_trajectory(kind
     assert len(seqs[True]) == 10 and torch.isfinite(seqs[True]).all() and all(math.isfinite(n) for n in norms[True])
     assert float(seqs[False][-1, 0]) < float(seqs[False][0, 0])                       # (the steps train)
     assert torch.allclose(seqs[True][:, 0], seqs[False][:, 0], rtol=2e-2), (seqs[True][:, 0], seqs[False][:, 0])
-    # per term; the ITM term of the 4-pair ITR batch loosely (its 8 hard negatives are drawn from the device random stream,
-    # whose position differs between the two runs: different negatives, the same distribution - 20 % there)
+    # per term, the ITM term included (hard negatives injected: the same in both runs)
     tol = torch.full((seqs[True].shape[1],), 4e-2)
-    if kind == "itr384":
-        tol[2] = 2e-1
     assert bool(((seqs[True] - seqs[False]).abs() <= 2e-3 + tol * seqs[False].abs()).all()), (seqs[True], seqs[False])
-    # (the last step's gradient norms: same order of magnitude only - at random init on white-noise images the ITC part of
-    # the gradient is bf16 noise of near-identical CLS rows, 30 % from run to run: see the ITR gradient parity test)
+    # the last step's gradient norms per optimiser group, within 10 % (round 4: a factor of two)
     for a, b in zip(norms[True], norms[False]):
-        assert 0.5 * b <= a <= 2.0 * b, (norms[True], norms[False])
+        assert 0.9 * b <= a <= 1.1 * b, (norms[True], norms[False])
 
 
 @pytest.mark.parametrize("use_graph", [False, True, "step"])
@@ -1765,7 +1767,7 @@ def test_itr_trainer_with_pipelined_teacher_reproduces_the_unpipelined_trajector
 # the ITC logits' 1 / temp = 14 (vision_proj, text_proj) and behind all six ViT layers (class / position embeddings) at
 # batch 8 / 3, where nothing averages the bf16 noise of the residual stream
 ITR_WORST_TENSOR = 0.25
-VQA_WORST_TENSOR = 0.25
+VQA_WORST_TENSOR = 0.05      # (measured: every tensor <= 2.0 % at B = 3; round 4 admitted 25 %)
 
 
 def tint_images(image, seed):
@@ -1817,9 +1819,10 @@ def test_itr_384_step_full_width_bf16_tracks_the_fp32_oracle(pipelined, B, scene
         batch["image"] = tint_images(batch["image"], 77)
     idx = torch.arange(B)
     idx[2] = idx[1]
-    with_grads = B == 8                           # gradient-level parity at the small batch (lr 0: the step leaves the
-    tr = ITRTrainer(student, teacher, lr=0.0 if with_grads else 3e-5, reg_learning_rate=0.0 if with_grads else 0.05,
-                    dtype=torch.bfloat16, pipeline_teacher=pipelined)          # parameters where the oracle has them)
+    # gradient-level parity at EVERY batch (round 5: also at B = 64, the per-GPU shard configs[2] is quoted on - the oracle's
+    # fp32 backward of that batch is a few minutes of host time; lr 0: the step leaves the parameters where the oracle has them)
+    with_grads = True
+    tr = ITRTrainer(student, teacher, lr=0.0, reg_learning_rate=0.0, dtype=torch.bfloat16, pipeline_teacher=pipelined)
     eps = {t: torch.rand(s_sd["l0_module." + O.L0_PARAM[t]].shape, generator=gen).clamp(1e-6, 1 - 1e-6) for t in O.L0_TYPES}
     s_neg = torch.tensor([(i + 3) % B for i in range(2 * B)])
     t_neg = torch.tensor([(i + 5) % B for i in range(2 * B)])
@@ -1870,7 +1873,9 @@ def test_itr_384_step_full_width_bf16_tracks_the_fp32_oracle(pipelined, B, scene
             # attention backward; everything else stays within the GD bounds
             itc = [r for r, _, n in st["stats"] if n.startswith(ITC_PATH)]
             rest = [r for r, _, n in st["stats"] if not n.startswith(ITC_PATH)]
-            assert max(itc) < 0.32 and max(rest) < 0.15, st["stats"][:8]
+            # (measured, round 5: 29.1 - 29.5 % / 12.6 - 13.4 % at B = 8 - round 4 admitted 32 % / 15 % -, 26.1 % / 9.0 % at B = 64)
+            lim_itc, lim_rest = (0.31, 0.145) if B == 8 else (0.29, 0.11)
+            assert max(itc) < lim_itc and max(rest) < lim_rest, st["stats"][:8]
 
 
 @pytest.mark.parametrize("pipelined,B", [(False, 3), (True, 3), (True, 32)])
@@ -1890,9 +1895,8 @@ def test_vqa_480_step_full_width_bf16_tracks_the_fp32_oracle(pipelined, B):
     student.to(DEV); teacher.to(DEV)
     batch = synth.make_vqa_batch(geom, B, seed=23)
     batch["image"] = torch.randn(B, 3, 480, 480, generator=gen)
-    with_grads = B == 3                           # gradient-level parity at the small batch (lr 0: parameters stay put)
-    tr = VQATrainer(student, teacher, lr=0.0 if with_grads else 5e-5, reg_learning_rate=0.0 if with_grads else 0.05,
-                    dtype=torch.bfloat16, pipeline_teacher=pipelined)
+    with_grads = True                             # gradient-level parity at B = 3 AND at the quoted shard B = 32 (lr 0)
+    tr = VQATrainer(student, teacher, lr=0.0, reg_learning_rate=0.0, dtype=torch.bfloat16, pipeline_teacher=pipelined)
     eps = {t: torch.rand(s_sd["l0_module." + O.L0_PARAM[t]].shape, generator=gen).clamp(1e-6, 1 - 1e-6) for t in O.L0_TYPES_VQA}
     student.l0_module.injected_eps = {t: e.clone() for t, e in eps.items()}
     dev_batch = {k: v.to(DEV) for k, v in batch.items()}
