@@ -861,7 +861,11 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
     // 55 % (tools/gemm_pp256.py), but the step keeps two streams busy (student + pipelined teacher), so CUs a launch
     // leaves free are taken by the other stream's kernels and the per-tile efficiency decides (measured: +1.3 % step)
     static const int pp_pct = getenv("EVLM_PP256_PCT") ? atoi(getenv("EVLM_PP256_PCT")) : 30;   // tuning aid; > 100 disables
-    if (evlm_gemm_w4_eligible(g, pt, qt)) {            // one-wave-per-SIMD 256 x 256 kernel (gemm_w4.hip; opt-in: EVLM_W4=1)
+#ifdef EVLM_EXPERIMENTAL_W4
+    // (build option, `make EXPERIMENTAL=1`: the one-wave-per-SIMD 256 x 256 kernel of round 4 - gemm_w4.hip, then opt-in through
+    // EVLM_W4=1.  Measured 8-35 % slower than the ping-pong flavours on every shape of the step (profiles/r04_w4_kloop.md),
+    // so it is NOT part of the default library: no routing rule would pick it.)
+    if (evlm_gemm_w4_eligible(g, pt, qt)) {
       const int w4rows = evlm_gemm_w4_launch(g, qt, stream);
       if (w4rows < 0) return -1;
       g_last_kernel = w4rows == 192 ? (qt ? "gemm_bf16_w4_kernel<true,6>" : "gemm_bf16_w4_kernel<false,6>")
@@ -869,6 +873,7 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
       EVLM_LAUNCH_CHECK("evlm_gemm");
       return 0;
     }
+#endif
     if (evlm_gemm_pp128_eligible(g, pt, qt) && !evlm_gemm_pp256_streamk(g, pt)) {   // 128 x 256 tiles: thinly filled launches
       if (evlm_gemm_pp128_launch(g, qt, stream)) return -1;
       g_last_kernel = qt ? "gemm_bf16_pp128_kernel<true>" : "gemm_bf16_pp128_kernel<false>";

@@ -1631,7 +1631,11 @@ def test_one_wave_per_simd_gemm_kernel_passes_the_race_screen():
     read once per process"""
     import subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, EVLM_W4="1")
+    # (round 5: the kernel is out of the default library - `make -C efficientvlm_amd/csrc EXPERIMENTAL=1 LIB=...` builds it)
+    exp = os.path.join(repo, "tools", "_build", "libevlm_exp.so")
+    if not os.path.exists(exp):
+        pytest.skip("experimental library (gemm_w4.hip) not built")
+    env = dict(os.environ, EVLM_W4="1", EVLM_LIB=exp)
     r = subprocess.run([sys.executable, os.path.join(repo, "tools", "gemm_pp256_race_screen.py"), "2"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "race screen: CLEAN" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
