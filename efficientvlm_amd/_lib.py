@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVLM_LIB", os.path.join(_HERE, "libevlm_hip.so"))
 
-ABI_VERSION = 7      # evlm_abi_version() of the library this binding was written against (struct layouts, entry points)
+ABI_VERSION = 8      # evlm_abi_version() of the library this binding was written against (struct layouts, entry points)
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2
 GATE_PRE, GATE_POST = 0, 1
@@ -42,7 +42,8 @@ class AttnFwdArgs(C.Structure):
                 ("scale", _f), ("O", _vp), ("P", _vp), ("causal", _i),
                 ("dropout_p", _f), ("rng_state", _vp), ("call_id", C.c_uint32),
                 ("kd_teacher", _vp), ("kd_loss", _vp), ("kd_weight", _f), ("lse", _vp), ("Bkv", _i),
-                ("kd_rowdot", _vp)]
+                ("kd_rowdot", _vp),
+                ("kd_tq", _vp), ("kd_tk", _vp), ("kd_tld", _i), ("kd_tlse", _vp)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -55,7 +56,8 @@ class AttnBwdArgs(C.Structure):
                 ("dS", _vp), ("dQ", _vp), ("dK", _vp), ("dV", _vp), ("dgate", _vp),
                 ("dropout_p", _f), ("rng_state", _vp), ("call_id", C.c_uint32),
                 ("kd_teacher", _vp), ("kd_gout", _vp), ("kd_weight", _f),
-                ("lse", _vp), ("mask", _vp), ("causal", _i), ("P_ws", _vp), ("O", _vp), ("kd_rowdot", _vp)]
+                ("lse", _vp), ("mask", _vp), ("causal", _i), ("P_ws", _vp), ("O", _vp), ("kd_rowdot", _vp),
+                ("kd_tq", _vp), ("kd_tk", _vp), ("kd_tld", _i), ("kd_tlse", _vp)]
 
 
 class XAttnFusedArgs(C.Structure):

@@ -18,6 +18,9 @@ struct MAttnF {
   float* lse;                                    // [B, H, Lq] log2-sum-exp of the scaled, masked scores (recomputing backward)
   float* rkd;                                    // [B, H, Lq] sum_k P (P - Pt) of the fused distillation (one-pass long backward)
   int skip_dead;                                 // heads with a gate of exactly 0: zero context, nothing staged (A/B switch)
+  // ABI 8: the teacher's map REBUILT in the kernel instead of read (streaming kernels): its projected queries / keys
+  // ([B, L, H, dh] bf16 inside its packed QKV buffer, row stride tld) and its row lse [B, H, L]
+  const bf16* Tq; const bf16* Tk; int tld; const float* tlse;
 };
 
 #define DH 64
@@ -722,12 +725,18 @@ __device__ __forceinline__ void stage_block(const bf16* base, int ld, int L, int
   }
 }
 
-template <int NW, bool LSE, int TQ>
+// KDR (round 5, ABI 8): the fused map distillation against a teacher map that is NOT in memory - the frozen teacher kept
+// its projected queries / keys and its row lse (113 MB + 1.8 MB per ViT layer at 577 tokens) instead of writing a 517 MB
+// bf16 map that this kernel and the backward would each read once.  The teacher's K block streams through LDS beside the
+// student's (a third 16 KiB tile per buffer), its scores are rebuilt per key tile - 2 MFMAs, 4 exponentials per lane - and
+// consumed at once by the running sums of the term: p_t = 2^(s_t log2e - lse_t) in fp32, not a bf16-rounded stored value.
+template <int NW, bool LSE, int TQ, bool KDR = false>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
   constexpr int KBT = 8, KB = KBT * 16;                  // 128 keys per block
+  constexpr int BUF = (KDR ? 3 : 2) * KB * 128;          // one staging buffer: K | V [| teacher K]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nblk = (a.Lk + KB - 1) / KB;
-  float* Ms = reinterpret_cast<float*>(smem + 4 * KB * 128);     // [nblk * KB] additive mask (+ -1e30 beyond Lk)
+  float* Ms = reinterpret_cast<float*>(smem + 2 * BUF);          // [nblk * KB] additive mask (+ -1e30 beyond Lk)
   float* kdw = Ms + nblk * KB;
   // XCD-aware map: hardware workgroup id i runs on XCD i % 8; logical ids (i % 8) * (n / 8) + i / 8 are then consecutive
   // per XCD, and the gridDim.x query blocks of one (batch, head) - consecutive logical ids - share an L2
@@ -771,8 +780,24 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
     }
   stage_block<SW_K>(Kb, a.ldk, a.Lk, 0, KB, NW, smem);
   stage_block<SW_V>(Vb, a.ldv, a.Lk, 0, KB, NW, smem + KB * 128);
+  const bf16* Tkb = KDR ? a.Tk + (size_t)b * a.Lk * a.tld + h * DH : nullptr;
+  bf16x8 qt[KDR ? TQ : 1][2];
+  float tl[KDR ? TQ : 1];
+  if (KDR) {
+    stage_block<SW_K>(Tkb, a.tld, a.Lk, 0, KB, NW, smem + 2 * KB * 128);
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+      tl[j] = qok[j] ? a.tlse[((size_t)b * a.H + h) * a.Lq + q[j]] : 3.0e38f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (qok[j]) v = *reinterpret_cast<const uint4*>(a.Tq + ((size_t)b * a.Lq + q[j]) * a.tld + h * DH + ks * 32 + g * 8);
+        qt[j][ks] = *reinterpret_cast<bf16x8*>(&v);
+      }
+    }
+  }
   const float sc = a.scale * 1.44269504088896341f;
-  const bool kd_any = LSE && a.Pt != nullptr;
+  const bool kd_any = LSE && (KDR || a.Pt != nullptr);
   float m[TQ], l[TQ], se2[TQ], sep[TQ], spt[TQ];
   f32x4 o[TQ][4];
 #pragma unroll
@@ -786,8 +811,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
     __syncthreads();                                     // block blk has landed; everyone is done with the other buffer
     // the teacher map's piece for this block is requested BEFORE the next block's DMA: vmcnt counts in order, a wait for
     // a load issued behind the DMA would drain the DMA with it
-    bf16x8 t8[TQ][KBT / 2];
-    if (kd_any) {
+    bf16x8 t8[KDR ? 1 : TQ][KBT / 2];
+    if (!KDR && kd_any) {
 #pragma unroll
       for (int j = 0; j < TQ; ++j)
 #pragma unroll
@@ -799,13 +824,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
         }
     }
     if (blk + 1 < nblk) {
-      char* nb = smem + ((blk + 1) & 1) * 2 * KB * 128;
+      char* nb = smem + ((blk + 1) & 1) * BUF;
       stage_block<SW_K>(Kb, a.ldk, a.Lk, (blk + 1) * KB, KB, NW, nb);
       stage_block<SW_V>(Vb, a.ldv, a.Lk, (blk + 1) * KB, KB, NW, nb + KB * 128);
+      if (KDR) stage_block<SW_K>(Tkb, a.tld, a.Lk, (blk + 1) * KB, KB, NW, nb + 2 * KB * 128);
     }
     if (!active) continue;                               // (wave-uniform)
-    const char* Ks = smem + (blk & 1) * 2 * KB * 128;
+    const char* Ks = smem + (blk & 1) * BUF;
     const char* Vs = Ks + KB * 128;
+    const char* Kts = Ks + 2 * KB * 128;
     f32x4 acc[TQ][KBT];
 #pragma unroll
     for (int t = 0; t < KBT; ++t) {
@@ -854,7 +881,28 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
           acc[j][t][r] = EXP2(acc[j][t][r] - mn);
           l[j] += acc[j][t][r];                          // (this lane's keys; the lane groups meet after the last block)
         }
-      if (kd_any && qok[j]) {
+      if (KDR) {                       // (wave-uniform: the MFMAs run for every lane; rows beyond Lq carry lse = +3e38 -> p_t = 0)
+        se2[j] *= alpha[j] * alpha[j];
+        sep[j] *= alpha[j];
+#pragma unroll
+        for (int t = 0; t < KBT; ++t) {
+          f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Kts, t, ks, lane), qt[j][ks], sa, 0, 0, 0);
+          const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + blk * KB + tile_key0(t, g));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = acc[j][t][r];
+            const float pt = EXP2(fmaf(sa[r], sc, mk[r] * LOG2E) - tl[j]);
+            se2[j] = fmaf(e, e, se2[j]);
+            sep[j] = fmaf(e, pt, sep[j]);
+            spt[j] = fmaf(pt, pt, spt[j]);
+          }
+          // (two query tiles per wave sit at the register limit: keep one tile's teacher scores alive at a time)
+          if (TQ == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if (kd_any && qok[j]) {
         se2[j] *= alpha[j] * alpha[j];
         sep[j] *= alpha[j];
 #pragma unroll
@@ -872,7 +920,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
     // O^T += V^T E^T with the un-normalised e (<= 1) as bf16: the row's 1 / l is applied once, to the context
     // (asm fragment reads, one tile pair ahead of the MFMAs that consume them: the next block's DMA stays in flight)
     // (16 waves per workgroup run at 128 VGPRs: no room for the second fragment set - read, wait, multiply there)
-    constexpr bool AHEAD = NW <= 8;
+    constexpr bool AHEAD = NW <= 8 && !(KDR && TQ == 2);
     bf16x8 vfr[AHEAD ? 2 : 1][4];
     __builtin_amdgcn_sched_barrier(0);
     if (AHEAD) {
@@ -1153,6 +1201,19 @@ static bool launch_fwd_stream(const MAttnF& f, hipStream_t stream) {
   // measured (tools/attn_long_bench.py, TQ = 1 -> 2): with lse 190 -> 158 us (577 keys) / 227 -> 162 (901), with lse + fused
   // distillation 289 -> 264 / 359 -> 289, no-grad 155 -> 166 / 177 -> 158; two text query tiles on image tokens 62 -> 111
   const int tq = tq_env == 1 || tq_env == 2 ? tq_env : ((qtiles > 8 && (f.lse || qtiles > 40)) ? 2 : 1);
+  if (f.Tq) {                                            // the teacher's map rebuilt in the kernel (KDR): a third tile per buffer
+    const size_t ldsr = (size_t)6 * KB * 128 + (size_t)nblk * KB * sizeof(float) + 16;
+#define STREAM_KDR_LAUNCH(TQ_)                                                                                           \
+  do {                                                                                                                   \
+    (void)hipFuncSetAttribute((const void*)attn_fwd_stream_kernel<8, true, TQ_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)ldsr);                                                                                \
+    dim3 grid((qtiles + 8 * TQ_ - 1) / (8 * TQ_), f.H, f.B), block(512);                                                \
+    hipLaunchKernelGGL((attn_fwd_stream_kernel<8, true, TQ_, true>), grid, block, ldsr, stream, f);                      \
+  } while (0)
+    if (tq == 2) STREAM_KDR_LAUNCH(2); else STREAM_KDR_LAUNCH(1);
+#undef STREAM_KDR_LAUNCH
+    return true;
+  }
   if (f.lse) {
     if (nw == 16) STREAM_LAUNCH(16, true, 1); else if (tq == 2) STREAM_LAUNCH(8, true, 2); else STREAM_LAUNCH(8, true, 1);
   } else {
@@ -1240,6 +1301,8 @@ struct MAttnB {
   // one-pass form of the long-sequence kernel: delta = rowsum(P .* dP) = dO . O + kd_coef * g * rkd (O: the forward's
   // output, gate included; rkd: the forward's sum_k P (P - Pt)), so no first pass over the keys is needed for it
   const bf16* O; const float* rkd;
+  // ABI 8: the teacher's map rebuilt in the kernel (see MAttnF)
+  const bf16* Tq; const bf16* Tk; int tld; const float* tlse;
 };
 
 // mask row of one (batch): Ms[k] = additive mask of key k (0 without one), -1e30 beyond Lk - as the forward kernel builds it
@@ -1573,12 +1636,15 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
 // attn_fwd_stream_kernel): K and V pass through LDS in double-buffered blocks of 128 keys (64 KiB instead of the 80 KiB
 // key half staged behind two barriers with nothing in flight), the teacher map's piece of a block is requested before the
 // next block's DMA, workgroups of one (batch, head) share an XCD.  Arithmetic per tile pair as above.
-template <int NW>
+// KDR: the teacher's probabilities rebuilt from its Q, K and row lse (see attn_fwd_stream_kernel) - its K block streams
+// through a third LDS tile per buffer, recompute_p forms p_t exactly as it forms the student's p.
+template <int NW, bool KDR = false>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
   constexpr int KBT = 8, KB = KBT * 16;
+  constexpr int BUF = (KDR ? 3 : 2) * KB * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nblk = (a.Lk + KB - 1) / KB;
-  float* Ms = reinterpret_cast<float*>(smem + 4 * KB * 128);
+  float* Ms = reinterpret_cast<float*>(smem + 2 * BUF);
   const int gx = gridDim.x, nwg = gx * gridDim.y * gridDim.z;
   int lid = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
   if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
@@ -1610,18 +1676,31 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
   d += __shfl_xor(d, 16, 64); d += __shfl_xor(d, 32, 64);
   const size_t prow = (((size_t)b * a.H + h) * a.Lq + (qok ? q : 0)) * a.ldpr;
   const float gz = a.gate ? a.gate[h] : 1.0f;
-  const float kdc = a.Pt ? a.kd_coef * a.kd_gout[0] : 0.f;
+  const float kdc = (KDR || a.Pt) ? a.kd_coef * a.kd_gout[0] : 0.f;
   const float sc = a.scale * LOG2E;
   const float lse_q = qok ? a.lse[((size_t)b * a.H + h) * a.Lq + q] : 0.f;
   // delta = sum_k p (gz dpo + kdc (p - pt)) = dO . O + kdc * rkd   (see attn_bwd_dq_long_kernel)
-  const float dsum = (a.Pt && qok) ? fmaf(kdc, a.rkd[((size_t)b * a.H + h) * a.Lq + q], d) : d;
-  const bool kd_on = a.Pt != nullptr && qok;
+  const float dsum = ((KDR || a.Pt) && qok) ? fmaf(kdc, a.rkd[((size_t)b * a.H + h) * a.Lq + q], d) : d;
+  const bool kd_on = !KDR && a.Pt != nullptr && qok;
+  const bf16* Tkb = KDR ? a.Tk + (size_t)b * a.Lk * a.tld + h * DH : nullptr;
+  bf16x8 qt[2];
+  float tl = 0.f;
+  if (KDR) {
+    tl = qok ? a.tlse[((size_t)b * a.H + h) * a.Lq + q] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qok) v = *reinterpret_cast<const uint4*>(a.Tq + ((size_t)b * a.Lq + q) * a.tld + h * DH + ks * 32 + g * 8);
+      qt[ks] = *reinterpret_cast<bf16x8*>(&v);
+    }
+  }
   float gsum = 0.f;
   f32x4 o[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   stage_block<SW_K>(Vb, a.ldv, a.Lk, 0, KB, NW, smem);
   stage_block<SW_KV>(Kb, a.ldk, a.Lk, 0, KB, NW, smem + KB * 128);
+  if (KDR) stage_block<SW_K>(Tkb, a.tld, a.Lk, 0, KB, NW, smem + 2 * KB * 128);
   for (int blk = 0; blk < nblk; ++blk) {
     stage_wait();
     __syncthreads();
@@ -1636,14 +1715,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
       }
     }
     if (blk + 1 < nblk) {
-      char* nb = smem + ((blk + 1) & 1) * 2 * KB * 128;
+      char* nb = smem + ((blk + 1) & 1) * BUF;
       stage_block<SW_K>(Vb, a.ldv, a.Lk, (blk + 1) * KB, KB, NW, nb);
       stage_block<SW_KV>(Kb, a.ldk, a.Lk, (blk + 1) * KB, KB, NW, nb + KB * 128);
+      if (KDR) stage_block<SW_K>(Tkb, a.tld, a.Lk, (blk + 1) * KB, KB, NW, nb + 2 * KB * 128);
     }
 
     if (!active) continue;
-    const char* Vs = smem + (blk & 1) * 2 * KB * 128;
+    const char* Vs = smem + (blk & 1) * BUF;
     const char* Ks = Vs + KB * 128;
+    const char* Kts = Vs + 2 * KB * 128;
 #pragma unroll
     for (int s2 = 0; s2 < KBT / 2; ++s2) {
       const int kcol = blk * KB + s2 * 32 + g * 8;
@@ -1655,8 +1736,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) kfr[dt] = vcol_frag_a<SW_KV>(Ks, 2 * s2, 2 * s2 + 1, dt, lane);
       __builtin_amdgcn_sched_barrier(0);
-      float pr[8];
+      float pr[8], ptr[8];
       recompute_p<SW_KV>(Ks, Ms + blk * KB, qf, s2, g, lane, sc, lse_q, qok, 0, 0, pr);
+      if (KDR) recompute_p<SW_K>(Kts, Ms + blk * KB, qt, s2, g, lane, sc, tl, qok, 0, 0, ptr);
       bf16x8 d8, p8o;
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -1667,7 +1749,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float pp = pr[hh * 4 + r];
-          const float ex = (kd_on && ok) ? kdc * (pp - (float)t8[s2][hh * 4 + r]) : 0.f;
+          const float ex = KDR ? (ok ? kdc * (pp - ptr[hh * 4 + r]) : 0.f)
+                               : ((kd_on && ok) ? kdc * (pp - (float)t8[s2][hh * 4 + r]) : 0.f);
           const float dp = fmaf(gz, acc[r], ex);
           gsum = fmaf(pp, acc[r], gsum);
           d8[hh * 4 + r] = (bf16)(pp * (dp - dsum));
@@ -1702,7 +1785,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
 // [B, H, Lq, Lk] probability workspace when it holds)
 static bool bwd_dq_stream_applies(const MAttnB& f) {
   const char* env = getenv("EVLM_ATTN_NO_STREAM");         // (A/B switch, read per call)
-  return !((env && atoi(env)) || f.Lk <= 224 || f.Lk > 1024 || f.causal || !f.lse || !f.O || f.E || (f.Pt && !f.rkd));
+  return !((env && atoi(env)) || f.Lk <= 224 || f.Lk > 1024 || f.causal || !f.lse || !f.O || f.E || ((f.Pt || f.Tq) && !f.rkd));
 }
 static bool launch_bwd_dq_stream(MAttnB& f, hipStream_t stream) {
   if (!bwd_dq_stream_applies(f)) return false;
@@ -1710,9 +1793,15 @@ static bool launch_bwd_dq_stream(MAttnB& f, hipStream_t stream) {
   if (!(keep && atoi(keep))) { f.P = nullptr; f.Pw = nullptr; }
   constexpr int KB = 128, NW = 8;
   const int nblk = (f.Lk + KB - 1) / KB, qtiles = (f.Lq + 15) / 16;
+  dim3 grid((qtiles + NW - 1) / NW, f.H, f.B), block(64 * NW);
+  if (f.Tq) {                                            // the teacher's map rebuilt in the kernel: a third tile per buffer
+    const size_t ldsr = (size_t)6 * KB * 128 + (size_t)nblk * KB * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_stream_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
+    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<NW, true>), grid, block, ldsr, stream, f);
+    return true;
+  }
   const size_t lds = (size_t)4 * KB * 128 + (size_t)nblk * KB * sizeof(float);
   (void)hipFuncSetAttribute((const void*)attn_bwd_dq_stream_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  dim3 grid((qtiles + NW - 1) / NW, f.H, f.B), block(64 * NW);
   hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<NW>), grid, block, lds, stream, f);
   return true;
 }
@@ -2150,6 +2239,15 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
   if (a->kd_teacher && !a->kd_gout) return evlm_set_error("evlm_attention_bwd: kd_teacher without kd_gout");
   f.lse = a->lse; f.mask = a->mask; f.causal = a->causal; f.Pw = nullptr;
   f.O = (const bf16*)a->O; f.rkd = a->kd_rowdot;
+  f.Tq = (const bf16*)a->kd_tq; f.Tk = (const bf16*)a->kd_tk; f.tld = a->kd_tld; f.tlse = a->kd_tlse;
+  if (f.Tq) {
+    if (!(f.Tk && f.tlse && a->kd_gout && !a->kd_teacher && !a->mask && !a->kv_index && a->Lq == a->Lk && a->kd_tld % 8 == 0))
+      return evlm_set_error("evlm_attention_bwd: kd_tq needs kd_tk, kd_tlse and kd_gout, self-attention without a mask, no kd_teacher");
+    f.kd_coef = 2.0f * a->kd_weight / ((float)a->B * a->H * a->Lq * a->Lk);
+    if (!bwd_dq_stream_applies(f))
+      return evlm_set_error("evlm_attention_bwd: kd_tq is served by the one-pass streaming kernel only (225..928 keys, lse, O, "
+                            "kd_rowdot, no dP_ext, no causal mask)");
+  }
   const bool rc = a->lse != nullptr;
   if (rc && !evlm_attention_lse_supported(a->dtype, a->dh, a->Lk, 0.f))
     return evlm_set_error("evlm_attention_bwd: the recomputing form serves Lk <= 224 and 417..928 (got %d)", a->Lk);
@@ -2226,15 +2324,24 @@ int evlm_attention_fwd_mfma(const evlm_attn_fwd_args* a, hipStream_t stream, int
   f.Pt = (const bf16*)a->kd_teacher; f.kd = a->kd_loss;
   f.kd_coef = a->kd_teacher ? a->kd_weight / ((float)a->B * a->H * a->Lq * a->Lk) : 0.f;
   f.lse = a->lse; f.rkd = a->kd_rowdot;
+  f.Tq = (const bf16*)a->kd_tq; f.Tk = (const bf16*)a->kd_tk; f.tld = a->kd_tld; f.tlse = a->kd_tlse;
+  if (f.Tq) {
+    if (!(f.Tk && f.tlse && a->lse && a->kd_loss && !a->kd_teacher && !a->P && !a->mask && !a->kv_index && !a->causal &&
+          a->Lq == a->Lk && a->Lk > 224 && a->Lk <= 928 && a->kd_tld % 8 == 0))
+      return evlm_set_error("evlm_attention_fwd: kd_tq (the teacher's map rebuilt in the kernel) needs kd_tk, kd_tlse, lse and "
+                            "kd_loss, self-attention on 225..928 keys without a mask, and neither P nor kd_teacher");
+    f.kd_coef = a->kd_weight / ((float)a->B * a->H * a->Lq * a->Lk);
+  }
   static const bool no_head_skip = getenv("EVLM_ATTN_NO_HEAD_SKIP") != nullptr;      // (A/B switch)
   f.skip_dead = no_head_skip ? 0 : 1;
-  if (a->kd_rowdot && !(a->lse && a->kd_teacher))
+  if (a->kd_rowdot && !(a->lse && (a->kd_teacher || a->kd_tq)))
     return evlm_set_error("evlm_attention_fwd: kd_rowdot needs lse and kd_teacher");
   if (a->lse && !evlm_attention_lse_supported(a->dtype, a->dh, a->Lk, 0.f))
     return evlm_set_error("evlm_attention_fwd: the lse form serves Lk <= 224 and 417..928 (got %d)", a->Lk);
   if (a->kd_teacher && !a->kd_loss) return evlm_set_error("evlm_attention_fwd: kd_teacher without kd_loss");
   if (a->Lk > 64 && a->Lk <= 224 && launch_fwd_grouped<14>(f, a->Bkv, stream)) {}
   else if (launch_fwd_stream(f, stream)) {}
+  else if (f.Tq) return evlm_set_error("evlm_attention_fwd: kd_tq is served by the streaming kernels only");
   else if (a->Lk <= 32) launch_fwd<2>(f, stream);
   else if (a->Lk <= 64) launch_fwd<4>(f, stream);
   else if (a->Lk <= 224) launch_fwd<14>(f, stream);

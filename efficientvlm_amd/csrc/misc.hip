@@ -13,7 +13,7 @@ int evlm_set_error(const char* fmt, ...) {
   return 1;
 }
 extern "C" const char* evlm_last_error(void) { return g_err; }
-extern "C" int evlm_abi_version(void) { return 7; }
+extern "C" int evlm_abi_version(void) { return 8; }
 
 // ---- BERT embeddings -------------------------------------------------------------------------
 template <typename T>

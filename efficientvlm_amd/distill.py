@@ -279,9 +279,11 @@ def fuse_image_map_kd(student, teacher_out, batch):
         return None
     cor = get_cor_teacher(maps, [None] * ns, is_attn=True)
     attn = enc.layers[0].self_attn
-    if any(m is None or ops._padded_base(m) is None for m in cor):
+    if all(isinstance(m, ops.MapRecipe) for m in cor):
+        pass                                   # (the teacher kept Q, K and row lse instead of its maps: rebuilt in-kernel)
+    elif any(m is None or isinstance(m, ops.MapRecipe) or ops._padded_base(m) is None for m in cor):
         return None
-    if not ops.attention_kd_fusable(cor[0], attn.num_heads, attn.head_dim, cor[0].shape[-1]):
+    elif not ops.attention_kd_fusable(cor[0], attn.num_heads, attn.head_dim, cor[0].shape[-1]):
         return None
     enc.kd_teacher_maps = cor
     # ... and the hidden-state term of the same encoder inside each layer's first LayerNorm (round 5): student state i - the

@@ -88,7 +88,7 @@ class CLIPAttention(nn.Module):
         self.pruned_heads = self.pruned_heads.union(heads)
 
     def forward(self, hidden_states, attention_mask=None, causal_attention_mask=None, output_attentions=False,
-                head_z=None, head_layer_z=None, residual=None, kd_teacher=None, kd_word=None, p_out=None):
+                head_z=None, head_layer_z=None, residual=None, kd_teacher=None, kd_word=None, p_out=None, recipe=False):
         """hidden_states [B,N,C] -> (attn_output [B,N,C], probs [B,H,N,N] | None).
 
         `residual` (extension): added in the out_proj GEMM epilogue; the layer passes the block input.
@@ -120,8 +120,13 @@ class CLIPAttention(nn.Module):
                                                 kd_weight=float(tgt_len) if kd_word is None else ops.KdSlot(kd_word, tgt_len))
             out = ops.linear(out, self.out_proj.weight, self.out_proj.bias, residual=residual)
             return out, (probs if output_attentions else None), kd
-        out, probs = ops.self_attention(qkv, self.num_heads, self.head_dim, self.scale, mask=mask2d, gate=head_z,
-                                        want_probs=bool(output_attentions), p_out=p_out if output_attentions else None)
+        if recipe and output_attentions and p_out is None and ops.map_recipe_supported(qkv, self.num_heads, self.head_dim, mask2d):
+            # (`recipe`, extension: a frozen teacher whose kept maps are only read by fused distillation terms on long key
+            # sequences hands out ops.MapRecipe - its QKV buffer + row lse - in the map's slot; no map is written)
+            out, probs = ops.self_attention_recipe(qkv, self.num_heads, self.head_dim, self.scale, gate=head_z)
+        else:
+            out, probs = ops.self_attention(qkv, self.num_heads, self.head_dim, self.scale, mask=mask2d, gate=head_z,
+                                            want_probs=bool(output_attentions), p_out=p_out if output_attentions else None)
         out = ops.linear(out, self.out_proj.weight, self.out_proj.bias, residual=residual)
         return out, (probs if output_attentions else None)
 
@@ -153,7 +158,7 @@ class CLIPEncoderLayer(nn.Module):
         self.layer_norm2 = nn.LayerNorm(hidden_size)
 
     def forward(self, hidden_states, attention_mask: None, output_attentions: Optional[bool] = False, head_z=None,
-                head_layer_z=None, mlp_z=None, kd_teacher=None, kd_word=None, p_out=None, kd_state=None):
+                head_layer_z=None, mlp_z=None, kd_teacher=None, kd_word=None, p_out=None, kd_state=None, recipe=False):
         # (layer_norm_fork: the residual branch gets an ALIAS of the block input, so that the LayerNorm backward kernel sums
         # the two gradients of the input itself - evlm_layernorm_bwd_add - instead of autograd adding them element-wise)
         # (`tap`: a third alias of the block input, for the hidden-state distillation that reads it - CLIPEncoder reports it
@@ -171,7 +176,7 @@ class CLIPEncoderLayer(nn.Module):
         attn_out = self.self_attn(hidden_states=h, attention_mask=attention_mask,
                                   causal_attention_mask=None, output_attentions=output_attentions,
                                   head_z=head_z, head_layer_z=head_layer_z, residual=residual, kd_teacher=kd_teacher,
-                                  kd_word=kd_word, p_out=p_out)
+                                  kd_word=kd_word, p_out=p_out, recipe=recipe)
         hidden_states, attn_weights = attn_out[0], attn_out[1]
         self.kd_term = attn_out[2] if kd_teacher is not None else None
         h, residual = ops.layer_norm_fork(hidden_states, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps)
@@ -202,6 +207,10 @@ class CLIPEncoder(nn.Module):
         # kd_hidden_fused (distill.fuse_image_map_kd / collect_fused_kd)
         self.kd_teacher_states = None
         self.kd_hidden_fused = None
+        # extension (False = maps as tensors): a FROZEN TEACHER whose kept image maps are read by nothing but the student's
+        # fused distillation kernels returns ops.MapRecipe objects in their slots on long key sequences (trainer.ITRTrainer /
+        # VQATrainer set it with the prefetched teacher): QKV buffer + row lse instead of a [B, H, L, L] map
+        self.attn_recipe = False
         # extension (False = the reference's behaviour of returning every map): a layer whose map distillation ran fused in
         # its attention kernel does not materialise the map (None in its slot) - nobody else reads a student's ViT maps in
         # the GD recipe (trainer.GDTrainer sets this on the student)
@@ -253,6 +262,8 @@ class CLIPEncoder(nn.Module):
             kdkw = dict(kd_teacher=kd_maps[idx], kd_word=kd_words[idx]) if kd_maps is not None else {}
             if self.attn_out and idx in self.attn_out and want_map and not do_gather and image_atts_blk is None:
                 kdkw["p_out"] = self.attn_out[idx]
+            if self.attn_recipe and want_map and not do_gather and image_atts_blk is None and not torch.is_grad_enabled():
+                kdkw["recipe"] = True
             if kd_states is not None and kd_states[idx] is not None:
                 # MSELoss (mean over the elements) with weight 1 (GeneralDistill.py:78-80)
                 kdkw["kd_state"] = (kd_states[idx], kd_hslots[idx], 1.0 / float(hidden_states.numel()))

@@ -1060,7 +1060,23 @@ class _Attention(torch.autograd.Function):
                           kv_index=L.ptr(kv_index), mask=L.ptr(m32), head_gate=L.ptr(g32), scale=scale, O=L.ptr(O),
                           P=L.ptr(Pbuf), causal=int(bool(causal)), lse=L.ptr(lse), Bkv=Bkv if kv_index is not None else 0)
         kd = kd_base = rkd = None
-        if kd_teacher is not None:                # fused map distillation: the teacher's (padded) map, read once in-kernel
+        recipe = kd_teacher if isinstance(kd_teacher, MapRecipe) else None
+        if recipe is not None:                    # the teacher's map is REBUILT in the kernel from its Q, K and row lse (ABI 8)
+            tq, tlse = recipe.qkv, recipe.lse
+            if (not rc or Lk <= 224 or Pbuf is not None or m32 is not None or kv_index is not None or causal
+                    or tuple(tq.shape) != (B, Lk, 3 * H * dh) or tq.dtype != torch.bfloat16 or not tq.is_contiguous()
+                    or recipe.H != H or recipe.dh != dh or abs(recipe.scale - scale) > 1e-12 or qbuf is not kvbuf):
+                raise RuntimeError("fused attention-map distillation from a MapRecipe needs a self-attention on 225..928 keys in "
+                                   "the recomputing form (bf16, no map output, no mask) and a teacher of the same head geometry")
+            if isinstance(kd_weight, KdSlot):
+                kd, kd_weight = kd_weight.word, kd_weight.weight
+            else:
+                kd = zero_scalar(dev)
+            a.kd_tq, a.kd_tk, a.kd_tld, a.kd_tlse = L.ptr(tq), C.c_void_p(tq.data_ptr() + H * dh * es), 3 * H * dh, L.ptr(tlse)
+            a.kd_loss, a.kd_weight = L.ptr(kd), float(kd_weight)
+            rkd = torch.empty((B, H, Lq), dtype=torch.float32, device=dev)
+            a.kd_rowdot = L.ptr(rkd)
+        elif kd_teacher is not None:              # fused map distillation: the teacher's (padded) map, read once in-kernel
             kd_base = _padded_base(kd_teacher, Lkp) if kd_teacher.shape[-1] != Lkp else kd_teacher
             if (kd_base is None or not kd_base.is_contiguous() or tuple(kd_base.shape) != (B, H, Lq, Lkp)
                     or kd_base.dtype != tdt or tdt != torch.bfloat16 or (Pbuf is None and lse is None)):
@@ -1083,7 +1099,8 @@ class _Attention(torch.autograd.Function):
             ATTN_FLOPS[0] += 4.0 * B * H * Lq * Lk * dh
         ctx.set_materialize_grads(False)        # an unused probability map must not cost a zero tensor in backward
         ctx.save_for_backward(qbuf, kvbuf, Pbuf, g32, kv_index, kd_base, lse, m32 if rc else None,
-                              O if (rc and Lk > 224) else None, rkd)
+                              O if (rc and Lk > 224) else None, rkd,
+                              recipe.qkv if recipe is not None else None, recipe.lse if recipe is not None else None)
         ctx.meta = (H, dh, q_off, k_off, v_off, scale, qbuf is kvbuf or qbuf.data_ptr() == kvbuf.data_ptr(),
                     gate.shape if gate is not None else None)
         ctx.causal = int(bool(causal))
@@ -1095,7 +1112,7 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dO, dP, dkd):
-        qbuf, kvbuf, P, g32, kv_index, kd_base, lse, m32, O_fwd, rkd = ctx.saved_tensors
+        qbuf, kvbuf, P, g32, kv_index, kd_base, lse, m32, O_fwd, rkd, t_qkv, t_lse = ctx.saved_tensors
         H, dh, q_off, k_off, v_off, scale, self_attn, gshape = ctx.meta
         B, Lq, ldq = qbuf.shape
         Bkv, Lk, ldk = kvbuf.shape
@@ -1138,7 +1155,7 @@ class _Attention(torch.autograd.Function):
         # for the life of a captured step's pool) would never be touched
         env_on = lambda n: os.environ.get(n, "0") not in ("", "0")
         streams = (lse is not None and Lk > 224 and Lk <= 928 and not ctx.causal and O_fwd is not None and dPc is None
-                   and (kd_base is None or dkd is None or rkd is not None) and tdt == torch.bfloat16 and dh == 64
+                   and ((kd_base is None and t_qkv is None) or dkd is None or rkd is not None) and tdt == torch.bfloat16 and dh == 64
                    and not env_on("EVLM_ATTN_NO_STREAM") and not env_on("EVLM_ATTN_STREAM_PWS"))
         P_ws = (torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev)
                 if (lse is not None and not single_pass and not streams) else None)
@@ -1155,6 +1172,11 @@ class _Attention(torch.autograd.Function):
                           dV=C.c_void_p(dkvbuf.data_ptr() + v_off * es), dgate=L.ptr(dgate),
                           lse=L.ptr(lse), mask=L.ptr(m32), causal=ctx.causal if lse is not None else 0, P_ws=L.ptr(P_ws),
                           O=L.ptr(O_fwd), kd_rowdot=L.ptr(rkd))
+        if t_qkv is not None and dkd is not None:         # ... from the teacher's Q, K and row lse (MapRecipe: ABI 8)
+            gk = dkd.to(torch.float32).contiguous()
+            a.kd_tq, a.kd_tk, a.kd_tld, a.kd_tlse = (L.ptr(t_qkv), C.c_void_p(t_qkv.data_ptr() + H * dh * es), 3 * H * dh,
+                                                     L.ptr(t_lse))
+            a.kd_gout, a.kd_weight = L.ptr(gk), ctx.kd_weight
         if kd_base is not None and dkd is not None:       # dP of the fused distillation term is formed in-kernel from P_t
             gk = dkd.to(torch.float32).contiguous()
             a.kd_teacher, a.kd_gout, a.kd_weight = L.ptr(kd_base), L.ptr(gk), ctx.kd_weight
@@ -1182,6 +1204,59 @@ def self_attention(qkv, H, dh, scale, mask=None, gate=None, want_probs=True, cau
     O, P, kd = _Attention.apply(qkv, qkv, mask, gate, H, dh, 0, d, 2 * d, scale, want_probs, None, causal, dropout_p,
                                 kd_teacher, kd_weight, p_out)
     return (O, P) if kd_teacher is None else (O, P, kd)
+
+
+class MapRecipe(tuple):
+    """What a frozen teacher keeps of one self-attention layer INSTEAD of its probability map when the map's only reader is a
+    fused distillation term on a long key sequence (ABI 8: evlm_attn_*_args.kd_tq / kd_tk / kd_tlse): its packed QKV buffer
+    [B, L, 3 H dh] (bf16) and its row lse [B, H, L] (f32, log2 domain).  The student's streaming attention kernels rebuild
+    P_t = 2^(scale q_t.k_t log2e - lse_t) per key tile - 113 MB + 1.8 MB per ViT layer at 577 tokens instead of a 517 MB map
+    written once and read twice.  A tuple of tensors, so the trainers' nest walkers (distill._tensors) see its members."""
+
+    def __new__(cls, qkv, lse, H, dh, scale):
+        self = super().__new__(cls, (qkv, lse))
+        self.H, self.dh, self.scale = int(H), int(dh), float(scale)
+        return self
+
+    qkv = property(lambda self: self[0])
+    lse = property(lambda self: self[1])
+
+    @property
+    def shape(self):                       # (shape of the map it stands for)
+        B, Lk = self[0].shape[0], self[0].shape[1]
+        return (B, self.H, Lk, Lk)
+
+    def detach(self):
+        return self
+
+
+def map_recipe_supported(qkv, H, dh, mask=None, causal=False):
+    """can a no-grad self-attention on this packed buffer hand out a MapRecipe (streaming kernels: 225..928 keys, bf16,
+    head dim 64, no mask)?"""
+    return bool(qkv.is_cuda and qkv.dtype == torch.bfloat16 and dh == 64 and 224 < qkv.shape[1] <= 928 and mask is None
+                and not causal and not torch.is_grad_enabled() and not os.environ.get("EVLM_NO_KD_RECIPE")
+                and os.environ.get("EVLM_ATTN_NO_STREAM", "0") in ("", "0") and ATTN_RC_LONG and not ATTN_STORE_P
+                # (the student's side needs the recomputing form of this length: 417..928 keys)
+                and _lib().evlm_attention_lse_supported(L.dt(qkv.dtype), dh, qkv.shape[1], 0.0))
+
+
+def self_attention_recipe(qkv, H, dh, scale, gate=None):
+    """no-grad self-attention that keeps (context, MapRecipe) - no probability map is written (see MapRecipe)"""
+    L.require_cuda(qkv)
+    assert qkv.is_contiguous() and not torch.is_grad_enabled()
+    B, Lq, ld = qkv.shape
+    d = H * dh
+    dev, es = qkv.device, qkv.element_size()
+    O = torch.empty((B, Lq, d), dtype=qkv.dtype, device=dev)
+    lse = torch.empty((B, H, Lq), dtype=torch.float32, device=dev)
+    g32 = gate.detach().reshape(-1).to(torch.float32).contiguous() if gate is not None else None
+    a = L.AttnFwdArgs(dtype=L.dt(qkv.dtype), p_dtype=L.dt(qkv.dtype), B=B, H=H, Lq=Lq, Lk=Lq, dh=dh, ldq=ld, ldk=ld, ldv=ld,
+                      ldo=d, ldpr=_pad8(Lq), Q=C.c_void_p(qkv.data_ptr()), K=C.c_void_p(qkv.data_ptr() + d * es),
+                      V=C.c_void_p(qkv.data_ptr() + 2 * d * es), head_gate=L.ptr(g32), scale=scale, O=L.ptr(O), lse=L.ptr(lse))
+    L.check(_lib().evlm_attention_fwd(C.byref(a), L.stream()), "attention_fwd")
+    if ATTN_FLOPS is not None:
+        ATTN_FLOPS[0] += 4.0 * B * H * Lq * Lq * dh
+    return O, MapRecipe(qkv, lse, H, dh, scale)
 
 
 class KdSlot:

@@ -1345,6 +1345,13 @@ class ITRTrainer(_StagedExchange, _CapturedStep):
         enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
         if enc is not None and hasattr(enc, "kd_drop_maps") and not os.environ.get("EVLM_STUDENT_ALL_MAPS"):
             enc.kd_drop_maps = True        # a ViT map whose distillation term was formed in-kernel is not materialised
+        # the prefetched teacher's kept image maps have ONE reader - the student's fused distillation kernels (bf16) - so on
+        # long key sequences it keeps its QKV buffers + row lse instead (ops.MapRecipe: 115 MB per layer at 577 tokens
+        # instead of a 517 MB map written once and read twice); EVLM_NO_KD_RECIPE=1: maps as before
+        tenc = getattr(getattr(teacher, "vision_encoder", None), "encoder", None)
+        if (tenc is not None and hasattr(tenc, "attn_recipe") and pipeline_teacher and dtype == torch.bfloat16
+                and not os.environ.get("EVLM_NO_FUSED_KD") and not os.environ.get("EVLM_TEACHER_ALL_MAPS")):
+            tenc.attn_recipe = True
 
     def _teacher_forward(self, b):
         with torch.no_grad(), compute(self.dtype):
@@ -1458,6 +1465,13 @@ class VQATrainer(_StagedExchange, _CapturedStep):
         enc = getattr(getattr(student, "vision_encoder", None), "encoder", None)
         if enc is not None and hasattr(enc, "kd_drop_maps") and not os.environ.get("EVLM_STUDENT_ALL_MAPS"):
             enc.kd_drop_maps = True        # a ViT map whose distillation term was formed in-kernel is not materialised
+        # the prefetched teacher's kept image maps have ONE reader - the student's fused distillation kernels (bf16) - so on
+        # long key sequences it keeps its QKV buffers + row lse instead (ops.MapRecipe: 115 MB per layer at 577 tokens
+        # instead of a 517 MB map written once and read twice); EVLM_NO_KD_RECIPE=1: maps as before
+        tenc = getattr(getattr(teacher, "vision_encoder", None), "encoder", None)
+        if (tenc is not None and hasattr(tenc, "attn_recipe") and pipeline_teacher and dtype == torch.bfloat16
+                and not os.environ.get("EVLM_NO_FUSED_KD") and not os.environ.get("EVLM_TEACHER_ALL_MAPS")):
+            tenc.attn_recipe = True
 
     def _teacher_forward(self, b):
         from types import SimpleNamespace as NS

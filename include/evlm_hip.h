@@ -190,6 +190,13 @@ typedef struct {
   /* optional [B, H, Lq] f32, with lse AND kd_teacher: kd_rowdot[row] = sum_k P (P - P_t), the distillation term's share of
      the backward's row sum  delta = sum_k P dP  (evlm_attn_bwd_args.kd_rowdot: one-pass long-sequence backward) */
   float* kd_rowdot;
+  /* ABI 8 - the fused map distillation against a teacher map that is NOT in memory (long key sequences: 225..928 keys,
+     self-attention, no mask; kd_teacher NULL): the frozen teacher kept its projected queries / keys - kd_tq / kd_tk, bf16
+     [B, L, H, dh] views of its packed QKV buffer with row stride kd_tld - and its row lse kd_tlse [B, H, L] (what its own
+     forward call wrote through `lse`) instead of a [B, H, L, L] map; the kernel rebuilds P_t = 2^(scale q_t.k_t log2e - lse_t)
+     per key tile in fp32 and forms the same term (and kd_rowdot).  113 MB + 1.8 MB per ViT layer at 577 tokens instead of
+     a 517 MB map written once and read twice (Eff_Retrieval.py:141-147, Eff_VQA.py:140-146 distil these maps). */
+  const void* kd_tq; const void* kd_tk; int kd_tld; const float* kd_tlse;
 } evlm_attn_fwd_args;
 int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream);
 
@@ -237,6 +244,8 @@ typedef struct {
      keys instead of two (the flash-attention identity, extended by the fused distillation term).  Ignored elsewhere. */
   const void* O;
   const float* kd_rowdot;
+  /* ABI 8: the teacher's map rebuilt in the kernel, as in the forward call (one-pass streaming kernel only) */
+  const void* kd_tq; const void* kd_tk; int kd_tld; const float* kd_tlse;
 } evlm_attn_bwd_args;
 int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream);
 /* 1 when evlm_attention_fwd / _bwd serve (dtype, dh, Lk, dropout_p) through the lse / recompute form, else 0 */

@@ -1308,6 +1308,64 @@ def test_one_pass_long_sequence_backward_with_fused_distillation_and_gates(B, H,
     assert l2(gate.grad, gr.grad) < 5e-3, (gate.grad, gr.grad)
 
 
+@pytest.mark.parametrize("B,H,L,tq", [(2, 12, 577, 0), (1, 4, 901, 0), (2, 3, 450, 1), (2, 12, 577, 2), (3, 2, 420, 0)])
+def test_fused_map_distillation_from_a_teacher_recipe_equals_the_fp32_reference(B, H, L, tq, monkeypatch):
+    """ABI 8 (round 5): the fused attention-map distillation of a long key sequence with the teacher's map REBUILT in the
+    student's streaming kernels from the teacher's Q, K and row lse (ops.MapRecipe, evlm_attn_*_args.kd_tq / kd_tk /
+    kd_tlse) instead of read from a [B, H, L, L] bf16 map: forward term, context and the q / k / v / gate gradients against
+    plain fp32 autograd of softmax / P V / gate / MSELoss(P, P_t) * L with P_t = the TEACHER'S fp32 softmax (the recipe's
+    probabilities are not bf16-rounded), and against the stored-map form of the same kernels at bf16 resolution.
+    tq: EVLM_ATTN_STREAM_TQ (query tiles per wave of the forward kernel; 0 = the dispatcher's choice)."""
+    import subprocess, sys
+    if tq and os.environ.get("EVLM_ATTN_STREAM_TQ") != str(tq):
+        # (the switch is read once per process)
+        env = dict(os.environ, EVLM_ATTN_STREAM_TQ=str(tq))
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k",
+                            f"teacher_recipe and {B}-{H}-{L}-{tq}"], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+        return
+    o = ops()
+    g = torch.Generator().manual_seed(400 + L)
+    dh, d = 64, H * 64
+    qkv0 = rnd((B, L, 3 * d), torch.bfloat16, g, 0.7)
+    tqkv = rnd((B, L, 3 * d), torch.bfloat16, g, 0.7)
+    gate0 = (torch.rand(H, generator=g) + 0.5).to(DEV)
+    gO = rnd((B, L, d), torch.bfloat16, g)
+    coef = 0.3
+    with torch.no_grad():
+        assert o.map_recipe_supported(tqkv, H, dh)
+        Ot, recipe = o.self_attention_recipe(tqkv, H, dh, 0.125)
+        Ot2, Pt = o.self_attention(tqkv, H, dh, 0.125)                    # the same teacher, map written
+    assert isinstance(recipe, o.MapRecipe) and tuple(recipe.shape) == (B, H, L, L) and rel_err(Ot.float(), Ot2.float()) < 1e-2
+
+    def run(kd_teacher):
+        x = qkv0.clone().requires_grad_(True)
+        gate = gate0.clone().requires_grad_(True)
+        O, P, kd = o.self_attention(x, H, dh, 0.125, gate=gate, want_probs=False, kd_teacher=kd_teacher, kd_weight=float(L))
+        assert P is None
+        ((O.float() * gO.float()).sum() + coef * kd).backward()
+        return O.detach(), kd.detach(), x.grad, gate.grad
+
+    O1, kd1, gx1, gg1 = run(recipe)
+    O2, kd2, gx2, gg2 = run(Pt)
+    sp = lambda t: t.reshape(B, L, H, dh).transpose(1, 2)
+    with torch.no_grad():
+        Ptr = torch.softmax(sp(tqkv.float()[..., :d]) @ sp(tqkv.float()[..., d:2 * d]).transpose(-1, -2) * 0.125, -1)
+    xr = qkv0.float().requires_grad_(True)
+    gr = gate0.clone().requires_grad_(True)
+    Pr = torch.softmax(sp(xr[..., :d]) @ sp(xr[..., d:2 * d]).transpose(-1, -2) * 0.125, -1)
+    Or = ((Pr @ sp(xr[..., 2 * d:])) * gr[None, :, None, None]).transpose(1, 2).reshape(B, L, d)
+    kdr = torch.nn.functional.mse_loss(Pr, Ptr) * L
+    ((Or * gO.float()).sum() + coef * kdr).backward()
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    assert torch.equal(O1, O2)                                   # (the context does not depend on the form of the term)
+    assert rel_err(kd1, kdr) < 2e-4, (float(kd1), float(kdr))   # fp32 teacher probabilities: the reference's own operands
+    assert rel_err(kd2, kdr) < 2e-2                              # (the stored map is bf16-rounded)
+    assert l2(gx1.float(), xr.grad) < 8e-3 and l2(gx1.float()[..., :2 * d], xr.grad[..., :2 * d]) < 1e-2
+    assert l2(gx1.float(), gx2.float()) < 1e-2
+    assert l2(gg1, gr.grad) < 5e-3 and l2(gg1, gg2) < 5e-3
+
+
 @pytest.mark.parametrize("B,Bkv,Lq,Lk,with_mask", [(7, 3, 30, 197, False), (256, 64, 30, 197, True), (9, 2, 17, 100, True),
                                                    (5, 4, 64, 224, False), (700, 90, 30, 197, False), (40, 3, 40, 150, True)])
 def test_grouped_cross_attention_forward_is_bit_identical_to_the_per_batch_kernel(B, Bkv, Lq, Lk, with_mask, monkeypatch):

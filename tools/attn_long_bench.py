@@ -47,6 +47,20 @@ for B, L in ((64, 577), (32, 901)):
             t3 = bench(lambda: ops.self_attention(qkv, H, dh, 0.125, want_probs=True))
         out[tag] = dict(no_grad_us=round(t0, 1), lse_us=round(t1, 1), lse_kd_us=round(t2, 1), map_written_us=round(t3, 1), fwd_bwd_us=round(tb1, 1), fwd_bwd_kd_us=round(tb2, 1),
                         no_grad_tflops=round(fl / t0 / 1e6, 1))
+        if tag == "stream":
+            # round 5 (ABI 8): the teacher keeps Q, K and its row lse instead of the map (ops.MapRecipe); the student's kernels
+            # rebuild P_t.  teacher_recipe_us: the teacher's layer in that form (against map_written_us)
+            tq = (torch.randn(B, L, 3 * d, device=dev) * 0.5).bfloat16()
+            with torch.no_grad():
+                rec = ops.self_attention_recipe(tq, H, dh, 0.125)[1]
+                t4 = bench(lambda: ops.self_attention_recipe(tq, H, dh, 0.125))
+            t5 = bench(lambda: ops.self_attention(x, H, dh, 0.125, want_probs=False, kd_teacher=rec, kd_weight=1.0))
+            def fbr():
+                O, _, k = ops.self_attention(x, H, dh, 0.125, want_probs=False, kd_teacher=rec, kd_weight=1.0)
+                torch.autograd.grad((O.float() * gO.float()).sum() + k, x)
+            t6 = bench(fbr, 6)
+            out[tag].update(teacher_recipe_us=round(t4, 1), lse_kd_recipe_us=round(t5, 1), fwd_bwd_kd_recipe_us=round(t6, 1))
+            del rec, tq
     print(json.dumps(out), flush=True)
     del Pt
 for Bimg, rows, L in ((64, 3, 577), (32, 4, 901)):
