@@ -26,7 +26,7 @@ class GemmArgs(C.Structure):
                 ("P", _vp), ("Q", _vp), ("C", _vp), ("bias", _vp), ("gate", _vp),
                 ("preact", _vp), ("aux", _vp), ("residual", _vp),
                 ("alpha", _f), ("act", _i), ("gate_pos", _i), ("dact", _i), ("accumulate", _i), ("psum", _vp),
-                ("sk_workspace", _vp)]
+                ("sk_workspace", _vp), ("dgate", _vp)]
 
 
 class WgradProblem(C.Structure):

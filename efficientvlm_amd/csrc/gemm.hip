@@ -831,7 +831,10 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(a && a->P && a->Q && a->C, "evlm_gemm: null operand");
   EVLM_REQUIRE(a->I > 0 && a->J > 0 && a->K > 0, "evlm_gemm: bad shape I=%d J=%d K=%d", a->I, a->J, a->K);
-  EVLM_REQUIRE(!(a->dact && (a->gate || a->act)), "evlm_gemm: dact excludes act/gate");
+  EVLM_REQUIRE(!(a->dact && a->act), "evlm_gemm: dact excludes act");
+  EVLM_REQUIRE(!(a->dact && a->gate) || a->dgate, "evlm_gemm: dact with a gate needs dgate (the gated activation backward, ABI 8)");
+  EVLM_REQUIRE(!a->dgate || (a->dact && a->gate && a->dtype == EVLM_BF16 && !a->residual && !a->bias && !a->preact && !a->c_f32),
+               "evlm_gemm: dgate goes with dact + gate on a plain bf16 product");
   EVLM_REQUIRE(!a->dact || a->aux, "evlm_gemm: dact needs aux");
   const int vec = a->dtype == EVLM_BF16 ? 8 : 4;
   EVLM_REQUIRE(a->ldp % vec == 0 && a->ldq % vec == 0, "evlm_gemm: ldp/ldq must be multiples of %d", vec);
@@ -846,6 +849,7 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
   g.accumulate = a->accumulate;
   g.psum = a->psum;
   g.sk_ws = a->sk_workspace; g.sk = 0;
+  g.dgate = a->dgate;
   EVLM_REQUIRE(!a->psum || (a->dtype == EVLM_BF16 && a->K % 64 == 0), "evlm_gemm: psum needs bf16 operands and K a multiple of 64");
   EVLM_REQUIRE(!a->accumulate || (a->dtype == EVLM_BF16 && a->c_f32 && !a->bias && !a->gate && !a->preact && !a->aux &&
                                    !a->residual && a->act == EVLM_ACT_NONE && a->K % 64 == 0),
@@ -882,13 +886,13 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
     }
     if (evlm_gemm_pp192_eligible(g, pt, qt) && !evlm_gemm_pp256_streamk(g, pt)) {   // 192 x 256 tiles: one round filled 50-80 %
       if (evlm_gemm_pp192_launch(g, qt, stream)) return -1;
-      g_last_kernel = qt ? "gemm_bf16_pp192_kernel<true>" : "gemm_bf16_pp192_kernel<false>";
+      g_last_kernel = g.dgate ? "gemm_bf16_pp192_kernel<gated dact>" : (qt ? "gemm_bf16_pp192_kernel<true>" : "gemm_bf16_pp192_kernel<false>");
       EVLM_LAUNCH_CHECK("evlm_gemm");
       return 0;
     }
     if (evlm_gemm_pp256_eligible(g, pt, qt)) {
       const int items = ceil_div(g.I, 256) * ceil_div(g.J, 256) * evlm_gemm_pp256_splits(g);
-      if (items * 100 >= pp_pct * ceil_div(items, 256) * 256 || evlm_gemm_pp256_streamk(g, pt)) {
+      if (!g.dgate && (items * 100 >= pp_pct * ceil_div(items, 256) * 256 || evlm_gemm_pp256_streamk(g, pt))) {
         if (g.c_f32 && evlm_gemm_pp256_splits(g) > 1 && !g.accumulate) {
           if (zero_f32((float*)g.C, (int64_t)g.I * g.ldc, stream)) return -1;
         }
@@ -900,6 +904,9 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
         return 0;
       }
     }
+    if (g.dgate)      // (only the ping-pong family's epilogue forms the gate gradient: gemm_pp256_epi.h)
+      return evlm_set_error("evlm_gemm: the gated activation backward (dgate) needs a product the 256-column ping-pong kernels "
+                            "take: K a multiple of 64 and >= 128, J / ldc / ldx multiples of 8, P not transposed");
     if (!fast) {
       g.tiles_i = ceil_div(g.I, BT); g.tiles_j = ceil_div(g.J, BT); g.kt_per_split = 0; g.bare_f32 = 0;
       dim3 grid(g.tiles_i * g.tiles_j);

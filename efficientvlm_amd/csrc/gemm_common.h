@@ -16,6 +16,7 @@ struct GemmP {
   float* psum;        // [I] += sum_k P(i,k) (bias gradient), or nullptr
   void* sk_ws;        // stream-K workspace (gemm_pp256.hip): 256 flag words, then 256 f32 tile slots of 256 KiB; or nullptr
   int sk;             // launch form chosen by the host: 1 = stream-K
+  float* dgate;       // [J] f32, accumulated: gate gradient of a gated activation backward folded into this dX product (ABI 8)
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -561,7 +561,7 @@ __device__ __forceinline__ void pp_src_192(const GemmP& g, int i0, int j0, int t
     PP_MFMA_END();                                                                                         \
   } while (0)
 
-template <bool QT>
+template <bool QT, bool GD = false>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp192_kernel(GemmP g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x 56 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -610,8 +610,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_pp192_kernel(GemmP g) {
   asm volatile("" : "+v"(tid_e));
   const int lane_e = tid_e & 63;
   char* swin = smem + wave * 4096;              // (stage 0 is dead: one tile per workgroup)
-  if (full) pp_epilogue<true, false, 2>(g, accL, accH, ib, jb, lane_e, swin);
-  else pp_epilogue<false, false, 2>(g, accL, accH, ib, jb, lane_e, swin);
+  if (full) pp_epilogue<true, false, 2, GD>(g, accL, accH, ib, jb, lane_e, swin);
+  else pp_epilogue<false, false, 2, GD>(g, accL, accH, ib, jb, lane_e, swin);
 }
 
 template <bool PT, bool QT, int OUT>
@@ -645,7 +645,8 @@ bool evlm_gemm_pp256_eligible(const GemmP& g, int pt, int qt) {
   if (g.psum) return false;
 #endif
   if (pt || g.accumulate) return false;
-  if (g.dact != EVLM_ACT_NONE && (g.residual || g.gate)) return false;
+  if (g.dact != EVLM_ACT_NONE && (g.residual || (g.gate && !g.dgate))) return false;
+  if (g.dgate && g.sk_ws) return false;            // (the stream-K owner epilogue does not form the gate gradient)
   if (g.J % 8 != 0 || g.ldc % 8 != 0) return false;
   if ((g.preact || g.aux || g.residual) && g.ldx % 8 != 0) return false;
   return true;
@@ -675,6 +676,7 @@ bool evlm_gemm_pp256_streamk(const GemmP& g, int pt) {
 
 // 128 x 256 flavour: bf16 output, K-contiguous P, products whose 256 x 256 tiles fill less than ~40 % of one round
 bool evlm_gemm_pp128_eligible(const GemmP& g, int pt, int qt) {
+  if (g.dgate) return false;                      // (the gated activation backward lives in the 192-row kernel only)
   static const int on = getenv("EVLM_PP128") ? atoi(getenv("EVLM_PP128")) : 1;
   if (!on || pt || g.c_f32 || g.accumulate || g.psum) return false;
   if (!evlm_gemm_pp256_eligible(g, pt, qt)) return false;
@@ -707,6 +709,7 @@ int evlm_gemm_pp128_launch(GemmP& g, int qt, hipStream_t stream) {
 // 192 x 256 flavour: one round of 256 x 256 tiles filled 50-80 %, and 192-row tiles still fit one round
 bool evlm_gemm_pp192_eligible(const GemmP& g, int pt, int qt) {
   static const int on = getenv("EVLM_PP192") ? atoi(getenv("EVLM_PP192")) : 1;
+  if (g.dgate) return !pt && !g.c_f32 && !g.accumulate && !g.psum && evlm_gemm_pp256_eligible(g, pt, qt);   // (its only home)
   if (!on || pt || g.c_f32 || g.accumulate || g.psum) return false;
   if (!evlm_gemm_pp256_eligible(g, pt, qt)) return false;
   const int t256 = ceil_div(g.I, 256) * ceil_div(g.J, 256), t192 = ceil_div(g.I, 192) * ceil_div(g.J, 256);
@@ -722,18 +725,19 @@ int evlm_gemm_pp192_launch(GemmP& g, int qt, hipStream_t stream) {
   const int lds = 2 * PPX_STAGE;
   g.tiles_i = ceil_div(g.I, 192); g.tiles_j = ceil_div(g.J, 256); g.bare_f32 = 0; g.sk = 0; g.kt_per_split = g.K / 64;
   const dim3 grid(g.tiles_i * g.tiles_j), block(512);
-#define PP_LAUNCH_X(QT_)                                                                                      \
+#define PP_LAUNCH_X(QT_, GD_)                                                                                 \
   do {                                                                                                        \
     static bool attr_set = false;                                                                             \
     if (!attr_set) {                                                                                          \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp192_kernel<QT_>),          \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp192_kernel<QT_, GD_>),     \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);                    \
       if (e != hipSuccess) return evlm_set_error("evlm_gemm: cannot reserve 112 KiB LDS: %s", hipGetErrorString(e)); \
       attr_set = true;                                                                                        \
     }                                                                                                         \
-    hipLaunchKernelGGL((gemm_bf16_pp192_kernel<QT_>), grid, block, lds, stream, g);                           \
+    hipLaunchKernelGGL((gemm_bf16_pp192_kernel<QT_, GD_>), grid, block, lds, stream, g);                      \
   } while (0)
-  if (qt) PP_LAUNCH_X(true); else PP_LAUNCH_X(false);
+  if (g.dgate) { if (qt) PP_LAUNCH_X(true, true); else PP_LAUNCH_X(false, true); }
+  else if (qt) PP_LAUNCH_X(true, false); else PP_LAUNCH_X(false, false);
 #undef PP_LAUNCH_X
   return 0;
 }

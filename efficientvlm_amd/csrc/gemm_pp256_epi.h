@@ -65,10 +65,18 @@ __device__ __forceinline__ void pp_sk_load8(const char* base, f32x4 (&v)[2][4]) 
                : "v"(base), "v"(base + 4096) : "memory");
 }
 
+// GATED && XM == 1 (round 5): the backward of an L0-GATED activation in the dX product's epilogue (what evlm_gated_act_bwd did
+// in a second pass over [rows, ffn]: read dA, read the pre-activation, write dH, column-sum the gate gradient).  With h = the
+// pre-activation rows (aux), z = the gate row, dA = this tile:
+//   gate before the activation (CLIP MLP, eff_vit.py:214-220):  t = dA act'(h z);  dH = t z;  dgate += sum_rows t h
+//   gate after it (BERT FFN, eff_bert.py:552-557):              dH = dA act'(h) z;            dgate += sum_rows dA act(h)
+// `dgs` = the wave's per-lane partial column sums (4 column groups x 4 columns), reduced and added to g.dgate once per tile.
 template <bool FULL, int MODE, bool GATED, int XM, int ACT, int DACT, bool SKP>
 __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4], int b0, const PPRows& xr,
-                                             int ic, int jb, int lane, char* sw, bf16* dst, int ldd, const PPSk& sk) {
+                                             int ic, int jb, int lane, char* sw, bf16* dst, int ldd, const PPSk& sk,
+                                             f32x4* dgs = nullptr) {
   constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && XM == 2;
+  constexpr bool gdact = MODE == 2 && GATED && XM == 1;
   const int il = lane & 15, jl = (lane >> 4) * 4;
   const int act = ACT >= 0 ? ACT : g.act, dact = DACT >= 0 ? DACT : g.dact;
   f32x4 gz[4];                             // L0 FFN gate (per output column), fetched per chunk: L2-resident, 16 registers
@@ -111,7 +119,26 @@ __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4],
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = (SKP ? acc[a][b0 + bb][e] + pk[bb][a][e] : acc[a][b0 + bb][e]) * g.alpha + bz[a][e];
-      if (MODE == 2) {
+      if (gdact) {
+        const bf16x4 xx = *reinterpret_cast<const bf16x4*>(cell);
+        const bool live = FULL || (ic + r < g.I);             // (clamped rows of an edge tile carry no gate gradient)
+        if (g.gate_pos == EVLM_GATE_PRE_ACT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float hv = (float)xx[e];
+            const float t = v[e] * act_grad_fast(dact, hv * gz[a][e]);
+            v[e] = t * gz[a][e];
+            if (live) dgs[a][e] = fmaf(t, hv, dgs[a][e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float hv = (float)xx[e];
+            if (live) dgs[a][e] = fmaf(v[e], act_apply_fast(dact, hv), dgs[a][e]);
+            v[e] = v[e] * act_grad_fast(dact, hv) * gz[a][e];
+          }
+        }
+      } else if (MODE == 2) {
         if (gated && g.gate_pos == EVLM_GATE_PRE_ACT) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= gz[a][e];
@@ -162,7 +189,8 @@ __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4],
 // 2 residual
 template <bool FULL, int MODE, bool GATED, int XM, int ACT, int DACT, bool SKP>
 __device__ __forceinline__ void pp_epi_half(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4],
-                                            int ib, int jb, int lane, char* sw, bf16* dst, int ldd, const PPSk& sk) {
+                                            int ib, int jb, int lane, char* sw, bf16* dst, int ldd, const PPSk& sk,
+                                            f32x4* dgs = nullptr) {
   constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && XM == 2;
   // (rows are requested per 64-row half: requesting all four chunks of the tile up front - 64 registers - was measured
   // SLOWER, 12.7 k against 10.6 k cycles per tile, the extra registers spill around the epilogue)
@@ -172,8 +200,8 @@ __device__ __forceinline__ void pp_epi_half(const GemmP& g, f32x4 (&acc)[4][4], 
     x0 = pp_epi_rows<FULL>(g, xb, ib, jb, lane);
     x1 = pp_epi_rows<FULL>(g, xb, ib + 32, jb, lane);
   }
-  pp_epi_chunk<FULL, MODE, GATED, XM, ACT, DACT, SKP>(g, acc, bz, 0, x0, ib, jb, lane, sw, dst, ldd, sk);
-  pp_epi_chunk<FULL, MODE, GATED, XM, ACT, DACT, SKP>(g, acc, bz, 2, x1, ib + 32, jb, lane, sw, dst, ldd, sk);
+  pp_epi_chunk<FULL, MODE, GATED, XM, ACT, DACT, SKP>(g, acc, bz, 0, x0, ib, jb, lane, sw, dst, ldd, sk, dgs);
+  pp_epi_chunk<FULL, MODE, GATED, XM, ACT, DACT, SKP>(g, acc, bz, 2, x1, ib + 32, jb, lane, sw, dst, ldd, sk, dgs);
 }
 
 __device__ __forceinline__ PPSk pp_sk_high(const PPSk& sk) {      // the slot addresses of the H half (i rows 64..127)
@@ -184,26 +212,50 @@ __device__ __forceinline__ PPSk pp_sk_high(const PPSk& sk) {      // the slot ad
 // 32 more rows (i fragments 0, 1 of `acc`): the 192 x 256 tile flavour's third piece
 template <bool FULL, int MODE, bool GATED, int XM, int ACT, int DACT>
 __device__ __forceinline__ void pp_epi_third(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4],
-                                             int ib, int jb, int lane, char* sw, bf16* dst, int ldd) {
+                                             int ib, int jb, int lane, char* sw, bf16* dst, int ldd, f32x4* dgs = nullptr) {
   constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && XM == 2;
   PPRows x0;
   if (need_h || need_r) x0 = pp_epi_rows<FULL>(g, reinterpret_cast<const bf16*>(need_h ? g.aux : g.residual), ib, jb, lane);
-  pp_epi_chunk<FULL, MODE, GATED, XM, ACT, DACT, false>(g, acc, bz, 0, x0, ib, jb, lane, sw, dst, ldd, PPSk{nullptr, 0});
+  pp_epi_chunk<FULL, MODE, GATED, XM, ACT, DACT, false>(g, acc, bz, 0, x0, ib, jb, lane, sw, dst, ldd, PPSk{nullptr, 0}, dgs);
 }
 // HI: 0 = the wave owns 64 rows (accL), 1 = 128 rows (accL, accH), 2 = 96 rows (accL + i fragments 0, 1 of accH)
 template <bool FULL, bool GATED, int XM, int ACT, int DACT, bool SKP, int HI>
 __device__ __forceinline__ void pp_epi_c(const GemmP& g, f32x4 (&accL)[4][4], f32x4 (&accH)[4][4], const f32x4 (&bz)[4], int ib,
                                          int jb, int lane, char* sw, const PPSk& sk) {
-  pp_epi_half<FULL, 2, GATED, XM, ACT, DACT, SKP>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc, sk);
+  constexpr bool gdact = GATED && XM == 1;
+  f32x4 dgs[gdact ? 4 : 1];
+  if (gdact) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) dgs[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4* dp = gdact ? dgs : nullptr;
+  pp_epi_half<FULL, 2, GATED, XM, ACT, DACT, SKP>(g, accL, bz, ib, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc, sk, dp);
   if (HI == 1)
     pp_epi_half<FULL, 2, GATED, XM, ACT, DACT, SKP>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc,
-                                                    pp_sk_high(sk));
+                                                    pp_sk_high(sk), dp);
   if (HI == 2)
-    pp_epi_third<FULL, 2, GATED, XM, ACT, DACT>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc);
+    pp_epi_third<FULL, 2, GATED, XM, ACT, DACT>(g, accH, bz, ib + 64, jb, lane, sw, reinterpret_cast<bf16*>(g.C), g.ldc, dp);
+  if (gdact) {
+    // the wave's column sums: lanes il = 0..15 of one column quad hold different rows - reduce over them, then one f32 atomic
+    // per column from the lane with il == 0 (64 columns per wave and tile; a column collects one atomic per row block)
+    const int il = lane & 15, jl = (lane >> 4) * 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = dgs[a][e];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        const int j = jb + a * 16 + jl + e;
+        if (il == 0 && (FULL || j < g.J)) atomicAdd(g.dgate + j, v);
+      }
+  }
 }
 
 // HI = 0: the wave owns a 64 x 64 block only (128 x 256 tile flavour: accH is not touched); 2: 96 x 64 (192 x 256 flavour)
-template <bool FULL, bool SKP = false, int HI = 1>
+// GD: the kernel instantiation that serves the gated activation backward (evlm_gemm_args.dgate) - a SEPARATE instantiation
+// (gemm_bf16_pp192_kernel<QT, true>): compiled into the shared kernels the flavour's 16 column-sum registers pushed the
+// 256-row kernel over 256 VGPRs (37-47 spilled registers in the kernel that carries a third of the step's GEMM time).
+template <bool FULL, bool SKP = false, int HI = 1, bool GD = false>
 __device__ __forceinline__ void pp_epilogue(const GemmP& g, f32x4 (&accL)[4][4], f32x4 (&accH)[4][4], int ib, int jb, int lane,
                                             char* sw, const PPSk& sk = PPSk{nullptr, 0}) {
   f32x4 bz[4];
@@ -219,6 +271,10 @@ __device__ __forceinline__ void pp_epilogue(const GemmP& g, f32x4 (&accL)[4][4],
   // one instantiation per epilogue flavour (ONE wave-uniform dispatch per tile): the plain one carries neither gate nor
   // row registers, and every flavour of the training path has its activation code as a compile-time constant
   constexpr int G = EVLM_ACT_GELU, QG = EVLM_ACT_QUICK_GELU, N = EVLM_ACT_NONE;
+  if (GD) {                          // backward of the L0-gated activation (round 5): dH and the gate gradient, run-time codes
+    pp_epi_c<FULL, true, 1, N, -1, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+    return;
+  }
   if (g.gate) {                      // L0-gated FFN (pruning fine-tune only): activation code read at run time
     if (g.residual) pp_epi_c<FULL, true, 2, -1, N, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
     else pp_epi_c<FULL, true, 0, -1, N, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);

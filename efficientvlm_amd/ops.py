@@ -241,13 +241,13 @@ def _sk_workspace(dev):
 
 def _gemm(dtype, P, Q, Cm, I, J, K, ldp, ldq, ldc, p_trans=0, q_trans=0, bias=None, gate=None, preact=None,
           aux=None, residual=None, ldx=0, alpha=1.0, act=L.ACT_NONE, gate_pos=L.GATE_PRE, dact=L.ACT_NONE, c_f32=0,
-          accumulate=0, p_off=0, psum=None):
+          accumulate=0, p_off=0, psum=None, dgate=None):
     Pp = L.ptr(P) if not p_off else C.c_void_p(P.data_ptr() + p_off * P.element_size())
     a = L.GemmArgs(dtype=dtype, c_f32=c_f32, p_trans=p_trans, q_trans=q_trans, I=I, J=J, K=K, ldp=ldp, ldq=ldq,
                    ldc=ldc, ldx=ldx, P=Pp, Q=L.ptr(Q), C=L.ptr(Cm), bias=L.ptr(bias), gate=L.ptr(gate),
                    preact=L.ptr(preact), aux=L.ptr(aux), residual=L.ptr(residual), alpha=alpha, act=act,
-                   gate_pos=gate_pos, dact=dact, accumulate=accumulate, psum=L.ptr(psum))
-    if _SK_ON and dtype == L.BF16 and not c_f32 and not p_trans and K >= 512 and I * J >= 16 * 65536:
+                   gate_pos=gate_pos, dact=dact, accumulate=accumulate, psum=L.ptr(psum), dgate=L.ptr(dgate))
+    if _SK_ON and dgate is None and dtype == L.BF16 and not c_f32 and not p_trans and K >= 512 and I * J >= 16 * 65536:
         a.sk_workspace = L.ptr(_sk_workspace(P.device))     # (shapes stream-K can apply to: gemm_pp256.hip)
     if GEMM_PROFILE is None:
         L.check(_lib().evlm_gemm(C.byref(a), L.stream()), "gemm")
@@ -806,12 +806,17 @@ class _MLP(torch.autograd.Function):
             # dH = (dY W2) .* act'(h), fused into the GEMM epilogue
             _gemm(dtype, d2, Q2, dh, M, Fh, N, N, ld2, Fh, aux=h, ldx=Fh, dact=act, **q2)
         else:
-            da = torch.empty((M, Fh), dtype=x2.dtype, device=dev)
-            _gemm(dtype, d2, Q2, da, M, Fh, N, N, ld2, Fh, **q2)
             gslot = ctx.gate_slot if (ctx.gate_slot is not None and ctx.gate_slot[0].row(ctx.gate_slot[1]).numel() == Fh) else None
             dg = gslot[0].row(gslot[1]) if gslot is not None else torch.zeros(Fh, dtype=torch.float32, device=dev)
-            L.check(lib.evlm_gated_act_bwd(dtype, L.ptr(da), L.ptr(h), L.ptr(g32), M, Fh, Fh, act, gate_pos, L.ptr(dh),
-                                           L.ptr(dg), L.stream()), "gated_act_bwd")
+            if bf and N % 64 == 0 and N >= 128 and Fh % 8 == 0 and not _NO_GATED_DACT_FOLD:
+                # round 5: dH = (dY W2) act'(.) z AND the gate gradient in the dX product's epilogue (evlm_gemm_args.dgate) -
+                # no dA round trip through HBM, no second pass over [rows, ffn]
+                _gemm(dtype, d2, Q2, dh, M, Fh, N, N, ld2, Fh, aux=h, ldx=Fh, dact=act, gate=g32, gate_pos=gate_pos, dgate=dg, **q2)
+            else:
+                da = torch.empty((M, Fh), dtype=x2.dtype, device=dev)
+                _gemm(dtype, d2, Q2, da, M, Fh, N, N, ld2, Fh, **q2)
+                L.check(lib.evlm_gated_act_bwd(dtype, L.ptr(da), L.ptr(h), L.ptr(g32), M, Fh, Fh, act, gate_pos, L.ptr(dh),
+                                               L.ptr(dg), L.stream()), "gated_act_bwd")
             dgate = gslot[0].take(gslot[1], gshape) if gslot is not None else dg.view(gshape)
         w1, b1, w2, b2 = ctx.params
         (dW2,), (db2,) = _wgrad(dtype, d2, N, a, Fh, M, Fh, (w2,), (N,), (b2,))
@@ -1333,6 +1338,10 @@ def gate_rows(z):
 
 
 _NO_GATE_SLOTS = bool(os.environ.get("EVLM_NO_GATE_SLOTS"))
+# evlm_gemm_args.dgate (the gated activation backward inside the dX product's epilogue) is OPT-IN, EVLM_GATED_DACT_FOLD=1:
+# same-box A/B x3 (profiles/r05_pruning_residue.md) ITR-384 36.39 vs 36.43 ms, VQA-480 32.01 vs 31.95 ms - the 192-row
+# kernel that hosts the flavour costs on these products what the saved pass over [rows, ffn] was worth
+_NO_GATED_DACT_FOLD = not os.environ.get("EVLM_GATED_DACT_FOLD")
 
 
 class KVGradSlot:

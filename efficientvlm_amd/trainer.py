@@ -18,6 +18,7 @@ MI355X-first execution
 import os
 import contextlib
 import gc
+import time
 
 import torch
 import torch.distributed as dist
@@ -31,6 +32,25 @@ def dist_ready():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+_QUIESCE_S = float(os.environ.get("EVLM_CAPTURE_QUIESCE_MS", "300")) / 1e3
+
+
+def _quiesce_collectives():
+    """before a hipGraph capture in a process with an RCCL group: no collective of an EARLIER step may still be on the
+    process group's watchdog list.  The watchdog thread polls the end event of every unfinished Work (every 100 ms); on
+    this stack such a hipEventQuery, when it lands while a stream of this process captures, can fail with
+    hipErrorCapturedEvent ("operation not permitted on an event last recorded in a capturing stream") and the watchdog
+    then terminates the process (seen in 2 of 3 runs of the ITR segment capture after round 5's teacher-recipe change
+    moved the captures' timing; profiles/r05_capture_watchdog.md).  Captures happen a bounded number of times per
+    trainer, so draining the device and giving the watchdog three polls to retire the finished Works costs ~0.3 s each."""
+    if _QUIESCE_S <= 0 or not torch.cuda.is_available() or not dist.is_available() or not dist.is_initialized():
+        return
+    if dist.get_backend() != "nccl":
+        return
+    torch.cuda.synchronize()
+    time.sleep(_QUIESCE_S)
+
+
 @contextlib.contextmanager
 def no_gc_during_capture():
     """around a hipGraph capture: the cyclic garbage collector must not run inside it.  A collection that fires during a
@@ -41,6 +61,7 @@ def no_gc_during_capture():
     Everything collectable is collected before the capture starts."""
     was = gc.isenabled()
     gc.collect()
+    _quiesce_collectives()
     gc.disable()
     try:
         yield

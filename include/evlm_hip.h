@@ -77,6 +77,13 @@ typedef struct {
                            the calls of ONE stream at a time: lets bf16 products whose 256x256 tiles fill only part of
                            the chip be cut along K as well (stream-K: partial accumulators + flags live here; the
                            kernel leaves the flags zero again).  NULL: never cut */
+  float* dgate;         /* ABI 8, optional [J] f32, ACCUMULATED - the backward of an L0-GATED activation folded into the dX product
+                           (CLIP MLP fc1 * mlp_z before quick_gelu, eff_vit.py:214-220; BERT gelu(dense) * mlp_z, eff_bert.py:
+                           552-557): with gate [J], aux = the pre-activation rows h [I, J] and dact, the epilogue turns the
+                           product dA = P Q^T into  dH = dA act'(h z) z  (gate_pos PRE)  /  dA act'(h) z  (POST)  and adds the
+                           gate gradient  sum_rows dA act'(h z) h  /  sum_rows dA act(h)  to dgate.  bf16, no bias / residual /
+                           preact, a product the 256-column ping-pong kernels take (K % 64 == 0, K >= 128, J, ldc, ldx % 8 == 0,
+                           P not transposed); replaces a second pass over [I, J] (evlm_gated_act_bwd) */
 } evlm_gemm_args;
 #define EVLM_GEMM_SK_WORKSPACE_BYTES (4096 + 256 * 262144)
 

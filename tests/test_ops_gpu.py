@@ -161,6 +161,51 @@ def test_mlp_block(dtype, act_name, gate_pos, with_gate):
         assert rel_err(gate.grad, gr.grad) < t
 
 
+@pytest.mark.parametrize("M,K,Fh", [(1154, 768, 3072), (3 * 197, 384, 1536), (70, 128, 264)])
+@pytest.mark.parametrize("act_name,gate_pos", [("quick_gelu", 0), ("gelu", 1)])
+def test_gated_activation_backward_in_the_gemm_epilogue(M, K, Fh, act_name, gate_pos, monkeypatch):
+    """Round 5: the backward of the L0-gated FFN activation (dH = (dY W2) act'(.) z and the gate gradient sum_rows(dA .
+    d a/d z), eff_vit.py:213-224 / eff_bert.py intermediate gates) runs in the dX product's epilogue
+    (evlm_gemm_args.dgate, gemm_bf16_pp192_kernel<*, true>) - against the separate evlm_gated_act_bwd pass it replaces
+    (which rounds dA to bf16 first) and against plain fp32 autograd, at ragged row counts and a ragged column tile"""
+    o = ops()
+    from efficientvlm_amd import _lib as L
+    act = L.ACT_QUICK_GELU if act_name == "quick_gelu" else L.ACT_GELU
+    fn = (lambda t: t * torch.sigmoid(1.702 * t)) if act_name == "quick_gelu" else F.gelu
+    g = torch.Generator().manual_seed(77)
+    x0 = rnd((1, M, K), torch.bfloat16, g)
+    w1 = torch.nn.Parameter(rnd((Fh, K), torch.float32, g, 0.05)); b1 = torch.nn.Parameter(rnd((Fh,), torch.float32, g, 0.1))
+    w2 = torch.nn.Parameter(rnd((K, Fh), torch.float32, g, 0.05)); b2 = torch.nn.Parameter(rnd((K,), torch.float32, g, 0.1))
+    gate0 = (torch.rand(1, 1, Fh, generator=g).to(DEV) * 1.3).clamp(0, 1)      # (some gates exactly 0 and 1, as hard-concrete gives)
+    go = rnd((1, M, K), torch.bfloat16, g)
+
+    def run(fold):
+        monkeypatch.setattr(o, "_NO_GATED_DACT_FOLD", not fold)
+        x, gate = x0.clone().requires_grad_(True), gate0.clone().requires_grad_(True)
+        for p in (w1, b1, w2, b2): p.grad = None
+        o.GEMM_PROFILE = prof = []
+        try:
+            o.mlp(x, w1, b1, w2, b2, act, gate=gate, gate_pos=gate_pos, residual=x).backward(go)
+        finally:
+            o.GEMM_PROFILE = None
+        return x.grad.float(), gate.grad.clone(), w1.grad.clone(), b1.grad.clone(), prof
+
+    folded, separate = run(True), run(False)
+    assert any("gated dact" in str(r) for r in folded[4]), folded[4]
+    assert not any("gated dact" in str(r) for r in separate[4])
+    xr = x0.float().requires_grad_(True); gr = gate0.clone().requires_grad_(True)
+    ps = [p.detach().bfloat16().float().requires_grad_(True) if p.dim() == 2 else p.detach().clone().requires_grad_(True) for p in (w1, b1, w2, b2)]
+    h = F.linear(xr, ps[0], ps[1])
+    a = fn(h * gr) if gate_pos == 0 else fn(h) * gr
+    (F.linear(a, ps[2], ps[3]) + xr).backward(go.float())
+    ref = (xr.grad, gr.grad, ps[0].grad, ps[1].grad)
+    for name, f_, s_, r_ in zip(("dx", "dgate", "dW1", "db1"), folded, separate, ref):
+        # the folded path skips one bf16 rounding (dA), so it may not be further from fp32 autograd than the separate pass
+        ef, es = rel_err(f_.float(), r_), rel_err(s_.float(), r_)
+        assert ef < 2e-2 and ef <= es * 1.25 + 1e-4, (name, ef, es)
+        assert rel_err(f_.float(), s_.float()) < 2e-2, name
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("d,eps", [(64, 1e-12), (768, 1e-5), (1536, 1e-5)])
 def test_layernorm(dtype, d, eps):
