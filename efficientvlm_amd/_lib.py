@@ -86,13 +86,13 @@ SIGNATURES = {
     "evlm_mse_fwd": [_i, _vp, _i, _vp, _i64, _f, _vp, _vp],
     "evlm_mse_bwd": [_i, _vp, _i, _vp, _i64, _f, _vp, _vp, _vp],
     "evlm_ce_fwd": [_i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp],
-    "evlm_ce_bwd": [_i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _vp],
+    "evlm_ce_bwd": [_i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evlm_transpose_grouped": [_vp, _i, _i, _vp],
     "evlm_copy_grouped": [_vp, _i, _i, _vp],
     "evlm_ce_weighted_fwd": [_i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp],
-    "evlm_ce_weighted_bwd": [_i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _vp],
+    "evlm_ce_weighted_bwd": [_i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evlm_kl_fwd": [_i, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
-    "evlm_kl_bwd": [_i, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _i, _vp],
+    "evlm_kl_bwd": [_i, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evlm_log_softmax_fwd": [_i, _vp, _i, _i, _i, _vp, _i, _vp],
     "evlm_log_softmax_bwd": [_i, _vp, _vp, _i, _i, _i, _vp, _vp],
     "evlm_bert_embed_fwd": [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
@@ -116,7 +116,11 @@ SIGNATURES = {
     "evlm_dropout_mask": [_i64, _f, _vp, C.c_uint32, _vp, _vp],
     "evlm_layernorm_bwd_reduce_grouped": [_vp, _i, _i, _vp],
     "evlm_mse_grouped": [_i, _i, _vp, _i, _i, _vp],
-    "evlm_sample_negatives": [_vp, _i, _i, _vp, _vp, _vp, C.c_uint32, _vp, _vp],
+    "evlm_sample_negatives": [_vp, _i, _i, _vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp],
+    "evlm_select_batches_fwd": [_vp, _vp, _i, C.c_int64, _vp, _vp],
+    "evlm_select_batches_bwd": [_i, _vp, _vp, _i, _i, C.c_int64, _vp, _vp],
+    "evlm_itc_loss_fwd": [_i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "evlm_itc_loss_bwd": [_i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "evlm_sumsq": [_vp, _i64, _vp, _vp, _vp],
     "evlm_adamw_step": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _vp, _vp, _vp],
 }

@@ -247,14 +247,15 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
                                                      const int64_t* __restrict__ labels, int ignore_index, float weight,
                                                      const float* __restrict__ lse, const int32_t* __restrict__ valid,
                                                      const float* __restrict__ gout, const float* __restrict__ roww,
-                                                     T* __restrict__ dl, int ldd) {
+                                                     T* __restrict__ dl, int ldd, int acc) {
   const int r = blockIdx.x;
   const int64_t lb = labels[r];
   const T* x = logits + (size_t)r * ld;
   T* d = dl + (size_t)r * ldd;
   // (the padding columns C .. ldd-1 of a gradient row are written here too - zeros: the caller allocates, never fills)
+  // acc: dl already holds another loss's gradient of the same logits (ops.join_grads) - this one is added to it
   if (lb == ignore_index) {
-    for (int c = threadIdx.x; c < ldd; c += blockDim.x) d[c] = from_f<T>(0.f);
+    if (!acc) for (int c = threadIdx.x; c < ldd; c += blockDim.x) d[c] = from_f<T>(0.f);
     return;
   }
   float g = roww ? gout[0] * weight * roww[r] : gout[0] * weight / (float)valid[0];
@@ -267,11 +268,17 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
     load8<T>(x + c * 8, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = g * (__expf(v[e] - l) - ((c * 8 + e) == lb ? 1.f : 0.f));
+    if (acc) {
+      float o[8];
+      load8<T>(d + c * 8, o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += o[e];
+    }
     store8<T>(d + c * 8, v);
   }
-  for (int c = nv * 8 + threadIdx.x; c < ldd; c += blockDim.x) {
+  for (int c = nv * 8 + threadIdx.x; c < (acc ? C : ldd); c += blockDim.x) {
     const float p = c < C ? __expf(to_f(x[c]) - l) : 0.f;
-    d[c] = from_f<T>(c < C ? g * (p - (c == lb ? 1.f : 0.f)) : 0.f);
+    d[c] = from_f<T>((c < C ? g * (p - (c == lb ? 1.f : 0.f)) : 0.f) + (acc ? to_f(d[c]) : 0.f));
   }
 }
 
@@ -298,21 +305,21 @@ extern "C" int evlm_ce_weighted_fwd(int dtype, const void* logits, int R, int C,
 }
 extern "C" int evlm_ce_weighted_bwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
                                     float weight, const float* row_weight, const float* lse, const float* gout,
-                                    void* dlogits, int ldd, void* stream_) {
+                                    void* dlogits, int ldd, int accumulate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(logits && labels && row_weight && lse && gout && dlogits, "evlm_ce_weighted_bwd: bad args");
   EVLM_DISPATCH_DTYPE(dtype, "evlm_ce_weighted_bwd",
-    hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(R), dim3(256), 0, stream, (const T*)logits, C, ld, labels, ignore_index, weight, lse, (const int32_t*)nullptr, gout, row_weight, (T*)dlogits, ldd);)
+    hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(R), dim3(256), 0, stream, (const T*)logits, C, ld, labels, ignore_index, weight, lse, (const int32_t*)nullptr, gout, row_weight, (T*)dlogits, ldd, accumulate);)
   EVLM_LAUNCH_CHECK("evlm_ce_weighted_bwd");
   return 0;
 }
 extern "C" int evlm_ce_bwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
                            float weight, const float* lse, const int32_t* valid_count, const float* gout,
-                           void* dlogits, int ldd, void* stream_) {
+                           void* dlogits, int ldd, int accumulate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(logits && labels && lse && valid_count && gout && dlogits, "evlm_ce_bwd: bad args");
   EVLM_DISPATCH_DTYPE(dtype, "evlm_ce_bwd",
-    hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(R), dim3(256), 0, stream, (const T*)logits, C, ld, labels, ignore_index, weight, lse, valid_count, gout, (const float*)nullptr, (T*)dlogits, ldd);)
+    hipLaunchKernelGGL((ce_bwd_kernel<T>), dim3(R), dim3(256), 0, stream, (const T*)logits, C, ld, labels, ignore_index, weight, lse, valid_count, gout, (const float*)nullptr, (T*)dlogits, ldd, accumulate);)
   EVLM_LAUNCH_CHECK("evlm_ce_bwd");
   return 0;
 }
@@ -357,7 +364,7 @@ template <typename TS, typename TT>
 __global__ __launch_bounds__(256) void kl_bwd_kernel(const TS* __restrict__ s, int lds_, const TT* __restrict__ t, int ldt,
                                                      int C, float it, float coef, const float* __restrict__ lse_s,
                                                      const float* __restrict__ lse_t, const float* __restrict__ gout,
-                                                     TS* __restrict__ ds, int ldds) {
+                                                     TS* __restrict__ ds, int ldds, int acc) {
   const int r = blockIdx.x;
   const TS* sr = s + (size_t)r * lds_;
   const TT* tr = t + (size_t)r * ldt;
@@ -371,10 +378,16 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(const TS* __restrict__ s, i
     load8<TT>(tr + c * 8, tv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) sv[e] = g * (__expf(sv[e] * it - ls) - __expf(tv[e] * it - lt));
+    if (acc) {                                                       // (added to another loss's gradient of the same logits)
+      float o[8];
+      load8<TS>(dr + c * 8, o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sv[e] += o[e];
+    }
     store8<TS>(dr + c * 8, sv);
   }
-  for (int c = nv * 8 + threadIdx.x; c < ldds; c += blockDim.x)     // (+ the padding columns: zeros, never filled by the caller)
-    dr[c] = from_f<TS>(c < C ? g * (__expf(to_f(sr[c]) * it - ls) - __expf(to_f(tr[c]) * it - lt)) : 0.f);
+  for (int c = nv * 8 + threadIdx.x; c < (acc ? C : ldds); c += blockDim.x)     // (+ the padding columns: zeros, never filled by the caller)
+    dr[c] = from_f<TS>((c < C ? g * (__expf(to_f(sr[c]) * it - ls) - __expf(to_f(tr[c]) * it - lt)) : 0.f) + (acc ? to_f(dr[c]) : 0.f));
 }
 extern "C" int evlm_kl_fwd(int dtype_s, const void* s, int lds_, int dtype_t, const void* t, int ldt, int R, int C,
                            float inv_t, float weight, float* lse_s, float* lse_t, float* loss, void* stream_) {
@@ -388,12 +401,12 @@ extern "C" int evlm_kl_fwd(int dtype_s, const void* s, int lds_, int dtype_t, co
 }
 extern "C" int evlm_kl_bwd(int dtype_s, const void* s, int lds_, int dtype_t, const void* t, int ldt, int R, int C,
                            float inv_t, float weight, const float* lse_s, const float* lse_t, const float* gout,
-                           void* ds, int ldds, void* stream_) {
+                           void* ds, int ldds, int accumulate, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(s && t && lse_s && lse_t && gout && ds, "evlm_kl_bwd: bad args");
   const float coef = weight / (float)R;
   DISPATCH2(dtype_s, dtype_t, "evlm_kl_bwd",
-    hipLaunchKernelGGL((kl_bwd_kernel<TA, TB>), dim3(R), dim3(256), 0, stream, (const TA*)s, lds_, (const TB*)t, ldt, C, inv_t, coef, lse_s, lse_t, gout, (TA*)ds, ldds);)
+    hipLaunchKernelGGL((kl_bwd_kernel<TA, TB>), dim3(R), dim3(256), 0, stream, (const TA*)s, lds_, (const TB*)t, ldt, C, inv_t, coef, lse_s, lse_t, gout, (TA*)ds, ldds, accumulate);)
   EVLM_LAUNCH_CHECK("evlm_kl_bwd");
   return 0;
 }
@@ -522,6 +535,190 @@ extern "C" int evlm_adamw_step(float* p, const float* g, float* m, float* v, int
   return 0;
 }
 
+// ---- ITC loss (reference efficient_models/xvlm.py:384-416) in one launch each way ---------------------------------------
+// logits = I T^t / temp over the GATHERED batch, loss = (CE(logits, labels) + CE(logits^t, labels)) / 2 with labels the
+// identity (idx None) or pos / pos.sum(1) for pos[i,j] = (idx_i == idx_j).  Written with torch ops that is ~35 launches
+// of 4-7 us on [Bt, Bt] and [Bt, 256] tensors (two exact-fp32 GEMMs at 27 us each, two divisions by the temperature and
+// their six-launch backward, two cross-entropies, the gradient products) - a launch-latency chain on the student's
+// critical path.  Here one wave per batch row i forms BOTH its row of the logits (image i against every text) and its
+// column (text i against every image) from the features in exact fp32, their log-sum-exps and label terms; the last
+// workgroup to arrive sums the row terms in a fixed order.  The backward's wave i rebuilds d logits[i, :] and
+// d logits[:, i] from the stored similarities and log-sum-exps and accumulates dI_i, dT_i and its share of d temp.
+// stats f32 [4 Bt + 8]: lse_row | lse_col | row term (fwd) / row share of d temp (bwd) | positives per row | arrival
+// counter (kept zero between launches) .
+#define ITC_EMAX 256
+template <typename T>
+__global__ __launch_bounds__(256) void itc_fwd_kernel(const T* __restrict__ I, int ldi, const T* __restrict__ Tx, int ldt,
+                                                      int Bt, int E, const float* __restrict__ temp,
+                                                      const int64_t* __restrict__ group, float* __restrict__ sim, int lds,
+                                                      float* __restrict__ stats, float* __restrict__ loss) {
+  __shared__ __attribute__((aligned(16))) float feat[4][2][ITC_EMAX];
+  __shared__ float red[16];
+  __shared__ int last;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = blockIdx.x * 4 + w;
+  const float it = 1.0f / temp[0];
+  if (i < Bt) {
+    for (int e = lane; e < E; e += 64) {
+      feat[w][0][e] = to_f(I[(int64_t)i * ldi + e]);
+      feat[w][1][e] = to_f(Tx[(int64_t)i * ldt + e]);
+    }
+  }
+  __syncthreads();
+  if (i < Bt) {
+    const int64_t gi = group ? group[i] : 0;
+    float mr = -INFINITY, zr = 0.f, mc = -INFINITY, zc = 0.f, lr = 0.f, lc = 0.f, cnt = 0.f;
+    for (int c = 0; c < Bt; c += 64) {
+      const int j = c + lane;
+      if (j >= Bt) continue;
+      const T* tj = Tx + (int64_t)j * ldt;
+      const T* ij = I + (int64_t)j * ldi;
+      float sr = 0.f, sc = 0.f;
+      for (int e = 0; e < E; e += 8) {
+        float a[8], b[8];
+        load8<T>(tj + e, a);
+        load8<T>(ij + e, b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          sr = fmaf(feat[w][0][e + k], a[k], sr);
+          sc = fmaf(feat[w][1][e + k], b[k], sc);
+        }
+      }
+      sim[(int64_t)i * lds + j] = sr;
+      const float xr = sr * it, xc = sc * it;
+      if (xr > mr) { zr = zr * __expf(mr - xr) + 1.f; mr = xr; } else zr += __expf(xr - mr);
+      if (xc > mc) { zc = zc * __expf(mc - xc) + 1.f; mc = xc; } else zc += __expf(xc - mc);
+      if (group ? group[j] == gi : j == i) { lr += xr; lc += xc; cnt += 1.f; }
+    }
+    const float Mr = wave_max(mr), Mc = wave_max(mc);
+    zr = wave_sum(zr * __expf(mr - Mr));
+    zc = wave_sum(zc * __expf(mc - Mc));
+    lr = wave_sum(lr); lc = wave_sum(lc); cnt = wave_sum(cnt);
+    const float lse_r = Mr + logf(zr), lse_c = Mc + logf(zc);
+    if (lane == 0) {
+      stats[i] = lse_r;
+      stats[Bt + i] = lse_c;
+      stats[3 * Bt + i] = cnt;
+      const float term = (lse_r - lr / cnt) + (lse_c - lc / cnt);
+      const float old = __hip_atomic_exchange(stats + 2 * Bt + i, term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" :: "v"(old) : "memory");
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    last = __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(stats + 4 * Bt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  float t = 0.f;
+  for (int b = threadIdx.x; b < Bt; b += blockDim.x) t += __hip_atomic_load(stats + 2 * Bt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = block_sum(t, red);
+  if (threadIdx.x == 0) {
+    loss[0] = t / (2.0f * (float)Bt);
+    atomicExch(reinterpret_cast<unsigned int*>(stats + 4 * Bt), 0u);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void itc_bwd_kernel(const T* __restrict__ I, int ldi, const T* __restrict__ Tx, int ldt,
+                                                      int Bt, int E, const float* __restrict__ temp,
+                                                      const int64_t* __restrict__ group, const float* __restrict__ sim, int lds,
+                                                      float* __restrict__ stats, const float* __restrict__ dloss,
+                                                      T* __restrict__ dI, int lddi, T* __restrict__ dT, int lddt,
+                                                      float* __restrict__ dtemp) {
+  extern __shared__ float coef[];                 // [4 waves][2][Bt]: d logits[i, :] and d logits[:, i]
+  __shared__ float red[16];
+  __shared__ int last;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = blockIdx.x * 4 + w;
+  const float it = 1.0f / temp[0], g = dloss[0] / (2.0f * (float)Bt);
+  float* ca = coef + (size_t)w * 2 * Bt;
+  float* cb = ca + Bt;
+  if (i < Bt) {
+    const int64_t gi = group ? group[i] : 0;
+    const float lse_ri = stats[i], lse_ci = stats[Bt + i], ici = 1.0f / stats[3 * Bt + i];
+    float dt = 0.f;
+    for (int c = 0; c < Bt; c += 64) {
+      const int j = c + lane;
+      if (j >= Bt) continue;
+      const float sij = sim[(int64_t)i * lds + j], sji = sim[(int64_t)j * lds + i];
+      const bool pos = group ? group[j] == gi : j == i;
+      const float Lij = pos ? ici : 0.f, Lji = pos ? 1.0f / stats[3 * Bt + j] : 0.f;
+      // d loss / d logits[i, j]: row i's softmax over j (image-to-text) + column j's softmax over i (text-to-image)
+      const float a = g * ((__expf(sij * it - lse_ri) - Lij) + (__expf(sij * it - stats[Bt + j]) - Lji));
+      const float b = g * ((__expf(sji * it - stats[j]) - Lji) + (__expf(sji * it - lse_ci) - Lij));
+      ca[j] = a; cb[j] = b;
+      dt = fmaf(a, sij, dt);
+    }
+    dt = wave_sum(dt);
+    if (lane == 0) {
+      const float old = __hip_atomic_exchange(stats + 2 * Bt + i, dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" :: "v"(old) : "memory");
+    }
+    // (the coefficients were written and are read by this wave only: LDS operations of one wave complete in order)
+    __builtin_amdgcn_wave_barrier();
+    const int e = lane * 4;
+    if (e < E) {
+      float aI[4] = {0.f, 0.f, 0.f, 0.f}, aT[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < Bt; ++j) {
+        float t[4], x[4];
+        Vec4<T>::load(Tx + (int64_t)j * ldt + e, t);
+        Vec4<T>::load(I + (int64_t)j * ldi + e, x);
+        const float a = ca[j], b = cb[j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { aI[k] = fmaf(a, t[k], aI[k]); aT[k] = fmaf(b, x[k], aT[k]); }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { aI[k] *= it; aT[k] *= it; }
+      Vec4<T>::store(dI + (int64_t)i * lddi + e, aI);
+      Vec4<T>::store(dT + (int64_t)i * lddt + e, aT);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    last = __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(stats + 4 * Bt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  float t = 0.f;
+  for (int b = threadIdx.x; b < Bt; b += blockDim.x) t += __hip_atomic_load(stats + 2 * Bt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = block_sum(t, red);
+  if (threadIdx.x == 0) {
+    dtemp[0] = -t * it * it;                      // logits = sim / temp: d/d temp = -sim / temp^2
+    atomicExch(reinterpret_cast<unsigned int*>(stats + 4 * Bt), 0u);
+  }
+}
+static bool itc_args_ok(int dtype, const void* I, int ldi, const void* Tx, int ldt, int Bt, int E) {
+  const int al = dtype == EVLM_BF16 ? 8 : 4;          // 16-byte rows
+  return (dtype == EVLM_BF16 || dtype == EVLM_F32) && I && Tx && Bt > 0 && E > 0 && E <= ITC_EMAX && E % 8 == 0 && ldi >= E &&
+         ldt >= E && ldi % al == 0 && ldt % al == 0 && ((uintptr_t)I) % 16 == 0 && ((uintptr_t)Tx) % 16 == 0;
+}
+extern "C" int evlm_itc_loss_fwd(int dtype, const void* I, int ldi, const void* Tx, int ldt, int Bt, int E, const float* temp,
+                                 const int64_t* group, float* sim, int lds, float* stats, float* loss, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(itc_args_ok(dtype, I, ldi, Tx, ldt, Bt, E) && temp && sim && lds >= Bt && stats && loss,
+               "evlm_itc_loss_fwd: bad args (bf16 / f32 features, E <= 256 and a multiple of 8, 16-byte aligned rows)");
+  const dim3 grid(ceil_div(Bt, 4)), block(256);
+  if (dtype == EVLM_BF16)
+    hipLaunchKernelGGL(itc_fwd_kernel<bf16>, grid, block, 0, stream, (const bf16*)I, ldi, (const bf16*)Tx, ldt, Bt, E, temp, group, sim, lds, stats, loss);
+  else
+    hipLaunchKernelGGL(itc_fwd_kernel<float>, grid, block, 0, stream, (const float*)I, ldi, (const float*)Tx, ldt, Bt, E, temp, group, sim, lds, stats, loss);
+  EVLM_LAUNCH_CHECK("evlm_itc_loss_fwd");
+  return 0;
+}
+extern "C" int evlm_itc_loss_bwd(int dtype, const void* I, int ldi, const void* Tx, int ldt, int Bt, int E, const float* temp,
+                                 const int64_t* group, const float* sim, int lds, float* stats, const float* dloss,
+                                 void* dI, int lddi, void* dT, int lddt, float* dtemp, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(itc_args_ok(dtype, I, ldi, Tx, ldt, Bt, E) && temp && sim && lds >= Bt && stats && dloss && dI && dT && dtemp &&
+               lddi >= E && lddt >= E && lddi % 4 == 0 && lddt % 4 == 0 && Bt <= 4096,
+               "evlm_itc_loss_bwd: bad args (as evlm_itc_loss_fwd; gradient rows 4-element aligned, Bt <= 4096)");
+  const dim3 grid(ceil_div(Bt, 4)), block(256);
+  const size_t lds_bytes = (size_t)4 * 2 * Bt * sizeof(float);
+  if (dtype == EVLM_BF16)
+    hipLaunchKernelGGL(itc_bwd_kernel<bf16>, grid, block, lds_bytes, stream, (const bf16*)I, ldi, (const bf16*)Tx, ldt, Bt, E, temp, group, sim, lds, stats, dloss, (bf16*)dI, lddi, (bf16*)dT, lddt, dtemp);
+  else
+    hipLaunchKernelGGL(itc_bwd_kernel<float>, grid, block, lds_bytes, stream, (const float*)I, ldi, (const float*)Tx, ldt, Bt, E, temp, group, sim, lds, stats, dloss, (float*)dI, lddi, (float*)dT, lddt, dtemp);
+  EVLM_LAUNCH_CHECK("evlm_itc_loss_bwd");
+  return 0;
+}
+
 // ---- ITM hard-negative sampling (reference efficient_models/xvlm.py:422-458) ----------------------------------------
 // The reference draws, per text, one image from  softmax_i(sim[i,t] / temp) + 1e-5  with the positives zeroed, and per
 // image one text likewise - 2B host-synchronising torch.multinomial(...).item() calls.  Here: ONE launch, one wave per
@@ -531,7 +728,8 @@ extern "C" int evlm_adamw_step(float* p, const float* g, float* m, float* v, int
 __global__ __launch_bounds__(256) void sample_neg_kernel(const float* __restrict__ sim, int B, int ld,
                                                          const float* __restrict__ temp, const int64_t* __restrict__ group,
                                                          const int64_t* __restrict__ rng_state, uint32_t call,
-                                                         int64_t* __restrict__ out) {
+                                                         int64_t* __restrict__ out, int64_t* __restrict__ sel4,
+                                                         int32_t* __restrict__ img4) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= 2 * B) return;
   const bool t2i = row < B;
@@ -576,14 +774,27 @@ __global__ __launch_bounds__(256) void sample_neg_kernel(const float* __restrict
     acc += __shfl(inc, 63, 64);
   }
   if (pick < 0) pick = last;                                  // u rounded onto the total: the last admissible index
-  if (lane == 0) out[row] = pick;
+  if (lane == 0) {
+    out[row] = pick;
+    // the fusion pass's batch layout [pos B ; neg 2B (text x negative image | negative text x image) ; masked text B]:
+    // sel4 = rows of the text pass's [text ; masked text] output, img4 = the image every fusion row attends to
+    if (sel4 && img4) {
+      if (t2i) {                       // row r: the image drawn for text r
+        sel4[r] = r; sel4[B + r] = r; sel4[3 * B + r] = B + r;
+        img4[r] = r; img4[B + r] = pick; img4[2 * B + r] = r; img4[3 * B + r] = r;
+      } else {                         // row B + r: the text drawn for image r
+        sel4[2 * B + r] = pick;
+      }
+    }
+  }
 }
 extern "C" int evlm_sample_negatives(const float* sim, int B, int ld, const float* temp, const int64_t* group,
-                                     const int64_t* rng_state, uint32_t call_id, int64_t* out, void* stream_) {
+                                     const int64_t* rng_state, uint32_t call_id, int64_t* out, int64_t* sel4, int32_t* img4,
+                                     void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  EVLM_REQUIRE(sim && temp && rng_state && out && B > 0 && ld >= B, "evlm_sample_negatives: bad args");
+  EVLM_REQUIRE(sim && temp && rng_state && out && B > 0 && ld >= B && !sel4 == !img4, "evlm_sample_negatives: bad args");
   hipLaunchKernelGGL(sample_neg_kernel, dim3(ceil_div(2 * B, 4)), dim3(256), 0, stream, sim, B, ld, temp, group, rng_state,
-                     call_id, out);
+                     call_id, out, sel4, img4);
   EVLM_LAUNCH_CHECK("evlm_sample_negatives");
   return 0;
 }

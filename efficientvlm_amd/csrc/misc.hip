@@ -220,6 +220,55 @@ extern "C" int evlm_gather_rows_bwd(int dtype, const void* dout, const int64_t* 
   return 0;
 }
 
+// ---- whole-sample selection (the fusion pass's batch: [text ; text ; hard-negative text ; masked text]) ---------------
+// out[k] = x[sel[k]] for samples of `row_bytes` bytes (a multiple of 16): ONE launch where the reference's
+// cat([t, t, index_select(t, neg), m]) (models/model_pretrain.py:179-184 of this package; reference xvlm.py:436-458) is two,
+// and a DETERMINISTIC backward dx[r] = sum over {k : sel[k] == r} of dy[k] in ascending k, one launch, where autograd runs
+// a zero-fill, an atomic index_add and three element-wise adds.
+__global__ __launch_bounds__(256) void select_batches_fwd_kernel(const uint4* __restrict__ x, const int64_t* __restrict__ sel,
+                                                                 int64_t w16, uint4* __restrict__ out) {
+  const int k = blockIdx.y;
+  const uint4* src = x + sel[k] * w16;
+  uint4* dst = out + (int64_t)k * w16;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < w16; c += (int64_t)gridDim.x * blockDim.x) dst[c] = src[c];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void select_batches_bwd_kernel(const T* __restrict__ dy, const int64_t* __restrict__ sel,
+                                                                 int n, int64_t w8, T* __restrict__ dx) {
+  const int64_t r = blockIdx.y;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < w8; c += (int64_t)gridDim.x * blockDim.x) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < n; ++k)
+      if (sel[k] == r) {
+        float v[8];
+        load8<T>(dy + ((int64_t)k * w8 + c) * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      }
+    store8<T>(dx + (r * w8 + c) * 8, acc);
+  }
+}
+extern "C" int evlm_select_batches_fwd(const void* x, const int64_t* sel, int n, int64_t row_bytes, void* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(x && sel && out && n > 0 && n <= 65535 && row_bytes > 0 && row_bytes % 16 == 0 && ((uintptr_t)x) % 16 == 0 &&
+               ((uintptr_t)out) % 16 == 0, "evlm_select_batches_fwd: bad args (samples of a multiple of 16 bytes, 16-byte aligned)");
+  const int64_t w16 = row_bytes / 16;
+  hipLaunchKernelGGL(select_batches_fwd_kernel, dim3(imin(64, ceil_div(w16, 256)), n), dim3(256), 0, stream, (const uint4*)x, sel, w16, (uint4*)out);
+  EVLM_LAUNCH_CHECK("evlm_select_batches_fwd");
+  return 0;
+}
+extern "C" int evlm_select_batches_bwd(int dtype, const void* dy, const int64_t* sel, int n, int rows, int64_t row_elems, void* dx,
+                                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(dy && sel && dx && n > 0 && rows > 0 && rows <= 65535 && row_elems > 0 && row_elems % 8 == 0 &&
+               ((uintptr_t)dy) % 16 == 0 && ((uintptr_t)dx) % 16 == 0, "evlm_select_batches_bwd: bad args");
+  const int64_t w8 = row_elems / 8;
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_select_batches_bwd",
+    hipLaunchKernelGGL((select_batches_bwd_kernel<T>), dim3(imin(64, ceil_div(w8, 256)), rows), dim3(256), 0, stream, (const T*)dy, sel, n, w8, (T*)dx);)
+  EVLM_LAUNCH_CHECK("evlm_select_batches_bwd");
+  return 0;
+}
+
 // ---- dtype cast ---------------------------------------------------------------------------------
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t n) {
@@ -660,6 +709,14 @@ __global__ __launch_bounds__(256) void copy_grouped_kernel(const int64_t* __rest
   uint4* dst = reinterpret_cast<uint4*>(table[4 * u + 1]);
   const int64_t nvec = table[4 * u + 2] >> 4;
   const int64_t v0 = ((int64_t)blockIdx.x - table[4 * u + 3]) * 4096;
+  if (!src) {                          // a unit without a source is a ZERO FILL (ops.zero_grouped: a step's gradient ranges)
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+      const int64_t i = v0 + k * 256 + threadIdx.x;
+      if (i < nvec) dst[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    return;
+  }
 #pragma unroll 4
   for (int k = 0; k < 16; ++k) {
     const int64_t i = v0 + k * 256 + threadIdx.x;

@@ -239,6 +239,164 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
+// Round 5: the same arithmetic, software-pipelined.  The kernel above spends each trip in phases - loads, reduction, the
+// addend's loads, stores - with two waves per SIMD (177 VGPRs at d = 768) and nothing in flight while both reduce: 25 us
+// for 56 MB in the step (2.2 TB/s).  Here a wave owns ONE row per trip, keeps the row as LOADED (16-byte raw registers,
+// converted where used - twice - instead of 8 floats per chunk held across the reduction) and issues the NEXT row's x /
+// dy / addend loads before it touches the current one; gamma is read from LDS.  ~1/3 fewer registers, every load of a row
+// in flight behind the previous row's arithmetic.  EXTRA: the rare second addend / fused distillation teacher row, loaded
+// at the top of the row's trip.
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+  bf16x8 v;
+  __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ void get(float o[8]) const {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+  }
+  // (the compiler otherwise keeps the converted floats of the first pass alive across the row reduction for the second)
+  __device__ __forceinline__ void opaque() { asm volatile("" : "+v"(v)); }
+};
+template <> struct Raw8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const f32x4*>(p);
+    b = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ void get(float o[8]) const {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+  }
+  __device__ __forceinline__ void opaque() {}
+};
+template <typename T, int DCH, bool ADD, bool EXTRA>
+__global__ __launch_bounds__(256) void ln_bwd_pipe_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ addend,
+                                                          const T* __restrict__ addend2,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, int rows, int d, T* __restrict__ dx,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          float* __restrict__ partials, const T* __restrict__ kd_t,
+                                                          const float* __restrict__ kd_g, float kd_k) {
+  extern __shared__ __attribute__((aligned(16))) float sred[];   // [4 waves][2][d] column sums, then [d] gamma
+  float* gs = sred + 8 * (size_t)d;
+  for (int i = threadIdx.x; i < d; i += 256) gs[i] = gamma[i];
+  const float kdk = (EXTRA && kd_t) ? kd_k * kd_g[0] : 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = d >> 3;
+  float pg[DCH][8], pb[DCH][8];
+#pragma unroll
+  for (int u = 0; u < DCH; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pg[u][e] = 0.f; pb[u][e] = 0.f; }
+  __syncthreads();
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + wave;
+  Raw8<T> xn[DCH], dn[DCH], an[DCH];
+  float mun = 0.f, rsn = 0.f;
+  auto issue = [&](int r) {
+#pragma unroll
+    for (int u = 0; u < DCH; ++u) {
+      const int c = lane + 64 * u;
+      if (c < nchunk) {
+        xn[u].load(x + (size_t)r * d + c * 8);
+        dn[u].load(dy + (size_t)r * d + c * 8);
+        if (ADD) an[u].load(addend + (size_t)r * d + c * 8);
+      }
+    }
+    mun = mean[r]; rsn = rstd[r];
+  };
+  if (row < rows) issue(row);
+  for (; row < rows; row += stride) {
+    Raw8<T> xc[DCH], dc[DCH], ac[DCH], a2[DCH], kt[DCH];
+#pragma unroll
+    for (int u = 0; u < DCH; ++u) { xc[u] = xn[u]; dc[u] = dn[u]; if (ADD) ac[u] = an[u]; }
+    const float mu = mun, rs = rsn;
+    if (row + stride < rows) issue(row + stride);
+    if (EXTRA) {
+#pragma unroll
+      for (int u = 0; u < DCH; ++u) {
+        const int c = lane + 64 * u;
+        if (c < nchunk) {
+          if (addend2) a2[u].load(addend2 + (size_t)row * d + c * 8);
+          if (kd_t) kt[u].load(kd_t + (size_t)row * d + c * 8);
+        }
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < DCH; ++u) {
+      const int c = lane + 64 * u;
+      if (c < nchunk) {
+        float xv[8], dv[8], gm[8];
+        xc[u].get(xv); dc[u].get(dv);
+        load8<float>(gs + c * 8, gm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[e] - mu) * rs, gd = gm[e] * dv[e];
+          s1 += gd; s2 += gd * xh;
+          pg[u][e] += dv[e] * xh; pb[u][e] += dv[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int u = 0; u < DCH; ++u) { xc[u].opaque(); dc[u].opaque(); }
+    T* dxr = dx + (size_t)row * d;
+    const float irs = 1.0f / rs;
+#pragma unroll
+    for (int u = 0; u < DCH; ++u) {
+      const int c = lane + 64 * u;
+      if (c < nchunk) {
+        float xv[8], dv[8], gm[8], o[8];
+        xc[u].get(xv); dc[u].get(dv);
+        load8<float>(gs + c * 8, gm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[e] - mu) * rs;
+          o[e] = rs * (gm[e] * dv[e] - s1 - xh * s2);
+        }
+        if (ADD) {                    // the gradient that reaches x past this LayerNorm (residual branch): summed here
+          float ad[8];
+          ac[u].get(ad);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += ad[e];
+        }
+        if (EXTRA) {
+          if (addend2) {              // ... and a second one: the distillation term that reads x itself (the "tap")
+            float ad[8];
+            a2[u].get(ad);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += ad[e];
+          }
+          if (kd_t) {                 // ... or that term's gradient formed here (same expression as ln_bwd_kernel: x rebuilt from xhat)
+            float tv[8];
+            kt[u].get(tv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(kdk, fmaf((xv[e] - mu) * rs, irs, mu) - tv[e], o[e]);
+          }
+        }
+        store8<T>(dxr + c * 8, o);
+      }
+    }
+  }
+  float* mine = sred + wave * 2 * d;
+#pragma unroll
+  for (int u = 0; u < DCH; ++u) {
+    const int c = lane + 64 * u;
+    if (c < nchunk) {
+      store8<float>(mine + c * 8, pg[u]);
+      store8<float>(mine + d + c * 8, pb[u]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * d; i += 256) {
+    const float v = sred[i] + sred[2 * d + i] + sred[4 * d + i] + sred[6 * d + i];
+    if (partials) partials[(size_t)blockIdx.x * 2 * d + i] = v;
+    else atomicAdd((i < d ? dgamma + i : dbeta + (i - d)), v);
+  }
+}
+
 // column sums of partials [nblk][2*d] -> dgamma / dbeta (accumulated).  grid (ceil(2d/256), LN_RED_SLICES): each thread sums
 // its slice of the block rows for one column, then one atomic per column per slice.
 #define LN_RED_SLICES 16
@@ -327,7 +485,13 @@ extern "C" int evlm_layernorm_fwd(int dtype, const void* x, const float* gamma, 
   return 0;
 }
 
-static int ln_bwd_blocks(int rows) { return imin(ceil_div(rows, 8), 768); }   // 12 resident waves per CU (150 VGPRs)
+// one wave per row per trip, 3 workgroups of 4 waves resident per CU (<= 160 VGPRs): the trip count of a launch is what 768
+// resident workgroups need, and the grid is then cut so that EVERY wave makes that many trips - 12 608 rows on 768
+// workgroups left 320 waves a fifth row while 2 752 waited (a 20 % tail), on 631 workgroups every wave takes five
+static int ln_bwd_blocks(int rows) {
+  const int trips = imax(1, ceil_div(rows, 4 * 768));
+  return imax(1, ceil_div(rows, 4 * trips));
+}
 
 extern "C" int evlm_layernorm_bwd_blocks(int rows) { return ln_bwd_blocks(rows); }
 
@@ -344,10 +508,24 @@ static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const vo
   const int nblk = ln_bwd_blocks(rows);                // row pairs per wave
   dim3 grid(nblk), block(256);
   const size_t lds = 8 * (size_t)d * sizeof(float);
+  static const bool pipe = !getenv("EVLM_LN_BWD_PHASED");       // (A/B switch: the phased two-rows-per-trip kernel)
+  if (pipe && d <= 1024) {
+    // the pipelined kernel (one row per wave per trip, next row's loads in flight): addend2 / kd_t only in its EXTRA flavour
+    const size_t lds_p = 9 * (size_t)d * sizeof(float);
+    const bool extra = addend2 || kd_t;
+#define LN_BWDP(DCH_, ADD_, EX_) hipLaunchKernelGGL((ln_bwd_pipe_kernel<T, DCH_, ADD_, EX_>), grid, block, lds_p, stream, (const T*)dy, (const T*)x, (const T*)addend, (const T*)addend2, gamma, mean, rstd, rows, d, (T*)dx, dgamma, dbeta, partials, (const T*)kd_t, kd_g, kd_k)
+#define LN_BWDP_D(DCH_) do { if (extra) { if (addend) LN_BWDP(DCH_, true, true); else LN_BWDP(DCH_, false, true); } \
+                             else if (addend) LN_BWDP(DCH_, true, false); else LN_BWDP(DCH_, false, false); } while (0)
+    EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_bwd",
+      if (d <= 512) LN_BWDP_D(1); else LN_BWDP_D(2);)
+#undef LN_BWDP_D
+#undef LN_BWDP
+  } else {
 #define LN_BWD(DCH_) hipLaunchKernelGGL((ln_bwd_kernel<T, DCH_>), grid, block, lds, stream, (const T*)dy, (const T*)x, (const T*)addend, (const T*)addend2, gamma, mean, rstd, rows, d, (T*)dx, dgamma, dbeta, partials, (const T*)kd_t, kd_g, kd_k)
   EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_bwd",
     if (d <= 512) LN_BWD(1); else if (d <= 1024) LN_BWD(2); else if (d <= 1536) LN_BWD(3); else LN_BWD(4);)
 #undef LN_BWD
+  }
   if (partials && dgamma)
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(2 * d, 256), LN_RED_SLICES), dim3(256), 0, stream, partials, nblk, d,
                        dgamma, dbeta);

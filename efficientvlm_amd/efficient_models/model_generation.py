@@ -11,6 +11,7 @@ import copy
 
 import torch
 
+from .. import ops
 from .eff_bert import BertLMHeadModel
 from .generation_l0_module import VQAL0Module
 from .xvlm import XVLMBase, load_pretrained
@@ -91,7 +92,7 @@ class _VQABase(XVLMBase):
                 head_z=z("vision_head_z"), mlp_z=z("vision_intermediate_z"))
         else:
             image_embeds = self.vision_encoder(image, head_z=z("vision_head_z"), mlp_z=z("vision_intermediate_z"))[0]
-        image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
+        image_atts = ops.const_ones(image_embeds.size()[:-1], torch.long, image.device)
         # k: number of answers per question; weights: weight of each answer          (model_generation.py:110-113)
         answer_targets = answer.input_ids.masked_fill(answer.input_ids == self.pad_token_id, -100)
         enc_hz = torch.cat((zs["text_head_z"], zs["cross_head_z"]), dim=0) if zs is not None else None      # :123-124

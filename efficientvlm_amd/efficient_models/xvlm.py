@@ -9,6 +9,7 @@ plumbing only: the all-gather collective (RCCL), index_select/cat for the hard-n
 scalar glue (division by `temp`).  The hard-negative draw itself is one evlm_sample_negatives launch.
 """
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -51,6 +52,8 @@ def load_params_choose_layers(prefix: str, state_dict: dict, mapper: dict):
 # set by trainer.GDTrainer while it captures / replays a multi-GPU step as hipGraph segments: called INSTEAD of
 # dist.all_gather(output_list, tensor) - it ends the running capture, issues the collective eagerly, starts the next one
 GATHER_HOOK = None
+_NO_BATCH_SELECT = bool(os.environ.get("EVLM_NO_BATCH_SELECT"))  # (A/B switch: the fusion batch built with cat / index_select)
+_NO_FUSED_ITC = bool(os.environ.get("EVLM_NO_FUSED_ITC"))      # (A/B switch: the ITC loss as ~35 torch / HIP launches)
 
 
 class AllGather(torch.autograd.Function):
@@ -264,17 +267,17 @@ class XVLMBase(nn.Module):
         if idx_to_group_img is None:
             if not output_attentions and self.get_vision_embeds_returns_pair:
                 image_embeds = self.vision_encoder(image, head_z=head_z, head_layer_z=head_layer_z, mlp_z=mlp_z)[0]
-                image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
+                image_atts = ops.const_ones(image_embeds.size()[:-1], torch.long, image.device)
                 return image_embeds, image_atts
             image_embeds, image_hidden_states, image_all_attentions = self.vision_encoder(
                 image, output_attentions=output_attentions, output_hidden_states=output_hidden_states, head_z=head_z,
                 head_layer_z=head_layer_z, mlp_z=mlp_z)
-            image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
+            image_atts = ops.const_ones(image_embeds.size()[:-1], torch.long, image.device)
             return image_embeds, image_atts, image_hidden_states, image_all_attentions
         if image_atts is None:
             image_embeds_fullatts = self.vision_encoder(image, head_z=head_z, head_layer_z=head_layer_z, mlp_z=mlp_z)[0]
             image_embeds_fullatts = torch.index_select(image_embeds_fullatts, 0, idx_to_group_img.view(-1))
-            image_atts = torch.ones(image_embeds_fullatts.size()[:-1], dtype=torch.long, device=image.device)
+            image_atts = ops.const_ones(image_embeds_fullatts.size()[:-1], torch.long, image.device)
             return image_embeds_fullatts, image_atts
         assert image_atts.size(0) == idx_to_group_img.size(0)
         image_embeds, image_hidden_states, image_all_attentions, image_embeds_fullatts = self.vision_encoder(
@@ -344,6 +347,27 @@ class XVLMBase(nn.Module):
         # similarity logits are formed in exact fp32 whatever the compute dtype ([B,256] x [B,256]: negligible cost)
         # ONE all-gather of [B, 2E] for both feature sets (latency-bound message: SURVEY.md 2.2); the slice-only backward of
         # the reference's two gathers (xvlm.py:54-74) is unchanged - it acts row-wise
+        gathered = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("EVLM_FORCE_REDUCE"))
+        if image_feat.is_cuda and not _NO_FUSED_ITC and image_feat.dtype == text_feat.dtype and self.embed_dim <= 256 and self.embed_dim % 8 == 0:
+            # round 5: logits, both cross-entropies (soft labels when idx is given) and the whole backward in ONE launch each
+            # way (ops.itc_loss) - it was ~35 launches of 4-27 us on the student's critical path
+            both = allgather(torch.cat([image_feat, text_feat], dim=1)) if gathered else None
+            group = None
+            if idx is not None:
+                idx = idx.view(-1, 1)
+                assert idx.size(0) == image_feat.size(0)
+                group = allgather(idx).view(-1)
+            if gathered:
+                loss, sim = ops.itc_loss(both, None, self.temp, group)
+                B, r0 = image_feat.shape[0], dist.get_rank() * image_feat.shape[0]
+                sim = sim[r0:r0 + B, r0:r0 + B]
+            else:
+                loss, sim = ops.itc_loss(image_feat, text_feat, self.temp, group)
+            # this rank's block is what the ITM hard-negative sampler draws from.  WEAK references to the features: a strong
+            # one would keep this forward's autograd graph - and the AccumulateGrad nodes of its parameters, with the stream
+            # they were created on - alive into the next step, which a later hipGraph capture of the backward cannot join
+            self._itc_sim = (weakref.ref(image_feat), weakref.ref(text_feat), sim.detach())
+            return loss
         both = allgather(torch.cat([image_feat, text_feat], dim=1))
         image_feat_all = ops.cast(both[:, :self.embed_dim], torch.float32)
         text_feat_all = ops.cast(both[:, self.embed_dim:], torch.float32)
@@ -366,8 +390,12 @@ class XVLMBase(nn.Module):
 
     @torch.no_grad()
     def _sample_negatives(self, image_feat, text_feat, idx):
-        """efficient_models/xvlm.py:422-458, batched: one device-side sampling launch for both directions, no host syncs."""
+        """efficient_models/xvlm.py:422-458, batched: one device-side sampling launch for both directions, no host syncs.
+        A caller that set self._want_neg_layout gets, from the same launch, the batched fusion pass's row / image index
+        vectors (ops.sample_negatives) in self._neg_layout = (all 2B draws, sel4, img4) - None when the draws were injected."""
         bs = image_feat.size(0)
+        cached, self._itc_sim = getattr(self, "_itc_sim", None), None
+        layout, self._want_neg_layout, self._neg_layout = getattr(self, "_want_neg_layout", False), False, None
         if self.injected_neg_idx is not None:
             neg = self.injected_neg_idx.to(image_feat.device).long()
             # consumed by ONE forward unless keep_injected_neg is set (parity tests of trainers that run warm-up steps and
@@ -375,18 +403,28 @@ class XVLMBase(nn.Module):
             self.injected_neg_idx = neg if getattr(self, "keep_injected_neg", False) else None
             assert neg.numel() == 2 * bs
             return neg[:bs], neg[bs:]
-        sim_i2t = _matmul_nt(image_feat.float(), text_feat.float())                   # (the HIP fp32 GEMM, not a vendor one)
+        if cached is not None and cached[0]() is image_feat and cached[1]() is text_feat:
+            sim_i2t = cached[2]                  # (formed by the ITC loss kernel of this forward, same features)
+        else:
+            sim_i2t = _matmul_nt(image_feat.float(), text_feat.float())               # (the HIP fp32 GEMM, not a vendor one)
         # softmax(sim / temp) + 1e-5, positives zeroed, one categorical draw per row and per column: ONE launch
-        neg = ops.sample_negatives(sim_i2t, self.temp, None if idx is None else idx.view(-1))
+        if layout:
+            self._neg_layout = ops.sample_negatives(sim_i2t, self.temp, None if idx is None else idx.view(-1), layout=True)
+            neg = self._neg_layout[0]
+        else:
+            neg = ops.sample_negatives(sim_i2t, self.temp, None if idx is None else idx.view(-1))
         return neg[:bs], neg[bs:]
 
     def get_matching_loss(self, image_embeds, image_atts, image_feat, text_embeds, text_atts, text_feat, idx=None,
                           output_attentions=None, output_hidden_states=None, head_z=None, head_layer_z=None, mlp_z=None):
         """efficient_models/xvlm.py:418-490"""
         bs = image_embeds.size(0)
-        img_neg, txt_neg = self._sample_negatives(image_feat, text_feat, idx)
-        self.last_neg_idx = torch.cat([img_neg, txt_neg])
-        if output_hidden_states and self.batched_itm:
+        batched = bool(output_hidden_states and self.batched_itm)
+        self._neg_layout, self._want_neg_layout = None, batched and image_embeds.is_cuda
+        img_neg, txt_neg = self._sample_negatives(image_feat, text_feat, idx)      # (tests replace this method: no new arguments)
+        lay, self._want_neg_layout = self._neg_layout, False
+        self.last_neg_idx = lay[0] if lay is not None else torch.cat([img_neg, txt_neg])
+        if batched:
             return self._matching_loss_batched(image_embeds, image_atts, text_embeds, text_atts, img_neg, txt_neg,
                                                head_z, head_layer_z, mlp_z)
         image_embeds_neg = torch.index_select(image_embeds, 0, img_neg)
@@ -410,7 +448,7 @@ class XVLMBase(nn.Module):
             neg_last = self.get_cross_embeds(image_embeds_all, image_atts_all, text_embeds=text_embeds_all,
                                              text_atts=text_atts_all, **zkw)
         cls_rows = torch.cat([pos_last[:, 0, :], neg_last[:, 0, :]], dim=0)
-        output = mlp_head_forward(self.itm_head, cls_rows)
+        output = ops.join_grads(mlp_head_forward(self.itm_head, cls_rows))      # (this CE + the distillation KL: one gradient buffer)
         dev = image_embeds.device
         itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)], dim=0)
         matching_loss = ops.cross_entropy(output, itm_labels)
@@ -427,19 +465,31 @@ class XVLMBase(nn.Module):
     def _matching_loss_batched(self, image_embeds, image_atts, text_embeds, text_atts, img_neg, txt_neg, head_z,
                                head_layer_z, mlp_z):
         bs, dev = image_embeds.size(0), image_embeds.device
-        ar = torch.arange(bs, device=dev)
-        txt_all = torch.cat([text_embeds, text_embeds, torch.index_select(text_embeds, 0, txt_neg)], 0)
-        atts_all = torch.cat([text_atts, text_atts, torch.index_select(text_atts, 0, txt_neg)], 0)
-        img_index = torch.cat([ar, img_neg, ar], 0)            # pos | (text, image_neg) | (text_neg, image)
+        lay = getattr(self, "_neg_layout", None)
+        ones = image_atts is ops.const_ones(image_atts.shape, image_atts.dtype, dev)       # (get_vision_embeds' all-ones mask)
+        if (lay is not None and ones and not _NO_BATCH_SELECT and text_embeds.is_contiguous() and text_atts.is_contiguous()
+                and (text_embeds[0].numel() * text_embeds.element_size()) % 16 == 0 and text_embeds[0].numel() % 8 == 0
+                and (text_atts[0].numel() * text_atts.element_size()) % 16 == 0):
+            # round 5: the sampling launch wrote this layout's row / image indices (the first 3B entries of its 4-block
+            # vectors: pos | (text, image_neg) | (text_neg, image)); one selection launch each for embeddings and masks
+            sel3, img3 = lay[1][:3 * bs], lay[2][:3 * bs]
+            txt_all, atts_all = ops.select_batches(text_embeds, sel3), ops.select_batches(text_atts, sel3)
+            enc_mask = ops.const_ones((3 * bs,) + tuple(image_atts.shape[1:]), image_atts.dtype, dev)
+        else:
+            ar = ops.const_tensor("arange", bs, dev)
+            txt_all = torch.cat([text_embeds, text_embeds, torch.index_select(text_embeds, 0, txt_neg)], 0)
+            atts_all = torch.cat([text_atts, text_atts, torch.index_select(text_atts, 0, txt_neg)], 0)
+            img_index = torch.cat([ar, img_neg, ar], 0)            # pos | (text, image_neg) | (text_neg, image)
+            enc_mask, img3 = torch.index_select(image_atts, 0, img_index), img_index.to(torch.int32)
         f = self._text_core()(encoder_embeds=txt_all, attention_mask=atts_all, encoder_hidden_states=image_embeds,
-                              encoder_attention_mask=torch.index_select(image_atts, 0, img_index),
-                              encoder_batch_index=img_index.to(torch.int32), return_dict=True, mode="fusion", output_attentions=True,
+                              encoder_attention_mask=enc_mask,
+                              encoder_batch_index=img3, return_dict=True, mode="fusion", output_attentions=True,
                               output_hidden_states=True, head_z=head_z, head_layer_z=head_layer_z, mlp_z=mlp_z)
         two = lambda tup: tuple(zip(*[torch.split(x, [bs, 2 * bs], 0) if x is not None else (None, None) for x in tup]))
         (pos_hs, neg_hs), (pos_att, neg_att), (pos_catt, neg_catt) = two(f.hidden_states), two(f.attentions), \
             two(f.cross_attentions)
-        output = mlp_head_forward(self.itm_head, f.last_hidden_state[:, 0, :])
-        itm_labels = torch.cat([torch.ones(bs, dtype=torch.long, device=dev), torch.zeros(2 * bs, dtype=torch.long, device=dev)])
+        output = ops.join_grads(mlp_head_forward(self.itm_head, f.last_hidden_state[:, 0, :]))
+        itm_labels = ops.const_tensor("itm_labels", bs, dev)
         # extension: the same lists as row ranges of the UN-split pass outputs (ops.RowSlice) - the distillation losses take
         # these, so each batched tensor receives ONE gradient buffer instead of autograd concatenating a positive and a
         # negative piece (the cross-attention maps of a 384 x 384 step are 80 MB each: six 54-us cats per step)

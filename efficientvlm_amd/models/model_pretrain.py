@@ -10,6 +10,8 @@ from .xvlm import XVLMBase
 from .. import ops
 from ..efficient_models.xvlm import mlp_head_forward
 
+_NO_BATCH_SELECT = bool(os.environ.get("EVLM_NO_BATCH_SELECT"))      # (A/B switch: the fusion batch built with cat / index_select)
+
 
 class XVLM(XVLMBase):
     def __init__(self, config):
@@ -121,8 +123,10 @@ class XVLM(XVLMBase):
         dev = image.device
         core = self._text_core()
 
+        atts2 = torch.cat([text_atts, text_atts], 0)
+
         def text_pass():      # text layers 0..F-1 on [text_ids ; text_ids_masked]
-            return core(torch.cat([text_ids, text_ids_masked], 0), attention_mask=torch.cat([text_atts, text_atts], 0),
+            return core(torch.cat([text_ids, text_ids_masked], 0), attention_mask=atts2,
                         return_dict=True, mode="text", output_attentions=True, output_hidden_states=True)
         # extension: the text pass is independent of the image encoder until the ITC features - with `text_stream` set
         # (single-GPU trainers) it is issued on that stream BESIDE the image encoder: its ~25 small FORWARD launches share
@@ -175,23 +179,38 @@ class XVLM(XVLMBase):
         image_feat, text_feat = self.get_features(image_embeds, text_embeds)
         skip = self.skip_task_losses and not torch.is_grad_enabled()
         loss_itc = None if skip else self.get_contrastive_loss(image_feat, text_feat)
-        img_neg, txt_neg = self._sample_negatives(image_feat, text_feat, None)
-        self.last_neg_idx = torch.cat([img_neg, txt_neg])
+        fast = (region is None and image.is_cuda and not _NO_BATCH_SELECT and t.last_hidden_state.is_contiguous()
+                and t.last_hidden_state.shape[0] == 2 * B and (t.last_hidden_state[0].numel() * t.last_hidden_state.element_size()) % 16 == 0
+                and t.last_hidden_state[0].numel() % 8 == 0 and (atts2[0].numel() * atts2.element_size()) % 16 == 0)
+        self._neg_layout, self._want_neg_layout = None, fast
+        img_neg, txt_neg = self._sample_negatives(image_feat, text_feat, None)     # (tests replace this method: no new arguments)
+        lay, self._want_neg_layout = self._neg_layout, False
+        self.last_neg_idx = lay[0] if lay is not None else torch.cat([img_neg, txt_neg])
         # fusion layers on [pos (B) ; neg (2B: text|text_neg x img_neg|img) ; mlm (B)]
-        ar = ops.const_tensor("arange", B, dev)
-        txt_all = torch.cat([text_embeds, text_embeds, torch.index_select(text_embeds, 0, txt_neg), mlm_text], 0)
-        atts_all = torch.cat([text_atts, text_atts, torch.index_select(text_atts, 0, txt_neg), text_atts], 0)
-        img_index = torch.cat([ar, img_neg, ar, ar], 0)
         sizes = [B, 2 * B, B]
-        if region is not None:                      # + bbox rows: the text again, attending to the un-masked image
-            txt_all = torch.cat([txt_all, text_embeds], 0)
-            atts_all = torch.cat([atts_all, text_atts], 0)
-            img_index = torch.cat([img_index, B + idx_to_group_img.view(-1)], 0)
-            sizes.append(B)
+        if lay is not None:
+            # round 5: the sampling launch wrote the row / image indices of this layout itself; ONE selection launch builds the
+            # embeddings (and one the masks) from the text pass's un-split [text ; masked text] output - it was two index_select,
+            # five cat and a cast, and in backward a zero-fill, an atomic index_add and three adds over [B, L, d]
+            _, sel4, img4 = lay
+            txt_all = ops.select_batches(t.last_hidden_state, sel4)
+            atts_all = ops.select_batches(atts2, sel4)
+            img_index = None
+        else:
+            ar = ops.const_tensor("arange", B, dev)
+            txt_all = torch.cat([text_embeds, text_embeds, torch.index_select(text_embeds, 0, txt_neg), mlm_text], 0)
+            atts_all = torch.cat([text_atts, text_atts, torch.index_select(text_atts, 0, txt_neg), text_atts], 0)
+            img_index = torch.cat([ar, img_neg, ar, ar], 0)
+            if region is not None:                      # + bbox rows: the text again, attending to the un-masked image
+                txt_all = torch.cat([txt_all, text_embeds], 0)
+                atts_all = torch.cat([atts_all, text_atts], 0)
+                img_index = torch.cat([img_index, B + idx_to_group_img.view(-1)], 0)
+                sizes.append(B)
+            img4 = img_index.to(torch.int32)             # (cast once here, not in every cross-attention)
         f = core(encoder_embeds=txt_all, attention_mask=atts_all, encoder_hidden_states=enc_states,
                  # (a general batch attends to every image token - get_vision_embeds' all-ones mask: no mask is built)
                  encoder_attention_mask=None if region is None else torch.index_select(enc_atts, 0, img_index),
-                 encoder_batch_index=img_index.to(torch.int32),      # (cast once here, not in every cross-attention)
+                 encoder_batch_index=img4,
                  return_dict=True, mode="fusion", output_attentions=True, output_hidden_states=True)
         yield "fusion_done"
         # (the hidden-state / attention-map distillation terms depend on nothing past this point: a trainer that runs them
@@ -204,15 +223,16 @@ class XVLM(XVLMBase):
                                          for x in tup]))                                       # pos | neg | mlm [| bbox]
         f_hid, f_att, f_cross = thirds(f.hidden_states), thirds(f.attentions), thirds(f.cross_attentions)
         last = f.last_hidden_state
-        itm_logits = mlp_head_forward(self.itm_head, last[:3 * B, 0, :])
+        # (join_grads: the hard-label CE here and the distillation KL of distill.kd_terms sum their gradients into ONE buffer)
+        itm_logits = ops.join_grads(mlp_head_forward(self.itm_head, last[:3 * B, 0, :]))
         itm_labels = ops.const_tensor("itm_labels", B, dev)
         loss_itm = None if skip else ops.cross_entropy(itm_logits, itm_labels)
         # MLM head on the masked positions of the last quarter
         enc = self.text_encoder
         mlm_last = f_hid[2][-1] if f.hidden_states[-1] is last else last[3 * B:4 * B]
         mlm_seq = enc.gather_seq_out_by_pos(mlm_last, masked_pos)
-        mlm_logits = enc.cls(mlm_seq)
-        loss_mlm = None if skip else ops.cross_entropy(mlm_logits.reshape(-1, enc.config.vocab_size), masked_ids.reshape(-1))
+        mlm_logits = ops.join_grads(enc.cls(mlm_seq))
+        loss_mlm = None if skip else ops.cross_entropy(mlm_logits, masked_ids.reshape(-1))
         nF = len(t.attentions)
         hidden_dict = {"image_hidden_states": image_hidden_states, "text_hidden_states": text_hidden_states,
                        "itm_pos_hidden_states": f_hid[0], "itm_neg_hidden_states": f_hid[1],

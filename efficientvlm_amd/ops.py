@@ -353,9 +353,7 @@ def finish_assign():
     st = WGRAD_ASSIGN
     if st is None:
         return
-    for k, g in st["skip"].items():
-        if k not in st["done"]:
-            g.zero_()
+    _keep_table(zero_grouped([g for k, g in st["skip"].items() if k not in st["done"]]))
     st["done"].clear()
     st["pending"].clear()
 
@@ -585,6 +583,18 @@ def const_tensor(kind, n, device):
         else:
             raise ValueError(kind)
         if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _CONST[key] = t
+    return t
+
+
+def const_ones(shape, dtype, device):
+    """torch.ones(shape) for a READ-ONLY all-ones tensor (the image encoder's attention mask of every forward): built once
+    per (shape, dtype, device), no fill launch per forward.  Never write to it."""
+    key = ("ones", tuple(shape), dtype, str(device))
+    t = _CONST.get(key)
+    if t is None:
+        t = torch.ones(tuple(shape), dtype=dtype, device=device)
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):      # (a capture's allocations live in its graph's pool)
             _CONST[key] = t
     return t
 
@@ -1488,6 +1498,51 @@ def copy_grouped(pairs):
     return table
 
 
+def zero_grouped(tensors):
+    """zero-fill every tensor of `tensors` in ONE launch (evlm_copy_grouped units without a source) - a step's gradient
+    ranges were one fill launch each.  Tensors that do not qualify (not contiguous, not 16-byte sized / aligned) are filled
+    one by one.  Returns the device table (keep it alive while a captured graph may replay the launch) or None."""
+    rows, blocks, n = [], 0, 0
+    for t in tensors:
+        nb = t.numel() * t.element_size()
+        if nb == 0:
+            continue
+        if not t.is_cuda or nb % 16 or t.data_ptr() % 16 or not t.is_contiguous():
+            t.zero_()
+            continue
+        rows += [0, t.data_ptr(), nb, blocks]
+        blocks += (nb + 65535) // 65536
+        n += 1
+        dev = t.device
+    if n == 0:
+        return None
+    if n == 1:                                   # (one range: a plain fill, no table)
+        for t in tensors:
+            if t.data_ptr() == rows[1]:
+                t.zero_()
+                return None
+    key = (dev, tuple(rows))
+    table = _ZERO_CACHE.get(key)                 # (a step zeroes the same ranges every time: the table is uploaded once)
+    if table is None:
+        table = _upload_table(rows, dev)
+        # (never evicted: a later capture may have recorded a launch that reads a cached table; tables are a few hundred bytes)
+        if not torch.cuda.is_current_stream_capturing() and len(_ZERO_CACHE) < 256:
+            _ZERO_CACHE[key] = table
+    L.check(_lib().evlm_copy_grouped(L.ptr(table), n, blocks, L.stream()), "zero_grouped")
+    return table
+
+
+_ZERO_CACHE = {}
+_ZERO_TABLES = []         # tables of captured / in-flight zero_grouped launches (bounded: the oldest go once 64 are held)
+
+
+def _keep_table(t):
+    if t is not None:
+        _ZERO_TABLES.append(t)
+        if len(_ZERO_TABLES) > 64 and not torch.cuda.is_current_stream_capturing():
+            del _ZERO_TABLES[:-64]
+
+
 def xattn_fusable(q, x_img, weights, H, dh):
     """does the fused cross-attention forward (evlm_xattn_fused_fwd: K/V projection + attention in one launch, nothing
     kept for a backward) apply?  no-grad forwards only - the frozen teacher, inference"""
@@ -1572,7 +1627,7 @@ def _next_drop_call(kind, shape, p):
     return _DROP_CALL[0]
 
 
-def sample_negatives(sim, temp, group=None):
+def sample_negatives(sim, temp, group=None, layout=False):
     """ITM hard negatives in one launch (evlm_sample_negatives; reference efficient_models/xvlm.py:422-458): sim f32 [B, B]
     image x text similarities, temp the (device) temperature, group optional int64 [B] positive-group ids.  Returns int64
     [2B]: for every text an image index, then for every image a text index.  Draws from the device Philox stream of
@@ -1587,10 +1642,104 @@ def sample_negatives(sim, temp, group=None):
     DROPOUT_USED = True
     _DROP_CALL[0] = (_DROP_CALL[0] + 1) & 0xFFFFFFFF
     out = torch.empty(2 * B, dtype=torch.int64, device=sim.device)
+    sel4 = torch.empty(4 * B, dtype=torch.int64, device=sim.device) if layout else None
+    img4 = torch.empty(4 * B, dtype=torch.int32, device=sim.device) if layout else None
     L.check(_lib().evlm_sample_negatives(L.ptr(sim), B, sim.stride(0), L.ptr(t), L.ptr(g) if g is not None else None,
-                                         L.ptr(dropout_state(sim.device)), _DROP_CALL[0], L.ptr(out), L.stream()),
+                                         L.ptr(dropout_state(sim.device)), _DROP_CALL[0], L.ptr(out),
+                                         L.ptr(sel4) if layout else None, L.ptr(img4) if layout else None, L.stream()),
             "sample_negatives")
-    return out
+    # layout: + (sel4, img4), the batched fusion pass's row / image indices written by the same launch (evlm_hip.h)
+    return (out, sel4, img4) if layout else out
+
+
+class _SelectBatches(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sel):
+        L.require_cuda(x, sel)
+        xc = x if x.is_contiguous() else x.contiguous()
+        n, rows = sel.numel(), xc.shape[0]
+        out = torch.empty((n,) + tuple(xc.shape[1:]), dtype=xc.dtype, device=xc.device)
+        rb = (xc.numel() // rows) * xc.element_size()
+        L.check(_lib().evlm_select_batches_fwd(L.ptr(xc), L.ptr(sel), n, rb, L.ptr(out), L.stream()), "select_batches_fwd")
+        ctx.save_for_backward(sel)
+        ctx.meta = (n, rows, xc.numel() // rows, tuple(xc.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (sel,) = ctx.saved_tensors
+        n, rows, w, shape = ctx.meta
+        dc = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty(shape, dtype=dy.dtype, device=dy.device)
+        L.check(_lib().evlm_select_batches_bwd(L.dt(dc), L.ptr(dc), L.ptr(sel), n, rows, w, L.ptr(dx), L.stream()), "select_batches_bwd")
+        return dx, None
+
+
+def select_batches(x, sel):
+    """x[sel] over whole samples (dim 0) in one launch, with a deterministic one-launch backward (evlm_select_batches_*):
+    sel int64 [n], x contiguous with samples of a multiple of 16 bytes (and, to be differentiable, of 8 elements)"""
+    assert sel.dtype == torch.int64 and sel.is_contiguous()
+    return _SelectBatches.apply(x, sel)
+
+
+class _ITCLoss(torch.autograd.Function):
+    """evlm_itc_loss_fwd / _bwd.  a: image features [Bt, E], b: text features [Bt, E] - or a = the gathered [Bt, 2E] buffer
+    [image | text] and b = None (its gradient then comes back as one [Bt, 2E] tensor for the gather's slice-only backward)"""
+
+    @staticmethod
+    def forward(ctx, a, b, temp, group):
+        L.require_cuda(a)
+        packed = b is None
+        if a.stride(-1) != 1 or (a.stride(0) * a.element_size()) % 16 or a.data_ptr() % 16:
+            a = a.contiguous()
+        if not packed and (b.stride(-1) != 1 or (b.stride(0) * b.element_size()) % 16 or b.data_ptr() % 16 or b.dtype != a.dtype):
+            b = b.to(a.dtype).contiguous()
+        Bt = a.shape[0]
+        E = a.shape[1] // 2 if packed else a.shape[1]
+        I, ldi = a, a.stride(0)
+        Tp, ldt = (C.c_void_p(a.data_ptr() + E * a.element_size()), ldi) if packed else (L.ptr(b), b.stride(0))
+        t = temp.detach().reshape(-1)[:1]
+        assert t.dtype == torch.float32
+        g = None if group is None else group.reshape(-1).to(torch.int64).contiguous()
+        lds = _pad8(Bt)
+        sim = torch.empty((Bt, lds), dtype=torch.float32, device=a.device)
+        stats = zeros_small((4 * Bt + 8,), torch.float32, a.device)
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        L.check(_lib().evlm_itc_loss_fwd(L.dt(a), L.ptr(I), ldi, Tp, ldt, Bt, E, L.ptr(t), L.ptr(g) if g is not None else None,
+                                         L.ptr(sim), lds, L.ptr(stats), L.ptr(loss), L.stream()), "itc_loss_fwd")
+        ctx.save_for_backward(a, b, t, g, sim, stats)
+        ctx.dims = (packed, Bt, E, lds, tuple(temp.shape))
+        sim_v = sim[:, :Bt]
+        ctx.mark_non_differentiable(sim_v)
+        return loss, sim_v
+
+    @staticmethod
+    def backward(ctx, dloss, _dsim):
+        a, b, t, g, sim, stats = ctx.saved_tensors
+        packed, Bt, E, lds, tshape = ctx.dims
+        dl = dloss.reshape(-1)[:1]
+        if dl.dtype != torch.float32:
+            dl = dl.float()
+        ldi = a.stride(0)
+        Tp, ldt = (C.c_void_p(a.data_ptr() + E * a.element_size()), ldi) if packed else (L.ptr(b), b.stride(0))
+        if packed:
+            da = torch.empty((Bt, 2 * E), dtype=a.dtype, device=a.device)
+            dIp, lddi, dTp, lddt, db = L.ptr(da), 2 * E, C.c_void_p(da.data_ptr() + E * da.element_size()), 2 * E, None
+        else:
+            da, db = torch.empty((Bt, E), dtype=a.dtype, device=a.device), torch.empty((Bt, E), dtype=a.dtype, device=a.device)
+            dIp, lddi, dTp, lddt = L.ptr(da), E, L.ptr(db), E
+        dtemp = torch.empty(1, dtype=torch.float32, device=a.device)
+        L.check(_lib().evlm_itc_loss_bwd(L.dt(a), L.ptr(a), ldi, Tp, ldt, Bt, E, L.ptr(t), L.ptr(g) if g is not None else None,
+                                         L.ptr(sim), lds, L.ptr(stats), L.ptr(dl), dIp, lddi, dTp, lddt, L.ptr(dtemp),
+                                         L.stream()), "itc_loss_bwd")
+        return da, db, dtemp.view(tshape), None
+
+
+def itc_loss(image_feat, text_feat, temp, group=None):
+    """the ITC loss of efficient_models/xvlm.py:384-416 over the (gathered) batch in one launch each way: returns (loss, sim)
+    - sim f32 [Bt, Bt] = I T^t un-scaled, which the ITM hard-negative sampler reads instead of forming it again.
+    text_feat None: image_feat is the gathered [Bt, 2E] buffer [image | text]."""
+    return _ITCLoss.apply(image_feat, text_feat, temp, group)
 
 
 def dropout_mask(call_id, shape, p, device="cuda"):
@@ -1892,6 +2041,60 @@ def mse_terms(terms):
     return [outs[t] if t in used else 0 for t in range(len(terms))]
 
 
+class GradJoin:
+    """shared gradient buffer of ONE logits tensor that several loss ops read (join_grads): every loss backward that knows
+    of it writes / adds its gradient into one padded buffer and hands autograd nothing; the join point's own backward -
+    which autograd runs after ALL consumers, joined or not - passes the buffer (plus whatever other consumers produced) on"""
+
+    def __init__(self, stream):
+        self.buf, self.stream = None, stream
+
+
+_NO_GRAD_JOIN = bool(os.environ.get("EVLM_NO_GRAD_JOIN"))      # (A/B switch: one gradient tensor per loss, autograd adds them)
+
+
+class _JoinPoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        ctx.set_materialize_grads(False)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        slot = ctx.slot
+        buf, slot.buf = slot.buf, None            # (a second backward over a retained graph starts over)
+        if buf is None:
+            return g, None
+        d = buf[0]
+        return (d if g is None else d + g), None
+
+
+def join_grads(x):
+    """an alias of `x` (logits that feed several loss ops - the hard-label CE and the distillation KL of the MLM / ITM heads)
+    whose loss backward kernels sum into ONE padded buffer instead of each producing a tensor for autograd to add (an
+    element-wise pass over [rows, classes]) and the producer's dX product re-padding the sum.  Pass the RETURNED object to
+    every loss op; consumers that know nothing of the join still work (their gradients are added at the join point)."""
+    if not (x.is_cuda and torch.is_grad_enabled() and x.requires_grad) or _NO_GRAD_JOIN:
+        return x
+    slot = GradJoin(torch.cuda.current_stream(x.device))
+    y = _JoinPoint.apply(x, slot)
+    y._evlm_join = slot
+    return y
+
+
+def _join_target(ctx, R, ldd, dtype):
+    """the joined buffer [R, ldd] a loss backward should ADD into (None: none yet / not joinable) and whether this backward
+    takes part in the join at all - only on the stream the logits were produced on: the join point's backward runs there,
+    behind every kernel this stream was given before it"""
+    j = ctx.join
+    if j is None or torch.cuda.current_stream() != j.stream:
+        return None, None
+    if j.buf is not None and (j.buf[1].shape != (R, ldd) or j.buf[1].dtype != dtype):
+        return None, None
+    return (j.buf[1] if j.buf is not None else None), j
+
+
 def _rows2d(x):
     Cn = x.shape[-1]
     x2 = x.reshape(-1, Cn) if x.dim() != 2 else x
@@ -1913,6 +2116,7 @@ class _CE(torch.autograd.Function):
                                    L.ptr(out), L.stream()), "ce_fwd")
         ctx.save_for_backward(x2, lab, lse, valid)
         ctx.meta = (R, Cn, ld, ignore_index, logits.shape)
+        ctx.join = getattr(logits, "_evlm_join", None)
         return out
 
     @staticmethod
@@ -1921,12 +2125,18 @@ class _CE(torch.autograd.Function):
         R, Cn, ld, ignore_index, shape = ctx.meta
         gc = g.to(torch.float32).contiguous()
         ldd = _pad8(Cn)
-        dl = torch.empty((R, ldd), dtype=x2.dtype, device=x2.device)      # (padding columns: zeroed by the kernel)
+        acc, join = _join_target(ctx, R, ldd, x2.dtype)
+        dl = acc if acc is not None else torch.empty((R, ldd), dtype=x2.dtype, device=x2.device)      # (padding columns: zeroed by the kernel)
         L.check(_lib().evlm_ce_bwd(L.dt(x2), L.ptr(x2), R, Cn, ld, L.ptr(lab), ignore_index, 1.0, L.ptr(lse), L.ptr(valid),
-                                   L.ptr(gc), L.ptr(dl), ldd, L.stream()), "ce_bwd")
+                                   L.ptr(gc), L.ptr(dl), ldd, int(acc is not None), L.stream()), "ce_bwd")
+        if acc is not None:
+            return None, None, None
         d = dl[:, :Cn] if ldd != Cn else dl
         if len(shape) > 2:
             d = d.unflatten(0, shape[:-1])
+        if join is not None:                   # first joined writer: the join point hands (view, buffer) on
+            join.buf = (d, dl)
+            return None, None, None
         return d, None, None
 
 
@@ -1961,7 +2171,7 @@ class _CEWeighted(torch.autograd.Function):
         ldd = _pad8(Cn)
         dl = torch.empty((R, ldd), dtype=x2.dtype, device=x2.device)      # (padding columns: zeroed by the kernel)
         L.check(_lib().evlm_ce_weighted_bwd(L.dt(x2), L.ptr(x2), R, Cn, ld, L.ptr(lab), ignore_index, 1.0, L.ptr(rw),
-                                            L.ptr(lse), L.ptr(gc), L.ptr(dl), ldd, L.stream()), "ce_weighted_bwd")
+                                            L.ptr(lse), L.ptr(gc), L.ptr(dl), ldd, 0, L.stream()), "ce_weighted_bwd")
         d = dl[:, :Cn] if ldd != Cn else dl
         if len(shape) > 2:
             d = d.unflatten(0, shape[:-1])
@@ -1989,6 +2199,7 @@ class _KL(torch.autograd.Function):
                                    L.ptr(out), L.stream()), "kl_fwd")
         ctx.save_for_backward(s2, t2, ls, lt)
         ctx.meta = (R, Cn, lds, ldt, inv_t, s.shape)
+        ctx.join = getattr(s, "_evlm_join", None)
         return out
 
     @staticmethod
@@ -1997,12 +2208,18 @@ class _KL(torch.autograd.Function):
         R, Cn, lds, ldt, inv_t, shape = ctx.meta
         gc = g.to(torch.float32).contiguous()
         ldd = _pad8(Cn)
-        ds = torch.empty((R, ldd), dtype=s2.dtype, device=s2.device)      # (padding columns: zeroed by the kernel)
+        acc, join = _join_target(ctx, R, ldd, s2.dtype)
+        ds = acc if acc is not None else torch.empty((R, ldd), dtype=s2.dtype, device=s2.device)      # (padding columns: zeroed by the kernel)
         L.check(_lib().evlm_kl_bwd(L.dt(s2), L.ptr(s2), lds, L.dt(t2), L.ptr(t2), ldt, R, Cn, inv_t, 1.0, L.ptr(ls), L.ptr(lt),
-                                   L.ptr(gc), L.ptr(ds), ldd, L.stream()), "kl_bwd")
+                                   L.ptr(gc), L.ptr(ds), ldd, int(acc is not None), L.stream()), "kl_bwd")
+        if acc is not None:
+            return None, None, None
         d = ds[:, :Cn] if ldd != Cn else ds
         if len(shape) > 2:
             d = d.unflatten(0, shape[:-1])
+        if join is not None:
+            join.buf = (d, ds)
+            return None, None, None
         return d, None, None
 
 

@@ -82,7 +82,9 @@ class FlatAdamW:
         self._assign = None
         self._scheduled, self._last_mult = False, 1.0      # has set_schedule() run since the last step()?
         dev = named[0][1].device
-        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._gn = torch.zeros(4, dtype=torch.float32, device=dev)       # (16 bytes: a unit of the grouped zero fill)
+        self.gnorm_sq = self._gn[:1]
+        self._gnorm_zeroed = False
         # fixed-order sum of squares (include/evlm_hip.h: evlm_sumsq): data-parallel replicas clip by bit-identical factors
         self.sumsq_ws = torch.zeros(2050, dtype=torch.float32, device=dev) if torch.device(dev).type == "cuda" else None
         self.hyper = torch.ones(3, dtype=torch.float32, device=dev)       # {lr multiplier, bias_c1, bias_c2}
@@ -157,12 +159,14 @@ class FlatAdamW:
         """skip_assigned: leave out the ranges of assign_state() - the caller promises that this step's backward runs with
         ops.WGRAD_ASSIGN = that state (every such range is then written by its first contribution or zero-filled by
         ops.finish_assign)"""
-        if not skip_assigned or self._assign is None:
-            for g in self.groups:
-                g["g"].zero_()
-            return
-        for view in self._assign["fill"]:
-            view.zero_()
+        # ONE fill launch for all ranges (+ the norm accumulator step() sums into): they were 7 launches of a GD step
+        ranges = ([g["g"] for g in self.groups] if (not skip_assigned or self._assign is None) else list(self._assign["fill"]))
+        if self.gnorm_sq.is_cuda:
+            ops._keep_table(ops.zero_grouped(ranges + [self._gn]))
+            self._gnorm_zeroed = True
+        else:
+            for r in ranges:
+                r.zero_()
 
     def assign_state(self, model):
         """state for ops.WGRAD_ASSIGN: the weights of the model's nn.Linear modules (not tied to an embedding) - the
@@ -223,7 +227,9 @@ class FlatAdamW:
                     g["g"][off:off + k].copy_(p.grad.reshape(-1))
                     p.grad = g["g"][off:off + k].view(p.shape)
                 off += _seg(p)
-        self.gnorm_sq.zero_()
+        if not self._gnorm_zeroed:          # (zero_grad() of this step cleared it together with the gradient ranges)
+            self.gnorm_sq.zero_()
+        self._gnorm_zeroed = False
         for g in self.groups:
             L.check(lib.evlm_sumsq(L.ptr(g["g"]), g["g"].numel(), L.ptr(self.gnorm_sq), L.ptr(self.sumsq_ws), L.stream()), "sumsq")
         b1, b2 = self.betas

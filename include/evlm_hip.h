@@ -328,12 +328,14 @@ int evlm_mse_grouped(int dtype, int backward, const int64_t* table, int n_units,
  * eff_bert.py:1697-1699, ITM xvlm.py:484, ITC :399-400).  logits [R,C] (ld), labels int64.
  * lse [2R] f32 workspace (lse, then per-row losses) saved for backward; *loss += weight * mean;
  * valid_count: device int32 word (written).  The backward kernels write every column 0 .. ldd-1 of a gradient row (the
- * padding columns C .. ldd-1 as zeros): dlogits needs no initialisation. */
+ * padding columns C .. ldd-1 as zeros): dlogits needs no initialisation.  accumulate != 0 (ABI 8; also evlm_kl_bwd): dlogits
+ * already holds another loss's gradient of the same logits (same R, ldd) and this one is ADDED to it - the hard-label and the
+ * distillation loss of the MLM / ITM logits then hand their producer ONE padded buffer (no element-wise add, no re-padding). */
 int evlm_ce_fwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
                 float weight, float* lse, int32_t* valid_count, float* loss, void* stream);
 int evlm_ce_bwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
                 float weight, const float* lse, const int32_t* valid_count, const float* gout,
-                void* dlogits, int ldd, void* stream);
+                void* dlogits, int ldd, int accumulate, void* stream);
 /* weighted-SUM form: *loss += weight * sum_r row_weight[r] * ce[r] (ignored rows contribute 0, no normalisation) - the
  * per-answer weighted next-token loss of the VQA decoder: BertLMHeadModel reduction='none' summed per sequence
  * (eff_bert.py:1419-1431) times `weights`, summed (efficient_models/model_generation.py:166-167).  row_weight [R] f32. */
@@ -341,7 +343,7 @@ int evlm_ce_weighted_fwd(int dtype, const void* logits, int R, int C, int ld, co
                          float weight, const float* row_weight, float* lse, int32_t* valid_count, float* loss, void* stream);
 int evlm_ce_weighted_bwd(int dtype, const void* logits, int R, int C, int ld, const int64_t* labels, int ignore_index,
                          float weight, const float* row_weight, const float* lse, const float* gout,
-                         void* dlogits, int ldd, void* stream);
+                         void* dlogits, int ldd, int accumulate, void* stream);
 
 /* soft_cross_entropy (GeneralDistill.py:84-89): KLDiv(log_softmax(s*inv_t), softmax(t*inv_t), batchmean)
  * over R rows of C classes.  lse_s/lse_t [R] f32 saved for backward.  d s = (p_s - p_t) * inv_t / R; columns C .. ldds-1
@@ -350,7 +352,7 @@ int evlm_kl_fwd(int dtype_s, const void* s, int lds, int dtype_t, const void* t,
                 float inv_t, float weight, float* lse_s, float* lse_t, float* loss, void* stream);
 int evlm_kl_bwd(int dtype_s, const void* s, int lds, int dtype_t, const void* t, int ldt, int R, int C,
                 float inv_t, float weight, const float* lse_s, const float* lse_t, const float* gout,
-                void* ds, int ldds, void* stream);
+                void* ds, int ldds, int accumulate, void* stream);
 
 /* row-wise log_softmax (for the soft-label ITC branch, xvlm.py:411-414) and its backward */
 int evlm_log_softmax_fwd(int dtype, const void* x, int R, int C, int ld, void* y, int ldy, void* stream);
@@ -425,6 +427,23 @@ int evlm_l0_deterministic(const float* loga, int rows, int size, float temperatu
                           float* z, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * ITC loss (efficient_models/xvlm.py:384-416; ABI 8), one launch each way.  I / T: [Bt, E] image / text features of the
+ * GATHERED batch (dtype bf16 or f32, leading dimensions ldi / ldt - the two may be column ranges of one gathered buffer;
+ * E <= 256, a multiple of 8, rows 16-byte aligned), temp: device f32 word, group: optional int64 [Bt] (idx: equal entries
+ * are positives of each other; NULL: the diagonal).
+ *   fwd: sim f32 [Bt, lds] = I T^t (un-scaled: evlm_sample_negatives reads this rank's block of it),
+ *        loss[0] = (CE(sim / temp, labels) + CE(sim^t / temp, labels)) / 2, labels = pos / pos.sum(1);
+ *        stats f32 [4 Bt + 8] (row / column log-sum-exps, work words) - its word [4 Bt] must be ZERO on entry and is zero
+ *        again on exit (arrival counter of the fixed-order final sum).
+ *   bwd: dI, dT ([Bt, E], dtype, written) = dloss[0] * d loss / d I, d T; dtemp[0] (written) = dloss[0] * d loss / d temp.
+ * ---------------------------------------------------------------------------------------------- */
+int evlm_itc_loss_fwd(int dtype, const void* I, int ldi, const void* T, int ldt, int Bt, int E, const float* temp,
+                      const int64_t* group, float* sim, int lds, float* stats, float* loss, void* stream);
+int evlm_itc_loss_bwd(int dtype, const void* I, int ldi, const void* T, int ldt, int Bt, int E, const float* temp,
+                      const int64_t* group, const float* sim, int lds, float* stats, const float* dloss,
+                      void* dI, int lddi, void* dT, int lddt, float* dtemp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * ITM hard negatives (efficient_models/xvlm.py:422-458 - there 2B host-synchronising torch.multinomial calls).
  * sim: f32 [B, ld] image x text similarities (un-scaled), temp: device f32 word, group: optional int64 [B] ids whose
  * equal entries are positives of each other (NULL: only the diagonal).  out int64 [2B]: out[t] = image drawn for text t
@@ -432,7 +451,16 @@ int evlm_l0_deterministic(const float* loga, int rows, int size, float temperatu
  * the inverse CDF at a Philox(rng_state {seed, step}, call_id, row) uniform: one launch, no host sync, replayable.
  * ---------------------------------------------------------------------------------------------- */
 int evlm_sample_negatives(const float* sim, int B, int ld, const float* temp, const int64_t* group,
-                          const int64_t* rng_state, uint32_t call_id, int64_t* out, void* stream);
+                          const int64_t* rng_state, uint32_t call_id, int64_t* out, int64_t* sel4, int32_t* img4, void* stream);
+/* sel4 / img4 (ABI 8, both or neither): the batched fusion pass's layout [pos B ; text x negative image B ; negative text x
+ * image B ; masked text B] written by the same launch - sel4 int64 [4B] = rows of the text pass's [text ; masked text] output
+ * (r, r, out[B + r], B + r), img4 int32 [4B] = the image each fusion row attends to (r, out[r], r, r).
+ *
+ * out[k] = x[sel[k]] over whole samples of row_bytes bytes (a multiple of 16; any dtype), n <= 65535 - and its deterministic
+ * backward dx[r] = sum_{k : sel[k] == r} dy[k] in ascending k (zero rows where nothing selects r); row_elems % 8 == 0. */
+int evlm_select_batches_fwd(const void* x, const int64_t* sel, int n, int64_t row_bytes, void* out, void* stream);
+int evlm_select_batches_bwd(int dtype, const void* dy, const int64_t* sel, int n, int rows, int64_t row_elems, void* dx,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser-side helpers (next-tier row §8f-1; kept minimal here)

@@ -206,6 +206,135 @@ def test_gated_activation_backward_in_the_gemm_epilogue(M, K, Fh, act_name, gate
         assert rel_err(f_.float(), s_.float()) < 2e-2, name
 
 
+def test_fusion_batch_selection_and_the_samplers_layout_vectors():
+    """ops.select_batches (whole-sample x[sel] with a deterministic one-launch backward) against index_select + autograd's
+    index_add, and the layout vectors evlm_sample_negatives writes beside its draws: sel4 = (r, r, drawn text, B + r) over
+    the text pass's [text ; masked text] rows, img4 = (r, drawn image, r, r) - models/model_pretrain.py's fusion batch
+    [pos ; text x negative image ; negative text x image ; masked text] (reference xvlm.py:436-458)"""
+    o = ops()
+    g = torch.Generator().manual_seed(9)
+    B, Ln, d = 12, 30, 64
+    x0 = torch.randn(2 * B, Ln, d, generator=g).to(DEV).bfloat16()
+    sim = torch.randn(B, B, generator=g).to(DEV)
+    o.dropout_seed(11)
+    neg, sel4, img4 = o.sample_negatives(sim, torch.tensor(0.5, device=DEV), None, layout=True)
+    ar = torch.arange(B, device=DEV)
+    assert torch.equal(sel4, torch.cat([ar, ar, neg[B:], B + ar])) and torch.equal(img4.long(), torch.cat([ar, neg[:B], ar, ar]))
+    assert bool((neg[:B] != ar).all()) and bool((neg[B:] != ar).all())
+    x = x0.clone().requires_grad_(True)
+    y = o.select_batches(x, sel4)
+    assert torch.equal(y, x0[sel4])
+    gy = torch.randn(y.shape, generator=g).to(DEV).bfloat16()
+    y.backward(gy)
+    ref = torch.zeros(2 * B, Ln, d, device=DEV).index_add_(0, sel4, gy.float())
+    assert rel_err(x.grad.float(), ref) < 4e-3                      # (fp32 sums of up to 3 rows, rounded once)
+    x.grad = None
+    o.select_batches(x, sel4).backward(gy)
+    x2 = x.grad.clone()
+    x.grad = None
+    o.select_batches(x, sel4).backward(gy)
+    assert torch.equal(x.grad, x2)
+    m = torch.randint(0, 2, (2 * B, Ln), generator=g).to(DEV)      # int64 masks: 240-byte samples
+    assert torch.equal(o.select_batches(m, sel4), m[sel4])
+
+
+@pytest.mark.parametrize("R,Cn,shape3", [(64, 30522, (8, 8)), (192, 2, None), (40, 1000, None)])
+def test_losses_of_one_logits_tensor_sum_their_gradients_in_one_buffer(R, Cn, shape3, monkeypatch):
+    """ops.join_grads: the hard-label CE (model_pretrain.py MLM / ITM heads) and the distillation KL (GeneralDistill.py:84-89)
+    of the SAME logits write ONE padded gradient buffer (first backward writes, second accumulates in-kernel) - equal to
+    autograd's sum of the two separate gradients, also over a retained graph run twice, with ignored rows, and with a third
+    consumer that knows nothing of the join"""
+    o = ops()
+    g = torch.Generator().manual_seed(3)
+    x0 = (torch.randn(R, Cn, generator=g) * 2).to(DEV).bfloat16()
+    t = (torch.randn(R, Cn, generator=g) * 2).to(DEV).bfloat16()
+    lab = torch.randint(0, Cn, (R,), generator=g).to(DEV)
+    lab[::7] = -100
+    w = (torch.randn(Cn, 16, generator=g) * 0.1).to(DEV).bfloat16()
+
+    def run(join, third=False):
+        monkeypatch.setattr(o, "_NO_GRAD_JOIN", not join)
+        x = x0.clone().requires_grad_(True)
+        y = x * 1.0                                                  # (a non-leaf producer, as the decoder product is)
+        if shape3:
+            y = y.view(*shape3, Cn)
+        y = o.join_grads(y)
+        assert (getattr(y, "_evlm_join", None) is not None) == join
+        loss = o.cross_entropy(y, lab) * 0.6 + o.soft_cross_entropy(y, t.view(y.shape), 2.0) * 0.4
+        if third:
+            loss = loss + (y.float().reshape(R, Cn) @ w.float()).square().mean()
+        loss.backward(retain_graph=True)
+        g1 = x.grad.clone()
+        x.grad = None
+        loss.backward()
+        return loss.detach(), g1, x.grad.clone()
+
+    la, ga1, ga2 = run(True)
+    lb, gb1, gb2 = run(False)
+    assert torch.equal(la, lb)
+    assert torch.equal(ga1, ga2) and torch.equal(gb1, gb2)
+    # (the joined sum rounds to bf16 twice - first writer, accumulating writer; autograd.s sum of two bf16 tensors three times)
+    xr = x0.float().requires_grad_(True)
+    valid = lab != -100
+    ref = F.cross_entropy(xr[valid], lab[valid]) * 0.6 + \
+        F.kl_div(F.log_softmax(xr / 2.0, -1), F.softmax(t.float() / 2.0, -1), reduction="batchmean") * 0.4
+    ref.backward()
+    ea, eb = rel_err(ga1.float(), xr.grad), rel_err(gb1.float(), xr.grad)
+    assert ea < 8e-3 and ea <= eb * 1.1 + 1e-4, (ea, eb)
+    lc, gc1, gc2 = run(True, third=True)
+    ld, gd1, gd2 = run(False, third=True)
+    assert rel_err(gc1.float(), gd1.float()) < 8e-3 and torch.equal(gc1, gc2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Bt,E,grouped,packed", [(64, 256, False, False), (64, 256, True, False), (130, 256, True, True),
+                                                 (7, 64, False, True), (512, 256, True, True)])
+def test_itc_loss_in_one_launch_each_way(dtype, Bt, E, grouped, packed):
+    """ops.itc_loss (evlm_itc_loss_fwd / _bwd) against plain fp32 autograd of efficient_models/xvlm.py:384-416:
+    logits = I T^t / temp, (CE(logits, labels) + CE(logits^t, labels)) / 2 with identity labels or the idx-equality soft
+    labels pos / pos.sum(1); its gradients wrt the features and the temperature; the un-scaled similarities it hands the
+    hard-negative sampler; ragged batch sizes, the gathered [Bt, 2E] form, and run-to-run bit identity (fixed-order sums)"""
+    o = ops()
+    g = torch.Generator().manual_seed(5)
+    I = F.normalize(torch.randn(Bt, E, generator=g), dim=-1).to(DEV).to(dtype)
+    T = F.normalize(torch.randn(Bt, E, generator=g) + 0.5 * I.cpu().float(), dim=-1).to(DEV).to(dtype)
+    temp = torch.nn.Parameter(torch.tensor(0.07, device=DEV))
+    group = torch.randint(0, max(2, Bt // 3), (Bt,), generator=g).to(DEV) if grouped else None
+    up = torch.tensor(0.7, device=DEV)
+
+    def run():
+        temp.grad = None
+        if packed:
+            both = torch.cat([I, T], 1).requires_grad_(True)
+            loss, sim = o.itc_loss(both, None, temp, group)
+            (loss * up).backward()
+            return loss.detach(), sim, both.grad[:, :E], both.grad[:, E:], temp.grad.clone()
+        a, b = I.clone().requires_grad_(True), T.clone().requires_grad_(True)
+        loss, sim = o.itc_loss(a, b, temp, group)
+        (loss * up).backward()
+        return loss.detach(), sim, a.grad, b.grad, temp.grad.clone()
+
+    loss, sim, dI, dT, dtemp = run()
+    Ir, Tr = I.float().clone().requires_grad_(True), T.float().clone().requires_grad_(True)
+    tr = temp.detach().clone().requires_grad_(True)
+    logits = Ir @ Tr.t() / tr
+    if grouped:
+        pos = torch.eq(group.view(-1, 1), group.view(1, -1)).float()
+        labels = pos / pos.sum(1, keepdim=True)
+        ref = (-(F.log_softmax(logits, 1) * labels).sum(1).mean() - (F.log_softmax(logits.t(), 1) * labels).sum(1).mean()) / 2
+    else:
+        lab = torch.arange(Bt, device=DEV)
+        ref = (F.cross_entropy(logits, lab) + F.cross_entropy(logits.t(), lab)) / 2
+    (ref * up).backward()
+    assert abs(float(loss) - float(ref.detach())) < 2e-5 * max(1.0, abs(float(ref.detach())))
+    assert rel_err(sim, (Ir @ Tr.t()).detach()) < 1e-5
+    t = 1e-4 if dtype == torch.float32 else 6e-3          # (bf16: the gradients are rounded to bf16 on the way out)
+    assert rel_err(dI.float(), Ir.grad) < t and rel_err(dT.float(), Tr.grad) < t
+    assert abs(float(dtemp) - float(tr.grad)) < 1e-4 * max(1.0, abs(float(tr.grad)))
+    again = run()
+    assert torch.equal(again[0], loss) and torch.equal(again[2], dI) and torch.equal(again[3], dT) and torch.equal(again[4], dtemp)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("d,eps", [(64, 1e-12), (768, 1e-5), (1536, 1e-5)])
 def test_layernorm(dtype, d, eps):

@@ -47,3 +47,19 @@ for rows in (12608, 7680, 3840):
     tf, tfb = timeit(f, 50), timeit(fb, 50)
     mb = rows * 768 * 2 * 3 / 1e6
     print(f"ln_bwd rows={rows}: ~{tfb - tf:.2f} us (fwd+bwd {tfb:.2f}, fwd {tf:.2f})  ({mb / (tfb - tf):.2f} TB/s of dy + x read, dx written)")
+
+# ... and the pre-LN block form (layer_norm_fork: the residual branch's gradient summed inside the backward kernel)
+for rows in (12608, 7680, 3840):
+    x = torch.randn(rows, 768, device="cuda", dtype=torch.bfloat16).requires_grad_()
+    w = torch.nn.Parameter(torch.randn(768, device="cuda")); b = torch.nn.Parameter(torch.randn(768, device="cuda"))
+    gy = torch.randn(rows, 768, device="cuda", dtype=torch.bfloat16)
+    gx = torch.randn(rows, 768, device="cuda", dtype=torch.bfloat16)
+    def fb():
+        y, xa = ops.layer_norm_fork(x, w, b, 1e-5)
+        torch.autograd.grad((y, xa), (x, w, b), (gy, gx))
+    def f():
+        with torch.no_grad():
+            ops.layer_norm(x, w, b, 1e-5)
+    tf, tfb = timeit(f, 50), timeit(fb, 50)
+    mb = rows * 768 * 2 * 4 / 1e6
+    print(f"ln_bwd + residual gradient rows={rows}: ~{tfb - tf:.2f} us (fwd+bwd {tfb:.2f}, fwd {tf:.2f})  ({mb / (tfb - tf):.2f} TB/s of dy + x + addend read, dx written)")
