@@ -489,7 +489,7 @@ extern "C" int evlm_layernorm_fwd(int dtype, const void* x, const float* gamma, 
 // resident workgroups need, and the grid is then cut so that EVERY wave makes that many trips - 12 608 rows on 768
 // workgroups left 320 waves a fifth row while 2 752 waited (a 20 % tail), on 631 workgroups every wave takes five
 static int ln_bwd_blocks(int rows) {
-  const int trips = imax(1, ceil_div(rows, 4 * 768));
+  const int trips = imax(2, ceil_div(rows, 4 * 768));      // (>= 2: a workgroup's 2 d column sums leave through a workspace)
   return imax(1, ceil_div(rows, 4 * trips));
 }
 
