@@ -1711,10 +1711,13 @@ class _ITCLoss(torch.autograd.Function):
         ctx.dims = (packed, Bt, E, lds, tuple(temp.shape))
         sim_v = sim[:, :Bt]
         ctx.mark_non_differentiable(sim_v)
+        ctx.set_materialize_grads(False)          # (no zero tensor for the similarities' "gradient")
         return loss, sim_v
 
     @staticmethod
     def backward(ctx, dloss, _dsim):
+        if dloss is None:
+            return None, None, None, None
         a, b, t, g, sim, stats = ctx.saved_tensors
         packed, Bt, E, lds, tshape = ctx.dims
         dl = dloss.reshape(-1)[:1]

@@ -55,6 +55,6 @@ EVLM_FORCE_REDUCE=1 python3 tools/dp_path_probe.py --reps 1 --only joint,cuts_al
 # soak: joint graph 3 000 steps; N > 1 segments (one-rank RCCL) 1 500 steps of GD and of the ITR pruning step
 ( python3 bench.py --steps 3000 --warmup 5 --no-cpu-baseline --no-oracle-check --no-roofline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('GD joint graph, 3000 steps:', d['ms_per_step'], 'ms/step', d['last_losses'])"
   EVLM_FORCE_REDUCE=1 python3 bench.py --steps 1500 --warmup 5 --no-cpu-baseline --no-oracle-check --no-roofline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('GD segments (one-rank RCCL), 1500 steps:', d['ms_per_step'], 'ms/step', d['last_losses'], d['config']['launch'])"
-  EVLM_FORCE_REDUCE=1 python3 tools/itr_bench.py 384 64 1500 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('ITR-384 segments (one-rank RCCL), 1500 steps:', d)"
+  EVLM_FORCE_REDUCE=1 python3 tools/itr_bench.py 384 64 1500 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print('ITR-384 segments (one-rank RCCL), 1500 steps:', d)"
   python3 tools/vqa_bench.py 480 32 1000 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('VQA-480 captured step, 1000 steps:', d)" ) > $OUT/soak.txt 2>&1
 ls -la $OUT
