@@ -271,7 +271,7 @@ def test_losses_of_one_logits_tensor_sum_their_gradients_in_one_buffer(R, Cn, sh
 
     la, ga1, ga2 = run(True)
     lb, gb1, gb2 = run(False)
-    assert torch.equal(la, lb)
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))       # (the KL forward sums its rows with f32 atomics: last-bit order noise)
     assert torch.equal(ga1, ga2) and torch.equal(gb1, gb2)
     # (the joined sum rounds to bf16 twice - first writer, accumulating writer; autograd.s sum of two bf16 tensors three times)
     xr = x0.float().requires_grad_(True)
