@@ -637,7 +637,14 @@ class _Linear(torch.autograd.Function):
         N = W.shape[0]
         ydt = torch.float32 if out_f32 else x2.dtype
         ldc = _pad8(N)
-        ybuf = torch.empty((M, ldc), dtype=ydt, device=x.device) if ldc == N else zeros_small((M, ldc), ydt, x.device)
+        if ldc == N:
+            ybuf = torch.empty((M, ldc), dtype=ydt, device=x.device)
+        elif M * ldc * (4 if out_f32 else x2.element_size()) <= ZERO_SMALL_MAX:
+            ybuf = zeros_small((M, ldc), ydt, x.device)
+        else:
+            # (the vocabulary head: [512, 30 528] for 30 522 classes - only the padding columns need the zeros, not 31 MB)
+            ybuf = torch.empty((M, ldc), dtype=ydt, device=x.device)
+            ybuf[:, N:].zero_()
         need_grad = any(ctx.needs_input_grad)
         preact = None
         if act != L.ACT_NONE and need_grad:

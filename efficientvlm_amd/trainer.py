@@ -101,6 +101,8 @@ class GradReducer:
         self.active = self.world > 1 or (force and ready)
         self.prescaled = prescaled
         self.buckets = self._buckets(self.flat)
+        # (a high-priority stream was measured - profiles/r05_exchange_overlap.md: it gets a hardware queue of its own, and a
+        # long kernel on it then starves every normal-priority queue: 24.7 against 17.9 ms in the simulated-wire probe)
         self.stream = torch.cuda.Stream() if (self.flat and self.flat[0].is_cuda) else None
         self._pending = []
         self.coalesce = self.active and self._probe_coalescing()
@@ -296,6 +298,19 @@ class _StagedExchange:
         self._sent = len(self._stages)
         if self._cut is None:
             self.reducer.finish()
+
+    def _off_default_stream(self, fn):
+        """run fn() on a pool stream of this trainer when the caller is on the legacy default stream (joined both ways)"""
+        cur = torch.cuda.current_stream()
+        if cur != torch.cuda.default_stream():
+            return fn()
+        if getattr(self, "_loop", None) is None:
+            self._loop = torch.cuda.Stream()
+        self._loop.wait_stream(cur)
+        with torch.cuda.stream(self._loop):
+            out = fn()
+        cur.wait_stream(self._loop)
+        return out
 
     def _replay_segments(self, segs, last_reduce):
         """a step captured as hipGraph segments around its collectives: graphs replay on the current stream, the ITC gather
@@ -876,6 +891,10 @@ class GDTrainer(_StagedExchange):
         torch.cuda.synchronize()
         ops.flush_table_uploads()
         last_reduce = [item for kind, item in segs if kind == "reduce"][-1]
+        if os.environ.get("EVLM_DEBUG_SEGMENTS"):
+            import sys
+            print("[efficientvlm_amd] segments:", [kind if kind != "reduce" else f"reduce({sum(r.numel() for r in item) * 4 / 1e6:.0f} MB)"
+                                                   for kind, item in segs], file=sys.stderr)
         return dict(segs=segs, out=out, kd=kd, last_reduce=last_reduce)
 
     def _ranks_agree(self, ok):
@@ -963,6 +982,16 @@ class GDTrainer(_StagedExchange):
     def step(self, batch, lr_mult=1.0):
         """one GD step on a general or a region batch (the latter carries idx_to_group_img / image_atts / target_bbox /
         is_image); returns a device tensor [total, itc, itm, mlm, kd] (no host sync)."""
+        if self.reducer.active and batch["image"].is_cuda and not os.environ.get("EVLM_NO_LOOP_STREAM"):
+            # N > 1: NEVER on the legacy default stream.  On this stack a process-group collective - issued from any stream,
+            # async or not - makes the DEFAULT stream wait for the group's own stream: a training loop that runs there
+            # stalls at every gradient stage until its all-reduce has finished (measured with a simulated wire: 18.4 ms
+            # per step on the default stream, 16.0 on a pool stream, 15.3 without any exchange;
+            # profiles/r05_exchange_overlap.md).  The pruning trainers' captured steps already run on a stream of their own.
+            return self._off_default_stream(lambda: self._step_on_current(batch, lr_mult))
+        return self._step_on_current(batch, lr_mult)
+
+    def _step_on_current(self, batch, lr_mult):
         if self.pipeline_teacher:
             return self._step_pipelined(batch, lr_mult)
         return self._step_unpipelined(batch, lr_mult)
@@ -1227,6 +1256,8 @@ class _CapturedStep:
         l0 = self.student.l0_module
         if not self.capture_step or key is None:
             self.last_launch = "eager"
+            if self.reducer.active and torch.cuda.is_available() and not os.environ.get("EVLM_NO_LOOP_STREAM"):
+                return self._off_default_stream(lambda: body(self.global_step, False))      # (see GDTrainer.step)
             return body(self.global_step, False)
         # Every step of a capturing trainer - the eager ones too - runs on ONE dedicated stream: autograd remembers the stream
         # an AccumulateGrad node was created on and synchronises a later backward with it, which inside a capture would pull

@@ -818,16 +818,18 @@ student, teacher = build_gd(geom, 9)
 tr = GDTrainer(student, teacher, dtype=torch.bfloat16, use_graph=True, pipeline_teacher=True)
 batches = [{k: v.cuda() for k, v in synth.make_batch(geom, 4, seed=3 + i).items()} for i in range(3)]
 seqs = []
+inner, streams = tr._step_on_current, []
+tr._step_on_current = lambda b, m: (streams.append(torch.cuda.current_stream() != torch.cuda.default_stream()), inner(b, m))[1]
 for i in range(7):
     runtime.COLLECTIVES = []
-    tr.step(batches[i % 3])
+    tr.step(batches[i % 3])                    # (called on the default stream, as a plain training loop does)
     seqs.append(runtime.COLLECTIVES)
 torch.cuda.synchronize()
 runtime.COLLECTIVES = None
 segmented = bool(tr._seg) and not getattr(tr, "_segments_broken", False)
 slab = sum(g.numel() for g in tr.opt.flat_grads)
 dist.destroy_process_group()
-print("RESULT " + json.dumps({"seqs": seqs, "segmented": segmented, "slab": slab}))
+print("RESULT " + json.dumps({"seqs": seqs, "segmented": segmented, "slab": slab, "off_default_stream": all(streams) and len(streams) == 7}))
 """
 
 
@@ -850,6 +852,10 @@ def test_segmented_and_eager_multi_gpu_steps_issue_the_same_collective_sequence(
 
     seg, eag = run(False), run(True)
     assert seg["segmented"] and not eag["segmented"]
+    # with a live reducer the step never runs on the legacy default stream: on this stack every process-group collective
+    # makes THAT stream wait for the group's stream, which serialises the gradient exchange with backward
+    # (profiles/r05_exchange_overlap.md)
+    assert seg["off_default_stream"] and eag["off_default_stream"]
     assert seg["seqs"][0] == eag["seqs"][0]        # the priming call: two eager warm-up steps in both modes
     for a, b in zip(seg["seqs"][1:], eag["seqs"][1:]):
         assert a == b and len(a) >= 5, (a, b)

@@ -10,7 +10,7 @@ algorithm bandwidth, without its CU / HBM contention).  "exchange hidden" = (seg
 exchange).
 
     EVLM_FORCE_REDUCE=1 python tools/dp_path_probe.py [--wire-gbps 170] [--steps 12] [--only tag,tag]"""
-import argparse, os, sys, time
+import argparse, contextlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("EVLM_FORCE_REDUCE", "1")
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29561")
@@ -64,25 +64,135 @@ def run(tag, env=None, patch=None, sim=False):
     s, t = bench.build(geom, dev, 1234)
     tr = bench.make_trainer(s, t, torch.bfloat16, True, True)
     if patch: patch(tr)
-    SIM["on"], SIM["bytes"] = sim, 0
+    if os.environ.get("EVLM_PROBE_SEGMENT_TIMES") and tr.reducer.active:
+        time_segments(tr)
+    SIM["on"], SIM["bytes"] = sim is True, 0
     it = 0
-    for _ in range(7):
-        tr.step(batches[it % 4]); it += 1
-    torch.cuda.synchronize(); SIM["bytes"] = 0; t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step(batches[it % 4]); it += 1
-    host = time.perf_counter() - t0
+    # EVLM_PROBE_STREAM=1: the training loop on a pool stream instead of the (legacy) default stream
+    loop_stream = torch.cuda.stream(torch.cuda.Stream()) if os.environ.get("EVLM_PROBE_STREAM") else contextlib.nullcontext()
+    with loop_stream:
+        for _ in range(7):
+            tr.step(batches[it % 4]); it += 1
+        torch.cuda.synchronize(); SIM["bytes"] = 0; t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.step(batches[it % 4]); it += 1
+        host = time.perf_counter() - t0
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     wire = f"  simulated wire {SIM['bytes'] / args.steps / 1e6:6.1f} MB = {SIM['bytes'] / args.steps / (args.wire_gbps * 1e6):5.2f} ms/step" if sim else ""
     mode = "segments" if (tr._seg and not getattr(tr, "_segments_broken", False)) else ("joint graph" if tr._joint else "eager")
     print(f"{tag:58s} {el / args.steps * 1e3:7.2f} ms/step   (host issue {host / args.steps * 1e3:6.2f} ms) [{mode}]{wire}", flush=True)
     SIM["on"] = False
+    if getattr(tr, "_seg_times", None):
+        report_segments(tr, tag.split(":")[0])
     for k, v in saved.items():
         if v is None:
             os.environ.pop(k, None)
         else:
             os.environ[k] = v
     del tr, s, t
+
+
+def sleep_only(tr):
+    """the exchange as NOTHING BUT the simulated wire on the reducer's stream (no process-group call at all): separates what
+    the collectives' own stream bookkeeping costs from what a long kernel beside the segments costs"""
+    red = tr.reducer
+
+    def reduce_async(tensors):
+        red.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(red.stream):
+            for t in red._buckets(tensors):
+                nb = t.numel() * t.element_size()
+                SIM["bytes"] += nb
+                torch.cuda._sleep(int(nb / (args.wire_gbps * 1e3) * CYC_PER_US))
+
+    def finish():
+        torch.cuda.current_stream().wait_stream(red.stream)
+    red.reduce_async, red.finish = reduce_async, finish
+
+
+def sleep_fresh(tr):
+    """... and on a stream created just now, ordered behind the segment by an event"""
+    red = tr.reducer
+    red.stream = torch.cuda.Stream()
+    sleep_only(tr)
+
+
+def time_segments(tr):
+    """HIP events on the step's stream around every item of the segment chain (printed for the last step)"""
+    def replay(segs, last_reduce):
+        evs = [torch.cuda.Event(enable_timing=True)]
+        evs[0].record()
+        names = []
+        for kind, item in segs:
+            if kind == "graph":
+                item.replay()
+            elif kind == "gather":
+                dist.all_gather(item[0], item[1])
+            else:
+                tr.reducer.reduce_async(item)
+                if item is last_reduce:
+                    tr.reducer.finish()
+            e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e); names.append(kind)
+        tr._seg_times = (names, evs)
+    tr._replay_segments = replay
+
+
+def report_segments(tr, tag):
+    names, evs = tr._seg_times
+    torch.cuda.synchronize()
+    print(f"#   {tag}: " + "  ".join(f"{n} {evs[i].elapsed_time(evs[i + 1]):.2f}" for i, n in enumerate(names)), flush=True)
+
+
+_NCCL_ALIAS = []
+
+
+def find_nccl_stream():
+    """the process group launches its kernels on an internal stream it takes from torch's pool of 32 - the pool
+    torch.cuda.Stream() cycles through.  Find OUR handle of that stream: the one whose pending sleep delays a collective."""
+    if _NCCL_ALIAS:
+        return _NCCL_ALIAS[0]
+    x = torch.ones(4, device=dev)
+    w = _real_all_reduce(x, async_op=True); w.wait(); torch.cuda.synchronize()        # (the group's stream exists now)
+    for _ in range(40):
+        s_ = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s_):
+            torch.cuda._sleep(int(15e3 * CYC_PER_US))
+        t0 = time.perf_counter()
+        w = _real_all_reduce(x, async_op=True); w.wait()
+        torch.cuda.current_stream().synchronize()
+        dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        if dt > 8e-3:
+            _NCCL_ALIAS.append(s_)
+            print(f"# the process group's stream found among torch's pool streams (a collective behind a 15 ms sleep on it took {dt * 1e3:.1f} ms)", flush=True)
+            return s_
+    raise RuntimeError("the process group's stream is not one of torch's pool streams")
+
+
+def sim_on_nccl(from_main):
+    """the faithful form: the spin kernels sit ON the process group's own stream, in front of each stage's (one-rank, empty)
+    all-reduce - where the RCCL kernels of a real run execute.  from_main: the collectives are issued from the step's
+    stream (no reducer stream in the chain) instead of from the reducer's."""
+    def patch(tr):
+        red, ns = tr.reducer, find_nccl_stream()
+        if from_main:
+            red.stream = None
+        real = red.reduce_async
+
+        def reduce_async(tensors):
+            src = red.stream if red.stream is not None else torch.cuda.current_stream()
+            if red.stream is not None:
+                red.stream.wait_stream(torch.cuda.current_stream())
+            ns.wait_stream(src)
+            with torch.cuda.stream(ns):
+                for t in red._buckets(tensors):
+                    nb = t.numel() * t.element_size()
+                    SIM["bytes"] += nb
+                    torch.cuda._sleep(int(nb / (args.wire_gbps * 1e3) * CYC_PER_US))
+            real(tensors)
+        red.reduce_async = reduce_async
+    return patch
 
 
 def no_reduce(tr):
@@ -99,6 +209,21 @@ for rep in range(args.reps):
     run("nosplit: segments, cuts=all, whole teacher forward behind the gather", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER_SPLIT": "0"})
     run("nosplit_sim: same + simulated wire", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER_SPLIT": "0"}, sim=True)
     run("cuts_all_noex: same, no gradient exchange", env={"EVLM_DP_CUTS": "all"}, patch=no_reduce)
+    run("cuts_all_sleep: the simulated wire alone (no process-group calls)", env={"EVLM_DP_CUTS": "all"}, patch=sleep_only, sim=True)
+    run("cuts_all_sleepfresh: same on a fresh stream", env={"EVLM_DP_CUTS": "all"}, patch=sleep_fresh, sim=True)
+    run("cuts_all_nccl: simulated wire ON the process group's stream", env={"EVLM_DP_CUTS": "all"}, patch=sim_on_nccl(False), sim="nccl")
+    run("cuts_all_nccl_main: same, collectives issued from the step's stream", env={"EVLM_DP_CUTS": "all"}, patch=sim_on_nccl(True), sim="nccl")
+    run("tgraph_noex: teacher as its own graph on the side stream, no exchange", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER": "graph"}, patch=no_reduce)
+    run("tgraph_nccl: same + simulated wire on the group's stream", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER": "graph"}, patch=sim_on_nccl(False), sim="nccl")
+
+    def serial_teacher(inner):
+        def patch(tr):
+            tr._side = torch.cuda.current_stream()         # the teacher graph replays IN FRONT of the segments, same stream
+            inner(tr)
+        return patch
+    run("tserial_noex: teacher graph serial on the step's stream, no exchange", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER": "graph"}, patch=serial_teacher(no_reduce))
+    run("tserial_nccl: same + simulated wire on the group's stream", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER": "graph"}, patch=serial_teacher(sim_on_nccl(False)), sim="nccl")
+    run("tserial_nccl_main: same, collectives issued from the step's stream", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER": "graph"}, patch=serial_teacher(sim_on_nccl(True)), sim="nccl")
     for vc in ("4", "3", "2"):
         run(f"cuts_v{vc}: segments, ONE ViT cut at layer {vc}", env={"EVLM_DP_VIT_CUTS": vc})
         run(f"cuts_v{vc}_sim: same + simulated wire", env={"EVLM_DP_VIT_CUTS": vc}, sim=True)
