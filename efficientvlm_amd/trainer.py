@@ -299,6 +299,17 @@ class _StagedExchange:
         if self._cut is None:
             self.reducer.finish()
 
+    def _wants_pool_stream(self, on_gpu):
+        """live reducer over RCCL: the step must not run on the legacy default stream (GDTrainer.step).  Not for gloo - the
+        two-ranks-on-one-GPU tests and dry runs: its device-tensor path blocks the host per collective and measured 4 x
+        slower with the step on a pool stream (6.5 against 1.5 s per step of the bench.py dry run)"""
+        if not (on_gpu and self.reducer.active) or os.environ.get("EVLM_NO_LOOP_STREAM"):
+            return False
+        try:
+            return dist.get_backend(self.reducer.group) == "nccl"
+        except Exception:
+            return False
+
     def _off_default_stream(self, fn):
         """run fn() on a pool stream of this trainer when the caller is on the legacy default stream (joined both ways)"""
         cur = torch.cuda.current_stream()
@@ -982,7 +993,7 @@ class GDTrainer(_StagedExchange):
     def step(self, batch, lr_mult=1.0):
         """one GD step on a general or a region batch (the latter carries idx_to_group_img / image_atts / target_bbox /
         is_image); returns a device tensor [total, itc, itm, mlm, kd] (no host sync)."""
-        if self.reducer.active and batch["image"].is_cuda and not os.environ.get("EVLM_NO_LOOP_STREAM"):
+        if self._wants_pool_stream(batch["image"].is_cuda):
             # N > 1: NEVER on the legacy default stream.  On this stack a process-group collective - issued from any stream,
             # async or not - makes the DEFAULT stream wait for the group's own stream: a training loop that runs there
             # stalls at every gradient stage until its all-reduce has finished (measured with a simulated wire: 18.4 ms
@@ -1256,7 +1267,7 @@ class _CapturedStep:
         l0 = self.student.l0_module
         if not self.capture_step or key is None:
             self.last_launch = "eager"
-            if self.reducer.active and torch.cuda.is_available() and not os.environ.get("EVLM_NO_LOOP_STREAM"):
+            if self._wants_pool_stream(torch.cuda.is_available()):
                 return self._off_default_stream(lambda: body(self.global_step, False))      # (see GDTrainer.step)
             return body(self.global_step, False)
         # Every step of a capturing trainer - the eager ones too - runs on ONE dedicated stream: autograd remembers the stream
