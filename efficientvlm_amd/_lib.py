@@ -89,6 +89,7 @@ SIGNATURES = {
     "evlm_ce_bwd": [_i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evlm_transpose_grouped": [_vp, _i, _i, _vp],
     "evlm_copy_grouped": [_vp, _i, _i, _vp],
+    "evlm_copy_few": [_vp, _vp, _vp, _i, _vp],
     "evlm_ce_weighted_fwd": [_i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "evlm_ce_weighted_bwd": [_i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evlm_kl_fwd": [_i, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],

@@ -723,6 +723,38 @@ __global__ __launch_bounds__(256) void copy_grouped_kernel(const int64_t* __rest
     if (i < nvec) dst[i] = src[i];
   }
 }
+// ... and the same for up to 8 units whose addresses change from call to call (a step's input batch going into its static
+// buffers): the units travel as KERNEL ARGUMENTS - no device table to upload.
+struct CopyFew { const void* src[8]; void* dst[8]; int64_t nbytes[8]; int first_block[9]; int n; };
+__global__ __launch_bounds__(256) void copy_few_kernel(CopyFew a) {
+  int u = 0;
+  while (u + 1 < a.n && (int)blockIdx.x >= a.first_block[u + 1]) ++u;
+  const uint4* src = reinterpret_cast<const uint4*>(a.src[u]);
+  uint4* dst = reinterpret_cast<uint4*>(a.dst[u]);
+  const int64_t nvec = a.nbytes[u] >> 4;
+  const int64_t v0 = ((int64_t)blockIdx.x - a.first_block[u]) * 4096;
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int64_t i = v0 + k * 256 + threadIdx.x;
+    if (i < nvec) dst[i] = src[i];
+  }
+}
+extern "C" int evlm_copy_few(const void* const* src, void* const* dst, const int64_t* nbytes, int n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(src && dst && nbytes && n > 0 && n <= 8, "evlm_copy_few: 1..8 units");
+  CopyFew a;
+  int blocks = 0;
+  for (int u = 0; u < n; ++u) {
+    EVLM_REQUIRE(src[u] && dst[u] && nbytes[u] > 0 && nbytes[u] % 16 == 0 && ((uintptr_t)src[u]) % 16 == 0 && ((uintptr_t)dst[u]) % 16 == 0,
+                 "evlm_copy_few: units of a multiple of 16 bytes, 16-byte aligned");
+    a.src[u] = src[u]; a.dst[u] = dst[u]; a.nbytes[u] = nbytes[u]; a.first_block[u] = blocks;
+    blocks += (int)((nbytes[u] + 65535) / 65536);
+  }
+  a.first_block[n] = blocks; a.n = n;
+  hipLaunchKernelGGL(copy_few_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  EVLM_LAUNCH_CHECK("evlm_copy_few");
+  return 0;
+}
 extern "C" int evlm_copy_grouped(const int64_t* table, int n_units, int total_blocks, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(table && n_units > 0 && total_blocks > 0, "evlm_copy_grouped: bad args");

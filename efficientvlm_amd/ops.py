@@ -324,6 +324,10 @@ def _assign_prepare(params, will_assign):
         if f:
             st["skip"][k].zero_()
             st["done"].add(k)
+            # a weight whose first contribution is not an assigning product (the small heads: their dW is not one of the
+            # grouped products) would be zero-filled HERE, by a launch of its own, every step: from the next step on it
+            # belongs to the ranges the step's ONE grouped fill zeroes (finish_assign moves it)
+            st.setdefault("demote", set()).add(k)
         elif k is not None and k in st["pending"]:
             rec = st["pending"].pop(k)
             if rec[10]:
@@ -356,6 +360,13 @@ def finish_assign():
     _keep_table(zero_grouped([g for k, g in st["skip"].items() if k not in st["done"]]))
     st["done"].clear()
     st["pending"].clear()
+    if st.get("demote") and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        fill = st.get("fill")                    # (the optimiser's list of ranges its zero_grad() fills; absent in bare states)
+        for k in st["demote"] if fill is not None else ():
+            g = st["skip"].pop(k, None)
+            if g is not None:
+                fill.append(g)
+        st["demote"].clear()
 
 
 def flush_wgrad():
@@ -1503,6 +1514,27 @@ def copy_grouped(pairs):
     table = _upload_table(rows, dev)
     L.check(_lib().evlm_copy_grouped(L.ptr(table), len(pairs), blocks, L.stream()), "copy_grouped")
     return table
+
+
+def copy_few(pairs):
+    """[(src, dst)] -> as few launches as possible WITHOUT a device table (evlm_copy_few: up to 8 units per launch, passed
+    by value): for copies whose source addresses change from step to step - a training batch going into its static buffers.
+    Pairs that do not qualify (size not a multiple of 16 bytes, unaligned, not contiguous, dtypes differ) use Tensor.copy_."""
+    good = []
+    for src, dst in pairs:
+        nb = src.numel() * src.element_size()
+        if (src.is_cuda and dst.is_cuda and src.dtype == dst.dtype and nb and nb % 16 == 0 and src.is_contiguous() and dst.is_contiguous()
+                and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0 and nb == dst.numel() * dst.element_size()):
+            good.append((src, dst, nb))
+        else:
+            dst.copy_(src, non_blocking=True)
+    for i in range(0, len(good), 8):
+        part = good[i:i + 8]
+        n = len(part)
+        srcs = (C.c_void_p * n)(*[p_[0].data_ptr() for p_ in part])
+        dsts = (C.c_void_p * n)(*[p_[1].data_ptr() for p_ in part])
+        nbs = (C.c_int64 * n)(*[p_[2] for p_ in part])
+        L.check(_lib().evlm_copy_few(srcs, dsts, nbs, n, L.stream()), "copy_few")
 
 
 def zero_grouped(tensors):

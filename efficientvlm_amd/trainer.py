@@ -740,8 +740,7 @@ class GDTrainer(_StagedExchange):
         cur, side = torch.cuda.current_stream(), self._side
         cur.wait_stream(side)                     # the waiting batch's teacher outputs are complete
         p = pipe["par"] = 1 - pipe["par"]
-        for name, v in batch.items():
-            pipe["B"][p][name].copy_(v, non_blocking=True)
+        ops.copy_few([(v, pipe["B"][p][name]) for name, v in batch.items()])      # (one launch: they were six copies per step)
         out = None
         done = False                              # both halves of this call issued (joint graph / graph segments)?
         graphs_ok = self.use_graph and not pipe.get("eager") and (self._pending is None or not self._pending[0].get("eager"))

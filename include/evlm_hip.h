@@ -263,6 +263,10 @@ int evlm_attention_lse_supported(int dtype, int dh, int Lk, float dropout_p);
  * total_blocks = sum over units of ceil(bytes / 65536).  Plumbing of the teacher pipeline (the frozen teacher's outputs,
  * computed one batch ahead, are parked in persistent buffers: GeneralDistill.py:295-298 consumes them in the same step). */
 int evlm_copy_grouped(const int64_t* table, int n_units, int total_blocks, void* stream);
+/* ... up to 8 such copies whose addresses change from call to call (a step's input batch going into static buffers): the units
+ * are passed by value with the launch - no device table.  src / dst / nbytes: HOST arrays of n entries (n <= 8), each unit a
+ * multiple of 16 bytes and 16-byte aligned (ABI 8). */
+int evlm_copy_few(const void* const* src, void* const* dst, const int64_t* nbytes, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused cross-attention FORWARD: K/V projection of the image tokens + Q K^T + softmax + P V (+ the map) in one launch.

@@ -206,6 +206,27 @@ def test_gated_activation_backward_in_the_gemm_epilogue(M, K, Fh, act_name, gate
         assert rel_err(f_.float(), s_.float()) < 2e-2, name
 
 
+def test_a_batch_goes_into_its_static_buffers_in_one_launch():
+    """ops.copy_few (evlm_copy_few: up to 8 copies per launch, the units passed by value - no device table to upload for
+    sources that change every step): a training batch's six tensors, more than eight units, and pairs that do not qualify
+    (odd byte counts, a host source, a strided destination) falling back to Tensor.copy_"""
+    o = ops()
+    g = torch.Generator().manual_seed(21)
+    srcs = [torch.randn(64, 3, 32, 32, generator=g).to(DEV), torch.randint(0, 30000, (64, 30), generator=g).to(DEV),
+            torch.randint(0, 2, (64, 30), generator=g).to(DEV), torch.randint(0, 30, (64, 8), generator=g).to(DEV),
+            torch.randn(7, 3, generator=g).to(DEV),                       # 84 bytes: not a multiple of 16
+            torch.randn(64, 16, generator=g),                              # a host tensor
+            torch.randn(33, 8, generator=g).to(DEV)]
+    srcs += [torch.randn(256, generator=g).to(DEV) for _ in range(9)]     # > 8 qualifying units: two launches
+    dsts = [torch.empty_like(s_, device=DEV) for s_ in srcs]
+    strided = torch.empty(33, 16, device=DEV)[:, ::2]
+    dsts[6] = strided
+    o.copy_few(list(zip(srcs, dsts)))
+    torch.cuda.synchronize()
+    for s_, d in zip(srcs, dsts):
+        assert torch.equal(d.cpu(), s_.cpu())
+
+
 def test_fusion_batch_selection_and_the_samplers_layout_vectors():
     """ops.select_batches (whole-sample x[sel] with a deterministic one-launch backward) against index_select + autograd's
     index_add, and the layout vectors evlm_sample_negatives writes beside its draws: sel4 = (r, r, drawn text, B + r) over
