@@ -687,6 +687,17 @@ class GDTrainer(_StagedExchange):
                 enc.attn_out = None
         return st
 
+    def _teacher_advance(self, st, until):
+        """resume the suspended teacher forward of _teacher_begin up to its phase `until` ("text_done", "fusion_done")"""
+        if st["gen"] is None:
+            return
+        with torch.no_grad(), compute(self.dtype):
+            try:
+                while next(st["gen"]) != until:
+                    pass
+            except StopIteration as done:          # (a forward without that phase: it is complete)
+                st["T"], st["gen"] = done.value, None
+
     def _teacher_finish(self, st, pipe, k):
         """second half: the teacher's text / fusion passes, then its outputs parked in the persistent buffers k"""
         T = st["T"]
@@ -817,12 +828,18 @@ class GDTrainer(_StagedExchange):
         cur, cs, side = torch.cuda.current_stream(), self._cap_stream, self._side
         ops.reserve_tables()
         torch.cuda.synchronize()
-        segs, state = [], {"g": None, "forked": tpipe is None, "joined": tpipe is None, "half": None}
+        segs, state = [], {"g": None, "forked": tpipe is None, "joined": tpipe is None, "half": None,
+                           "late_left": ["text_done", "fusion_done", None]}
         # the teacher in two halves (default): its image encoder beside the student's forward in the FIRST segment, its text /
         # fusion passes in the segment behind the ITC gather - each half about as long as the student work it shares the
         # chip with (one fork behind the gather leaves the first segment without a partner and the teacher outlasts the
         # second).  EVLM_SEG_TEACHER_SPLIT=0: the whole forward behind the gather.
-        split = tpipe is not None and os.environ.get("EVLM_SEG_TEACHER_SPLIT", "1") not in ("", "0")
+        mode = os.environ.get("EVLM_SEG_TEACHER_SPLIT", "1")
+        # "late" (round 5 experiment): the pairing the single-GPU joint graph gets for free - the teacher's image encoder
+        # (chip-filling products) beside the student's PART-FILLED phase behind the gather, its text / fusion passes
+        # (part-filled) beside the student's ViT backward (chip-filling) in the segment behind the first gradient stage
+        late = tpipe is not None and mode == "late"
+        split = tpipe is not None and not late and mode not in ("", "0")
 
         def fork_teacher():
             side.wait_stream(cs)
@@ -833,6 +850,25 @@ class GDTrainer(_StagedExchange):
                 else:
                     self._teacher_eager(tpipe, tp)
             state["forked"] = True
+
+        def fork_teacher_piece():
+            """late mode: the next piece of the teacher's forward behind its image encoder - text pass, fusion pass, heads +
+            parking of the outputs - beside ONE segment of the student's ViT backward (joins where that segment ends)"""
+            side.wait_stream(cs)
+            with torch.cuda.stream(side):
+                if state["half"] is None:            # (no gather cut the forward: the whole teacher here)
+                    self._teacher_eager(tpipe, tp)
+                    state["late_left"] = []
+                else:
+                    ph = state["late_left"].pop(0)
+                    if ph is None:
+                        self._teacher_finish(state["half"], tpipe, tp)
+                        state["half"] = None
+                    else:
+                        self._teacher_advance(state["half"], ph)
+            state["vision_open"] = True
+            if not state["late_left"]:
+                state["forked"] = state["joined"] = True
 
         def fork_teacher_vision():
             side.wait_stream(cs)
@@ -862,15 +898,19 @@ class GDTrainer(_StagedExchange):
             end()
             segs.append(("gather", (out_list, src)))
             begin()
-            if not state["forked"]:
+            if late:
+                fork_teacher_vision()
+            elif not state["forked"]:
                 fork_teacher()
 
         def cut(ranges):
-            if not state["forked"]:                  # (no gather cut the forward: single-rank group without the forced gather)
+            if not late and not state["forked"]:     # (no gather cut the forward: single-rank group without the forced gather)
                 fork_teacher()
             end()
             segs.append(("reduce", ranges))
             begin()
+            if late and not state["forked"]:         # the teacher's next piece beside this segment of the ViT backward
+                fork_teacher_piece()
 
         ops.CACHE.invalidate()
         cs.wait_stream(cur)
@@ -885,6 +925,8 @@ class GDTrainer(_StagedExchange):
                         fork_teacher_vision()
                     out = self._forward_backward(pipe["B"][k], pipe["T"][k])
                     self._reduce_rest()                  # the remaining stages: one cut each
+                    while late and not state["forked"]:  # (fewer cuts than teacher pieces: the rest beside the optimiser)
+                        fork_teacher_piece()
                     self.opt.step()                      # clip + AdamW: the segment behind the last all-reduce
                     end()
                 finally:

@@ -438,13 +438,15 @@ print("RESULT " + json.dumps(out))
 """
 
 
-@pytest.mark.parametrize("split", ["1", "0"])
+@pytest.mark.parametrize("split", ["1", "0", "late"])
 def test_segmented_graph_step_of_the_multi_gpu_path_matches_the_single_gpu_graph(split):
     """N > 1 code path with world_size 1 (RCCL group of one rank, the ITC all-gather forced through the collective): the
     student step replayed as hipGraph segments around the gather and the gradient all-reduce (trainer._student_segmented)
     must train exactly like the single-GPU joint graph - same losses over five optimiser steps on rotating batches.
     split: the pipelined teacher forward in two halves (image encoder in the first segment, text / fusion passes in the
-    second: the forward suspended at its "vision_done" phase between two captures) or whole behind the gather"""
+    second: the forward suspended at its "vision_done" phase between two captures), whole behind the gather, or "late" - the
+    image encoder behind the gather and the text pass / fusion pass / heads each beside one segment of the ViT backward (the
+    forward suspended at three phases across four captures; an opt-in experiment, profiles/r05_exchange_overlap.md)"""
     import json, os, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
