@@ -567,6 +567,8 @@ __global__ __launch_bounds__(256) void itc_fwd_kernel(const T* __restrict__ I, i
   if (i < Bt) {
     const int64_t gi = group ? group[i] : 0;
     float mr = -INFINITY, zr = 0.f, mc = -INFINITY, zc = 0.f, lr = 0.f, lc = 0.f, cnt = 0.f;
+    // (measured alternative, round 5: lanes along the feature dimension - coalesced row reads, one wave reduction per dot
+    // product - 29.3 us against 18.5 us for this lane-per-column form at Bt = 64: twelve dependent shuffles per column)
     for (int c = 0; c < Bt; c += 64) {
       const int j = c + lane;
       if (j >= Bt) continue;
@@ -657,6 +659,7 @@ __global__ __launch_bounds__(256) void itc_bwd_kernel(const T* __restrict__ I, i
     const int e = lane * 4;
     if (e < E) {
       float aI[4] = {0.f, 0.f, 0.f, 0.f}, aT[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
       for (int j = 0; j < Bt; ++j) {
         float t[4], x[4];
         Vec4<T>::load(Tx + (int64_t)j * ldt + e, t);
