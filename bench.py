@@ -45,11 +45,14 @@ REF_FLOPS_PER_PAIR = 161.4e9     # 3 x student fwd (32.41 GF) + 
 SEED = 1234
 
 
-def build(geom, dev, seed):
+def build(geom, dev, seed, dropout=0.0):
+    """dropout: hidden_dropout_prob = attention_probs_dropout_prob of the STUDENT's BERT (the stock config trains with 0.1,
+    reference: efficient_models/eff_bert.py:180,214,242,346,372-379,456-460; the ViT's attention_dropout is 0.0 in the
+    reference configs; the frozen teacher runs in eval mode, where dropout is the identity)"""
     from efficientvlm_amd.models.model_pretrain import XVLM
     from efficientvlm_amd.workload import model_config
     torch.manual_seed(seed)
-    student = XVLM(model_config(geom, "s")).to(dev)
+    student = XVLM(model_config(geom, "s", dropout=dropout)).to(dev)
     teacher = XVLM(model_config(geom, "t")).to(dev)
     return student, teacher
 
@@ -363,6 +366,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE.json configs[1]: 64)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="student BERT hidden / attention-probability dropout (BASELINE.md / SURVEY 8c quote the metric at 0; "
+                         "the reference's stock recipe trains with 0.1 - the default line carries that as `with_dropout`)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="teacher forward inside the same step as its student step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -408,7 +414,7 @@ def main():
     from efficientvlm_amd.workload import GEOMS, make_batch
     geom = GEOMS["full"]
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    student, teacher = build(geom, dev, seed=SEED)
+    student, teacher = build(geom, dev, seed=SEED, dropout=args.dropout)
     pipelined = not args.no_pipeline
     trainer = make_trainer(student, teacher, dtype, not args.no_graph, pipelined)
     B = args.batch
@@ -472,6 +478,9 @@ def main():
                                        if trainer.reducer.active else "")
                                     + (" [DRY RUN: ranks share one GPU, gloo]" if os.environ.get("EVLM_BENCH_SHARE_GPU") else ""),
                           "teacher_pipelined": pipelined, "distinct_batches": 4,
+                          # student BERT hidden_dropout_prob = attention_probs_dropout_prob (keep-masks regenerated in the
+                          # kernels from a device {seed, step} word: new masks on every replay)
+                          "dropout": args.dropout,
                           "init": "random (reference init), no checkpoints"},
                "last_losses": {"total": losses[0], "itc": losses[1], "itm": losses[2], "mlm": losses[3], "kd": losses[4]}}
         if roof is not None:
@@ -501,8 +510,31 @@ def main():
             res["unpipelined"] = {"value": round(B * n2 / e2, 2), "unit": "pairs/s", "ms_per_step": round(e2 / n2 * 1e3, 3),
                                   "steps": n2}
             del tr2, s2, t2
-        if world == 1 and not args.no_oracle_check:
+        if world == 1 and pipelined and not args.no_roofline and args.dropout == 0.0:
+            # the SAME step under the reference's stock training-mode dropout (student BERT p = 0.1: attention
+            # probabilities inside the MFMA attention kernels, hidden states in the GEMM residual epilogues)
+            s3, t3 = build(geom, dev, seed=SEED, dropout=0.1)
+            tr3 = make_trainer(s3, t3, dtype, not args.no_graph, True)
+            for i in range(4):
+                o3 = tr3.step(batches[i % 4])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n3 = min(args.steps, 10)
+            for i in range(n3):
+                o3 = tr3.step(batches[i % 4])
+            torch.cuda.synchronize()
+            e3 = time.perf_counter() - t1
+            l3 = [float(x) for x in o3.tolist()]
+            res["with_dropout"] = {"dropout": 0.1, "value": round(B * n3 / e3, 2), "unit": "pairs/s",
+                                   "ms_per_step": round(e3 / n3 * 1e3, 3), "steps": n3,
+                                   "vs_no_dropout": round((e3 / n3) / (elapsed / args.steps), 4),
+                                   "last_losses": {"total": l3[0], "itc": l3[1], "itm": l3[2], "mlm": l3[3], "kd": l3[4]}}
+            del tr3, s3, t3
+        if world == 1 and not args.no_oracle_check and args.dropout == 0.0:
             res["oracle_check"] = oracle_check(geom, dev, dtype, B, not args.no_graph)
+        elif world == 1 and not args.no_oracle_check:
+            res["oracle_check"] = {"skipped": "dropout > 0: the masks are a device-side draw; parity under dropout is held by "
+                                              "tests/test_dropout_gpu.py, which hands the same masks to the oracle"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

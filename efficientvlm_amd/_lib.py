@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVLM_LIB", os.path.join(_HERE, "libevlm_hip.so"))
 
-ABI_VERSION = 8      # evlm_abi_version() of the library this binding was written against (struct layouts, entry points)
+ABI_VERSION = 9      # evlm_abi_version() of the library this binding was written against (struct layouts, entry points)
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2
 GATE_PRE, GATE_POST = 0, 1
@@ -26,7 +26,8 @@ class GemmArgs(C.Structure):
                 ("P", _vp), ("Q", _vp), ("C", _vp), ("bias", _vp), ("gate", _vp),
                 ("preact", _vp), ("aux", _vp), ("residual", _vp),
                 ("alpha", _f), ("act", _i), ("gate_pos", _i), ("dact", _i), ("accumulate", _i), ("psum", _vp),
-                ("sk_workspace", _vp), ("dgate", _vp)]
+                ("sk_workspace", _vp), ("dgate", _vp),
+                ("dropout_p", _f), ("rng_state", _vp), ("call_id", C.c_uint32)]
 
 
 class WgradProblem(C.Structure):
@@ -76,6 +77,7 @@ SIGNATURES = {
     "evlm_layernorm_bwd_blocks": [_i],
     "evlm_layernorm_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "evlm_layernorm_bwd_add": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "evlm_layernorm_bwd_drop": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _f, _vp, C.c_uint32, _vp, _vp, _vp, _vp],
     "evlm_layernorm_fwd_kd_slots": [],
     "evlm_layernorm_fwd_kd": [_i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp],
     "evlm_layernorm_bwd_kd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp],

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnF a) {
     const bool drop = a.drop_p > 0.f;
     DropRng rng;
     if (drop) rng = drop_rng(a.rng, a.call, a.drop_p);
-    const uint64_t drow = (((uint64_t)b * a.H + h) * a.Lq + (q0 + r)) * (uint64_t)Lk;
+    const uint64_t drow = (((uint64_t)b * a.H + h) * a.Lq + (q0 + r)) * (uint64_t)((Lk + 7) & ~7);   // (rows padded to 8: common.h)
     for (int k = kl; k < Lk; k += 16) {
       const float p = Ss[r * Lkp + k] * inv;
       Ss[r * Lkp + k] = (drop && rowok) ? p * drop_factor(rng, drow + k) : p;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnB a) {
     const bool drop = a.drop_p > 0.f;
     DropRng rng;
     if (drop) rng = drop_rng(a.rng, a.call, a.drop_p);
-    const uint64_t drow = (((uint64_t)b * a.H + h) * a.Lq + (q0 + r)) * (uint64_t)Lk;
+    const uint64_t drow = (((uint64_t)b * a.H + h) * a.Lq + (q0 + r)) * (uint64_t)((Lk + 7) & ~7);
     if (rowok) {
       for (int k = kl; k < Lk; k += 16) {
         const float p = to_f(Pr[k]);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnB a) {
       if (q0 + rr < a.Lq && k0 + kk < Lk) {
         ds = to_f(dSb[(size_t)(q0 + rr) * a.ldpr + k0 + kk]);
         p = to_f(Pb[(size_t)(q0 + rr) * a.ldpr + k0 + kk]);
-        if (drop) p *= drop_factor(rng, (((uint64_t)b * a.H + h) * a.Lq + (q0 + rr)) * (uint64_t)Lk + k0 + kk);   // dV = gate (P .* M)^T dO
+        if (drop) p *= drop_factor(rng, (((uint64_t)b * a.H + h) * a.Lq + (q0 + rr)) * (uint64_t)((Lk + 7) & ~7) + k0 + kk);   // dV = gate (P .* M)^T dO
       }
       dSs[rr * (AKC + 1) + kk] = ds;
       Ps[rr * (AKC + 1) + kk] = p;
@@ -330,13 +330,11 @@ extern "C" int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream_) {
   EVLM_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f && (a->dropout_p == 0.f || a->rng_state),
                "evlm_attention_fwd: dropout_p = %f needs 0 <= p < 1 and an rng_state", (double)a->dropout_p);
   int handled = 0;
-  if (a->dropout_p == 0.f) {          // probability dropout runs on the shape-generic kernels (text-side problems)
-    if (int e = evlm_attention_fwd_mfma(a, stream, &handled)) return e;
-  }
+  if (int e = evlm_attention_fwd_mfma(a, stream, &handled)) return e;     // (round 6: with or without probability dropout)
   if (handled) return 0;
   EVLM_REQUIRE(!a->lse, "evlm_attention_fwd: the lse form exists on the bf16 MFMA path only (evlm_attention_lse_supported)");
   EVLM_REQUIRE(!a->kd_teacher, "evlm_attention_fwd: the fused map distillation exists on the bf16 MFMA path only "
-               "(head dim 64, Lk <= 928, no dropout); use evlm_mse_fwd on the returned map");
+               "(head dim 64, Lk <= 928); use evlm_mse_fwd on the returned map");
   AttnF f;
   f.drop_p = a->dropout_p; f.rng = a->rng_state; f.call = a->call_id;
   f.Q = a->Q; f.K = a->K; f.V = a->V; f.kv_index = a->kv_index; f.mask = a->mask; f.gate = a->head_gate; f.causal = a->causal;
@@ -365,7 +363,7 @@ extern "C" int evlm_attention_bwd(const evlm_attn_bwd_args* a, void* stream_) {
   EVLM_REQUIRE(a->ldpr >= a->Lk && a->ldpr % 8 == 0, "evlm_attention_bwd: ldpr must be a multiple of 8 and >= Lk");
   EVLM_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f && (a->dropout_p == 0.f || a->rng_state),
                "evlm_attention_bwd: dropout_p = %f needs 0 <= p < 1 and an rng_state", (double)a->dropout_p);
-  if (a->dropout_p == 0.f) {
+  {
     int handled = 0;
     if (int e = evlm_attention_bwd_mfma(a, stream, &handled)) return e;
     if (handled) return 0;

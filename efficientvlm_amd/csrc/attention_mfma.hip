@@ -21,6 +21,10 @@ struct MAttnF {
   // ABI 8: the teacher's map REBUILT in the kernel instead of read (streaming kernels): its projected queries / keys
   // ([B, L, H, dh] bf16 inside its packed QKV buffer, row stride tld) and its row lse [B, H, L]
   const bf16* Tq; const bf16* Tk; int tld; const float* tlse;
+  // round 6: dropout of the probabilities that form the context (eff_bert.py:346; the map / lse / distillation taps see the
+  // un-dropped softmax).  DROP kernels regenerate keep / (1 - p) for the lane's 8 consecutive keys of a tile pair with ONE
+  // Philox call (common.h: drop_factor8)
+  float drop_p; const int64_t* rng; uint32_t call;
 };
 
 #define DH 64
@@ -149,7 +153,7 @@ __device__ __forceinline__ bf16x8 vcol_frag_a(const char* sm, int t0, int t1, in
 // LSE: the per-row log2-sum-exp is written for a backward that recomputes P in fp32 (the map itself is then written only
 // when a caller wants it), and the fused map distillation compares the fp32 probabilities - the ones that backward will
 // rebuild - with the teacher map, before the P V product (while the un-normalised row is still in registers).
-template <int NT, int MAXW, bool SEQ, bool LSE>
+template <int NT, int MAXW, bool SEQ, bool LSE, bool DROP = false>
 __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;                                       // [NT*16][64] bf16, k_swz
@@ -259,11 +263,26 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   }
   // P (bf16): 4 consecutive keys per lane per tile -> 8-byte stores; also the PV B operand
   bf16x4 pk[NT];
+  bf16x4 pd[DROP ? NT : 1];                      // DROP: the PV operand is P .* keep / (1 - p), rounded once from fp32
   bf16* Pr = a.P ? a.P + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr : nullptr;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) pk[t][r] = (bf16)(acc[t][r] * inv);
+  }
+  if (DROP) {
+    const DropRng rng = drop_rng(a.rng, a.call, a.drop_p);
+    const uint64_t d8 = (((uint64_t)b * a.H + h) * a.Lq + (qok ? q : 0)) * (uint64_t)((a.Lk + 7) >> 3) + g;
+#pragma unroll
+    for (int s = 0; s < NT / 2; ++s) {
+      float f[8];
+      drop_factor8(rng, d8 + s * 4, f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pd[DROP ? 2 * s : 0][r] = (bf16)(acc[2 * s][r] * inv * f[r]);
+        pd[DROP ? 2 * s + 1 : 0][r] = (bf16)(acc[2 * s + 1][r] * inv * f[4 + r]);
+      }
+    }
   }
 #pragma unroll
   for (int s = 0; s < NT / 2; ++s) {            // 8 consecutive keys per lane: one 16-byte store per tile pair
@@ -289,7 +308,10 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   for (int s = 0; s < NT / 2; ++s) {
     bf16x8 pb;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { pb[r] = pk[2 * s][r]; pb[4 + r] = pk[2 * s + 1][r]; }
+    for (int r = 0; r < 4; ++r) {
+      pb[r] = DROP ? pd[DROP ? 2 * s : 0][r] : pk[2 * s][r];
+      pb[4 + r] = DROP ? pd[DROP ? 2 * s + 1 : 0][r] : pk[2 * s + 1][r];
+    }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
       o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Vs, 2 * s, 2 * s + 1, dt, lane), pb, o[dt], 0, 0, 0);
@@ -339,7 +361,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
 // ballot over the index, 64 entries at a time; the (query batch, 16-query tile) tasks go round the waves.  The per-batch
 // kernel above stages the same 50 KiB once per text row (4x per image in the GD step) with two waves per workgroup to use
 // them.  Each wave keeps the additive mask row of its current query batch in a private LDS strip.
-template <int NT, int NW, bool LSE>
+template <int NT, int NW, bool LSE, bool DROP = false>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_kernel(MAttnF a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;                                       // [NT*16][64] bf16, k_swz
@@ -356,6 +378,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_kernel(MAttnF a) {
   __syncthreads();
   const int qtiles = (a.Lq + 15) >> 4;
   const float sc = a.scale * 1.44269504088896341f;
+  DropRng rng;
+  if (DROP) rng = drop_rng(a.rng, a.call, a.drop_p);
   int task = 0;                                          // running (query batch, tile) counter: wave w takes task % NW == w
   for (int b0 = 0; b0 < a.B; b0 += 64) {
     unsigned long long hits = __ballot(b0 + lane < a.B && a.kv_index[min(b0 + lane, a.B - 1)] == bkv);
@@ -421,11 +445,25 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_kernel(MAttnF a) {
         const float inv = 1.0f / sum;
         if (LSE && qok && g == 0) a.lse[((size_t)b * a.H + h) * a.Lq + q] = m + __log2f(sum);
         bf16x4 pk[NT];
+        bf16x4 pd[DROP ? NT : 1];                        // DROP: the PV operand P .* keep / (1 - p), rounded once from fp32
         bf16* Pr = a.P ? a.P + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr : nullptr;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) pk[t][r] = (bf16)(acc[t][r] * inv);
+        }
+        if (DROP) {
+          const uint64_t d8 = (((uint64_t)b * a.H + h) * a.Lq + (qok ? q : 0)) * (uint64_t)((a.Lk + 7) >> 3) + g;
+#pragma unroll
+          for (int s = 0; s < NT / 2; ++s) {
+            float f[8];
+            drop_factor8(rng, d8 + s * 4, f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              pd[DROP ? 2 * s : 0][r] = (bf16)(acc[2 * s][r] * inv * f[r]);
+              pd[DROP ? 2 * s + 1 : 0][r] = (bf16)(acc[2 * s + 1][r] * inv * f[4 + r]);
+            }
+          }
         }
 #pragma unroll
         for (int s = 0; s < NT / 2; ++s) {
@@ -444,7 +482,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_kernel(MAttnF a) {
         for (int s = 0; s < NT / 2; ++s) {
           bf16x8 pb;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { pb[r] = pk[2 * s][r]; pb[4 + r] = pk[2 * s + 1][r]; }
+          for (int r = 0; r < 4; ++r) {
+            pb[r] = DROP ? pd[DROP ? 2 * s : 0][r] : pk[2 * s][r];
+            pb[4 + r] = DROP ? pd[DROP ? 2 * s + 1 : 0][r] : pk[2 * s + 1][r];
+          }
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt)
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag(Vs, 2 * s, 2 * s + 1, dt, lane), pb, o[dt], 0, 0, 0);
@@ -730,7 +771,7 @@ __device__ __forceinline__ void stage_block(const bf16* base, int ld, int L, int
 // bf16 map that this kernel and the backward would each read once.  The teacher's K block streams through LDS beside the
 // student's (a third 16 KiB tile per buffer), its scores are rebuilt per key tile - 2 MFMAs, 4 exponentials per lane - and
 // consumed at once by the running sums of the term: p_t = 2^(s_t log2e - lse_t) in fp32, not a bf16-rounded stored value.
-template <int NW, bool LSE, int TQ, bool KDR = false>
+template <int NW, bool LSE, int TQ, bool KDR = false, bool DROP = false>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
   constexpr int KBT = 8, KB = KBT * 16;                  // 128 keys per block
   constexpr int BUF = (KDR ? 3 : 2) * KB * 128;          // one staging buffer: K | V [| teacher K]
@@ -798,6 +839,18 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
   }
   const float sc = a.scale * 1.44269504088896341f;
   const bool kd_any = LSE && (KDR || a.Pt != nullptr);
+  // DROP: the un-normalised e of a dropped key leaves the P V product (keep is 0 / 1 here; the kept keys' 1 / (1 - p)
+  // joins the row's 1 / l on the context); l, the lse and the distillation sums see every key
+  DropRng rng;
+  uint64_t d8[TQ];
+  float keep_scale = 1.0f;
+  if (DROP) {
+    rng = drop_rng(a.rng, a.call, a.drop_p);
+    keep_scale = rng.scale;
+    rng.scale = 1.0f;
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) d8[j] = (((uint64_t)b * a.H + h) * a.Lq + (qok[j] ? q[j] : 0)) * (uint64_t)((a.Lk + 7) >> 3) + g;
+  }
   float m[TQ], l[TQ], se2[TQ], sep[TQ], spt[TQ];
   f32x4 o[TQ][4];
 #pragma unroll
@@ -931,9 +984,17 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
     for (int s2 = 0; s2 < KBT / 2; ++s2) {
       bf16x8 pb[TQ];
 #pragma unroll
-      for (int j = 0; j < TQ; ++j)
+      for (int j = 0; j < TQ; ++j) {
+        if (DROP) {
+          float f[8];
+          drop_factor8(rng, d8[j] + (blk * KBT / 2 + s2) * 4, f);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { pb[j][r] = (bf16)acc[j][2 * s2][r]; pb[j][4 + r] = (bf16)acc[j][2 * s2 + 1][r]; }
+          for (int r = 0; r < 4; ++r) { pb[j][r] = (bf16)(acc[j][2 * s2][r] * f[r]); pb[j][4 + r] = (bf16)(acc[j][2 * s2 + 1][r] * f[4 + r]); }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pb[j][r] = (bf16)acc[j][2 * s2][r]; pb[j][4 + r] = (bf16)acc[j][2 * s2 + 1][r]; }
+        }
+      }
       if (!AHEAD) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -963,7 +1024,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
       const float inv = 1.0f / lj;
       if (LSE && qok[j] && g == 0) a.lse[((size_t)b * a.H + h) * a.Lq + q[j]] = m[j] + __log2f(lj);
       if (qok[j]) {
-        const float gz = (a.gate ? a.gate[h] : 1.0f) * inv;
+        const float gz = (a.gate ? a.gate[h] : 1.0f) * (DROP ? inv * keep_scale : inv);
         bf16* Or = a.O + ((size_t)b * a.Lq + q[j]) * a.ldo + h * DH;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -998,7 +1059,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
 // maximum m and sum l online; pass 2 streams K and V, recomputes the scores, writes p = 2^(s - m) / l as bf16 - 16-byte
 // pieces, rows of `ldpr` - and multiplies the SAME rounded probabilities into V (what a reader of the map would
 // recompute), with the distillation term formed from them (stored-map form) or from the fp32 values (lse form).
-template <int NW, bool LSE>
+template <int NW, bool LSE, bool DROP = false>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_map_kernel(MAttnF a) {
   constexpr int KBT = 8, KB = KBT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1076,6 +1137,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_map_kernel(MAttnF a) 
   const bf16* Tr = kd_on ? a.Pt + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr : nullptr;
   bf16* Pr = (a.P && qok) ? a.P + (((size_t)b * a.H + h) * a.Lq + q) * a.ldpr : nullptr;
   float sq = 0.f, rk = 0.f;
+  DropRng rng;
+  if (DROP) rng = drop_rng(a.rng, a.call, a.drop_p);
+  const uint64_t d8 = (((uint64_t)b * a.H + h) * a.Lq + (qok ? q : 0)) * (uint64_t)((a.Lk + 7) >> 3) + g;
   f32x4 o[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1130,6 +1194,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_map_kernel(MAttnF a) 
           rk = fmaf(p0, d0, rk); rk = fmaf(p1, d1, rk);
         }
       }
+      if (DROP) {                                        // the context sees P .* keep / (1 - p); the map above stays un-dropped
+        float f[8];
+        drop_factor8(rng, d8 + (blk * KBT / 2 + s2) * 4, f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pb[r] = (bf16)(acc[2 * s2][r] * f[r]); pb[4 + r] = (bf16)(acc[2 * s2 + 1][r] * f[4 + r]); }
+      }
       bf16x8 vfr[4];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1172,27 +1242,31 @@ static bool launch_fwd_stream(const MAttnF& f, hipStream_t stream) {
   constexpr int KB = 128;
   const int nblk = (f.Lk + KB - 1) / KB, qtiles = (f.Lq + 15) / 16;
   const size_t lds = (size_t)4 * KB * 128 + (size_t)nblk * KB * sizeof(float) + 16;
-#define STREAM_LAUNCH(NW_, LSE_, TQ_)                                                                                    \
+#define STREAM_LAUNCH_D(NW_, LSE_, TQ_, DROP_)                                                                           \
   do {                                                                                                                   \
-    (void)hipFuncSetAttribute((const void*)attn_fwd_stream_kernel<NW_, LSE_, TQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)lds);                                                                                 \
+    (void)hipFuncSetAttribute((const void*)attn_fwd_stream_kernel<NW_, LSE_, TQ_, false, DROP_>,                         \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
     dim3 grid((qtiles + NW_ * TQ_ - 1) / (NW_ * TQ_), f.H, f.B), block(64 * NW_);                                       \
-    hipLaunchKernelGGL((attn_fwd_stream_kernel<NW_, LSE_, TQ_>), grid, block, lds, stream, f);                           \
+    hipLaunchKernelGGL((attn_fwd_stream_kernel<NW_, LSE_, TQ_, false, DROP_>), grid, block, lds, stream, f);             \
   } while (0)
+  // (probability dropout: text queries on image tokens - a few query tiles; one tile per wave, 8 waves)
+#define STREAM_LAUNCH(NW_, LSE_, TQ_) do { if (drop) STREAM_LAUNCH_D(8, LSE_, 1, true); else STREAM_LAUNCH_D(NW_, LSE_, TQ_, false); } while (0)
+  const bool drop = f.drop_p > 0.f;
   // 8 waves = 128 queries per workgroup: measured (tools/attn_long_bench.py) level with or ahead of 16 waves on the ViT's
   // 577 / 901 tokens (the last query block is fuller, two workgroups share a CU), and a few text queries on those image
   // tokens want the 8 waves for the K / V streaming itself (61 us against 82 us with one wave per query tile)
   static const int nw_env = getenv("EVLM_ATTN_STREAM_NW") ? atoi(getenv("EVLM_ATTN_STREAM_NW")) : 0;     // (tuning aid)
   const int nw = nw_env == 16 ? 16 : 8;
   if (f.P || (f.Pt && !f.lse)) {                         // the map is an output (or the stored-map distillation form): two passes
-#define STREAM_MAP_LAUNCH(LSE_)                                                                                          \
+#define STREAM_MAP_LAUNCH(LSE_, DROP_)                                                                                   \
   do {                                                                                                                   \
-    (void)hipFuncSetAttribute((const void*)attn_fwd_stream_map_kernel<8, LSE_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    (void)hipFuncSetAttribute((const void*)attn_fwd_stream_map_kernel<8, LSE_, DROP_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                                                 \
     dim3 grid((qtiles + 7) / 8, f.H, f.B), block(512);                                                                  \
-    hipLaunchKernelGGL((attn_fwd_stream_map_kernel<8, LSE_>), grid, block, lds, stream, f);                              \
+    hipLaunchKernelGGL((attn_fwd_stream_map_kernel<8, LSE_, DROP_>), grid, block, lds, stream, f);                       \
   } while (0)
-    if (f.lse) STREAM_MAP_LAUNCH(true); else STREAM_MAP_LAUNCH(false);
+    if (drop) { if (f.lse) STREAM_MAP_LAUNCH(true, true); else STREAM_MAP_LAUNCH(false, true); }
+    else if (f.lse) STREAM_MAP_LAUNCH(true, false); else STREAM_MAP_LAUNCH(false, false);
 #undef STREAM_MAP_LAUNCH
     return true;
   }
@@ -1220,6 +1294,7 @@ static bool launch_fwd_stream(const MAttnF& f, hipStream_t stream) {
     if (nw == 16) STREAM_LAUNCH(16, false, 1); else if (tq == 2) STREAM_LAUNCH(8, false, 2); else STREAM_LAUNCH(8, false, 1);
   }
 #undef STREAM_LAUNCH
+#undef STREAM_LAUNCH_D
   return true;
 }
 
@@ -1234,7 +1309,7 @@ static bool launch_fwd_grouped(const MAttnF& f, int Bkv, hipStream_t stream) {
   // Measured 23.7 us against 21.2 us for one workgroup per item on the GD shape (profiles/r05_xattn_persist.md): opt-in.
   // The index copy bounds B (a query batch count of 4 096 is 16 KiB of LDS)
   const char* pe = getenv("EVLM_ATTN_GROUP_PERSIST");     // (A/B switch, read per call; measured SLOWER: opt-in)
-  if (pe && atoi(pe) == 1 && f.B <= 4096) {
+  if (pe && atoi(pe) == 1 && f.B <= 4096 && !(f.drop_p > 0.f)) {
     const int nitems = Bkv * f.H;
     const size_t ldsp = (size_t)4 * NT * 16 * 128 + (size_t)NW * NT * 16 * sizeof(float) + (size_t)f.B * sizeof(int);
     static const int ncu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); (void)hipGetDeviceProperties(&p, d); return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }();
@@ -1250,15 +1325,16 @@ static bool launch_fwd_grouped(const MAttnF& f, int Bkv, hipStream_t stream) {
   }
   const size_t lds = (size_t)2 * NT * 16 * 128 + (size_t)NW * NT * 16 * sizeof(float);
   dim3 grid(1, f.H, Bkv), block(64 * NW);
-  if (f.lse) {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)attn_fwd_grouped_kernel<NT, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_fwd_grouped_kernel<NT, NW, true>), grid, block, lds, stream, f);
-  } else {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)attn_fwd_grouped_kernel<NT, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_fwd_grouped_kernel<NT, NW, false>), grid, block, lds, stream, f);
-  }
+#define GROUPED_LAUNCH(LSE_, DROP_)                                                                                       \
+  do {                                                                                                                   \
+    if (lds > 64 * 1024)                                                                                                 \
+      (void)hipFuncSetAttribute((const void*)attn_fwd_grouped_kernel<NT, NW, LSE_, DROP_>,                               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
+    hipLaunchKernelGGL((attn_fwd_grouped_kernel<NT, NW, LSE_, DROP_>), grid, block, lds, stream, f);                     \
+  } while (0)
+  if (f.drop_p > 0.f) { if (f.lse) GROUPED_LAUNCH(true, true); else GROUPED_LAUNCH(false, true); }
+  else if (f.lse) GROUPED_LAUNCH(true, false); else GROUPED_LAUNCH(false, false);
+#undef GROUPED_LAUNCH
   return true;
 }
 
@@ -1271,17 +1347,27 @@ static int launch_fwd(const MAttnF& f, hipStream_t stream) {
   int nw = imin(MAXW, (f.Lq + 15) / 16);               // waves per workgroup (16 queries each)
   if (nw_cap > 0 && !SEQ) nw = imin(nw, nw_cap);
   dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
-  if constexpr (NT != 26) {                            // (225..416 keys keep the stored-map backward: no lse form)
-    if (f.lse) {
-      if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT, MAXW, SEQ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT, MAXW, SEQ, true>), grid, block, lds, stream, f);
+#define FWD_LAUNCH(LSE_, DROP_)                                                                                           \
+  do {                                                                                                                   \
+    if (lds > 64 * 1024)                                                                                                 \
+      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT, MAXW, SEQ, LSE_, DROP_>,                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
+    hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT, MAXW, SEQ, LSE_, DROP_>), grid, block, lds, stream, f);                 \
+  } while (0)
+  if constexpr (NT <= 14) {                            // probability dropout: text-side problems (<= 224 keys) take this kernel,
+    if (f.drop_p > 0.f) {                              // longer ones the streaming pair (evlm_attention_fwd_mfma)
+      if (f.lse) FWD_LAUNCH(true, true); else FWD_LAUNCH(false, true);
       return 0;
     }
   }
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<NT, MAXW, SEQ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT, MAXW, SEQ, false>), grid, block, lds, stream, f);
+  if constexpr (NT != 26) {                            // (225..416 keys keep the stored-map backward: no lse form)
+    if (f.lse) {
+      FWD_LAUNCH(true, false);
+      return 0;
+    }
+  }
+  FWD_LAUNCH(false, false);
+#undef FWD_LAUNCH
   return 0;
 }
 
@@ -1303,6 +1389,10 @@ struct MAttnB {
   const bf16* O; const float* rkd;
   // ABI 8: the teacher's map rebuilt in the kernel (see MAttnF)
   const bf16* Tq; const bf16* Tk; int tld; const float* tlse;
+  // round 6: dropout of the probabilities (see MAttnF): with M = keep / (1 - p) regenerated per tile pair,
+  //   dP = gate (M .* dO V^T) + E ;  dgate += sum P M dPo ;  dV = gate (P .* M)^T dO ;  delta = dO . O as before.
+  // p_dropped: the map kernel B reads (P = the workspace kernel A wrote) already carries M
+  float drop_p; const int64_t* rng; uint32_t call; int p_dropped;
 };
 
 // mask row of one (batch): Ms[k] = additive mask of key k (0 without one), -1e30 beyond Lk - as the forward kernel builds it
@@ -1341,7 +1431,7 @@ __device__ __forceinline__ void recompute_p(const char* Ks, const float* Ms, con
 // kernel A: same shape as the forward (a wave owns 16 queries and ALL keys):
 //   dPo^T = V dO^T ;  dP = gate*dPo + E ;  delta = rowsum(P .* dP) ;  dS = P .* (dP - delta) -> HBM (for kernel B)
 //   dQ^T  = scale * K^T dS^T           (dS^T accumulators reused as the MFMA B operand, K^T through tr16 reads)
-template <int NT, int MAXW, bool RC>
+template <int NT, int MAXW, bool RC, bool DROP = false>
 __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KSW = RC ? SW_KV : SW_V;
@@ -1378,11 +1468,16 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
   f32x4 pf[RC ? NT : 1];
   bf16x4 pv[NT];
   float dsum = 0.f, gsum = 0.f;
+  DropRng rng;
+  if (DROP) rng = drop_rng(a.rng, a.call, a.drop_p);
+  const uint64_t d8 = (((uint64_t)b * a.H + h) * a.Lq + (qok ? q : 0)) * (uint64_t)((a.Lk + 7) >> 3) + g;
 #pragma unroll
   for (int s = 0; s < NT / 2; ++s) {            // tile pair: this lane's 8 consecutive keys 32s + 8g .. + 7
     const int kcol = s * 32 + g * 8;
     const bool ok = qok && kcol < a.ldpr;
     float pr[8], ex[8];                          // ex: external gradient on the map (dP_ext and / or the fused distillation term)
+    float fm[DROP ? 8 : 1];
+    if constexpr (DROP) drop_factor8(rng, d8 + s * 4, fm);
 #pragma unroll
     for (int r = 0; r < 8; ++r) { pr[r] = 0.f; ex[r] = 0.f; }
     if (RC) recompute_p<KSW>(Ks, Ms, qf, s, g, lane, sc, lse_q, qok, a.causal, q, pr);
@@ -1412,8 +1507,11 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, t, ks, lane), dof[ks], acc[t], 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = pr[hh * 4 + r], dpo = acc[t][r];
-        pv[t][r] = (bf16)p;
+        const float p = pr[hh * 4 + r];
+        const float dpo = DROP ? acc[t][r] * fm[DROP ? hh * 4 + r : 0] : acc[t][r];      // (the gradient reaches P through M)
+        // (RC: pv feeds kernel B's dV through the workspace - with DROP it carries M; the stored-map form keeps the
+        // un-dropped value for dS and kernel B applies M to the forward's map itself)
+        pv[t][r] = (DROP && RC) ? (bf16)(p * fm[DROP ? hh * 4 + r : 0]) : (bf16)p;
         if (RC) pf[RC ? t : 0][r] = p;
         gsum = fmaf(p, dpo, gsum);                 // (explicit fma forms: the single-pass kernel and kernels A + B must
         const float dp = fmaf(gz, dpo, ex[hh * 4 + r]);   //  round identically whatever the compiler would contract)
@@ -1478,7 +1576,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_mfma_kernel(MAttnB a) {
 //   pass 2: per key HALF, V_h and K_h side by side in the same LDS space: dP recomputed (2 MFMAs per tile), dS = P .* (dP -
 //           delta) stored for kernel B and consumed at once by dQ^T += K_h^T dS^T.
 // P and E are read twice (the second time mostly from the last-level cache); ~70 VGPRs, 8 waves = 128 queries per workgroup.
-template <int NT, int MAXW, bool RC>
+template <int NT, int MAXW, bool RC, bool DROP = false>
 __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HT = NT / 2;                               // key tiles per half (even: tile pairs stay together)
@@ -1523,6 +1621,9 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
   // so pass 0 - a second score product, exponentials and a dP product per key just for this row sum - is not run; the gate
   // gradient's sum_k p dpo is collected in the one pass that remains.  (Wave-uniform: kernel arguments only.)
   const bool one_pass = RC && a.O != nullptr && a.E == nullptr && (a.Pt == nullptr || a.rkd != nullptr);
+  DropRng rng;
+  if (DROP) rng = drop_rng(a.rng, a.call, a.drop_p);
+  const uint64_t d8 = (((uint64_t)b * a.H + h) * a.Lq + (qok ? q : 0)) * (uint64_t)((a.Lk + 7) >> 3) + g;
   if (one_pass) {
     float d = 0.f;
     if (qok) {
@@ -1584,7 +1685,9 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
             for (int r = 0; r < 8; ++r) ex[r] = fmaf(kdc, pr[r] - (float)t8[r], ex[r]);
           }
         }
-        bf16x8 d8, p8o;
+        float fm[DROP ? 8 : 1];
+        if constexpr (DROP) drop_factor8(rng, d8 + (kcol >> 5) * 4, fm);
+        bf16x8 ds8, p8o;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1594,25 +1697,26 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float p = pr[hh * 4 + r];
-            const float dp = fmaf(gz, acc[r], ex[hh * 4 + r]);
+            const float dpo = DROP ? acc[r] * fm[DROP ? hh * 4 + r : 0] : acc[r];
+            const float dp = fmaf(gz, dpo, ex[hh * 4 + r]);
             if (pass == 0) {
-              gsum = fmaf(p, acc[r], gsum);
+              gsum = fmaf(p, dpo, gsum);
               dsum = fmaf(p, dp, dsum);
             } else {
-              if (one_pass) gsum = fmaf(p, acc[r], gsum);
-              d8[hh * 4 + r] = (bf16)(p * (dp - dsum));
-              p8o[hh * 4 + r] = (bf16)p;
+              if (one_pass) gsum = fmaf(p, dpo, gsum);
+              ds8[hh * 4 + r] = (bf16)(p * (dp - dsum));
+              p8o[hh * 4 + r] = DROP ? (bf16)(p * fm[DROP ? hh * 4 + r : 0]) : (bf16)p;
             }
           }
         }
         if (pass == 1) {
           if (ok) {
-            *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
+            *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = ds8;
             if (RC && a.Pw) *reinterpret_cast<bf16x8*>(a.Pw + prow + kcol) = p8o;
           }
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt)
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag<KSW>(Ks, 2 * s, 2 * s + 1, dt, lane), d8, o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vcol_frag<KSW>(Ks, 2 * s, 2 * s + 1, dt, lane), ds8, o[dt], 0, 0, 0);
         }
       }
     }
@@ -1638,7 +1742,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
 // next block's DMA, workgroups of one (batch, head) share an XCD.  Arithmetic per tile pair as above.
 // KDR: the teacher's probabilities rebuilt from its Q, K and row lse (see attn_fwd_stream_kernel) - its K block streams
 // through a third LDS tile per buffer, recompute_p forms p_t exactly as it forms the student's p.
-template <int NW, bool KDR = false>
+template <int NW, bool KDR = false, bool DROP = false>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
   constexpr int KBT = 8, KB = KBT * 16;
   constexpr int BUF = (KDR ? 3 : 2) * KB * 128;
@@ -1695,6 +1799,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
     }
   }
   float gsum = 0.f;
+  DropRng rng;
+  if (DROP) rng = drop_rng(a.rng, a.call, a.drop_p);
+  const uint64_t dr8 = (((uint64_t)b * a.H + h) * a.Lq + (qok ? q : 0)) * (uint64_t)((a.Lk + 7) >> 3) + g;
   f32x4 o[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1739,6 +1846,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
       float pr[8], ptr[8];
       recompute_p<SW_KV>(Ks, Ms + blk * KB, qf, s2, g, lane, sc, lse_q, qok, 0, 0, pr);
       if (KDR) recompute_p<SW_K>(Kts, Ms + blk * KB, qt, s2, g, lane, sc, tl, qok, 0, 0, ptr);
+      float fm[DROP ? 8 : 1];
+      if constexpr (DROP) drop_factor8(rng, dr8 + (blk * KBT / 2 + s2) * 4, fm);
       bf16x8 d8, p8o;
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -1751,10 +1860,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
           const float pp = pr[hh * 4 + r];
           const float ex = KDR ? (ok ? kdc * (pp - ptr[hh * 4 + r]) : 0.f)
                                : ((kd_on && ok) ? kdc * (pp - (float)t8[s2][hh * 4 + r]) : 0.f);
-          const float dp = fmaf(gz, acc[r], ex);
-          gsum = fmaf(pp, acc[r], gsum);
+          const float dpo = DROP ? acc[r] * fm[DROP ? hh * 4 + r : 0] : acc[r];
+          const float dp = fmaf(gz, dpo, ex);
+          gsum = fmaf(pp, dpo, gsum);
           d8[hh * 4 + r] = (bf16)(pp * (dp - dsum));
-          p8o[hh * 4 + r] = (bf16)pp;
+          p8o[hh * 4 + r] = DROP ? (bf16)(pp * fm[DROP ? hh * 4 + r : 0]) : (bf16)pp;
         }
       }
       if (ok) {
@@ -1801,6 +1911,11 @@ static bool launch_bwd_dq_stream(MAttnB& f, hipStream_t stream) {
     return true;
   }
   const size_t lds = (size_t)4 * KB * 128 + (size_t)nblk * KB * sizeof(float);
+  if (f.drop_p > 0.f) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_stream_kernel<NW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<NW, false, true>), grid, block, lds, stream, f);
+    return true;
+  }
   (void)hipFuncSetAttribute((const void*)attn_bwd_dq_stream_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<NW>), grid, block, lds, stream, f);
   return true;
@@ -1835,6 +1950,7 @@ __device__ __forceinline__ bf16x8 qcol_frag(const char* sm, int ct, int lane) {
   return out;
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
   __shared__ __attribute__((aligned(16))) char sm[4 * 32 * 128];
   char* Qs = sm; char* dOs = sm + 4096; char* Ps = sm + 8192; char* Ss = sm + 12288;
@@ -1844,6 +1960,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
   // 32-query chunk) instead of read from a [B, H, Lq, Lk] workspace that kernel A would have to write - the streaming
   // kernel A of long sequences then moves 517 MB less per ViT layer at 577 tokens, and this kernel reads 517 MB less
   const bool rcp = a.P == nullptr && a.lse != nullptr;
+  // DROP: dV = gate (P .* M)^T dO.  A workspace map written by kernel A carries M already (p_dropped); the forward's stored
+  // map gets it as its 16-byte pieces are staged (8 consecutive keys of one query = one Philox call); a rebuilt map gets it
+  // per lane - 4 keys of one query, i.e. one half of a call's 8 factors
+  DropRng rng;
+  if (DROP) rng = drop_rng(a.rng, a.call, a.drop_p);
+  const bool mask_staged = DROP && !rcp && !a.p_dropped;
+  const uint64_t lk8 = (uint64_t)((a.Lk + 7) >> 3);
   bf16x8 kf[2];
   float mk[4] = {0.f, 0.f, 0.f, 0.f};
   const float sc = a.scale * LOG2E;
@@ -1908,6 +2031,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
       const int so = srow * 128 + p_swz(srow, scol) * 16;
       *reinterpret_cast<uint4*>(Qs + so) = nq;
       *reinterpret_cast<uint4*>(dOs + so) = ndo;
+      if (DROP && mask_staged) {
+        float f[8];
+        drop_factor8(rng, (((uint64_t)b * a.H + h) * a.Lq + min(q0 + srow, a.Lq - 1)) * lk8 + (k0 >> 3) + scol, f);
+        bf16x8 p8 = *reinterpret_cast<bf16x8*>(&np);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p8[e] = (bf16)((float)p8[e] * f[e]);
+        np = *reinterpret_cast<uint4*>(&p8);
+      }
       if (!rcp) *reinterpret_cast<uint4*>(Ps + so) = np;
       *reinterpret_cast<uint4*>(Ss + so) = ns;
       const float lq[2] = {nlq[0], nlq[1]};
@@ -1928,6 +2059,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
           }
           const bool qv = q0 + row < a.Lq;
           bf16x4 p4;
+          if (DROP) {
+            float f[4];
+            drop_factor4(rng, (((uint64_t)b * a.H + h) * a.Lq + min(q0 + row, a.Lq - 1)) * lk8 + ((k0 + wave * 16 + 4 * g) >> 3), (g & 1) != 0, f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p4[r] = (bf16)(qv ? EXP2(fmaf(sa[r], sc, mk[r]) - lq[j]) * f[r] : 0.f);
+          } else
 #pragma unroll
           for (int r = 0; r < 4; ++r) p4[r] = (bf16)(qv ? EXP2(fmaf(sa[r], sc, mk[r]) - lq[j]) : 0.f);
           *reinterpret_cast<bf16x4*>(Ps + row * 128 + p_swz(row, 2 * wave + (g >> 1)) * 16 + (g & 1) * 8) = p4;
@@ -1983,8 +2120,9 @@ __device__ __forceinline__ bf16x8 scol_frag(const char* tile, int ct, int lane) 
   return out;
 }
 
-template <int NT, int NW, bool RC, bool NOCAUSAL = false>
+template <int NT, int NW, bool RC, bool NOCAUSAL = false, bool DROP = false>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
+  static_assert(!DROP || RC, "the single-pass kernel carries the dropout mask in its recomputing form only");
   constexpr int G = (NT + NW - 1) / NW, KC = NT / 2, QC = NT / 2;
   constexpr int KSW = RC ? SW_KV : SW_V;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2021,6 +2159,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
   const float sc = a.scale * LOG2E;
   bf16x4 pvg[G][NT];
   float gsum = 0.f;
+  DropRng rng;
+  if (DROP) rng = drop_rng(a.rng, a.call, a.drop_p);
 #pragma unroll
   for (int gi = 0; gi < G; ++gi) {
     const int qt = gi * NW + wave;
@@ -2058,6 +2198,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
       const uint4 t_cu = t_nx, e_cu = e_nx;
       if (s + 1 < NT / 2) { t_nx = piece(a.Pt, s + 1); e_nx = piece(a.E, s + 1); }
       float pr[8], ex[8];
+      float fm[DROP ? 8 : 1];
+      if constexpr (DROP) drop_factor8(rng, (((uint64_t)b * a.H + h) * a.Lq + (qok ? q : 0)) * (uint64_t)((a.Lk + 7) >> 3) + s * 4 + g, fm);
 #pragma unroll
       for (int r = 0; r < 8; ++r) { pr[r] = 0.f; ex[r] = 0.f; }
       if (RC) recompute_p<KSW, NOCAUSAL>(Ks, Ms, qf, s, g, lane, sc, lse_q, qok, a.causal, q, pr);
@@ -2087,8 +2229,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(MAttnB a) {
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(krow_frag(Vs, t, ks, lane), dof[ks], acc[t], 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = pr[hh * 4 + r], dpo = acc[t][r];
-          pvg[gi][t][r] = (bf16)p;
+          const float p = pr[hh * 4 + r];
+          const float dpo = DROP ? acc[t][r] * fm[DROP ? hh * 4 + r : 0] : acc[t][r];
+          pvg[gi][t][r] = DROP ? (bf16)(p * fm[DROP ? hh * 4 + r : 0]) : (bf16)p;     // (phase 3: dV from P .* M)
           if (RC) pf[RC ? t : 0][r] = p;
           gsum = fmaf(p, dpo, gsum);
           const float dp = fmaf(gz, dpo, ex[hh * 4 + r]);
@@ -2190,15 +2333,23 @@ static bool launch_bwd_fused(const MAttnB& f, hipStream_t stream) {
   const char* env = getenv("EVLM_ATTN_BWD_SPLIT");          // (debug / A-B switch: force kernels A + B)
   if ((env && atoi(env)) || f.kv_index || f.Lq > NT * 16 || f.Lk > NT * 16) return false;
   const size_t lds = (size_t)(NT / 2) * (NT / 2) * 2048 + (size_t)(NT <= 4 ? 4 : 2) * NT * 16 * 128 + (RC ? NT * 16 * sizeof(float) : 0);
-  if (RC && !f.causal) {                    // (the encoders: no causal clamp in the recomputation)
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<NT, NW, RC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<NT, NW, RC, true>), dim3(f.H, f.B), dim3(64 * NW), lds, stream, f);
-    return true;
+#define FUSED_LAUNCH(NOC_, DROP_)                                                                                         \
+  do {                                                                                                                   \
+    if (lds > 64 * 1024)                                                                                                 \
+      (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<NT, NW, RC, NOC_, DROP_>,                             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<NT, NW, RC, NOC_, DROP_>), dim3(f.H, f.B), dim3(64 * NW), lds, stream, f); \
+  } while (0)
+  if (f.drop_p > 0.f) {                     // probability dropout: the recomputing form only (the stored-map form takes kernels A + B),
+    if constexpr (RC && NT <= 4) {          // text-length problems only (at NT = 14 the mask registers spill: kernels A + B)
+      if (!f.causal) FUSED_LAUNCH(true, true); else FUSED_LAUNCH(false, true);
+      return true;
+    }
+    return false;
   }
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<NT, NW, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_bwd_fused_kernel<NT, NW, RC>), dim3(f.H, f.B), dim3(64 * NW), lds, stream, f);
+  if (RC && !f.causal) FUSED_LAUNCH(true, false);      // (the encoders: no causal clamp in the recomputation)
+  else FUSED_LAUNCH(false, false);
+#undef FUSED_LAUNCH
   return true;
 }
 
@@ -2206,10 +2357,16 @@ template <int NT, bool RC>
 static void launch_bwd_dq(const MAttnB& f, hipStream_t stream) {
   constexpr int MAXW = NT <= 14 ? 8 : 4;
   const size_t lds = (size_t)2 * NT * 16 * 128 + (RC ? NT * 16 * sizeof(float) : 0);
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<NT, MAXW, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nw = imin(MAXW, (f.Lq + 15) / 16);
   dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
+  if (f.drop_p > 0.f) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<NT, MAXW, RC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NT, MAXW, RC, true>), grid, block, lds, stream, f);
+    return;
+  }
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<NT, MAXW, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<NT, MAXW, RC>), grid, block, lds, stream, f);
 }
 
@@ -2217,9 +2374,14 @@ template <int NT, bool RC>
 static void launch_bwd_dq_long(const MAttnB& f, hipStream_t stream) {
   constexpr int MAXW = 8;
   const size_t lds = (size_t)NT * 16 * 128 + (RC ? NT * 16 * sizeof(float) : 0);
-  (void)hipFuncSetAttribute((const void*)attn_bwd_dq_long_kernel<NT, MAXW, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nw = imin(MAXW, (f.Lq + 15) / 16);
   dim3 grid((f.Lq + 16 * nw - 1) / (16 * nw), f.H, f.B), block(64 * nw);
+  if (f.drop_p > 0.f) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_long_kernel<NT, MAXW, RC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_bwd_dq_long_kernel<NT, MAXW, RC, true>), grid, block, lds, stream, f);
+    return;
+  }
+  (void)hipFuncSetAttribute((const void*)attn_bwd_dq_long_kernel<NT, MAXW, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((attn_bwd_dq_long_kernel<NT, MAXW, RC>), grid, block, lds, stream, f);
 }
 
@@ -2240,6 +2402,9 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
   f.lse = a->lse; f.mask = a->mask; f.causal = a->causal; f.Pw = nullptr;
   f.O = (const bf16*)a->O; f.rkd = a->kd_rowdot;
   f.Tq = (const bf16*)a->kd_tq; f.Tk = (const bf16*)a->kd_tk; f.tld = a->kd_tld; f.tlse = a->kd_tlse;
+  f.drop_p = a->dropout_p; f.rng = a->rng_state; f.call = a->call_id; f.p_dropped = 0;
+  if (f.drop_p > 0.f && (f.Tq || (a->Lk > 224 && a->Lk <= 416 && false)))
+    return evlm_set_error("evlm_attention_bwd: probability dropout does not combine with kd_tq");
   if (f.Tq) {
     if (!(f.Tk && f.tlse && a->kd_gout && !a->kd_teacher && !a->mask && !a->kv_index && a->Lq == a->Lk && a->kd_tld % 8 == 0))
       return evlm_set_error("evlm_attention_bwd: kd_tq needs kd_tk, kd_tlse and kd_gout, self-attention without a mask, no kd_teacher");
@@ -2275,6 +2440,7 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
     if (a->P_ws) {
       f.Pw = (bf16*)a->P_ws;
       f.P = (const bf16*)a->P_ws;
+      f.p_dropped = 1;                                    // (kernel A writes P .* M into the workspace)
     } else if (!a->P && !bwd_dq_stream_applies(f))       // (the streaming pair needs neither: kernel B rebuilds the map)
       return evlm_set_error("evlm_attention_bwd: the two-kernel recomputing path needs P or the P_ws workspace");
     // (a grouped-by-K/V-row form of kernel A - the backward counterpart of attn_fwd_grouped_kernel - was measured 20 %
@@ -2293,7 +2459,8 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
   else if (a->Lk <= 640) launch_bwd_dq_long<40, false>(f, stream);      // long sequences: two passes over the keys, nothing spilled
   else launch_bwd_dq_long<60, false>(f, stream);
   dim3 gridB((a->Lk + 63) / 64, a->H, f.Bkv), block(256);
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, gridB, block, 0, stream, f);
+  if (f.drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, gridB, block, 0, stream, f);
+  else hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<false>, gridB, block, 0, stream, f);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return evlm_set_error("evlm_attention_bwd(mfma): %s", hipGetErrorString(e));
   *handled = 1;
@@ -2307,7 +2474,8 @@ extern "C" int evlm_attention_lse_supported(int dtype, int dh, int Lk, float dro
   // ITR-384 step and stays for calls with a dP_ext).  Whether to ask for the lse form is the caller's choice per call
   // (ops._Attention: when nobody wants the map).  225..416 keys: stored-map form only (the one-pass kernel A of that bucket
   // holds a whole row in registers).
-  if (dtype != EVLM_BF16 || dh != DH || dropout_p != 0.f) return 0;
+  // (round 6: with or without probability dropout - the MFMA kernels regenerate the mask)
+  if (dtype != EVLM_BF16 || dh != DH || dropout_p < 0.f || dropout_p >= 1.f) return 0;
   return Lk <= 224 || (Lk > 416 && Lk <= 928);
 }
 
@@ -2325,6 +2493,13 @@ int evlm_attention_fwd_mfma(const evlm_attn_fwd_args* a, hipStream_t stream, int
   f.kd_coef = a->kd_teacher ? a->kd_weight / ((float)a->B * a->H * a->Lq * a->Lk) : 0.f;
   f.lse = a->lse; f.rkd = a->kd_rowdot;
   f.Tq = (const bf16*)a->kd_tq; f.Tk = (const bf16*)a->kd_tk; f.tld = a->kd_tld; f.tlse = a->kd_tlse;
+  f.drop_p = a->dropout_p; f.rng = a->rng_state; f.call = a->call_id;
+  if (f.drop_p > 0.f) {
+    // probability dropout (round 6): <= 224 keys on the whole-row / grouped kernels, 225..928 on the streaming pair; the
+    // combinations nothing on the path issues stay with the shape-generic kernels (which then refuse lse / kd_teacher)
+    if (f.Tq) return evlm_set_error("evlm_attention_fwd: probability dropout does not combine with kd_tq");
+    if (a->Lk > 224 && (a->causal || getenv("EVLM_ATTN_NO_STREAM"))) return 0;
+  }
   if (f.Tq) {
     if (!(f.Tk && f.tlse && a->lse && a->kd_loss && !a->kd_teacher && !a->P && !a->mask && !a->kv_index && !a->causal &&
           a->Lq == a->Lk && a->Lk > 224 && a->Lk <= 928 && a->kd_tld % 8 == 0))

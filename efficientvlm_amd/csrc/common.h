@@ -127,38 +127,74 @@ __device__ __forceinline__ float act_grad(int act, float x) {
 }
 
 // ---- counter-based dropout masks (Philox4x32-10) ---------------------------------------------
-// A dropout site is identified by (seed, step, call id); element `idx` of that site keeps its value iff word (idx & 3) of
-// Philox(counter = {idx >> 2 lo, idx >> 2 hi, call, step}, key = seed) is >= p * 2^32.  The mask is a pure function of
-// those numbers, so the backward kernels REGENERATE it: no mask tensor ever exists in HBM.  rng_state is a DEVICE
-// int64[2] = {seed, step}: a captured hipGraph draws fresh masks on every replay once the host (or a one-word kernel)
-// has bumped `step`; the call id is a host constant of each call site.
+// A dropout site is identified by (seed, step, call id).  A site is a matrix [rows][cols]; with its columns padded to a
+// multiple of 8 (cols8 = 8 ceil(cols / 8)) element (row, col) has the index idx = row * cols8 + col, and it keeps its value
+// iff the 16-bit lane (idx & 7) of Philox(counter = {idx >> 3 lo, idx >> 3 hi, call, step}, key = seed) - lane e = bits
+// 16 (e & 1) .. +15 of output word e >> 1 - is >= round(p * 2^16).  ONE Philox call serves 8 consecutive columns of a row:
+// the 16-byte piece a lane of the attention kernels owns per key-tile pair (8 consecutive keys of one query), the 16-byte
+// piece a lane of the GEMM epilogue stores, the 8 elements a thread of the element-wise kernels handles.  (Round 6: before,
+// a 32-bit word per element of the FLAT index - one Philox call per 4 flat elements, which in the attention layouts was
+// one call per element.)  A kept element is multiplied by exactly 1 / (1 - p), as the reference's nn.Dropout does; the
+// keep probability itself is 1 - round(p 2^16) / 2^16 (p = 0.1: 0.899994).  The mask is a pure function of those numbers,
+// so the backward kernels REGENERATE it: no mask tensor ever exists in HBM.  rng_state is a DEVICE int64[2] = {seed, step}:
+// a captured hipGraph draws fresh masks on every replay once the host (or a one-word kernel) has bumped `step`; the call
+// id is a host constant of each call site.  Hidden-state sites have cols % 8 == 0 or are addressed flat (evlm_dropout).
 struct DropRng { uint32_t k0, k1, call, step; uint32_t thresh; float scale; };
 __device__ __forceinline__ DropRng drop_rng(const int64_t* __restrict__ state, uint32_t call, float p) {
   DropRng r;
   const uint64_t seed = (uint64_t)state[0], step = (uint64_t)state[1];
   r.k0 = (uint32_t)seed; r.k1 = (uint32_t)(seed >> 32); r.call = call; r.step = (uint32_t)step;
-  const double t = (double)p * 4294967296.0;
-  r.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  const float t = rintf(p * 65536.0f);
+  r.thresh = t >= 65535.0f ? 65535u : (uint32_t)t;
   r.scale = 1.0f / (1.0f - p);
   return r;
 }
-__device__ __forceinline__ void philox4(const DropRng& r, uint64_t block, uint32_t (&o)[4]) {
+// (scalars, not arrays, all the way: a select between two elements of a private array - the half-call forms below - is turned
+// into a dynamically indexed load, and the array into scratch memory)
+__device__ __forceinline__ void philox4s(const DropRng& r, uint64_t block, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
   uint32_t c0 = (uint32_t)block, c1 = (uint32_t)(block >> 32), c2 = r.call, c3 = r.step, k0 = r.k0, k1 = r.k1;
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint64_t m0 = (uint64_t)0xD2511F53u * c0, m1 = (uint64_t)0xCD9E8D57u * c2;      // (v_mad_u64_u32: hi and lo at once)
+    const uint32_t h0 = (uint32_t)(m0 >> 32), l0 = (uint32_t)m0, h1 = (uint32_t)(m1 >> 32), l1 = (uint32_t)m1;
     c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
-  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+  o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
-// keep / (1 - p) of ONE element (attention kernels: elements of a thread are not consecutive)
+__device__ __forceinline__ void philox4(const DropRng& r, uint64_t block, uint32_t (&o)[4]) {
+  philox4s(r, block, o[0], o[1], o[2], o[3]);
+}
+// x .* m rounded on its own (HIP's __fmul_rn is a plain `x * y`, which the compiler contracts with a following add into one
+// fma): the hidden-dropout sites compute round(x m) + residual wherever they run - evlm_dropout, the GEMM residual epilogues,
+// the LayerNorm backward's masked output - so that the fused and the separate forms agree bit for bit
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+// keep / (1 - p) of the 8 consecutive elements idx8 * 8 .. + 7 (idx8 = padded index >> 3): ONE Philox call
+__device__ __forceinline__ void drop_factor8(const DropRng& r, uint64_t idx8, float (&f)[8]) {
+  uint32_t o0, o1, o2, o3;
+  philox4s(r, idx8, o0, o1, o2, o3);
+  f[0] = (o0 & 0xFFFFu) >= r.thresh ? r.scale : 0.f; f[1] = (o0 >> 16) >= r.thresh ? r.scale : 0.f;
+  f[2] = (o1 & 0xFFFFu) >= r.thresh ? r.scale : 0.f; f[3] = (o1 >> 16) >= r.thresh ? r.scale : 0.f;
+  f[4] = (o2 & 0xFFFFu) >= r.thresh ? r.scale : 0.f; f[5] = (o2 >> 16) >= r.thresh ? r.scale : 0.f;
+  f[6] = (o3 & 0xFFFFu) >= r.thresh ? r.scale : 0.f; f[7] = (o3 >> 16) >= r.thresh ? r.scale : 0.f;
+}
+// ... of elements 4 hi .. 4 hi + 3 of that group (lanes that own 4 consecutive columns: half of a call's factors)
+__device__ __forceinline__ void drop_factor4(const DropRng& r, uint64_t idx8, bool hi, float (&f)[4]) {
+  uint32_t o0, o1, o2, o3;
+  philox4s(r, idx8, o0, o1, o2, o3);
+  const uint32_t a = hi ? o2 : o0, b = hi ? o3 : o1;
+  f[0] = (a & 0xFFFFu) >= r.thresh ? r.scale : 0.f; f[1] = (a >> 16) >= r.thresh ? r.scale : 0.f;
+  f[2] = (b & 0xFFFFu) >= r.thresh ? r.scale : 0.f; f[3] = (b >> 16) >= r.thresh ? r.scale : 0.f;
+}
+// ... of ONE element (shape-generic kernels whose threads do not own 8 consecutive columns)
 __device__ __forceinline__ float drop_factor(const DropRng& r, uint64_t idx) {
-  uint32_t o[4];
-  philox4(r, idx >> 2, o);
-  const uint32_t w = (idx & 2) ? ((idx & 1) ? o[3] : o[2]) : ((idx & 1) ? o[1] : o[0]);
-  return w >= r.thresh ? r.scale : 0.f;
+  uint32_t o0, o1, o2, o3;
+  philox4s(r, idx >> 3, o0, o1, o2, o3);
+  const uint32_t w = (idx & 4) ? ((idx & 2) ? o3 : o2) : ((idx & 2) ? o1 : o0);
+  return ((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) >= r.thresh ? r.scale : 0.f;
 }
 
 // ---- wave / block reductions (64-lane waves) ------------------------------------------------

@@ -850,6 +850,11 @@ extern "C" int evlm_gemm(const evlm_gemm_args* a, void* stream_) {
   g.psum = a->psum;
   g.sk_ws = a->sk_workspace; g.sk = 0;
   g.dgate = a->dgate;
+  g.drop_p = a->dropout_p; g.rng = a->rng_state; g.call = a->call_id;
+  EVLM_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "evlm_gemm: dropout_p = %f outside [0, 1)", (double)a->dropout_p);
+  EVLM_REQUIRE(a->dropout_p == 0.f || (a->rng_state && a->residual && a->J % 8 == 0 && !a->c_f32 && !a->act && !a->dact && !a->gate &&
+                                        !a->preact && !a->accumulate && !a->psum),
+               "evlm_gemm: dropout_p needs rng_state, a residual, J a multiple of 8, an output of `dtype` and no act / gate / dact / preact");
   EVLM_REQUIRE(!a->psum || (a->dtype == EVLM_BF16 && a->K % 64 == 0), "evlm_gemm: psum needs bf16 operands and K a multiple of 64");
   EVLM_REQUIRE(!a->accumulate || (a->dtype == EVLM_BF16 && a->c_f32 && !a->bias && !a->gate && !a->preact && !a->aux &&
                                    !a->residual && a->act == EVLM_ACT_NONE && a->K % 64 == 0),

@@ -17,6 +17,7 @@ struct GemmP {
   void* sk_ws;        // stream-K workspace (gemm_pp256.hip): 256 flag words, then 256 f32 tile slots of 256 KiB; or nullptr
   int sk;             // launch form chosen by the host: 1 = stream-K
   float* dgate;       // [J] f32, accumulated: gate gradient of a gated activation backward folded into this dX product (ABI 8)
+  float drop_p; const int64_t* rng; uint32_t call;      // ABI 9: C = (..) .* keep / (1 - p) + residual (hidden-state dropout)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -57,12 +58,16 @@ __device__ __forceinline__ int ctile_off(int r, int c) {
 // LDS tile to stage through, so it runs the two outputs as two passes)
 // ACT / DACT: compile-time activation codes, -1 = read g.act / g.dact at run time (tile_epilogue below dispatches ONCE per
 // tile: with run-time codes hipcc keeps scalar compares and branches around every single element)
-template <typename T, int NA, int NB, bool FULL, bool LDS_OUT, int MT, int MODE, int ACT, int DACT>
+// DROP (ABI 9): v = v .* keep / (1 - p) ahead of the residual.  A lane owns 4 consecutive columns of a row - one half of a
+// Philox call's 8 factors (the 256-column ping-pong kernels apply the mask at their 16-byte store stage, a full call each)
+template <typename T, int NA, int NB, bool FULL, bool LDS_OUT, int MT, int MODE, int ACT, int DACT, bool DROP = false>
 __device__ __forceinline__ void tile_epilogue_impl(const GemmP& g, f32x4 (&acc)[NA][NB], int ibase, int jbase, int lane,
                                                    char* sC, char* sH, int i0, int j0) {
   const int il = lane & 15, jl = (lane >> 4) * 4;
   const int act = ACT >= 0 ? ACT : g.act, dact = DACT >= 0 ? DACT : g.dact;
   constexpr bool LOWP = sizeof(T) == 2;      // bf16 path: fast activation math (common.h); the f32 parity path stays exact
+  DropRng rng;
+  if (DROP) rng = drop_rng(g.rng, g.call, g.drop_p);
 #pragma unroll
   for (int a = 0; a < NA; ++a) {
     const int j = jbase + a * 16 + jl;
@@ -114,6 +119,14 @@ __device__ __forceinline__ void tile_epilogue_impl(const GemmP& g, f32x4 (&acc)[
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= LOWP ? act_grad_fast(dact, hx[b][e]) : act_grad(dact, hx[b][e]);
       }
+      if (DROP && MODE != 1) {
+        float f[4];
+        drop_factor4(rng, ((uint64_t)i * g.J + j) >> 3, (j & 4) != 0, f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = mul_rn(to_f(from_f<T>(v[e])), f[e]);      // (the product as it would be STORED, then
+                                                                                       // x .* m rounded before the residual: what the
+                                                                                       // 256-column kernels and evlm_dropout compute)
+      }
       if (g.residual) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += rx[b][e];
@@ -131,6 +144,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& g, f32x4 (&acc)[NA][N
                                               char* sC = nullptr, char* sH = nullptr, int i0 = 0, int j0 = 0) {
 #define EVLM_EPI(A_, D_) tile_epilogue_impl<T, NA, NB, FULL, LDS_OUT, MT, MODE, A_, D_>(g, acc, ibase, jbase, lane, sC, sH, i0, j0)
   constexpr int G = EVLM_ACT_GELU, QG = EVLM_ACT_QUICK_GELU, N = EVLM_ACT_NONE;
+  if (g.drop_p > 0.f) {                              // hidden-state dropout + residual (the host admits no act / gate / dact with it)
+    tile_epilogue_impl<T, NA, NB, FULL, LDS_OUT, MT, MODE, N, N, true>(g, acc, ibase, jbase, lane, sC, sH, i0, j0);
+    return;
+  }
   if (sizeof(T) == 2 && FULL && !g.gate) {           // interior bf16 tiles of the training path: compile-time activation codes
     if (g.dact == N) {
       if (g.act == N) EVLM_EPI(N, N);

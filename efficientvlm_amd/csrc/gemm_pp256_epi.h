@@ -76,6 +76,10 @@ __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4],
                                              int ic, int jb, int lane, char* sw, bf16* dst, int ldd, const PPSk& sk,
                                              f32x4* dgs = nullptr) {
   constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && XM == 2;
+  // XM == 3 (ABI 9): hidden-state dropout ahead of the residual.  The residual rows stay in the registers they were fetched
+  // into - their [row][16-byte chunk] layout IS the store stage's - and the mask meets the result there: a lane then holds 8
+  // consecutive columns of one row = one Philox call (in the accumulator layout it would hold 4: half a call)
+  constexpr bool drop_r = MODE == 2 && XM == 3;
   constexpr bool gdact = MODE == 2 && GATED && XM == 1;
   const int il = lane & 15, jl = (lane >> 4) * 4;
   const int act = ACT >= 0 ? ACT : g.act, dact = DACT >= 0 ? DACT : g.dact;
@@ -167,11 +171,22 @@ __device__ __forceinline__ void pp_epi_chunk(const GemmP& g, f32x4 (&acc)[4][4],
   }
   asm volatile("" ::: "memory");           // same-wave LDS traffic is in order; keep the compiler from reordering it
   __builtin_amdgcn_wave_barrier();
+  DropRng rng;
+  if (drop_r) rng = drop_rng(g.rng, g.call, g.drop_p);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int r = k * 8 + (lane >> 3), ch = lane & 7;
-    const uint4 v16 = *reinterpret_cast<const uint4*>(sw + r * 128 + ((ch ^ (r & 7)) << 4));
+    uint4 v16 = *reinterpret_cast<const uint4*>(sw + r * 128 + ((ch ^ (r & 7)) << 4));
     const int i = ic + r, j = jb + ch * 8;
+    if (drop_r) {
+      float f[8];
+      drop_factor8(rng, ((uint64_t)(FULL ? i : min(i, g.I - 1)) * g.J + (FULL ? j : min(j, g.J - 8))) >> 3, f);
+      const bf16x8 vv = *reinterpret_cast<const bf16x8*>(&v16), rr = *reinterpret_cast<const bf16x8*>(&xr.r[k]);
+      bf16x8 oo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) oo[e] = (bf16)(mul_rn((float)vv[e], f[e]) + (float)rr[e]);
+      v16 = *reinterpret_cast<const uint4*>(&oo);
+    }
 #if defined(PP_EXP_NOSTORE)        // diagnostic builds only (tools/): what the epilogue costs without its global stores
     if (g.alpha == 12345.f) *reinterpret_cast<uint4*>(dst + (size_t)i * ldd + j) = v16;
 #else
@@ -191,7 +206,7 @@ template <bool FULL, int MODE, bool GATED, int XM, int ACT, int DACT, bool SKP>
 __device__ __forceinline__ void pp_epi_half(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4],
                                             int ib, int jb, int lane, char* sw, bf16* dst, int ldd, const PPSk& sk,
                                             f32x4* dgs = nullptr) {
-  constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && XM == 2;
+  constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && (XM == 2 || XM == 3);
   // (rows are requested per 64-row half: requesting all four chunks of the tile up front - 64 registers - was measured
   // SLOWER, 12.7 k against 10.6 k cycles per tile, the extra registers spill around the epilogue)
   PPRows x0, x1;
@@ -213,7 +228,7 @@ __device__ __forceinline__ PPSk pp_sk_high(const PPSk& sk) {      // the slot ad
 template <bool FULL, int MODE, bool GATED, int XM, int ACT, int DACT>
 __device__ __forceinline__ void pp_epi_third(const GemmP& g, f32x4 (&acc)[4][4], const f32x4 (&bz)[4],
                                              int ib, int jb, int lane, char* sw, bf16* dst, int ldd, f32x4* dgs = nullptr) {
-  constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && XM == 2;
+  constexpr bool need_h = MODE == 2 && XM == 1, need_r = MODE == 2 && (XM == 2 || XM == 3);
   PPRows x0;
   if (need_h || need_r) x0 = pp_epi_rows<FULL>(g, reinterpret_cast<const bf16*>(need_h ? g.aux : g.residual), ib, jb, lane);
   pp_epi_chunk<FULL, MODE, GATED, XM, ACT, DACT, false>(g, acc, bz, 0, x0, ib, jb, lane, sw, dst, ldd, PPSk{nullptr, 0}, dgs);
@@ -278,7 +293,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmP& g, f32x4 (&accL)[4][4],
   if (g.gate) {                      // L0-gated FFN (pruning fine-tune only): activation code read at run time
     if (g.residual) pp_epi_c<FULL, true, 2, -1, N, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
     else pp_epi_c<FULL, true, 0, -1, N, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
-  } else if (g.dact == G) pp_epi_c<FULL, false, 1, N, G, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
+  } else if (g.drop_p > 0.f) pp_epi_c<FULL, false, 3, N, N, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);      // (+ residual)
+  else if (g.dact == G) pp_epi_c<FULL, false, 1, N, G, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
   else if (g.dact == QG) pp_epi_c<FULL, false, 1, N, QG, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);
   else if (g.residual) {
     if (g.act == N) pp_epi_c<FULL, false, 2, N, N, SKP, HI>(g, accL, accH, bz, ib, jb, lane, sw, sk);

@@ -13,7 +13,7 @@ int evlm_set_error(const char* fmt, ...) {
   return 1;
 }
 extern "C" const char* evlm_last_error(void) { return g_err; }
-extern "C" int evlm_abi_version(void) { return 8; }
+extern "C" int evlm_abi_version(void) { return 9; }
 
 // ---- BERT embeddings -------------------------------------------------------------------------
 template <typename T>
@@ -646,29 +646,24 @@ extern "C" int evlm_l2norm_bwd(int dtype, const void* y, const void* dy, const f
 }
 
 // ---- dropout (hidden states): y = x .* keep / (1 - p) (+ residual) --------------------------------
-// The same kernel is its own backward (dx = dy .* the regenerated mask).  8 elements per thread = two Philox blocks.
+// The same kernel is its own backward (dx = dy .* the regenerated mask).  8 elements per thread = ONE Philox call (common.h).
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, const T* __restrict__ res, int64_t n, float p,
                                                       const int64_t* __restrict__ state, uint32_t call, T* __restrict__ y) {
   const DropRng r = drop_rng(state, call, p);
   const int64_t nv = n >> 3;
   for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nv; c += (int64_t)gridDim.x * blockDim.x) {
-    float v[8], rr[8];
+    float v[8], rr[8], f[8];
     load8<T>(x + c * 8, v);
     if (res) load8<T>(res + c * 8, rr);
-    uint32_t o0[4], o1[4];
-    philox4(r, (uint64_t)c * 2, o0);
-    philox4(r, (uint64_t)c * 2 + 1, o1);
+    drop_factor8(r, (uint64_t)c, f);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] = (o0[e] >= r.thresh ? v[e] * r.scale : 0.f) + (res ? rr[e] : 0.f);
-      v[4 + e] = (o1[e] >= r.thresh ? v[4 + e] * r.scale : 0.f) + (res ? rr[4 + e] : 0.f);
-    }
+    for (int e = 0; e < 8; ++e) v[e] = mul_rn(v[e], f[e]) + (res ? rr[e] : 0.f);      // (no fma: x .* m is rounded, then + residual)
     store8<T>(y + c * 8, v);
   }
   if (blockIdx.x == 0 && threadIdx.x < (int)(n & 7)) {
     const int64_t i = (nv << 3) + threadIdx.x;
-    y[i] = from_f<T>(to_f(x[i]) * drop_factor(r, (uint64_t)i) + (res ? to_f(res[i]) : 0.f));
+    y[i] = from_f<T>(mul_rn(to_f(x[i]), drop_factor(r, (uint64_t)i)) + (res ? to_f(res[i]) : 0.f));
   }
 }
 __global__ __launch_bounds__(256) void dropout_mask_kernel(int64_t n, float p, const int64_t* __restrict__ state, uint32_t call,

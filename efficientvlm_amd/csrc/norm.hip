@@ -269,20 +269,27 @@ template <> struct Raw8<float> {
   }
   __device__ __forceinline__ void opaque() {}
 };
-template <typename T, int DCH, bool ADD, bool EXTRA>
+// DROP (round 6, ABI 9): a SECOND output dxm = dx .* keep / (1 - p) of hidden-dropout site `call` - the gradient of
+// dense(h) in LayerNorm(dropout(dense(h)) + input) (eff_bert.py:372-381,456-462) - written beside dx (= the gradient of the
+// input branch) from the same registers: a lane's 16-byte chunk is 8 consecutive columns = one Philox call.  Replaces the
+// evlm_dropout pass over dy in the backward of every such site.
+struct LnDrop { void* dxm; float p; const int64_t* rng; uint32_t call; };
+template <typename T, int DCH, bool ADD, bool EXTRA, bool DROP = false>
 __global__ __launch_bounds__(256) void ln_bwd_pipe_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ addend,
                                                           const T* __restrict__ addend2,
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, int rows, int d, T* __restrict__ dx,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                           float* __restrict__ partials, const T* __restrict__ kd_t,
-                                                          const float* __restrict__ kd_g, float kd_k) {
+                                                          const float* __restrict__ kd_g, float kd_k, LnDrop drp = LnDrop{nullptr, 0.f, nullptr, 0}) {
   extern __shared__ __attribute__((aligned(16))) float sred[];   // [4 waves][2][d] column sums, then [d] gamma
   float* gs = sred + 8 * (size_t)d;
   for (int i = threadIdx.x; i < d; i += 256) gs[i] = gamma[i];
   const float kdk = (EXTRA && kd_t) ? kd_k * kd_g[0] : 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
+  DropRng rng;
+  if (DROP) rng = drop_rng(drp.rng, drp.call, drp.p);
   float pg[DCH][8], pb[DCH][8];
 #pragma unroll
   for (int u = 0; u < DCH; ++u)
@@ -377,6 +384,13 @@ __global__ __launch_bounds__(256) void ln_bwd_pipe_kernel(const T* __restrict__ 
           }
         }
         store8<T>(dxr + c * 8, o);
+        if (DROP) {                   // (the mask meets the value AS STORED: what a separate evlm_dropout pass over dx would read)
+          float f[8], om[8];
+          drop_factor8(rng, ((uint64_t)row * d + c * 8) >> 3, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) om[e] = mul_rn(to_f(from_f<T>(o[e])), f[e]);
+          store8<T>(reinterpret_cast<T*>(drp.dxm) + (size_t)row * d + c * 8, om);
+        }
       }
     }
   }
@@ -537,6 +551,53 @@ extern "C" int evlm_layernorm_bwd(int dtype, const void* dy, const void* x, cons
                                   const float* rstd, int rows, int d, void* dx, float* dgamma, float* dbeta,
                                   float* partials, void* stream) {
   return layernorm_bwd_impl(dtype, dy, x, nullptr, nullptr, gamma, mean, rstd, rows, d, dx, dgamma, dbeta, partials, stream);
+}
+// dx = LayerNorm backward AND dx_dropped = dx .* keep / (1 - p) of hidden-dropout site (rng_state, call_id) over [rows, d]
+// (flat element index row * d + col, as evlm_dropout / evlm_gemm_args.dropout_p): see ln_bwd_pipe_kernel DROP
+template <typename T>
+__global__ __launch_bounds__(256) void ln_drop_copy_kernel(const T* __restrict__ x, int64_t n8, float p, const int64_t* __restrict__ state,
+                                                           uint32_t call, T* __restrict__ y) {
+  const DropRng r = drop_rng(state, call, p);
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < n8; c += (int64_t)gridDim.x * blockDim.x) {
+    float v[8], f[8];
+    load8<T>(x + c * 8, v);
+    drop_factor8(r, (uint64_t)c, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = mul_rn(v[e], f[e]);
+    store8<T>(y + c * 8, v);
+  }
+}
+extern "C" int evlm_layernorm_bwd_drop(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                                       const float* rstd, int rows, int d, void* dx, void* dx_dropped, float dropout_p,
+                                       const int64_t* rng_state, uint32_t call_id, float* dgamma, float* dbeta, float* partials,
+                                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(dy && x && gamma && mean && rstd && dx && dx_dropped && rng_state && rows > 0, "evlm_layernorm_bwd_drop: bad args");
+  EVLM_REQUIRE(dropout_p > 0.f && dropout_p < 1.f, "evlm_layernorm_bwd_drop: dropout_p = %f outside (0, 1)", (double)dropout_p);
+  EVLM_REQUIRE((dgamma && dbeta) || (partials && !dgamma && !dbeta), "evlm_layernorm_bwd_drop: dgamma / dbeta missing");
+  EVLM_REQUIRE(d % 8 == 0 && d <= 2048, "evlm_layernorm_bwd_drop: d=%d unsupported (multiple of 8, <= 2048)", d);
+  static const bool pipe = !getenv("EVLM_LN_BWD_PHASED");
+  if (!pipe || d > 1024) {             // (outside the pipelined kernel's range: the plain backward, then one masked copy)
+    if (int e = layernorm_bwd_impl(dtype, dy, x, nullptr, nullptr, gamma, mean, rstd, rows, d, dx, dgamma, dbeta, partials, stream_)) return e;
+    const int64_t n8 = (int64_t)rows * d / 8;
+    EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_bwd_drop",
+      hipLaunchKernelGGL((ln_drop_copy_kernel<T>), dim3(imin(ceil_div(n8, 256), 2048)), dim3(256), 0, stream, (const T*)dx, n8,
+                         dropout_p, rng_state, call_id, (T*)dx_dropped);)
+    EVLM_LAUNCH_CHECK("evlm_layernorm_bwd_drop");
+    return 0;
+  }
+  const int nblk = ln_bwd_blocks(rows);
+  dim3 grid(nblk), block(256);
+  const size_t lds_p = 9 * (size_t)d * sizeof(float);
+  const LnDrop drp{dx_dropped, dropout_p, rng_state, call_id};
+#define LN_BWDD(DCH_) hipLaunchKernelGGL((ln_bwd_pipe_kernel<T, DCH_, false, false, true>), grid, block, lds_p, stream, (const T*)dy, (const T*)x, (const T*)nullptr, (const T*)nullptr, gamma, mean, rstd, rows, d, (T*)dx, dgamma, dbeta, partials, (const T*)nullptr, (const float*)nullptr, 0.f, drp)
+  EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_bwd_drop", if (d <= 512) LN_BWDD(1); else LN_BWDD(2);)
+#undef LN_BWDD
+  if (partials && dgamma)
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(2 * d, 256), LN_RED_SLICES), dim3(256), 0, stream, partials, nblk, d,
+                       dgamma, dbeta);
+  EVLM_LAUNCH_CHECK("evlm_layernorm_bwd_drop");
+  return 0;
 }
 // dx = LayerNorm backward + addend: the gradient that reaches x along the residual branch past this LayerNorm (pre-LN
 // blocks: h = x + f(LN(x))) is summed inside the kernel instead of by a separate element-wise add over [rows, d]

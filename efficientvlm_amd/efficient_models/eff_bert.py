@@ -13,8 +13,10 @@ Arithmetic (all in libevlm_hip.so):
     causal LM head (VQA decoder)     -> causal flag of evlm_attention, tied-decoder GEMM, evlm_ce_weighted (:1332-1443)
 
 Dropout (hidden_dropout_prob / attention_probs_dropout_prob, eff_bert.py:180,214,242,346,372-379,456-460): in training
-mode with p > 0 the hidden-state sites run evlm_dropout (fused with the "+ input_tensor" that feeds the LayerNorm) and
-the attention kernels drop the probabilities that form the context; masks are counter-based (Philox, keyed by a device
+mode with p > 0 the hidden-state sites apply the keep-mask inside the producing GEMM's residual epilogue (round 6:
+evlm_gemm_args.dropout_p; their gradients leave the following LayerNorm's backward already masked, evlm_layernorm_bwd_drop;
+the embedding site and EVLM_NO_FUSED_DROPOUT=1 run evlm_dropout) and the attention kernels - the bf16 MFMA ones included -
+drop the probabilities that form the context; masks are counter-based (Philox, keyed by a device
 {seed, step} word and a per-site call id) and regenerated in backward - no mask tensor exists.  eval() models and p = 0
 take the fully fused p = 0 path.  The reference's CUDA RNG stream is not reproducible: parity tests feed
 the SAME masks to the oracle (ops.dropout_mask).
@@ -41,6 +43,9 @@ __all__ = ["BertConfig", "BertModel", "BertForMaskedLM", "BertEmbeddings", "Bert
 FUSED_CROSS_ATTENTION = False
 # one K/V projection of the image tokens for ALL fusion layers of an encoder (round 4); EVLM_NO_MERGED_KV=1: one per layer
 MERGED_CROSS_KV = not os.environ.get("EVLM_NO_MERGED_KV")
+# hidden-state dropout inside the producing GEMM's residual epilogue (round 6); EVLM_NO_FUSED_DROPOUT=1: the separate
+# evlm_dropout pass per site (A/B switch, and what tests compare the fused form with)
+FUSED_HIDDEN_DROPOUT = not os.environ.get("EVLM_NO_FUSED_DROPOUT")
 
 
 def _p(config, name):
@@ -123,7 +128,7 @@ class BertSelfAttention(nn.Module):
                                                        mask=_key_mask(encoder_attention_mask), gate=head_z,
                                                        want_probs=bool(output_attentions), kv_index=encoder_batch_index)
                 return ((ctx, probs) if output_attentions else (ctx,)) + (None,)
-            if encoder_kv is not None and drop == 0.0:          # (BertEncoder projected K/V of every fusion layer at once)
+            if encoder_kv is not None:                          # (BertEncoder projected K/V of every fusion layer at once)
                 kv, col, slot = encoder_kv
             else:
                 kv, col, slot = ops.linear_packed(encoder_hidden_states, (self.key.weight, self.value.weight),
@@ -176,11 +181,12 @@ class BertSelfOutput(nn.Module):
     def forward(self, hidden_states, input_tensor, head_layer_z=None):
         if head_layer_z is not None:
             raise NotImplementedError("head_layer_z is dead plumbing in the reference (BertEncoder never forwards it)")
-        if self.training and self.hidden_dropout_prob > 0.0:         # LayerNorm(dropout(dense(h)) + input), eff_bert.py:374-381
+        drop = self.hidden_dropout_prob if self.training else 0.0
+        if drop > 0.0 and not FUSED_HIDDEN_DROPOUT:                  # LayerNorm(dropout(dense(h)) + input), eff_bert.py:374-381
             h = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
-            h = ops.dropout(h, self.hidden_dropout_prob, True, residual=input_tensor)
-        else:                                                        # p = 0 / eval: the residual rides on the GEMM epilogue
-            h = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor)
+            h = ops.dropout(h, drop, True, residual=input_tensor)
+        else:                         # the residual - and, round 6, the keep-mask ahead of it - ride on the GEMM epilogue
+            h = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor, dropout_p=drop)
         return ops.layer_norm(h, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
 
 
@@ -241,11 +247,12 @@ class BertOutput(nn.Module):
         self.hidden_dropout_prob = _p(config, "hidden_dropout_prob")
 
     def forward(self, hidden_states, input_tensor):
-        if self.training and self.hidden_dropout_prob > 0.0:         # eff_bert.py:458-462
+        drop = self.hidden_dropout_prob if self.training else 0.0
+        if drop > 0.0 and not FUSED_HIDDEN_DROPOUT:                  # eff_bert.py:458-462
             h = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
-            h = ops.dropout(h, self.hidden_dropout_prob, True, residual=input_tensor)
+            h = ops.dropout(h, drop, True, residual=input_tensor)
         else:
-            h = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor)
+            h = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor, dropout_p=drop)
         return ops.layer_norm(h, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
 
 
@@ -301,11 +308,13 @@ class BertLayer(nn.Module):
         """eff_bert.py:552-560: gelu(dense(x)) * mlp_z -> dense -> +x -> LayerNorm (the gate comes AFTER the activation)"""
         o = self.output
         drop = o.hidden_dropout_prob if self.training else 0.0
-        h = ops.mlp(attention_output, self.intermediate.dense.weight, self.intermediate.dense.bias, o.dense.weight,
-                    o.dense.bias, ACT_GELU, gate=self.mlp_z, gate_pos=GATE_POST,
-                    residual=None if drop > 0.0 else attention_output)
-        if drop > 0.0:                                               # BertOutput: LayerNorm(dropout(dense(h)) + input), :458-462
+        if drop > 0.0 and not FUSED_HIDDEN_DROPOUT:                  # BertOutput: LayerNorm(dropout(dense(h)) + input), :458-462
+            h = ops.mlp(attention_output, self.intermediate.dense.weight, self.intermediate.dense.bias, o.dense.weight,
+                        o.dense.bias, ACT_GELU, gate=self.mlp_z, gate_pos=GATE_POST, residual=None)
             h = ops.dropout(h, drop, True, residual=attention_output)
+        else:                         # (round 6: the keep-mask in the second product's residual epilogue)
+            h = ops.mlp(attention_output, self.intermediate.dense.weight, self.intermediate.dense.bias, o.dense.weight,
+                        o.dense.bias, ACT_GELU, gate=self.mlp_z, gate_pos=GATE_POST, residual=attention_output, dropout_p=drop)
         return ops.layer_norm(h, o.LayerNorm.weight, o.LayerNorm.bias, o.LayerNorm.eps)
 
 
@@ -326,7 +335,7 @@ class BertEncoder(nn.Module):
         """{layer index: (merged K/V buffer, first column, gradient slot)} - the cross-attention K / V of every fusion layer
         in `layers` from ONE product over the image tokens (N = n * 2 * all_head_size instead of n products of N = 2 *
         all_head_size: eff_bert.py:284-296 per layer).  Empty when the layers cannot share a buffer (fp32 parity path,
-        physically pruned projections of different widths, dropout on the probabilities, a list of encoder states)."""
+        physically pruned projections of different widths, a list of encoder states)."""
         xl = [i for i in layers if self.layer[i].has_cross_attention]
         if (not MERGED_CROSS_KV or len(xl) < 2 or enc is None or type(enc) == list or not enc.is_cuda
                 or enc.dtype != torch.bfloat16 or enc.dim() != 3 or enc.shape[1] > 928):
@@ -334,7 +343,7 @@ class BertEncoder(nn.Module):
         sas = [self.layer[i].crossattention.self for i in xl]
         d = sas[0].all_head_size
         if any(sa.all_head_size != d or sa.attention_head_size != 64 or sa.key.bias is None or sa.value.bias is None
-               or (self.training and sa.attention_probs_dropout_prob > 0.0) for sa in sas) or d % 8 != 0:
+               for sa in sas) or d % 8 != 0:
             return {}
         if enc_index is None and FUSED_CROSS_ATTENTION:
             return {}

@@ -241,12 +241,15 @@ def _sk_workspace(dev):
 
 def _gemm(dtype, P, Q, Cm, I, J, K, ldp, ldq, ldc, p_trans=0, q_trans=0, bias=None, gate=None, preact=None,
           aux=None, residual=None, ldx=0, alpha=1.0, act=L.ACT_NONE, gate_pos=L.GATE_PRE, dact=L.ACT_NONE, c_f32=0,
-          accumulate=0, p_off=0, psum=None, dgate=None):
+          accumulate=0, p_off=0, psum=None, dgate=None, drop=None):
+    """drop: DropSlot of a hidden-dropout site - C = (..) .* keep / (1 - p) + residual in the epilogue (evlm_gemm_args.dropout_p)"""
     Pp = L.ptr(P) if not p_off else C.c_void_p(P.data_ptr() + p_off * P.element_size())
     a = L.GemmArgs(dtype=dtype, c_f32=c_f32, p_trans=p_trans, q_trans=q_trans, I=I, J=J, K=K, ldp=ldp, ldq=ldq,
                    ldc=ldc, ldx=ldx, P=Pp, Q=L.ptr(Q), C=L.ptr(Cm), bias=L.ptr(bias), gate=L.ptr(gate),
                    preact=L.ptr(preact), aux=L.ptr(aux), residual=L.ptr(residual), alpha=alpha, act=act,
                    gate_pos=gate_pos, dact=dact, accumulate=accumulate, psum=L.ptr(psum), dgate=L.ptr(dgate))
+    if drop is not None:
+        a.dropout_p, a.rng_state, a.call_id = drop.p, L.ptr(drop.state), drop.call
     if _SK_ON and dgate is None and dtype == L.BF16 and not c_f32 and not p_trans and K >= 512 and I * J >= 16 * 65536:
         a.sk_workspace = L.ptr(_sk_workspace(P.device))     # (shapes stream-K can apply to: gemm_pp256.hip)
     if GEMM_PROFILE is None:
@@ -639,6 +642,8 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, residual, act, out_f32, nw, *wb):
+        # (nw may be (nw, DropSlot): hidden dropout between the product and the residual - y = drop(x W^T + b) + residual)
+        nw, drop = nw if isinstance(nw, tuple) else (nw, None)
         weights, biases = wb[:nw], wb[nw:]
         L.require_cuda(x, *weights)
         x2, M, K, ldp = _as2d(x)
@@ -665,8 +670,11 @@ class _Linear(torch.autograd.Function):
             r2, rm, rn, ldr = _as2d(residual)
             if ldr != ldc or r2.dtype != x2.dtype:
                 raise RuntimeError("residual must be contiguous [M, N] of the activation dtype")
+        if drop is not None and (r2 is None or act != L.ACT_NONE or out_f32 or ldc != N or N % 8 != 0):
+            raise RuntimeError("linear(dropout=): needs a residual, no activation, an output of the activation dtype and N % 8 == 0")
         _gemm(dtype, x2, W, ybuf, M, N, K, ldp, K, ldc, bias=b, preact=preact, residual=r2, ldx=ldc, act=act,
-              c_f32=1 if out_f32 else 0)
+              c_f32=1 if out_f32 else 0, drop=drop)
+        ctx.drop_slot = drop
         ctx.save_for_backward(x2, W, preact)
         ctx.params = (weights, biases)
         ctx.meta = (M, N, K, ldp, ldc, act, nw, tuple(w.shape[0] for w in weights), biases and biases[0] is not None,
@@ -688,6 +696,8 @@ def _linear_backward(ctx, dy, dx_add):
         dtype = L.dt(x2)
         lib = _lib()
         d2 = dy.reshape(M, N)
+        if getattr(ctx, "drop_slot", None) is not None:      # the product's gradient is dy .* M (dy itself goes to the residual)
+            d2 = ctx.drop_slot.masked_grad(dy).reshape(M, N)
         if d2.dtype != x2.dtype:          # f32-output heads only: bring the gradient to the compute dtype
             d2 = cast(d2.contiguous(), x2.dtype)
         if d2.stride(1) != 1 or d2.stride(0) % 8 != 0 or d2.stride(0) < _pad8(N):
@@ -760,7 +770,15 @@ class _LinearFork(torch.autograd.Function):
         return _linear_backward(ctx, dy, dxa)
 
 
-def linear(x, weight, bias=None, act=L.ACT_NONE, residual=None, out_f32=False):
+def linear(x, weight, bias=None, act=L.ACT_NONE, residual=None, out_f32=False, dropout_p=0.0):
+    """dropout_p > 0 (training): y = dropout(x W^T + b) + residual with the keep-mask applied in the GEMM's residual epilogue
+    (BertSelfOutput / BertOutput, eff_bert.py:372-381,456-462); the result carries its DropSlot so that the LayerNorm that
+    consumes it writes the masked gradient beside its own (layer_norm)"""
+    if dropout_p and dropout_p > 0.0:
+        slot = DropSlot(dropout_p, x.device, tuple(x.shape[:-1]) + (weight.shape[0],))
+        y = _Linear.apply(x, residual, act, out_f32, (1, slot), weight, bias)
+        y._evlm_drop_slot = slot
+        return y
     return _Linear.apply(x, residual, act, out_f32, 1, weight, bias)
 
 
@@ -782,7 +800,7 @@ def linear_fork(x, weights, biases):
 # ---------------------------------------------------------------------------------------------------
 class _MLP(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gate, residual, act, gate_pos):
+    def forward(ctx, x, w1, b1, w2, b2, gate, residual, act, gate_pos, drop=None):
         L.require_cuda(x, w1, w2)
         x2, M, K, ldp = _as2d(x)
         dtype = L.dt(x2)
@@ -801,7 +819,10 @@ class _MLP(torch.autograd.Function):
             r2 = residual.reshape(M, N)
             if not r2.is_contiguous():
                 r2 = r2.contiguous()
-        _gemm(dtype, a, W2, y, M, N, Fh, Fh, Fh, N, bias=b2.detach(), residual=r2, ldx=N)
+        if drop is not None and (r2 is None or N % 8 != 0):
+            raise RuntimeError("mlp(dropout=): needs the residual and N % 8 == 0")
+        _gemm(dtype, a, W2, y, M, N, Fh, Fh, Fh, N, bias=b2.detach(), residual=r2, ldx=N, drop=drop)
+        ctx.drop_slot = drop
         ctx.save_for_backward(x2, W1, W2, h, a, g32)
         ctx.params = (w1, b1, w2, b2)
         # residual IS the input (post-LN BERT FFN: LayerNorm(x + FFN(x))): the backward then adds dy in the dX GEMM's
@@ -821,6 +842,11 @@ class _MLP(torch.autograd.Function):
         d2 = dy.reshape(M, N)
         if not d2.is_contiguous():
             d2 = d2.contiguous()
+        d_res = d2                                 # what the residual branch receives: dy itself
+        if ctx.drop_slot is not None:              # ... while the second product's gradient is dy .* M
+            d2 = ctx.drop_slot.masked_grad(dy).reshape(M, N)
+            if not d2.is_contiguous():
+                d2 = d2.contiguous()
         dev = x2.device
         dh = torch.empty((M, Fh), dtype=x2.dtype, device=dev)
         dgate = None
@@ -851,7 +877,7 @@ class _MLP(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dxb = torch.empty((M, K), dtype=x2.dtype, device=dev)
-            rkw = dict(residual=d2, ldx=K) if ctx.res_is_x else {}
+            rkw = dict(residual=d_res, ldx=K) if ctx.res_is_x else {}
             if W1t is not None:
                 _gemm(dtype, dh, W1t, dxb, M, K, Fh, Fh, Fh, K, p_trans=0, q_trans=0, **rkw)
             else:
@@ -859,10 +885,17 @@ class _MLP(torch.autograd.Function):
             dx = dxb.view(xshape)
         (dW1,), (db1,) = _wgrad(dtype, dh, Fh, x2, ldp, M, K, (w1,), (Fh,), (b1,))
         dres = None if (ctx.res_is_x and dx is not None) else (dy if has_res else None)
-        return dx, dW1, db1, dW2, db2, dgate, dres, None, None
+        return dx, dW1, db1, dW2, db2, dgate, dres, None, None, None
 
 
-def mlp(x, w1, b1, w2, b2, act, gate=None, gate_pos=L.GATE_PRE, residual=None):
+def mlp(x, w1, b1, w2, b2, act, gate=None, gate_pos=L.GATE_PRE, residual=None, dropout_p=0.0):
+    """dropout_p > 0 (training): y = dropout(act_gate(x W1^T + b1) W2^T + b2) + residual, the mask in the second product's
+    residual epilogue (BertOutput, eff_bert.py:456-462); see linear()"""
+    if dropout_p and dropout_p > 0.0:
+        slot = DropSlot(dropout_p, x.device, tuple(x.shape[:-1]) + (w2.shape[0],))
+        y = _MLP.apply(x, w1, b1, w2, b2, gate, residual, act, gate_pos, slot)
+        y._evlm_drop_slot = slot
+        return y
     return _MLP.apply(x, w1, b1, w2, b2, gate, residual, act, gate_pos)
 
 
@@ -871,8 +904,9 @@ def mlp(x, w1, b1, w2, b2, act, gate=None, gate_pos=L.GATE_PRE, residual=None):
 # ---------------------------------------------------------------------------------------------------
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, drop_slot=None):
         L.require_cuda(x, gamma)
+        ctx.drop_slot = drop_slot
         d = x.shape[-1]
         xc = x if x.is_contiguous() else x.contiguous()
         rows = xc.numel() // d
@@ -903,10 +937,20 @@ class _LayerNorm(torch.autograd.Function):
         defer = inplace and WGRAD_DEFER is not None          # column sums reduced with the grouped weight gradients
         if defer:
             LN_DEFER.append((ws, nblk, d, dg, db))
-        L.check(_lib().evlm_layernorm_bwd(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd),
-                                          rows, d, L.ptr(dx), None if defer else L.ptr(dg), None if defer else L.ptr(db),
-                                          L.ptr(ws), L.stream()), "layernorm_bwd")
-        return (dx, None, None, None) if inplace else (dx, dg, db, None)
+        slot = ctx.drop_slot
+        if slot is not None and slot.shape == (rows, d):
+            # x = dropout(dense(h)) + input: dx goes to `input`, dx .* M to the product - both written by this kernel
+            dxm = torch.empty_like(xc)
+            L.check(_lib().evlm_layernorm_bwd_drop(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd),
+                                                   rows, d, L.ptr(dx), L.ptr(dxm), slot.p, L.ptr(slot.state), slot.call,
+                                                   None if defer else L.ptr(dg), None if defer else L.ptr(db), L.ptr(ws),
+                                                   L.stream()), "layernorm_bwd_drop")
+            slot.hand(dx, dxm)
+        else:
+            L.check(_lib().evlm_layernorm_bwd(L.dt(xc), L.ptr(dyc), L.ptr(xc), L.ptr(gamma.detach()), L.ptr(mean), L.ptr(rstd),
+                                              rows, d, L.ptr(dx), None if defer else L.ptr(dg), None if defer else L.ptr(db),
+                                              L.ptr(ws), L.stream()), "layernorm_bwd")
+        return (dx, None, None, None, None) if inplace else (dx, dg, db, None, None)
 
 
 class _LayerNormFork(torch.autograd.Function):
@@ -1037,13 +1081,16 @@ def hidden_kd_slots():
 
 
 def layer_norm(x, gamma, beta, eps):
-    return _LayerNorm.apply(x, gamma, beta, eps)
+    slot = getattr(x, "_evlm_drop_slot", None)
+    if slot is not None and torch.is_grad_enabled() and x.requires_grad:
+        return _LayerNorm.apply(x, gamma, beta, eps, slot)
+    return _LayerNorm.apply(x, gamma, beta, eps, None)
 
 
 def layer_norm_fork(x, gamma, beta, eps, tap=False):
     """(LayerNorm(x), alias of x for the residual branch [, alias of x for a distillation term]): see _LayerNormFork"""
     if not (torch.is_grad_enabled() and x.requires_grad) or _NO_FORK:
-        y = _LayerNorm.apply(x, gamma, beta, eps)
+        y = _LayerNorm.apply(x, gamma, beta, eps, None)
         return (y, x, x) if tap else (y, x)
     return _LayerNormFork.apply(x, gamma, beta, eps, tap)
 
@@ -1066,7 +1113,8 @@ class _Attention(torch.autograd.Function):
         O = torch.empty((B, Lq, H * dh), dtype=tdt, device=dev)
         need = any(ctx.needs_input_grad)
         Lkp = _pad8(Lk)          # probability rows are padded to 16 bytes; the kernels zero the padding
-        # Recomputing form (bf16 MFMA kernels, Lk <= 224, no dropout): the forward keeps the per-row log2-sum-exp instead
+        # Recomputing form (bf16 MFMA kernels, Lk <= 224; round 6: with or without probability dropout - the kernels
+        # regenerate the keep-mask from (rng state, call id, row, key)): the forward keeps the per-row log2-sum-exp instead
         # of the map, the backward rebuilds P from Q and K in fp32 - no [B, H, Lq, Lk] bf16 map is written or read back
         # unless a caller wants it, and the q / k gradients are formed from fp32 probabilities, as the reference's
         # autocast softmax does.  EVLM_ATTN_STORE_P=1: the round-2 form (backward from the stored bf16 map).
@@ -1074,8 +1122,9 @@ class _Attention(torch.autograd.Function):
         # come back for it): the backward then needs one pass over the keys - delta from dO . O (+ the fused distillation
         # term's row sums, kd_rowdot) - and the student's 518 MB-per-layer maps of the ITR / VQA steps are never written.
         # A caller that asks for the map keeps the stored-map form there.  EVLM_ATTN_RC_LONG=0: the round-3 behaviour.
-        rc = bool(need and not ATTN_STORE_P and not (dropout_p and dropout_p > 0.0)
-                  and _lib().evlm_attention_lse_supported(L.dt(tdt), dh, Lk, 0.0)
+        rc = bool(need and not ATTN_STORE_P
+                  and _lib().evlm_attention_lse_supported(L.dt(tdt), dh, Lk, float(dropout_p or 0.0))
+                  and not (dropout_p and causal and Lk > 224)
                   and (Lk <= 224 or (not want_probs and ATTN_RC_LONG)))
         lse = torch.empty((B, H, Lq), dtype=torch.float32, device=dev) if rc else None
         Pbuf = torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev) if (want_probs or (need and not rc)) else None
@@ -1180,7 +1229,8 @@ class _Attention(torch.autograd.Function):
         # dS workspace of the two-kernel path; the single-pass kernel (self-attention problems that fit one workgroup,
         # attention_mfma.hip) keeps dS in LDS and takes none
         single_pass = (tdt == torch.bfloat16 and dh == 64 and kv_index is None and Lq <= 224 and Lk <= 224
-                       and ctx.drop is None and os.environ.get("EVLM_ATTN_BWD_SPLIT", "0") in ("", "0"))
+                       and (ctx.drop is None or (lse is not None and Lq <= 64 and Lk <= 64))
+                       and os.environ.get("EVLM_ATTN_BWD_SPLIT", "0") in ("", "0"))
         dS = None if single_pass else torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev)
         # (two-kernel recomputing path: the second kernel reads the map the first one rebuilds)
         # ... except on the streaming one-pass path (attention_mfma.hip:launch_bwd_dq_stream - the same conditions): there
@@ -1215,8 +1265,6 @@ class _Attention(torch.autograd.Function):
             a.kd_teacher, a.kd_gout, a.kd_weight = L.ptr(kd_base), L.ptr(gk), ctx.kd_weight
         if ctx.drop is not None:          # the keep-mask is regenerated from the same (state, call id), never stored
             a.dropout_p, a.rng_state, a.call_id = ctx.drop[0], L.ptr(ctx.drop[1]), ctx.drop[2]
-            if kv_index is not None:      # generic kernels accumulate shared K/V gradients with f32 atomics
-                raise RuntimeError("attention-probability dropout with a shared K/V index: materialise the gather first")
         L.check(_lib().evlm_attention_bwd(C.byref(a), L.stream()), "attention_bwd")
         if ATTN_FLOPS is not None:
             ATTN_FLOPS[0] += (10.0 if lse is not None else 8.0) * B * H * Lq * Lk * dh     # dP, dV, dQ, dK (+ S when P is recomputed)
@@ -1303,8 +1351,8 @@ class KdSlot:
 def attention_recomputes(x, dh, Lk, dropout_p=0.0):
     """will the attention backward of this problem rebuild the probabilities from Q and K (bf16 MFMA kernels, lse saved by
     the forward) instead of reading a stored map - provided, on long key sequences, that the caller does not ask for the map?"""
-    return bool(x.is_cuda and not ATTN_STORE_P and not dropout_p and (Lk <= 224 or ATTN_RC_LONG)
-                and _lib().evlm_attention_lse_supported(L.dt(x.dtype), dh, Lk, 0.0))
+    return bool(x.is_cuda and not ATTN_STORE_P and (Lk <= 224 or ATTN_RC_LONG)
+                and _lib().evlm_attention_lse_supported(L.dt(x.dtype), dh, Lk, float(dropout_p or 0.0)))
 
 
 def attention_kd_fusable(x, H, dh, Lk):
@@ -1420,11 +1468,11 @@ def cross_attention(q, kv, H, dh, scale, mask=None, gate=None, want_probs=True, 
     d = H * dh
     k_off = 0 if kv_col is None else int(kv_col)
     if kv_index is not None:
-        if q.dtype == torch.bfloat16 and dh == 64 and kv.shape[1] <= 928 and not dropout_p:
+        if q.dtype == torch.bfloat16 and dh == 64 and kv.shape[1] <= 928:
             kv_index = kv_index.to(torch.int32).contiguous()
         else:                                   # exact-fp32 / generic path: materialise the gather (autograd scatters back)
             if kv_col is not None:
-                raise RuntimeError("merged K/V buffers need the in-kernel K/V index (bf16, dh = 64, no dropout)")
+                raise RuntimeError("merged K/V buffers need the in-kernel K/V index (bf16, dh = 64)")
             kv = torch.index_select(kv, 0, kv_index.long())
             kv_index = None
     return _Attention.apply(q, kv, mask, gate, H, dh, 0, k_off, k_off + d, scale, want_probs, kv_index, False, dropout_p,
@@ -1627,6 +1675,7 @@ def cross_attention_fused(q, x_img, weights, biases, H, dh, scale, mask=None, ga
 # ---------------------------------------------------------------------------------------------------
 _DROP_STATE = {}
 _DROP_CALL = [0]
+_DROP_KINDS = {}          # call id -> kind of the sites logged while DROPOUT_LOG is set (dropout_mask reads it)
 DROPOUT_LOG = None        # tests: set to a list to collect (call id, kind, shape, p) of every dropout site of a forward
 DROPOUT_USED = False      # a trainer bumps the device-side step word once per step while this is set
 
@@ -1663,6 +1712,7 @@ def _next_drop_call(kind, shape, p):
     _DROP_CALL[0] = (_DROP_CALL[0] + 1) & 0xFFFFFFFF
     if DROPOUT_LOG is not None:
         DROPOUT_LOG.append((_DROP_CALL[0], kind, tuple(shape), float(p)))
+        _DROP_KINDS[_DROP_CALL[0]] = kind
     return _DROP_CALL[0]
 
 
@@ -1784,16 +1834,57 @@ def itc_loss(image_feat, text_feat, temp, group=None):
     return _ITCLoss.apply(image_feat, text_feat, temp, group)
 
 
-def dropout_mask(call_id, shape, p, device="cuda"):
+def dropout_mask(call_id, shape, p, device="cuda", kind=None):
     """keep / (1 - p) of dropout site `call_id` as an f32 tensor of `shape` (what the kernels regenerate on the fly; tests
-    hand it to the CPU oracle)"""
+    hand it to the CPU oracle).  A site's elements are indexed with its rows padded to a multiple of 8 columns (csrc/common.h:
+    one Philox call per 8 consecutive columns): attention-probability sites ([B, H, Lq, Lk], any Lk) are generated padded and
+    sliced; hidden-state sites are addressed flat (their rows are multiples of 8 wherever a kernel other than evlm_dropout
+    regenerates them).  kind: "attention_probs" | "hidden"; default = what DROPOUT_LOG recorded for the call id."""
+    kind = kind or _DROP_KINDS.get(call_id, "hidden")
+    shape = tuple(shape)
+    pshape = shape[:-1] + ((shape[-1] + 7) // 8 * 8,) if kind == "attention_probs" else shape
     n = 1
-    for v in shape:
+    for v in pshape:
         n *= v
     out = torch.empty(n, dtype=torch.float32, device=device)
     L.check(_lib().evlm_dropout_mask(n, float(p), L.ptr(dropout_state(torch.device(device))), call_id, L.ptr(out), L.stream()),
             "dropout_mask")
-    return out.view(*shape)
+    out = out.view(*pshape)
+    return out[..., :shape[-1]].contiguous() if pshape != shape else out
+
+
+class DropSlot:
+    """One hidden-dropout site fused into a GEMM's residual epilogue: y = (x W^T + b) .* M + residual (linear / mlp with
+    dropout_p).  Holds what regenerates M = keep / (1 - p) - the device {seed, step} word and the site's call id - and carries
+    the site's MASKED gradient from the LayerNorm that consumes y to the product's backward: evlm_layernorm_bwd_drop writes
+    dx (for the residual) and dx .* M (for the product) in one pass (`hand`), _linear_backward / _MLP.backward pick the latter
+    up when the gradient they receive IS that dx (`masked_grad`); any other gradient (y consumed by something else) is masked
+    by one evlm_dropout call.  A plain object: autograd does not see it."""
+
+    def __init__(self, p, device, shape):
+        self.p = float(p)
+        self.state = dropout_state(device)
+        shape = tuple(int(v) for v in shape)
+        rows = 1
+        for v in shape[:-1]:
+            rows *= v
+        self.shape = (rows, shape[-1])             # the [rows, N] matrix the kernels index (flat: N % 8 == 0)
+        self.call = _next_drop_call("hidden", shape, p)
+        self._dx_ptr, self._masked = None, None
+
+    def hand(self, dx, masked):
+        self._dx_ptr, self._masked = dx.data_ptr(), masked
+
+    def masked_grad(self, dy):
+        ptr_, m = self._dx_ptr, self._masked
+        self._dx_ptr, self._masked = None, None
+        if m is not None and dy.data_ptr() == ptr_ and dy.numel() == m.numel() and dy.dtype == m.dtype:
+            return m.view(dy.shape)
+        dyc = dy if dy.is_contiguous() else dy.contiguous()
+        out = torch.empty_like(dyc)
+        L.check(_lib().evlm_dropout(L.dt(dyc), L.ptr(dyc), None, dyc.numel(), self.p, L.ptr(self.state), self.call, L.ptr(out),
+                                    L.stream()), "dropout")
+        return out
 
 
 class _Dropout(torch.autograd.Function):

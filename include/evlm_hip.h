@@ -84,6 +84,14 @@ typedef struct {
                            gate gradient  sum_rows dA act'(h z) h  /  sum_rows dA act(h)  to dgate.  bf16, no bias / residual /
                            preact, a product the 256-column ping-pong kernels take (K % 64 == 0, K >= 128, J, ldc, ldx % 8 == 0,
                            P not transposed); replaces a second pass over [I, J] (evlm_gated_act_bwd) */
+  /* ABI 9 - hidden-state dropout in the residual epilogue (BertSelfOutput / BertOutput: LayerNorm(dropout(dense(h)) + input),
+     eff_bert.py:372-381,456-462):  C = (alpha P Q^T + bias) .* keep / (1 - p) + residual,  the keep-mask of site `call_id`
+     regenerated from rng_state exactly as evlm_dropout generates it for the [I, J] result (element index i * J + j; ONE Philox
+     call per 8 consecutive columns).  Needs residual, J % 8 == 0, a bf16 / f32 output of `dtype` and no act / gate / dact.
+     Replaces the separate evlm_dropout pass over [I, J] (one launch, a read and a write of the tensor per site). */
+  float dropout_p;
+  const int64_t* rng_state;
+  uint32_t call_id;
 } evlm_gemm_args;
 #define EVLM_GEMM_SK_WORKSPACE_BYTES (4096 + 256 * 262144)
 
@@ -131,6 +139,14 @@ int evlm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* ga
 int evlm_layernorm_bwd_add(int dtype, const void* dy, const void* x, const void* addend, const void* addend2,
                            const float* gamma, const float* mean, const float* rstd, int rows, int d, void* dx,
                            float* dgamma, float* dbeta, float* partials, void* stream);
+/* ABI 9 - the backward of  y = LayerNorm(dropout(dense(h)) + input)  (BertSelfOutput / BertOutput, eff_bert.py:372-381,
+ * 456-462): dx = the LayerNorm's input gradient (what `input` receives) AND dx_dropped = dx .* keep / (1 - p) (what dense(h)
+ * receives), the keep-mask of hidden-dropout site (rng_state, call_id) regenerated over [rows, d] exactly as the forward's
+ * evlm_gemm_args.dropout_p / evlm_dropout generated it.  One pass instead of evlm_layernorm_bwd + evlm_dropout on dx. */
+int evlm_layernorm_bwd_drop(int dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                            const float* rstd, int rows, int d, void* dx, void* dx_dropped, float dropout_p,
+                            const int64_t* rng_state, uint32_t call_id, float* dgamma, float* dbeta, float* partials,
+                            void* stream);
 /* LayerNorm with the HIDDEN-STATE DISTILLATION TERM of its input fused in (ABI 7; GeneralDistill.py:60-82 get_kd_loss on
  * image_hidden_states: MSELoss(student state, teacher state), the state being the input of a pre-LN ViT block,
  * eff_vit.py:250).  Forward: kd_slots[evlm_layernorm_fwd_kd_slots() floats, zeroed by the caller] receive
@@ -300,10 +316,13 @@ int evlm_xattn_fused_fwd(const evlm_xattn_fused_args* a, void* stream);
  * Replaces nn.Dropout(hidden_dropout_prob) in BertEmbeddings (eff_bert.py:180,214), BertSelfOutput (:372,:379) and
  * BertOutput (:456,:460); with `residual` it also forms the "+ input_tensor" the LayerNorm that follows consumes.
  * The keep-mask is a pure function of (rng_state = device int64[2] {seed, step}, call_id, element index) - Philox4x32-10,
- * counter {index / 4, call_id, step}, key seed - so the backward pass is THE SAME CALL on dy (residual NULL) and no mask
+ * counter {index / 8, call_id, step}, key seed, element (index % 8) = one 16-bit lane of the 128-bit output, kept iff the
+ * lane >= round(p 2^16) (ABI 9; csrc/common.h) - so the backward pass is THE SAME CALL on dy (residual NULL) and no mask
  * tensor exists in HBM; a captured hipGraph draws new masks on every replay once `step` has been bumped on the device.
- * evlm_dropout_mask writes keep / (1 - p) as f32 (tests feed it to the CPU oracle; the attention kernels index their
- * mask by ((b*H + h)*Lq + q)*Lk + k).
+ * evlm_dropout_mask writes keep / (1 - p) as f32 for the flat indices 0 .. n-1 (tests feed it to the CPU oracle).  The
+ * attention kernels index their mask by ((b*H + h)*Lq + q) * Lk8 + k with Lk8 = 8 ceil(Lk / 8) (rows padded to 8 keys: a lane
+ * of the MFMA kernels owns 8 consecutive keys of a query per key-tile pair = one Philox call); the GEMM residual epilogue
+ * (evlm_gemm_args.dropout_p) and evlm_layernorm_bwd_drop index [rows, d] results flat, as evlm_dropout does.
  * ---------------------------------------------------------------------------------------------- */
 int evlm_dropout(int dtype, const void* x, const void* residual, int64_t n, float p, const int64_t* rng_state,
                  uint32_t call_id, void* y, void* stream);

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/evlm_hip.h but not exported by libevlm_hip.so"
     bound = set(_lib.SIGNATURES) | {"evlm_last_error", "evlm_abi_version", "evlm_gemm_last_kernel"}
     assert set(names) == bound, sorted(set(names) ^ bound)
-    assert lib.evlm_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.evlm_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_struct_layout_matches_header():

@@ -99,6 +99,217 @@ def test_attention_probability_dropout_against_torch_with_the_same_mask(dtype, c
         assert rel_err(qkv.grad.float(), torch.cat([qr.grad, kr.grad, vr.grad], -1)) < 4 * tol
 
 
+MFMA_CASES = [
+    # name, B, Bkv, H, Lq, Lk, self-attention?, want the map?, causal?
+    ("text_self_30", 5, 5, 3, 30, 30, True, False, False),
+    ("text_self_30_map", 5, 5, 3, 30, 30, True, True, False),
+    ("decoder_self_causal_12", 4, 4, 2, 12, 12, True, False, True),
+    ("text_self_50", 3, 3, 2, 50, 50, True, True, False),
+    ("cross_grouped_197", 8, 2, 3, 30, 197, False, False, False),
+    ("cross_grouped_197_map", 8, 3, 2, 30, 197, False, True, False),
+    ("cross_per_batch_197", 3, 3, 2, 30, 197, False, True, False),
+    ("cross_stream_577", 6, 2, 2, 30, 577, False, False, False),
+    ("cross_stream_577_map", 4, 2, 2, 30, 577, False, True, False),
+    ("cross_stream_901", 3, 3, 1, 20, 901, False, False, False),
+]
+
+
+@pytest.mark.parametrize("case", MFMA_CASES, ids=[c[0] for c in MFMA_CASES])
+def test_probability_dropout_inside_the_mfma_attention_kernels(case):
+    """Round 6: the bf16 MFMA kernels (head dim 64) regenerate the keep-mask themselves - whole-row, grouped (shared K/V
+    index), streaming and map-writing forwards; single-pass, kernels A + B and streaming backwards, with the recomputing
+    (lse) form kept.  Against fp32 torch on the same bf16 operands with the SAME mask (ops.dropout_mask): the returned map is
+    the un-dropped softmax (eff_bert.py:338-361), the context and every gradient go through P .* M, the gate gradient
+    included; an external gradient on the map (the unfused distillation terms) rides along where the map is returned."""
+    from efficientvlm_amd import ops
+    name, B, Bkv, H, Lq, Lk, self_attn, want, causal = case
+    ops.dropout_seed(4321)
+    g = torch.Generator().manual_seed(11)
+    dh, p = 64, 0.1
+    d = H * dh
+    scale = 1.0 / math.sqrt(dh)
+    mask = torch.zeros(B, Lk)
+    mask[1, Lk - 5:] = -10000.0
+    gate = (torch.rand(H, generator=g) + 0.5).to(DEV).requires_grad_(True)
+    idx = None
+    if self_attn:
+        qkv = (torch.randn(B, Lq, 3 * d, generator=g) * 0.7).to(DEV, torch.bfloat16).requires_grad_(True)
+        ops.DROPOUT_LOG = []
+        Oo, P = ops.self_attention(qkv, H, dh, scale, mask=mask.to(DEV), gate=gate, want_probs=want, causal=causal, dropout_p=p)
+        x = qkv.detach().float()
+        qr, kr, vr = x[..., :d], x[..., d:2 * d], x[..., 2 * d:]
+    else:
+        q = (torch.randn(B, Lq, d, generator=g) * 0.7).to(DEV, torch.bfloat16).requires_grad_(True)
+        kv = (torch.randn(Bkv, Lk, 2 * d, generator=g) * 0.7).to(DEV, torch.bfloat16).requires_grad_(True)
+        if Bkv != B:
+            idx = (torch.arange(B) % Bkv).to(DEV)
+        ops.DROPOUT_LOG = []
+        Oo, P = ops.cross_attention(q, kv, H, dh, scale, mask=mask.to(DEV), gate=gate, want_probs=want, kv_index=idx, dropout_p=p)
+        qr = q.detach().float()
+        kvf = kv.detach().float()
+        kr, vr = kvf[..., :d], kvf[..., d:]
+    (call, kind, shp, pp), = ops.DROPOUT_LOG
+    ops.DROPOUT_LOG = None
+    assert kind == "attention_probs" and shp == (B, H, Lq, Lk)
+    M = ops.dropout_mask(call, (B, H, Lq, Lk), p)
+    keep = float((M > 0).float().mean())
+    assert abs(keep - (1 - p)) < 5 * math.sqrt(p * (1 - p) / M.numel()) + 1e-3, keep
+    assert set(torch.unique(M).tolist()) <= {0.0, float(torch.tensor(1.0 / (1.0 - p), dtype=torch.float32))}
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (qr, kr, vr))
+    gr = gate.detach().clone().requires_grad_(True)
+    sp = lambda t, Ln: t.reshape(t.shape[0], Ln, H, dh).transpose(1, 2)
+    K4, V4 = sp(kr, Lk), sp(vr, Lk)
+    if idx is not None:
+        K4, V4 = K4[idx], V4[idx]
+    S = sp(qr, Lq) @ K4.transpose(-1, -2) * scale + mask.to(DEV)[:, None, None, :]
+    if causal:
+        S = S + torch.triu(torch.full((Lq, Lk), -10000.0, device=DEV), 1)
+    Pr = torch.softmax(S, -1)
+    Or = ((Pr * M) @ V4 * gr[None, :, None, None]).transpose(1, 2).reshape(B, Lq, d)
+    tol = 2.5e-2
+    assert rel_err(Oo.float(), Or) < tol, rel_err(Oo.float(), Or)
+    gO = torch.randn(B, Lq, d, generator=g).to(DEV, torch.bfloat16)
+    loss, lref = (Oo.float() * gO.float()).sum(), (Or * gO.float()).sum()
+    if want:
+        assert rel_err(P.float(), Pr) < tol
+        gP = (torch.randn(B, H, Lq, Lk, generator=g) * 0.5).to(DEV, torch.bfloat16)
+        loss, lref = loss + (P.float() * gP.float()).sum(), lref + (Pr * gP.float()).sum()
+    else:
+        assert P is None
+    loss.backward()
+    lref.backward()
+    if self_attn:
+        got, ref = qkv.grad.float(), torch.cat([qr.grad, kr.grad, vr.grad], -1)
+        for nm, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+            assert rel_err(got[..., sl], ref[..., sl]) < 2 * tol, (nm, rel_err(got[..., sl], ref[..., sl]))
+    else:
+        assert rel_err(q.grad.float(), qr.grad) < 2 * tol, rel_err(q.grad.float(), qr.grad)
+        ref = torch.cat([kr.grad, vr.grad], -1)
+        assert rel_err(kv.grad.float()[..., :d], ref[..., :d]) < 2 * tol, rel_err(kv.grad.float()[..., :d], ref[..., :d])
+        assert rel_err(kv.grad.float()[..., d:], ref[..., d:]) < 2 * tol, rel_err(kv.grad.float()[..., d:], ref[..., d:])
+    assert rel_err(gate.grad, gr.grad) < 2 * tol, rel_err(gate.grad, gr.grad)
+    # dropout is really on: the p = 0 context differs
+    with torch.no_grad():
+        O0 = ((Pr @ V4) * gr[None, :, None, None]).transpose(1, 2).reshape(B, Lq, d)
+    assert rel_err(Oo.float(), O0) > 0.05
+
+
+def test_grouped_cross_attention_with_dropout_is_bit_identical_to_the_per_batch_kernel(monkeypatch):
+    """the (K/V row, head)-grouped forward and the per-batch kernel regenerate the same mask for the same (batch, head,
+    query, key) - whichever workgroup serves a text row - so their contexts, maps and row lse are bit-identical with p > 0"""
+    from efficientvlm_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, Bkv, H, Lq, Lk, dh, p = 12, 3, 4, 30, 197, 64, 0.1
+    d = H * dh
+    q = (torch.randn(B, Lq, d, generator=g) * 0.7).to(DEV, torch.bfloat16)
+    kv = (torch.randn(Bkv, Lk, 2 * d, generator=g) * 0.7).to(DEV, torch.bfloat16)
+    idx = torch.tensor([0, 1, 2, 1, 0, 2, 2, 1, 0, 0, 1, 2]).to(DEV)
+    mask = torch.zeros(B, Lk)
+    mask[3, 150:] = -10000.0
+    outs = []
+    for no_group in ("0", "1"):
+        monkeypatch.setenv("EVLM_ATTN_NO_GROUP", no_group)
+        ops.dropout_seed(77)
+        with torch.no_grad():
+            outs.append(ops.cross_attention(q, kv, H, dh, 0.125, mask=mask.to(DEV), want_probs=True, kv_index=idx, dropout_p=p))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ops.dropout_seed(78)
+    with torch.no_grad():
+        other = ops.cross_attention(q, kv, H, dh, 0.125, mask=mask.to(DEV), want_probs=True, kv_index=idx, dropout_p=p)
+    assert not torch.equal(other[0], outs[0][0]) and torch.equal(other[1], outs[0][1])      # another seed: another context, the same map
+
+
+@pytest.mark.parametrize("dtype,M,K,N", [(torch.float32, 20, 64, 64), (torch.bfloat16, 3840, 768, 768), (torch.bfloat16, 7680, 768, 768),
+                                         (torch.bfloat16, 7680, 3072, 768), (torch.bfloat16, 1920, 3072, 768), (torch.bfloat16, 90, 256, 128)])
+def test_hidden_dropout_in_the_gemm_epilogue_and_the_layernorm_backward_equals_the_separate_passes(dtype, M, K, N):
+    """Round 6 (ABI 9): LayerNorm(dropout(x W^T + b) + residual) with the keep-mask applied in the GEMM's residual epilogue
+    (evlm_gemm_args.dropout_p; every kernel family the text-side products reach) and its backward's masked gradient written by
+    the LayerNorm backward itself (evlm_layernorm_bwd_drop) - bit-identical, forward and every gradient, to the round-5 chain
+    linear -> evlm_dropout(+ residual) -> LayerNorm with evlm_dropout on the gradient, and equal to fp32 torch given the mask"""
+    from efficientvlm_amd import ops
+    from efficientvlm_amd._lib import load
+    g = torch.Generator().manual_seed(M + K)
+    p = 0.1
+    x0 = (torch.randn(M, K, generator=g) * 0.5).to(DEV, dtype)
+    r0 = torch.randn(M, N, generator=g).to(DEV, dtype)
+    W0 = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    b0 = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    gam0, bet0 = (torch.rand(N, generator=g) + 0.5).to(DEV), (torch.randn(N, generator=g) * 0.1).to(DEV)
+    gy = torch.randn(M, N, generator=g).to(DEV, dtype)
+    res = {}
+    for fused in (True, False):
+        ops.dropout_seed(31)
+        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        W, b, gam, bet = (t.clone().requires_grad_(True) for t in (W0, b0, gam0, bet0))
+        ops.DROPOUT_LOG = []
+        if fused:
+            h = ops.linear(x, W, b, residual=r, dropout_p=p)
+            kern = load().evlm_gemm_last_kernel().decode()
+        else:
+            h = ops.dropout(ops.linear(x, W, b), p, True, residual=r)
+        (call, kind, shp, pp), = ops.DROPOUT_LOG
+        ops.DROPOUT_LOG = None
+        assert kind == "hidden" and tuple(shp) == (M, N)
+        y = ops.layer_norm(h, gam, bet, 1e-12)
+        y.backward(gy)
+        res[fused] = [t.detach().clone() for t in (h, y, x.grad, r.grad, W.grad, b.grad, gam.grad, bet.grad)]
+        mask = ops.dropout_mask(call, (M, N), p)
+    names = ("h", "y", "dx", "dr", "dW", "db", "dgamma", "dbeta")
+    for nm, a, c in zip(names, res[True], res[False]):
+        if nm in ("dW", "db", "dgamma", "dbeta"):        # (split reductions / f32 atomics: the same operands in another order)
+            assert rel_err(a.float(), c.float()) < 1e-5, (nm, kern, rel_err(a.float(), c.float()))
+        else:
+            assert torch.equal(a, c), (nm, kern, rel_err(a.float(), c.float()))
+    # ... and against fp32 torch with the same mask
+    xf, rf = x0.float().requires_grad_(True), r0.float().requires_grad_(True)
+    Wf = (W0 if dtype == torch.float32 else W0.bfloat16().float()).clone().requires_grad_(True)
+    hf = (xf @ Wf.t() + b0) * mask + rf
+    yf = torch.nn.functional.layer_norm(hf, (N,), gam0, bet0, 1e-12)
+    yf.backward(gy.float())
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert rel_err(res[True][0].float(), hf.detach()) < tol and rel_err(res[True][1].float(), yf.detach()) < tol
+    assert rel_err(res[True][2].float(), xf.grad) < 2 * tol and rel_err(res[True][3].float(), rf.grad) < 2 * tol
+    assert rel_err(res[True][4].float(), Wf.grad) < 2 * tol
+
+
+@pytest.mark.parametrize("dtype,with_gate", [(torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)])
+def test_ffn_block_with_hidden_dropout_in_the_second_products_epilogue(dtype, with_gate):
+    """BertOutput inside ops.mlp: LayerNorm(dropout(gelu(x W1^T + b1) [.* z] W2^T + b2) + x) - fused (mask in the second
+    product's epilogue, masked gradient from the LayerNorm backward) against the separate-pass chain, bit for bit"""
+    from efficientvlm_amd import ops
+    from efficientvlm_amd._lib import ACT_GELU, GATE_POST
+    g = torch.Generator().manual_seed(3)
+    M, d, Fh, p = (24, 64, 128, 0.25) if dtype == torch.float32 else (3840, 768, 3072, 0.1)
+    x0 = (torch.randn(4, M // 4, d, generator=g) * 0.5).to(DEV, dtype)
+    w1, w2 = (torch.randn(Fh, d, generator=g) * 0.05).to(DEV), (torch.randn(d, Fh, generator=g) * 0.05).to(DEV)
+    b1, b2 = (torch.randn(Fh, generator=g) * 0.1).to(DEV), (torch.randn(d, generator=g) * 0.1).to(DEV)
+    z0 = torch.rand(Fh, generator=g).to(DEV) if with_gate else None
+    gam0, bet0 = (torch.rand(d, generator=g) + 0.5).to(DEV), (torch.randn(d, generator=g) * 0.1).to(DEV)
+    gy = torch.randn(4, M // 4, d, generator=g).to(DEV, dtype)
+    res = {}
+    for fused in (True, False):
+        ops.dropout_seed(5)
+        x = x0.clone().requires_grad_(True)
+        ps = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2, gam0, bet0)]
+        z = z0.clone().requires_grad_(True) if with_gate else None
+        if fused:
+            h = ops.mlp(x, ps[0], ps[1], ps[2], ps[3], ACT_GELU, gate=z, gate_pos=GATE_POST, residual=x, dropout_p=p)
+        else:
+            h = ops.dropout(ops.mlp(x, ps[0], ps[1], ps[2], ps[3], ACT_GELU, gate=z, gate_pos=GATE_POST), p, True, residual=x)
+        y = ops.layer_norm(h, ps[4], ps[5], 1e-12)
+        y.backward(gy)
+        res[fused] = [y.detach().clone(), x.grad.clone()] + [t.grad.clone() for t in ps] + ([z.grad.clone()] if with_gate else [])
+    for i, (a, c) in enumerate(zip(res[True], res[False])):
+        if i == 1 and dtype == torch.bfloat16:
+            # (dx: the fused form adds the residual's gradient in the dX product's epilogue, the chain lets autograd add two
+            # bf16 tensors - one rounding apart)
+            assert rel_err(a.float(), c.float()) < 1e-2, rel_err(a.float(), c.float())
+        elif i >= 1:                                     # (gradient sums: split reductions / f32 atomics, order-dependent)
+            assert rel_err(a.float(), c.float()) < 1e-5, (i, rel_err(a.float(), c.float()))
+        else:
+            assert torch.equal(a, c), (i, rel_err(a.float(), c.float()))
+
+
 def _models(p, seed=0):
     from efficientvlm_amd.models.model_pretrain import XVLM
     geom = synth.GEOMS["tiny"]
