@@ -96,6 +96,8 @@ SIGNATURES = {
     "evlm_ce_weighted_bwd": [_i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "evlm_kl_fwd": [_i, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
     "evlm_kl_bwd": [_i, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "evlm_kl_fwd_rows": [_i, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "evlm_kl_bwd_rows": [_i, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
     "evlm_log_softmax_fwd": [_i, _vp, _i, _i, _i, _vp, _i, _vp],
     "evlm_log_softmax_bwd": [_i, _vp, _vp, _i, _i, _i, _vp, _vp],
     "evlm_bert_embed_fwd": [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],

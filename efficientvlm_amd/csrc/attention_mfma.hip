@@ -1838,11 +1838,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
       const bool ok = qok && kcol < a.ldpr;
       // (K^T fragments of this tile pair through asm reads, requested here and consumed behind the softmax-backward
       // arithmetic below: the next block's DMA stays in flight through the whole block)
+      // (DROP: requested right in front of their wait instead - with the mask arithmetic in between the register allocator
+      // moved the loads' destinations before the wait, which tools/check_asm_loads.py rejects: an asm load's destination
+      // must not be touched before its explicit wait)
       bf16x8 kfr[4];
-      __builtin_amdgcn_sched_barrier(0);
+      if (!DROP) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) kfr[dt] = vcol_frag_a<SW_KV>(Ks, 2 * s2, 2 * s2 + 1, dt, lane);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int dt = 0; dt < 4; ++dt) kfr[dt] = vcol_frag_a<SW_KV>(Ks, 2 * s2, 2 * s2 + 1, dt, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       float pr[8], ptr[8];
       recompute_p<SW_KV>(Ks, Ms + blk * KB, qf, s2, g, lane, sc, lse_q, qok, 0, 0, pr);
       if (KDR) recompute_p<SW_K>(Kts, Ms + blk * KB, qt, s2, g, lane, sc, tl, qok, 0, 0, ptr);
@@ -1870,6 +1875,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
       if (ok) {
         *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
         if (a.Pw) *reinterpret_cast<bf16x8*>(a.Pw + prow + kcol) = p8o;
+      }
+      if (DROP) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) kfr[dt] = vcol_frag_a<SW_KV>(Ks, 2 * s2, 2 * s2 + 1, dt, lane);
       }
       TR_WAIT();
 #pragma unroll

@@ -91,26 +91,52 @@ extern "C" int evlm_mse_bwd(int dtype_a, const void* a, int dtype_b, const void*
 
 // ---- grouped MSE: every (student, teacher) pair of a distillation step in ONE launch per direction --------------------
 // A GD step holds ~40 pairs (hidden states and attention maps of GeneralDistill.py:300-366), most of them a few MB: 40
-// forward + 40 backward launches of 5-8 us each.  table: int64 [n][8] =
+// forward + 40 backward launches of 5-8 us each.  table: int64 [n][12] =
 //   {a, b, n (elements), first block of the unit, blocks of the unit, loss word (fwd) / gout word (bwd), grad_a (bwd),
-//    coef as f32 bits}   with coef = weight / n (fwd), 2 weight / n (bwd).
+//    coef as f32 bits, S, unit, ext, slots}   with coef = weight / n (fwd), 2 weight / n (bwd); S = 0: a plain unit, else
+//   a RAGGED one (below).
 // A block finds its unit with one vector load + ballot per 64 units (first blocks ascend), then runs the single-pair loop
 // on its share of the unit.
+#define MSE_UNIT 12       // int64 words per unit
 __device__ __forceinline__ int grouped_unit(const int64_t* __restrict__ table, int n_units) {
   const int lane = threadIdx.x & 63;
   int u = -1;
   for (int u0 = 0; u0 < n_units; u0 += 64) {
-    const bool le = u0 + lane < n_units && table[8 * (int64_t)(u0 + lane) + 3] <= (int64_t)blockIdx.x;
+    const bool le = u0 + lane < n_units && table[MSE_UNIT * (int64_t)(u0 + lane) + 3] <= (int64_t)blockIdx.x;
     const unsigned long long m = __ballot(le);
     if (!m) break;
     u = u0 + __popcll(m) - 1;
   }
   return __builtin_amdgcn_readfirstlane(u);
 }
+// ABI 9 - RAGGED units (bucket-padded batches: text padded to a few lengths, answer rows to a few counts, so that a captured
+// step replays whatever the batch's real extents are).  The operand is [outer][inner items][unit elements] with S = elements
+// per outer block; only outer < ext[outer slot] * mult and inner item < ext[inner slot] take part, ext being DEVICE int32
+// words refilled per batch (the captured launch never learns the real extents).  What lies beyond - the rows of padded
+// tokens / padded answer rows, which hold arbitrary values - adds nothing to the sum and receives a zero gradient.  S and
+// unit are multiples of 8, so a 16-byte chunk is valid or not as a whole.  (The mean's denominator stays the padded element
+// count baked into coef; the caller rescales the term by padded / real - distill.ragged_correction.)
+struct MseRag { int64_t S, lim_in, lim_out; };
+__device__ __forceinline__ MseRag mse_rag(const int64_t* e) {
+  MseRag r;
+  r.S = e[8];
+  if (r.S) {
+    const int32_t* ext = reinterpret_cast<const int32_t*>(e[10]);
+    const int si = (int)(e[11] & 0xFF), so = (int)((e[11] >> 8) & 0xFF);
+    const int64_t mult = e[11] >> 16;
+    r.lim_in = si == 0xFF ? r.S : (int64_t)ext[si] * e[9];
+    r.lim_out = so == 0xFF ? (int64_t)1 << 62 : (int64_t)ext[so] * mult;
+  }
+  return r;
+}
+__device__ __forceinline__ bool mse_valid(const MseRag& r, int64_t off) {
+  const int64_t o = off / r.S;
+  return o < r.lim_out && off - o * r.S < r.lim_in;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void mse_grouped_fwd_kernel(const int64_t* __restrict__ table, int n_units) {
   __shared__ float red[16];
-  const int64_t* e = table + 8 * (int64_t)grouped_unit(table, n_units);
+  const int64_t* e = table + MSE_UNIT * (int64_t)grouped_unit(table, n_units);
   const T* a = reinterpret_cast<const T*>(e[0]);
   const T* b = reinterpret_cast<const T*>(e[1]);
   const int64_t n = e[2], nv = n >> 3;
@@ -118,6 +144,17 @@ __global__ __launch_bounds__(256) void mse_grouped_fwd_kernel(const int64_t* __r
   const int64_t stride = e[4] * 256;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int64_t c = blk * 256 + threadIdx.x;
+  const MseRag rg = mse_rag(e);
+  if (rg.S) {                                   // (unit-uniform) ragged unit: chunk by chunk, the invalid ones skipped
+    for (; c < nv; c += stride) {
+      if (!mse_valid(rg, c * 8)) continue;
+      float x[8], y[8];
+      load8<T>(a + c * 8, x);
+      load8<T>(b + c * 8, y);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float d = x[k] - y[k]; s0 = fmaf(d, d, s0); }
+    }
+  }
   for (; c + 3 * stride < nv; c += 4 * stride) {
     float x0[8], y0[8], x1[8], y1[8], x2[8], y2[8], x3[8], y3[8];
     load8<T>(a + c * 8, x0); load8<T>(b + c * 8, y0);
@@ -138,29 +175,36 @@ __global__ __launch_bounds__(256) void mse_grouped_fwd_kernel(const int64_t* __r
     for (int k = 0; k < 8; ++k) { const float d = x[k] - y[k]; s0 = fmaf(d, d, s0); }
   }
   float s = (s0 + s1) + (s2 + s3);
-  if (blk == 0)
+  if (blk == 0 && !rg.S)
     for (int64_t i = (nv << 3) + threadIdx.x; i < n; i += 256) { const float d = to_f(a[i]) - to_f(b[i]); s = fmaf(d, d, s); }
   s = block_sum(s, red);
   if (threadIdx.x == 0) atomicAdd(reinterpret_cast<float*>(e[5]), s * __int_as_float((int)e[7]));
 }
 template <typename T>
 __global__ __launch_bounds__(256) void mse_grouped_bwd_kernel(const int64_t* __restrict__ table, int n_units) {
-  const int64_t* e = table + 8 * (int64_t)grouped_unit(table, n_units);
+  const int64_t* e = table + MSE_UNIT * (int64_t)grouped_unit(table, n_units);
   const T* a = reinterpret_cast<const T*>(e[0]);
   const T* b = reinterpret_cast<const T*>(e[1]);
   T* ga = reinterpret_cast<T*>(e[6]);
   const int64_t n = e[2], nv = n >> 3;
   const int blk = (int)(blockIdx.x - e[3]);
   const float c2 = __int_as_float((int)e[7]) * reinterpret_cast<const float*>(e[5])[0];
+  const MseRag rg = mse_rag(e);
   for (int64_t c = blk * 256 + threadIdx.x; c < nv; c += e[4] * 256) {
     float x[8], y[8];
+    if (rg.S && !mse_valid(rg, c * 8)) {        // beyond the real extents: a zero gradient (nothing is read)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = 0.f;
+      store8<T>(ga + c * 8, x);
+      continue;
+    }
     load8<T>(a + c * 8, x);
     load8<T>(b + c * 8, y);
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = c2 * (x[k] - y[k]);
     store8<T>(ga + c * 8, x);
   }
-  if (blk == 0)
+  if (blk == 0 && !rg.S)
     for (int64_t i = (nv << 3) + threadIdx.x; i < n; i += 256) ga[i] = from_f<T>(c2 * (to_f(a[i]) - to_f(b[i])));
 }
 extern "C" int evlm_mse_grouped(int dtype, int backward, const int64_t* table, int n_units, int total_blocks, void* stream_) {
@@ -327,12 +371,25 @@ extern "C" int evlm_ce_bwd(int dtype, const void* logits, int R, int C, int ld, 
 // ---------------------------------------------------------------------------------------------
 // KL(log_softmax(s*it) || softmax(t*it)), batchmean   (soft_cross_entropy, GeneralDistill.py:84-89)
 // ---------------------------------------------------------------------------------------------
+// ABI 9 - ragged rows (bucket-padded VQA batches: logits [answer rows][answer tokens][vocabulary]): row r = (o, i) with
+// i = r % row_inner takes part iff i < ext[inner slot] and o < ext[outer slot]; the others add nothing / get a zero gradient
+struct KlRows { const int32_t* ext; int inner, slots; };
+__device__ __forceinline__ bool kl_row_valid(const KlRows& rr, int r) {
+  if (!rr.ext) return true;
+  const int si = rr.slots & 0xFF, so = (rr.slots >> 8) & 0xFF;
+  const int o = r / rr.inner, i = r - o * rr.inner;
+  return (si == 0xFF || i < rr.ext[si]) && (so == 0xFF || o < rr.ext[so]);
+}
 template <typename TS, typename TT>
 __global__ __launch_bounds__(256) void kl_fwd_kernel(const TS* __restrict__ s, int lds_, const TT* __restrict__ t, int ldt,
                                                      int C, float it, float coef, float* __restrict__ lse_s,
-                                                     float* __restrict__ lse_t, float* __restrict__ loss) {
+                                                     float* __restrict__ lse_t, float* __restrict__ loss, KlRows rr) {
   __shared__ float red[16];
   const int r = blockIdx.x;
+  if (!kl_row_valid(rr, r)) {                    // (block-uniform)
+    if (threadIdx.x == 0) { lse_s[r] = 0.f; lse_t[r] = 0.f; }
+    return;
+  }
   const TS* sr = s + (size_t)r * lds_;
   const TT* tr = t + (size_t)r * ldt;
   const float ls = row_lse<TS>(sr, C, it, red);
@@ -364,11 +421,16 @@ template <typename TS, typename TT>
 __global__ __launch_bounds__(256) void kl_bwd_kernel(const TS* __restrict__ s, int lds_, const TT* __restrict__ t, int ldt,
                                                      int C, float it, float coef, const float* __restrict__ lse_s,
                                                      const float* __restrict__ lse_t, const float* __restrict__ gout,
-                                                     TS* __restrict__ ds, int ldds, int acc) {
+                                                     TS* __restrict__ ds, int ldds, int acc, KlRows rr) {
   const int r = blockIdx.x;
   const TS* sr = s + (size_t)r * lds_;
   const TT* tr = t + (size_t)r * ldt;
   TS* dr = ds + (size_t)r * ldds;
+  if (!kl_row_valid(rr, r)) {                    // a row beyond the real extents: zero gradient (left alone when accumulating)
+    if (!acc)
+      for (int c = threadIdx.x; c < ldds; c += blockDim.x) dr[c] = from_f<TS>(0.f);
+    return;
+  }
   const float g = gout[0] * coef * it, ls = lse_s[r], lt = lse_t[r];
   const bool vec = (((uintptr_t)sr | (uintptr_t)tr | (uintptr_t)dr) & 15) == 0;
   const int nv = vec ? (C >> 3) : 0;
@@ -389,26 +451,51 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(const TS* __restrict__ s, i
   for (int c = nv * 8 + threadIdx.x; c < (acc ? C : ldds); c += blockDim.x)     // (+ the padding columns: zeros, never filled by the caller)
     dr[c] = from_f<TS>((c < C ? g * (__expf(to_f(sr[c]) * it - ls) - __expf(to_f(tr[c]) * it - lt)) : 0.f) + (acc ? to_f(dr[c]) : 0.f));
 }
-extern "C" int evlm_kl_fwd(int dtype_s, const void* s, int lds_, int dtype_t, const void* t, int ldt, int R, int C,
-                           float inv_t, float weight, float* lse_s, float* lse_t, float* loss, void* stream_) {
+static int kl_fwd_impl(int dtype_s, const void* s, int lds_, int dtype_t, const void* t, int ldt, int R, int C,
+                       float inv_t, float weight, float* lse_s, float* lse_t, float* loss, KlRows rr, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   EVLM_REQUIRE(s && t && lse_s && lse_t && loss && R > 0 && C > 0, "evlm_kl_fwd: bad args");
   const float coef = weight / (float)R;
   DISPATCH2(dtype_s, dtype_t, "evlm_kl_fwd",
-    hipLaunchKernelGGL((kl_fwd_kernel<TA, TB>), dim3(R), dim3(256), 0, stream, (const TA*)s, lds_, (const TB*)t, ldt, C, inv_t, coef, lse_s, lse_t, loss);)
+    hipLaunchKernelGGL((kl_fwd_kernel<TA, TB>), dim3(R), dim3(256), 0, stream, (const TA*)s, lds_, (const TB*)t, ldt, C, inv_t, coef, lse_s, lse_t, loss, rr);)
   EVLM_LAUNCH_CHECK("evlm_kl_fwd");
+  return 0;
+}
+extern "C" int evlm_kl_fwd(int dtype_s, const void* s, int lds_, int dtype_t, const void* t, int ldt, int R, int C,
+                           float inv_t, float weight, float* lse_s, float* lse_t, float* loss, void* stream_) {
+  return kl_fwd_impl(dtype_s, s, lds_, dtype_t, t, ldt, R, C, inv_t, weight, lse_s, lse_t, loss, KlRows{nullptr, 1, 0xFFFF}, stream_);
+}
+extern "C" int evlm_kl_fwd_rows(int dtype_s, const void* s, int lds_, int dtype_t, const void* t, int ldt, int R, int C,
+                                float inv_t, float weight, float* lse_s, float* lse_t, float* loss, const int32_t* ext,
+                                int row_inner, int inner_slot, int outer_slot, void* stream_) {
+  EVLM_REQUIRE(ext && row_inner > 0 && R % row_inner == 0, "evlm_kl_fwd_rows: bad row extents");
+  return kl_fwd_impl(dtype_s, s, lds_, dtype_t, t, ldt, R, C, inv_t, weight, lse_s, lse_t, loss,
+                     KlRows{ext, row_inner, (inner_slot & 0xFF) | ((outer_slot & 0xFF) << 8)}, stream_);
+}
+static int kl_bwd_impl(int dtype_s, const void* s, int lds_, int dtype_t, const void* t, int ldt, int R, int C,
+                       float inv_t, float weight, const float* lse_s, const float* lse_t, const float* gout,
+                       void* ds, int ldds, int accumulate, KlRows rr, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  EVLM_REQUIRE(s && t && lse_s && lse_t && gout && ds, "evlm_kl_bwd: bad args");
+  const float coef = weight / (float)R;
+  DISPATCH2(dtype_s, dtype_t, "evlm_kl_bwd",
+    hipLaunchKernelGGL((kl_bwd_kernel<TA, TB>), dim3(R), dim3(256), 0, stream, (const TA*)s, lds_, (const TB*)t, ldt, C, inv_t, coef, lse_s, lse_t, gout, (TA*)ds, ldds, accumulate, rr);)
+  EVLM_LAUNCH_CHECK("evlm_kl_bwd");
   return 0;
 }
 extern "C" int evlm_kl_bwd(int dtype_s, const void* s, int lds_, int dtype_t, const void* t, int ldt, int R, int C,
                            float inv_t, float weight, const float* lse_s, const float* lse_t, const float* gout,
                            void* ds, int ldds, int accumulate, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  EVLM_REQUIRE(s && t && lse_s && lse_t && gout && ds, "evlm_kl_bwd: bad args");
-  const float coef = weight / (float)R;
-  DISPATCH2(dtype_s, dtype_t, "evlm_kl_bwd",
-    hipLaunchKernelGGL((kl_bwd_kernel<TA, TB>), dim3(R), dim3(256), 0, stream, (const TA*)s, lds_, (const TB*)t, ldt, C, inv_t, coef, lse_s, lse_t, gout, (TA*)ds, ldds, accumulate);)
-  EVLM_LAUNCH_CHECK("evlm_kl_bwd");
-  return 0;
+  return kl_bwd_impl(dtype_s, s, lds_, dtype_t, t, ldt, R, C, inv_t, weight, lse_s, lse_t, gout, ds, ldds, accumulate,
+                     KlRows{nullptr, 1, 0xFFFF}, stream_);
+}
+extern "C" int evlm_kl_bwd_rows(int dtype_s, const void* s, int lds_, int dtype_t, const void* t, int ldt, int R, int C,
+                                float inv_t, float weight, const float* lse_s, const float* lse_t, const float* gout,
+                                void* ds, int ldds, int accumulate, const int32_t* ext, int row_inner, int inner_slot,
+                                int outer_slot, void* stream_) {
+  EVLM_REQUIRE(ext && row_inner > 0 && R % row_inner == 0, "evlm_kl_bwd_rows: bad row extents");
+  return kl_bwd_impl(dtype_s, s, lds_, dtype_t, t, ldt, R, C, inv_t, weight, lse_s, lse_t, gout, ds, ldds, accumulate,
+                     KlRows{ext, row_inner, (inner_slot & 0xFF) | ((outer_slot & 0xFF) << 8)}, stream_);
 }
 
 // ---------------------------------------------------------------------------------------------

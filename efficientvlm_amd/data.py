@@ -12,6 +12,7 @@ import random
 import re
 
 import torch
+import torch.nn.functional as F
 
 PAD_MASK = -100          # label of an unused mask slot (ignored by the MLM cross entropy)
 
@@ -129,3 +130,76 @@ class MLMBatcher:
 
     def __call__(self, captions):
         return self.collate([self.preprocess(c) for c in captions])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Bucket padding for the fine-tune steps (round 6).  The reference tokenises a batch with padding='longest'
+# (Eff_Retrieval.py:97, Eff_VQA.py:97-98) and a VQA batch carries a variable number of answers per question
+# (dataset/vqa_dataset.py:101-116), so nearly every batch of an epoch has its own shape - and a captured step (hipGraph)
+# its own graph.  Here a batch is padded on to one of a FEW shapes: text to the next length of a short ladder, answer rows
+# to the next multiple of a block.  The step's arithmetic stays that of the 'longest'-padded batch:
+#   * padded tokens are padding tokens (id pad, attention mask 0): as keys they get the -10000 mask, i.e. probability 0;
+#   * a padded answer row has weight 0 (no LM loss), the pad id throughout (labels -100) and attends to the last question;
+#   * the rows such tokens / answers occupy as QUERIES hold arbitrary values - the distillation terms skip them in their
+#     kernels (`extents`: device int32 words with the REAL extents, ops.Ragged) and are rescaled from the padded to the real
+#     denominator (`kd_corr`: padded / real element counts, distill.*_loss_mix).
+# Both vectors travel inside the batch dict, so a teacher prefetch copies them into its static buffers like any tensor.
+# ---------------------------------------------------------------------------------------------------------------------
+TEXT_BUCKETS = (16, 24, 32, 40, 48, 64)
+# VQA shapes are a product (question length x answer length x answer rows): coarser ladders keep the number of captured
+# kinds small - the text side of a 480 x 480 step is a few per cent of its work, padding it costs little
+QUESTION_BUCKETS = (16, 32, 48, 64)
+ANSWER_TOKEN_BUCKETS = (8, 16, 32)
+ANSWER_ROW_BLOCK = 128
+
+
+def _bucket(n, ladder):
+    for b in ladder:
+        if n <= b:
+            return b
+    return (n + 7) // 8 * 8                     # beyond the ladder: the next multiple of 8 (a shape of its own)
+
+
+def _pad_cols(t, width, value):
+    return t if t.shape[1] == width else F.pad(t, (0, width - t.shape[1]), value=value)
+
+
+def bucket_pad_itr(batch, buckets=TEXT_BUCKETS, pad_token_id=0):
+    """batch: dict(image, text_ids [B, L], text_atts [B, L] [, idx]) as Eff_Retrieval.py:97-101 builds it -> the same batch
+    with the text padded to the next bucket length, plus extents = int32 [L, 0, 0, 0] and kd_corr = f32 [L' / L, 1]"""
+    L = int(batch["text_ids"].shape[1])
+    Lp = _bucket(L, buckets)
+    out = dict(batch)
+    out["text_ids"] = _pad_cols(batch["text_ids"], Lp, pad_token_id)
+    out["text_atts"] = _pad_cols(batch["text_atts"], Lp, 0)
+    dev = batch["text_ids"].device
+    out["extents"] = torch.tensor([L, 0, 0, 0], dtype=torch.int32, device=dev)
+    out["kd_corr"] = torch.tensor([Lp / L, 1.0], dtype=torch.float32, device=dev)
+    return out
+
+
+def bucket_pad_vqa(batch, question_buckets=QUESTION_BUCKETS, answer_buckets=ANSWER_TOKEN_BUCKETS, row_block=ANSWER_ROW_BLOCK,
+                   pad_token_id=0):
+    """batch: dict(image, question_ids / question_atts [B, Lq], answer_ids / answer_atts [R, La], k [B], weights [R]) as
+    Eff_VQA.py:92-103 builds it (R = sum k) -> question and answer tokens padded to their bucket lengths, the answer rows
+    to the next multiple of `row_block` (weight 0, all-pad rows credited to the LAST question: k[-1] grows), plus
+    extents = int32 [Lq, La, R, 0] and kd_corr = f32 [Lq' / Lq, (R' La') / (R La)]"""
+    Lq, (R, La) = int(batch["question_ids"].shape[1]), (int(v) for v in batch["answer_ids"].shape)
+    Lqp, Lap = _bucket(Lq, question_buckets), _bucket(La, answer_buckets)
+    Rp = (R + row_block - 1) // row_block * row_block
+    out = dict(batch)
+    out["question_ids"] = _pad_cols(batch["question_ids"], Lqp, pad_token_id)
+    out["question_atts"] = _pad_cols(batch["question_atts"], Lqp, 0)
+    ids, atts = _pad_cols(batch["answer_ids"], Lap, pad_token_id), _pad_cols(batch["answer_atts"], Lap, 0)
+    w = batch["weights"]
+    k = torch.as_tensor(batch["k"]).clone()
+    if Rp != R:
+        ids = F.pad(ids, (0, 0, 0, Rp - R), value=pad_token_id)
+        atts = F.pad(atts, (0, 0, 0, Rp - R), value=0)
+        w = F.pad(w, (0, Rp - R), value=0.0)
+        k[-1] += Rp - R
+    out.update(answer_ids=ids, answer_atts=atts, weights=w, k=k)
+    dev = batch["question_ids"].device
+    out["extents"] = torch.tensor([Lq, La, R, 0], dtype=torch.int32, device=dev)
+    out["kd_corr"] = torch.tensor([Lqp / Lq, (Rp * Lap) / (R * La)], dtype=torch.float32, device=dev)
+    return out

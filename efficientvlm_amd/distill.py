@@ -44,15 +44,26 @@ def get_kd_loss(student_reps=None, teacher_reps=None, is_attn=False, loss=None, 
     return ops.mse_sum(pairs, weights) if pairs else 0
 
 
-def soft_cross_entropy(predicts, targets, temperature=1.0):
+def soft_cross_entropy(predicts, targets, temperature=1.0, ragged=None):
     """GeneralDistill.py:84-89; callers that pre-divide by T (as the reference does) pass temperature=1."""
-    return ops.soft_cross_entropy(predicts, targets, temperature)
+    return ops.soft_cross_entropy(predicts, targets, temperature, ragged=ragged)
 
 
-def kd_terms(S, T, temperature=1.0, with_cross_attn=False, fused=None, side=None):
+def batch_ragged(batch):
+    """ops.Ragged views of a bucket-padded batch's real extents (data.bucket_pad_itr / bucket_pad_vqa: batch['extents'] =
+    device int32 [text or question tokens, answer tokens, answer rows, 0]) -> (text / question side, decoder side), or
+    (None, None) for a batch in the reference's own 'longest' padding"""
+    ext = batch.get("extents") if isinstance(batch, dict) else None
+    if ext is None:
+        return None, None
+    return ops.Ragged(ext, inner=0), ops.Ragged(ext, inner=1, outer=2)
+
+
+def kd_terms(S, T, temperature=1.0, with_cross_attn=False, fused=None, side=None, ragged=None):
     """the per-pair KD scalars of GeneralDistill.py:300-366 (+ cross-attention maps, Eff_Retrieval.py:141-159).
     fused: {term name: scalar} of terms the attention kernels already produced (fuse_image_map_kd) - same arithmetic,
-    no separate pass over the maps."""
+    no separate pass over the maps.  ragged (ops.Ragged): the text of the batch is bucket-padded - the text-side terms skip
+    the token rows beyond the real length in their kernels (their means keep the padded denominators: *_loss_mix rescales)."""
     sh, th, sa, ta = S["hidden_dict"], T["hidden_dict"], S["attention_dict"], T["attention_dict"]
     out = {}
     fused = fused or {}
@@ -63,16 +74,17 @@ def kd_terms(S, T, temperature=1.0, with_cross_attn=False, fused=None, side=None
     s_list = lambda d, key: rows[key] if (key in rows and all(x is not None for x in rows[key])) else d[key]
 
     def pair(name, hkey, akey, is_img=False):
+        rag = None if is_img else ragged           # (image tokens are never padded)
         if name + "_hidden" in fused:
             out[name + "_hidden"] = fused[name + "_hidden"]
         else:
             names.append(name + "_hidden")
-            terms.append(_kd_pairs(s_list(sh, hkey), get_cor_teacher(th[hkey], sh[hkey]), is_img=is_img))
+            terms.append(_kd_pairs(s_list(sh, hkey), get_cor_teacher(th[hkey], sh[hkey]), is_img=is_img) + (rag,))
         if name + "_attn" in fused:
             out[name + "_attn"] = fused[name + "_attn"]
         else:
             names.append(name + "_attn")
-            terms.append(_kd_pairs(s_list(sa, akey), get_cor_teacher(ta[akey], sa[akey], True), is_attn=True))
+            terms.append(_kd_pairs(s_list(sa, akey), get_cor_teacher(ta[akey], sa[akey], True), is_attn=True) + (rag,))
 
     pair("text", "text_hidden_states", "text_attentions")
     pair("image", "image_hidden_states", "image_attentions", is_img=True)
@@ -87,7 +99,7 @@ def kd_terms(S, T, temperature=1.0, with_cross_attn=False, fused=None, side=None
         for nm in ("itm_pos", "itm_neg"):
             k = nm + "_cross_attentions"
             names.append(nm + "_cross")
-            terms.append(_kd_pairs(s_list(sc, k), get_cor_teacher(tc[k], sc[k], True), is_attn=True))
+            terms.append(_kd_pairs(s_list(sc, k), get_cor_teacher(tc[k], sc[k], True), is_attn=True) + (ragged,))
     if side is not None:
         # side = (stream, event recorded behind the student's fusion pass): the grouped MSE forward - and, since autograd
         # runs a node on its forward's stream, its backward - runs beside the task heads (MLM decoder product, the CEs)
@@ -144,48 +156,66 @@ def gd_loss_mix(loss, kd):
     return total, dict(loss_small=rep[0], loss_text_kd=rep[1], loss_img_kd=rep[2], loss_cross_kd=rep[3], loss_kd=rep[4])
 
 
-def itr_loss_mix(loss, kd, lagrangian):
-    """Eff_Retrieval.py:165-178"""
+def itr_loss_mix(loss, kd, lagrangian, kd_corr=None):
+    """Eff_Retrieval.py:165-178.  kd_corr (device f32 [2], a bucket-padded batch: data.bucket_pad_itr): every text-side term
+    is a mean over [.., text tokens, ..] whose kernels summed the REAL token rows but divided by the padded count (and took
+    the padded key count as the map terms' weight) - all of them are off by the one factor kd_corr[0] = padded / real length"""
     loss_text_kd = kd["text_hidden"] + kd["text_attn"]
     loss_img_kd = 0.2 * kd["image_hidden"] + kd["image_attn"]
     loss_cross_kd = (kd["itm_neg_hidden"] + kd["itm_pos_hidden"] + kd["itm_pos_attn"] + kd["itm_pos_cross"]
                      + kd["itm_neg_attn"] + kd["itm_neg_cross"]) * 0.5
+    if kd_corr is not None:
+        loss_text_kd, loss_cross_kd = loss_text_kd * kd_corr[0], loss_cross_kd * kd_corr[0]
     loss_kd = kd["itm_logits"] + (loss_text_kd + loss_img_kd + loss_cross_kd) * 0.33
     loss_small = loss["loss_itc"] + loss["loss_itm"]
     return (loss_kd + loss_small) * 0.5 + lagrangian, dict(loss_text_kd=loss_text_kd, loss_img_kd=loss_img_kd,
                                                            loss_cross_kd=loss_cross_kd, loss_kd=loss_kd)
 
 
-def vqa_kd_terms(S, T, temperature=1.0, fused=None):
+def vqa_kd_terms(S, T, temperature=1.0, fused=None, ragged=(None, None)):
     """Eff_VQA.py:113-163.  The split of the question encoder's lists at state 4 / map 3 is hard-coded there for the
     (3 text + 3 fusion)-layer student; the decoder-hidden term passes is_img=True (skip of list index 6: a no-op on the
-    student's 4 decoder states)."""
+    student's 4 decoder states).  Round 6: every MSE term of the step in ONE grouped launch each way (ops.mse_terms; they
+    were ten launch chains); ragged = (question side, decoder side) ops.Ragged of a bucket-padded batch (batch_ragged)."""
     sh, th, sa, ta = S["hidden_dict"], T["hidden_dict"], S["attention_dict"], T["attention_dict"]
     sc, tc = S["cross_attention_dict"], T["cross_attention_dict"]
     s_h, s_a = sh["text_hidden_states"], sa["text_attentions"]
     t_h, t_a = get_cor_teacher(th["text_hidden_states"], s_h), get_cor_teacher(ta["text_attentions"], s_a, True)
     cor = lambda d_t, d_s, key, attn: get_cor_teacher(d_t[key], d_s[key], attn)
-    return {
-        "text_hidden": get_kd_loss(s_h[:4], t_h[:4]), "text_attn": get_kd_loss(s_a[:3], t_a[:3], is_attn=True),
-        "cross_hidden": get_kd_loss(s_h[4:], t_h[4:]), "cross_self_attn": get_kd_loss(s_a[3:], t_a[3:], is_attn=True),
-        "cross_attn": get_kd_loss(sc["cross_attentions"], cor(tc, sc, "cross_attentions", True), is_attn=True),
-        "image_hidden": (fused["image_hidden"] if fused and "image_hidden" in fused else
-                         get_kd_loss(sh["image_hidden_states"], cor(th, sh, "image_hidden_states", False), is_img=True)),
-        "image_attn": (fused["image_attn"] if fused and "image_attn" in fused else
-                       get_kd_loss(sa["image_attentions"], cor(ta, sa, "image_attentions", True), is_attn=True)),
-        "decoder_hidden": get_kd_loss(sh["decoder_hidden_states"], cor(th, sh, "decoder_hidden_states", False), is_img=True),
-        "decoder_attn": get_kd_loss(sa["decoder_attentions"], cor(ta, sa, "decoder_attentions", True), is_attn=True),
-        "decoder_cross": get_kd_loss(sc["decoder_cross_attentions"], cor(tc, sc, "decoder_cross_attentions", True), is_attn=True),
-        "logits": soft_cross_entropy(S["logits_dict"]["logits"], T["logits_dict"]["logits"], temperature)}
+    rq, rd = ragged
+    fused = fused or {}
+    spec = [("text_hidden", _kd_pairs(s_h[:4], t_h[:4]), rq), ("text_attn", _kd_pairs(s_a[:3], t_a[:3], is_attn=True), rq),
+            ("cross_hidden", _kd_pairs(s_h[4:], t_h[4:]), rq), ("cross_self_attn", _kd_pairs(s_a[3:], t_a[3:], is_attn=True), rq),
+            ("cross_attn", _kd_pairs(sc["cross_attentions"], cor(tc, sc, "cross_attentions", True), is_attn=True), rq)]
+    if "image_hidden" not in fused:
+        spec.append(("image_hidden", _kd_pairs(sh["image_hidden_states"], cor(th, sh, "image_hidden_states", False), is_img=True), None))
+    if "image_attn" not in fused:
+        spec.append(("image_attn", _kd_pairs(sa["image_attentions"], cor(ta, sa, "image_attentions", True), is_attn=True), None))
+    spec += [("decoder_hidden", _kd_pairs(sh["decoder_hidden_states"], cor(th, sh, "decoder_hidden_states", False), is_img=True), rd),
+             ("decoder_attn", _kd_pairs(sa["decoder_attentions"], cor(ta, sa, "decoder_attentions", True), is_attn=True), rd),
+             ("decoder_cross", _kd_pairs(sc["decoder_cross_attentions"], cor(tc, sc, "decoder_cross_attentions", True), is_attn=True), rd)]
+    values = ops.mse_terms([pw + (rag,) for _, pw, rag in spec])
+    out = {name: v for (name, _, _), v in zip(spec, values)}
+    for k in ("image_hidden", "image_attn"):
+        if k in fused:
+            out[k] = fused[k]
+    out["logits"] = soft_cross_entropy(S["logits_dict"]["logits"], T["logits_dict"]["logits"], temperature, ragged=rd)
+    return out
 
 
-def vqa_loss_mix(loss_small, kd, lagrangian):
-    """Eff_VQA.py:165-176"""
+def vqa_loss_mix(loss_small, kd, lagrangian, kd_corr=None):
+    """Eff_VQA.py:165-176.  kd_corr (device f32 [2], a bucket-padded batch: data.bucket_pad_vqa): the question-side terms
+    are rescaled by kd_corr[0] = padded / real question length, the decoder-side terms and the logit term by kd_corr[1] =
+    (padded rows x padded answer tokens) / (real rows x real tokens) - see itr_loss_mix"""
     loss_text_kd = kd["text_attn"] + kd["text_hidden"]
     loss_img_kd = kd["image_attn"] + kd["image_hidden"] * 0.2
     loss_cross_kd = (kd["cross_hidden"] + kd["cross_self_attn"] + kd["cross_attn"]) * 0.5
     loss_decoder_kd = kd["decoder_attn"] + kd["decoder_hidden"] + kd["decoder_cross"]
-    loss_kd = kd["logits"] + loss_text_kd + loss_img_kd + loss_cross_kd + loss_decoder_kd
+    logits_kd = kd["logits"]
+    if kd_corr is not None:
+        loss_text_kd, loss_cross_kd = loss_text_kd * kd_corr[0], loss_cross_kd * kd_corr[0]
+        loss_decoder_kd, logits_kd = loss_decoder_kd * kd_corr[1], logits_kd * kd_corr[1]
+    loss_kd = logits_kd + loss_text_kd + loss_img_kd + loss_cross_kd + loss_decoder_kd
     return loss_kd * 0.4 + loss_small * 0.6 + lagrangian, dict(loss_text_kd=loss_text_kd, loss_img_kd=loss_img_kd,
                                                               loss_cross_kd=loss_cross_kd, loss_decoder_kd=loss_decoder_kd,
                                                               loss_kd=loss_kd)

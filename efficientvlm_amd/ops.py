@@ -2062,6 +2062,33 @@ class RowSlice:
         return self.full[self.r0:self.r1]
 
 
+class Ragged:
+    """Real extents of a bucket-padded distillation operand (mse_terms): `ext` = device int32 words refilled per batch,
+    `inner` = index of the word holding the real length of the operand's second-to-last dimension (the token axis of
+    [.., L, d] states and of [.., H, L, Lk] maps), `outer` = index of the word holding the real length of its FIRST dimension
+    (answer rows), either may be None.  The kernels skip what lies beyond (evlm_mse_grouped, ragged units); the mean's
+    denominator stays the padded one - distill.ragged_correction rescales the term."""
+
+    def __init__(self, ext, inner=None, outer=None):
+        self.ext, self.inner, self.outer = ext, inner, outer
+
+
+def _rag_words(rag, abuf):
+    """words 8..11 of a grouped-MSE unit for operand buffer `abuf` ([outer.., inner items, unit])"""
+    if rag is None or (rag.inner is None and rag.outer is None):
+        return [0, 0, 0, 0]
+    unit, items = int(abuf.shape[-1]), int(abuf.shape[-2])
+    S = unit * items
+    mult = 1
+    for v in abuf.shape[1:-2]:
+        mult *= int(v)
+    if unit % 8 or rag.ext.dtype != torch.int32 or not rag.ext.is_cuda:
+        raise RuntimeError("ragged distillation operand: rows must be multiples of 8 elements, extents device int32 words")
+    si = 0xFF if rag.inner is None else int(rag.inner)
+    so = 0xFF if rag.outer is None else int(rag.outer)
+    return [S, unit, rag.ext.data_ptr(), si | (so << 8) | (mult << 16)]
+
+
 def _mse_operand(x):
     """(buffer, padded?) the kernels sweep for x: the row-padded base of a map view, or x made contiguous"""
     base = _padded_base(x)
@@ -2072,8 +2099,8 @@ def _mse_operand(x):
 
 class _MSETerms(torch.autograd.Function):
     """T distillation terms, term t = sum over its pairs of weight * mean((a - b)^2), in ONE launch per direction
-    (evlm_mse_grouped).  spec: per pair (term, weight, index of its `a` tensor, r0, r1); tensors: the distinct a's, then one
-    b per pair.  Returns T scalars; each a receives ONE gradient buffer (rows no term covers are zero)."""
+    (evlm_mse_grouped).  spec: per pair (term, weight, index of its `a` tensor, r0, r1, Ragged | None); tensors: the distinct
+    a's, then one b per pair.  Returns T scalars; each a receives ONE gradient buffer (rows no term covers are zero)."""
 
     @staticmethod
     def forward(ctx, spec, n_terms, n_a, *tensors):
@@ -2081,7 +2108,7 @@ class _MSETerms(torch.autograd.Function):
         outs = [zero_scalar(dev) for _ in range(n_terms)]
         A = [_mse_operand(t) for t in tensors[:n_a]]
         saved, meta, rows, blocks = [a for a, _ in A], [], [], 0
-        for i, (term, weight, ai, r0, r1) in enumerate(spec):
+        for i, (term, weight, ai, r0, r1, rag) in enumerate(spec):
             abuf, padded = A[ai]
             full = tensors[ai]
             b = tensors[n_a + i]
@@ -2094,10 +2121,10 @@ class _MSETerms(torch.autograd.Function):
             w = weight * (ne / n_true)
             nb = max(1, min(256, (ne // 8 + 1023) // 1024))      # (each block ends in one atomic on the term word)
             rows += [abuf.data_ptr() + r0 * per_row * abuf.element_size(), bbuf.data_ptr(), ne, blocks, nb,
-                     outs[term].data_ptr(), 0, _f32_bits(w / ne)]
+                     outs[term].data_ptr(), 0, _f32_bits(w / ne)] + _rag_words(rag, abuf)
             blocks += nb
             saved.append(bbuf)
-            meta.append((term, w, ai, r0, r1))
+            meta.append((term, w, ai, r0, r1, rag))
         table = _upload_table(rows, dev)
         L.check(_lib().evlm_mse_grouped(L.dt(saved[0].dtype), 0, L.ptr(table), len(spec), blocks, L.stream()), "mse_grouped")
         ctx.save_for_backward(*saved)
@@ -2111,7 +2138,7 @@ class _MSETerms(torch.autograd.Function):
         n_a = ctx.n_a
         abufs, bbufs = ctx.saved_tensors[:n_a], ctx.saved_tensors[n_a:]
         live = [[] for _ in range(n_a)]                       # per a: the pairs whose term received a gradient
-        for i, (term, w, ai, r0, r1) in enumerate(ctx.meta):
+        for i, (term, w, ai, r0, r1, _rag) in enumerate(ctx.meta):
             if gs[term] is not None and ctx.needs_input_grad[3 + ai]:
                 live[ai].append(i)
         grads, rows, blocks, units, keep = [None] * n_a, [], 0, 0, []
@@ -2129,7 +2156,7 @@ class _MSETerms(torch.autograd.Function):
             ga = torch.empty_like(abuf) if (full_cover and end == abuf.shape[0]) else torch.zeros_like(abuf)
             per_row = abuf[0].numel()
             for i in live[ai]:
-                term, w, _, r0, r1 = ctx.meta[i]
+                term, w, _, r0, r1, rag = ctx.meta[i]
                 g = gs[term]
                 if g.dtype != torch.float32 or not g.is_contiguous():
                     g = g.to(torch.float32).contiguous()
@@ -2138,7 +2165,7 @@ class _MSETerms(torch.autograd.Function):
                 off = r0 * per_row * abuf.element_size()
                 nb = max(1, min(2048, (ne // 8 + 255) // 256))
                 rows += [abuf.data_ptr() + off, bbufs[i].data_ptr(), ne, blocks, nb, g.data_ptr(), ga.data_ptr() + off,
-                         _f32_bits(2.0 * w / ne)]
+                         _f32_bits(2.0 * w / ne)] + _rag_words(rag, abuf)
                 blocks += nb
                 units += 1
             padded, shape = ctx.a_info[ai]
@@ -2150,27 +2177,31 @@ class _MSETerms(torch.autograd.Function):
 
 
 def mse_terms(terms):
-    """terms: [(pairs, weights)] with pairs = [(a, b)]; returns the list of scalars  sum_i weights_i * mse(a_i, b_i), one per
-    term (0 for an empty term).  An `a` may be a RowSlice of a larger tensor.  All pairs of all terms run in one launch
-    forward and one backward when they share a dtype (bf16 or f32); gradient flows to the a's only."""
-    flat = [(t, a, b.detach(), 1.0 if weights is None else float(weights[i]))
-            for t, (pairs, weights) in enumerate(terms) for i, (a, b) in enumerate(pairs)]
+    """terms: [(pairs, weights [, Ragged])] with pairs = [(a, b)]; returns the list of scalars  sum_i weights_i * mse(a_i, b_i),
+    one per term (0 for an empty term).  An `a` may be a RowSlice of a larger tensor; a term's Ragged names the real extents
+    of its (bucket-padded) operands.  All pairs of all terms run in one launch forward and one backward when they share a
+    dtype (bf16 or f32); gradient flows to the a's only."""
+    terms = [tuple(t) + (None,) * (3 - len(t)) for t in terms]
+    flat = [(t, a, b.detach(), 1.0 if weights is None else float(weights[i]), rag)
+            for t, (pairs, weights, rag) in enumerate(terms) for i, (a, b) in enumerate(pairs)]
     if not flat:
         return [0 for _ in terms]
-    dts = {a.dtype for _, a, _, _ in flat} | {b.dtype for _, _, b, _ in flat}
+    dts = {a.dtype for _, a, _, _, _ in flat} | {b.dtype for _, _, b, _, _ in flat}
     if len(dts) != 1 or next(iter(dts)) not in (torch.bfloat16, torch.float32):
+        if any(rag is not None for _, _, _, _, rag in flat):
+            raise RuntimeError("ragged distillation terms need operands of one dtype (bf16 or f32)")
         plain = lambda a: a.tensor() if isinstance(a, RowSlice) else a
-        return [mse_sum([(plain(a), b) for a, b in pairs], weights) if pairs else 0 for pairs, weights in terms]
+        return [mse_sum([(plain(a), b) for a, b in pairs], weights) if pairs else 0 for pairs, weights, _ in terms]
     fulls, index, spec, Bt = [], {}, [], []
-    for t, a, b, w in flat:
+    for t, a, b, w, rag in flat:
         full, r0, r1 = (a.full, a.r0, a.r1) if isinstance(a, RowSlice) else (a, 0, a.shape[0])
         ai = index.setdefault(id(full), len(fulls))
         if ai == len(fulls):
             fulls.append(full)
-        spec.append((t, w, ai, r0, r1))
+        spec.append((t, w, ai, r0, r1, rag))
         Bt.append(b)
     outs = _MSETerms.apply(spec, len(terms), len(fulls), *fulls, *Bt)
-    used = {t for t, _, _, _ in flat}
+    used = {t for t, _, _, _, _ in flat}
     return [outs[t] if t in used else 0 for t in range(len(terms))]
 
 
@@ -2320,7 +2351,7 @@ class _KL(torch.autograd.Function):
     """soft_cross_entropy(predicts, targets): KLDiv(log_softmax(s*inv_t), softmax(t*inv_t), batchmean)"""
 
     @staticmethod
-    def forward(ctx, s, t, inv_t):
+    def forward(ctx, s, t, inv_t, rag=None):
         L.require_cuda(s, t)
         s2, R, Cn, lds = _rows2d(s)
         t2, Rt, Ct, ldt = _rows2d(t)
@@ -2328,8 +2359,19 @@ class _KL(torch.autograd.Function):
         out = zero_scalar(s.device)
         ls = torch.empty(R, dtype=torch.float32, device=s.device)
         lt = torch.empty(R, dtype=torch.float32, device=s.device)
-        L.check(_lib().evlm_kl_fwd(L.dt(s2), L.ptr(s2), lds, L.dt(t2), L.ptr(t2), ldt, R, Cn, inv_t, 1.0, L.ptr(ls), L.ptr(lt),
-                                   L.ptr(out), L.stream()), "kl_fwd")
+        ctx.rag = None
+        if rag is not None and (rag.inner is not None or rag.outer is not None):
+            # ragged rows (bucket-padded batches): s is [outer, inner, C]; rows beyond the real extents take no part
+            if s.dim() != 3:
+                raise RuntimeError("ragged soft_cross_entropy: logits must be [rows, tokens, classes]")
+            ctx.rag = (rag.ext, int(s.shape[1]), 0xFF if rag.inner is None else int(rag.inner),
+                       0xFF if rag.outer is None else int(rag.outer))
+            L.check(_lib().evlm_kl_fwd_rows(L.dt(s2), L.ptr(s2), lds, L.dt(t2), L.ptr(t2), ldt, R, Cn, inv_t, 1.0, L.ptr(ls),
+                                            L.ptr(lt), L.ptr(out), L.ptr(ctx.rag[0]), ctx.rag[1], ctx.rag[2], ctx.rag[3],
+                                            L.stream()), "kl_fwd_rows")
+        else:
+            L.check(_lib().evlm_kl_fwd(L.dt(s2), L.ptr(s2), lds, L.dt(t2), L.ptr(t2), ldt, R, Cn, inv_t, 1.0, L.ptr(ls), L.ptr(lt),
+                                       L.ptr(out), L.stream()), "kl_fwd")
         ctx.save_for_backward(s2, t2, ls, lt)
         ctx.meta = (R, Cn, lds, ldt, inv_t, s.shape)
         ctx.join = getattr(s, "_evlm_join", None)
@@ -2343,21 +2385,28 @@ class _KL(torch.autograd.Function):
         ldd = _pad8(Cn)
         acc, join = _join_target(ctx, R, ldd, s2.dtype)
         ds = acc if acc is not None else torch.empty((R, ldd), dtype=s2.dtype, device=s2.device)      # (padding columns: zeroed by the kernel)
-        L.check(_lib().evlm_kl_bwd(L.dt(s2), L.ptr(s2), lds, L.dt(t2), L.ptr(t2), ldt, R, Cn, inv_t, 1.0, L.ptr(ls), L.ptr(lt),
-                                   L.ptr(gc), L.ptr(ds), ldd, int(acc is not None), L.stream()), "kl_bwd")
+        if ctx.rag is not None:
+            L.check(_lib().evlm_kl_bwd_rows(L.dt(s2), L.ptr(s2), lds, L.dt(t2), L.ptr(t2), ldt, R, Cn, inv_t, 1.0, L.ptr(ls),
+                                            L.ptr(lt), L.ptr(gc), L.ptr(ds), ldd, int(acc is not None), L.ptr(ctx.rag[0]),
+                                            ctx.rag[1], ctx.rag[2], ctx.rag[3], L.stream()), "kl_bwd_rows")
+        else:
+            L.check(_lib().evlm_kl_bwd(L.dt(s2), L.ptr(s2), lds, L.dt(t2), L.ptr(t2), ldt, R, Cn, inv_t, 1.0, L.ptr(ls), L.ptr(lt),
+                                       L.ptr(gc), L.ptr(ds), ldd, int(acc is not None), L.stream()), "kl_bwd")
         if acc is not None:
-            return None, None, None
+            return None, None, None, None
         d = ds[:, :Cn] if ldd != Cn else ds
         if len(shape) > 2:
             d = d.unflatten(0, shape[:-1])
         if join is not None:
             join.buf = (d, ds)
-            return None, None, None
-        return d, None, None
+            return None, None, None, None
+        return d, None, None, None
 
 
-def soft_cross_entropy(predicts, targets, temperature=1.0):
-    return _KL.apply(predicts, targets.detach(), 1.0 / float(temperature))
+def soft_cross_entropy(predicts, targets, temperature=1.0, ragged=None):
+    """ragged (ops.Ragged): the logits are [rows, tokens, classes] of a bucket-padded batch - rows / tokens beyond the real
+    extents take no part (the mean keeps the padded count: the caller rescales)"""
+    return _KL.apply(predicts, targets.detach(), 1.0 / float(temperature), ragged)
 
 
 class _LogSoftmax(torch.autograd.Function):

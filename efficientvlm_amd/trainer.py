@@ -1100,7 +1100,10 @@ class TeacherPrefetch:
     tensors then stay valid until that same graph is replayed two submits later - exactly as long as they are needed -
     so nothing is copied."""
 
-    MAX_GRAPH_KINDS = 6         # batch shapes whose teacher forward is captured (first come: each holds two private pools)
+    # batch shapes whose teacher forward is captured (first come: each holds two private pools).  Round 6: a bucket-padded
+    # epoch (data.bucket_pad_itr / _vqa) has a handful of shapes - 4 text lengths, or ~3 question lengths x ~2 answer-row
+    # counts - and ALL of them should replay; EVLM_MAX_GRAPH_KINDS overrides
+    MAX_GRAPH_KINDS = int(os.environ.get("EVLM_MAX_GRAPH_KINDS", "12"))
     MAX_EAGER_KINDS = 4         # ... further shapes run the same kernels eagerly; least recently used static buffers evicted
 
     def __init__(self, run_teacher, use_graph=True):
@@ -1190,7 +1193,9 @@ class _CapturedStep:
     eagerly: no agreement round is held here - VQA batch kinds (answer rows) differ from rank to rank, so ranks reach
     their captures at different steps and a collective at that moment would pair with a peer's gradient all-reduce."""
     capture_step = False
-    MAX_STEP_GRAPHS = 8         # static pairs whose step is captured (first come); pairs beyond that step eagerly
+    # static pairs whose step is captured (first come); pairs beyond that step eagerly.  (kinds x 2 teacher parities [x 2
+    # stop_prune]; the graphs share one memory pool.)  EVLM_MAX_STEP_GRAPHS overrides
+    MAX_STEP_GRAPHS = int(os.environ.get("EVLM_MAX_STEP_GRAPHS", "32"))
 
     def _cap_init(self):
         dev = next(self.student.parameters()).device
@@ -1502,9 +1507,11 @@ class ITRTrainer(_StagedExchange, _CapturedStep):
                     lambda: self.student(batch["image"], batch["text_ids"], batch["text_atts"], **kw),
                     lambda: self.teacher(batch["image"], batch["text_ids"], batch["text_atts"], **kw),
                     batch["image"], self.overlap_teacher)
-            kd = distill.kd_terms(S, T, self.temperature, with_cross_attn=True, fused=fused)
+            # (a bucket-padded batch - data.bucket_pad_itr - carries its real text length in device words: the text-side terms
+            # skip the padded token rows and are rescaled to the 'longest'-padded denominators)
+            kd = distill.kd_terms(S, T, self.temperature, with_cross_attn=True, fused=fused, ragged=distill.batch_ragged(batch)[0])
             lagrangian = self._lagrangian_end(lag, pruned_steps)
-            total, mix = distill.itr_loss_mix(S["loss"], kd, lagrangian)
+            total, mix = distill.itr_loss_mix(S["loss"], kd, lagrangian, kd_corr=batch.get("kd_corr"))
             ops.WGRAD_INPLACE = True
             ops.WGRAD_DEFER = [] if self.defer_wgrad else None
             self._sent = 0
@@ -1626,9 +1633,9 @@ class VQATrainer(_StagedExchange, _CapturedStep):
                 S, T = distill.student_and_teacher(
                     lambda: self.student(batch["image"], question, answer, stop_prune=stop_prune, **kw),
                     lambda: self.teacher(batch["image"], question, answer, **kw), batch["image"], self.overlap_teacher)
-            kd = distill.vqa_kd_terms(S, T, self.temperature, fused=fused)
+            kd = distill.vqa_kd_terms(S, T, self.temperature, fused=fused, ragged=distill.batch_ragged(batch))
             lagrangian = self._lagrangian_end(lag, pruned_steps)
-            total, mix = distill.vqa_loss_mix(S["loss"], kd, lagrangian)
+            total, mix = distill.vqa_loss_mix(S["loss"], kd, lagrangian, kd_corr=batch.get("kd_corr"))
             ops.WGRAD_INPLACE = True
             ops.WGRAD_DEFER = [] if self.defer_wgrad else None
             self._sent = 0

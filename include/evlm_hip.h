@@ -341,10 +341,18 @@ int evlm_mse_fwd(int dtype_a, const void* a, int dtype_b, const void* b, int64_t
 int evlm_mse_bwd(int dtype_a, const void* a, int dtype_b, const void* b, int64_t n, float weight,
                  const float* gout, void* grad_a, void* stream);
 /* Every (a, b) pair of a distillation step in ONE launch per direction (a GD step has ~40, most of a few MB).
- * table: device int64 [n_units][8] = {a, b, n, first block of the unit, blocks of the unit,
+ * table: device int64 [n_units][12] = {a, b, n, first block of the unit, blocks of the unit,
  *   loss word (forward: += coef * sum (a-b)^2) | gout word (backward), grad_a (backward: = coef * gout * (a-b)),
- *   coef as f32 bits (forward: weight / n, backward: 2 weight / n)};  a and b share `dtype`, are contiguous and 16-byte
- * aligned; first blocks ascend from 0 and total_blocks is their sum.  backward != 0 selects the gradient kernel. */
+ *   coef as f32 bits (forward: weight / n, backward: 2 weight / n), S, unit, ext, slots};  a and b share `dtype`, are
+ * contiguous and 16-byte aligned; first blocks ascend from 0 and total_blocks is their sum.  backward != 0 selects the
+ * gradient kernel.
+ * ABI 9 - S != 0 marks a RAGGED unit, for bucket-padded batches (the reference pads a batch to its longest text,
+ * Eff_Retrieval.py:97 / Eff_VQA.py:97-98, and feeds a variable number of answer rows, dataset/vqa_dataset.py:101-116; a
+ * captured step wants a few fixed shapes): the operands are [outer][inner items][unit elements] with S elements per outer
+ * block (S, unit multiples of 8) and only  outer < ext[outer slot] * mult,  inner item < ext[inner slot]  take part - ext
+ * (word 10) = device int32 words holding the batch's REAL extents, slots (word 11) = inner slot | outer slot << 8 | mult <<
+ * 16, slot 0xFF = "all".  The rest adds nothing to the sum and gets a zero gradient; coef keeps the padded element count
+ * (the caller rescales the term by padded / real). */
 int evlm_mse_grouped(int dtype, int backward, const int64_t* table, int n_units, int total_blocks, void* stream);
 
 /* hard-label cross entropy, mean over rows with label != ignore_index (F.cross_entropy: MLM loss
@@ -376,6 +384,17 @@ int evlm_kl_fwd(int dtype_s, const void* s, int lds, int dtype_t, const void* t,
 int evlm_kl_bwd(int dtype_s, const void* s, int lds, int dtype_t, const void* t, int ldt, int R, int C,
                 float inv_t, float weight, const float* lse_s, const float* lse_t, const float* gout,
                 void* ds, int ldds, int accumulate, void* stream);
+/* ABI 9 - the same over RAGGED rows (bucket-padded VQA batches, Eff_VQA.py:97-98 / dataset/vqa_dataset.py:101-116: logits
+ * [answer rows][answer tokens][vocabulary] padded to a few shapes): row r = (o, i), i = r % row_inner, takes part iff
+ * i < ext[inner_slot] and o < ext[outer_slot] (ext: device int32 words with the batch's real extents; slot 0xFF = all); the
+ * other rows add nothing and get a zero gradient.  The mean keeps the padded row count R (the caller rescales the term). */
+int evlm_kl_fwd_rows(int dtype_s, const void* s, int lds, int dtype_t, const void* t, int ldt, int R, int C,
+                     float inv_t, float weight, float* lse_s, float* lse_t, float* loss, const int32_t* ext, int row_inner,
+                     int inner_slot, int outer_slot, void* stream);
+int evlm_kl_bwd_rows(int dtype_s, const void* s, int lds, int dtype_t, const void* t, int ldt, int R, int C,
+                     float inv_t, float weight, const float* lse_s, const float* lse_t, const float* gout,
+                     void* ds, int ldds, int accumulate, const int32_t* ext, int row_inner, int inner_slot, int outer_slot,
+                     void* stream);
 
 /* row-wise log_softmax (for the soft-label ITC branch, xvlm.py:411-414) and its backward */
 int evlm_log_softmax_fwd(int dtype, const void* x, int R, int C, int ld, void* y, int ldy, void* stream);

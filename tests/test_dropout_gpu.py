@@ -423,3 +423,103 @@ def test_gd_trainer_with_stock_dropout_draws_new_masks_every_step(use_graph):
     assert float((outs[0.1][1, 3] - outs[0.1][2, 3]).abs()) > 1e-4 * float(outs[0.1][1, 3].abs())
     assert float((outs[0.1][0, 3] - outs[0.1][1, 3]).abs()) > 1e-4 * float(outs[0.1][1, 3].abs())
     assert abs(float(outs[0.1][1, 0]) - float(outs[0.0][1, 0])) < 0.2 * abs(float(outs[0.0][1, 0]))
+
+
+def test_benchmarked_configuration_with_stock_dropout_matches_the_oracle_given_the_same_masks():
+    """Round 6: the configuration bench.py times (bf16, batch 64, full geometry, joint hipGraph replay, teacher pipelined,
+    batched text / fusion passes, merged K/V projection, grouped MFMA cross-attention) under the reference's stock
+    training-mode dropout - student BERT hidden_dropout_prob = attention_probs_dropout_prob = 0.1 (eff_bert.py:180,214,346,
+    372-381,456-462) - against the fp32 CPU oracle multiplying by the SAME masks: the masks of the REPLAYED step are
+    regenerated from (device seed, the step word that replay drew, the call ids baked into the graph) and cut, per site, into
+    the row ranges of the reference's four passes (text | fusion positive | fusion negatives | MLM).  Losses within 1e-3,
+    every distillation term within 1e-2 / 5e-2, the whole gradient at cosine > 0.9999."""
+    from efficientvlm_amd import ops
+    from efficientvlm_amd.models.model_pretrain import XVLM
+    from efficientvlm_amd.trainer import GDTrainer
+    B, p = 64, 0.1
+    geom = synth.GEOMS["full"]
+    s_cfg, t_cfg = O.model_cfg(geom, "s"), O.model_cfg(geom, "t")
+    student, teacher = XVLM(model_config(geom, "s", dropout=p)), XVLM(model_config(geom, "t"))
+    load_det_weights(student, schema.xvlm_schema(s_cfg, geom["max_pos"]), 1000 + 21, geom["std"])
+    load_det_weights(teacher, schema.xvlm_schema(t_cfg, geom["max_pos"]), 2000 + 21, geom["std"])
+    student.to(DEV).train()
+    teacher.to(DEV).eval()
+    for q in teacher.parameters():
+        q.requires_grad_(False)
+    s_sd = schema.det_weights(schema.xvlm_schema(s_cfg, geom["max_pos"]), 1000 + 21, geom["std"])
+    t_sd = schema.det_weights(schema.xvlm_schema(t_cfg, geom["max_pos"]), 2000 + 21, geom["std"])
+    batch = synth.make_batch(geom, B, seed=77, ragged=True)
+    g = torch.Generator().manual_seed(5)
+    s_neg = torch.cat([(torch.arange(B) + 1 + torch.randint(0, B - 1, (B,), generator=g)) % B for _ in range(2)])
+    t_neg = torch.cat([(torch.arange(B) + 1 + torch.randint(0, B - 1, (B,), generator=g)) % B for _ in range(2)])
+    student.injected_neg_idx, teacher.injected_neg_idx = s_neg, t_neg
+    student.keep_injected_neg = teacher.keep_injected_neg = True
+    ops.dropout_seed(2024)
+    tr = GDTrainer(student, teacher, lr=1e-4, weight_decay=0.01, lr_mult=2.0, max_grad_norm=1.0, dtype=torch.bfloat16,
+                   use_graph=True, pipeline_teacher=True)
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    ops.DROPOUT_LOG = []
+    assert tr.step(gb) is None                    # primes the teacher pipeline
+    out = tr.step(gb)                             # two eager warm-ups, the capture, then THIS step replayed from the joint graph
+    torch.cuda.synchronize()
+    log, ops.DROPOUT_LOG = ops.DROPOUT_LOG, None
+    assert tr._joint, "the step did not run from a captured graph"
+    got = [float(x) for x in out.tolist()]
+    got_kd = {k: float(v) for k, v in tr.last_kd.items()}
+    got_grad = {n: q.grad.detach().float().cpu().clone() for n, q in student.named_parameters()}
+
+    # the sites of ONE student step: batched text pass [2B rows: clean | masked ids] = 1 + 3 per text layer, batched fusion
+    # pass [4B rows: positive | text x negative image | negative text x image | masked] = 5 per fusion layer
+    nt, nf = s_cfg["fusion_layer"], s_cfg["text_layers"] - s_cfg["fusion_layer"]
+    per_step = (1 + 3 * nt) + 5 * nf
+    assert len(log) % per_step == 0 and len(log) >= per_step, (len(log), per_step)
+    sites = log[-per_step:]                       # (the capture pass: the call ids the replayed graph carries)
+    assert [k for _, k, _, _ in sites[:4]] == ["hidden", "attention_probs", "hidden", "hidden"]
+    assert all(shp[0] == 2 * B for _, _, shp, _ in sites[:1 + 3 * nt]) and all(shp[0] == 4 * B for _, _, shp, _ in sites[1 + 3 * nt:])
+    st = ops.dropout_state(torch.device(DEV))
+    now = int(st[1].item())
+    st[1] = now - 1                               # the step word the replayed step drew its masks with (ticked on the device since)
+    full = [ops.dropout_mask(c, shp, pp, kind=kind).cpu() for c, kind, shp, pp in sites]
+    st[1] = now
+    text_sites, fus_sites = full[:1 + 3 * nt], full[1 + 3 * nt:]
+    order = ([m[:B] for m in text_sites] + [m[:B] for m in fus_sites] + [m[B:3 * B] for m in fus_sites]
+             + [m[B:2 * B] for m in text_sites] + [m[3 * B:] for m in fus_sites])
+
+    leaves = {k: v.clone().requires_grad_(True) for k, v in s_sd.items()}
+    tie = lambda sd: {**sd, "text_encoder.cls.predictions.decoder.weight": sd["text_encoder.bert.embeddings.word_embeddings.weight"],
+                      "text_encoder.cls.predictions.decoder.bias": sd["text_encoder.cls.predictions.bias"]}
+    O.DROPOUT_MASKS = iter(order)
+    try:
+        oS = O.pretrain_forward(tie(leaves), s_cfg, batch, s_neg)
+        assert next(O.DROPOUT_MASKS, None) is None, "the oracle visited fewer dropout sites than the HIP path"
+    finally:
+        O.DROPOUT_MASKS = None
+    with torch.no_grad():
+        oT = O.pretrain_forward(tie(t_sd), t_cfg, batch, t_neg)
+    okd = O.kd_terms(oS, oT, 1.0)
+    ototal, omix = O.gd_loss_mix(oS["loss"], okd)
+    ototal.backward()
+    want = [float(ototal), float(oS["loss"]["loss_itc"]), float(oS["loss"]["loss_itm"]), float(oS["loss"]["loss_mlm"]),
+            float(omix["loss_kd"])]
+    for name, a, b in zip(("total", "itc", "itm", "mlm", "kd"), got, want):
+        assert abs(a - b) <= 1e-3 * abs(b), f"{name}: {a} vs oracle {b}"
+    for k, v in got_kd.items():
+        rt = 5e-2 if k.endswith("_logits") else 1e-2
+        assert abs(v - float(okd[k])) <= rt * abs(float(okd[k])) + 1e-6, f"kd.{k}: {v} vs oracle {float(okd[k])}"
+    stats, num, da, db = [], 0.0, 0.0, 0.0
+    gmax = max(float(l.grad.norm()) for l in leaves.values() if l.grad is not None)
+    for name, leaf in leaves.items():
+        if leaf.grad is None or name not in got_grad or float(leaf.grad.norm()) < 1e-5 * gmax:
+            continue
+        a, b = got_grad[name].double().reshape(-1), leaf.grad.double().reshape(-1)
+        stats.append((float((a - b).norm() / b.norm()), float((a * b).sum() / (a.norm() * b.norm())), name))
+        num += float((a * b).sum()); da += float((a * a).sum()); db += float((b * b).sum())
+    assert len(stats) > 150
+    worst = sorted(stats, reverse=True)[:5]
+    assert num / math.sqrt(da * db) > 0.9999, (num / math.sqrt(da * db), worst)
+    assert all(r < 0.25 and c > 0.96 for r, c, _ in stats), worst
+    # and the dropout really ran: the p = 0 oracle losses differ
+    with torch.no_grad():
+        o0 = O.pretrain_forward(tie(s_sd), s_cfg, batch, s_neg)
+    assert abs(float(o0["loss"]["loss_mlm"]) - want[3]) > 1e-4 * abs(want[3])
+    tr.close()

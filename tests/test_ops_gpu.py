@@ -1743,7 +1743,7 @@ def test_streaming_long_sequence_kernels_agree_with_the_whole_row_kernels(case, 
 
 
 def test_attention_lse_form_refuses_what_it_cannot_serve():
-    """C ABI: the lse / recompute form exists for bf16, head dim 64, Lk <= 224 without dropout; anything else answers with
+    """C ABI: the lse / recompute form exists for bf16, head dim 64, Lk <= 224 or 417..928; anything else answers with
     an error code - never a fault - and evlm_attention_lse_supported says so beforehand"""
     import ctypes as C
     from efficientvlm_amd import _lib as L
@@ -1754,7 +1754,8 @@ def test_attention_lse_form_refuses_what_it_cannot_serve():
     assert lib.evlm_attention_lse_supported(L.BF16, 64, 1000, 0.0) == 0
     assert lib.evlm_attention_lse_supported(L.F32, 64, 30, 0.0) == 0
     assert lib.evlm_attention_lse_supported(L.BF16, 32, 30, 0.0) == 0
-    assert lib.evlm_attention_lse_supported(L.BF16, 64, 30, 0.1) == 0
+    assert lib.evlm_attention_lse_supported(L.BF16, 64, 30, 0.1) == 1         # (round 6: the MFMA kernels regenerate the keep-mask)
+    assert lib.evlm_attention_lse_supported(L.BF16, 64, 577, 0.1) == 1 and lib.evlm_attention_lse_supported(L.BF16, 64, 30, 1.0) == 0
     B, H, Lq, Lk, dh = 1, 2, 16, 300, 64
     d = H * dh
     q = torch.zeros(B, Lq, d, dtype=torch.bfloat16, device=DEV)

@@ -11,8 +11,8 @@ from oracle import synth
 from efficientvlm_amd.trainer import ITRTrainer
 from efficientvlm_amd.efficient_models.model_retrieval import EffXVLMforRetrieval
 from efficientvlm_amd.models.model_retrieval import XVLM as TeacherITR
-res = int(sys.argv[1]) if len(sys.argv) > 1 else 384
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+res = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 384
+B = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 64
 geom = dict(synth.GEOMS["full"]); geom["image_res"] = res
 dev = torch.device("cuda")
 if os.environ.get("EVLM_FORCE_REDUCE"):       # the N > 1 code path (collectives, gradient stages, graph segments) on a one-rank RCCL group
@@ -29,9 +29,44 @@ tr = ITRTrainer(student, teacher, lr=3e-5, weight_decay=0.01, lr_mult=2, reg_lea
                 pipeline_teacher=pipe, capture_step=not os.environ.get("EVLM_NO_STEP_GRAPH"))
 batch = {k: v.to(dev) for k, v in synth.make_batch(geom, B, seed=5).items()}
 idx = torch.arange(B, device=dev)
+if "--ragged" in sys.argv:
+    # Round 6: batches as an epoch of the reference delivers them - every batch padded to ITS longest caption (Eff_Retrieval.py:97
+    # padding='longest'; here a random real length of 8..40 tokens per batch) - fed through data.bucket_pad_itr: a few shapes,
+    # so the captured step replays.  Reports how many steps replayed from a hipGraph and the mean host time per step.
+    import random
+    from efficientvlm_amd.data import bucket_pad_itr
+    steps = int(sys.argv[sys.argv.index("--ragged") + 1]) if len(sys.argv) > sys.argv.index("--ragged") + 1 else 200
+    rnd = random.Random(0)
+    pool = {}
+    def ragged_batch():
+        L = rnd.randint(8, 40)
+        if L not in pool:                      # (one synthetic batch per real length: the data itself is not the subject)
+            g = dict(geom); g["L"] = L; g["M"] = 2
+            pool[L] = {k: v.to(dev) for k, v in synth.make_batch(g, B, seed=100 + L, ragged=True).items() if k in ("image", "text_ids", "text_atts")}
+        return L, bucket_pad_itr(pool[L])
+    launches, host_s, shapes, t_all = [], 0.0, set(), None
+    for s in range(steps + 16):
+        if s == 16:
+            torch.cuda.synchronize(); t_all = time.perf_counter(); launches, host_s = [], 0.0
+        L, b = ragged_batch()
+        shapes.add(int(b["text_ids"].shape[1]))
+        t0 = time.perf_counter()
+        out = tr.step(b, idx=idx)
+        host_s += time.perf_counter() - t0
+        if out is not None:
+            launches.append(tr.last_launch)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t_all) / steps
+    rep = sum(1 for l in launches if l.startswith("hipGraph"))
+    print(json.dumps({"workload": "ITR pruning fine-tune step, ragged epoch (real text length 8..40 per batch, bucket-padded)",
+                      "image_res": res, "batch": B, "steps": steps, "padded_text_lengths": sorted(shapes),
+                      "replayed_from_hipgraph": rep, "replay_frac": round(rep / len(launches), 4),
+                      "host_ms_per_step": round(host_s / steps * 1e3, 2), "ms_per_step": round(dt * 1e3, 2),
+                      "pairs_per_s": round(B / dt, 1), "captured_pairs": len(tr._sgraphs),
+                      "losses[total,itc,itm,kd,lagrangian]": [round(float(x), 4) for x in out.tolist()]}))
+    sys.exit(0)
 for _ in range(6): out = tr.step(batch, idx=idx)      # (prime, one eager step per parity, one capture per parity)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-K = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+K = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 10
 for _ in range(K): out = tr.step(batch, idx=idx)
 host = (time.perf_counter() - t0) / K      # host time per step (before the device has caught up)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K

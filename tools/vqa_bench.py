@@ -13,8 +13,8 @@ from oracle import synth
 from efficientvlm_amd.trainer import VQATrainer
 from efficientvlm_amd.efficient_models.model_generation import EffXVLMForVQA
 from efficientvlm_amd.models.model_generation import XVLMForVQA
-res = int(sys.argv[1]) if len(sys.argv) > 1 else 480
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+res = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 480
+B = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 32
 geom = dict(synth.GEOMS["full"]); geom["image_res"] = res
 dev = torch.device("cuda")
 if os.environ.get("EVLM_FORCE_REDUCE"):       # the N > 1 code path (collectives, gradient stages, graph segments) on a one-rank RCCL group
@@ -30,6 +30,48 @@ student.l0_module.set_lagrangian_warmup_steps(100)
 pipe = not os.environ.get("EVLM_NO_PIPELINE")
 tr = VQATrainer(student, teacher, lr=5e-5, weight_decay=0.01, lr_mult=2, reg_learning_rate=0.1, dtype=torch.bfloat16,
                 pipeline_teacher=pipe, capture_step=not os.environ.get("EVLM_NO_STEP_GRAPH"))
+if "--ragged" in sys.argv:
+    # Round 6: batches as an epoch of the reference delivers them - questions padded to the batch's longest (8..40 tokens),
+    # 1..10 candidate answers per question (dataset/vqa_dataset.py:101-116), answers padded to their longest (3..8 tokens) -
+    # fed through data.bucket_pad_vqa: a few shapes, so the captured step replays.
+    import random
+    from efficientvlm_amd.data import bucket_pad_vqa
+    steps = int(sys.argv[sys.argv.index("--ragged") + 1]) if len(sys.argv) > sys.argv.index("--ragged") + 1 else 200
+    rnd = random.Random(0)
+    images = torch.randn(B, 3, res, res, generator=torch.Generator().manual_seed(1)).to(dev)
+    def ragged_batch():
+        Lq, La = rnd.randint(8, 40), rnd.randint(3, 8)
+        g = dict(geom); g["L"] = Lq; g["M"] = 2
+        b = synth.make_vqa_batch(g, B, seed=rnd.randint(0, 1 << 20), La=max(La, 3))
+        k = torch.tensor([rnd.randint(1, 10) for _ in range(B)], dtype=torch.long)
+        n = int(k.sum())
+        reps = (n + b["answer_ids"].shape[0] - 1) // b["answer_ids"].shape[0]
+        for key in ("answer_ids", "answer_atts", "weights"):
+            b[key] = torch.cat([b[key]] * reps, 0)[:n]
+        b["k"] = k
+        b = {kk: v.to(dev) for kk, v in b.items() if kk != "image"}
+        b["image"] = images
+        return bucket_pad_vqa(b)
+    launches, host_s, shapes, t_all = [], 0.0, set(), None
+    for s in range(steps + 24):
+        if s == 24:
+            torch.cuda.synchronize(); t_all = time.perf_counter(); launches, host_s = [], 0.0
+        b = ragged_batch()
+        shapes.add((int(b["question_ids"].shape[1]), int(b["answer_ids"].shape[1]), int(b["answer_ids"].shape[0])))
+        t0 = time.perf_counter()
+        out = tr.step(b)
+        host_s += time.perf_counter() - t0
+        if out is not None:
+            launches.append(tr.last_launch)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t_all) / steps
+    rep = sum(1 for l in launches if l.startswith("hipGraph"))
+    print(json.dumps({"workload": "VQA pruning fine-tune step, ragged epoch (questions 8..40 tokens, 1..10 answers each, bucket-padded)",
+                      "image_res": res, "batch": B, "steps": steps, "padded_shapes[q_len,a_len,rows]": sorted(shapes),
+                      "replayed_from_hipgraph": rep, "replay_frac": round(rep / len(launches), 4),
+                      "host_ms_per_step": round(host_s / steps * 1e3, 2), "ms_per_step": round(dt * 1e3, 2),
+                      "questions_per_s": round(B / dt, 1), "captured_pairs": len(tr._sgraphs),
+                      "losses[total,answer,kd,lagrangian]": [round(float(x), 4) for x in out.tolist()]}))
+    sys.exit(0)
 batch = synth.make_vqa_batch(geom, B, seed=5, La=8)
 batch["k"] = torch.full((B,), 4, dtype=torch.long)                 # 4 answers per question
 n = 4 * B
@@ -39,7 +81,7 @@ for key in ("answer_ids", "answer_atts", "weights"):
 batch = {k: v.to(dev) for k, v in batch.items()}
 for _ in range(6): out = tr.step(batch)      # (prime, one eager step per parity, one capture per parity)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-K = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+K = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 8
 for _ in range(K): out = tr.step(batch)
 host = (time.perf_counter() - t0) / K      # host time per step (before the device has caught up)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
