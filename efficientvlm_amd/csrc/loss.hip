@@ -801,6 +801,10 @@ extern "C" int evlm_itc_loss_bwd(int dtype, const void* I, int ldi, const void* 
                "evlm_itc_loss_bwd: bad args (as evlm_itc_loss_fwd; gradient rows 4-element aligned, Bt <= 4096)");
   const dim3 grid(ceil_div(Bt, 4)), block(256);
   const size_t lds_bytes = (size_t)4 * 2 * Bt * sizeof(float);
+  if (lds_bytes > 64 * 1024) {       // gathered batches beyond 2 048 rows (64 ranks x 64): up to 128 of the 160 KiB
+    (void)hipFuncSetAttribute((const void*)itc_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    (void)hipFuncSetAttribute((const void*)itc_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  }
   if (dtype == EVLM_BF16)
     hipLaunchKernelGGL(itc_bwd_kernel<bf16>, grid, block, lds_bytes, stream, (const bf16*)I, ldi, (const bf16*)Tx, ldt, Bt, E, temp, group, sim, lds, stats, dloss, (bf16*)dI, lddi, (bf16*)dT, lddt, dtemp);
   else

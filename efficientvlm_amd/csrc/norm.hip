@@ -123,6 +123,146 @@ __global__ __launch_bounds__(256) void ln_fwd_reg_kernel(const T* __restrict__ x
   }
 }
 
+// Round 6: d = 768 (the hidden size of both models: 82 launches per GD step, 80 per ITR-384 step).  The kernel above gives a
+// row of 96 16-byte chunks to 64 lanes - a second chunk for half of them -, walks its rows one after the other with nothing
+// in flight while it reduces, and measured 3.6 TB/s on [12 608, 768] / 2.8 TB/s on [36 928, 768].  Here a wave owns a PAIR
+// of consecutive rows = 192 contiguous chunks = exactly three per lane, and the NEXT pair's loads are issued before the
+// current pair is touched (raw 16-byte registers, converted where used).  Row 0 of a pair sits in the lanes the kernel above
+// would give it (chunks l, l + 64); row 1 sits in that assignment ROTATED by 32 lanes (l ^ 32), which the xor-butterfly of
+// wave_sum does not see: per-lane partial sums in the same order, the same tree - bit-identical outputs, mean / rstd included.
+template <typename T> struct Raw8;
+template <typename T, bool KD>
+__global__ __launch_bounds__(256) void ln_fwd_pair768_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, int rows,
+                                                             T* __restrict__ y, float* __restrict__ mean_out,
+                                                             float* __restrict__ rstd_out, const T* __restrict__ kd_t,
+                                                             float* __restrict__ kd_slots, float kd_coef) {
+  constexpr int D = 768;                        // 96 16-byte chunks of bf16 per row
+  const int lane = threadIdx.x & 63;
+  const bool up = lane >= 32;                    // chunk slot 1 (pair chunk lane + 64) belongs to row 1 for the upper lanes
+  // column chunk of this lane's three pair chunks: slot 0 -> row 0 chunk lane; slot 1 -> row 0 chunk lane + 64 | row 1 chunk
+  // lane - 32; slot 2 -> row 1 chunk lane + 32
+  const int cc[3] = {lane, up ? lane - 32 : lane + 64, lane + 32};
+  // gamma / beta sit in LDS (6 KiB), read where used: held in registers - 48 of them - the kernel ran 3 waves per SIMD
+  __shared__ __attribute__((aligned(16))) float gs[D], bs[D];
+  for (int i = threadIdx.x; i < D; i += 256) { gs[i] = gamma[i]; bs[i] = beta[i]; }
+  __syncthreads();
+  const int npairs = (rows + 1) >> 1, stride = gridDim.x * 4;
+  int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  Raw8<T> xn[3], tn[KD ? 3 : 1];
+  auto issue = [&](int p) {
+    // (an odd row count: the last pair's second row reads the first one again and is not stored)
+    const size_t r0 = (size_t)2 * p, r1 = min(2 * p + 1, rows - 1);
+    const size_t o[3] = {r0 * D + lane * 8, (up ? r1 : r0) * D + cc[1] * 8, r1 * D + cc[2] * 8};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      xn[j].load(x + o[j]);
+      if (KD) tn[KD ? j : 0].load(kd_t + o[j]);
+    }
+  };
+  float sq = 0.f;
+  if (pair < npairs) issue(pair);
+  for (; pair < npairs; pair += stride) {
+    Raw8<T> xc[3], tc[KD ? 3 : 1];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { xc[j] = xn[j]; if (KD) tc[KD ? j : 0] = tn[KD ? j : 0]; }
+    if (pair + stride < npairs) issue(pair + stride);
+    const bool has1 = 2 * pair + 1 < rows;
+    // (the row stays as LOADED - 12 raw registers - and is converted in each of the three passes: 24 floats held across the
+    // reductions, plus the next pair in flight, cost a wave per SIMD)
+    // row sums in the order of ln_fwd_reg_kernel: a lane's first chunk (the lower-numbered one), then its second
+    float s0 = 0.f, s1 = 0.f;
+    {
+      float v[8];
+      xc[0].get(v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s0 += v[e];
+      xc[1].get(v);
+      if (!up) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s0 += v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1 += v[e];
+      }
+      xc[2].get(v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1 += v[e];
+    }
+    if (KD) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float v[8], tv[8];
+        xc[j].get(v);
+        tc[KD ? j : 0].get(tv);
+        if (j == 0 || has1 || (j == 1 && !up)) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float df = v[e] - tv[e]; sq = fmaf(df, df, sq); }
+        }
+      }
+    }
+    const float mean0 = wave_sum(s0) / (float)D, mean1 = wave_sum(s1) / (float)D;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) xc[j].opaque();
+    // (t * t rounded, then added: the one-row kernels' loops compile to a multiply and an add, and the outputs are to be theirs
+    // bit for bit - with two interleaved chains the compiler otherwise contracts SOME of these into fmas)
+    float q0 = 0.f, q1 = 0.f;
+    {
+      float v[8];
+      xc[0].get(v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float t = v[e] - mean0; q0 += mul_rn(t, t); }
+      xc[1].get(v);
+      if (!up) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float t = v[e] - mean0; q0 += mul_rn(t, t); }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float t = v[e] - mean1; q1 += mul_rn(t, t); }
+      }
+      xc[2].get(v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float t = v[e] - mean1; q1 += mul_rn(t, t); }
+    }
+    const float rstd0 = rsqrtf(wave_sum(q0) / (float)D + eps), rstd1 = rsqrtf(wave_sum(q1) / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) xc[j].opaque();
+    const size_t r0 = (size_t)2 * pair, r1 = r0 + 1;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const bool second = j == 2 || (j == 1 && up);
+      if (second && !has1) continue;
+      const float mu = second ? mean1 : mean0, rs = second ? rstd1 : rstd0;
+      float v[8], o[8], gm[8], bt[8];
+      xc[j].get(v);
+      load8<float>(gs + cc[j] * 8, gm);
+      load8<float>(bs + cc[j] * 8, bt);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[e] - mu) * rs * gm[e] + bt[e];
+      store8<T>(y + (second ? r1 : r0) * D + cc[j] * 8, o);
+    }
+    if (lane == 0) {
+      if (mean_out) { mean_out[r0] = mean0; if (has1) mean_out[r1] = mean1; }
+      if (rstd_out) { rstd_out[r0] = rstd0; if (has1) rstd_out[r1] = rstd1; }
+    }
+  }
+  if (KD) {
+    __shared__ float kdsum[4];
+    sq = wave_sum(sq);
+    if (lane == 0) kdsum[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      atomicAdd(kd_slots + (blockIdx.x & (LN_KD_SLOTS - 1)) * 32, ((kdsum[0] + kdsum[1]) + (kdsum[2] + kdsum[3])) * kd_coef);
+  }
+}
+// grid of the pair kernel: every wave makes the same number of trips (>= 2, so that the prefetch has something to hide),
+// all workgroups resident
+static int ln_pair_blocks(int rows) {
+  const int npairs = (rows + 1) / 2;
+  const int trips = imax(2, ceil_div(npairs, 4 * 1280));       // (86 VGPRs: 5 workgroups of 4 waves per CU)
+  return imax(1, ceil_div(npairs, 4 * trips));
+}
+
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma += sum_rows dy*xhat;  dbeta += sum_rows dy.
 // One wave per row, the row (x, dy) is read ONCE and kept in registers (DCH 16-byte chunks per lane: d <= 512*DCH).
 // Each block walks rows blockIdx.x*4 + w, += gridDim.x*4 and keeps per-lane partial dgamma/dbeta for the columns it
@@ -246,7 +386,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 // dy / addend loads before it touches the current one; gamma is read from LDS.  ~1/3 fewer registers, every load of a row
 // in flight behind the previous row's arithmetic.  EXTRA: the rare second addend / fused distillation teacher row, loaded
 // at the top of the row's trip.
-template <typename T> struct Raw8;
 template <> struct Raw8<bf16> {
   bf16x8 v;
   __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
@@ -469,6 +608,14 @@ extern "C" int evlm_layernorm_fwd_kd(int dtype, const void* x, const float* gamm
   EVLM_REQUIRE(x && y && gamma && beta && rows > 0 && d > 0 && kd_teacher && kd_slots, "evlm_layernorm_fwd_kd: bad args");
   EVLM_REQUIRE(d % 8 == 0 && d <= 2048, "evlm_layernorm_fwd_kd: d=%d unsupported (multiple of 8, <= 2048)", d);
   dim3 block(256), rgrid(rows >= 4096 ? ceil_div(rows, 12) : ceil_div(rows, 4));
+  static const bool pair_kd = !getenv("EVLM_LN_FWD_NO_PAIR");        // (A/B switch)
+  if (pair_kd && d == 768 && rows >= 1024) {
+    EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_fwd_kd",
+      hipLaunchKernelGGL((ln_fwd_pair768_kernel<T, true>), dim3(ln_pair_blocks(rows)), block, 0, stream, (const T*)x, gamma, beta, eps,
+                         rows, (T*)y, mean, rstd, (const T*)kd_teacher, kd_slots, kd_coef);)
+    EVLM_LAUNCH_CHECK("evlm_layernorm_fwd_kd");
+    return 0;
+  }
 #define LN_FWD_KD(DCH_) hipLaunchKernelGGL((ln_fwd_reg_kernel<T, DCH_, true>), rgrid, block, 0, stream, (const T*)x, gamma, beta, eps, rows, d, (T*)y, mean, rstd, (const T*)kd_teacher, kd_slots, kd_coef)
   EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_fwd_kd",
     if (d <= 512) LN_FWD_KD(1); else if (d <= 1024) LN_FWD_KD(2); else if (d <= 1536) LN_FWD_KD(3); else LN_FWD_KD(4);)
@@ -484,6 +631,14 @@ extern "C" int evlm_layernorm_fwd(int dtype, const void* x, const float* gamma, 
   EVLM_REQUIRE(d % 8 == 0, "evlm_layernorm_fwd: d=%d must be a multiple of 8", d);
   dim3 grid(ceil_div(rows, 4)), block(256);
   const char* env = getenv("EVLM_LN_FWD_3PASS");      // (debug / A-B switch)
+  static const bool pair_on = !getenv("EVLM_LN_FWD_NO_PAIR");        // (A/B switch)
+  if (pair_on && d == 768 && rows >= 1024 && !(env && atoi(env))) {      // round 6: row pairs, next pair prefetched
+    EVLM_DISPATCH_DTYPE(dtype, "evlm_layernorm_fwd",
+      hipLaunchKernelGGL((ln_fwd_pair768_kernel<T, false>), dim3(ln_pair_blocks(rows)), block, 0, stream, (const T*)x, gamma, beta, eps,
+                         rows, (T*)y, mean, rstd, (const T*)nullptr, (float*)nullptr, 0.f);)
+    EVLM_LAUNCH_CHECK("evlm_layernorm_fwd");
+    return 0;
+  }
   if (d <= 2048 && !(env && atoi(env))) {     // the row fits the registers of one wave: single pass, 3 rows per wave
     dim3 rgrid(rows >= 4096 ? ceil_div(rows, 12) : ceil_div(rows, 4));
 #define LN_FWD(DCH_) hipLaunchKernelGGL((ln_fwd_reg_kernel<T, DCH_>), rgrid, block, 0, stream, (const T*)x, gamma, beta, eps, rows, d, (T*)y, mean, rstd)

@@ -348,7 +348,10 @@ class XVLMBase(nn.Module):
         # ONE all-gather of [B, 2E] for both feature sets (latency-bound message: SURVEY.md 2.2); the slice-only backward of
         # the reference's two gathers (xvlm.py:54-74) is unchanged - it acts row-wise
         gathered = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("EVLM_FORCE_REDUCE"))
-        if image_feat.is_cuda and not _NO_FUSED_ITC and image_feat.dtype == text_feat.dtype and self.embed_dim <= 256 and self.embed_dim % 8 == 0:
+        world = dist.get_world_size() if gathered else 1
+        # (the one-launch form holds a row block of the gathered coefficients in LDS: gathered batches of up to 4 096 rows)
+        if (image_feat.is_cuda and not _NO_FUSED_ITC and image_feat.dtype == text_feat.dtype and self.embed_dim <= 256
+                and self.embed_dim % 8 == 0 and image_feat.shape[0] * world <= 4096):
             # round 5: logits, both cross-entropies (soft labels when idx is given) and the whole backward in ONE launch each
             # way (ops.itc_loss) - it was ~35 launches of 4-27 us on the student's critical path
             both = allgather(torch.cat([image_feat, text_feat], dim=1)) if gathered else None

@@ -1364,7 +1364,8 @@ class GateGradSlot:
     """gradient buffer of ONE L0 gate tensor z [n, ...] (a row per gated layer: xvlm_l0_module.py zs['*_z']): zeroed, f32,
     a slice of the step's zero arena.  Every consumer of row i - an attention or an FFN backward kernel - ACCUMULATES its
     gate gradient into row i itself; the first consumer of a row hands the row to autograd, later ones hand back nothing
-    (the KVGradSlot protocol), and _GateFanout.backward returns the whole buffer.  Before: one zero-filled vector per
+    (the KVGradSlot protocol), and _GateFanout.backward returns the whole buffer (a row whose only consumers know nothing of
+    the slot is added the ordinary way; a row with BOTH kinds of consumer raises - its alias would be counted twice).  Before: one zero-filled vector per
     consumer, one zero-filled [n, ...] tensor + one add per row in autograd's SelectBackward - ~70 launches of a few
     microseconds each on the critical path of a pruning step."""
 
@@ -1394,6 +1395,12 @@ class _GateFanout(torch.autograd.Function):
         buf = slot.buf
         for i, g in enumerate(grads):          # a row whose consumer did not go through the slot (an op that knows nothing
             if g is not None and g.data_ptr() != buf[i].data_ptr():      # of it): its gradient is added the ordinary way
+                if i in slot.handed:
+                    # a slot-aware consumer handed autograd an ALIAS of buf[i]; summed with another consumer's gradient it
+                    # comes back as a fresh tensor that already contains buf[i] - adding it would count the row twice
+                    raise RuntimeError(f"gate row {i} has both a slot-aware consumer (attention / FFN kernels) and one that "
+                                       "returns its own gradient: read the gate through ops.gate_rows consumers only, or "
+                                       "set EVLM_NO_GATE_SLOTS=1")
                 buf[i].add_(g.reshape(buf[i].shape).to(buf.dtype))
         slot.handed = set()
         return buf, None

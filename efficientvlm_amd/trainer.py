@@ -366,6 +366,11 @@ class _StagedExchange:
             enc = getattr(getattr(model, "vision_encoder", None), "encoder", None)
             if enc is not None and getattr(enc, "grad_hooks", None):
                 enc.grad_hooks = {}
+        # (the ITR / VQA trainers ask their frozen teacher for attention-map RECIPES instead of maps: a teacher that outlives
+        # its trainer hands out maps again)
+        tenc = getattr(getattr(getattr(self, "teacher", None), "vision_encoder", None), "encoder", None)
+        if tenc is not None and getattr(tenc, "attn_recipe", False):
+            tenc.attn_recipe = False
         pre = getattr(self, "prefetch", None)
         if pre is not None:
             pre.close()

@@ -388,6 +388,36 @@ def _ref_attention(q, k, v, mask, gate, scale):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows", [1024, 1027, 12608])
+def test_layernorm_row_pair_kernel_is_bit_identical_to_the_one_row_kernels(dtype, rows, monkeypatch):
+    """round 6: ln_fwd_pair768_kernel (d = 768: a wave owns two consecutive rows = three 16-byte chunks per lane, the next pair
+    prefetched) against the three-pass kernel (EVLM_LN_FWD_3PASS=1, read per call): the same per-lane partial sums in the same
+    order and the same reduction tree - outputs, saved mean / rstd and therefore the backward bit-identical; an odd row count
+    exercises the half-filled last pair; the fused hidden-state distillation term agrees with the separate reduction"""
+    from efficientvlm_amd import ops as o
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, 768, generator=g) * 2 + 0.3).to(DEV, dtype)
+    w, b = (torch.rand(768, generator=g) + 0.5).to(DEV), torch.randn(768, generator=g).to(DEV)
+    gy = torch.randn(rows, 768, generator=g).to(DEV, dtype)
+    outs = []
+    for three in ("0", "1"):
+        monkeypatch.setenv("EVLM_LN_FWD_3PASS", three)
+        xx, ww, bb = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = o.layer_norm(xx, ww, bb, 1e-12)
+        y.backward(gy)
+        outs.append((y.detach().clone(), xx.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    monkeypatch.setenv("EVLM_LN_FWD_3PASS", "0")
+    t = (x.float() + 0.1 * torch.randn(rows, 768, generator=g).to(DEV)).to(dtype)
+    slots = torch.zeros(o.hidden_kd_slots(), dtype=torch.float32, device=DEV)
+    xx = x.clone().requires_grad_(True)
+    y2, alias, kd = o.layer_norm_fork_kd(xx, w, b, 1e-12, t, slots, 0.5 / x.numel())
+    assert torch.equal(y2.detach(), outs[0][0])
+    ref = 0.5 * torch.nn.functional.mse_loss(x.float(), t.float())
+    assert abs(float(kd.sum()) - float(ref)) <= 1e-4 * float(ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,L,dh", [(3, 12, 7, 64), (2, 4, 11, 16), (2, 12, 40, 64)])
 def test_causal_self_attention(dtype, B, H, L, dh):
     """decoder self-attention (BertLMHeadModel, eff_bert.py:975-996): key-padding mask AND -10000 on keys after the query,

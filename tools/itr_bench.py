@@ -21,7 +21,9 @@ if os.environ.get("EVLM_FORCE_REDUCE"):       # the N > 1 code path (collectives
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1)
 torch.manual_seed(0)
-student = EffXVLMforRetrieval(model_config(geom, "s", image_res=res)).to(dev)
+# --dropout P: the student BERT's hidden / attention-probability dropout (the stock recipe trains with 0.1; default 0 as BASELINE quotes)
+DROP = float(sys.argv[sys.argv.index("--dropout") + 1]) if "--dropout" in sys.argv else 0.0
+student = EffXVLMforRetrieval(model_config(geom, "s", image_res=res, dropout=DROP)).to(dev)
 teacher = TeacherITR(model_config(geom, "t", image_res=res)).to(dev)
 student.l0_module.set_lagrangian_warmup_steps(100)
 pipe = not os.environ.get("EVLM_NO_PIPELINE")
@@ -58,7 +60,7 @@ if "--ragged" in sys.argv:
     torch.cuda.synchronize(); dt = (time.perf_counter() - t_all) / steps
     rep = sum(1 for l in launches if l.startswith("hipGraph"))
     print(json.dumps({"workload": "ITR pruning fine-tune step, ragged epoch (real text length 8..40 per batch, bucket-padded)",
-                      "image_res": res, "batch": B, "steps": steps, "padded_text_lengths": sorted(shapes),
+                      "dropout": DROP, "launch": tr.last_launch, "image_res": res, "batch": B, "steps": steps, "padded_text_lengths": sorted(shapes),
                       "replayed_from_hipgraph": rep, "replay_frac": round(rep / len(launches), 4),
                       "host_ms_per_step": round(host_s / steps * 1e3, 2), "ms_per_step": round(dt * 1e3, 2),
                       "pairs_per_s": round(B / dt, 1), "captured_pairs": len(tr._sgraphs),
@@ -70,5 +72,5 @@ K = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 10
 for _ in range(K): out = tr.step(batch, idx=idx)
 host = (time.perf_counter() - t0) / K      # host time per step (before the device has caught up)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
-print(json.dumps({"workload": "ITR pruning fine-tune step", "teacher_pipelined": pipe, "launch": tr.last_launch, "host_ms_per_step": round(host * 1e3, 2), "image_res": res, "batch": B, "ms_per_step": round(dt * 1e3, 2),
+print(json.dumps({"workload": "ITR pruning fine-tune step", "dropout": DROP, "teacher_pipelined": pipe, "launch": tr.last_launch, "host_ms_per_step": round(host * 1e3, 2), "image_res": res, "batch": B, "ms_per_step": round(dt * 1e3, 2),
                   "pairs_per_s": round(B / dt, 1), "losses[total,itc,itm,kd,lagrangian]": [round(float(x), 4) for x in out.tolist()]}))

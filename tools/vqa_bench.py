@@ -23,7 +23,9 @@ if os.environ.get("EVLM_FORCE_REDUCE"):       # the N > 1 code path (collectives
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1)
 torch.manual_seed(0)
-cfg = lambda role, nd: dict(model_config(geom, role, image_res=res), pad_token_id=0, num_dec_layers=nd)
+# --dropout P: the student BERT's (question encoder + answer decoder) hidden / attention-probability dropout; default 0
+DROP = float(sys.argv[sys.argv.index("--dropout") + 1]) if "--dropout" in sys.argv else 0.0
+cfg = lambda role, nd: dict(model_config(geom, role, image_res=res, dropout=DROP if role == "s" else 0.0), pad_token_id=0, num_dec_layers=nd)
 student = EffXVLMForVQA(cfg("s", 3)).to(dev)
 teacher = XVLMForVQA(cfg("t", 6)).to(dev)
 student.l0_module.set_lagrangian_warmup_steps(100)
@@ -66,7 +68,7 @@ if "--ragged" in sys.argv:
     torch.cuda.synchronize(); dt = (time.perf_counter() - t_all) / steps
     rep = sum(1 for l in launches if l.startswith("hipGraph"))
     print(json.dumps({"workload": "VQA pruning fine-tune step, ragged epoch (questions 8..40 tokens, 1..10 answers each, bucket-padded)",
-                      "image_res": res, "batch": B, "steps": steps, "padded_shapes[q_len,a_len,rows]": sorted(shapes),
+                      "dropout": DROP, "launch": tr.last_launch, "image_res": res, "batch": B, "steps": steps, "padded_shapes[q_len,a_len,rows]": sorted(shapes),
                       "replayed_from_hipgraph": rep, "replay_frac": round(rep / len(launches), 4),
                       "host_ms_per_step": round(host_s / steps * 1e3, 2), "ms_per_step": round(dt * 1e3, 2),
                       "questions_per_s": round(B / dt, 1), "captured_pairs": len(tr._sgraphs),
@@ -85,6 +87,6 @@ K = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 8
 for _ in range(K): out = tr.step(batch)
 host = (time.perf_counter() - t0) / K      # host time per step (before the device has caught up)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
-print(json.dumps({"workload": "VQA pruning fine-tune step", "teacher_pipelined": pipe, "launch": tr.last_launch, "host_ms_per_step": round(host * 1e3, 2), "image_res": res, "batch": B, "answers": n,
+print(json.dumps({"workload": "VQA pruning fine-tune step", "dropout": DROP, "teacher_pipelined": pipe, "launch": tr.last_launch, "host_ms_per_step": round(host * 1e3, 2), "image_res": res, "batch": B, "answers": n,
                   "ms_per_step": round(dt * 1e3, 2), "questions_per_s": round(B / dt, 1),
                   "losses[total,answer,kd,lagrangian]": [round(float(x), 4) for x in out.tolist()]}))
