@@ -51,7 +51,8 @@ def score(model, z=None):
 MASKED = len(sys.argv) > 1 and sys.argv[1] == "masked"
 
 
-for keep in (1.0, 0.75, 0.5, 0.25):
+KEEPS = [float(v) for v in sys.argv[sys.argv.index("--keep") + 1].split(",")] if "--keep" in sys.argv else [1.0, 0.75, 0.5, 0.25]
+for keep in KEEPS:
     torch.manual_seed(0)
     model = EffXVLMforRetrieval(model_config(geom, "s")).to(dev).eval()
     n0 = sum(p.numel() for n, p in model.named_parameters() if not n.startswith("l0_module"))
