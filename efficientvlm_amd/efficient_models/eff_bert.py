@@ -55,6 +55,15 @@ def _p(config, name):
     return p
 
 
+def _run(gen):
+    """drive a *_gen generator to its end and return its value"""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as done:
+        return done.value
+
+
 class BertEmbeddings(nn.Module):
     """eff_bert.py:168-215"""
 
@@ -352,10 +361,17 @@ class BertEncoder(nn.Module):
         kv, slot = ops.merged_kv(enc, ws, bs, len(xl))
         return {i: (kv, 2 * d * n, slot) for n, i in enumerate(xl)}
 
-    def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
-                encoder_attention_mask=None, past_key_values=None, use_cache=None, output_attentions=False,
-                output_hidden_states=False, return_dict=True, mode="multi_modal", head_z=None, head_layer_z=None, mlp_z=None,
-                encoder_batch_index=None):
+    def forward(self, *args, **kwargs):
+        return _run(self.forward_gen(*args, **kwargs))
+
+    def forward_gen(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
+                    encoder_attention_mask=None, past_key_values=None, use_cache=None, output_attentions=False,
+                    output_hidden_states=False, return_dict=True, mode="multi_modal", head_z=None, head_layer_z=None, mlp_z=None,
+                    encoder_batch_index=None):
+        """forward() as a GENERATOR (extension, round 6): yields ("layer", i) behind every layer and returns forward()'s value
+        (StopIteration.value).  A trainer resumes it layer by layer where it wants the next piece issued - the pipelined
+        teacher's fusion pass beside successive hipGraph segments of the multi-GPU student step (trainer._capture_segments,
+        `late` placement); forward() drives it to the end."""
         all_hidden_states = () if output_hidden_states else None
         all_self_attentions = () if output_attentions else None
         all_cross_attentions = () if output_attentions else None
@@ -396,6 +412,7 @@ class BertEncoder(nn.Module):
                 all_self_attentions = all_self_attentions + (layer_outputs[1],)
                 if len(layer_outputs) > 3:
                     all_cross_attentions = all_cross_attentions + (layer_outputs[2],)
+            yield ("layer", i)
         if output_hidden_states:
             all_hidden_states = all_hidden_states + (hidden_states,)
         if not return_dict:
@@ -547,6 +564,17 @@ class BertModel(BertPreTrainedModel):
                 past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None,
                 return_dict=None, is_decoder=False, mode="multi_modal", head_z=None, head_layer_z=None, mlp_z=None,
                 encoder_batch_index=None):
+        return _run(self.forward_gen(input_ids, attention_mask, token_type_ids, position_ids, head_mask, inputs_embeds, encoder_embeds,
+                                     encoder_hidden_states, encoder_attention_mask, past_key_values, use_cache, output_attentions,
+                                     output_hidden_states, return_dict, is_decoder, mode, head_z, head_layer_z, mlp_z,
+                                     encoder_batch_index))
+
+    def forward_gen(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
+                    inputs_embeds=None, encoder_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                    past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None,
+                    return_dict=None, is_decoder=False, mode="multi_modal", head_z=None, head_layer_z=None, mlp_z=None,
+                    encoder_batch_index=None):
+        """forward() as a generator over its encoder's layers (BertEncoder.forward_gen); returns forward()'s value"""
         output_attentions = output_attentions if output_attentions is not None else self.config.output_attentions
         output_hidden_states = output_hidden_states if output_hidden_states is not None else self.config.output_hidden_states
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
@@ -586,12 +614,11 @@ class BertModel(BertPreTrainedModel):
                                                token_type_ids=token_type_ids, inputs_embeds=inputs_embeds)
         else:
             embedding_output = encoder_embeds
-        encoder_outputs = self.encoder(embedding_output, attention_mask=extended_attention_mask, head_mask=None,
-                                       encoder_hidden_states=encoder_hidden_states,
-                                       encoder_attention_mask=encoder_extended_attention_mask,
-                                       output_attentions=output_attentions, output_hidden_states=output_hidden_states,
-                                       return_dict=return_dict, mode=mode, head_z=head_z, head_layer_z=head_layer_z, mlp_z=mlp_z,
-                                       encoder_batch_index=encoder_batch_index)
+        encoder_outputs = yield from self.encoder.forward_gen(
+            embedding_output, attention_mask=extended_attention_mask, head_mask=None,
+            encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_extended_attention_mask,
+            output_attentions=output_attentions, output_hidden_states=output_hidden_states, return_dict=return_dict, mode=mode,
+            head_z=head_z, head_layer_z=head_layer_z, mlp_z=mlp_z, encoder_batch_index=encoder_batch_index)
         sequence_output = encoder_outputs[0]
         if not return_dict:
             return (sequence_output, None) + tuple(encoder_outputs[1:])

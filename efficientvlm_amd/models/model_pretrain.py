@@ -207,11 +207,23 @@ class XVLM(XVLMBase):
                 img_index = torch.cat([img_index, B + idx_to_group_img.view(-1)], 0)
                 sizes.append(B)
             img4 = img_index.to(torch.int32)             # (cast once here, not in every cross-attention)
-        f = core(encoder_embeds=txt_all, attention_mask=atts_all, encoder_hidden_states=enc_states,
-                 # (a general batch attends to every image token - get_vision_embeds' all-ones mask: no mask is built)
-                 encoder_attention_mask=None if region is None else torch.index_select(enc_atts, 0, img_index),
-                 encoder_batch_index=img4,
-                 return_dict=True, mode="fusion", output_attentions=True, output_hidden_states=True)
+        fkw = dict(encoder_embeds=txt_all, attention_mask=atts_all, encoder_hidden_states=enc_states,
+                   # (a general batch attends to every image token - get_vision_embeds' all-ones mask: no mask is built)
+                   encoder_attention_mask=None if region is None else torch.index_select(enc_atts, 0, img_index),
+                   encoder_batch_index=img4,
+                   return_dict=True, mode="fusion", output_attentions=True, output_hidden_states=True)
+        if hasattr(core, "forward_gen"):
+            # (round 6) the fusion pass LAYER BY LAYER: "fusion_layer_<i>" behind layer i - a trainer that spreads the frozen
+            # teacher over several hipGraph segments resumes it a few layers at a time (trainer._capture_segments, `late`)
+            gen = core.forward_gen(**fkw)
+            try:
+                while True:
+                    ph = next(gen)
+                    yield "fusion_layer_%d" % ph[1]
+            except StopIteration as done:
+                f = done.value
+        else:
+            f = core(**fkw)
         yield "fusion_done"
         # (the hidden-state / attention-map distillation terms depend on nothing past this point: a trainer that runs them
         # on the side stream - distill.kd_terms - forks from HERE, beside the task heads below)

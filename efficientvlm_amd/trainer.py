@@ -834,7 +834,7 @@ class GDTrainer(_StagedExchange):
         ops.reserve_tables()
         torch.cuda.synchronize()
         segs, state = [], {"g": None, "forked": tpipe is None, "joined": tpipe is None, "half": None,
-                           "late_left": ["text_done", "fusion_done", None]}
+                           "late_left": self._late_plan()}
         # the teacher in two halves (default): its image encoder beside the student's forward in the FIRST segment, its text /
         # fusion passes in the segment behind the ITC gather - each half about as long as the student work it shares the
         # chip with (one fork behind the gather leaves the first segment without a partner and the teacher outlasts the
@@ -953,6 +953,23 @@ class GDTrainer(_StagedExchange):
             print("[efficientvlm_amd] segments:", [kind if kind != "reduce" else f"reduce({sum(r.numel() for r in item) * 4 / 1e6:.0f} MB)"
                                                    for kind, item in segs], file=sys.stderr)
         return dict(segs=segs, out=out, kd=kd, last_reduce=last_reduce)
+
+    def _late_plan(self):
+        """`late` placement: the phases up to which the teacher's forward (suspended behind its image encoder) is resumed beside
+        the successive segments of the student's backward - one entry per gradient-stage cut, None = the rest.  Round 6: the
+        fusion pass resumes LAYER BY LAYER (BertEncoder.forward_gen), so its 2.6 ms spread over the three ViT-backward segments
+        (~1.1 ms each) and the optimiser segment instead of sitting whole beside one of them: [text pass + first fusion layer]
+        [2 layers] [2 layers] [last layer + heads + parking].  EVLM_SEG_LATE_PLAN="text_done,fusion_done" restores round 5's."""
+        env = os.environ.get("EVLM_SEG_LATE_PLAN")
+        if env:
+            return [p for p in env.split(",") if p] + [None]
+        cfg = getattr(getattr(self.teacher, "text_encoder", None), "config", None)
+        fl, n = getattr(cfg, "fusion_layer", None), getattr(cfg, "num_hidden_layers", None)
+        if fl is None or n is None or n - fl < 4:
+            return ["text_done", "fusion_done", None]
+        per = (n - fl) / 3.0                                   # fusion layers per ViT-backward segment, the first shares with the text pass
+        marks = [fl + max(0, int(round(per * 0.5)) - 1), fl + int(round(per * 1.5)) - 1, fl + int(round(per * 2.5)) - 1]
+        return ["fusion_layer_%d" % m for m in marks] + [None]
 
     def _ranks_agree(self, ok):
         """did the capture succeed on EVERY rank?  (MIN all-reduce of the local flag: a rank that fell back to the eager

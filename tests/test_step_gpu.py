@@ -328,8 +328,8 @@ def test_benchmarked_configuration_matches_the_oracle(B, monkeypatch):
 def test_forward_phases_generator_equals_forward():
     """XVLM.forward_phases (the batched forward as a generator over its phases - what lets a trainer issue the pipelined
     teacher's image encoder and its text / fusion passes in two different hipGraph segments, and a trainer fork the teacher's
-    branch at a phase of the student's forward) yields "vision_done", "text_done", "fusion_done" and returns forward()'s
-    dict, tensor for tensor"""
+    branch at a phase of the student's forward) yields "vision_done", "text_done", the fusion layers, "fusion_done" and returns
+    forward()'s dict, tensor for tensor"""
     from efficientvlm_amd import distill
     from efficientvlm_amd.runtime import compute
     geom = synth.GEOMS["tiny"]
@@ -346,7 +346,10 @@ def test_forward_phases_generator_equals_forward():
                 names.append(next(gen))
         except StopIteration as done:
             out = done.value
-    assert names == ["vision_done", "text_done", "fusion_done"]
+    # (round 6: the fusion pass is resumable LAYER BY LAYER - "fusion_layer_<i>" behind layer i of the teacher's 6 + 6 layers)
+    assert [n for n in names if not n.startswith("fusion_layer_")] == ["vision_done", "text_done", "fusion_done"]
+    assert [n for n in names if n.startswith("fusion_layer_")] == ["fusion_layer_%d" % i for i in range(6, 12)]
+    assert names.index("fusion_layer_6") > names.index("text_done") and names.index("fusion_layer_11") < names.index("fusion_done")
     a, b = list(distill._tensors(ref)), list(distill._tensors(out))
     assert len(a) == len(b) and len(a) > 20
     for x, y in zip(a, b):

@@ -209,6 +209,12 @@ for rep in range(args.reps):
     run("nosplit: segments, cuts=all, whole teacher forward behind the gather", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER_SPLIT": "0"})
     run("nosplit_sim: same + simulated wire", env={"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER_SPLIT": "0"}, sim=True)
     run("cuts_all_noex: same, no gradient exchange", env={"EVLM_DP_CUTS": "all"}, patch=no_reduce)
+    # `late` placement (round 6: the teacher's fusion pass resumed layer by layer beside the ViT-backward segments)
+    late = {"EVLM_DP_CUTS": "all", "EVLM_SEG_TEACHER_SPLIT": "late"}
+    run("late: segments, teacher image encoder behind the gather, text / fusion layers beside the ViT backward", env=late)
+    run("late_sim: same + simulated wire", env=late, sim=True)
+    run("late_noex: same, no gradient exchange", env=late, patch=no_reduce)
+    run("late5: round 5's late plan (text pass | whole fusion pass | heads)", env=dict(late, EVLM_SEG_LATE_PLAN="text_done,fusion_done"))
     run("cuts_all_sleep: the simulated wire alone (no process-group calls)", env={"EVLM_DP_CUTS": "all"}, patch=sleep_only, sim=True)
     run("cuts_all_sleepfresh: same on a fresh stream", env={"EVLM_DP_CUTS": "all"}, patch=sleep_fresh, sim=True)
     run("cuts_all_nccl: simulated wire ON the process group's stream", env={"EVLM_DP_CUTS": "all"}, patch=sim_on_nccl(False), sim="nccl")
