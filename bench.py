@@ -333,9 +333,35 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _visible_gpus():
+    """GPUs this node shows, counted WITHOUT bringing the HIP runtime up in this (parent) process: the kfd topology's nodes
+    with SIMDs (CPUs have none), cut by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  (torch.cuda.device_count() falls
+    back to hipGetDeviceCount on builds without amdsmi - harmless here, the parent only starts children, but it would make
+    "the parent never touches the GPU" untrue.)  Falls back to torch's count when the topology is not readable."""
+    n = None
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for d in os.listdir(base):
+            with open(os.path.join(base, d, "properties")) as f:
+                props = dict(l.split()[:2] for l in f if len(l.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except (OSError, ValueError):
+        n = None
+    if n is None:
+        return torch.cuda.device_count()
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(gpus, argv, run=subprocess.run):
     """parent of an N > 1 run started without a launcher: one child (the launcher module), N grandchildren (the ranks)"""
-    have = torch.cuda.device_count()             # (counting devices does not initialise the GPU)
+    have = _visible_gpus()
+    if have < gpus:                              # (second opinion before refusing: the runtime's own count)
+        have = max(have, torch.cuda.device_count())
     if have < gpus and not os.environ.get("EVLM_BENCH_SHARE_GPU"):
         print(f"bench.py: --gpus {gpus} but this node shows {have} GPU(s)  (EVLM_BENCH_SHARE_GPU=1: a dry run of the launch "
               f"contract with every rank on device 0 over gloo)", file=sys.stderr)

@@ -45,10 +45,18 @@ def _quiesce_collectives():
     trainer, so draining the device and giving the watchdog three polls to retire the finished Works costs ~0.3 s each."""
     if _QUIESCE_S <= 0 or not torch.cuda.is_available() or not dist.is_available() or not dist.is_initialized():
         return
-    if dist.get_backend() != "nccl":
-        return
+    # (any RCCL group of the process has a watchdog: the default group or a sub-group a reducer was given)
+    groups = [None] + [g for g in _RCCL_GROUPS if g is not None]
+    try:
+        if not any(dist.get_backend(g) == "nccl" for g in groups):
+            return
+    except (RuntimeError, ValueError):
+        pass
     torch.cuda.synchronize()
     time.sleep(_QUIESCE_S)
+
+
+_RCCL_GROUPS = []      # process groups handed to a GradReducer (registered there): _quiesce_collectives looks at them too
 
 
 @contextlib.contextmanager
@@ -94,6 +102,8 @@ class GradReducer:
     def __init__(self, flat_grads, bucket_bytes=64 << 20, compress=None, group=None, force=False, prescaled=False):
         self.flat = list(flat_grads)
         self.group = group
+        if group is not None and group not in _RCCL_GROUPS:
+            _RCCL_GROUPS.append(group)
         self.compress = compress
         self.bucket_bytes = bucket_bytes
         ready = dist.is_available() and dist.is_initialized()
