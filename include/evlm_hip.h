@@ -191,7 +191,9 @@ typedef struct {
   int causal;                   /* != 0: additionally add -10000 where key > query - the decoder's causal mask
                                    (get_extended_attention_mask is_decoder branch, eff_bert.py:975-996); needs Lq == Lk */
   float dropout_p;              /* attention_probs_dropout_prob (eff_bert.py:242,346): O = ((P .* keep / (1-p)) V) * gate, while
-                                   the map written to P stays the un-dropped softmax (:338-361).  0 = off */
+                                   the map written to P stays the un-dropped softmax (:338-361).  0 = off.  ABI 9: served by the
+                                   bf16 MFMA kernels too (whole-row, shared-K/V grouped, streaming, map-writing), which regenerate
+                                   the mask per (batch, head, query, 8 consecutive keys) in registers */
   const int64_t* rng_state;     /* device int64[2] {seed, step} (see evlm_dropout); required when dropout_p > 0 */
   uint32_t call_id;             /* identifies this dropout site; the backward call passes the same triple */
   /* fused attention-map distillation (GeneralDistill.py:63-69: MSELoss(student_att, teacher_att) * att.shape[-1]): with
@@ -205,7 +207,8 @@ typedef struct {
      s_k = (scale * q.k + mask) * log2(e).  With it the backward RECOMPUTES the probabilities from Q and K in fp32
      (evlm_attn_bwd_args.lse) and P may be NULL: no [B, H, Lq, Lk] map is written or read back unless a caller wants it
      (the reference keeps softmax in fp32 under Apex O1; a bf16-stored P costs 13-36 % of the q / k gradients' norm).
-     bf16 MFMA path, Lk <= 224 or 417 <= Lk <= 928, no dropout: evlm_attention_lse_supported(). */
+     bf16 MFMA path, Lk <= 224 or 417 <= Lk <= 928 (ABI 9: with or without dropout - the kernels regenerate the keep-mask):
+     evlm_attention_lse_supported(). */
   float* lse;
   int Bkv;                      /* with kv_index: number of K/V batch rows (0 = unknown).  When given, problems in which
                                    several short query batches share a K/V row run one workgroup per (K/V row, head) that
@@ -225,7 +228,8 @@ int evlm_attention_fwd(const evlm_attn_fwd_args* a, void* stream);
 
 /* backward: given dO and (optionally) an external gradient dP_ext on the probability map (from the
  * attention-map KD loss), produce dQ, dK, dV (+ dgate[H] accumulated, f32).  dS ([B,H,Lq,Lk], dtype) is a
- * caller-provided workspace; it may be NULL for bf16 self-attention problems (no kv_index, head dim 64, no dropout) with
+ * caller-provided workspace; it may be NULL for bf16 self-attention problems (no kv_index, head dim 64; with dropout: the lse form
+ * and Lq, Lk <= 64) with
  * Lq, Lk <= 224, which run in one pass with dS kept in LDS (any other problem then fails with an error, never a fault).  With kv_index (several query batches sharing one K/V row: the image tokens of the
  * positive, hard-negative and MLM fusion passes) dK/dV are [Bkv,Lk,H,dh]: the bf16 MFMA path sums the sharing query
  * batches inside one workgroup per K/V row (deterministic); the generic path ACCUMULATES with f32 atomics and then

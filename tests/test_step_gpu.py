@@ -666,7 +666,10 @@ XVLMBase._sample_negatives = fixed_negatives
 geom = synth.GEOMS["tiny"]
 s_cfg, t_cfg = O.model_cfg(geom, "s"), O.model_cfg(geom, "t")
 B = 4
-student, teacher = EffXVLMforRetrieval(model_config(geom, "s")), TeacherITR(model_config(geom, "t"))
+# EVLM_TEST_RECIPE=1: the reference's real recipe - stock BERT dropout 0.1 on the student (each rank its own mask stream) and
+# batches in 'longest' padding whose real text length differs per rank and step, fed through data.bucket_pad_itr
+RECIPE = bool(os.environ.get("EVLM_TEST_RECIPE"))
+student, teacher = EffXVLMforRetrieval(model_config(geom, "s", dropout=0.1 if RECIPE else 0.0)), TeacherITR(model_config(geom, "t"))
 load_det_weights(student, schema.xvlm_schema(s_cfg, geom["max_pos"], mlm=False, bbox=False, l0=True), 51 + 7 * rank, geom["std"])
 load_det_weights(teacher, schema.xvlm_schema(t_cfg, geom["max_pos"], mlm=False, bbox=False), 52, geom["std"])
 gen = torch.Generator().manual_seed(8 + rank)                # rank-specific gate parameters too: the broadcast levels them
@@ -679,6 +682,14 @@ tr = ITRTrainer(student, teacher, lr=1e-3, reg_learning_rate=0.05, dtype=torch.f
 assert tr.reducer.active and tr.reducer.world == 2
 batches = [{k: v.cuda() for k, v in synth.make_batch(geom, B, seed=30 + i + 40 * rank, ragged=True).items()
             if k in ("image", "text_ids", "text_atts")} for i in range(3)]
+if RECIPE:
+    from efficientvlm_amd import ops
+    from efficientvlm_amd.data import bucket_pad_itr
+    ops.dropout_seed(100 + rank)
+    batches = [bucket_pad_itr({k: v.cuda() for k, v in synth.make_batch(dict(geom, L=5 + (i + 2 * rank) % 4, M=2), B, seed=30 + i + 40 * rank,
+                                                                         ragged=True).items() if k in ("image", "text_ids", "text_atts")})
+               for i in range(3)]
+    assert len({int(b["extents"][0]) for b in batches}) == 3 and all(b["text_ids"].shape[1] == 16 for b in batches)
 idx = torch.arange(B).cuda() + B * rank
 out, launches = [], []
 for c in range(8):
@@ -699,19 +710,25 @@ print("RESULT " + json.dumps({"rank": rank, "out": out, "digest": h.hexdigest(),
 """
 
 
-def test_two_ranks_of_the_itr_pruning_step_stay_bit_identical():
+@pytest.mark.parametrize("recipe", [False, True], ids=["fixed shapes, p = 0", "bucket-padded ragged batches, dropout 0.1"])
+def test_two_ranks_of_the_itr_pruning_step_stay_bit_identical(recipe):
     """the ITR pruning fine-tune (ITRTrainer: three optimisers, L0 gate parameters and Lagrange multipliers travelling in the
     LAST gradient stage, teacher prefetched through hipGraphs) on TWO ranks - two processes on the one GPU, gloo: students
     and gate parameters built differently per rank are levelled by the constructor's broadcast, every rank draws its own
     gate noise and batches; the student step replays as hipGraph SEGMENTS around its collectives (two gathers - ITC features,
     image ids - and the staged all-reduces: first step per prefetch parity eager, second captured, then replays); after seven
-    optimiser steps every student tensor (gates and multipliers included) is bit-identical on the two ranks"""
+    optimiser steps every student tensor (gates and multipliers included) is bit-identical on the two ranks.  recipe (round 6):
+    the same under the reference's real recipe - dropout 0.1 on the student with a mask stream per rank, batches whose real
+    text length differs per rank and step, bucket-padded: one segment chain per prefetch parity serves them all"""
     import json, os, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     procs = []
     for rank in (0, 1):
         env = dict(os.environ, EVLM_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK=str(rank), WORLD_SIZE="2", GLOO_SOCKET_IFNAME="lo")
         env.pop("EVLM_FORCE_REDUCE", None)
+        env.pop("EVLM_TEST_RECIPE", None)
+        if recipe:
+            env["EVLM_TEST_RECIPE"] = "1"
         procs.append(subprocess.Popen([sys.executable, "-c", _DP2_ITR_SCRIPT], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     res = []

@@ -47,8 +47,8 @@ if "--ragged" in sys.argv:
             pool[L] = {k: v.to(dev) for k, v in synth.make_batch(g, B, seed=100 + L, ragged=True).items() if k in ("image", "text_ids", "text_atts")}
         return L, bucket_pad_itr(pool[L])
     launches, host_s, shapes, t_all = [], 0.0, set(), None
-    for s in range(steps + 16):
-        if s == 16:
+    for s in range(steps + 32):
+        if s == 32:
             torch.cuda.synchronize(); t_all = time.perf_counter(); launches, host_s = [], 0.0
         L, b = ragged_batch()
         shapes.add(int(b["text_ids"].shape[1]))
