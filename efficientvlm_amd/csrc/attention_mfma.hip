@@ -504,6 +504,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_kernel(MAttnF a) {
   }
 }
 
+#ifdef EVLM_EXPERIMENTAL_ATTN_PERSIST      // (make EXPERIMENTAL=1: 23.7 against 21.2 us on the GD shape - profiles/r05_xattn_persist.md)
 // ---------------------------------------------------------------------------------------------------------------------
 // PERSISTENT form of the grouped cross-attention forward (round 5).  The kernel above is one workgroup per (K/V row, head):
 // it stages 56 KiB, waits for them, then computes - two workgroups per CU, 768 of them on 512 slots, and while a workgroup
@@ -732,6 +733,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_persist_kernel(MAttn
     }
   }
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Long key sequences (225..928 keys: the ViT at 384 x 384 / 480 x 480, cross-attention onto those image tokens) when
@@ -1308,6 +1311,7 @@ static bool launch_fwd_grouped(const MAttnF& f, int Bkv, hipStream_t stream) {
   // persistent, double-buffered form (round 5): one workgroup per CU walks the (K/V row, head) items - EVLM_ATTN_GROUP_PERSIST=1.
   // Measured 23.7 us against 21.2 us for one workgroup per item on the GD shape (profiles/r05_xattn_persist.md): opt-in.
   // The index copy bounds B (a query batch count of 4 096 is 16 KiB of LDS)
+#ifdef EVLM_EXPERIMENTAL_ATTN_PERSIST
   const char* pe = getenv("EVLM_ATTN_GROUP_PERSIST");     // (A/B switch, read per call; measured SLOWER: opt-in)
   if (pe && atoi(pe) == 1 && f.B <= 4096 && !(f.drop_p > 0.f)) {
     const int nitems = Bkv * f.H;
@@ -1323,6 +1327,7 @@ static bool launch_fwd_grouped(const MAttnF& f, int Bkv, hipStream_t stream) {
     }
     return true;
   }
+#endif
   const size_t lds = (size_t)2 * NT * 16 * 128 + (size_t)NW * NT * 16 * sizeof(float);
   dim3 grid(1, f.H, Bkv), block(64 * NW);
 #define GROUPED_LAUNCH(LSE_, DROP_)                                                                                       \

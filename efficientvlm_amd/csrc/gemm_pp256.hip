@@ -618,10 +618,12 @@ template <bool PT, bool QT, int OUT>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_kernel(GemmP g) {
   pp256_body<PT, QT, OUT, false>(g, nullptr);
 }
+#ifdef EVLM_EXPERIMENTAL_SK      // (make EXPERIMENTAL=1: measured 3.6 x slower - register allocation around the partial-tile epilogue)
 template <bool QT>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_sk_kernel(GemmP g) {
   pp256_body<false, QT, 0, false, true>(g, nullptr);
 }
+#endif
 __global__ __launch_bounds__(512, 1) void gemm_bf16_pp256_grouped_kernel(GemmP g, PPGroup grp) {
   pp256_body<true, true, 1, true>(g, &grp);
 }
@@ -668,6 +670,9 @@ int evlm_gemm_pp256_splits(const GemmP& g) {
 // stream-K pays when one round of 256x256 tiles leaves a good part of the chip idle and K is long enough to cut
 bool evlm_gemm_pp256_streamk(const GemmP& g, int pt) {
   // OPT-IN (EVLM_PP256_SK=1): correct and deterministic (tests), but not yet faster - profiles/r02_streamk.md
+#ifndef EVLM_EXPERIMENTAL_SK
+  return false;                            // (the kernel is out of the default build: make EXPERIMENTAL=1)
+#endif
   static const int on = getenv("EVLM_PP256_SK") ? atoi(getenv("EVLM_PP256_SK")) : 0;
   if (!on || !g.sk_ws || g.c_f32 || pt) return false;
   const int tiles = ceil_div(g.I, 256) * ceil_div(g.J, 256), nt = g.K / 64;
@@ -746,6 +751,7 @@ int evlm_gemm_pp256_launch(GemmP& g, int pt, int qt, hipStream_t stream) {
   const int lds = 2 * PPB + 8 * 4096;
   g.tiles_i = ceil_div(g.I, 256); g.tiles_j = ceil_div(g.J, 256); g.bare_f32 = g.c_f32;
   g.sk = evlm_gemm_pp256_streamk(g, pt) ? 1 : 0;
+#ifdef EVLM_EXPERIMENTAL_SK
   if (g.sk) {
     g.kt_per_split = g.K / 64;
 #define PP_LAUNCH_SK(QT_)                                                                                     \
@@ -763,6 +769,7 @@ int evlm_gemm_pp256_launch(GemmP& g, int pt, int qt, hipStream_t stream) {
 #undef PP_LAUNCH_SK
     return 0;
   }
+#endif
   const int tiles = g.tiles_i * g.tiles_j, nt = g.K / 64;
   const int splits = evlm_gemm_pp256_splits(g);
   g.kt_per_split = ceil_div(nt, splits);
