@@ -69,6 +69,17 @@ if "--ragged" in sys.argv:
         if out is not None:
             launches.append(tr.last_launch)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t_all) / steps
+    # host ISSUE time per step, measured with the device idle at every call (in the loop above the host runs ahead until the
+    # launch queue pushes back: its time per call then converges to the device's)
+    host_s = 0.0
+    for s in range(40):
+        b = feed[rnd.randrange(48)]
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = tr.step(b)
+        host_s += time.perf_counter() - t0
+        launches.append(tr.last_launch)
+    host_s *= steps / 40.0
+    torch.cuda.synchronize()
     rep = sum(1 for l in launches if l.startswith("hipGraph"))
     print(json.dumps({"workload": "VQA pruning fine-tune step, ragged epoch (questions 8..40 tokens, 1..10 answers each, bucket-padded)",
                       "dropout": DROP, "launch": tr.last_launch, "image_res": res, "batch": B, "steps": steps, "padded_shapes[q_len,a_len,rows]": sorted(shapes),
