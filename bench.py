@@ -451,6 +451,16 @@ def main():
     if pipelined:
         trainer.step(batches[0])          # primes the pipeline (teacher outputs of the first batch); not a step
         it = 1
+    if not args.no_graph:
+        # untimed and uncounted: step until BOTH teacher-prefetch parities of the step have been captured (the joint graph on
+        # one GPU, the segment chain under a live reducer) - whatever --warmup the caller asks for, no capture falls into the
+        # warm-up's tail or the timed region.  (At most 6 steps; a trainer that steps eagerly - a capture the stack refused -
+        # stops the loop through its own flag.)
+        for _ in range(6):
+            have = len(getattr(trainer, "_joint", None) or {}) + len(getattr(trainer, "_seg", None) or {})
+            if have >= 2 or getattr(trainer, "_segments_broken", False) or not pipelined:
+                break
+            trainer.step(batches[it % 4]); it += 1
 
     for _ in range(args.warmup):
         out = trainer.step(batches[it % 4]); it += 1
