@@ -12,7 +12,10 @@ import bench
 geom = synth.GEOMS["full"]; dev = torch.device("cuda")
 KIND = next((a for a in sys.argv[1:] if a in ("gd", "itr", "vqa")), "gd")       # which step: GD (default), ITR-384, VQA-480
 if KIND == "gd":
-    s, t = bench.build(geom, dev, 1234)
+    # --dropout P: the student BERT's stock training-mode dropout (the ATen list must not grow: no index_select of K / V, no
+    # separate mask passes - the masks are regenerated inside the attention kernels and the GEMM epilogues)
+    DROP = float(sys.argv[sys.argv.index("--dropout") + 1]) if "--dropout" in sys.argv else 0.0
+    s, t = bench.build(geom, dev, 1234, dropout=DROP)
     # (teacher pipelined one batch ahead, as bench.py runs it: the fused distillation paths are armed; launched eagerly)
     tr = GDTrainer(s, t, dtype=torch.bfloat16, use_graph=False, pipeline_teacher=True)
     batch = {k: v.to(dev) for k, v in synth.make_batch(geom, 64, seed=42).items()}
