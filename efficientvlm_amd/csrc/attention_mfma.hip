@@ -2456,8 +2456,8 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
       f.Pw = (bf16*)a->P_ws;
       f.P = (const bf16*)a->P_ws;
       f.p_dropped = 1;                                    // (kernel A writes P .* M into the workspace)
-    } else if (!a->P && !bwd_dq_stream_applies(f))       // (the streaming pair needs neither: kernel B rebuilds the map)
-      return evlm_set_error("evlm_attention_bwd: the two-kernel recomputing path needs P or the P_ws workspace");
+    } else if (!a->P && !bwd_dq_stream_applies(f) && a->Lk > 224)      // (the streaming pair needs neither: kernel B rebuilds the map;
+      return evlm_set_error("evlm_attention_bwd: the two-kernel recomputing path needs P or the P_ws workspace");   // round 6: so do <= 224 keys)
     // (a grouped-by-K/V-row form of kernel A - the backward counterpart of attn_fwd_grouped_kernel - was measured 20 %
     // SLOWER than this per-batch launch on the GD shape, tools/attn_bench.py: a backward task is VALU-bound work of ~20 k
     // cycles per wave, so the staging it would share is a small part of it, and 256 registers leave one workgroup per CU)

@@ -1240,8 +1240,12 @@ class _Attention(torch.autograd.Function):
         streams = (lse is not None and Lk > 224 and Lk <= 928 and not ctx.causal and O_fwd is not None and dPc is None
                    and ((kd_base is None and t_qkv is None) or dkd is None or rkd is not None) and tdt == torch.bfloat16 and dh == 64
                    and not env_on("EVLM_ATTN_NO_STREAM") and not env_on("EVLM_ATTN_STREAM_PWS"))
+        # round 6 (EVLM_ATTN_KB_REBUILD=1, A/B): on <= 224 keys, too, kernel B may rebuild the probabilities from Q, K and the row lse
+        # instead of reading a workspace kernel A writes (the cross-attention backward of the GD step: 2 x 37 MB per layer)
+        kb_rebuild = (env_on("EVLM_ATTN_KB_REBUILD") and lse is not None and not single_pass and Lk <= 224 and P is None
+                      and tdt == torch.bfloat16 and dh == 64)
         P_ws = (torch.empty((B, H, Lq, Lkp), dtype=tdt, device=dev)
-                if (lse is not None and not single_pass and not streams) else None)
+                if (lse is not None and not single_pass and not streams and not kb_rebuild) else None)
         gslot = ctx.gate_slot if (g32 is not None and ctx.gate_slot is not None
                                   and ctx.gate_slot[0].row(ctx.gate_slot[1]).numel() == H) else None
         dgate = (gslot[0].row(gslot[1]) if gslot is not None
