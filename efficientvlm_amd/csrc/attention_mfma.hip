@@ -7,6 +7,7 @@
 //                    operands), V^T comes from a row-major [key][d] LDS tile through ds_read_b64_tr_b16.
 // The probability map is an OUTPUT (the KD losses read it): rows are written once, with stride ldpr (padding zeroed).
 #include "common.h"
+#include <type_traits>
 
 struct MAttnF {
   const bf16* Q; const bf16* K; const bf16* V; const int32_t* kv_index; const float* mask; const float* gate;
@@ -1916,7 +1917,7 @@ static bool launch_bwd_dq_stream(MAttnB& f, hipStream_t stream) {
   if (!bwd_dq_stream_applies(f)) return false;
   const char* keep = getenv("EVLM_ATTN_STREAM_PWS");       // (A/B switch) 1: kernel B reads the map from the workspace
   if (!(keep && atoi(keep))) { f.P = nullptr; f.Pw = nullptr; }
-  constexpr int KB = 128, NW = 8;
+  constexpr int KB = 128, NW = 8;      // (NW = 4, two workgroups per CU: 388 against 367 us at 577 keys, round 6)
   const int nblk = (f.Lk + KB - 1) / KB, qtiles = (f.Lq + 15) / 16;
   dim3 grid((qtiles + NW - 1) / NW, f.H, f.B), block(64 * NW);
   if (f.Tq) {                                            // the teacher's map rebuilt in the kernel: a third tile per buffer
@@ -2107,6 +2108,163 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(MAttnB a) {
       *reinterpret_cast<bf16x4*>(dVr + dt * 16 + g * 4) = vv;
     }
   }
+}
+
+// Kernel B, STREAMED (round 6): the form of the kernel above for self-attention whose map is rebuilt (no stored P, row lse
+// given, no kv_index, no dropout - the ViT layers at 577 / 901 tokens of the ITR / VQA steps).  Same arithmetic, same operands
+// in the same k-slots, same order of the sums over the query chunks (bit-identical results); what changes is how a chunk
+// reaches the MFMAs.  The old loop was  barrier / 4 register-staged ds_writes / barrier / 20 transposing reads each followed
+// by its own `s_waitcnt lgkmcnt(0)` and one MFMA  (rocprofv3 at 64 x 12 x 577: 28 % of the wave cycles in issue stalls, 41 %
+// parked at a wait, matrix pipe 11 % busy).  Here
+//   * the Q / dO / dS tiles of chunk i+1 arrive by LDS-DMA into the other half of a double buffer while chunk i is multiplied
+//     (no staging registers, no ds_writes, ONE barrier per chunk);
+//   * all 20 transposing reads of a chunk are issued back to back (inline asm, counted waits: the dK operands are complete at
+//     lgkmcnt(10), the dV operands at 0), the 8 MFMAs follow in two groups;
+//   * workgroups of one (batch, head) share an XCD (its Q and dO are read by ceil(Lk / 64) workgroups).
+// Rows of the last chunk beyond Lq: the DMA reads row Lq-1 again; their P is zero by construction and their dS rows are
+// zeroed in LDS before use.
+template <int OFF> __device__ __forceinline__ bf16x8 tr_pair_a(uint32_t addr) {   // two transposing reads, rows 4 apart
+  bf16x4 t0, t1;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t0) : "v"(addr), "i"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t1) : "v"(addr), "i"(OFF + 512));
+  bf16x8 out;
+  out[0] = t0[0]; out[1] = t0[1]; out[2] = t0[2]; out[3] = t0[3];
+  out[4] = t1[0]; out[5] = t1[1]; out[6] = t1[2]; out[7] = t1[3];
+  return out;
+}
+#define DKVS_TILE 4096
+#define DKVS_BUF (3 * DKVS_TILE)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_dkv_stream_kernel(MAttnB a) {
+  __shared__ __attribute__((aligned(16))) char sm[2 * DKVS_BUF + DKVS_TILE];      // 2 x (Q, dO, dS) + P
+  const int gx = gridDim.x, nwg = gx * gridDim.y * gridDim.z;
+  int lid = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int k0 = (lid % gx) * 64, h = (lid / gx) % a.H, b = lid / (gx * a.H);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
+  const float sc = a.scale * LOG2E;
+  bf16x8 kf[2];
+  {
+    const int krow = min(k0 + wave * 16 + ql, a.Lk - 1);             // A operand: row = key, k-slots = 8 head-dim values
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 v = *reinterpret_cast<const uint4*>(a.K + ((size_t)b * a.Lk + krow) * a.ldk + h * DH + ks * 32 + g * 8);
+      kf[ks] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+  }
+  float mk[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int key = k0 + wave * 16 + 4 * g + r;
+    mk[r] = (key < a.Lk ? (a.mask ? a.mask[(size_t)b * a.Lk + key] : 0.f) : -1e30f) * LOG2E;
+  }
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const bf16* Qb = a.Q + (size_t)b * a.Lq * a.ldq + h * DH;
+  const bf16* dOb = a.dO + (size_t)b * a.Lq * a.ldo + h * DH;
+  const bf16* dSb = a.dS + ((size_t)b * a.H + h) * a.Lq * a.ldpr;
+  const float* lseb = a.lse + ((size_t)b * a.H + h) * a.Lq;
+  // DMA: this wave fills rows 8 wave .. 8 wave + 7 of each tile; the lane's LDS slot (row, cs) takes source chunk p_swz(row, cs)
+  const int srow = wave * 8 + (lane >> 3), sc8 = p_swz(srow, lane & 7) * 8;
+  const int sck = min(k0 + sc8, a.ldpr - 8);                          // (columns past the map's row: any in-bounds piece)
+  auto stage = [&](int q0, char* buf) {
+    const size_t r = (size_t)min(q0 + srow, a.Lq - 1);
+    char* dst = buf + wave * 8 * 128;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Qb + r * a.ldq + sc8),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dOb + r * a.ldo + sc8),
+                                     (__attribute__((address_space(3))) void*)(dst + DKVS_TILE), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dSb + r * a.ldpr + sck),
+                                     (__attribute__((address_space(3))) void*)(dst + 2 * DKVS_TILE), 16, 0, 0);
+  };
+  // transposing-read addresses of buffer 0 (qcol_frag's map): column tile ct -> chunk slot p_swz(row, 2 ct + (p >> 1)); the
+  // second read of a pair sits 4 rows = 512 bytes further (same swizzle: p_swz ignores that row bit)
+  const uint32_t sb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)sm;
+  uint32_t tra[4];
+  {
+    const int q = ql >> 2, pp = ql & 3, row = g * 8 + q;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) tra[ct] = sb + row * 128 + p_swz(row, ct * 2 + (pp >> 1)) * 16 + ((pp & 1) << 3);
+  }
+  const uint32_t trw = sb + (g * 8 + (ql >> 2)) * 128 + p_swz(g * 8 + (ql >> 2), wave * 2 + ((ql & 3) >> 1)) * 16 + ((ql & 1) << 3);
+  float nlq[2] = {0.f, 0.f};
+  auto fetch_lse = [&](int q0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) nlq[j] = (q0 + 16 * j + ql < a.Lq) ? lseb[q0 + 16 * j + ql] : 0.f;
+  };
+  stage(0, sm);
+  fetch_lse(0);
+  auto chunk = [&](int q0, auto bufc) {
+    constexpr int BO = decltype(bufc)::value * DKVS_BUF;
+    stage_wait();
+    __syncthreads();                          // chunk q0 has landed; every wave is done with the other buffer
+    const float lq[2] = {nlq[0], nlq[1]};
+    if (q0 + 32 < a.Lq) {
+      stage(q0 + 32, sm + (DKVS_BUF - BO));
+      fetch_lse(q0 + 32);
+    } else if (q0 + 32 > a.Lq) {              // ragged last chunk: zero the dS rows of the queries that do not exist
+      const int zr = threadIdx.x >> 3;
+      if (q0 + zr >= a.Lq) *reinterpret_cast<uint4*>(sm + BO + 2 * DKVS_TILE + zr * 128 + (threadIdx.x & 7) * 16) = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+    }
+    const char* Qs = sm + BO;
+    char* Ps = sm + 2 * DKVS_BUF;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {             // P of this wave's 16 keys x 32 queries, into the wave's OWN columns of the P tile
+      f32x4 sa = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int row = 16 * j + ql;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(Qs + row * 128 + p_swz(row, ks * 4 + g) * 16);
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qfr, sa, 0, 0, 0);
+      }
+      const bool qv = q0 + row < a.Lq;
+      bf16x4 p4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p4[r] = (bf16)(qv ? EXP2(fmaf(sa[r], sc, mk[r]) - lq[j]) : 0.f);
+      *reinterpret_cast<bf16x4*>(Ps + row * 128 + p_swz(row, 2 * wave + (g >> 1)) * 16 + (g & 1) * 8) = p4;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 fq[4], fo[4];
+    const bf16x8 bS = tr_pair_a<BO + 2 * DKVS_TILE>(trw);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) fq[dt] = tr_pair_a<BO>(tra[dt]);
+    const bf16x8 bP = tr_pair_a<2 * DKVS_BUF>(trw);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) fo[dt] = tr_pair_a<BO + DKVS_TILE>(tra[dt]);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[dt], bS, dk[dt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo[dt], bP, dv[dt], 0, 0, 0);
+  };
+  for (int q0 = 0; q0 < a.Lq; q0 += 64) {
+    chunk(q0, std::integral_constant<int, 0>());
+    if (q0 + 32 < a.Lq) chunk(q0 + 32, std::integral_constant<int, 1>());
+  }
+  const int key = k0 + wave * 16 + ql;
+  if (key < a.Lk) {
+    const float gz = a.gate ? a.gate[h] : 1.0f;
+    bf16* dKr = a.dK + ((size_t)b * a.Lk + key) * a.lddk + h * DH;
+    bf16* dVr = a.dV + ((size_t)b * a.Lk + key) * a.lddv + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 kv = {(bf16)(dk[dt][0] * a.scale), (bf16)(dk[dt][1] * a.scale), (bf16)(dk[dt][2] * a.scale), (bf16)(dk[dt][3] * a.scale)};
+      bf16x4 vv = {(bf16)(dv[dt][0] * gz), (bf16)(dv[dt][1] * gz), (bf16)(dv[dt][2] * gz), (bf16)(dv[dt][3] * gz)};
+      *reinterpret_cast<bf16x4*>(dKr + dt * 16 + g * 4) = kv;
+      *reinterpret_cast<bf16x4*>(dVr + dt * 16 + g * 4) = vv;
+    }
+  }
+}
+static bool bwd_dkv_stream_applies(const MAttnB& f) {
+  const char* env = getenv("EVLM_ATTN_DKV_NO_STREAM");      // (A/B switch, read per call)
+  return !(env && atoi(env)) && !f.P && f.lse && !f.kv_index && f.drop_p == 0.f && f.ldpr >= 64;
 }
 
 // =============================================================================================
@@ -2474,7 +2632,8 @@ int evlm_attention_bwd_mfma(const evlm_attn_bwd_args* a, hipStream_t stream, int
   else if (a->Lk <= 640) launch_bwd_dq_long<40, false>(f, stream);      // long sequences: two passes over the keys, nothing spilled
   else launch_bwd_dq_long<60, false>(f, stream);
   dim3 gridB((a->Lk + 63) / 64, a->H, f.Bkv), block(256);
-  if (f.drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, gridB, block, 0, stream, f);
+  if (bwd_dkv_stream_applies(f)) hipLaunchKernelGGL(attn_bwd_dkv_stream_kernel, gridB, block, 0, stream, f);
+  else if (f.drop_p > 0.f) hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, gridB, block, 0, stream, f);
   else hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<false>, gridB, block, 0, stream, f);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return evlm_set_error("evlm_attention_bwd(mfma): %s", hipGetErrorString(e));

@@ -1777,6 +1777,45 @@ def test_streaming_long_sequence_kernels_agree_with_the_whole_row_kernels(case, 
     assert l2(a[5], b[5]) < 6e-3, (a[5], b[5])
 
 
+@pytest.mark.parametrize("B,H,L,kd", [(2, 12, 577, True), (1, 4, 901, False), (3, 2, 450, False), (2, 3, 641, False)])
+def test_streamed_kernel_b_is_bit_identical_to_the_register_staged_one(B, H, L, kd, monkeypatch):
+    """attn_bwd_dkv_stream_kernel (round 6: chunks by LDS-DMA into a double buffer, one barrier per chunk, the transposing reads
+    issued together behind counted waits) against attn_bwd_dkv_mfma_kernel (EVLM_ATTN_DKV_NO_STREAM=1) on the self-attention
+    backward that rebuilds its map: the same operands in the same k-slots, the same order of the sums - every gradient bit for
+    bit, with a key padding mask, head gates, a fused distillation term and sequences that end inside a chunk / a key block."""
+    o = ops()
+    dh, d = 64, H * 64
+    g = torch.Generator().manual_seed(5100 + L)
+    x0 = rnd((B, L, 3 * d), torch.bfloat16, g, 0.7)
+    mask = torch.zeros(B, L)
+    mask[0, L - 13:] = -10000.0
+    mask = mask.to(DEV)
+    gate0 = (torch.rand(H, generator=g) + 0.5).to(DEV)
+    gO = rnd((B, L, d), torch.bfloat16, g)
+    Pt = None
+    if kd:
+        with torch.no_grad():
+            Pt = o.self_attention(rnd((B, L, 3 * d), torch.bfloat16, g, 0.7), H, dh, 0.125, mask=mask)[1]
+
+    def run(old):
+        monkeypatch.setenv("EVLM_ATTN_DKV_NO_STREAM", "1" if old else "0")
+        x = x0.clone().requires_grad_(True)
+        gate = gate0.clone().requires_grad_(True)
+        if kd:
+            O, _, k_term = o.self_attention(x, H, dh, 0.125, mask=mask, gate=gate, want_probs=False, kd_teacher=Pt, kd_weight=float(L))
+            loss = (O.float() * gO.float()).sum() + 0.3 * k_term
+        else:
+            O, _ = o.self_attention(x, H, dh, 0.125, mask=mask, gate=gate, want_probs=False)
+            loss = (O.float() * gO.float()).sum()
+        loss.backward()
+        return x.grad.clone(), gate.grad.clone()
+
+    (xa, ga), (xb, gb) = run(False), run(True)
+    assert torch.isfinite(xa.float()).all()
+    assert torch.equal(xa.view(torch.int16), xb.view(torch.int16))
+    assert torch.allclose(ga, gb, rtol=1e-5, atol=1e-5)        # (kernel A's gate gradient: f32 atomics, order not fixed)
+
+
 def test_attention_lse_form_refuses_what_it_cannot_serve():
     """C ABI: the lse / recompute form exists for bf16, head dim 64, Lk <= 224 or 417..928; anything else answers with
     an error code - never a fault - and evlm_attention_lse_supported says so beforehand"""

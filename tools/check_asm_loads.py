@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Safety check for the inline-asm loads of attention_mfma.hip - GLOAD16_ASM (global, waited for by VM_WAIT) and the
 transposing LDS reads vcol_frag_a / vcol_frag_asm (waited for by TR_WAIT): between an asm load and the explicit wait that
-covers it (the next `s_waitcnt vmcnt(N)` / `s_waitcnt lgkmcnt(0)` inside an asm block) no instruction may read or write the
+covers it (the next `s_waitcnt vmcnt(N)` / `s_waitcnt lgkmcnt(N)` inside an asm block; a counted LDS wait covers all but the newest N reads) no instruction may read or write the
 load's destination registers - the compiler does not know the data is still in flight, so a copy or a spill there would
 move garbage and free the register for something else.  Compiles the file to assembly and scans every kernel; exits
 non-zero on a violation (also a CPU test: tests/test_lint.py).   python tools/check_asm_loads.py"""
@@ -48,8 +48,14 @@ for f in re.split(r"\n(?=_Z[\w]+:)", txt):
         if in_asm and l.startswith("s_waitcnt vmcnt"):
             pending = [p for p in pending if p[2] != "vm"]
             continue
-        if in_asm and l.startswith("s_waitcnt lgkmcnt(0)"):
-            pending = [p for p in pending if p[2] != "lgkm"]
+        m = re.match(r"s_waitcnt lgkmcnt\((\d+)\)", l) if in_asm else None
+        if m:
+            # a counted wait retires all but the newest N LDS reads: LDS operations complete in order, and whatever else sits
+            # in the queue (the compiler's own LDS traffic, scalar loads) can only make the wait cover MORE of them
+            n = int(m.group(1))
+            lg = [p for p in pending if p[2] == "lgkm"]
+            keep = set(id(p) for p in lg[len(lg) - n:]) if n else set()
+            pending = [p for p in pending if p[2] != "lgkm" or id(p) in keep]
             continue
         if pending:
             used = set()
