@@ -145,6 +145,36 @@ __device__ __forceinline__ bf16x8 vcol_frag_a(const char* sm, int t0, int t1, in
     __builtin_amdgcn_sched_barrier(0);                     \
   } while (0)
 
+// 16-byte LDS reads through inline asm with an immediate offset (round 6, the batched form of the streaming backward: every
+// read of a tile pair is issued up front and the consumers sit behind COUNTED waits - LDS operations complete in order).
+// Same contract as vcol_frag_a: the destination must not be touched before the wait that covers it (tools/check_asm_loads.py).
+template <int OFF> __device__ __forceinline__ bf16x8 lds_b128_a(uint32_t addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+template <int OFF> __device__ __forceinline__ f32x4 lds_f32x4_a(uint32_t addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+template <int OFF0, int OFF1> __device__ __forceinline__ bf16x8 tr_two_a(uint32_t addr) {   // vcol_frag_a with immediate offsets
+  bf16x4 t0, t1;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t0) : "v"(addr), "i"(OFF0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t1) : "v"(addr), "i"(OFF1));
+  bf16x8 out;
+  out[0] = t0[0]; out[1] = t0[1]; out[2] = t0[2]; out[3] = t0[3];
+  out[4] = t1[0]; out[5] = t1[1]; out[6] = t1[2]; out[7] = t1[3];
+  return out;
+}
+#define LGKM_WAIT(n)                                               \
+  do {                                                             \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");        \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+__device__ __forceinline__ uint32_t lds_addr(const char* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)const_cast<char*>(p); }
+
 // NT = number of 16-key tiles (even).  One workgroup = up to 16 waves x 16 queries of one (batch, head): with Lq <= 256
 // (the ViT's 197 tokens) a single workgroup covers every query, so K and V are staged into LDS exactly once per
 // (batch, head) instead of once per 64-query block on four different XCDs.
@@ -1748,8 +1778,16 @@ __global__ __launch_bounds__(64 * MAXW) void attn_bwd_dq_long_kernel(MAttnB a) {
 // next block's DMA, workgroups of one (batch, head) share an XCD.  Arithmetic per tile pair as above.
 // KDR: the teacher's probabilities rebuilt from its Q, K and row lse (see attn_fwd_stream_kernel) - its K block streams
 // through a third LDS tile per buffer, recompute_p forms p_t exactly as it forms the student's p.
-template <int NW, bool KDR = false, bool DROP = false>
+// BATCH (round 6): every LDS read of a tile pair issued up front through inline asm (K rows + mask strip, the teacher's K
+// rows, V rows, then the K^T fragments), the MFMAs behind COUNTED waits - the compiler-scheduled form drained the LDS queue five
+// times per tile pair (a `s_waitcnt lgkmcnt(0)` in front of every group of MFMAs: it cannot count across the asm reads), and in
+// the flavour without the teacher's recipe it waited `vmcnt(0)` - the next block's DMA - at the stored teacher map's first use
+// whether or not a map was given (PT: those loads exist only in the instantiation that serves a stored teacher map).
+// Arithmetic unchanged: bit-identical to BATCH = false (EVLM_ATTN_DQ_NO_BATCH=1), which stays for the dropout flavour.
+template <int NW, bool KDR = false, bool DROP = false, bool BATCH = false, bool PT = true>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
+  static_assert(!(BATCH && DROP), "the batched form carries no dropout mask");
+  static_assert(!(KDR && PT && BATCH), "teacher recipe and stored teacher map are alternatives");
   constexpr int KBT = 8, KB = KBT * 16;
   constexpr int BUF = (KDR ? 3 : 2) * KB * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1791,7 +1829,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
   const float lse_q = qok ? a.lse[((size_t)b * a.H + h) * a.Lq + q] : 0.f;
   // delta = sum_k p (gz dpo + kdc (p - pt)) = dO . O + kdc * rkd   (see attn_bwd_dq_long_kernel)
   const float dsum = ((KDR || a.Pt) && qok) ? fmaf(kdc, a.rkd[((size_t)b * a.H + h) * a.Lq + q], d) : d;
-  const bool kd_on = !KDR && a.Pt != nullptr && qok;
+  const bool kd_on = !KDR && PT && a.Pt != nullptr && qok;
   const bf16* Tkb = KDR ? a.Tk + (size_t)b * a.Lk * a.tld + h * DH : nullptr;
   bf16x8 qt[2];
   float tl = 0.f;
@@ -1811,6 +1849,19 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
   f32x4 o[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // BATCH: the lane's byte offsets inside a 16-row tile (every swizzle here depends on the row's low 4 bits only, so the tile
+  // index is an immediate): row fragments of the SW_KV / SW_K tiles (krow_frag) and the K^T column fragments (vcol_frag_a)
+  uint32_t offK[2], offV[2], offT[4];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    offK[ks] = ql * 128 + swz<SW_KV>(ql, ks * 4 + g) * 16;
+    offV[ks] = ql * 128 + swz<SW_K>(ql, ks * 4 + g) * 16;
+  }
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const int row = g * 4 + (ql >> 2), pq = ql & 3;
+    offT[dt] = row * 128 + swz<SW_KV>(row, dt * 2 + (pq >> 1)) * 16 + ((pq & 1) << 3);
+  }
   stage_block<SW_K>(Vb, a.ldv, a.Lk, 0, KB, NW, smem);
   stage_block<SW_KV>(Kb, a.ldk, a.Lk, 0, KB, NW, smem + KB * 128);
   if (KDR) stage_block<SW_K>(Tkb, a.tld, a.Lk, 0, KB, NW, smem + 2 * KB * 128);
@@ -1838,6 +1889,86 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
     const char* Vs = smem + (blk & 1) * BUF;
     const char* Ks = Vs + KB * 128;
     const char* Kts = Vs + 2 * KB * 128;
+    if constexpr (BATCH) {
+      // per-lane read addresses of this block's buffer; the tile (2 s + hh) and the row pair of a K^T fragment are immediates
+      const uint32_t vb0 = lds_addr(Vs) + offV[0], vb1 = lds_addr(Vs) + offV[1];
+      const uint32_t kb0 = lds_addr(Ks) + offK[0], kb1 = lds_addr(Ks) + offK[1];
+      const uint32_t tb0 = KDR ? lds_addr(Kts) + offV[0] : 0u, tb1 = KDR ? lds_addr(Kts) + offV[1] : 0u;
+      const uint32_t mb = lds_addr(reinterpret_cast<const char*>(Ms + blk * KB)) + g * 32;
+      const uint32_t ktb = lds_addr(Ks);
+      auto pair = [&](auto S_) {
+        constexpr int S = decltype(S_)::value, T0 = 2 * S * 2048, T1 = T0 + 2048;
+        const int kcol = blk * KB + S * 32 + g * 8;
+        const bool ok = qok && kcol < a.ldpr;
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 k00 = lds_b128_a<T0>(kb0), k10 = lds_b128_a<T1>(kb0), k01 = lds_b128_a<T0>(kb1), k11 = lds_b128_a<T1>(kb1);
+        const f32x4 mk0 = lds_f32x4_a<S * 128>(mb), mk1 = lds_f32x4_a<S * 128 + 16>(mb);
+        bf16x8 t00, t10, t01, t11;
+        if constexpr (KDR) { t00 = lds_b128_a<T0>(tb0); t10 = lds_b128_a<T1>(tb0); t01 = lds_b128_a<T0>(tb1); t11 = lds_b128_a<T1>(tb1); }
+        const bf16x8 v00 = lds_b128_a<T0>(vb0), v10 = lds_b128_a<T1>(vb0), v01 = lds_b128_a<T0>(vb1), v11 = lds_b128_a<T1>(vb1);
+        if constexpr (KDR) LGKM_WAIT(8); else LGKM_WAIT(4);
+        f32x4 sa0 = (f32x4){0.f, 0.f, 0.f, 0.f}, sa1 = sa0;
+        sa0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k00, qf[0], sa0, 0, 0, 0);
+        sa1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k10, qf[0], sa1, 0, 0, 0);
+        sa0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k01, qf[1], sa0, 0, 0, 0);
+        sa1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k11, qf[1], sa1, 0, 0, 0);
+        f32x4 ta0 = (f32x4){0.f, 0.f, 0.f, 0.f}, ta1 = ta0;
+        if constexpr (KDR) {
+          LGKM_WAIT(4);
+          ta0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t00, qt[0], ta0, 0, 0, 0);
+          ta1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t10, qt[0], ta1, 0, 0, 0);
+          ta0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t01, qt[1], ta0, 0, 0, 0);
+          ta1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t11, qt[1], ta1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 kfr[4];
+        kfr[0] = tr_two_a<T0, T1>(ktb + offT[0]); kfr[1] = tr_two_a<T0, T1>(ktb + offT[1]);
+        kfr[2] = tr_two_a<T0, T1>(ktb + offT[2]); kfr[3] = tr_two_a<T0, T1>(ktb + offT[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        const float lq = qok ? lse_q : 3.0e38f, ltq = qok ? tl : 3.0e38f;
+        float pr[8], ptr[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pr[r] = EXP2(fmaf(sa0[r], sc, mk0[r]) - lq);
+          pr[4 + r] = EXP2(fmaf(sa1[r], sc, mk1[r]) - lq);
+          if constexpr (KDR) {
+            ptr[r] = EXP2(fmaf(ta0[r], sc, mk0[r]) - ltq);
+            ptr[4 + r] = EXP2(fmaf(ta1[r], sc, mk1[r]) - ltq);
+          }
+        }
+        LGKM_WAIT(8);
+        f32x4 ac0 = (f32x4){0.f, 0.f, 0.f, 0.f}, ac1 = ac0;
+        ac0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v00, dof[0], ac0, 0, 0, 0);
+        ac1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v10, dof[0], ac1, 0, 0, 0);
+        ac0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v01, dof[1], ac0, 0, 0, 0);
+        ac1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v11, dof[1], ac1, 0, 0, 0);
+        bf16x8 d8, p8o;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pp = pr[hh * 4 + r];
+            const float ex = KDR ? (ok ? kdc * (pp - ptr[hh * 4 + r]) : 0.f)
+                                 : ((kd_on && ok) ? kdc * (pp - (float)t8[S][hh * 4 + r]) : 0.f);
+            const float dpo = hh ? ac1[r] : ac0[r];
+            const float dp = fmaf(gz, dpo, ex);
+            gsum = fmaf(pp, dpo, gsum);
+            d8[hh * 4 + r] = (bf16)(pp * (dp - dsum));
+            p8o[hh * 4 + r] = (bf16)pp;
+          }
+        if (ok) {
+          *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
+          if (a.Pw) *reinterpret_cast<bf16x8*>(a.Pw + prow + kcol) = p8o;
+        }
+        LGKM_WAIT(0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[dt], d8, o[dt], 0, 0, 0);
+      };
+      pair(std::integral_constant<int, 0>()); pair(std::integral_constant<int, 1>());
+      pair(std::integral_constant<int, 2>()); pair(std::integral_constant<int, 3>());
+      continue;
+    }
 #pragma unroll
     for (int s2 = 0; s2 < KBT / 2; ++s2) {
       const int kcol = blk * KB + s2 * 32 + g * 8;
@@ -1920,21 +2051,22 @@ static bool launch_bwd_dq_stream(MAttnB& f, hipStream_t stream) {
   constexpr int KB = 128, NW = 8;      // (NW = 4, two workgroups per CU: 388 against 367 us at 577 keys, round 6)
   const int nblk = (f.Lk + KB - 1) / KB, qtiles = (f.Lq + 15) / 16;
   dim3 grid((qtiles + NW - 1) / NW, f.H, f.B), block(64 * NW);
+  const char* nb = getenv("EVLM_ATTN_DQ_NO_BATCH");        // (A/B switch, read per call) the compiler-scheduled form of round 4
+  const bool batch = !(nb && atoi(nb));
+  auto go = [&](auto kern, size_t bytes) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipLaunchKernelGGL(kern, grid, block, bytes, stream, f);
+    return true;
+  };
   if (f.Tq) {                                            // the teacher's map rebuilt in the kernel: a third tile per buffer
     const size_t ldsr = (size_t)6 * KB * 128 + (size_t)nblk * KB * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_stream_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
-    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<NW, true>), grid, block, ldsr, stream, f);
-    return true;
+    return batch ? go(attn_bwd_dq_stream_kernel<NW, true, false, true, false>, ldsr) : go(attn_bwd_dq_stream_kernel<NW, true>, ldsr);
   }
   const size_t lds = (size_t)4 * KB * 128 + (size_t)nblk * KB * sizeof(float);
-  if (f.drop_p > 0.f) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_stream_kernel<NW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<NW, false, true>), grid, block, lds, stream, f);
-    return true;
-  }
-  (void)hipFuncSetAttribute((const void*)attn_bwd_dq_stream_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<NW>), grid, block, lds, stream, f);
-  return true;
+  if (f.drop_p > 0.f) return go(attn_bwd_dq_stream_kernel<NW, false, true>, lds);
+  if (!batch) return go(attn_bwd_dq_stream_kernel<NW>, lds);
+  return f.Pt ? go(attn_bwd_dq_stream_kernel<NW, false, false, true, true>, lds)
+              : go(attn_bwd_dq_stream_kernel<NW, false, false, true, false>, lds);
 }
 
 // kernel B: one workgroup = 64 keys of one (batch, head); wave w owns key tile w.  Sums over the queries in chunks of 32:

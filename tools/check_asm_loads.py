@@ -41,7 +41,7 @@ for f in re.split(r"\n(?=_Z[\w]+:)", txt):
             dest = regs(l.split()[1].rstrip(","))
             pending.append((i, dest, "vm")); total += 1
             continue
-        if in_asm and l.startswith("ds_read_b64_tr_b16"):
+        if in_asm and l.startswith(("ds_read_b64_tr_b16", "ds_read_b128")):
             dest = regs(l.split()[1].rstrip(","))
             pending.append((i, dest, "lgkm")); total += 1
             continue
