@@ -1866,6 +1866,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
   stage_block<SW_KV>(Kb, a.ldk, a.Lk, 0, KB, NW, smem + KB * 128);
   if (KDR) stage_block<SW_K>(Tkb, a.tld, a.Lk, 0, KB, NW, smem + 2 * KB * 128);
   for (int blk = 0; blk < nblk; ++blk) {
+    // (measured and not kept, round 6: a counted `vmcnt(4)` + raw s_barrier here, leaving the previous block's four dS stores in
+    // flight instead of draining their acknowledgements - 323 / 353 us against 305 / 364 at 577 / 901 keys: no gain; nor did a
+    // chunk swizzle of kernel B's tiles that spreads its Q row reads over all bank groups: SQ_LDS_BANK_CONFLICT unchanged)
     stage_wait();
     __syncthreads();
     bf16x8 t8[KBT / 2];
@@ -1896,29 +1899,43 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
       const uint32_t tb0 = KDR ? lds_addr(Kts) + offV[0] : 0u, tb1 = KDR ? lds_addr(Kts) + offV[1] : 0u;
       const uint32_t mb = lds_addr(reinterpret_cast<const char*>(Ms + blk * KB)) + g * 32;
       const uint32_t ktb = lds_addr(Ks);
+      // software pipeline over the block's four tile pairs: the K rows + mask strip of pair S + 1 are requested in front of pair
+      // S's dQ MFMAs (the teacher's K rows right behind them), so a pair starts with its first operands already in flight; at
+      // most 14 LDS reads are outstanding (the counter has 4 bits)
+      bf16x8 kc[4], tc[4];
+      f32x4 mkc[2];
+      auto req_k = [&](auto S_) {
+        constexpr int S = decltype(S_)::value, T0 = 2 * S * 2048, T1 = T0 + 2048;
+        kc[0] = lds_b128_a<T0>(kb0); kc[1] = lds_b128_a<T1>(kb0); kc[2] = lds_b128_a<T0>(kb1); kc[3] = lds_b128_a<T1>(kb1);
+        mkc[0] = lds_f32x4_a<S * 128>(mb); mkc[1] = lds_f32x4_a<S * 128 + 16>(mb);
+      };
+      auto req_t = [&](auto S_) {
+        constexpr int S = decltype(S_)::value, T0 = 2 * S * 2048, T1 = T0 + 2048;
+        if constexpr (KDR) { tc[0] = lds_b128_a<T0>(tb0); tc[1] = lds_b128_a<T1>(tb0); tc[2] = lds_b128_a<T0>(tb1); tc[3] = lds_b128_a<T1>(tb1); }
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      req_k(std::integral_constant<int, 0>());
+      req_t(std::integral_constant<int, 0>());
       auto pair = [&](auto S_) {
         constexpr int S = decltype(S_)::value, T0 = 2 * S * 2048, T1 = T0 + 2048;
         const int kcol = blk * KB + S * 32 + g * 8;
         const bool ok = qok && kcol < a.ldpr;
         __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 k00 = lds_b128_a<T0>(kb0), k10 = lds_b128_a<T1>(kb0), k01 = lds_b128_a<T0>(kb1), k11 = lds_b128_a<T1>(kb1);
-        const f32x4 mk0 = lds_f32x4_a<S * 128>(mb), mk1 = lds_f32x4_a<S * 128 + 16>(mb);
-        bf16x8 t00, t10, t01, t11;
-        if constexpr (KDR) { t00 = lds_b128_a<T0>(tb0); t10 = lds_b128_a<T1>(tb0); t01 = lds_b128_a<T0>(tb1); t11 = lds_b128_a<T1>(tb1); }
         const bf16x8 v00 = lds_b128_a<T0>(vb0), v10 = lds_b128_a<T1>(vb0), v01 = lds_b128_a<T0>(vb1), v11 = lds_b128_a<T1>(vb1);
         if constexpr (KDR) LGKM_WAIT(8); else LGKM_WAIT(4);
+        const f32x4 mk0 = mkc[0], mk1 = mkc[1];
         f32x4 sa0 = (f32x4){0.f, 0.f, 0.f, 0.f}, sa1 = sa0;
-        sa0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k00, qf[0], sa0, 0, 0, 0);
-        sa1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k10, qf[0], sa1, 0, 0, 0);
-        sa0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k01, qf[1], sa0, 0, 0, 0);
-        sa1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k11, qf[1], sa1, 0, 0, 0);
+        sa0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[0], qf[0], sa0, 0, 0, 0);
+        sa1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[1], qf[0], sa1, 0, 0, 0);
+        sa0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[2], qf[1], sa0, 0, 0, 0);
+        sa1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[3], qf[1], sa1, 0, 0, 0);
         f32x4 ta0 = (f32x4){0.f, 0.f, 0.f, 0.f}, ta1 = ta0;
         if constexpr (KDR) {
           LGKM_WAIT(4);
-          ta0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t00, qt[0], ta0, 0, 0, 0);
-          ta1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t10, qt[0], ta1, 0, 0, 0);
-          ta0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t01, qt[1], ta0, 0, 0, 0);
-          ta1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t11, qt[1], ta1, 0, 0, 0);
+          ta0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tc[0], qt[0], ta0, 0, 0, 0);
+          ta1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tc[1], qt[0], ta1, 0, 0, 0);
+          ta0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tc[2], qt[1], ta0, 0, 0, 0);
+          ta1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tc[3], qt[1], ta1, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 kfr[4];
@@ -1960,10 +1977,18 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_stream_kernel(MAttnB a) {
           *reinterpret_cast<bf16x8*>(a.dS + prow + kcol) = d8;
           if (a.Pw) *reinterpret_cast<bf16x8*>(a.Pw + prow + kcol) = p8o;
         }
-        LGKM_WAIT(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (S < 3) {
+          req_k(std::integral_constant<int, (S < 3 ? S + 1 : 0)>());
+          LGKM_WAIT(6);
+        } else {
+          LGKM_WAIT(0);
+        }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
           o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[dt], d8, o[dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (S < 3) req_t(std::integral_constant<int, (S < 3 ? S + 1 : 0)>());
       };
       pair(std::integral_constant<int, 0>()); pair(std::integral_constant<int, 1>());
       pair(std::integral_constant<int, 2>()); pair(std::integral_constant<int, 3>());
