@@ -41,6 +41,15 @@ python3 tools/itr_bench.py 384 64 --ragged 200 --dropout 0.1 2>/dev/null | grep 
 python3 tools/vqa_bench.py 480 32 --ragged 200 2>/dev/null | grep "^{" > $OUT/vqa_ragged.jsonl
 python3 tools/vqa_bench.py 480 32 --ragged 200 --dropout 0.1 2>/dev/null | grep "^{" >> $OUT/vqa_ragged.jsonl
 python3 tools/ln_fwd_pair_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/ln_fwd_pair.txt
+# round 6: the long-sequence attention backward - per-kernel durations of one ViT layer at 577 / 901 tokens (new forms, then the
+# forms they replace), and the SQ counter passes of the 577-token layer without / with the teacher's recipe
+( bash tools/attn_long_kernels.sh; PROBE_ARGS=--kd bash tools/attn_long_kernels.sh
+  export EVLM_ATTN_DQ_NO_BATCH=1 EVLM_ATTN_DKV_NO_STREAM=1
+  echo "-- round 4 / 5 forms (EVLM_ATTN_DQ_NO_BATCH=1 EVLM_ATTN_DKV_NO_STREAM=1)"
+  bash tools/attn_long_kernels.sh; PROBE_ARGS=--kd bash tools/attn_long_kernels.sh ) 2>&1 | grep -v "^$" > $OUT/attn_long_kernels.txt
+bash tools/attn_long_pmc.sh 64 577 > $OUT/attn_long_pmc_plain.txt 2>&1
+bash tools/attn_long_pmc.sh 64 577 --kd > $OUT/attn_long_pmc_kd.txt 2>&1
+( export EVLM_ATTN_DQ_NO_BATCH=1 EVLM_ATTN_DKV_NO_STREAM=1; bash tools/attn_long_pmc.sh 64 577 > $OUT/attn_long_pmc_plain_old_forms.txt 2>&1 )
 rocprofv3 --kernel-trace --stats -d $OUT/ki -o ki -- python3 tools/itr_bench.py 384 64 10 > $OUT/ki.log 2>&1
 MS=$(grep -o '"ms_per_step": [0-9.]*' $OUT/ki.log | head -1 | grep -o '[0-9.]*$')
 python3 tools/replay_window_stats.py $OUT/ki/ki_results.db 250 $MS 70 > $OUT/itr384_kernel_stats.txt 2>&1
