@@ -1777,7 +1777,8 @@ def test_streaming_long_sequence_kernels_agree_with_the_whole_row_kernels(case, 
     assert l2(a[5], b[5]) < 6e-3, (a[5], b[5])
 
 
-@pytest.mark.parametrize("B,H,L,kd", [(2, 12, 577, "map"), (1, 4, 901, "none"), (3, 2, 450, "none"), (2, 3, 641, "recipe"), (1, 12, 901, "recipe")])
+@pytest.mark.parametrize("B,H,L,kd", [(2, 12, 577, "map"), (1, 4, 901, "none"), (3, 2, 450, "none"), (2, 3, 641, "recipe"), (1, 12, 901, "recipe"),
+                                     (2, 2, 620, "none"), (1, 2, 448, "map"), (1, 3, 928, "recipe")])       # (even chunk counts, a full last chunk, the longest row)
 def test_round6_streaming_backward_kernels_are_bit_identical_to_the_forms_they_replace(B, H, L, kd, monkeypatch):
     """Round 6's long-sequence backward against round 4 / 5's (EVLM_ATTN_DQ_NO_BATCH=1, EVLM_ATTN_DKV_NO_STREAM=1):
     kernel A with every LDS read of a tile pair issued up front behind counted waits (attn_bwd_dq_stream_kernel<.., BATCH>), kernel
