@@ -304,6 +304,26 @@ class XVLMBase(nn.Module):
             return outputs.last_hidden_state, outputs.hidden_states, outputs.attentions
         return outputs.last_hidden_state
 
+    def get_pair_embeds(self, image, text_ids, text_atts, vision_kw=None, text_kw=None, side_stream=None):
+        """extension (inference): get_vision_embeds and get_text_embeds of one batch SIDE BY SIDE - the text encoder's ~45 small
+        launches (30-token rows) on `side_stream`, forked from and joined back into the current stream, under the image
+        encoder's GEMMs.  The two passes share nothing until the ITC features / the fusion layers (efficient_models/xvlm.py:
+        262-313), so the results are those of the two calls in sequence, bit for bit; captured into a hipGraph the fork
+        becomes two branches of the graph.  Without a stream (or on CPU tensors) it IS the two calls in sequence.
+        Returns (image_embeds, image_atts, text_embeds)."""
+        vision_kw, text_kw = vision_kw or {}, text_kw or {}
+        if side_stream is None or not image.is_cuda:
+            ie, ia = self.get_vision_embeds(image, **vision_kw)[:2]
+            return ie, ia, self.get_text_embeds(text_ids, text_atts, **text_kw)
+        cur = torch.cuda.current_stream()
+        side_stream.wait_stream(cur)
+        with torch.cuda.stream(side_stream):
+            te = self.get_text_embeds(text_ids, text_atts, **text_kw)
+        ie, ia = self.get_vision_embeds(image, **vision_kw)[:2]
+        cur.wait_stream(side_stream)
+        te.record_stream(cur)
+        return ie, ia, te
+
     def get_cross_embeds(self, image_embeds, image_atts, text_ids=None, text_embeds=None, text_atts=None,
                          output_hidden_states=None, output_attentions=None, head_z=None, head_layer_z=None, mlp_z=None):
         """efficient_models/xvlm.py:315-373"""

@@ -2065,3 +2065,19 @@ def test_pruned_inference_equals_masked_dense_at_every_sparsity_of_the_sweep(kee
     assert sum(p.numel() for p in model.parameters()) < n_before * (0.55 + 0.5 * keep)
     for a, b in zip(dense, pruned):
         close(b, a, 1e-4, 1e-6, f"keep {keep}")
+    # round 6: the two encoders side by side (XVLMBase.get_pair_embeds: the text pass on a second stream) - the same bits as
+    # the two calls in sequence, eagerly and replayed from a hipGraph
+    side = torch.cuda.Stream()
+    with torch.no_grad(), compute(torch.bfloat16):
+        seq = model.get_pair_embeds(batch["image"], batch["text_ids"], batch["text_atts"])
+        par = model.get_pair_embeds(batch["image"], batch["text_ids"], batch["text_atts"], side_stream=side)
+        torch.cuda.synchronize()
+        for a, b in zip(seq, par):
+            assert torch.equal(a, b)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            cap = model.get_pair_embeds(batch["image"], batch["text_ids"], batch["text_atts"], side_stream=side)
+        g.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(seq, cap):
+            assert torch.equal(a, b)

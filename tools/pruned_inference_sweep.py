@@ -38,10 +38,12 @@ def masks(keep, g):
 
 def score(model, z=None):
     z = z or {}
-    image_embeds, image_atts = model.get_vision_embeds(batch["image"], head_z=z.get("vision_head_z"),
-                                                       mlp_z=z.get("vision_intermediate_z"))[:2]
-    text_embeds = model.get_text_embeds(batch["text_ids"], batch["text_atts"], head_z=z.get("text_head_z"),
-                                        mlp_z=z.get("text_intermediate_z"))
+    # round 6: the two encoders side by side (XVLMBase.get_pair_embeds: the text pass on a second stream under the image
+    # encoder's GEMMs; EVLM_NO_PAIR_STREAM=1: in sequence, the round-5 form)
+    image_embeds, image_atts, text_embeds = model.get_pair_embeds(
+        batch["image"], batch["text_ids"], batch["text_atts"],
+        vision_kw=dict(head_z=z.get("vision_head_z"), mlp_z=z.get("vision_intermediate_z")),
+        text_kw=dict(head_z=z.get("text_head_z"), mlp_z=z.get("text_intermediate_z")), side_stream=SIDE)
     image_feat, text_feat = model.get_features(image_embeds, text_embeds)
     cross = model.get_cross_embeds(image_embeds, image_atts, text_embeds=text_embeds, text_atts=batch["text_atts"],
                                    head_z=z.get("cross_head_z"), mlp_z=z.get("cross_intermediate_z"))
@@ -49,6 +51,7 @@ def score(model, z=None):
 
 
 MASKED = len(sys.argv) > 1 and sys.argv[1] == "masked"
+SIDE = None if os.environ.get("EVLM_NO_PAIR_STREAM") else torch.cuda.Stream()
 
 
 KEEPS = [float(v) for v in sys.argv[sys.argv.index("--keep") + 1].split(",")] if "--keep" in sys.argv else [1.0, 0.75, 0.5, 0.25]
@@ -78,7 +81,7 @@ for keep in KEEPS:
         for _ in range(50): graph.replay()
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
     print(json.dumps({"retained": keep, "params_M": round(n1 / 1e6, 1), "params_dense_M": round(n0 / 1e6, 1),
-                      "ms_per_batch": round(dt * 1e3, 3), "pairs_per_s": round(B / dt, 1), "launch": "hipGraph replay",
+                      "ms_per_batch": round(dt * 1e3, 3), "pairs_per_s": round(B / dt, 1), "launch": "hipGraph replay", "encoders": "side by side" if SIDE is not None else "in sequence",
                       "form": ("masked dense" + ("" if os.environ.get("EVLM_ATTN_NO_HEAD_SKIP") else ", closed heads skipped in-kernel"))
                               if MASKED else "physically pruned",
                       "ms_per_batch_eager": round(dt_eager * 1e3, 3)}), flush=True)
