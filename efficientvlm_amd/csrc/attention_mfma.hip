@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
   stage_rows<SW_K>(Kb, a.ldk, a.Lk, NT * 16, Ks);
   if (!SEQ) stage_rows<SW_V>(Vb, a.ldv, a.Lk, NT * 16, Vs);
   for (int k = threadIdx.x; k < NT * 16; k += blockDim.x)
-    Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
+    Ms[k] = ((k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f) * LOG2E;      // (log2 domain, as stage_mask)
   float* kdw = Ms + NT * 16;                     // {partial sum, arrived waves} of the fused map distillation
   if (threadIdx.x < 2) kdw[threadIdx.x] = 0.f;
   stage_wait();
@@ -246,9 +246,11 @@ __global__ __launch_bounds__(64 * MAXW) void attn_fwd_mfma_kernel(MAttnF a) {
     const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + tile_key0(t, g));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      // (round 6: the mask strip is staged already multiplied by log2 e - the same fp32 product, formed once per key instead
+      // of once per (query, key); min commutes with a multiplication by a positive constant, bit for bit)
       float add = mk[r];
-      if (a.causal && tile_key0(t, g) + r > q) add = fminf(add, -10000.0f);   // decoder: keys after the query
-      acc[t][r] = fmaf(acc[t][r], sc, add * LOG2E);     // (explicit fma: the recomputing backward forms the same number)
+      if (a.causal && tile_key0(t, g) + r > q) add = fminf(add, -10000.0f * LOG2E);   // decoder: keys after the query
+      acc[t][r] = fmaf(acc[t][r], sc, add);             // (explicit fma: the recomputing backward forms the same number)
       m = fmaxf(m, acc[t][r]);
     }
   }
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_kernel(MAttnF a) {
         }
         if (!mask_ready) {                               // (in-order LDS: the strip is complete before this wave reads it)
           for (int k = lane; k < NT * 16; k += 64)
-            Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
+            Ms[k] = ((k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f) * LOG2E;      // (log2 domain, as stage_mask)
           mask_ready = true;
         }
         const int q = qt * 16 + ql;
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_kernel(MAttnF a) {
           const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + tile_key0(t, g));
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            acc[t][r] = fmaf(acc[t][r], sc, mk[r] * LOG2E);
+            acc[t][r] = fmaf(acc[t][r], sc, mk[r]);
             m = fmaxf(m, acc[t][r]);
           }
         }
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_persist_kernel(MAttn
   if (it >= nitems) return;
   for (int i = threadIdx.x; i < a.B; i += blockDim.x) kvs[i] = a.kv_index[i];
   if (!a.mask)
-    for (int k = lane; k < NT * 16; k += 64) Ms[k] = (k < a.Lk) ? 0.f : -1e30f;
+    for (int k = lane; k < NT * 16; k += 64) Ms[k] = ((k < a.Lk) ? 0.f : -1e30f) * LOG2E;
   const bool skip = !LSE && a.skip_dead && a.gate && !a.P;       // closed heads deliver a zero context and stage nothing
   const int qtiles = (a.Lq + 15) >> 4;
   const float sc = a.scale * 1.44269504088896341f;
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_persist_kernel(MAttn
         continue;
       }
       if (a.mask && mb != b) {                           // (in-order LDS: the strip is complete before this wave reads it)
-        for (int k = lane; k < NT * 16; k += 64) Ms[k] = (k < a.Lk) ? a.mask[(size_t)b * a.Lk + k] : -1e30f;
+        for (int k = lane; k < NT * 16; k += 64) Ms[k] = ((k < a.Lk) ? a.mask[(size_t)b * a.Lk + k] : -1e30f) * LOG2E;
         mb = b;
       }
       f32x4 acc[NT];
@@ -692,7 +694,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_grouped_persist_kernel(MAttn
         const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + tile_key0(tt, g));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          acc[tt][r] = fmaf(acc[tt][r], sc, mk[r] * LOG2E);
+          acc[tt][r] = fmaf(acc[tt][r], sc, mk[r]);
           m = fmaxf(m, acc[tt][r]);
         }
       }
@@ -842,7 +844,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
   const bf16* Kb = a.K + (size_t)bkv * a.Lk * a.ldk + h * DH;
   const bf16* Vb = a.V + (size_t)bkv * a.Lk * a.ldv + h * DH;
   for (int k = threadIdx.x; k < nblk * KB; k += blockDim.x)
-    Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
+    Ms[k] = ((k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f) * LOG2E;      // (log2 domain, as stage_mask)
   if (threadIdx.x < 2) kdw[threadIdx.x] = 0.f;
   bf16x8 qf[TQ][2];
 #pragma unroll
@@ -940,7 +942,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
       const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + blk * KB + tile_key0(t, g));
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float ml = mk[r] * LOG2E;
+        const float ml = mk[r];
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
           acc[j][t][r] = fmaf(acc[j][t][r], sc, ml);     // (the recomputing backward forms the same number)
@@ -981,7 +983,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_kernel(MAttnF a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float e = acc[j][t][r];
-            const float pt = EXP2(fmaf(sa[r], sc, mk[r] * LOG2E) - tl[j]);
+            const float pt = EXP2(fmaf(sa[r], sc, mk[r]) - tl[j]);
             se2[j] = fmaf(e, e, se2[j]);
             sep[j] = fmaf(e, pt, sep[j]);
             spt[j] = fmaf(pt, pt, spt[j]);
@@ -1112,7 +1114,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_map_kernel(MAttnF a) 
   const bf16* Kb = a.K + (size_t)bkv * a.Lk * a.ldk + h * DH;
   const bf16* Vb = a.V + (size_t)bkv * a.Lk * a.ldv + h * DH;
   for (int k = threadIdx.x; k < nblk * KB; k += blockDim.x)
-    Ms[k] = (k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f;
+    Ms[k] = ((k < a.Lk) ? (a.mask ? a.mask[(size_t)b * a.Lk + k] : 0.f) : -1e30f) * LOG2E;      // (log2 domain, as stage_mask)
   if (threadIdx.x < 2) kdw[threadIdx.x] = 0.f;
   bf16x8 qf[2];
 #pragma unroll
@@ -1145,7 +1147,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_map_kernel(MAttnF a) 
       const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + blk * KB + tile_key0(t, g));
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        acc[t][r] = fmaf(acc[t][r], sc, mk[r] * LOG2E);
+        acc[t][r] = fmaf(acc[t][r], sc, mk[r]);
         bm = fmaxf(bm, acc[t][r]);
       }
     }
@@ -1210,7 +1212,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_stream_map_kernel(MAttnF a) 
     for (int t = 0; t < KBT; ++t) {
       const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + blk * KB + tile_key0(t, g));
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][r] = EXP2(fmaf(acc[t][r], sc, mk[r] * LOG2E) - m) * inv;
+      for (int r = 0; r < 4; ++r) acc[t][r] = EXP2(fmaf(acc[t][r], sc, mk[r]) - m) * inv;
     }
 #pragma unroll
     for (int s2 = 0; s2 < KBT / 2; ++s2) {
