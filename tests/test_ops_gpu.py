@@ -1825,6 +1825,40 @@ def test_round6_streaming_backward_kernels_are_bit_identical_to_the_forms_they_r
     assert torch.allclose(ga, gb, rtol=1e-5, atol=1e-5)        # (kernel A's gate gradient: f32 atomics, order not fixed)
 
 
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_kernel_b_rebuilding_the_map_on_short_rows_is_bit_identical_to_the_workspace_form(drop, monkeypatch):
+    """EVLM_ATTN_KB_REBUILD=1 (round 6, opt-in): on <= 224 keys kernel B of the two-kernel cross-attention backward rebuilds the
+    probabilities from Q, K and the row lse instead of reading the workspace kernel A writes - the same bf16 values, so the same
+    gradients bit for bit; shared K/V rows (kv_index), key padding mask, head gates, with and without probability dropout."""
+    o = ops()
+    B, Bkv, H, Lq, Lk, dh = 12, 4, 12, 30, 197, 64
+    d = H * dh
+    g = torch.Generator().manual_seed(6100)
+    x0 = rnd((B, Lq, d), torch.bfloat16, g, 0.7)
+    kv0 = rnd((Bkv, Lk, 2 * d), torch.bfloat16, g, 0.7)
+    idx = (torch.arange(B) % Bkv).to(DEV)
+    mask = torch.zeros(B, Lk)
+    mask[1, Lk - 9:] = -10000.0
+    mask = mask.to(DEV)
+    gate0 = (torch.rand(H, generator=g) + 0.5).to(DEV)
+    gO = rnd((B, Lq, d), torch.bfloat16, g)
+
+    def run(rebuild):
+        monkeypatch.setenv("EVLM_ATTN_KB_REBUILD", "1" if rebuild else "0")
+        x = x0.clone().requires_grad_(True)
+        kv = kv0.clone().requires_grad_(True)
+        gate = gate0.clone().requires_grad_(True)
+        o.dropout_seed(77, DEV)
+        O, _ = o.cross_attention(x, kv, H, dh, 0.125, mask=mask, gate=gate, want_probs=False, kv_index=idx, dropout_p=drop)
+        (O.float() * gO.float()).sum().backward()
+        return x.grad.clone(), kv.grad.clone()
+
+    (xa, ka), (xb, kb) = run(True), run(False)
+    assert torch.isfinite(ka.float()).all() and float(ka.float().abs().max()) > 0
+    assert torch.equal(xa.view(torch.int16), xb.view(torch.int16))
+    assert torch.equal(ka.view(torch.int16), kb.view(torch.int16))
+
+
 def test_attention_lse_form_refuses_what_it_cannot_serve():
     """C ABI: the lse / recompute form exists for bf16, head dim 64, Lk <= 224 or 417..928; anything else answers with
     an error code - never a fault - and evlm_attention_lse_supported says so beforehand"""
