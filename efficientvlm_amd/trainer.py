@@ -1198,6 +1198,8 @@ class TeacherPrefetch:
                 st["T"][p] = self.run_teacher(st["B"][p])
                 for t in distill._tensors(st["T"][p]):     # allocated on the side stream, consumed on the main one
                     t.record_stream(cur)
+        if os.environ.get("EVLM_PREFETCH_SERIAL"):    # (A/B switch: the teacher's forward runs to its end BEFORE the student step)
+            cur.wait_stream(side)
         prev, self.pending = self.pending, (st, p)
         # (identity of the static buffers the returned pair lives in - a captured student step is keyed by it - or None when
         # the teacher ran eagerly into fresh tensors)
